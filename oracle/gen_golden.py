@@ -1,0 +1,299 @@
+"""Generate golden vectors by running the UPSTREAM REFERENCE itself (build container only).
+
+Usage (from the repo root, in the container where /root/reference exists):
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Writes tests/golden/*.safetensors (+ manifest.json).  Each file holds the inputs and the
+reference's outputs for one family of hot-path functions; tests/test_oracle_golden.py checks
+the C oracle against them on CPU, and tests/test_gpu_parity.py checks the HIP kernels
+against the same files on the GPU box (where /root/reference does not exist).
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product imports this.
+"""
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_import  # noqa: E402
+
+ref_import.import_reference()
+
+from compressed_tensors.compressors import BaseCompressor  # noqa: E402
+from compressed_tensors.compressors.pack_quantized.helpers import (  # noqa: E402
+    pack_to_int32,
+    unpack_from_int32,
+)
+from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme  # noqa: E402
+from compressed_tensors.quantization.lifecycle.forward import (  # noqa: E402
+    dequantize,
+    fake_quantize,
+    quantize,
+)
+from compressed_tensors.quantization.utils import calculate_qparams  # noqa: E402
+from compressed_tensors.utils.helpers import pack_bitmasks, unpack_bitmasks  # noqa: E402
+from compressed_tensors.utils.permutations_24 import get_permutations_24  # noqa: E402
+from compressed_tensors.utils.semi_structured_conversions import (  # noqa: E402
+    mask_creator,
+    sparse_semi_structured_from_dense_cutlass,
+    sparse_semi_structured_to_dense_cutlass,
+)
+from safetensors.torch import save_file  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+manifest = {}
+
+
+def save(name, tensors, meta):
+    tensors = {k: v.contiguous().clone() for k, v in tensors.items()}
+    save_file(tensors, os.path.join(OUT, name + ".safetensors"))
+    manifest[name] = meta
+
+
+def special_values(dtype):
+    """values that stress the rounding model: NaN, infs, signed zero, ties, huge, tiny"""
+    v = [float("nan"), float("inf"), -float("inf"), 0.0, -0.0, 1e30, -1e30, 1e-30, 2.498, 3.496,
+         0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 6.5, 7.5, -7.5, -8.5, 127.5, -128.5, 65504.0, 1e-8]
+    return torch.tensor(v, dtype=torch.float32).to(dtype)
+
+
+# ----------------------------------------------------------------------------- pack / unpack
+def gen_pack():
+    g = torch.Generator().manual_seed(1234)
+    tensors, cases = {}, []
+    shapes = [(5, 33), (7, 100), (4, 1024), (3, 64), (1, 1), (2, 31), (16, 256)]
+    for bits in range(1, 9):
+        lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+        for shape in shapes:
+            for pd in (1, 0):
+                key = f"b{bits}_{shape[0]}x{shape[1]}_d{pd}"
+                v = torch.randint(lo, hi + 1, shape, dtype=torch.int8, generator=g)
+                p = pack_to_int32(v, bits, packed_dim=pd)
+                u = unpack_from_int32(p, bits, torch.Size(shape), packed_dim=pd)
+                assert torch.equal(u, v)
+                tensors[key + ".value"] = v
+                tensors[key + ".packed"] = p.contiguous()
+                cases.append({"key": key, "bits": bits, "shape": list(shape), "packed_dim": pd})
+        # 3-D (MoE) slice-wise packing
+        key = f"b{bits}_3d"
+        v = torch.randint(lo, hi + 1, (3, 8, 40), dtype=torch.int8, generator=g)
+        tensors[key + ".value"] = v
+        tensors[key + ".packed"] = pack_to_int32(v, bits).contiguous()
+        cases.append({"key": key, "bits": bits, "shape": [3, 8, 40], "packed_dim": 1})
+    # out-of-range int8 input (the reference does not mask before shifting; helpers.py:54-83)
+    v = torch.randint(-128, 128, (4, 64), dtype=torch.int8, generator=g)
+    for bits in (4, 8):
+        key = f"b{bits}_oob"
+        tensors[key + ".value"] = v
+        tensors[key + ".packed"] = pack_to_int32(v, bits).contiguous()
+        cases.append({"key": key, "bits": bits, "shape": [4, 64], "packed_dim": 1, "oob": True})
+    save("pack", tensors, {"cases": cases})
+
+
+# ----------------------------------------------------------------------------- quant / dequant
+def make_qparams(x, args):
+    """per-strategy min/max -> reference calculate_qparams (what a min-max observer does)"""
+    st = str(getattr(args.strategy, "value", args.strategy))
+    if st == "tensor":
+        mn, mx = torch.aminmax(x)
+    elif st == "channel":
+        mn, mx = torch.aminmax(x, dim=-1, keepdim=True)
+    elif st == "group":
+        xg = x.unflatten(-1, (x.shape[-1] // args.group_size, args.group_size))
+        mn, mx = torch.aminmax(xg, dim=-1)
+    elif st == "block":
+        bh, bw = args.block_structure
+        xb = x.reshape(x.shape[0] // bh, bh, x.shape[1] // bw, bw)
+        mn = xb.amin(dim=(1, 3))
+        mx = xb.amax(dim=(1, 3))
+    else:
+        raise ValueError(st)
+    return calculate_qparams(mn, mx, args)
+
+
+def gen_quant():
+    g = torch.Generator().manual_seed(4321)
+    tensors, cases = {}, []
+    configs = [
+        # (name, kwargs for QuantizationArgs, shape)
+        ("g128_b4_sym", dict(num_bits=4, strategy="group", group_size=128, symmetric=True), (8, 512)),
+        ("g128_b4_asym", dict(num_bits=4, strategy="group", group_size=128, symmetric=False), (8, 512)),
+        ("g32_b8_asym", dict(num_bits=8, strategy="group", group_size=32, symmetric=False), (6, 128)),
+        ("g16_b3_sym", dict(num_bits=3, strategy="group", group_size=16, symmetric=True), (5, 64)),
+        ("ch_b4_sym", dict(num_bits=4, strategy="channel", symmetric=True), (9, 200)),
+        ("ch_b8_asym", dict(num_bits=8, strategy="channel", symmetric=False), (9, 200)),
+        ("t_b8_sym", dict(num_bits=8, strategy="tensor", symmetric=True), (16, 96)),
+        ("t_b4_asym", dict(num_bits=4, strategy="tensor", symmetric=False), (16, 96)),
+        ("blk_b8_sym", dict(num_bits=8, strategy="block", block_structure=[4, 32], symmetric=True), (8, 128)),
+    ]
+    for name, kw, shape in configs:
+        args = QuantizationArgs(**kw)
+        for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+            for scale_dt_name, sdt in (("same", None), ("f32", torch.float32)):
+                if dt is torch.float32 and sdt is not None:
+                    continue
+                key = f"{name}_{dt_name}_s{scale_dt_name}"
+                x = torch.randn(shape, generator=g).mul(3.0).to(dt)
+                sp = special_values(dt)
+                x.view(-1)[: sp.numel()] = sp
+                # qparams from the finite part only (NaN/inf would poison every scale)
+                xf = torch.nan_to_num(x.float(), nan=0.0, posinf=4.0, neginf=-4.0).clamp(-9, 9).to(dt)
+                scale, zp = make_qparams(xf, args)
+                if sdt is not None:
+                    scale = scale.to(sdt)
+                if str(getattr(args.strategy, "value", args.strategy)) == "tensor" and scale_dt_name == "f32":
+                    scale = scale.reshape(())  # 0-dim fp32 scale: result type stays x.dtype
+                    zp = zp.reshape(())
+                q8 = quantize(x, scale, zp, args, dtype=torch.int8)
+                qf = quantize(x, scale, zp, args)
+                fq = fake_quantize(x, scale, zp, args)
+                dq = dequantize(q8, scale, zp, args=args)
+                dq_inferred = dequantize(q8, scale, zp) if str(getattr(args.strategy, "value", args.strategy)) != "block" else dq
+                q8_nozp = quantize(x, scale, None, args, dtype=torch.int8)
+                tensors.update({
+                    key + ".x": x, key + ".scale": scale, key + ".zp": zp, key + ".q8": q8,
+                    key + ".qf": qf, key + ".fq": fq, key + ".dq": dq, key + ".dq_inferred": dq_inferred,
+                    key + ".q8_nozp": q8_nozp,
+                })
+                cases.append({"key": key, "args": kw, "shape": list(shape)})
+    # activation ordering (g_idx) on a group scheme
+    args = QuantizationArgs(num_bits=4, strategy="group", group_size=32, symmetric=False, actorder="group")
+    x = torch.randn((6, 128), generator=g).to(torch.bfloat16)
+    perm = torch.randperm(128, generator=g)
+    g_idx = (torch.arange(128, dtype=torch.int32) // 32)[perm].contiguous()
+    xp = x.index_select(-1, torch.argsort(g_idx))
+    scale, zp = make_qparams(xp, args)
+    key = "gidx_b4_asym_bf16"
+    tensors.update({
+        key + ".x": x, key + ".scale": scale, key + ".zp": zp, key + ".g_idx": g_idx,
+        key + ".q8": quantize(x, scale, zp, args, dtype=torch.int8, g_idx=g_idx),
+        key + ".fq": fake_quantize(x, scale, zp, args, g_idx=g_idx),
+    })
+    tensors[key + ".dq"] = dequantize(tensors[key + ".q8"], scale, zp, args=args, g_idx=g_idx)
+    cases.append({"key": key, "args": dict(num_bits=4, strategy="group", group_size=32, symmetric=False),
+                  "shape": [6, 128], "g_idx": True})
+    save("quant", tensors, {"cases": cases})
+
+
+# ----------------------------------------------------------------------------- qparams
+def gen_qparams():
+    g = torch.Generator().manual_seed(99)
+    tensors, cases = {}, []
+    for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+        for bits in (4, 8):
+            for sym in (True, False):
+                for gs in (None, 32, 128):
+                    key = f"{dt_name}_b{bits}_{'sym' if sym else 'asym'}_g{gs}"
+                    x = torch.randn((8, 256), generator=g).mul(0.05).to(dt)
+                    x[0, :128] = 0  # an all-zero group -> eps substitution path
+                    x[1, :32] = x[1, :32].abs()  # strictly positive group (min clamps to 0)
+                    kw = dict(num_bits=bits, symmetric=sym, strategy="group" if gs else "channel")
+                    if gs:
+                        kw["group_size"] = gs
+                    args = QuantizationArgs(**kw)
+                    scale, zp = make_qparams(x, args)
+                    tensors.update({key + ".x": x, key + ".scale": scale, key + ".zp": zp})
+                    cases.append({"key": key, "bits": bits, "symmetric": sym, "group_size": gs})
+    save("qparams", tensors, {"cases": cases})
+
+
+# ----------------------------------------------------------------------------- compressors
+def gen_compressors():
+    g = torch.Generator().manual_seed(777)
+    tensors, cases = {}, []
+    configs = [
+        ("pq_g128_b4_sym_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True), (64, 256), torch.bfloat16),
+        ("pq_g128_b4_asym_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=False), (64, 256), torch.bfloat16),
+        ("pq_ch_b4_asym_f16", "pack-quantized", dict(num_bits=4, strategy="channel", symmetric=False), (40, 100), torch.float16),
+        ("pq_ch_b8_sym_f32", "pack-quantized", dict(num_bits=8, strategy="channel", symmetric=True), (33, 70), torch.float32),
+        ("pq_t_b3_asym_f32", "pack-quantized", dict(num_bits=3, strategy="tensor", symmetric=False), (17, 45), torch.float32),
+        ("pq_g32_b5_asym_bf16", "pack-quantized", dict(num_bits=5, strategy="group", group_size=32, symmetric=False), (36, 96), torch.bfloat16),
+        ("iq_t_b8_sym_bf16", "int-quantized", dict(num_bits=8, strategy="tensor", symmetric=True), (64, 128), torch.bfloat16),
+        ("iq_ch_b8_asym_bf16", "int-quantized", dict(num_bits=8, strategy="channel", symmetric=False), (64, 128), torch.bfloat16),
+        ("nq_g64_b8_sym_f16", "naive-quantized", dict(num_bits=8, strategy="group", group_size=64, symmetric=True), (16, 128), torch.float16),
+    ]
+    for key, fmt, kw, shape, dt in configs:
+        args = QuantizationArgs(**kw)
+        act = QuantizationArgs(num_bits=8, strategy="tensor", symmetric=True) if fmt == "int-quantized" else None
+        scheme = QuantizationScheme(targets=["Linear"], weights=args, input_activations=act)
+        w = torch.randn(shape, generator=g).to(dt)
+        scale, zp = make_qparams(w, args)
+        sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+        comp = BaseCompressor.get_value_from_registry(fmt)
+        c = comp.compress(sd, scheme)
+        d = comp.decompress(c, scheme)
+        fq = fake_quantize(w, scale, zp, args)
+        assert torch.equal(fq, d["weight"].to(fq.dtype))
+        for k, v in sd.items():
+            tensors[f"{key}.in.{k}"] = v
+        for k, v in c.items():
+            tensors[f"{key}.c.{k}"] = v
+        for k, v in d.items():
+            tensors[f"{key}.d.{k}"] = v
+        cases.append({"key": key, "format": fmt, "args": kw, "shape": list(shape),
+                      "compressed_keys": sorted(c.keys()), "decompressed_keys": sorted(d.keys())})
+    save("compressors", tensors, {"cases": cases})
+
+
+# ----------------------------------------------------------------------------- sparse primitives
+def gen_sparse():
+    g = torch.Generator().manual_seed(2024)
+    tensors, cases = {}, []
+    # bitmask primitives
+    for shape in [(1, 10), (5, 64), (7, 100), (3, 8), (4, 129)]:
+        key = f"bm_{shape[0]}x{shape[1]}"
+        m = torch.rand(shape, generator=g) < 0.5
+        p = pack_bitmasks(m)
+        assert torch.equal(unpack_bitmasks(p, list(shape)), m)
+        tensors[key + ".mask"] = m.to(torch.uint8)
+        tensors[key + ".packed"] = p
+        cases.append({"key": key, "kind": "bitmask", "shape": list(shape)})
+    # cutlass 2:4
+    for dt_name, dt, shape in (("bf16", torch.bfloat16, (64, 128)), ("f16", torch.float16, (64, 64)),
+                               ("i8", torch.int8, (64, 128))):
+        key = f"c24_{dt_name}"
+        if dt is torch.int8:
+            d = torch.randint(-8, 8, shape, generator=g, dtype=torch.int8)
+            d = torch.where(d == 0, torch.ones_like(d), d)
+        else:
+            d = torch.randn(shape, generator=g).to(dt)
+        mask = mask_creator(d.float()).bool()
+        dm = d * mask.to(d.dtype)
+        # a few degenerate quads: all-zero, single non-zero, three/four non-zero
+        dm[0, 0:4] = 0
+        dm[0, 4:8] = 0
+        dm[0, 5] = 1
+        dm[1, 0:4] = 1
+        dm[1, 4:8] = 1
+        dm[1, 6] = 0
+        sparse, meta = sparse_semi_structured_from_dense_cutlass(dm)
+        dense_rt = sparse_semi_structured_to_dense_cutlass(sparse, meta)
+        tensors.update({key + ".raw": d, key + ".mask": mask.to(torch.uint8), key + ".dense": dm,
+                        key + ".sparse": sparse.contiguous(), key + ".meta": meta.contiguous(),
+                        key + ".dense_rt": dense_rt})
+        cases.append({"key": key, "kind": "cutlass24", "shape": list(shape)})
+    # marlin-24 permutation tables
+    for bits in (4, 8):
+        perm, scale_perm, scale_perm_single = get_permutations_24(bits)
+        tensors[f"perm24_b{bits}.perm"] = perm.to(torch.int64)
+        tensors[f"perm24_b{bits}.scale_perm"] = torch.tensor(scale_perm)
+        tensors[f"perm24_b{bits}.scale_perm_single"] = torch.tensor(scale_perm_single)
+        cases.append({"key": f"perm24_b{bits}", "kind": "perm24", "bits": bits})
+    save("sparse", tensors, {"cases": cases})
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    gen_pack()
+    gen_quant()
+    gen_qparams()
+    gen_compressors()
+    gen_sparse()
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    total = sum(os.path.getsize(os.path.join(OUT, n)) for n in os.listdir(OUT))
+    print(f"wrote {len(manifest)} golden files, {total/1e6:.2f} MB -> {OUT}")

@@ -1,0 +1,252 @@
+"""Pins the CPU oracle (oracle/ct_oracle.c) against golden vectors produced by the upstream
+reference itself (oracle/gen_golden.py) and against the known-answer vectors of the
+reference's own tests.  CPU only."""
+import math
+
+import pytest
+import torch
+from _golden import cases
+
+import oracle as O
+
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
+
+
+def eq(a, b):
+    """bitwise tensor equality (NaN == NaN, -0.0 != +0.0)"""
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    if a.dtype.is_floating_point:
+        it = {2: torch.int16, 4: torch.int32}[a.element_size()]
+        an, bn = a != a, b != b
+        if not torch.equal(an, bn):
+            return False
+        a = torch.where(an, torch.zeros_like(a), a)
+        b = torch.where(bn, torch.zeros_like(b), b)
+        return torch.equal(a.contiguous().view(it), b.contiguous().view(it))
+    return torch.equal(a, b)
+
+
+# ----------------------------------------------------------------------------- pack / unpack
+@pytest.mark.parametrize("case", cases("pack"), ids=lambda c: c["key"])
+def test_pack_unpack_golden(golden, case):
+    t = golden.case("pack", case["key"])
+    bits, pd = case["bits"], case["packed_dim"]
+    packed = O.pack_to_int32(t["value"], bits, packed_dim=pd)
+    assert eq(packed.contiguous(), t["packed"])
+    if not case.get("oob"):
+        un = O.unpack_from_int32(t["packed"], bits, torch.Size(case["shape"]), packed_dim=pd)
+        assert eq(un.contiguous(), t["value"])
+
+
+def _old_pack(value, bits):
+    """element-aligned historical layout (32//bits codes per word), restated from the
+    description in reference tests/test_compressors/test_pack_quant.py:27-39"""
+    pf = 32 // bits
+    u = (value.to(torch.int32) + (1 << (bits - 1))) & ((1 << bits) - 1)
+    rows, cols = u.shape
+    padded = math.ceil(cols / pf) * pf
+    u = torch.nn.functional.pad(u, (0, padded - cols))
+    out = torch.zeros(rows, padded // pf, dtype=torch.int32)
+    for i in range(pf):
+        out |= u[:, i::pf] << (i * bits)
+    return out
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4, 8])
+@pytest.mark.parametrize("k", [33, 64, 100, 1024])
+def test_old_format_compat(bits, k):
+    """reference tests/test_compressors/test_pack_quant.py:386-416"""
+    lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+    v = torch.randint(lo, hi + 1, (64, k), dtype=torch.int8)
+    old = _old_pack(v, bits)
+    assert torch.equal(O.pack_to_int32(v, bits), old)
+    assert torch.equal(O.unpack_from_int32(old, bits, torch.Size((64, k))), v)
+
+
+def test_pack_errors():
+    with pytest.raises(ValueError):
+        O.pack_to_int32(torch.zeros(2, 2, dtype=torch.int32), 4)
+    with pytest.raises(ValueError):
+        O.pack_to_int32(torch.zeros(2, 2, dtype=torch.int8), 9)
+    with pytest.raises(ValueError):
+        O.unpack_from_int32(torch.zeros(2, 2, dtype=torch.int8), 4, (2, 2))
+
+
+# ----------------------------------------------------------------------------- quantization
+def _kw(case):
+    a = case["args"]
+    return dict(num_bits=a["num_bits"], strategy=a["strategy"], group_size=a.get("group_size"),
+                block_structure=a.get("block_structure"))
+
+
+@pytest.mark.parametrize("case", cases("quant"), ids=lambda c: c["key"])
+def test_quant_golden(golden, case):
+    t = golden.case("quant", case["key"])
+    kw = _kw(case)
+    g_idx = t.get("g_idx")
+    q8 = O.quantize(t["x"], t["scale"], t["zp"], dtype=torch.int8, g_idx=g_idx, **kw)
+    assert eq(q8, t["q8"])
+    fq = O.fake_quantize(t["x"], t["scale"], t["zp"], g_idx=g_idx, **kw)
+    assert eq(fq, t["fq"])
+    dkw = dict(kw)
+    dkw.pop("num_bits")
+    dq = O.dequantize(t["q8"], t["scale"], t["zp"], g_idx=g_idx, **dkw)
+    assert eq(dq, t["dq"])
+    if "qf" in t:
+        assert eq(O.quantize(t["x"], t["scale"], t["zp"], g_idx=g_idx, **kw), t["qf"])
+        assert eq(O.quantize(t["x"], t["scale"], None, dtype=torch.int8, **kw), t["q8_nozp"])
+        if kw["strategy"] != "block":
+            assert eq(O.dequantize(t["q8"], t["scale"], t["zp"]), t["dq_inferred"])
+
+
+# known-answer vectors: reference tests/test_quantization/lifecycle/test_static_lifecycle.py:18-165
+_KA = [
+    ("tensor", None, [0.0], [23.0],
+     [[0.0000, 0.0000, 3.0625, 3.0625, 3.0625, 6.1250], [6.1250, 6.1250, 9.1875, 9.1875, 9.1875, 12.2500],
+      [12.2500, 12.2500, 15.3125, 15.3125, 15.3125, 18.3750], [18.3750, 18.3750, 21.5000, 21.5000, 21.5000, 21.5000]]),
+    ("channel", None, None, None,
+     [[0.0000, 1.3359, 2.0000, 2.6719, 4.0000, 4.6875], [5.8750, 7.3438, 7.3438, 8.8125, 10.2500, 10.2500],
+      [11.3125, 13.6250, 13.6250, 15.8750, 15.8750, 15.8750], [18.3750, 18.3750, 21.5000, 21.5000, 21.5000, 21.5000]]),
+    ("group", 3, None, None,
+     [[0.0000, 1.0703, 1.8750, 2.6719, 4.0000, 4.6875], [6.4375, 7.5000, 7.5000, 8.8125, 10.2500, 10.2500],
+      [11.1875, 13.0625, 13.0625, 15.8750, 15.8750, 15.8750], [18.7500, 18.7500, 18.7500, 21.5000, 21.5000, 21.5000]]),
+]
+
+
+@pytest.mark.parametrize("strategy,gs,_mn,_mx,expected", _KA, ids=[k[0] for k in _KA])
+def test_known_answer_static_lifecycle(strategy, gs, _mn, _mx, expected):
+    w = torch.arange(24, dtype=BF16).reshape(4, 6)
+    if strategy == "tensor":
+        scale, zp = O.calculate_qparams_minmax(w.reshape(1, -1), num_bits=4, symmetric=True)
+        scale, zp = scale.reshape(1), zp.reshape(1)
+    else:
+        scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=gs, symmetric=True)
+    fq = O.fake_quantize(w, scale, zp, num_bits=4, strategy=strategy, group_size=gs)
+    assert torch.allclose(fq.float(), torch.tensor(expected, dtype=BF16).float())
+
+
+@pytest.mark.parametrize("case", cases("qparams"), ids=lambda c: c["key"])
+def test_qparams_golden(golden, case):
+    t = golden.case("qparams", case["key"])
+    scale, zp = O.calculate_qparams_minmax(t["x"], num_bits=case["bits"], group_size=case["group_size"],
+                                           symmetric=case["symmetric"])
+    assert eq(scale, t["scale"])
+    assert eq(zp, t["zp"].to(torch.int8))
+
+
+# ----------------------------------------------------------------------------- compressors
+@pytest.mark.parametrize("case", cases("compressors"), ids=lambda c: c["key"])
+def test_compressor_golden(golden, case):
+    t = golden.case("compressors", case["key"])
+    a = case["args"]
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("in.")}
+    exp_c = {k[2:]: v for k, v in t.items() if k.startswith("c.")}
+    exp_d = {k[2:]: v for k, v in t.items() if k.startswith("d.")}
+    if case["format"] == "pack-quantized":
+        c = O.pack_quantized_compress(sd, num_bits=a["num_bits"], strategy=a["strategy"],
+                                      group_size=a.get("group_size"), symmetric=a["symmetric"])
+        assert sorted(c.keys()) == case["compressed_keys"]
+        for k in exp_c:
+            assert eq(c[k].contiguous(), exp_c[k]), k
+        d = O.pack_quantized_decompress(exp_c, num_bits=a["num_bits"], strategy=a["strategy"],
+                                        symmetric=a["symmetric"])
+        assert sorted(d.keys()) == case["decompressed_keys"]
+        for k in exp_d:
+            assert eq(d[k].contiguous(), exp_d[k]), k
+    else:
+        q = O.quantize(sd["weight"], sd["weight_scale"], sd["weight_zero_point"], num_bits=a["num_bits"],
+                       strategy=a["strategy"], group_size=a.get("group_size"), dtype=torch.int8)
+        assert eq(q, exp_c["weight"])
+        d = O.dequantize(exp_c["weight"], exp_c["weight_scale"], exp_c.get("weight_zero_point"))
+        assert eq(d, exp_d["weight"])
+
+
+# ----------------------------------------------------------------------------- sparse primitives
+@pytest.mark.parametrize("case", [c for c in cases("sparse") if c["kind"] == "bitmask"], ids=lambda c: c["key"])
+def test_bitmask_primitives_golden(golden, case):
+    t = golden.case("sparse", case["key"])
+    assert eq(O.pack_bitmasks(t["mask"].bool()), t["packed"])
+    assert torch.equal(O.unpack_bitmasks(t["packed"], case["shape"]), t["mask"].bool())
+
+
+def test_bitmask_known_answer():
+    # pack_bitmasks([[1,0,0,0,0,0,0,0,0,1]]) == [[1,2]] (verified on the reference)
+    m = torch.tensor([[1, 0, 0, 0, 0, 0, 0, 0, 0, 1]], dtype=torch.bool)
+    assert O.pack_bitmasks(m).tolist() == [[1, 2]]
+
+
+@pytest.mark.parametrize("case", [c for c in cases("sparse") if c["kind"] == "cutlass24"], ids=lambda c: c["key"])
+def test_cutlass24_golden(golden, case):
+    t = golden.case("sparse", case["key"])
+    sparse, meta = O.cutlass24_from_dense(t["dense"])
+    assert eq(sparse, t["sparse"])
+    assert eq(meta, t["meta"])
+    assert eq(O.cutlass24_to_dense(t["sparse"], t["meta"]), t["dense_rt"])
+    # the oracle's own top-2 mask agrees with the reference's mask_creator when there are no ties
+    m = O.sparse24_mask(t["raw"])
+    raw = t["raw"].float().abs().reshape(-1, 4)
+    no_ties = torch.tensor([len(set(r.tolist())) == 4 for r in raw])
+    assert torch.equal(m.reshape(-1, 4)[no_ties], t["mask"].bool().reshape(-1, 4)[no_ties])
+
+
+@pytest.mark.parametrize("bits", [4, 8])
+def test_perm24_golden(golden, bits):
+    t = golden.case("sparse", f"perm24_b{bits}")
+    assert torch.equal(O.marlin24_perm(bits).to(torch.int64), t["perm"])
+    sp, sps = O.marlin24_scale_perms()
+    assert sp == t["scale_perm"].tolist() and sps == t["scale_perm_single"].tolist()
+
+
+# ----------------------------------------------------------------------------- sparse codecs (self-pinned)
+@pytest.mark.parametrize("dtype", [BF16, F16, F32, torch.int8])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 10), (16, 64), (7, 129), (4, 0)])
+def test_bitmask_codec_roundtrip(dtype, shape):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g)
+    x = x.masked_fill(torch.rand(shape, generator=g) < 0.5, 0)
+    x = (x * 8).to(dtype) if dtype is torch.int8 else x.to(dtype)
+    if dtype.is_floating_point and x.numel() > 2:
+        x.view(-1)[0] = -0.0
+        x.view(-1)[1] = float("nan")
+    values, bitmask, row_offsets = O.bitmask_compress(x)
+    # cross-check against the reference primitive's definition via pack_bitmasks
+    mask = x != 0
+    assert torch.equal(bitmask, O.pack_bitmasks(mask).reshape(bitmask.shape))
+    counts = mask.reshape(-1, shape[-1]).sum(-1) if shape[-1] else torch.zeros(shape[0], dtype=torch.int64)
+    assert torch.equal(row_offsets, torch.cumsum(counts, 0) - counts)
+    assert eq(values, x[mask])
+    out = O.bitmask_decompress(values, bitmask, shape)
+    expect = torch.where(mask, x, torch.zeros_like(x))  # -0.0 comes back as +0.0
+    assert eq(out, expect)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, torch.int8])
+def test_sparse24_codec_roundtrip(dtype):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((16, 64), generator=g)
+    x = (x * 20).to(dtype) if dtype is torch.int8 else x.to(dtype)
+    m = O.sparse24_mask(x)
+    assert torch.equal(m.reshape(-1, 4).sum(-1), torch.full((x.numel() // 4,), 2))
+    pruned = x * m.to(x.dtype)
+    values, bitmask = O.sparse24_bitmask_compress(pruned)
+    assert values.shape == (16, 32)
+    out = O.sparse24_bitmask_decompress(values, bitmask, pruned.shape)
+    assert eq(out, torch.where(pruned != 0, pruned, torch.zeros_like(pruned)))
+
+
+def test_marlin24_pack_matches_torch_restatement():
+    """marlin-24 weight packing vs. a direct torch transcription of its definition
+    (reshape/permute/gather with the reference's get_permutations_24 table)."""
+    g = torch.Generator().manual_seed(8)
+    bits = 4
+    k, n = 64, 128
+    q = torch.randint(0, 16, (k, n), generator=g, dtype=torch.int32)
+    perm = O.marlin24_perm(bits).long()
+    t = q.reshape(k // 16, 16, n // 16, 16).permute(0, 2, 1, 3).reshape(k // 16, n * 16)
+    t = t.reshape(-1, perm.numel())[:, perm].reshape(t.shape)
+    pf = 32 // bits
+    expect = torch.zeros((t.shape[0], t.shape[1] // pf), dtype=torch.int32)
+    for i in range(pf):
+        expect |= t[:, i::pf] << (bits * i)
+    assert torch.equal(O.marlin24_pack_weights(q, bits), expect)
