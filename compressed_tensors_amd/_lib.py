@@ -1,0 +1,138 @@
+"""ctypes binding of libct_hip.so (the C ABI declared in include/ct_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950) next to
+this file.  There is NO fallback: if the shared object is missing, or no MI355X is visible
+when a compute entry point is called, the call raises.  Nothing in this package computes the
+hot path on the CPU.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libct_hip.so")
+
+# element type codes of include/ct_hip.h
+F32, F16, BF16, I8, I32, U8, I16, I64 = range(8)
+DT = {
+    torch.float32: F32,
+    torch.float16: F16,
+    torch.bfloat16: BF16,
+    torch.int8: I8,
+    torch.int32: I32,
+    torch.uint8: U8,
+    torch.bool: U8,
+    torch.int16: I16,
+    torch.int64: I64,
+}
+for _name in ("float8_e4m3fn", "float8_e5m2"):
+    if hasattr(torch, _name):
+        DT[getattr(torch, _name)] = I8  # fp8 payloads travel as raw bytes through the copy codecs
+
+CT_OK, CT_ERR_INVALID_ARG, CT_ERR_UNSUPPORTED, CT_ERR_HIP = range(4)
+
+_c = ctypes
+_P, _I, _L, _S = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_void_p
+_Q = [_P, _I, _P, _I, _P, _I, _L, _L, _L, _L, _L, _P]  # x,xdt,scale,sdt,zp,zdt,rows,cols,rdiv,cdiv,scale_cols,col_group
+
+_PROTOTYPES = {
+    "ct_abi_version": ([], _I),
+    "ct_last_error": ([], _c.c_char_p),
+    "ct_pack_int32": ([_P, _L, _L, _I, _P, _L, _S], _I),
+    "ct_unpack_int32": ([_P, _L, _L, _L, _L, _I, _P, _S], _I),
+    "ct_pack_int32_dim0": ([_P, _L, _L, _I, _P, _S], _I),
+    "ct_unpack_int32_dim0": ([_P, _L, _L, _L, _I, _P, _S], _I),
+    "ct_quantize": (_Q + [_I, _I, _P, _I, _S], _I),
+    "ct_dequantize": (_Q + [_P, _I, _S], _I),
+    "ct_fake_quantize": (_Q + [_I, _I, _P, _I, _S], _I),
+    "ct_quant_pack": (_Q + [_I, _I, _P, _S], _I),
+    "ct_unpack_dequant": ([_P, _L, _L, _L, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _I, _S], _I),
+    "ct_minmax_qparams": ([_P, _I, _L, _L, _L, _I, _I, _P, _P, _S], _I),
+    "ct_pack_bitmasks": ([_P, _L, _L, _P, _S], _I),
+    "ct_unpack_bitmasks": ([_P, _L, _L, _P, _S], _I),
+    "ct_bitmask_count": ([_P, _I, _L, _L, _P, _P, _S], _I),
+    "ct_exclusive_scan_i64": ([_P, _L, _P, _P, _S], _I),
+    "ct_bitmask_scatter": ([_P, _I, _L, _L, _P, _P, _S], _I),
+    "ct_bitmask_decompress": ([_P, _L, _P, _P, _L, _I, _L, _L, _P, _S], _I),
+    "ct_bitmask_row_popcount": ([_P, _L, _L, _P, _S], _I),
+    "ct_sparse24_compress": ([_P, _I, _L, _L, _P, _P, _S], _I),
+    "ct_sparse24_mask": ([_P, _I, _L, _P, _S], _I),
+    "ct_cutlass24_from_dense": ([_P, _I, _L, _L, _P, _P, _S], _I),
+    "ct_cutlass24_to_dense": ([_P, _I, _P, _I, _L, _L, _P, _S], _I),
+    "ct_marlin24_pack_weights": ([_P, _I, _I, _I, _L, _L, _I, _P, _S], _I),
+    "ct_marlin24_pack_scales": ([_P, _I, _L, _L, _I, _P, _S], _I),
+    "ct_selftest_bf16_div": ([_c.c_uint32, _c.c_uint32, _P, _S], _I),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libct_hip.so (once).  Raises HipExtensionMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipExtensionMissing(
+                    f"{LIB_PATH} not found: build the HIP extension first "
+                    "(python -c 'import __graft_entry__ as g; g.build()').  "
+                    "compressed_tensors_amd has no CPU fallback."
+                )
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (argtypes, restype) in _PROTOTYPES.items():
+                fn = getattr(lib, name)  # AttributeError here == ABI mismatch with include/ct_hip.h
+                fn.argtypes = argtypes
+                fn.restype = restype
+            _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    msg = load().ct_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int):
+    """Map a ct_status onto the exception types the reference raises."""
+    if status == CT_OK:
+        return
+    msg = last_error()
+    if status == CT_ERR_INVALID_ARG:
+        raise ValueError(msg)
+    if status == CT_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def call(name: str, *args):
+    check(getattr(load(), name)(*args))
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t: torch.Tensor):
+    """the caller's current HIP stream on the tensor's device, as an integer handle"""
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "compressed_tensors_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+            "no GPU is available and there is no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device())

@@ -1,0 +1,580 @@
+"""Tensor-level entry points of the hot path: thin wrappers that validate arguments, allocate
+outputs with torch and launch the HIP kernels of libct_hip.so on the caller's current stream.
+
+Every function mirrors a reference function (cited per function; paths relative to
+/root/reference/src/compressed_tensors/).  There is no eager/CPU implementation here: CPU
+tensors are staged through the GPU (H2D, kernel, D2H) so the arithmetic is always the HIP
+path; without a GPU the calls raise.
+"""
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import DT, call, ptr, stream_of
+
+__all__ = [
+    "pack_to_int32",
+    "unpack_from_int32",
+    "quantize_tensor",
+    "dequantize_tensor",
+    "fake_quantize_tensor",
+    "quantize_and_pack",
+    "unpack_and_dequantize",
+    "minmax_qparams",
+    "pack_bitmasks",
+    "unpack_bitmasks",
+    "bitmask_compress",
+    "bitmask_decompress",
+    "sparse24_mask",
+    "sparse24_bitmask_compress",
+    "sparse24_bitmask_decompress",
+    "cutlass24_from_dense",
+    "cutlass24_to_dense",
+    "marlin24_pack_weights",
+    "marlin24_pack_scales",
+    "selftest_bf16_div",
+    "QuantLayout",
+]
+
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16)
+
+
+# --------------------------------------------------------------------------- staging helpers
+def _dev(t: Optional[torch.Tensor], device: torch.device) -> Optional[torch.Tensor]:
+    """contiguous, 16-byte aligned tensor on `device` (views into other storage are cloned)"""
+    if t is None:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _compute_device(*tensors) -> torch.device:
+    for t in tensors:
+        if t is not None and t.is_cuda:
+            return t.device
+    return _lib.require_device()
+
+
+def _home(out: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """results live on the device of the input they were derived from (reference behaviour)"""
+    return out if out.device == like.device else out.to(like.device)
+
+
+def _strategy_name(strategy) -> Optional[str]:
+    if strategy is None:
+        return None
+    return str(getattr(strategy, "value", strategy)).lower()
+
+
+# --------------------------------------------------------------------------- pack / unpack
+def pack_to_int32(value: torch.Tensor, num_bits: int, packed_dim: int = 1) -> torch.Tensor:
+    """compressors/pack_quantized/helpers.py:20-101 (same arguments, same errors)."""
+    if value.dtype is not torch.int8:
+        raise ValueError("Tensor must be quantized to torch.int8 before packing")
+    if not 1 <= num_bits <= 8:
+        raise ValueError(f"Packing is only supported for num_bits in [1, 8], got {num_bits}")
+    if value.ndim > 2 and packed_dim == 0:
+        return torch.stack([pack_to_int32(value[i], num_bits, packed_dim) for i in range(value.shape[0])])
+    if value.ndim < 2:
+        raise ValueError(f"pack_to_int32 expects a tensor with at least 2 dims, got {value.ndim}")
+    dev = _compute_device(value)
+    v = _dev(value, dev)
+    if packed_dim == 0:
+        rows, cols = v.shape
+        out = torch.empty((math.ceil(rows * num_bits / 32), cols), dtype=torch.int32, device=dev)
+        call("ct_pack_int32_dim0", ptr(v), rows, cols, num_bits, ptr(out), stream_of(v))
+        return _home(out, value)
+    # packing is row-wise, so N-D (MoE) tensors are a stack of rows (helpers.py:45-51)
+    cols = v.shape[-1]
+    rows = v.numel() // cols if cols else math.prod(v.shape[:-1])
+    packed_cols = math.ceil(cols * num_bits / 32)
+    out = torch.empty((*v.shape[:-1], packed_cols), dtype=torch.int32, device=dev)
+    call("ct_pack_int32", ptr(v), rows, cols, num_bits, ptr(out), packed_cols, stream_of(v))
+    return _home(out, value)
+
+
+def unpack_from_int32(value: torch.Tensor, num_bits: int, shape: Sequence[int], packed_dim: int = 1) -> torch.Tensor:
+    """compressors/pack_quantized/helpers.py:104-180 (same arguments, same errors)."""
+    if value.dtype is not torch.int32:
+        raise ValueError(f"Expected {torch.int32} but got {value.dtype}, Aborting unpack.")
+    if not 1 <= num_bits <= 8:
+        raise ValueError(f"Unpacking is only supported for num_bits in [1, 8], got {num_bits}")
+    shape = tuple(int(s) for s in shape)
+    if value.ndim > 2 and packed_dim == 0:
+        return torch.stack(
+            [unpack_from_int32(value[i], num_bits, shape[1:], packed_dim) for i in range(value.shape[0])]
+        )
+    dev = _compute_device(value)
+    v = _dev(value, dev)
+    if packed_dim == 0:
+        words, cols = v.shape
+        rows = shape[0]
+        out = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+        call("ct_unpack_int32_dim0", ptr(v), words, cols, rows, num_bits, ptr(out), stream_of(v))
+        return _home(out, value)
+    words = v.shape[-1]
+    rows = math.prod(v.shape[:-1])
+    cols = shape[-1]
+    out = torch.empty((*v.shape[:-1], cols), dtype=torch.int8, device=dev)
+    call("ct_unpack_int32", ptr(v), rows, words, words, cols, num_bits, ptr(out), stream_of(v))
+    return _home(out, value)
+
+
+# --------------------------------------------------------------------------- quantization layout
+class QuantLayout:
+    """How scale / zero-point entries map onto the elements of x:
+    idx(r, c) = (r // rdiv) * scale_cols + (col_group[c] if col_group is not None else c // cdiv)
+    (see include/ct_hip.h).  Built from the reference's strategy vocabulary."""
+
+    __slots__ = ("rows", "cols", "rdiv", "cdiv", "scale_cols", "col_group", "is_group", "scale_zero_dim")
+
+    def __init__(self, x_shape, scale: torch.Tensor, strategy, group_size=None, block_structure=None,
+                 g_idx: Optional[torch.Tensor] = None):
+        st = _strategy_name(strategy)
+        cols = int(x_shape[-1]) if len(x_shape) else 1
+        rows = math.prod(x_shape[:-1]) if len(x_shape) > 1 else 1
+        self.rows, self.cols = rows, cols
+        self.col_group = None
+        self.is_group = st in ("group", "tensor_group")
+        self.scale_zero_dim = scale.ndim == 0 and not self.is_group
+        if self.is_group:
+            if group_size is None:
+                raise ValueError("group strategy requires group_size")
+            group_size = int(group_size)
+            # forward_helpers.py:141-145
+            if cols >= group_size and cols % group_size != 0:
+                raise ValueError(
+                    "tensor column shape must be divisble "
+                    f"by the given group_size {group_size} but got {cols}"
+                )
+            srows = math.prod(scale.shape[:-1]) if scale.ndim >= 2 else scale.numel()
+            scols = scale.shape[-1] if scale.ndim >= 2 else 1
+            if srows not in (1, rows):
+                raise ValueError(f"scale of shape {tuple(scale.shape)} does not match {rows} rows")
+            self.rdiv = 1 if srows == rows else max(rows, 1)
+            self.cdiv = group_size
+            self.scale_cols = scols
+            if scols * group_size < cols and scols != math.ceil(cols / group_size):
+                raise ValueError(f"scale of shape {tuple(scale.shape)} does not cover {cols} columns with groups of {group_size}")
+            if g_idx is not None and g_idx.device.type != "meta" and not bool((g_idx == -1).any()):
+                # activation ordering (forward_helpers.py:147-175): column c uses the group of
+                # its position in the g_idx-sorted order
+                perm = torch.argsort(g_idx)
+                inv = torch.argsort(perm)
+                self.col_group = (inv // group_size).to(torch.int32)
+        elif st == "block":
+            if len(x_shape) != 2:
+                raise NotImplementedError("block quantization expects a 2-D weight")
+            bh, bw = (int(b) for b in block_structure)
+            self.rdiv, self.cdiv, self.scale_cols = bh, bw, int(scale.shape[-1])
+            if scale.shape[0] != math.ceil(rows / bh) or scale.shape[1] != math.ceil(cols / bw):
+                raise ValueError(f"scale of shape {tuple(scale.shape)} does not match blocks {bh}x{bw} of {tuple(x_shape)}")
+        elif st in ("channel", "token"):
+            if scale.numel() != rows:
+                if scale.numel() == 1:
+                    self.rdiv, self.cdiv, self.scale_cols = max(rows, 1), max(cols, 1), 1
+                else:
+                    raise ValueError(f"scale of shape {tuple(scale.shape)} does not match {rows} channels")
+            else:
+                self.rdiv, self.cdiv, self.scale_cols = 1, max(cols, 1), 1
+        elif st in ("tensor", None):
+            if scale.numel() != 1:
+                raise ValueError(f"per-tensor quantization expects a single scale, got shape {tuple(scale.shape)}")
+            self.rdiv, self.cdiv, self.scale_cols = max(rows, 1), max(cols, 1), 1
+        else:
+            raise NotImplementedError(f"quantization strategy {st!r} is not supported by the MI355X path")
+
+    def args(self, dev):
+        cg = _dev(self.col_group, dev) if self.col_group is not None else None
+        return (self.rows, self.cols, self.rdiv, self.cdiv, self.scale_cols, ptr(cg)), cg
+
+
+def infer_dequant_layout(x_shape, scale: torch.Tensor):
+    """strategy inferred from the scale shape when no args are given (lifecycle/forward.py:99-130)"""
+    if scale.ndim in (0, 1):
+        return "tensor", None, None
+    if scale.ndim == 2:
+        if scale.shape[1] == 1:
+            return "channel", None, None
+        if scale.shape[0] == 1 or scale.shape[0] == x_shape[0]:
+            return "group", int(x_shape[1] / scale.shape[1]), None
+        rows, cols = x_shape[-2], x_shape[-1]
+        return "block", None, [rows // scale.shape[0], cols // scale.shape[1]]
+    raise ValueError(
+        f"Could not infer a quantization strategy from scale with {scale.ndim} "
+        "dimmensions. Expected 0 or 2 dimmensions."
+    )
+
+
+def _result_dtype(x: torch.Tensor, scale: torch.Tensor, zero_dim: bool) -> torch.dtype:
+    """torch result dtype of `x / scale` as the reference evaluates it (a 0-dim scale does not
+    promote a dimensioned x; group strategies always unsqueeze the scale first)"""
+    probe = scale if zero_dim else scale.reshape(-1)[:1]
+    return torch.result_type(x, probe)
+
+
+def _check_float(x, what):
+    if x.dtype not in _FLOATS:
+        raise NotImplementedError(f"{what} dtype {x.dtype} is not supported by the MI355X path")
+
+
+def _zp_arg(zp, dev):
+    if zp is None:
+        return None, -1
+    if zp.dtype not in DT or zp.dtype in (torch.bool,):
+        zp = zp.to(torch.int32)
+    z = _dev(zp, dev)
+    return z, DT[z.dtype]
+
+
+def _check_sz(layout: QuantLayout, scale, zp):
+    need = (max(layout.rows, 1) + layout.rdiv - 1) // layout.rdiv * layout.scale_cols if layout.rows else 0
+    if layout.rows and scale.numel() < need:
+        raise ValueError(f"scale has {scale.numel()} entries, layout needs {need}")
+    if zp is not None and zp.numel() != scale.numel():
+        raise ValueError(f"zero_point shape {tuple(zp.shape)} does not match scale shape {tuple(scale.shape)}")
+
+
+def quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
+                    dtype=None, g_idx=None) -> torch.Tensor:
+    """quantization/lifecycle/forward.py:36-73 for INT types: returns `dtype` (int8/int32 or a
+    float type) or, when dtype is None, x.dtype for group strategies and the promoted type
+    otherwise."""
+    _check_float(x, "x")
+    _check_float(scale, "scale")
+    layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
+    _check_sz(layout, scale, zero_point)
+    T = _result_dtype(x, scale, layout.scale_zero_dim)
+    out_dtype = dtype if dtype is not None else (x.dtype if layout.is_group else T)
+    if out_dtype not in (torch.int8, torch.int32, *_FLOATS):
+        raise NotImplementedError(f"quantize to {out_dtype} is not supported by the MI355X path")
+    dev = _compute_device(x, scale)
+    xd, sd = _dev(x, dev), _dev(scale, dev)
+    zd, zdt = _zp_arg(zero_point, dev)
+    out = torch.empty(x.shape, dtype=out_dtype, device=dev)
+    largs, _keep = layout.args(dev)
+    call("ct_quantize", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
+         ptr(out), DT[out_dtype], stream_of(xd))
+    return _home(out, x)
+
+
+def fake_quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
+                         g_idx=None) -> torch.Tensor:
+    """quantization/lifecycle/forward.py:148-181 (forward_helpers.py:180-215) for INT types."""
+    _check_float(x, "x")
+    _check_float(scale, "scale")
+    layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
+    _check_sz(layout, scale, zero_point)
+    T = _result_dtype(x, scale, layout.scale_zero_dim)
+    out_dtype = x.dtype if layout.is_group else scale.dtype
+    dev = _compute_device(x, scale)
+    xd, sd = _dev(x, dev), _dev(scale, dev)
+    zd, zdt = _zp_arg(zero_point, dev)
+    out = torch.empty(x.shape, dtype=out_dtype, device=dev)
+    largs, _keep = layout.args(dev)
+    call("ct_fake_quantize", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
+         ptr(out), DT[out_dtype], stream_of(xd))
+    return _home(out, x)
+
+
+def dequantize_tensor(x_q, scale, zero_point=None, *, strategy=None, group_size=None, block_structure=None,
+                      dtype=None, g_idx=None) -> torch.Tensor:
+    """quantization/lifecycle/forward.py:76-145 (forward_helpers.py:549-572)."""
+    _check_float(scale, "scale")
+    if x_q.dtype not in (torch.int8, torch.int32, *_FLOATS):
+        raise NotImplementedError(f"dequantize from {x_q.dtype} is not supported by the MI355X path")
+    if strategy is None:
+        strategy, group_size, block_structure = infer_dequant_layout(x_q.shape, scale)
+    layout = QuantLayout(x_q.shape, scale, strategy, group_size, block_structure, g_idx)
+    _check_sz(layout, scale, zero_point)
+    out_dtype = dtype if dtype is not None else scale.dtype
+    if out_dtype not in _FLOATS:
+        raise NotImplementedError(f"dequantize to {out_dtype} is not supported by the MI355X path")
+    dev = _compute_device(x_q, scale)
+    qd, sd = _dev(x_q, dev), _dev(scale, dev)
+    zd, zdt = _zp_arg(zero_point, dev)
+    out = torch.empty(x_q.shape, dtype=out_dtype, device=dev)
+    largs, _keep = layout.args(dev)
+    call("ct_dequantize", ptr(qd), DT[qd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, ptr(out), DT[out_dtype],
+         stream_of(qd))
+    return _home(out, x_q)
+
+
+def quantize_and_pack(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
+                      g_idx=None) -> torch.Tensor:
+    """Fused quantize(dtype=int8) + pack_to_int32 (compressors/pack_quantized/base.py:96-104):
+    one pass over the weight, no int8 intermediate.  Returns int32 (*x.shape[:-1], ceil(cols*bits/32))."""
+    _check_float(x, "weight")
+    _check_float(scale, "scale")
+    if not 1 <= num_bits <= 8:
+        raise ValueError(f"Packing is only supported for num_bits in [1, 8], got {num_bits}")
+    layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
+    _check_sz(layout, scale, zero_point)
+    T = _result_dtype(x, scale, layout.scale_zero_dim)
+    dev = _compute_device(x, scale)
+    xd, sd = _dev(x, dev), _dev(scale, dev)
+    zd, zdt = _zp_arg(zero_point, dev)
+    packed_cols = math.ceil(layout.cols * num_bits / 32)
+    out = torch.empty((*x.shape[:-1], packed_cols), dtype=torch.int32, device=dev)
+    largs, _keep = layout.args(dev)
+    call("ct_quant_pack", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
+         ptr(out), stream_of(xd))
+    return _home(out, x)
+
+
+def unpack_and_dequantize(packed, shape, scale, zero_point=None, *, num_bits, strategy=None, group_size=None,
+                          block_structure=None, dtype=None, g_idx=None) -> torch.Tensor:
+    """Fused unpack_from_int32 + dequantize (compressors/pack_quantized/base.py:155-161).
+    `zero_point` is the UNPACKED int8 zero point (or None)."""
+    if packed.dtype is not torch.int32:
+        raise ValueError(f"Expected {torch.int32} but got {packed.dtype}, Aborting unpack.")
+    if not 1 <= num_bits <= 8:
+        raise ValueError(f"Unpacking is only supported for num_bits in [1, 8], got {num_bits}")
+    _check_float(scale, "scale")
+    shape = tuple(int(s) for s in shape)
+    if strategy is None:
+        strategy, group_size, block_structure = infer_dequant_layout(shape, scale)
+    layout = QuantLayout(shape, scale, strategy, group_size, block_structure, g_idx)
+    _check_sz(layout, scale, zero_point)
+    out_dtype = dtype if dtype is not None else scale.dtype
+    if out_dtype not in _FLOATS:
+        raise NotImplementedError(f"dequantize to {out_dtype} is not supported by the MI355X path")
+    dev = _compute_device(packed, scale)
+    pd, sd = _dev(packed, dev), _dev(scale, dev)
+    zd, zdt = _zp_arg(zero_point, dev)
+    words = pd.shape[-1]
+    if math.prod(pd.shape[:-1]) != layout.rows:
+        raise ValueError(f"packed shape {tuple(pd.shape)} does not match weight shape {shape}")
+    out = torch.empty(shape, dtype=out_dtype, device=dev)
+    largs, _keep = layout.args(dev)
+    rows, cols, rdiv, cdiv, scols, cg = largs
+    call("ct_unpack_dequant", ptr(pd), rows, words, cols, int(num_bits), ptr(sd), DT[sd.dtype], ptr(zd), zdt, rdiv, cdiv,
+         scols, cg, ptr(out), DT[out_dtype], stream_of(pd))
+    return _home(out, packed)
+
+
+def minmax_qparams(x, *, num_bits, group_size=None, symmetric=True):
+    """Min-max observer + calculate_qparams (quantization/utils/helpers.py:50-137) over groups of
+    `group_size` consecutive columns (None: the whole row).  Returns (scale x.dtype (R, G),
+    zero_point int8 (R, G))."""
+    _check_float(x, "weight")
+    if x.ndim != 2:
+        raise ValueError("minmax_qparams expects a 2-D weight")
+    dev = _compute_device(x)
+    xd = _dev(x, dev)
+    rows, cols = xd.shape
+    cdiv = int(group_size) if group_size else max(cols, 1)
+    ng = math.ceil(cols / cdiv) if cols else 0
+    scale = torch.empty((rows, ng), dtype=xd.dtype, device=dev)
+    zp = torch.empty((rows, ng), dtype=torch.int8, device=dev)
+    call("ct_minmax_qparams", ptr(xd), DT[xd.dtype], rows, cols, cdiv, int(num_bits), int(bool(symmetric)), ptr(scale),
+         ptr(zp), stream_of(xd))
+    return _home(scale, x), _home(zp, x)
+
+
+# --------------------------------------------------------------------------- bitmask codecs
+def _bits_view(t: torch.Tensor) -> torch.Tensor:
+    """fp8 payloads are moved as raw bytes"""
+    if t.dtype.is_floating_point and t.element_size() == 1:
+        return t.view(torch.int8)
+    return t
+
+
+def _elem_code(t: torch.Tensor) -> int:
+    if t.dtype not in DT:
+        raise NotImplementedError(f"element dtype {t.dtype} is not supported by the MI355X path")
+    if t.element_size() not in (1, 2, 4):
+        raise NotImplementedError(f"{t.element_size()}-byte elements are not supported by the sparse codecs")
+    return DT[t.dtype]
+
+
+def pack_bitmasks(bytemasks: torch.Tensor) -> torch.Tensor:
+    """utils/helpers.py:306-318 (numpy.packbits(..., bitorder="little") on the GPU)."""
+    dev = _compute_device(bytemasks)
+    m = _dev(bytemasks if bytemasks.dtype in (torch.bool, torch.uint8) else bytemasks != 0, dev)
+    cols = m.shape[-1] if m.ndim else 1
+    rows = math.prod(m.shape[:-1]) if m.ndim > 1 else 1
+    out = torch.empty((*m.shape[:-1], math.ceil(cols / 8)), dtype=torch.uint8, device=dev)
+    call("ct_pack_bitmasks", ptr(m), rows, cols, ptr(out), stream_of(m))
+    return _home(out, bytemasks)
+
+
+def unpack_bitmasks(packed_bitmasks: torch.Tensor, original_shape) -> torch.Tensor:
+    """utils/helpers.py:321-343; returns a bool tensor of `original_shape`."""
+    shape = tuple(int(s) for s in original_shape)
+    dev = _compute_device(packed_bitmasks)
+    p = _dev(packed_bitmasks, dev)
+    cols = shape[-1]
+    rows = math.prod(shape[:-1])
+    out = torch.empty(shape, dtype=torch.uint8, device=dev)
+    call("ct_unpack_bitmasks", ptr(p), rows, cols, ptr(out), stream_of(p))
+    return _home(out.view(torch.bool), packed_bitmasks)
+
+
+def bitmask_compress(tensor: torch.Tensor):
+    """sparse-bitmask compression: returns (values, bitmask uint8 (R, ceil(C/8)), row_offsets int64 (R,)).
+    Two passes (count+bitmask, scatter) around a row-count scan; one host read of nnz to size
+    `values`, as unavoidable as the reference's `tensor[mask]`."""
+    if tensor.ndim < 1:
+        raise ValueError("bitmask compression expects at least a 1-D tensor")
+    dev = _compute_device(tensor)
+    x = _dev(_bits_view(tensor), dev)
+    dt = _elem_code(x)
+    cols = x.shape[-1]
+    rows = math.prod(x.shape[:-1]) if x.ndim > 1 else 1
+    bitmask = torch.empty((rows, math.ceil(cols / 8)), dtype=torch.uint8, device=dev)
+    counts = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+    row_offsets = torch.empty(rows, dtype=torch.int64, device=dev)
+    s = stream_of(x)
+    call("ct_bitmask_count", ptr(x), dt, rows, cols, ptr(bitmask), ptr(counts), s)
+    total = counts[rows:]
+    call("ct_exclusive_scan_i64", ptr(counts), rows, ptr(row_offsets), total.data_ptr(), s)
+    nnz = int(total.item())
+    values = torch.empty(nnz, dtype=x.dtype, device=dev)
+    if nnz:
+        call("ct_bitmask_scatter", ptr(x), dt, rows, cols, ptr(row_offsets), ptr(values), s)
+    return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor), _home(row_offsets, tensor)
+
+
+def bitmask_decompress(values: torch.Tensor, bitmask: torch.Tensor, shape, row_offsets: Optional[torch.Tensor] = None,
+                       fixed_row_nnz: Optional[int] = None) -> torch.Tensor:
+    """sparse-bitmask decompression: zeros(shape) with `values` written at the set bits."""
+    shape = tuple(int(s) for s in shape)
+    dev = _compute_device(values, bitmask)
+    v = _dev(_bits_view(values).reshape(-1), dev)
+    b = _dev(bitmask, dev)
+    dt = _elem_code(v)
+    cols = shape[-1]
+    rows = math.prod(shape[:-1])
+    s = stream_of(b)
+    ro = None
+    if fixed_row_nnz is None:
+        if row_offsets is None:
+            counts = torch.empty(rows, dtype=torch.int64, device=dev)
+            ro = torch.empty(rows, dtype=torch.int64, device=dev)
+            call("ct_bitmask_row_popcount", ptr(b), rows, cols, ptr(counts), s)
+            call("ct_exclusive_scan_i64", ptr(counts), rows, ptr(ro), None, s)
+        else:
+            ro = _dev(row_offsets.to(torch.int64), dev)
+    out = torch.empty(shape, dtype=v.dtype, device=dev)
+    call("ct_bitmask_decompress", ptr(v), v.numel(), ptr(b), ptr(ro), -1 if fixed_row_nnz is None else int(fixed_row_nnz),
+         dt, rows, cols, ptr(out), s)
+    return _home(out.view(values.dtype), values)
+
+
+def sparse24_mask(tensor: torch.Tensor) -> torch.Tensor:
+    """bool mask keeping the 2 largest-|x| of every 4 consecutive elements
+    (mask_creator, utils/semi_structured_conversions.py:301-330; ties: lower index first)."""
+    if tensor.numel() % 4 != 0:
+        raise ValueError(f"Tensor of size {tensor.shape} can't be evenly divided into 4 groups")
+    if tensor.numel() % 8 != 0:
+        raise NotImplementedError("the MI355X 2:4 path needs a multiple of 8 elements")
+    dev = _compute_device(tensor)
+    x = _dev(_bits_view(tensor), dev)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=dev)
+    call("ct_sparse24_mask", ptr(x), _elem_code(x), x.numel(), ptr(mask), stream_of(x))
+    return _home(mask.view(torch.bool), tensor)
+
+
+def sparse24_bitmask_compress(tensor: torch.Tensor):
+    """sparse-24-bitmask compression: (values (R, C/2), bitmask uint8 (R, C/8))."""
+    if tensor.ndim != 2:
+        raise ValueError("2:4 bitmask compression expects a 2-D tensor")
+    if tensor.numel() % 4 != 0:
+        raise ValueError("Tensor size must be a multiple of 4 for TWO_FOUR sparsity")
+    dev = _compute_device(tensor)
+    x = _dev(_bits_view(tensor), dev)
+    rows, cols = x.shape
+    values = torch.empty((rows, cols // 2), dtype=x.dtype, device=dev)
+    bitmask = torch.empty((rows, math.ceil(cols / 8)), dtype=torch.uint8, device=dev)
+    call("ct_sparse24_compress", ptr(x), _elem_code(x), rows, cols, ptr(values), ptr(bitmask), stream_of(x))
+    return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor)
+
+
+def sparse24_bitmask_decompress(values: torch.Tensor, bitmask: torch.Tensor, shape) -> torch.Tensor:
+    shape = tuple(int(s) for s in shape)
+    return bitmask_decompress(values, bitmask, shape, fixed_row_nnz=shape[-1] // 2)
+
+
+# --------------------------------------------------------------------------- 2:4 cutlass + marlin-24
+def cutlass24_from_dense(dense: torch.Tensor):
+    """utils/semi_structured_conversions.py:66-197 -> (sparse (m, k/2), meta_reordered)."""
+    if dense.dim() != 2:
+        raise RuntimeError(f"Expected 2-dimensional dense tensor, got {dense.dim()}-dimensional tensor")
+    if dense.dtype not in (torch.int8, torch.float16, torch.bfloat16):
+        if dense.dtype in (torch.float32, torch.int32):
+            raise NotImplementedError(f"{dense.dtype} 2:4 conversion is not supported by the MI355X path")
+        raise RuntimeError(f"Invalid datatype {dense.dtype} of dense matrix")
+    dev = _compute_device(dense)
+    d = _dev(dense, dev)
+    m, k = d.shape
+    meta_dtype = torch.int32 if d.dtype == torch.int8 else torch.int16
+    q = meta_dtype.itemsize * 2
+    if m % 64 != 0:
+        raise RuntimeError(f"Number of rows of dense matrix {m} must be divisible by 64")
+    if k % (4 * q) != 0:
+        raise RuntimeError(f"Number of columns of dense matrix {k} must be divisible by {4 * q}")
+    sparse = torch.empty((m, k // 2), dtype=d.dtype, device=dev)
+    meta = torch.empty((m, k // (4 * q)), dtype=meta_dtype, device=dev)
+    call("ct_cutlass24_from_dense", ptr(d), DT[d.dtype], m, k, ptr(sparse), ptr(meta), stream_of(d))
+    return _home(sparse, dense), _home(meta, dense)
+
+
+def cutlass24_to_dense(sparse: torch.Tensor, meta_reordered: torch.Tensor) -> torch.Tensor:
+    """utils/semi_structured_conversions.py:204-298."""
+    if sparse.dim() != 2:
+        raise RuntimeError(f"Expected 2-dimensional sparse tensor, got {sparse.dim()}-dimensional tensor")
+    if meta_reordered.dim() != 2:
+        raise RuntimeError(f"Expected 2-dimensional meta tensor, got {meta_reordered.dim()}-dimensional tensor")
+    if meta_reordered.dtype not in (torch.int16, torch.int32):
+        raise RuntimeError(f"Invalid datatype {meta_reordered.dtype} of meta matrix")
+    dev = _compute_device(sparse)
+    s, mt = _dev(sparse, dev), _dev(meta_reordered, dev)
+    m, k = s.shape
+    if mt.shape[0] != m:
+        raise RuntimeError(
+            f"Number of rows of meta matrix {mt.shape[0]} must be equal to number of columns of spase matrix {m}"
+        )
+    dense = torch.empty((m, 2 * k), dtype=s.dtype, device=dev)
+    call("ct_cutlass24_to_dense", ptr(s), DT[s.dtype], ptr(mt), mt.dtype.itemsize, m, k, ptr(dense), stream_of(s))
+    return _home(dense, sparse)
+
+
+def marlin24_pack_weights(q: torch.Tensor, num_bits: int, *, transposed: bool = False, add_offset: bool = False):
+    """marlin-24 weight packing.  q: (size_k, size_n) codes, or with transposed=True the
+    un-transposed (size_n, size_k) 2:4-compressed matrix."""
+    if num_bits not in (4, 8):
+        raise ValueError("num_bits must be 4 or 8, got {}".format(num_bits))
+    dev = _compute_device(q)
+    qd = _dev(q, dev)
+    size_k, size_n = (qd.shape[1], qd.shape[0]) if transposed else qd.shape
+    out = torch.empty((size_k // 16, size_n * 16 * num_bits // 32), dtype=torch.int32, device=dev)
+    call("ct_marlin24_pack_weights", ptr(qd), DT[qd.dtype], int(transposed), int(add_offset), size_k, size_n, num_bits,
+         ptr(out), stream_of(qd))
+    return _home(out, q)
+
+
+def marlin24_pack_scales(scale: torch.Tensor, *, single: bool):
+    """marlin-24 scale packing: (size_n, groups) -> permuted (groups, size_n)."""
+    dev = _compute_device(scale)
+    s = _dev(scale, dev)
+    size_n, groups = s.shape
+    out = torch.empty((groups, size_n), dtype=s.dtype, device=dev)
+    call("ct_marlin24_pack_scales", ptr(s), DT[s.dtype], size_n, groups, int(single), ptr(out), stream_of(s))
+    return _home(out, scale)
+
+
+# --------------------------------------------------------------------------- diagnostics
+def selftest_bf16_div(s_lo_bits: int = 0, s_hi_bits: int = 65536) -> int:
+    """number of (x, s) bf16 pairs for which the reciprocal fast path disagrees with the IEEE
+    divide (must be 0; see ct_quant.hip)."""
+    dev = _lib.require_device()
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    call("ct_selftest_bf16_div", s_lo_bits, s_hi_bits, ptr(out), torch.cuda.current_stream(dev).cuda_stream)
+    return int(out.item())

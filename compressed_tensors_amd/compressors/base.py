@@ -1,0 +1,100 @@
+"""Compressor plug-in surface, mirrored from the reference (compressors/base.py:34-219).
+
+`BaseCompressor` subclasses are never instantiated: they are looked up by their wire-format
+string (`BaseCompressor.get_value_from_registry("pack-quantized")`) and used through
+classmethods on *local-name* state dicts (`weight`, `weight_scale`, ...).  Inputs are never
+mutated; untouched tensors are returned by identity.
+"""
+from abc import ABC
+from typing import Optional
+
+import torch
+
+from ..config import CompressionFormat
+from ..quantization.quant_args import QuantizationStatus, is_scheme
+from ..registry import RegistryMixin
+from ..utils.module import get_direct_state_dict, replace_direct_state_dict
+
+__all__ = ["BaseCompressor", "compress_module", "decompress_module", "COMPRESSIBLE_MODULE_TYPES"]
+
+# reference compressors/base.py:31
+COMPRESSIBLE_MODULE_TYPES = (torch.nn.Linear, torch.nn.Embedding)
+
+
+class BaseCompressor(RegistryMixin, ABC):
+    @classmethod
+    def compression_param_names(cls, scheme) -> tuple:
+        raise NotImplementedError(
+            f"{cls.__name__} does not implement the classmethod compression_param_names interface"
+        )
+
+    @classmethod
+    def compress(cls, state_dict: dict, scheme) -> dict:
+        raise NotImplementedError(f"{cls.__name__} does not implement the classmethod compress interface")
+
+    @classmethod
+    def decompress(cls, state_dict: dict, scheme) -> dict:
+        raise NotImplementedError(f"{cls.__name__} does not implement the classmethod decompress interface")
+
+    @classmethod
+    def can_compress(cls, module_type: type, scheme) -> bool:
+        raise NotImplementedError(f"{cls.__name__} does not implement match")
+
+    @classmethod
+    def compress_module(cls, module: torch.nn.Module) -> None:
+        """compressors/base.py:95-112"""
+        scheme = getattr(module, "quantization_scheme")
+        state_dict = get_direct_state_dict(module)
+        replace_direct_state_dict(module, cls.compress(state_dict, scheme))
+        module.quantization_status = QuantizationStatus.COMPRESSED
+
+    @classmethod
+    def decompress_module(cls, module: torch.nn.Module) -> None:
+        """compressors/base.py:114-131"""
+        scheme = getattr(module, "quantization_scheme")
+        state_dict = get_direct_state_dict(module)
+        replace_direct_state_dict(module, cls.decompress(state_dict, scheme))
+        module.quantization_status = QuantizationStatus.DECOMPRESSED
+
+    @classmethod
+    def _remove_symmetric_zp(cls, state_dict: dict, scheme) -> dict:
+        """compressors/base.py:147-167: vLLM cannot load zero points of symmetric schemes"""
+        for args_name, key in (
+            ("input_activations", "input_zero_point"),
+            ("weights", "weight_zero_point"),
+            ("output_activations", "output_zero_point"),
+        ):
+            args = getattr(scheme, args_name, None)
+            if args is not None and getattr(args, "symmetric", False):
+                state_dict.pop(key, None)
+        return state_dict
+
+
+def _resolve_format(module, scheme, format):
+    from .format import infer_module_format
+
+    fmt = format or getattr(scheme, "format", None) or infer_module_format(type(module), scheme)
+    fmt = CompressionFormat(getattr(fmt, "value", fmt))
+    try:
+        scheme.format = fmt
+    except Exception:  # pydantic schemes validate assignment; the string value is always accepted
+        scheme.format = fmt.value
+    return fmt
+
+
+def compress_module(module: torch.nn.Module, format: Optional[CompressionFormat] = None):
+    """compressors/base.py:170-193"""
+    scheme = getattr(module, "quantization_scheme", None)
+    if not is_scheme(scheme):
+        return
+    fmt = _resolve_format(module, scheme, format)
+    BaseCompressor.get_value_from_registry(fmt.value).compress_module(module)
+
+
+def decompress_module(module: torch.nn.Module, format: Optional[CompressionFormat] = None):
+    """compressors/base.py:196-219"""
+    scheme = getattr(module, "quantization_scheme", None)
+    if not is_scheme(scheme):
+        return
+    fmt = _resolve_format(module, scheme, format)
+    BaseCompressor.get_value_from_registry(fmt.value).decompress_module(module)

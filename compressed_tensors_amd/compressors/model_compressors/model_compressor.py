@@ -1,0 +1,141 @@
+"""ModelCompressor (reference compressors/model_compressors/model_compressor.py:36-273):
+iterates the quantized modules of a model and compresses / decompresses each with the codec
+named by its scheme's format.
+
+Multi-GPU: when torch.distributed is initialised, modules are partitioned over ranks with the
+reference's own rule (largest first onto the lightest bin, distributed/assign.py:12-42) and each
+rank compresses its bin on its own MI355X.  No collective is issued: the reference's
+broadcast "recouple" step (distributed/module_parallel.py:74-90) only replicates results and
+is out of scope; `shard_only=False` is therefore not offered.
+"""
+import json
+import os
+from typing import Optional
+
+import torch
+
+from ...config import CompressionFormat
+from ...distributed import is_distributed, module_size, shard_modules
+from ...quantization.quant_args import QuantizationStatus
+from ...quantization.utils import is_module_quantized
+from ..base import compress_module, decompress_module
+from ..format import infer_model_format
+
+__all__ = ["ModelCompressor"]
+
+# reference base.py:5-12
+QUANTIZATION_CONFIG_NAME = "quantization_config"
+COMPRESSION_VERSION_NAME = "version"
+QUANTIZATION_METHOD_NAME = "quant_method"
+QUANTIZATION_METHOD = "compressed-tensors"
+SPARSITY_CONFIG_NAME = "sparsity_config"
+TRANSFORM_CONFIG_NAME = "transform_config"
+
+
+class ModelCompressor:
+    def __init__(self, quantization_config=None, transform_config=None, force_compression_format: Optional[str] = None):
+        self.quantization_config = quantization_config
+        self.transform_config = transform_config
+        self.force_compression_format = (
+            CompressionFormat(getattr(force_compression_format, "value", force_compression_format))
+            if force_compression_format is not None
+            else None
+        )
+
+    @classmethod
+    def from_compression_config(cls, compression_config):
+        """model_compressor.py:64-86 (HF quantizer entry point)"""
+        q_config = getattr(compression_config, "quantization_config", None)
+        if q_config is None and not hasattr(compression_config, "quantization_config"):
+            raise ValueError(
+                f"Support for compression config of type {type(compression_config)} is no longer supported."
+            )
+        return cls(quantization_config=q_config, transform_config=getattr(compression_config, "transform_config", None))
+
+    @classmethod
+    def from_pretrained_model(cls, model: torch.nn.Module, sparsity_config_or_format=None, quantization_format: Optional[str] = None):
+        """model_compressor.py:88-122; the quantization config object itself is the caller's
+        (pydantic, reference side) — here only the inferred format is recorded"""
+        fmt = infer_model_format(model, quantization_format)
+        compressor = cls(quantization_config=getattr(model, "quantization_config", None),
+                         transform_config=getattr(model, TRANSFORM_CONFIG_NAME, None),
+                         force_compression_format=quantization_format)
+        compressor.inferred_format = fmt
+        return compressor
+
+    # ------------------------------------------------------------------ compress / decompress
+    def _quantized_modules(self, model, skip_compressed=False):
+        return [
+            m for _, m in model.named_modules(remove_duplicate=True)
+            if is_module_quantized(m)
+            and (not skip_compressed or getattr(m, "quantization_status", None) != QuantizationStatus.COMPRESSED)
+        ]
+
+    def compress_model(self, model: torch.nn.Module, skip_compressed: bool = False) -> None:
+        """model_compressor.py:138-181"""
+        modules = self._quantized_modules(model, skip_compressed)
+        if is_distributed():
+            modules = shard_modules(modules, module_size)
+        for module in modules:
+            compress_module(module, self.force_compression_format)
+        if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
+            self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
+        self.add_decompress_hook(model)
+
+    def decompress_model(self, model: torch.nn.Module) -> None:
+        """model_compressor.py:183-207.  Under torch.distributed each rank decompresses the
+        modules of its own shard (upstream has no distributed decompression at all, :196)."""
+        modules = self._quantized_modules(model)
+        if is_distributed():
+            modules = [m for m in shard_modules(modules, module_size)
+                       if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED]
+        for module in modules:
+            decompress_module(module, self.force_compression_format)
+        if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
+            self.quantization_config.quantization_status = QuantizationStatus.DECOMPRESSED
+        self.remove_decompression_hook(model)
+
+    # ------------------------------------------------------------------ config.json
+    def update_config(self, save_directory: str) -> None:
+        """model_compressor.py:209-244"""
+        if not any((self.quantization_config, self.transform_config)):
+            return
+        path = os.path.join(save_directory, "config.json")
+        data = {}
+        if os.path.exists(path):
+            with open(path, "r") as f:
+                data = json.load(f)
+
+        def dump(cfg, **kw):
+            if cfg is None:
+                return {}
+            if hasattr(cfg, "model_dump"):
+                return cfg.model_dump(**kw)
+            return dict(cfg) if isinstance(cfg, dict) else dict(vars(cfg))
+
+        from ... import __version__
+
+        data[QUANTIZATION_CONFIG_NAME] = {
+            COMPRESSION_VERSION_NAME: __version__,
+            QUANTIZATION_METHOD_NAME: QUANTIZATION_METHOD,
+            SPARSITY_CONFIG_NAME: {},
+            TRANSFORM_CONFIG_NAME: dump(self.transform_config),
+            **{k: v for k, v in dump(self.quantization_config).items() if k != "quant_method"},
+        }
+        with open(path, "w") as f:
+            json.dump(data, f, indent=2, sort_keys=True, default=lambda o: getattr(o, "value", str(o)))
+
+    # ------------------------------------------------------------------ first-forward hook
+    def add_decompress_hook(self, model: torch.nn.Module):
+        """model_compressor.py:246-260"""
+
+        def ct_decompress_hook(model, args):
+            self.decompress_model(model)
+
+        model.ct_decompress_hook = model.register_forward_pre_hook(ct_decompress_hook)
+
+    def remove_decompression_hook(self, model: torch.nn.Module):
+        """model_compressor.py:262-273"""
+        if hasattr(model, "ct_decompress_hook"):
+            model.ct_decompress_hook.remove()
+            delattr(model, "ct_decompress_hook")

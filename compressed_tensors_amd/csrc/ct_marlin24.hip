@@ -1,0 +1,245 @@
+// ct_marlin24.hip — CUTLASS 2:4 semi-structured conversion and marlin-24 packing for gfx950.
+//
+// Reference: utils/semi_structured_conversions.py:33-298 (compress/decompress + metadata
+// reordering), utils/permutations_24.py:20-53 (marlin-24 permutation tables).  The
+// Marlin24Compressor class itself is absent from the reference snapshot;
+// the packing restated here follows its historical definition and is pinned against the CPU
+// oracle, which in turn is pinned against the surviving reference primitives.
+#include "ct_common.h"
+
+namespace ct {
+
+// destination linear offset of meta element (r, c) (semi_structured_conversions.py:33-60)
+__host__ __device__ __forceinline__ int64_t meta_reorder_offset(int64_t r, int64_t c, int64_t m, int meta_itemsize) {
+    const int64_t group_x = 64, group_y = meta_itemsize == 2 ? 32 : 16;
+    int64_t dr = r / group_x * group_x + (r % 2) * 2 + (r % 8) / 4 + ((r % group_y) % 4) / 2 * 32 + ((r % group_x) / 8) * 4;
+    int64_t dc = c;
+    const int topright = (dr % 2 == 0) && (dc % 2 == 1);
+    const int bottomleft = (dr % 2 == 1) && (dc % 2 == 0);
+    dr += topright - bottomleft;
+    dc -= topright - bottomleft;
+    return (dc / 2) * m * 2 + dr * 2 + dc % 2;
+}
+
+// 4-bit code of a quad from its non-zero flags (:111-153)
+__device__ __forceinline__ uint32_t quad_code(bool m0, bool m1, bool m3) {
+    const bool e0 = m0 && m1, e1 = !m0 && m1, e2 = !m0 && !m1;
+    const uint32_t bit0 = e1, bit1 = e2, bit2 = e0 || e2 || m3, bit3 = e1 || !m1;
+    return bit0 | (bit1 << 1) | (bit2 << 2) | (bit3 << 3);
+}
+
+// one lane per metadata word: Q quads = 16 (16-bit inputs) or 32 (int8 inputs) dense elements
+// = 32 bytes in, 16 bytes of kept values + one meta word out
+template <int ES>
+__global__ __launch_bounds__(kBlock) void cutlass24_from_dense_kernel(const void* __restrict__ dense, bool is_float, int64_t m, int64_t k,
+                                                                      void* __restrict__ sparse, void* __restrict__ meta) {
+    constexpr int MI = ES == 1 ? 4 : 2;  // meta itemsize
+    constexpr int Q = MI * 2;            // quads per meta word
+    const int64_t meta_ncols = k / (4 * Q);
+    const int64_t total = m * meta_ncols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / meta_ncols, mc = i - r * meta_ncols;
+        const u32x4* in = reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(dense) + (r * k + mc * 4 * Q) * ES);
+        const u32x4 a = in[0], b = in[1];
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t word = 0;
+        uint32_t outw[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int qd = 0; qd < Q; ++qd) {
+            uint32_t e[4];
+            if constexpr (ES == 2) {
+                e[0] = w[2 * qd] & 0xffffu; e[1] = w[2 * qd] >> 16; e[2] = w[2 * qd + 1] & 0xffffu; e[3] = w[2 * qd + 1] >> 16;
+            } else {
+                e[0] = w[qd] & 0xffu; e[1] = (w[qd] >> 8) & 0xffu; e[2] = (w[qd] >> 16) & 0xffu; e[3] = w[qd] >> 24;
+            }
+            const uint32_t zmask = (ES == 2 && is_float) ? 0x7fffu : 0xffffffffu;
+            const uint32_t code = quad_code((e[0] & zmask) != 0, (e[1] & zmask) != 0, (e[3] & zmask) != 0);
+            word |= code << (4 * qd);
+            const uint32_t i0 = code & 3u, i1 = (code >> 2) & 3u;
+            const uint32_t v0 = i0 == 0 ? e[0] : (i0 == 1 ? e[1] : (i0 == 2 ? e[2] : e[3]));
+            const uint32_t v1 = i1 == 0 ? e[0] : (i1 == 1 ? e[1] : (i1 == 2 ? e[2] : e[3]));
+            if constexpr (ES == 2) outw[qd] = v0 | (v1 << 16);
+            else outw[qd >> 1] |= (v0 | (v1 << 8)) << (16 * (qd & 1));
+        }
+        *reinterpret_cast<u32x4*>(static_cast<uint8_t*>(sparse) + (r * (k / 2) + mc * 2 * Q) * ES) = u32x4{outw[0], outw[1], outw[2], outw[3]};
+        const int64_t off = meta_reorder_offset(r, mc, m, MI);
+        if constexpr (MI == 2) static_cast<uint16_t*>(meta)[off] = (uint16_t)word;
+        else static_cast<uint32_t*>(meta)[off] = word;
+    }
+}
+
+template <int ES>
+__global__ __launch_bounds__(kBlock) void cutlass24_to_dense_kernel(const void* __restrict__ sparse, const void* __restrict__ meta, int64_t m,
+                                                                    int64_t k /*sparse cols*/, void* __restrict__ dense) {
+    constexpr int MI = ES == 1 ? 4 : 2;
+    constexpr int Q = MI * 2;
+    const int64_t meta_ncols = 2 * k / (4 * Q);
+    const int64_t total = m * meta_ncols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / meta_ncols, mc = i - r * meta_ncols;
+        const int64_t off = meta_reorder_offset(r, mc, m, MI);
+        const uint32_t word = MI == 2 ? (uint32_t)static_cast<const uint16_t*>(meta)[off] : static_cast<const uint32_t*>(meta)[off];
+        const u32x4 s = *reinterpret_cast<const u32x4*>(static_cast<const uint8_t*>(sparse) + (r * k + mc * 2 * Q) * ES);
+        const uint32_t sw[4] = {s.x, s.y, s.z, s.w};
+        uint32_t ow[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int qd = 0; qd < Q; ++qd) {
+            const uint32_t code = (word >> (4 * qd)) & 0xfu;
+            const uint32_t i0 = code & 3u, i1 = (code >> 2) & 3u;
+            uint32_t v0, v1;
+            if constexpr (ES == 2) { v0 = sw[qd] & 0xffffu; v1 = sw[qd] >> 16; }
+            else { const uint32_t h = (sw[qd >> 1] >> (16 * (qd & 1))) & 0xffffu; v0 = h & 0xffu; v1 = h >> 8; }
+            // later writes win, exactly like the reference's scatter_ with duplicate indices
+            // cannot happen here: i0 != i1 for every code the encoder emits
+            if constexpr (ES == 2) {
+                uint32_t lo = 0, hi = 0;  // elements 0,1 | 2,3 of the quad
+                auto put = [&](uint32_t idx, uint32_t v) {
+                    if (idx == 0) lo = (lo & 0xffff0000u) | v; else if (idx == 1) lo = (lo & 0xffffu) | (v << 16);
+                    else if (idx == 2) hi = (hi & 0xffff0000u) | v; else hi = (hi & 0xffffu) | (v << 16);
+                };
+                put(i0, v0); put(i1, v1);
+                ow[2 * qd] = lo; ow[2 * qd + 1] = hi;
+            } else {
+                uint32_t q4 = 0;
+                q4 = (q4 & ~(0xffu << (8 * i0))) | (v0 << (8 * i0));
+                q4 = (q4 & ~(0xffu << (8 * i1))) | (v1 << (8 * i1));
+                ow[qd] = q4;
+            }
+        }
+        u32x4* o = reinterpret_cast<u32x4*>(static_cast<uint8_t*>(dense) + (r * 2 * k + mc * 4 * Q) * ES);
+        o[0] = u32x4{ow[0], ow[1], ow[2], ow[3]};
+        o[1] = u32x4{ow[4], ow[5], ow[6], ow[7]};
+    }
+}
+
+// entry `within` of the marlin-24 weight permutation (permutations_24.py:20-45), computed
+// arithmetically instead of from a 1024-entry table
+__host__ __device__ __forceinline__ int marlin24_perm_entry(int within, int bits) {
+    const int ilen = bits == 4 ? 8 : 4;
+    const int grp = within / ilen, jj = within % ilen;
+    const int src_in_grp = bits == 4 ? ((jj < 4) ? 2 * jj : 2 * (jj - 4) + 1) : ((jj == 0) ? 0 : (jj == 1 ? 2 : (jj == 2 ? 1 : 3)));
+    const int idx = grp * ilen + src_in_grp;  // index into the un-interleaved list
+    // list layout: for i in 0..31: for j in 0..3: for q in 0..7: perm1_i[q] + j
+    const int i = idx / 32, rem = idx % 32, j = rem / 8, q = rem % 8;
+    const int col = i / 4, col_o = col / 2, block = q / 4, t = q % 4;
+    const int row = (t == 0) ? 2 * (i % 4) : (t == 1) ? 2 * (i % 4) + 1 : (t == 2) ? 2 * (i % 4 + 4) : 2 * (i % 4 + 4) + 1;
+    return 16 * row + col_o * 256 + 8 * (col % 2) + 4 * block + j;
+}
+
+__device__ __forceinline__ int load_code(const void* q, int dt, int64_t i, int add) {
+    switch (dt) {
+        case CT_I32: return static_cast<const int32_t*>(q)[i] + add;
+        case CT_I8: return (int)static_cast<const int8_t*>(q)[i] + add;
+        case CT_F16: return (int)f16_bits_to_f(static_cast<const uint16_t*>(q)[i]) + add;
+        case CT_BF16: return (int)bf16_bits_to_f(static_cast<const uint16_t*>(q)[i]) + add;
+        case CT_F32: return (int)static_cast<const float*>(q)[i] + add;
+    }
+    return 0;
+}
+
+// one lane per packed word.  q holds the codes either as (size_k, size_n) [transposed == 0]
+// or as the un-transposed compressed matrix (size_n, size_k) [transposed == 1]
+__global__ __launch_bounds__(kBlock) void marlin24_pack_kernel(const void* __restrict__ q, int dt, int transposed, int add, int64_t size_k,
+                                                               int64_t size_n, int bits, int32_t* __restrict__ packed) {
+    const int pf = 32 / bits;
+    const int64_t trow = size_n * 16;
+    const int64_t wpr = trow / pf;
+    const int64_t total = (size_k / 16) * wpr;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t kt = i / wpr, j = i - kt * wpr;
+        uint32_t w = 0;
+        for (int e = 0; e < pf; ++e) {
+            const int64_t pos = j * pf + e;
+            const int64_t chunk = pos >> 10;
+            const int within = (int)(pos & 1023);
+            const int64_t src = (chunk << 10) + marlin24_perm_entry(within, bits);
+            const int64_t nt = src >> 8;
+            const int rem = (int)(src & 255);
+            const int64_t kk = kt * 16 + (rem >> 4), nn = nt * 16 + (rem & 15);
+            const int64_t idx = transposed ? (nn * size_k + kk) : (kk * size_n + nn);
+            w |= (uint32_t)load_code(q, dt, idx, add) << (bits * e);
+        }
+        packed[i] = (int32_t)w;
+    }
+}
+
+// marlin-24 scale packing: scales (size_n, groups) -> transpose -> reshape(-1, 64)[:, perm]
+// -> (groups, size_n).  perm: group table or identity ("single", channel-wise)
+__global__ __launch_bounds__(kBlock) void marlin24_pack_scales_kernel(const uint16_t* __restrict__ scale, int64_t size_n, int64_t groups, int single,
+                                                                      uint16_t* __restrict__ out) {
+    const int64_t total = size_n * groups;
+    for (int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x; f < total; f += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = f >> 6;
+        const int j = (int)(f & 63);
+        const int tbl[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+        const int pj = single ? j : (8 * (j >> 3) + tbl[j & 7]);
+        const int64_t src = (i << 6) + pj;  // flat index into the transposed (groups, size_n) matrix
+        const int64_t g = src / size_n, n = src - g * size_n;
+        out[f] = scale[n * groups + g];
+    }
+}
+
+static unsigned grid_1d(int64_t items) {
+    int64_t g = cdiv64(items, kBlock);
+    int64_t cap = (int64_t)kCUs * 32;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace ct
+
+using namespace ct;
+
+extern "C" {
+
+int ct_cutlass24_from_dense(const void* dense, int dt, int64_t m, int64_t k, void* sparse, void* meta, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_F16 || dt == CT_BF16 || dt == CT_I8, "Invalid datatype code %d of dense matrix", dt);
+    const int mi = dt == CT_I8 ? 4 : 2, Q = mi * 2;
+    CT_REQUIRE(m >= 0 && k >= 0, "negative shape");
+    CT_REQUIRE(m % 64 == 0, "Number of rows of dense matrix %lld must be divisible by 64", (long long)m);
+    CT_REQUIRE(k % (4 * Q) == 0, "Number of columns of dense matrix %lld must be divisible by %d", (long long)k, 4 * Q);
+    CT_REQUIRE(aligned16(dense) && aligned16(sparse), "dense/sparse buffers must be 16-byte aligned");
+    if (m == 0 || k == 0) return CT_OK;
+    const int64_t total = m * (k / (4 * Q));
+    if (dt == CT_I8) hipLaunchKernelGGL((cutlass24_from_dense_kernel<1>), dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), dense, false, m, k, sparse, meta);
+    else hipLaunchKernelGGL((cutlass24_from_dense_kernel<2>), dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), dense, true, m, k, sparse, meta);
+    CT_LAUNCH_CHECK("ct_cutlass24_from_dense");
+}
+
+int ct_cutlass24_to_dense(const void* sparse, int dt, const void* meta, int meta_itemsize, int64_t m, int64_t k, void* dense, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_F16 || dt == CT_BF16 || dt == CT_I8, "Invalid datatype code %d of sparse matrix", dt);
+    const int mi = dt == CT_I8 ? 4 : 2, Q = mi * 2;
+    CT_REQUIRE(meta_itemsize == mi, "Invalid datatype of meta matrix (itemsize %d, expected %d)", meta_itemsize, mi);
+    CT_REQUIRE(m >= 0 && k >= 0 && m % 64 == 0 && (2 * k) % (4 * Q) == 0, "bad sparse shape (%lld, %lld)", (long long)m, (long long)k);
+    CT_REQUIRE(aligned16(dense) && aligned16(sparse), "dense/sparse buffers must be 16-byte aligned");
+    if (m == 0 || k == 0) return CT_OK;
+    const int64_t total = m * (2 * k / (4 * Q));
+    if (dt == CT_I8) hipLaunchKernelGGL((cutlass24_to_dense_kernel<1>), dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), sparse, meta, m, k, dense);
+    else hipLaunchKernelGGL((cutlass24_to_dense_kernel<2>), dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), sparse, meta, m, k, dense);
+    CT_LAUNCH_CHECK("ct_cutlass24_to_dense");
+}
+
+int ct_marlin24_pack_weights(const void* q, int dt, int transposed, int add_offset, int64_t size_k, int64_t size_n, int bits, int32_t* packed,
+                             ct_stream_t stream) {
+    CT_REQUIRE(bits == 4 || bits == 8, "num_bits must be 4 or 8, got %d", bits);
+    CT_REQUIRE(dt == CT_I32 || dt == CT_I8 || is_float_dt(dt), "unsupported code dtype %d", dt);
+    CT_REQUIRE(size_k >= 0 && size_n >= 0 && size_k % 16 == 0 && size_n % 64 == 0, "marlin-24 needs size_k %% 16 == 0 and size_n %% 64 == 0, got (%lld, %lld)",
+               (long long)size_k, (long long)size_n);
+    if (size_k == 0 || size_n == 0) return CT_OK;
+    const int64_t total = (size_k / 16) * (size_n * 16 * bits / 32);
+    hipLaunchKernelGGL(marlin24_pack_kernel, dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), q, dt, transposed, add_offset ? (1 << (bits - 1)) : 0,
+                       size_k, size_n, bits, packed);
+    CT_LAUNCH_CHECK("ct_marlin24_pack_weights");
+}
+
+int ct_marlin24_pack_scales(const void* scale, int dt, int64_t size_n, int64_t groups, int single, void* out, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_F16 || dt == CT_BF16, "marlin-24 scales must be 16-bit floats, got dtype %d", dt);
+    CT_REQUIRE(size_n >= 0 && groups >= 0 && (size_n * groups) % 64 == 0, "scale count must be a multiple of 64");
+    if (size_n == 0 || groups == 0) return CT_OK;
+    hipLaunchKernelGGL(marlin24_pack_scales_kernel, dim3(grid_1d(size_n * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale), size_n,
+                       groups, single, static_cast<uint16_t*>(out));
+    CT_LAUNCH_CHECK("ct_marlin24_pack_scales");
+}
+
+}  // extern "C"

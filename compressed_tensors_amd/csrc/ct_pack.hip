@@ -1,0 +1,220 @@
+// ct_pack.hip — unfused pack_to_int32 / unpack_from_int32 (reference
+// compressors/pack_quantized/helpers.py:20-180) for callers that hold int8 codes, and the
+// row-wise (packed_dim=0) variants used for zero points (compressors/pack_quantized/base.py:107-110,
+// 147-153).
+//
+// Layout: element i of a row occupies bits [i*B, i*B+B) of the row's little-endian bitstream;
+// 32 elements <-> B int32 words.  One 32-element group per lane: all bit positions are
+// compile-time constants after unrolling, every word is written exactly once, no atomics.
+#include "ct_common.h"
+
+namespace ct {
+
+// The reference accumulates with scatter_add_ on int32 and never masks the biased code, so
+// out-of-range int8 input yields the wrapping SUM of (u << off) plus the arithmetic-shifted
+// spill; in-range codes make the adds ORs of disjoint bits.  Adds are used here too, so the
+// result is bit-identical for any int8 input.
+template <int BITS>
+__device__ __forceinline__ void pack_insert(uint32_t (&words)[BITS + 1], int idx /*0..31, constant*/, int q) {
+    const int u = q + (1 << (BITS - 1));
+    const int pos = idx * BITS;
+    const int w = pos >> 5, sh = pos & 31;
+    words[w] += (uint32_t)u << sh;
+    if (sh + BITS > 32) words[w + 1] += (uint32_t)(u >> (32 - sh));
+}
+
+template <int BITS>
+__device__ __forceinline__ int unpack_extract(const uint32_t (&words)[BITS + 1], int idx) {
+    const int pos = idx * BITS;
+    const int w = pos >> 5, sh = pos & 31;
+    uint32_t code = words[w] >> sh;
+    if (sh + BITS > 32) code |= words[w + 1] << (32 - sh);
+    return (int)(code & ((1u << BITS) - 1u)) - (1 << (BITS - 1));
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void pack_rows_kernel(const int8_t* __restrict__ q, int64_t rows, int64_t cols,
+                                                           int32_t* __restrict__ out, int64_t out_stride,
+                                                           int64_t packed_cols, int vec) {
+    const int64_t gpr = (cols + 31) >> 5;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int8_t* qr = q + row * cols;
+        for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < gpr; g += (int64_t)gridDim.x * kBlock) {
+            uint32_t words[BITS + 1];
+#pragma unroll
+            for (int j = 0; j <= BITS; ++j) words[j] = 0;
+            const int64_t c0 = g << 5;
+            if (vec && c0 + 32 <= cols) {
+                const u32x4* p = reinterpret_cast<const u32x4*>(qr + c0);
+                u32x4 a = p[0], b = p[1];
+                const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 32; ++i) pack_insert<BITS>(words, i, (int)(int8_t)(ws[i >> 2] >> (8 * (i & 3))));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (c0 + i < cols) pack_insert<BITS>(words, i, (int)qr[c0 + i]);
+            }
+            int32_t* o = out + row * out_stride + g * BITS;
+#pragma unroll
+            for (int j = 0; j < BITS; ++j)
+                if (g * BITS + j < packed_cols) o[j] = (int32_t)words[j];
+        }
+    }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void unpack_rows_kernel(const int32_t* __restrict__ p, int64_t rows, int64_t words_per_row,
+                                                             int64_t p_stride, int64_t cols, int8_t* __restrict__ out,
+                                                             int vec) {
+    const int64_t gpr = (cols + 31) >> 5;
+    for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+        const int32_t* pr = p + row * p_stride;
+        int8_t* orow = out + row * cols;
+        for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < gpr; g += (int64_t)gridDim.x * kBlock) {
+            uint32_t words[BITS + 1];
+#pragma unroll
+            for (int j = 0; j < BITS; ++j) words[j] = (g * BITS + j < words_per_row) ? (uint32_t)pr[g * BITS + j] : 0u;
+            words[BITS] = 0;
+            const int64_t c0 = g << 5;
+            if (vec && c0 + 32 <= cols) {
+                uint32_t ws[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ws[j] = 0;
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    ws[i >> 2] |= ((uint32_t)unpack_extract<BITS>(words, i) & 0xffu) << (8 * (i & 3));
+                u32x4* o = reinterpret_cast<u32x4*>(orow + c0);
+                o[0] = u32x4{ws[0], ws[1], ws[2], ws[3]};
+                o[1] = u32x4{ws[4], ws[5], ws[6], ws[7]};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (c0 + i < cols) orow[c0 + i] = (int8_t)unpack_extract<BITS>(words, i);
+            }
+        }
+    }
+}
+
+// packed along rows: lane (g, c) packs rows [32g, 32g+32) of column c; lanes are consecutive
+// in c so every access is coalesced across the wave.
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void pack_dim0_kernel(const int8_t* __restrict__ q, int64_t rows, int64_t cols,
+                                                           int32_t* __restrict__ out, int64_t packed_rows) {
+    const int64_t groups = (rows + 31) >> 5;
+    for (int64_t g = blockIdx.y; g < groups; g += gridDim.y)
+        for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < cols; c += (int64_t)gridDim.x * kBlock) {
+            uint32_t words[BITS + 1];
+#pragma unroll
+            for (int j = 0; j <= BITS; ++j) words[j] = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int64_t r = (g << 5) + i;
+                if (r < rows) pack_insert<BITS>(words, i, (int)q[r * cols + c]);
+            }
+#pragma unroll
+            for (int j = 0; j < BITS; ++j)
+                if (g * BITS + j < packed_rows) out[(g * BITS + j) * cols + c] = (int32_t)words[j];
+        }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kBlock) void unpack_dim0_kernel(const int32_t* __restrict__ p, int64_t words_rows,
+                                                             int64_t cols, int64_t rows, int8_t* __restrict__ out) {
+    const int64_t groups = (rows + 31) >> 5;
+    for (int64_t g = blockIdx.y; g < groups; g += gridDim.y)
+        for (int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x; c < cols; c += (int64_t)gridDim.x * kBlock) {
+            uint32_t words[BITS + 1];
+#pragma unroll
+            for (int j = 0; j < BITS; ++j)
+                words[j] = (g * BITS + j < words_rows) ? (uint32_t)p[(g * BITS + j) * cols + c] : 0u;
+            words[BITS] = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int64_t r = (g << 5) + i;
+                if (r < rows) out[r * cols + c] = (int8_t)unpack_extract<BITS>(words, i);
+            }
+        }
+}
+
+static dim3 grid_rows(int64_t rows, int64_t items_per_row) {
+    int64_t gx = cdiv64(items_per_row, kBlock);
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
+    int64_t gy = rows < 1 ? 1 : rows;
+    int64_t cap = (8 * kCUs * 4) / gx;
+    if (cap < 1) cap = 1;
+    if (gy > cap) gy = cap;
+    if (gy > 65535) gy = 65535;
+    return dim3((unsigned)gx, (unsigned)gy, 1);
+}
+
+#define CT_BITS_SWITCH(bits, ...)                            \
+    switch (bits) {                                          \
+        case 1: { constexpr int B = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int B = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int B = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int B = 4; __VA_ARGS__; } break; \
+        case 5: { constexpr int B = 5; __VA_ARGS__; } break; \
+        case 6: { constexpr int B = 6; __VA_ARGS__; } break; \
+        case 7: { constexpr int B = 7; __VA_ARGS__; } break; \
+        case 8: { constexpr int B = 8; __VA_ARGS__; } break; \
+    }
+
+}  // namespace ct
+
+using namespace ct;
+
+extern "C" {
+
+int ct_pack_int32(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t* out, int64_t out_row_stride,
+                  ct_stream_t stream) {
+    CT_REQUIRE(bits >= 1 && bits <= 8, "Packing is only supported for num_bits in [1, 8], got %d", bits);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    const int64_t packed_cols = cdiv64(cols * bits, 32);
+    CT_REQUIRE(out_row_stride >= packed_cols, "output row stride %lld < %lld packed words", (long long)out_row_stride,
+               (long long)packed_cols);
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int vec = (cols % 16 == 0) && aligned16(q);
+    dim3 grid = grid_rows(rows, cdiv64(cols, 32));
+    CT_BITS_SWITCH(bits, hipLaunchKernelGGL((pack_rows_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), q, rows, cols, out,
+                                            out_row_stride, packed_cols, vec));
+    CT_LAUNCH_CHECK("ct_pack_int32");
+}
+
+int ct_unpack_int32(const int32_t* p, int64_t rows, int64_t words, int64_t p_row_stride, int64_t cols, int bits,
+                    int8_t* out, ct_stream_t stream) {
+    CT_REQUIRE(bits >= 1 && bits <= 8, "Unpacking is only supported for num_bits in [1, 8], got %d", bits);
+    CT_REQUIRE(rows >= 0 && cols >= 0 && words >= 0, "negative shape");
+    CT_REQUIRE(p_row_stride >= words, "packed row stride smaller than the row");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int vec = (cols % 16 == 0) && aligned16(out);
+    dim3 grid = grid_rows(rows, cdiv64(cols, 32));
+    CT_BITS_SWITCH(bits, hipLaunchKernelGGL((unpack_rows_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), p, rows, words,
+                                            p_row_stride, cols, out, vec));
+    CT_LAUNCH_CHECK("ct_unpack_int32");
+}
+
+int ct_pack_int32_dim0(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t* out, ct_stream_t stream) {
+    CT_REQUIRE(bits >= 1 && bits <= 8, "Packing is only supported for num_bits in [1, 8], got %d", bits);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int64_t packed_rows = cdiv64(rows * bits, 32);
+    dim3 grid = grid_rows(cdiv64(rows, 32), cols);
+    CT_BITS_SWITCH(bits, hipLaunchKernelGGL((pack_dim0_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), q, rows, cols, out,
+                                            packed_rows));
+    CT_LAUNCH_CHECK("ct_pack_int32_dim0");
+}
+
+int ct_unpack_int32_dim0(const int32_t* p, int64_t words, int64_t cols, int64_t rows, int bits, int8_t* out,
+                         ct_stream_t stream) {
+    CT_REQUIRE(bits >= 1 && bits <= 8, "Unpacking is only supported for num_bits in [1, 8], got %d", bits);
+    CT_REQUIRE(rows >= 0 && cols >= 0 && words >= 0, "negative shape");
+    if (rows == 0 || cols == 0) return CT_OK;
+    dim3 grid = grid_rows(cdiv64(rows, 32), cols);
+    CT_BITS_SWITCH(bits, hipLaunchKernelGGL((unpack_dim0_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), p, words, cols, rows,
+                                            out));
+    CT_LAUNCH_CHECK("ct_unpack_int32_dim0");
+}
+
+}  // extern "C"

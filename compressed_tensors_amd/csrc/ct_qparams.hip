@@ -1,0 +1,163 @@
+// ct_qparams.hip — min/max observer + calculate_qparams for weight groups.
+//
+// Reference: quantization/utils/helpers.py:50-137 applied to torch.aminmax over each group of
+// `cdiv` consecutive columns of a row (group / channel strategies; a tensor-wide range is the
+// same call on the tensor viewed as one row).  Every arithmetic step is rounded to the weight
+// dtype D exactly like the eager op sequence:
+//   mn = min(mn, 0); mx = max(mx, 0)
+//   symmetric : scale = rnd_D(max(|mn|, |mx|) / (range / 2)); zp = 0
+//   asymmetric: scale = rnd_D(rnd_D(mx - mn) / range); zp = clamp(rnd_D(qmin - rnd_D(mn / scale)), qmin, qmax)
+//   scale == 0 -> eps(D); zp -> clamp to int8, round half-even, cast
+// One streaming read of the weight: 16-byte loads, one 8-element unit per lane, groups reduced
+// across lanes with wave shuffles (a 128-wide group is 16 lanes).
+#include "ct_common.h"
+
+namespace ct {
+
+struct MinMax {
+    float mn, mx;
+    int nan;
+};
+
+__device__ __forceinline__ MinMax mm_merge(MinMax a, MinMax b) {
+    MinMax r;
+    r.mn = __builtin_fminf(a.mn, b.mn);
+    r.mx = __builtin_fmaxf(a.mx, b.mx);
+    r.nan = a.nan | b.nan;
+    return r;
+}
+
+template <int XDT>
+__device__ __forceinline__ void emit_qparams(MinMax m, int bits, int symmetric, void* scale_out, int8_t* zp_out, int64_t idx) {
+    const float bit_max = (float)((1 << bits) / 2 - 1), bit_min = -(float)((1 << bits) / 2);
+    const float bit_range = bit_max - bit_min;
+    const float eps = XDT == CT_BF16 ? 0.0078125f : (XDT == CT_F16 ? 0.0009765625f : 1.1920928955078125e-07f);
+    float mn = m.mn, mx = m.mx;
+    if (m.nan) {
+        mn = mx = __builtin_nanf("");
+    } else {
+        mn = mn < 0.0f ? mn : 0.0f;
+        mx = mx > 0.0f ? mx : 0.0f;
+    }
+    float s, z;
+    if (symmetric) {
+        const float a = __builtin_fabsf(mn), b = __builtin_fabsf(mx);
+        const float mm = m.nan ? mn : (a > b ? a : b);
+        s = round_to<XDT>(mm / (bit_range / 2.0f));
+        z = 0.0f;
+    } else {
+        s = round_to<XDT>(round_to<XDT>(mx - mn) / bit_range);
+        const float zz = round_to<XDT>(bit_min - round_to<XDT>(mn / s));
+        z = clamp_nan(zz, bit_min, bit_max);
+    }
+    if (s == 0.0f) s = eps;
+    store1<XDT>(scale_out, idx, s);
+    if (zp_out) {
+        float zc = clamp_nan(z, -128.0f, 127.0f);
+        zc = __builtin_rintf(zc);
+        zp_out[idx] = (zc != zc) ? (int8_t)0 : (int8_t)(int)zc;
+    }
+}
+
+// groups of LPG lanes x 8 elements (cdiv = 8 * LPG, LPG a power of two <= 64), cols % cdiv == 0
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void qparams_subwave_kernel(const void* __restrict__ x, int64_t units, int lpg, int bits, int symmetric,
+                                                                 void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
+    // units is a multiple of lpg, and kBlock is a multiple of lpg: groups never straddle waves
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t nloops = (units + stride - 1) / stride;
+    int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int64_t it = 0; it < nloops; ++it, u += stride) {
+        MinMax m;
+        m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+        const bool live = u < units;
+        if (live) {
+            float v[8];
+            load8<XDT>(x, u << 3, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                m.nan |= (v[k] != v[k]);
+                m.mn = __builtin_fminf(m.mn, v[k]);
+                m.mx = __builtin_fmaxf(m.mx, v[k]);
+            }
+        }
+        for (int d = 1; d < lpg; d <<= 1) {
+            MinMax o;
+            o.mn = __shfl_xor(m.mn, d, 64);
+            o.mx = __shfl_xor(m.mx, d, 64);
+            o.nan = __shfl_xor(m.nan, d, 64);
+            m = mm_merge(m, o);
+        }
+        if (live && (threadIdx.x & (lpg - 1)) == 0) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, u / lpg);
+    }
+}
+
+// generic: one wave per group, lanes stride over the group's columns
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void qparams_wave_kernel(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t cdiv, int bits,
+                                                              int symmetric, void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
+    const int64_t ngroups = (cols + cdiv - 1) / cdiv;
+    const int64_t total = rows * ngroups;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t gi = wave0; gi < total; gi += nwaves) {
+        const int64_t r = gi / ngroups, g = gi - r * ngroups;
+        const int64_t c0 = g * cdiv, c1 = (c0 + cdiv < cols) ? c0 + cdiv : cols;
+        MinMax m;
+        m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+        for (int64_t c = c0 + lane; c < c1; c += 64) {
+            const float v = load_as_f<XDT>(x, r * cols + c);
+            m.nan |= (v != v);
+            m.mn = __builtin_fminf(m.mn, v);
+            m.mx = __builtin_fmaxf(m.mx, v);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            MinMax o;
+            o.mn = __shfl_xor(m.mn, d, 64);
+            o.mx = __shfl_xor(m.mx, d, 64);
+            o.nan = __shfl_xor(m.nan, d, 64);
+            m = mm_merge(m, o);
+        }
+        if (lane == 0) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, gi);
+    }
+}
+
+}  // namespace ct
+
+using namespace ct;
+
+extern "C" {
+
+int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits, int symmetric, void* scale_out, int8_t* zp_out,
+                      ct_stream_t stream) {
+    CT_REQUIRE(is_float_dt(xdt), "weight dtype code %d is not a float type", xdt);
+    CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
+    CT_REQUIRE(rows >= 0 && cols >= 0 && cdiv >= 1, "bad shape");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int64_t lpg = cdiv / 8;
+    const bool subwave = (cdiv % 8 == 0) && (cols % cdiv == 0) && lpg >= 1 && lpg <= 64 && log2_exact(lpg) >= 0 && aligned16(x);
+    if (subwave) {
+        const int64_t units = rows * (cols / 8);
+        int64_t g = cdiv64(units, kBlock);
+        if (g > kCUs * 32) g = kCUs * 32;
+        switch (xdt) {
+            case CT_BF16: hipLaunchKernelGGL((qparams_subwave_kernel<CT_BF16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, units, (int)lpg, bits, symmetric, scale_out, zp_out); break;
+            case CT_F16: hipLaunchKernelGGL((qparams_subwave_kernel<CT_F16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, units, (int)lpg, bits, symmetric, scale_out, zp_out); break;
+            default: hipLaunchKernelGGL((qparams_subwave_kernel<CT_F32>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, units, (int)lpg, bits, symmetric, scale_out, zp_out); break;
+        }
+        CT_LAUNCH_CHECK("ct_minmax_qparams[subwave]");
+    }
+    const int64_t total = rows * cdiv64(cols, cdiv);
+    int64_t g = cdiv64(total, kBlock / 64);
+    if (g > kCUs * 32) g = kCUs * 32;
+    switch (xdt) {
+        case CT_BF16: hipLaunchKernelGGL((qparams_wave_kernel<CT_BF16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out); break;
+        case CT_F16: hipLaunchKernelGGL((qparams_wave_kernel<CT_F16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out); break;
+        default: hipLaunchKernelGGL((qparams_wave_kernel<CT_F32>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out); break;
+    }
+    CT_LAUNCH_CHECK("ct_minmax_qparams");
+}
+
+}  // extern "C"

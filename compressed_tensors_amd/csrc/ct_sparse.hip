@@ -1,0 +1,546 @@
+// ct_sparse.hip — sparse-bitmask and sparse-24-bitmask codecs for gfx950.
+//
+// Formats (reference config/base.py:17-18; bit order of utils/helpers.py:306-343 =
+// numpy.packbits(..., bitorder="little")): byte j of a bitmask row, bit k  <=>  x[r, 8j+k] != 0.
+// compress:   values = x[x != 0] (row-major), bitmask, row_offsets = exclusive cumsum of row nnz
+// decompress: out = zeros; out[mask] = values
+//
+// Data movement design: every lane owns one 8-element unit (one bitmask byte, one 16-byte
+// vector of 16-bit elements).  Compaction/expansion goes through an LDS staging buffer per
+// 2048-element chunk so that ALL global traffic is contiguous wide accesses: the dense side is
+// 16 B/lane coalesced, the value side is a contiguous run per chunk copied with aligned 16-byte
+// vectors (scalar head/tail), and only LDS sees the 2-byte scattered accesses.
+#include "ct_common.h"
+
+namespace ct {
+
+constexpr int kChunk = kBlock * 8;  // elements per block iteration
+
+// ------------------------------------------------------------------------- element helpers
+template <int ES> struct ElemT;
+template <> struct ElemT<1> { typedef uint8_t type; };
+template <> struct ElemT<2> { typedef uint16_t type; };
+template <> struct ElemT<4> { typedef uint32_t type; };
+
+// non-zero test on raw bits: floats ignore the sign bit (-0.0 == 0), NaN is non-zero
+template <int ES>
+__device__ __forceinline__ bool nz(typename ElemT<ES>::type bits, bool is_float) {
+    if constexpr (ES == 1) return bits != 0;
+    else if constexpr (ES == 2) return is_float ? (bits & 0x7fffu) != 0 : bits != 0;
+    else return is_float ? (bits & 0x7fffffffu) != 0 : bits != 0;
+}
+
+// load 8 consecutive elements (vector when `vec`, else scalar with bound n)
+template <int ES>
+__device__ __forceinline__ void load_unit(const void* base, int64_t i0, int n, bool vec,
+                                          typename ElemT<ES>::type (&e)[8]) {
+    typedef typename ElemT<ES>::type T;
+    const T* p = static_cast<const T*>(base) + i0;
+    if (vec && n == 8) {
+        if constexpr (ES == 2) {
+            u32x4 w = *reinterpret_cast<const u32x4*>(p);
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { e[2 * j] = (T)(ws[j] & 0xffffu); e[2 * j + 1] = (T)(ws[j] >> 16); }
+        } else if constexpr (ES == 4) {
+            u32x4 a = reinterpret_cast<const u32x4*>(p)[0], b = reinterpret_cast<const u32x4*>(p)[1];
+            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+        } else {
+            u32x2 w = *reinterpret_cast<const u32x2*>(p);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { e[k] = (T)(w.x >> (8 * k)); e[4 + k] = (T)(w.y >> (8 * k)); }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = k < n ? p[k] : (T)0;
+    }
+}
+
+template <int ES>
+__device__ __forceinline__ void store_unit_bits(void* base, int64_t i0, int n, bool vec,
+                                                const typename ElemT<ES>::type (&e)[8]) {
+    typedef typename ElemT<ES>::type T;
+    T* p = static_cast<T*>(base) + i0;
+    if (vec && n == 8) {
+        if constexpr (ES == 2) {
+            *reinterpret_cast<u32x4*>(p) = u32x4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                                                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+        } else if constexpr (ES == 4) {
+            reinterpret_cast<u32x4*>(p)[0] = u32x4{e[0], e[1], e[2], e[3]};
+            reinterpret_cast<u32x4*>(p)[1] = u32x4{e[4], e[5], e[6], e[7]};
+        } else {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo |= (uint32_t)e[k] << (8 * k); hi |= (uint32_t)e[4 + k] << (8 * k); }
+            *reinterpret_cast<u32x2*>(p) = u32x2{lo, hi};
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < n) p[k] = e[k];
+    }
+}
+
+// ------------------------------------------------------------------------- block scan
+// exclusive prefix sum of one int per lane across the 256-lane block; returns the prefix and
+// writes the block total to *total.  wave scan by DPP-style shuffles, 4 wave totals via LDS.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /*[4]*/, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) {
+        int t = s_wave[w];
+        if (w < wave) wbase += t;
+        tot += t;
+    }
+    *total = tot;
+    __syncthreads();  // s_wave may be reused by the caller's next iteration
+    return wbase + inc - v;
+}
+
+// ------------------------------------------------------------------------- pack / unpack bitmasks
+__global__ __launch_bounds__(kBlock) void pack_bitmasks_kernel(const uint8_t* __restrict__ mask, int64_t rows, int64_t cols,
+                                                               uint8_t* __restrict__ out) {
+    const int64_t bcols = (cols + 7) >> 3;
+    const int64_t total = rows * bcols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / bcols, j = i - r * bcols;
+        const uint8_t* m = mask + r * cols + (j << 3);
+        const int n = (int)((cols - (j << 3)) < 8 ? (cols - (j << 3)) : 8);
+        uint32_t b = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < n && m[k]) b |= 1u << k;
+        out[i] = (uint8_t)b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void unpack_bitmasks_kernel(const uint8_t* __restrict__ packed, int64_t rows, int64_t cols,
+                                                                 uint8_t* __restrict__ mask) {
+    const int64_t bcols = (cols + 7) >> 3;
+    const int64_t total = rows * bcols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / bcols, j = i - r * bcols;
+        const uint32_t b = packed[i];
+        uint8_t* m = mask + r * cols + (j << 3);
+        const int n = (int)((cols - (j << 3)) < 8 ? (cols - (j << 3)) : 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k < n) m[k] = (uint8_t)((b >> k) & 1u);
+    }
+}
+
+// ------------------------------------------------------------------------- compress pass 1
+// one workgroup per row (grid-strided): bitmask bytes + row nnz
+template <int ES>
+__global__ __launch_bounds__(kBlock) void bitmask_count_kernel(const void* __restrict__ x, bool is_float, int64_t rows, int64_t cols,
+                                                               uint8_t* __restrict__ bitmask, int64_t* __restrict__ row_counts, int vec) {
+    typedef typename ElemT<ES>::type T;
+    __shared__ int s_wave[kBlock / 64];
+    const int64_t bcols = (cols + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        int cnt = 0;
+        for (int64_t u = threadIdx.x; u < bcols; u += kBlock) {
+            const int64_t c0 = u << 3;
+            const int n = (int)((cols - c0) < 8 ? (cols - c0) : 8);
+            T e[8];
+            load_unit<ES>(x, row * cols + c0, n, vec, e);
+            uint32_t m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= (k < n && nz<ES>(e[k], is_float)) ? (1u << k) : 0u;
+            bitmask[row * bcols + u] = (uint8_t)m;
+            cnt += __popc(m);
+        }
+        // wave reduction, then 4 partials through LDS
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) t += s_wave[w];
+            row_counts[row] = (int64_t)t;
+        }
+        __syncthreads();
+    }
+}
+
+// popcount of each bitmask row (rebuilds row counts from a stored bitmask)
+__global__ __launch_bounds__(kBlock) void bitmask_row_popcount_kernel(const uint8_t* __restrict__ bitmask, int64_t rows, int64_t cols,
+                                                                      int64_t* __restrict__ row_counts) {
+    __shared__ int s_wave[kBlock / 64];
+    const int64_t bcols = (cols + 7) >> 3;
+    const int tail_bits = (int)(cols & 7);
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        int cnt = 0;
+        for (int64_t u = threadIdx.x; u < bcols; u += kBlock) {
+            uint32_t m = bitmask[row * bcols + u];
+            if (tail_bits && u == bcols - 1) m &= (1u << tail_bits) - 1u;
+            cnt += __popc(m);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) t += s_wave[w];
+            row_counts[row] = (int64_t)t;
+        }
+        __syncthreads();
+    }
+}
+
+// single-workgroup exclusive scan of int64 counts (n is the number of rows: small)
+__global__ __launch_bounds__(1024) void exclusive_scan_i64_kernel(const int64_t* __restrict__ counts, int64_t n,
+                                                                  int64_t* __restrict__ offsets, int64_t* __restrict__ total) {
+    __shared__ int64_t s_wave[16];
+    __shared__ int64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n ? counts[i] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int64_t wbase = s_carry, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            int64_t t = s_wave[w];
+            if (w < wave) wbase += t;
+            tot += t;
+        }
+        if (i < n) offsets[i] = wbase + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = s_carry;
+}
+
+// ------------------------------------------------------------------------- compress pass 2
+// one workgroup per row: compact each 2048-element chunk into LDS, then copy the contiguous
+// run to values[] with aligned 16-byte stores
+template <int ES>
+__global__ __launch_bounds__(kBlock) void bitmask_scatter_kernel(const void* __restrict__ x, bool is_float, int64_t rows, int64_t cols,
+                                                                 const int64_t* __restrict__ row_offsets, void* __restrict__ values, int vec) {
+    typedef typename ElemT<ES>::type T;
+    __shared__ __attribute__((aligned(16))) T s_val[kChunk];
+    __shared__ int s_wave[kBlock / 64];
+    T* vout = static_cast<T*>(values);
+    constexpr int VE = 16 / ES;  // elements per 16-byte vector
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        int64_t run = row_offsets[row];
+        for (int64_t cbase = 0; cbase < cols; cbase += kChunk) {
+            const int64_t c0 = cbase + ((int64_t)threadIdx.x << 3);
+            int64_t rem = cols - c0;
+            const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
+            T e[8];
+            uint32_t m = 0;
+            if (n > 0) {
+                load_unit<ES>(x, row * cols + c0, n, vec, e);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m |= (k < n && nz<ES>(e[k], is_float)) ? (1u << k) : 0u;
+            }
+            int total;
+            const int pre = block_exclusive_scan(__popc(m), s_wave, &total);
+            int pos = pre;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (m & (1u << k)) s_val[pos++] = e[k];
+            __syncthreads();
+            // copy s_val[0, total) -> vout[run, run+total): scalar head up to a 16-byte
+            // boundary of the destination, vector body, scalar tail
+            const uintptr_t dst = reinterpret_cast<uintptr_t>(vout + run);
+            int head = (int)(((16 - (dst & 15u)) & 15u) / ES);
+            if (head > total) head = total;
+            // the LDS source of the vector body starts at s_val[head], which is not 16-byte
+            // aligned in general: read it element-wise and assemble (LDS is cheap, HBM is not)
+            const int body_vecs = (total - head) / VE;
+            for (int i = threadIdx.x; i < head; i += kBlock) vout[run + i] = s_val[i];
+            for (int v = threadIdx.x; v < body_vecs; v += kBlock) {
+                const T* s = s_val + head + v * VE;
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (ES == 2) w[j] = (uint32_t)s[2 * j] | ((uint32_t)s[2 * j + 1] << 16);
+                    else if constexpr (ES == 4) w[j] = s[j];
+                    else w[j] = (uint32_t)s[4 * j] | ((uint32_t)s[4 * j + 1] << 8) | ((uint32_t)s[4 * j + 2] << 16) | ((uint32_t)s[4 * j + 3] << 24);
+                }
+                *reinterpret_cast<u32x4*>(vout + run + head + (int64_t)v * VE) = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            for (int i = head + body_vecs * VE + threadIdx.x; i < total; i += kBlock) vout[run + i] = s_val[i];
+            run += total;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- decompress
+// one workgroup per row: stage the chunk's contiguous value run in LDS (aligned 16-byte
+// loads), then every lane expands its bitmask byte into one 16-byte dense store
+template <int ES>
+__global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* __restrict__ values, int64_t values_len,
+                                                                    const uint8_t* __restrict__ bitmask,
+                                                                    const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz,
+                                                                    int64_t rows, int64_t cols, void* __restrict__ out, int vec_out,
+                                                                    int vec_in) {
+    typedef typename ElemT<ES>::type T;
+    constexpr int VE = 16 / ES;
+    __shared__ __attribute__((aligned(16))) T s_val[kChunk + 2 * VE];
+    __shared__ int s_wave[kBlock / 64];
+    const T* vin = static_cast<const T*>(values);
+    const int64_t bcols = (cols + 7) >> 3;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
+        for (int64_t cbase = 0; cbase < cols; cbase += kChunk) {
+            const int64_t c0 = cbase + ((int64_t)threadIdx.x << 3);
+            int64_t rem = cols - c0;
+            const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
+            uint32_t m = 0;
+            if (n > 0) {
+                m = bitmask[row * bcols + (c0 >> 3)];
+                if (n < 8) m &= (1u << n) - 1u;
+            }
+            int total;
+            const int pre = block_exclusive_scan(__popc(m), s_wave, &total);
+            // stage vin[run, run+total) at s_val[shift ...] where shift = run's offset inside
+            // its 16-byte vector, so that vector loads are aligned on the global side
+            const uintptr_t src = reinterpret_cast<uintptr_t>(vin + run);
+            const int shift = vec_in ? (int)((src & 15u) / ES) : 0;
+            if (vec_in) {
+                const int nvec = (shift + total + VE - 1) / VE;
+                const int64_t e0 = run - shift;  // element index of the first staged vector (>= 0)
+                const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
+                // the first/last vectors may straddle the run: the head stays inside the buffer
+                // because its base is 16-byte aligned; a tail vector that would cross the end of
+                // the buffer is read element-wise instead
+                for (int v = threadIdx.x; v < nvec; v += kBlock) {
+                    if (e0 + (int64_t)(v + 1) * VE <= values_len) {
+                        reinterpret_cast<u32x4*>(s_val)[v] = g[v];
+                    } else {
+                        for (int j = 0; j < VE; ++j) {
+                            const int64_t gi = e0 + (int64_t)v * VE + j;
+                            s_val[v * VE + j] = gi < values_len ? vin[gi] : (T)0;
+                        }
+                    }
+                }
+            } else {
+                for (int i = threadIdx.x; i < total; i += kBlock) s_val[i] = vin[run + i];
+            }
+            __syncthreads();
+            if (n > 0) {
+                T e[8];
+                int pos = shift + pre;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool on = (m >> k) & 1u;
+                    e[k] = on ? s_val[pos] : (T)0;
+                    pos += on ? 1 : 0;
+                }
+                store_unit_bits<ES>(out, row * cols + c0, n, vec_out, e);
+            }
+            run += total;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- 2:4
+// magnitude key: |x| as an orderable integer; NaN sorts largest (as torch.topk does)
+template <int ES>
+__device__ __forceinline__ uint32_t abs_key(typename ElemT<ES>::type bits, bool is_float) {
+    if constexpr (ES == 2) return is_float ? (bits & 0x7fffu) : (uint32_t)((int16_t)bits < 0 ? -(int)(int16_t)bits : (int)(int16_t)bits);
+    else if constexpr (ES == 4) return is_float ? (bits & 0x7fffffffu) : (uint32_t)((int32_t)bits < 0 ? 0u - bits : bits);
+    else { int v = (int8_t)bits; return (uint32_t)(v < 0 ? -v : v); }
+}
+
+// 4 keys -> 4-bit mask with exactly two bits: the two largest, ties to the lower index
+__device__ __forceinline__ uint32_t top2_mask(const uint32_t (&k)[4]) {
+    int a = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) if (k[j] > k[a]) a = j;
+    int b = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j == a) continue;
+        if (b < 0 || k[j] > k[b]) b = j;
+    }
+    return (1u << a) | (1u << b);
+}
+
+template <int ES>
+__global__ __launch_bounds__(kBlock) void sparse24_compress_kernel(const void* __restrict__ x, bool is_float, int64_t units,
+                                                                   void* __restrict__ values, uint8_t* __restrict__ bitmask,
+                                                                   uint8_t* __restrict__ bytemask, int vec) {
+    typedef typename ElemT<ES>::type T;
+    for (int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x; u < units; u += (int64_t)gridDim.x * kBlock) {
+        T e[8];
+        load_unit<ES>(x, u << 3, 8, vec, e);
+        uint32_t m = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t k4[4] = {abs_key<ES>(e[4 * h], is_float), abs_key<ES>(e[4 * h + 1], is_float),
+                                    abs_key<ES>(e[4 * h + 2], is_float), abs_key<ES>(e[4 * h + 3], is_float)};
+            m |= top2_mask(k4) << (4 * h);
+        }
+        if (bitmask) bitmask[u] = (uint8_t)m;
+        if (bytemask) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bytemask[(u << 3) + k] = (uint8_t)((m >> k) & 1u);
+        }
+        if (values) {
+            T o[4];
+            int pos = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((m >> k) & 1u) o[pos++] = e[k];
+            T* v = static_cast<T*>(values) + (u << 2);
+            if constexpr (ES == 2) {
+                *reinterpret_cast<u32x2*>(v) = u32x2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+            } else if constexpr (ES == 4) {
+                *reinterpret_cast<u32x4*>(v) = u32x4{o[0], o[1], o[2], o[3]};
+            } else {
+                *reinterpret_cast<uint32_t*>(v) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+            }
+        }
+    }
+}
+
+static bool float_kind(int dt) { return is_float_dt(dt); }
+
+static unsigned grid_1d(int64_t items) {
+    int64_t g = cdiv64(items, kBlock);
+    int64_t cap = (int64_t)kCUs * 32;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+static unsigned grid_rows_1d(int64_t rows) {
+    int64_t g = rows;
+    int64_t cap = (int64_t)kCUs * 32;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+#define CT_ES_SWITCH(es, ...)                                 \
+    switch (es) {                                             \
+        case 1: { constexpr int ES = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int ES = 2; __VA_ARGS__; } break; \
+        case 4: { constexpr int ES = 4; __VA_ARGS__; } break; \
+    }
+
+}  // namespace ct
+
+using namespace ct;
+
+extern "C" {
+
+int ct_pack_bitmasks(const uint8_t* mask, int64_t rows, int64_t cols, uint8_t* out, ct_stream_t stream) {
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0 || cols == 0) return CT_OK;
+    hipLaunchKernelGGL(pack_bitmasks_kernel, dim3(grid_1d(rows * cdiv64(cols, 8))), dim3(kBlock), 0, as_stream(stream), mask, rows, cols, out);
+    CT_LAUNCH_CHECK("ct_pack_bitmasks");
+}
+
+int ct_unpack_bitmasks(const uint8_t* packed, int64_t rows, int64_t cols, uint8_t* mask, ct_stream_t stream) {
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0 || cols == 0) return CT_OK;
+    hipLaunchKernelGGL(unpack_bitmasks_kernel, dim3(grid_1d(rows * cdiv64(cols, 8))), dim3(kBlock), 0, as_stream(stream), packed, rows, cols, mask);
+    CT_LAUNCH_CHECK("ct_unpack_bitmasks");
+}
+
+int ct_bitmask_count(const void* x, int dt, int64_t rows, int64_t cols, uint8_t* bitmask, int64_t* row_counts, ct_stream_t stream) {
+    const int es = dt_size(dt);
+    CT_REQUIRE(es == 1 || es == 2 || es == 4, "unsupported element dtype %d", dt);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0) return CT_OK;
+    const int vec = (cols % 8 == 0) && aligned16(x);
+    CT_ES_SWITCH(es, hipLaunchKernelGGL((bitmask_count_kernel<ES>), dim3(grid_rows_1d(rows)), dim3(kBlock), 0, as_stream(stream), x,
+                                        float_kind(dt), rows, cols, bitmask, row_counts, vec));
+    CT_LAUNCH_CHECK("ct_bitmask_count");
+}
+
+int ct_bitmask_row_popcount(const uint8_t* bitmask, int64_t rows, int64_t cols, int64_t* row_counts, ct_stream_t stream) {
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0) return CT_OK;
+    hipLaunchKernelGGL(bitmask_row_popcount_kernel, dim3(grid_rows_1d(rows)), dim3(kBlock), 0, as_stream(stream), bitmask, rows, cols, row_counts);
+    CT_LAUNCH_CHECK("ct_bitmask_row_popcount");
+}
+
+int ct_exclusive_scan_i64(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total, ct_stream_t stream) {
+    CT_REQUIRE(n >= 0, "negative length");
+    hipLaunchKernelGGL(exclusive_scan_i64_kernel, dim3(1), dim3(1024), 0, as_stream(stream), counts, n, offsets, total);
+    CT_LAUNCH_CHECK("ct_exclusive_scan_i64");
+}
+
+int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const int64_t* row_offsets, void* values, ct_stream_t stream) {
+    const int es = dt_size(dt);
+    CT_REQUIRE(es == 1 || es == 2 || es == 4, "unsupported element dtype %d", dt);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int vec = (cols % 8 == 0) && aligned16(x);
+    CT_ES_SWITCH(es, hipLaunchKernelGGL((bitmask_scatter_kernel<ES>), dim3(grid_rows_1d(rows)), dim3(kBlock), 0, as_stream(stream), x,
+                                        float_kind(dt), rows, cols, row_offsets, values, vec));
+    CT_LAUNCH_CHECK("ct_bitmask_scatter");
+}
+
+int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t* bitmask, const int64_t* row_offsets, int64_t fixed_row_nnz,
+                          int dt, int64_t rows, int64_t cols, void* out, ct_stream_t stream) {
+    const int es = dt_size(dt);
+    CT_REQUIRE(es == 1 || es == 2 || es == 4, "unsupported element dtype %d", dt);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    CT_REQUIRE(row_offsets != nullptr || fixed_row_nnz >= 0, "row_offsets is NULL and fixed_row_nnz < 0");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int vec_out = (cols % 8 == 0) && aligned16(out);
+    CT_REQUIRE(values_len >= 0, "negative values length");
+    // aligned 16-byte loads of the value runs need a 16-byte aligned base; vectors that would
+    // cross values_len are read element-wise in the kernel
+    const int vec_in = aligned16(values);
+    CT_ES_SWITCH(es, hipLaunchKernelGGL((bitmask_decompress_kernel<ES>), dim3(grid_rows_1d(rows)), dim3(kBlock), 0, as_stream(stream), values,
+                                        values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, out, vec_out, vec_in));
+    CT_LAUNCH_CHECK("ct_bitmask_decompress");
+}
+
+int ct_sparse24_compress(const void* x, int dt, int64_t rows, int64_t cols, void* values, uint8_t* bitmask, ct_stream_t stream) {
+    const int es = dt_size(dt);
+    CT_REQUIRE(es == 1 || es == 2 || es == 4, "unsupported element dtype %d", dt);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    CT_REQUIRE(cols % 8 == 0, "2:4 bitmask compression needs the row length to be a multiple of 8, got %lld", (long long)cols);
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int64_t units = rows * (cols / 8);
+    CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
+    const int vec = aligned16(x);
+    CT_ES_SWITCH(es, hipLaunchKernelGGL((sparse24_compress_kernel<ES>), dim3(grid_1d(units)), dim3(kBlock), 0, as_stream(stream), x,
+                                        float_kind(dt), units, values, bitmask, (uint8_t*)nullptr, vec));
+    CT_LAUNCH_CHECK("ct_sparse24_compress");
+}
+
+int ct_sparse24_mask(const void* x, int dt, int64_t numel, uint8_t* mask, ct_stream_t stream) {
+    const int es = dt_size(dt);
+    CT_REQUIRE(es == 1 || es == 2 || es == 4, "unsupported element dtype %d", dt);
+    CT_REQUIRE(numel >= 0 && numel % 8 == 0, "2:4 mask needs a multiple of 8 elements, got %lld", (long long)numel);
+    if (numel == 0) return CT_OK;
+    const int vec = aligned16(x);
+    CT_ES_SWITCH(es, hipLaunchKernelGGL((sparse24_compress_kernel<ES>), dim3(grid_1d(numel / 8)), dim3(kBlock), 0, as_stream(stream), x,
+                                        float_kind(dt), numel / 8, (void*)nullptr, (uint8_t*)nullptr, mask, vec));
+    CT_LAUNCH_CHECK("ct_sparse24_mask");
+}
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+"""Drop the MI355X codecs into a live upstream `compressed_tensors` install.
+
+    import compressed_tensors_amd.install as ct_amd
+    ct_amd.install()
+
+After this, every upstream caller that looks a codec up by its format string
+(`BaseCompressor.get_value_from_registry(...)`: compress_module / decompress_module,
+ModelCompressor, transformers' DecompressExperts, CompressedTensorsDequantizer) receives a
+subclass of the upstream codec whose `compress` / `decompress` run the HIP kernels whenever
+the weight lives on the GPU; anything else (CPU tensors, FP8/FP4 types, meta tensors) is handed
+to the upstream implementation it inherits from.  `_quantize` is additionally registered as an
+`ImplBackend` backend (upstream utils/impl_backend.py:50-79), which is the reference's own
+plug-in point for that function.
+
+The registry is overwritten directly because re-registering a name with a different class
+raises upstream (registry/registry.py:215-223); see SURVEY.md §8b.
+"""
+import torch
+
+from . import codec
+from .quantization.quant_args import enum_value
+
+__all__ = ["install", "uninstall"]
+
+_SAVED = {}
+
+
+def _on_gpu(*tensors) -> bool:
+    return any(t is not None and t.is_cuda for t in tensors)
+
+
+def _int_weights(scheme) -> bool:
+    w = getattr(scheme, "weights", None)
+    return w is not None and enum_value(getattr(w, "type", "int")) == "int" and 1 <= int(w.num_bits) <= 8
+
+
+def install():
+    import compressed_tensors  # the upstream package; ImportError if it is not installed
+    from compressed_tensors.compressors import BaseCompressor
+    from compressed_tensors.registry import registry as up_registry
+    from compressed_tensors.utils.impl_backend import ImplBackend
+
+    from .compressors.naive_quantized import NaiveQuantizationCompressor as _AmdNaive
+    from .compressors.pack_quantized import PackedQuantizationCompressor as _AmdPacked
+
+    table = up_registry._REGISTRY[BaseCompressor]
+
+    def subclass(up_cls, amd_cls, name):
+        class _Hip(up_cls):  # inherits can_compress / compression_param_names / *_module
+            @classmethod
+            def compress(cls, state_dict, scheme):
+                if _int_weights(scheme) and _on_gpu(state_dict.get("weight")):
+                    return amd_cls.compress.__func__(cls, state_dict, scheme)
+                return up_cls.compress.__func__(cls, state_dict, scheme)
+
+            @classmethod
+            def decompress(cls, state_dict, scheme):
+                probe = state_dict.get("weight_packed", state_dict.get("weight"))
+                if _int_weights(scheme) and _on_gpu(probe):
+                    return amd_cls.decompress.__func__(cls, state_dict, scheme)
+                return up_cls.decompress.__func__(cls, state_dict, scheme)
+
+        _Hip.__name__ = up_cls.__name__ + "MI355X"
+        _Hip.__qualname__ = _Hip.__name__
+        return _Hip
+
+    for fmt, amd_cls in (("pack-quantized", _AmdPacked), ("naive-quantized", _AmdNaive), ("int-quantized", _AmdNaive)):
+        up_cls = table[fmt]
+        if fmt not in _SAVED:
+            _SAVED[fmt] = up_cls
+        table[fmt] = subclass(_SAVED[fmt], amd_cls, fmt)
+
+    if "_quantize_mi355x" not in ImplBackend._fn_registry:
+
+        def _req(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
+            return (
+                x.is_cuda and global_scale is None and enum_value(getattr(args, "type", "int")) == "int"
+                and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
+                and dtype in (None, torch.int8, torch.int32, torch.float32, torch.float16, torch.bfloat16)
+                and x.is_contiguous() and _broadcast_layout(x, scale) is not None
+            )
+
+        @ImplBackend.register("_quantize", req=_req, priority=0)
+        def _quantize_mi355x(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
+            layout = _broadcast_layout(x, scale)
+            x2 = x.reshape(-1, x.shape[-1]) if layout["strategy"] != "group" else x.reshape(-1, x.shape[-2] * x.shape[-1])
+            out = codec.quantize_tensor(
+                x2, scale.reshape(layout["scale_shape"]), None if zero_point is None else zero_point.reshape(layout["scale_shape"]),
+                num_bits=int(args.num_bits), strategy=layout["strategy"], group_size=layout.get("group_size"),
+                dtype=dtype if dtype is not None else torch.result_type(x, scale),
+            )
+            return out.reshape(x.shape)
+
+    return compressed_tensors
+
+
+def _broadcast_layout(x, scale):
+    """Recognise the broadcast shapes upstream passes to `_quantize` (forward_helpers.py:154-167):
+    group: x (R, G, gs) with scale (R, G, 1); channel: x (R, C) with scale (R, 1); tensor: scale
+    with one element.  Returns None for anything else (upstream's eager body then runs)."""
+    if scale.numel() == 1 and scale.ndim > 0:
+        return {"strategy": "tensor", "scale_shape": (1,)}
+    if x.ndim == 3 and scale.ndim == 3 and scale.shape == (x.shape[0], x.shape[1], 1):
+        return {"strategy": "group", "group_size": x.shape[2], "scale_shape": (x.shape[0], x.shape[1])}
+    if x.ndim == 2 and scale.ndim == 2 and scale.shape == (x.shape[0], 1):
+        return {"strategy": "channel", "scale_shape": (x.shape[0], 1)}
+    return None
+
+
+def uninstall():
+    if not _SAVED:
+        return
+    from compressed_tensors.compressors import BaseCompressor
+    from compressed_tensors.registry import registry as up_registry
+
+    table = up_registry._REGISTRY[BaseCompressor]
+    for fmt, cls in _SAVED.items():
+        table[fmt] = cls
+    _SAVED.clear()

@@ -1,0 +1,193 @@
+/*
+ * ct_hip.h — C ABI of libct_hip.so: the MI355X (gfx950) implementation of the
+ * compressed-tensors compress/decompress hot path.
+ *
+ * Every entry point takes plain device pointers + sizes + a HIP stream (as void*), launches
+ * asynchronously on that stream, performs no host synchronisation and no allocation, and
+ * returns a ct_status.  ct_last_error() returns a thread-local message for the last
+ * non-OK status.  The functions are re-entrant (no global scratch).
+ *
+ * Each declaration names the reference interface it replaces; paths are relative to
+ * /root/reference/src/compressed_tensors/.  The Python host in compressed_tensors_amd/
+ * binds these with ctypes (compressed_tensors_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Tensors are row-major and contiguous unless a stride parameter says otherwise.
+ */
+#ifndef CT_HIP_H
+#define CT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ct_stream_t; /* hipStream_t */
+
+/* element type codes (shared with the oracle) */
+enum ct_dtype {
+    CT_F32 = 0,
+    CT_F16 = 1,
+    CT_BF16 = 2,
+    CT_I8 = 3,
+    CT_I32 = 4,
+    CT_U8 = 5,
+    CT_I16 = 6,
+    CT_I64 = 7
+};
+
+enum ct_status {
+    CT_OK = 0,
+    CT_ERR_INVALID_ARG = 1, /* maps to ValueError on the Python side */
+    CT_ERR_UNSUPPORTED = 2, /* maps to NotImplementedError                */
+    CT_ERR_HIP = 3          /* maps to RuntimeError (message has the HIP error string) */
+};
+
+const char* ct_last_error(void);
+int ct_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Scale / zero-point addressing used by every quantization entry point:
+ *     idx(r, c) = (r / rdiv) * scale_cols + (col_group ? col_group[c] : c / cdiv)
+ * tensor:  rdiv = rows, cdiv = cols, scale_cols = 1
+ * channel: rdiv = 1,    cdiv = cols, scale_cols = 1           (token: same)
+ * group:   rdiv = 1 (or rows if the scale has a single row), cdiv = group_size,
+ *          scale_cols = cols / group_size
+ * block:   rdiv = block_h, cdiv = block_w, scale_cols = ceil(cols / block_w)
+ * col_group (nullable, int32[cols], device) carries activation ordering:
+ *          argsort(argsort(g_idx)) / group_size  (quantization/lifecycle/forward_helpers.py:147-175)
+ * tdt is the torch result dtype of `x / scale` — every intermediate of the reference's
+ * eager op sequence is rounded to it (forward_helpers.py:523-546, quant_args.py:460-496).
+ * zp may be NULL (no zero point); zdt in {CT_I8, CT_I32, CT_F32, CT_F16, CT_BF16}.
+ * ------------------------------------------------------------------------------------ */
+
+/* pack_to_int32(value, num_bits, packed_dim=1)   compressors/pack_quantized/helpers.py:20-101
+ * q: int8 (rows, cols); out: int32 (rows, out_row_stride >= ceil(cols*bits/32)) */
+int ct_pack_int32(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t* out,
+                  int64_t out_row_stride, ct_stream_t stream);
+
+/* unpack_from_int32(value, num_bits, shape, packed_dim=1)   helpers.py:104-180
+ * p: int32 (rows, words) with row stride p_row_stride; out: int8 (rows, cols) */
+int ct_unpack_int32(const int32_t* p, int64_t rows, int64_t words, int64_t p_row_stride,
+                    int64_t cols, int bits, int8_t* out, ct_stream_t stream);
+
+/* pack_to_int32(zp, num_bits, packed_dim=0).contiguous()   compressors/pack_quantized/base.py:107-110
+ * q: int8 (rows, cols) packed along ROWS; out: int32 (ceil(rows*bits/32), cols) contiguous */
+int ct_pack_int32_dim0(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t* out,
+                       ct_stream_t stream);
+
+/* unpack_from_int32(zp, num_bits, shape, packed_dim=0)   base.py:147-153
+ * p: int32 (words, cols) contiguous; out: int8 (rows, cols) */
+int ct_unpack_int32_dim0(const int32_t* p, int64_t words, int64_t cols, int64_t rows, int bits,
+                         int8_t* out, ct_stream_t stream);
+
+/* quantize(x, scale, zero_point, args, dtype)   quantization/lifecycle/forward.py:36-73
+ * odt in {CT_I8, CT_I32, CT_F32, CT_F16, CT_BF16} */
+int ct_quantize(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                const int32_t* col_group, int bits, int tdt, void* out, int odt, ct_stream_t stream);
+
+/* dequantize(x_q, scale, zero_point, ...)   forward.py:76-145; forward_helpers.py:549-572
+ * xq: qdt in {CT_I8, CT_I32, float types}; arithmetic in sdt; odt in {CT_F32, CT_F16, CT_BF16} */
+int ct_dequantize(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt,
+                  int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                  const int32_t* col_group, void* out, int odt, ct_stream_t stream);
+
+/* fake_quantize(x, scale, zero_point, args)   forward.py:148-181; forward_helpers.py:180-215 */
+int ct_fake_quantize(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                     int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                     const int32_t* col_group, int bits, int tdt, void* out, int odt,
+                     ct_stream_t stream);
+
+/* Fused PackedQuantizationCompressor.compress weight path: quantize(dtype=int8) followed by
+ * pack_to_int32, without the int8 intermediate.   compressors/pack_quantized/base.py:96-104
+ * packed: int32 (rows, ceil(cols*bits/32)) contiguous */
+int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                  int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                  const int32_t* col_group, int bits, int tdt, int32_t* packed, ct_stream_t stream);
+
+/* Fused PackedQuantizationCompressor.decompress weight path: unpack_from_int32 followed by
+ * dequantize.   base.py:155-161.  zp is the UNPACKED zero point (int8) or NULL. */
+int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_t cols, int bits,
+                      const void* scale, int sdt, const void* zp, int zdt, int64_t rdiv,
+                      int64_t cdiv, int64_t scale_cols, const int32_t* col_group, void* out, int odt,
+                      ct_stream_t stream);
+
+/* Min/max observer + calculate_qparams for weight groups (rows x ceil(cols/cdiv) groups of
+ * cdiv consecutive columns).   quantization/utils/helpers.py:50-137
+ * scale_out has x's dtype; zp_out is int8 (may be NULL for symmetric). */
+int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits,
+                      int symmetric, void* scale_out, int8_t* zp_out, ct_stream_t stream);
+
+/* ---------------------------------------------------------------------------- sparse codecs
+ * The compressor classes for these formats were removed from the reference snapshot
+ * (compressors/base.py:43-44); the formats and primitives remain: config/base.py:17-18,23,
+ * utils/helpers.py:306-343 (pack_bitmasks / unpack_bitmasks, numpy little-endian packbits),
+ * utils/semi_structured_conversions.py:33-298, utils/permutations_24.py:20-53.
+ * `dt` describes the element for the `!= 0` test and its size; values are copied bit-for-bit.
+ */
+
+/* pack_bitmasks(mask)   utils/helpers.py:306-318.  mask: uint8/bool (rows, cols) */
+int ct_pack_bitmasks(const uint8_t* mask, int64_t rows, int64_t cols, uint8_t* out, ct_stream_t stream);
+/* unpack_bitmasks(packed, shape)   utils/helpers.py:321-343 */
+int ct_unpack_bitmasks(const uint8_t* packed, int64_t rows, int64_t cols, uint8_t* mask, ct_stream_t stream);
+
+/* sparse-bitmask compress, pass 1: bitmask = pack_bitmasks(x != 0), row_counts[r] = nnz of row r */
+int ct_bitmask_count(const void* x, int dt, int64_t rows, int64_t cols, uint8_t* bitmask,
+                     int64_t* row_counts, ct_stream_t stream);
+/* exclusive scan of int64 counts -> row_offsets (n) and the grand total (total[0]) */
+int ct_exclusive_scan_i64(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total,
+                          ct_stream_t stream);
+/* sparse-bitmask compress, pass 2: values[row_offsets[r] + rank] = x[r, c] for non-zero x */
+int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const int64_t* row_offsets,
+                       void* values, ct_stream_t stream);
+/* sparse-bitmask decompress: out = zeros; out[mask] = values.  row_offsets may be NULL only if
+ * fixed_row_nnz >= 0 (every row holds exactly that many values: the 2:4 codec) */
+int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t* bitmask,
+                          const int64_t* row_offsets, int64_t fixed_row_nnz, int dt, int64_t rows,
+                          int64_t cols, void* out, ct_stream_t stream);
+/* popcount of each bitmask row -> row_counts (to rebuild row_offsets when a checkpoint lacks them) */
+int ct_bitmask_row_popcount(const uint8_t* bitmask, int64_t rows, int64_t cols, int64_t* row_counts,
+                            ct_stream_t stream);
+
+/* sparse-24-bitmask compress: keep the 2 largest-|x| of every 4 consecutive elements (ties:
+ * lower index first; NaN largest); values (rows, cols/2); bitmask (rows, ceil(cols/8)) */
+int ct_sparse24_compress(const void* x, int dt, int64_t rows, int64_t cols, void* values,
+                         uint8_t* bitmask, ct_stream_t stream);
+/* the 2:4 magnitude mask alone (mask_creator, utils/semi_structured_conversions.py:301-330) */
+int ct_sparse24_mask(const void* x, int dt, int64_t numel, uint8_t* mask, ct_stream_t stream);
+
+/* sparse_semi_structured_from_dense_cutlass   utils/semi_structured_conversions.py:66-197
+ * dense (m, k) of CT_F16/CT_BF16 (meta int16) or CT_I8 (meta int32); sparse (m, k/2);
+ * meta (m, k/(4*Q)) reordered, Q = 4 (int16) or 8 (int32) */
+int ct_cutlass24_from_dense(const void* dense, int dt, int64_t m, int64_t k, void* sparse, void* meta,
+                            ct_stream_t stream);
+/* sparse_semi_structured_to_dense_cutlass   :204-298.  sparse (m, k) -> dense (m, 2k) */
+int ct_cutlass24_to_dense(const void* sparse, int dt, const void* meta, int meta_itemsize, int64_t m,
+                          int64_t k, void* dense, ct_stream_t stream);
+
+/* marlin-24 weight packing (historical Marlin24Compressor.pack_weight_24 with the table of
+ * utils/permutations_24.py:20-45).  q: codes of dtype dt (CT_I32 / CT_I8 / float holding
+ * integers), laid out (size_k, size_n) [transposed == 0] or as the un-transposed 2:4-compressed
+ * matrix (size_n, size_k) [transposed == 1]; add_offset != 0 adds 2^(bits-1) to make the codes
+ * unsigned.  packed: int32 (size_k/16, size_n*16*bits/32) */
+int ct_marlin24_pack_weights(const void* q, int dt, int transposed, int add_offset, int64_t size_k,
+                             int64_t size_n, int bits, int32_t* packed, ct_stream_t stream);
+/* marlin-24 scale packing: scale (size_n, groups) 16-bit float -> transposed, permuted with
+ * scale_perm (single == 0) or scale_perm_single (single != 0) of utils/permutations_24.py:46-53
+ * -> (groups, size_n) */
+int ct_marlin24_pack_scales(const void* scale, int dt, int64_t size_n, int64_t groups, int single,
+                            void* out, ct_stream_t stream);
+
+/* ---------------------------------------------------------------------------- diagnostics
+ * Exhaustive device-side check of the reciprocal fast path used by the bf16 fused kernels:
+ * for every bf16 (x, s) pair in [s_lo_bits, s_hi_bits) x all 65536 x, compares
+ * rnd_bf16(x * rcp(s)) with rnd_bf16(x / s).  mismatches[0] receives the count. */
+int ct_selftest_bf16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
+                         ct_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CT_HIP_H */

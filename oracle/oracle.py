@@ -381,7 +381,7 @@ def marlin24_compress(weight, scale, zero_point, *, num_bits, strategy, group_si
     packed = marlin24_pack_weights(codes, num_bits)
     sp, sps = marlin24_scale_perms()
     st = str(getattr(strategy, "value", strategy))
-    if st == "group" and group_size is not None and group_size < size_k * 2:
+    if st == "group" and group_size is not None and group_size < size_k:  # size_k = in_features / 2 (w_shape of the compressed, transposed weight)
         s_p = s_t.reshape(-1, len(sp))[:, sp]
     else:
         s_p = s_t.reshape(-1, len(sps))[:, sps]

@@ -1,0 +1,421 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the reference's golden
+vectors.  Every test here needs an MI355X:  python -m pytest tests -m gpu"""
+import math
+
+import pytest
+import torch
+from _golden import cases
+from test_oracle_golden import _kw, eq
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cta():
+    import compressed_tensors_amd as m
+    from compressed_tensors_amd import _lib
+
+    _lib.load()  # fail loudly if the HIP extension is missing
+    return m
+
+
+def d(t, dev):
+    return None if t is None else t.to(dev)
+
+
+def special_values(dtype):
+    v = [float("nan"), float("inf"), -float("inf"), 0.0, -0.0, 1e30, -1e30, 1e-30, 2.498, 3.496, 0.5, 1.5, 2.5, -0.5,
+         -1.5, -2.5, 6.5, 7.5, -7.5, -8.5, 127.5, -128.5, 65504.0, 1e-8]
+    return torch.tensor(v, dtype=torch.float32).to(dtype)
+
+
+# ----------------------------------------------------------------------------- golden: pack / unpack
+@pytest.mark.parametrize("case", cases("pack"), ids=lambda c: c["key"])
+def test_pack_unpack_golden(golden, cta, dev, case):
+    t = golden.case("pack", case["key"])
+    bits, pd = case["bits"], case["packed_dim"]
+    packed = cta.codec.pack_to_int32(d(t["value"], dev), bits, packed_dim=pd)
+    assert packed.is_cuda and packed.dtype == torch.int32 and packed.is_contiguous()
+    assert eq(packed.cpu(), t["packed"])
+    if not case.get("oob"):
+        un = cta.codec.unpack_from_int32(d(t["packed"], dev), bits, torch.Size(case["shape"]), packed_dim=pd)
+        assert eq(un.cpu(), t["value"])
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4, 8])
+@pytest.mark.parametrize("k", [33, 64, 100, 1024])
+def test_old_format_compat(cta, dev, bits, k):
+    """reference tests/test_compressors/test_pack_quant.py:386-416"""
+    from test_oracle_golden import _old_pack
+
+    lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+    v = torch.randint(lo, hi + 1, (64, k), dtype=torch.int8)
+    old = _old_pack(v, bits)
+    assert torch.equal(cta.codec.pack_to_int32(v.to(dev), bits).cpu(), old)
+    assert torch.equal(cta.codec.unpack_from_int32(old.to(dev), bits, torch.Size((64, k))).cpu(), v)
+
+
+@pytest.mark.parametrize("bits", range(1, 9))
+@pytest.mark.parametrize("shape", [(256, 1024), (512, 100), (128, 33), (64, 4096), (3, 8, 40)])
+def test_pack_unpack_vs_oracle(cta, dev, bits, shape):
+    g = torch.Generator().manual_seed(bits * 100 + shape[-1])
+    lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+    v = torch.randint(lo, hi + 1, shape, dtype=torch.int8, generator=g)
+    packed = cta.codec.pack_to_int32(v.to(dev), bits)
+    assert packed.shape == (*shape[:-1], math.ceil(shape[-1] * bits / 32))
+    assert torch.equal(packed.cpu(), O.pack_to_int32(v, bits).contiguous())
+    assert torch.equal(cta.codec.unpack_from_int32(packed, bits, torch.Size(shape)).cpu(), v)
+
+
+# ----------------------------------------------------------------------------- golden: quantization
+@pytest.mark.parametrize("case", cases("quant"), ids=lambda c: c["key"])
+def test_quant_golden(golden, cta, dev, case):
+    t = golden.case("quant", case["key"])
+    kw = _kw(case)
+    x, s, z = d(t["x"], dev), d(t["scale"], dev), d(t["zp"], dev)
+    g_idx = d(t.get("g_idx"), dev)
+    q8 = cta.codec.quantize_tensor(x, s, z, dtype=torch.int8, g_idx=g_idx, **kw)
+    assert eq(q8.cpu(), t["q8"])
+    assert eq(cta.codec.fake_quantize_tensor(x, s, z, g_idx=g_idx, **kw).cpu(), t["fq"])
+    dkw = dict(kw)
+    bits = dkw.pop("num_bits")
+    assert eq(cta.codec.dequantize_tensor(d(t["q8"], dev), s, z, g_idx=g_idx, **dkw).cpu(), t["dq"])
+    if "qf" in t:
+        assert eq(cta.codec.quantize_tensor(x, s, z, g_idx=g_idx, **kw).cpu(), t["qf"])
+        assert eq(cta.codec.quantize_tensor(x, s, None, dtype=torch.int8, **kw).cpu(), t["q8_nozp"])
+        if kw["strategy"] != "block":
+            assert eq(cta.codec.dequantize_tensor(d(t["q8"], dev), s, z).cpu(), t["dq_inferred"])
+    # fused kernels against the unfused golden results
+    packed = cta.codec.quantize_and_pack(x, s, z, g_idx=g_idx, **kw)
+    assert eq(packed.cpu(), O.pack_to_int32(t["q8"], bits).contiguous())
+    out = cta.codec.unpack_and_dequantize(packed, t["x"].shape, s, z, num_bits=bits, g_idx=g_idx, **dkw)
+    assert eq(out.cpu(), t["dq"])
+
+
+@pytest.mark.parametrize("case", cases("qparams"), ids=lambda c: c["key"])
+def test_qparams_golden(golden, cta, dev, case):
+    t = golden.case("qparams", case["key"])
+    scale, zp = cta.codec.minmax_qparams(d(t["x"], dev), num_bits=case["bits"], group_size=case["group_size"],
+                                         symmetric=case["symmetric"])
+    assert eq(scale.cpu(), t["scale"])
+    assert eq(zp.cpu(), t["zp"].to(torch.int8))
+
+
+# ----------------------------------------------------------------------------- golden: compressors
+def _scheme(cta, case):
+    a = case["args"]
+    args = cta.QuantizationArgs(**a)
+    act = cta.QuantizationArgs(num_bits=8, strategy="tensor", symmetric=True) if case["format"] == "int-quantized" else None
+    return cta.QuantizationScheme(targets=["Linear"], weights=args, input_activations=act)
+
+
+@pytest.mark.parametrize("case", cases("compressors"), ids=lambda c: c["key"])
+def test_compressor_golden(golden, cta, dev, case):
+    t = golden.case("compressors", case["key"])
+    sd = {k[3:]: d(v, dev) for k, v in t.items() if k.startswith("in.")}
+    exp_c = {k[2:]: v for k, v in t.items() if k.startswith("c.")}
+    exp_d = {k[2:]: v for k, v in t.items() if k.startswith("d.")}
+    scheme = _scheme(cta, case)
+    comp = cta.BaseCompressor.get_value_from_registry(case["format"])
+    sd_before = dict(sd)
+    c = comp.compress(sd, scheme)
+    assert sd == sd_before, "compress must not mutate its input dict"
+    assert sorted(c.keys()) == case["compressed_keys"]
+    for k, v in exp_c.items():
+        assert eq(c[k].cpu().contiguous(), v), k
+        if k == "weight_shape":
+            assert c[k].device.type == "cpu" and c[k].dtype == torch.int64
+        else:
+            assert c[k].is_cuda, k
+    assert c["weight_scale"] is sd["weight_scale"], "untouched tensors are returned by identity"
+    dd = comp.decompress({k: d(v, dev) if k != "weight_shape" else v for k, v in exp_c.items()}, scheme)
+    assert sorted(dd.keys()) == case["decompressed_keys"]
+    for k, v in exp_d.items():
+        assert eq(dd[k].cpu().contiguous(), v), k
+    assert sorted(comp.compression_param_names(scheme)) == sorted(k for k in case["compressed_keys"])
+
+
+# ----------------------------------------------------------------------------- random vs oracle
+QCASES = [
+    # dtype, scale dtype, bits, strategy, group, shape, symmetric
+    (BF16, BF16, 4, "group", 128, (256, 4096), True),
+    (BF16, BF16, 4, "group", 128, (256, 4096), False),
+    (BF16, BF16, 4, "group", 32, (64, 256), False),
+    (BF16, BF16, 4, "channel", None, (128, 1000), False),
+    (BF16, BF16, 8, "channel", None, (128, 1024), True),
+    (BF16, F32, 4, "group", 128, (64, 1024), False),
+    (F16, F16, 4, "group", 128, (128, 2048), False),
+    (F16, F16, 8, "tensor", None, (64, 512), True),
+    (F32, F32, 4, "group", 64, (64, 512), False),
+    (F32, F32, 3, "channel", None, (33, 70), False),
+    (BF16, BF16, 5, "group", 32, (36, 96), False),
+    (BF16, BF16, 2, "group", 16, (17, 48), True),
+    (BF16, BF16, 1, "channel", None, (8, 100), True),
+    (BF16, BF16, 7, "tensor", None, (16, 99), False),
+    (BF16, BF16, 8, "block", None, (64, 256), True),
+]
+
+
+def _make_qcase(xdt, sdt, bits, strategy, gs, shape, sym, seed=0):
+    g = torch.Generator().manual_seed(seed + bits)
+    x = torch.randn(shape, generator=g).mul(2.0).to(xdt)
+    sp = special_values(xdt)
+    x.view(-1)[: sp.numel()] = sp
+    xf = torch.nan_to_num(x.float(), nan=0.0, posinf=4.0, neginf=-4.0).clamp(-9, 9).to(xdt)
+    if strategy == "tensor":
+        scale, zp = O.calculate_qparams_minmax(xf.reshape(1, -1), num_bits=bits, symmetric=sym)
+        scale, zp = scale.reshape(1), zp.reshape(1)
+    elif strategy == "block":
+        bs = [8, 64]
+        scale = (torch.rand((shape[0] // 8, shape[1] // 64), generator=g) * 0.05 + 0.01).to(xdt)
+        zp = torch.zeros(scale.shape, dtype=torch.int8)
+    else:
+        scale, zp = O.calculate_qparams_minmax(xf, num_bits=bits, group_size=gs, symmetric=sym)
+    kw = dict(num_bits=bits, strategy=strategy, group_size=gs, block_structure=[8, 64] if strategy == "block" else None)
+    return x, scale.to(sdt), zp, kw
+
+
+@pytest.mark.parametrize("xdt,sdt,bits,strategy,gs,shape,sym", QCASES)
+def test_quant_paths_vs_oracle(cta, dev, xdt, sdt, bits, strategy, gs, shape, sym):
+    x, scale, zp, kw = _make_qcase(xdt, sdt, bits, strategy, gs, shape, sym)
+    q_ref = O.quantize(x, scale, zp, dtype=torch.int8, **kw)
+    q = cta.codec.quantize_tensor(x.to(dev), scale.to(dev), zp.to(dev), dtype=torch.int8, **kw)
+    assert eq(q.cpu(), q_ref)
+    fq = cta.codec.fake_quantize_tensor(x.to(dev), scale.to(dev), zp.to(dev), **kw)
+    assert eq(fq.cpu(), O.fake_quantize(x, scale, zp, **kw))
+    dkw = {k: v for k, v in kw.items() if k != "num_bits"}
+    dq_ref = O.dequantize(q_ref, scale, zp, **dkw)
+    assert eq(cta.codec.dequantize_tensor(q, scale.to(dev), zp.to(dev), **dkw).cpu(), dq_ref)
+    packed = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), zp.to(dev), **kw)
+    assert eq(packed.cpu(), O.pack_to_int32(q_ref, bits).contiguous())
+    out = cta.codec.unpack_and_dequantize(packed, x.shape, scale.to(dev), zp.to(dev), **kw)
+    assert eq(out.cpu(), dq_ref)
+    # symmetric call without a zero point takes the no-zp kernel path
+    q0 = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), None, **kw)
+    assert eq(q0.cpu(), O.pack_to_int32(O.quantize(x, scale, None, dtype=torch.int8, **kw), bits).contiguous())
+
+
+def test_gidx_vs_oracle(cta, dev):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((32, 512), generator=g).to(BF16)
+    perm = torch.randperm(512, generator=g)
+    g_idx = (torch.arange(512, dtype=torch.int32) // 128)[perm].contiguous()
+    scale = (torch.rand((32, 4), generator=g) * 0.3 + 0.05).to(BF16)
+    zp = torch.randint(-8, 8, (32, 4), generator=g).to(torch.int8)
+    kw = dict(num_bits=4, strategy="group", group_size=128)
+    ref = O.quantize(x, scale, zp, dtype=torch.int8, g_idx=g_idx, **kw)
+    got = cta.codec.quantize_tensor(x.to(dev), scale.to(dev), zp.to(dev), dtype=torch.int8, g_idx=g_idx.to(dev), **kw)
+    assert eq(got.cpu(), ref)
+    packed = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), zp.to(dev), g_idx=g_idx.to(dev), **kw)
+    assert eq(packed.cpu(), O.pack_to_int32(ref, 4).contiguous())
+    out = cta.codec.unpack_and_dequantize(packed, x.shape, scale.to(dev), zp.to(dev), g_idx=g_idx.to(dev), **kw)
+    assert eq(out.cpu(), O.dequantize(ref, scale, zp, strategy="group", group_size=128, g_idx=g_idx))
+
+
+def test_bf16_reciprocal_fast_path_is_exact(cta, dev):
+    """exhaustive over all 65536 x 65536 bf16 (x, scale) pairs inside the fast-path range"""
+    assert cta.codec.selftest_bf16_div(0, 65536) == 0
+
+
+def test_all_bf16_inputs_w4(cta, dev):
+    """every bf16 bit pattern as an input, against a spread of scales incl. extreme exponents"""
+    allx = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(BF16).reshape(64, 1024)
+    g = torch.Generator().manual_seed(3)
+    scales = torch.cat([
+        (torch.rand(40, generator=g) * 2 + 1e-3), torch.tensor([1e-30, 1e30, 2.0 ** -70, 2.0 ** 70, 1e-38, 3e38, 0.0, float("inf")])
+    ]).to(BF16)
+    for i in range(0, scales.numel(), 8):
+        s = scales[i:i + 8].reshape(1, 8).repeat(64, 1).contiguous()  # (64, 8): group 128
+        z = torch.randint(-8, 8, (64, 8), generator=g).to(torch.int8)
+        for zp in (None, z):
+            ref = O.pack_to_int32(O.quantize(allx, s, zp, num_bits=4, strategy="group", group_size=128, dtype=torch.int8), 4)
+            got = cta.codec.quantize_and_pack(allx.to(dev), s.to(dev), d(zp, dev), num_bits=4, strategy="group", group_size=128)
+            assert eq(got.cpu(), ref.contiguous())
+
+
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_w4a16_full_size(cta, dev, N):
+    """BASELINE config 2 at full size: compress + decompress vs the oracle, and the round-trip
+    property decompress(compress(W)) == fake_quantize(W) (reference test_pack_quant.py:160-183)"""
+    torch.manual_seed(0)
+    w = torch.randn(N, N, dtype=BF16)
+    scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=128, symmetric=True)
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    sd = {"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}
+    s_dev, z_dev = cta.codec.minmax_qparams(sd["weight"], num_bits=4, group_size=128, symmetric=True)
+    assert eq(s_dev.cpu(), scale) and eq(z_dev.cpu(), zp)
+    c = cta.PackedQuantizationCompressor.compress(sd, scheme)
+    assert c["weight_packed"].shape == (N, N // 8) and "weight_zero_point" not in c
+    q_ref = O.quantize(w, scale, zp, num_bits=4, strategy="group", group_size=128, dtype=torch.int8)
+    assert torch.equal(c["weight_packed"].cpu(), O.pack_to_int32(q_ref, 4))
+    dd = cta.PackedQuantizationCompressor.decompress(c, scheme)
+    assert dd["weight"].dtype == BF16 and dd["weight"].shape == (N, N)
+    assert eq(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, num_bits=4, strategy="group", group_size=128))
+    # idempotence: re-compressing the decompressed weight reproduces the same words
+    c2 = cta.PackedQuantizationCompressor.compress({**sd, "weight": dd["weight"]}, scheme)
+    assert torch.equal(c2["weight_packed"], c["weight_packed"])
+
+
+def test_int8_per_tensor_full_size(cta, dev):
+    """BASELINE config 1 on the GPU path: int8 per-tensor symmetric, 4096x4096 bf16"""
+    torch.manual_seed(0)
+    w = torch.randn(4096, 4096, dtype=BF16)
+    scale, zp = O.calculate_qparams_minmax(w.reshape(1, -1), num_bits=8, symmetric=True)
+    scale, zp = scale.reshape(1), zp.reshape(1)
+    args = cta.QuantizationArgs(num_bits=8, strategy="tensor", symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args, input_activations=cta.QuantizationArgs(num_bits=8))
+    comp = cta.BaseCompressor.get_value_from_registry("int-quantized")
+    c = comp.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+    q_ref = O.quantize(w, scale, zp, num_bits=8, strategy="tensor", dtype=torch.int8)
+    assert c["weight"].dtype == torch.int8 and torch.equal(c["weight"].cpu(), q_ref)
+    dd = comp.decompress(c, scheme)
+    assert eq(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, num_bits=8, strategy="tensor"))
+
+
+# ----------------------------------------------------------------------------- sparse
+@pytest.mark.parametrize("case", [c for c in cases("sparse") if c["kind"] == "bitmask"], ids=lambda c: c["key"])
+def test_bitmask_primitives_golden(golden, cta, dev, case):
+    t = golden.case("sparse", case["key"])
+    assert eq(cta.codec.pack_bitmasks(t["mask"].bool().to(dev)).cpu(), t["packed"])
+    assert torch.equal(cta.codec.unpack_bitmasks(t["packed"].to(dev), case["shape"]).cpu(), t["mask"].bool())
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32, torch.int8])
+@pytest.mark.parametrize("shape,p", [((1, 1), 0.5), ((3, 10), 0.5), ((16, 64), 0.5), ((7, 129), 0.3), ((64, 4096), 0.5),
+                                     ((5, 2048), 0.0), ((5, 2048), 1.0), ((9, 6000), 0.9)])
+def test_bitmask_codec_vs_oracle(cta, dev, dtype, shape, p):
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(shape, generator=g)
+    x = x.masked_fill(torch.rand(shape, generator=g) < p, 0)
+    x = (x * 8).to(dtype) if dtype is torch.int8 else x.to(dtype)
+    if dtype.is_floating_point and x.numel() > 2:
+        x.view(-1)[0] = -0.0
+        x.view(-1)[1] = float("nan")
+    rv, rb, ro = O.bitmask_compress(x)
+    values, bitmask, row_offsets = cta.codec.bitmask_compress(x.to(dev))
+    assert eq(values.cpu(), rv) and torch.equal(bitmask.cpu(), rb) and torch.equal(row_offsets.cpu(), ro)
+    ref = O.bitmask_decompress(rv, rb, shape)
+    assert eq(cta.codec.bitmask_decompress(values, bitmask, shape, row_offsets).cpu(), ref)
+    # a checkpoint without row_offsets: rebuilt from the bitmask
+    assert eq(cta.codec.bitmask_decompress(values, bitmask, shape).cpu(), ref)
+
+
+def test_bitmask_full_size(cta, dev):
+    """BASELINE config 3: 50 % unstructured, 8192x8192 bf16"""
+    N = 8192
+    torch.manual_seed(0)
+    w = torch.randn(N, N, dtype=BF16)
+    w = w.masked_fill(torch.rand(N, N, generator=torch.Generator().manual_seed(1)) < 0.5, 0)
+    rv, rb, ro = O.bitmask_compress(w)
+    t = cta.compressors.sparse.BitmaskTensor.from_dense(w.to(dev))
+    assert eq(t.compressed.cpu(), rv) and torch.equal(t.bitmask.cpu(), rb) and torch.equal(t.row_offsets.cpu(), ro)
+    assert eq(t.decompress().cpu(), w)  # no -0.0 in randn*mask: exact round trip
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, torch.int8])
+def test_sparse24_vs_oracle(cta, dev, dtype):
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((64, 256), generator=g)
+    x = (x * 20).to(dtype) if dtype is torch.int8 else x.to(dtype)
+    x[0, :8] = 0  # all-zero quads still get two bits
+    x[1, :4] = x[1, 0]  # ties
+    m = cta.codec.sparse24_mask(x.to(dev))
+    assert torch.equal(m.cpu(), O.sparse24_mask(x))
+    pruned = x * O.sparse24_mask(x).to(x.dtype)
+    rv, rb = O.sparse24_bitmask_compress(pruned)
+    values, bitmask = cta.codec.sparse24_bitmask_compress(pruned.to(dev))
+    assert eq(values.cpu(), rv) and torch.equal(bitmask.cpu(), rb)
+    out = cta.codec.sparse24_bitmask_decompress(values, bitmask, pruned.shape)
+    assert eq(out.cpu(), O.sparse24_bitmask_decompress(rv, rb, pruned.shape))
+
+
+@pytest.mark.parametrize("case", [c for c in cases("sparse") if c["kind"] == "cutlass24"], ids=lambda c: c["key"])
+def test_cutlass24_golden(golden, cta, dev, case):
+    t = golden.case("sparse", case["key"])
+    sparse, meta = cta.codec.cutlass24_from_dense(t["dense"].to(dev))
+    assert eq(sparse.cpu(), t["sparse"]) and eq(meta.cpu(), t["meta"])
+    assert eq(cta.codec.cutlass24_to_dense(t["sparse"].to(dev), t["meta"].to(dev)).cpu(), t["dense_rt"])
+
+
+@pytest.mark.parametrize("bits,strategy,gs", [(4, "group", 128), (4, "channel", None), (8, "channel", None)])
+def test_marlin24_vs_oracle(cta, dev, bits, strategy, gs):
+    g = torch.Generator().manual_seed(bits)
+    out_f, in_f = 128, 512
+    w = torch.randn((out_f, in_f), generator=g).to(BF16)
+    w = w * O.sparse24_mask(w).to(w.dtype)
+    scale, zp = O.calculate_qparams_minmax(w.to(F16), num_bits=bits, group_size=gs, symmetric=True)
+    ref = O.marlin24_compress(w, scale, zp, num_bits=bits, strategy=strategy, group_size=gs)
+    args = cta.QuantizationArgs(num_bits=bits, strategy=strategy, group_size=gs, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    got = cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+    assert sorted(got.keys()) == ["meta", "scale_packed", "weight_packed"]
+    for k in ref:
+        assert got[k].shape == ref[k].shape, k
+        assert eq(got[k].cpu().contiguous(), ref[k].contiguous()), k
+    # the permutation tables themselves
+    perm, sp, sps = cta.utils.get_permutations_24(bits)
+    assert torch.equal(perm, O.marlin24_perm(bits).long())
+
+
+# ----------------------------------------------------------------------------- modules / staging
+def test_compress_decompress_module(cta, dev):
+    """reference tests/test_compressors/test_compress_decompress_module.py:24-127"""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(256, 256, bias=True).to(dev).to(BF16)
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False)
+    lin.quantization_scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    scale, zp = cta.quantization.calculate_qparams_from_weight(lin.weight.data, args)
+    lin.register_parameter("weight_scale", torch.nn.Parameter(scale, requires_grad=False))
+    lin.register_parameter("weight_zero_point", torch.nn.Parameter(zp, requires_grad=False))
+    w0 = lin.weight.data.clone()
+    cta.compress_module(lin)
+    assert lin.quantization_status == cta.QuantizationStatus.COMPRESSED
+    names = dict(lin.named_parameters())
+    assert "weight" not in names and names["weight_packed"].dtype == torch.int32 and not names["weight_packed"].requires_grad
+    assert names["weight_zero_point"].dtype == torch.int32 and names["weight_shape"].tolist() == [256, 256]
+    assert lin.quantization_scheme.format == cta.CompressionFormat.pack_quantized
+    cta.decompress_module(lin)
+    assert lin.quantization_status == cta.QuantizationStatus.DECOMPRESSED
+    assert lin.weight.dtype == BF16 and lin.weight.shape == (256, 256) and lin.weight_zero_point.dtype == torch.int8
+    fq = O.fake_quantize(w0.cpu(), scale.cpu(), zp.cpu(), num_bits=4, strategy="group", group_size=128)
+    assert eq(lin.weight.data.cpu(), fq)
+
+
+def test_model_compressor_roundtrip(cta, dev):
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 512, bias=False), torch.nn.ReLU(), torch.nn.Linear(512, 128, bias=False)).to(dev).to(BF16)
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True)
+    expect = {}
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.Linear):
+            m.quantization_scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+            s, z = cta.quantization.calculate_qparams_from_weight(m.weight.data, args)
+            m.register_parameter("weight_scale", torch.nn.Parameter(s, requires_grad=False))
+            m.register_parameter("weight_zero_point", torch.nn.Parameter(z, requires_grad=False))
+            expect[name] = O.fake_quantize(m.weight.data.cpu(), s.cpu(), z.cpu(), num_bits=4, strategy="group", group_size=128)
+    mc = cta.ModelCompressor()
+    mc.compress_model(model)
+    assert all(hasattr(m, "weight_packed") for m in model if isinstance(m, torch.nn.Linear))
+    y = model(torch.randn(4, 256, device=dev, dtype=BF16))  # first forward decompresses (hook)
+    assert y.shape == (4, 128) and not hasattr(model, "ct_decompress_hook")
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.Linear):
+            assert eq(m.weight.data.cpu(), expect[name])
+
+
+def test_host_tensors_are_staged_through_the_gpu(cta, dev):
+    g = torch.Generator().manual_seed(2)
+    v = torch.randint(-8, 8, (32, 200), dtype=torch.int8, generator=g)
+    p = cta.codec.pack_to_int32(v, 4)
+    assert p.device.type == "cpu" and torch.equal(p, O.pack_to_int32(v, 4).contiguous())

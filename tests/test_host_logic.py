@@ -1,0 +1,267 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header declares, and
+the host-side mirror of the reference interface (registry, format inference, argument
+validation, meta-device paths, work partitioning) behaves like the reference.  No kernel is
+launched here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cta():
+    import __graft_entry__ as g
+
+    g.build_hip()  # no-op when the library is up to date
+    import compressed_tensors_amd as m
+
+    return m
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "ct_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ct_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(cta):
+    from compressed_tensors_amd import _lib
+
+    declared = _header_symbols()
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/ct_hip.h but not exported"
+    # the Python binding covers exactly the declared ABI
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+    assert _lib.load().ct_abi_version() == 1
+
+
+def test_library_targets_gfx950_only():
+    out = subprocess.run(["strings", "-a", os.path.join(ROOT, "compressed_tensors_amd", "libct_hip.so")],
+                         capture_output=True, text=True).stdout
+    archs = set(re.findall(r"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_no_product_import_of_the_oracle():
+    """the product must never import/link/execute anything under oracle/"""
+    pkg = os.path.join(ROOT, "compressed_tensors_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "libct_oracle" not in text and "ct_oracle.c" not in text, f
+
+
+def test_missing_extension_fails_loudly(cta, monkeypatch):
+    from compressed_tensors_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libct_hip.so")
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.load()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_without_gpu_raises(cta):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cta.codec.pack_to_int32(torch.zeros(2, 32, dtype=torch.int8), 4)
+
+
+def test_argument_errors_match_reference(cta):
+    """reference compressors/pack_quantized/helpers.py:36-42,122-130; forward_helpers.py:141-145"""
+    with pytest.raises(ValueError, match="torch.int8"):
+        cta.codec.pack_to_int32(torch.zeros(2, 2, dtype=torch.int32), 4)
+    with pytest.raises(ValueError, match=r"num_bits in \[1, 8\]"):
+        cta.codec.pack_to_int32(torch.zeros(2, 2, dtype=torch.int8), 9)
+    with pytest.raises(ValueError, match="Aborting unpack"):
+        cta.codec.unpack_from_int32(torch.zeros(2, 2, dtype=torch.int8), 4, (2, 2))
+    with pytest.raises(ValueError, match="divisble"):
+        cta.codec.QuantLayout((4, 100), torch.ones(4, 1), "group", group_size=64)
+    with pytest.raises(NotImplementedError):
+        args = cta.QuantizationArgs(num_bits=8, type="float")
+        cta.quantize(torch.zeros(2, 2), torch.ones(1), None, args)
+    with pytest.raises(ValueError, match="Could not infer"):
+        from compressed_tensors_amd.codec import infer_dequant_layout
+
+        infer_dequant_layout((2, 2, 2), torch.ones(2, 2, 2))
+
+
+def test_layout_resolution(cta):
+    L = cta.codec.QuantLayout
+    g = L((16, 256), torch.ones(16, 2), "group", group_size=128)
+    assert (g.rows, g.cols, g.rdiv, g.cdiv, g.scale_cols) == (16, 256, 1, 128, 2)
+    g1 = L((16, 256), torch.ones(1, 2), "group", group_size=128)
+    assert g1.rdiv == 16
+    c = L((16, 256), torch.ones(16, 1), "channel")
+    assert (c.rdiv, c.cdiv, c.scale_cols) == (1, 256, 1)
+    t = L((16, 256), torch.ones(1), "tensor")
+    assert (t.rdiv, t.cdiv, t.scale_cols) == (16, 256, 1) and not t.scale_zero_dim
+    t0 = L((16, 256), torch.tensor(1.0), "tensor")
+    assert t0.scale_zero_dim
+    b = L((16, 256), torch.ones(4, 4), "block", block_structure=[4, 64])
+    assert (b.rdiv, b.cdiv, b.scale_cols) == (4, 64, 4)
+    moe = L((3, 8, 256), torch.ones(3, 8, 2), "group", group_size=128)
+    assert (moe.rows, moe.cols, moe.rdiv) == (24, 256, 1)
+    # activation ordering: column -> group of its rank in the sorted order
+    g_idx = torch.tensor([1, 0, 1, 0], dtype=torch.int32)
+    a = L((2, 4), torch.ones(2, 2), "group", group_size=2, g_idx=g_idx)
+    assert a.col_group.tolist() == [1, 0, 1, 0]
+    from compressed_tensors_amd.codec import _result_dtype
+
+    x = torch.zeros(2, 2, dtype=torch.bfloat16)
+    assert _result_dtype(x, torch.tensor(1.0), True) == torch.bfloat16  # 0-dim fp32 scale does not promote
+    assert _result_dtype(x, torch.ones(1), False) == torch.float32
+    assert _result_dtype(x, torch.ones(1, dtype=torch.float16), False) == torch.float32
+
+
+def test_registry_and_format_inference(cta):
+    B = cta.BaseCompressor
+    assert B.get_value_from_registry("pack-quantized") is cta.PackedQuantizationCompressor
+    assert B.get_value_from_registry("pack_quantized") is cta.PackedQuantizationCompressor  # standardised
+    assert B.get_value_from_registry("int-quantized") is cta.IntQuantizationCompressor
+    with pytest.raises(KeyError):
+        B.get_value_from_registry("no-such-format")
+    with pytest.raises(RuntimeError):  # registry.py:215-223
+        B.register(name="pack-quantized")(type("Other", (B,), {}))
+    from compressed_tensors_amd.compressors import infer_module_format
+
+    w4 = cta.QuantizationScheme(weights=cta.QuantizationArgs(num_bits=4, group_size=128))
+    w8a8 = cta.QuantizationScheme(weights=cta.QuantizationArgs(num_bits=8), input_activations=cta.QuantizationArgs(num_bits=8))
+    dense = cta.QuantizationScheme()
+    assert infer_module_format(torch.nn.Linear, w4) == cta.CompressionFormat.pack_quantized
+    assert infer_module_format(torch.nn.Linear, w8a8) == cta.CompressionFormat.int_quantized
+    assert infer_module_format(torch.nn.Embedding, w4) == cta.CompressionFormat.pack_quantized
+    assert infer_module_format(torch.nn.Linear, dense) == cta.CompressionFormat.dense
+    assert infer_module_format(torch.nn.Conv2d, w4) == cta.CompressionFormat.dense
+    names = cta.PackedQuantizationCompressor.compression_param_names(
+        cta.QuantizationScheme(weights=cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, actorder="group")))
+    assert names == ("weight_packed", "weight_scale", "weight_shape", "weight_zero_point", "weight_g_idx")
+
+
+def test_meta_device_paths(cta):
+    """reference compressors/pack_quantized/base.py:86-94,138-144: shapes only, no kernels"""
+    scheme = cta.QuantizationScheme(weights=cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True))
+    sd = {"weight": torch.empty(64, 100, device="meta", dtype=torch.bfloat16),
+          "weight_scale": torch.empty(64, 1, device="meta", dtype=torch.bfloat16),
+          "weight_zero_point": torch.empty(64, 1, device="meta", dtype=torch.int8)}
+    c = cta.PackedQuantizationCompressor.compress(sd, scheme)
+    assert c["weight_packed"].shape == (64, 13) and c["weight_packed"].device.type == "meta"
+    assert c["weight_shape"].tolist() == [64, 100] and "weight_zero_point" not in c and "weight" not in c
+    d = cta.PackedQuantizationCompressor.decompress(c, scheme)
+    assert d["weight"].shape == (64, 100) and d["weight"].dtype == torch.bfloat16 and d["weight"].device.type == "meta"
+
+
+def test_module_state_dict_glue(cta):
+    from compressed_tensors_amd.utils import get_direct_state_dict, replace_direct_state_dict
+
+    lin = torch.nn.Linear(4, 4)
+    sd = get_direct_state_dict(lin)
+    assert set(sd) == {"weight", "bias"} and not isinstance(sd["weight"], torch.nn.Parameter)
+    new = {"bias": sd["bias"], "weight_packed": torch.zeros(4, 1, dtype=torch.int32)}
+    lin.register_buffer("running", torch.ones(2))
+    new["running"] = lin._buffers["running"]  # plain-tensor buffers are returned by identity -> untouched
+    bias_ptr = lin.bias.data_ptr()
+    replace_direct_state_dict(lin, new)
+    # Parameters are always re-wrapped (`.data` is a fresh object, as upstream utils/module.py:56-65);
+    # the storage is shared, and everything becomes non-trainable
+    assert not hasattr(lin, "weight") and lin.bias.data_ptr() == bias_ptr and not lin.bias.requires_grad
+    assert "running" in lin._buffers and lin._buffers["running"] is new["running"]
+    assert isinstance(lin.weight_packed, torch.nn.Parameter) and not lin.weight_packed.requires_grad
+
+
+def test_impl_backend_dispatch(cta, monkeypatch):
+    from compressed_tensors_amd.utils.impl_backend import ImplBackend
+
+    calls = []
+
+    @ImplBackend.register("demo_op", req=lambda x: x > 0, priority=1)
+    def demo_fast(x):
+        calls.append("fast")
+        return x * 2
+
+    @ImplBackend.entrypoint("demo_op")
+    def demo_op(x):
+        calls.append("eager")
+        return x
+
+    assert demo_op(3) == 6 and demo_op(-1) == -1 and calls == ["fast", "eager"]
+    assert ImplBackend.call("demo_fast", 5) == 10
+    with pytest.raises(ValueError):
+        ImplBackend.register("demo_op", req=lambda x: True, priority=0)(demo_fast)
+
+
+def test_greedy_bin_packing_matches_reference_rule(cta):
+    from compressed_tensors_amd.distributed import greedy_bin_packing, shard_items, shard_rows
+
+    items = list("abcdefg")
+    w = dict(zip(items, [7, 3, 5, 5, 2, 9, 1]))
+    sorted_items, bins, where = greedy_bin_packing(items, 3, w.__getitem__)
+    assert [w[i] for i in sorted_items] == sorted(w.values(), reverse=True)
+    loads = [sum(w[i] for i in b) for b in bins]
+    assert sum(loads) == sum(w.values()) and max(loads) - min(loads) <= 2
+    assert all(i in bins[where[i]] for i in items)
+    # TinyLlama-1.1B linear shapes: 154 modules over 8 ranks balance to <= one k_proj
+    shapes = ([(2048, 2048)] * 2 + [(256, 2048)] * 2 + [(5632, 2048)] * 2 + [(2048, 5632)]) * 22
+    per_rank = [sum(a * b for a, b in shard_items(shapes, lambda s: s[0] * s[1], rank=r, world_size=8)) for r in range(8)]
+    assert sum(per_rank) == 968884224 and max(per_rank) - min(per_rank) <= 256 * 2048
+    covered = [shard_rows(8192, rank=r, world_size=8, multiple=64) for r in range(8)]
+    assert covered[0][0] == 0 and covered[-1][1] == 8192 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    odd = [shard_rows(1000, rank=r, world_size=3) for r in range(3)]
+    assert [b - a for a, b in odd] == [334, 333, 333]
+
+
+def test_permutation_tables_host(cta):
+    perm, sp, sps = cta.utils.get_permutations_24(4)
+    assert perm.numel() == 1024 and sorted(perm.tolist()) == list(range(1024))
+    assert sp[:8] == [0, 4, 1, 5, 2, 6, 3, 7] and sps == list(range(64))
+    with pytest.raises(ValueError):
+        cta.utils.get_permutations_24(3)
+
+
+_DIST_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from compressed_tensors_amd.distributed import init_dist, rank_and_world, shard_modules, shard_rows, module_size
+init_dist()
+rank, world = rank_and_world()
+assert dist.get_backend() == "gloo" and world == 2
+mods = [torch.nn.Linear(8 * (i + 1), 16, bias=False) for i in range(7)]
+mine = shard_modules(mods)
+ids = torch.zeros(7, dtype=torch.int64)
+for m in mine:
+    ids[mods.index(m)] = 1
+# test-only all_reduce to verify the shards partition the work (the data path itself has no collective)
+dist.all_reduce(ids)
+assert ids.tolist() == [1] * 7, ids
+sizes = torch.tensor([sum(module_size(m) for m in mine)], dtype=torch.int64)
+gathered = [torch.zeros_like(sizes) for _ in range(world)]
+dist.all_gather(gathered, sizes)
+total = sum(int(g) for g in gathered)
+assert total == sum(module_size(m) for m in mods)
+a, b = shard_rows(1000)
+assert (a, b) == ((0, 500) if rank == 0 else (500, 1000))
+dist.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_world_size_2_sharding_gloo(tmp_path):
+    script = tmp_path / "dist_check.py"
+    script.write_text(_DIST_SCRIPT.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", "29731", str(script)],
+        capture_output=True, text=True, env=env, timeout=240,
+    )
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
