@@ -287,14 +287,22 @@ __global__ __launch_bounds__(kBlock) void unpack_dequant_g32_kernel(QParams p, i
 }
 
 // ------------------------------------------------------------------------------------------
-// HOT PATH — W4A16: 4-bit, 16-bit weights and scales of the same dtype, group/channel/tensor
-// scale shared by each 8-element unit (cdiv % 8 == 0), cols % 8 == 0.
+// HOT PATH — W4A16: 4-bit, 16-bit weights and scales of the same dtype.
 //
-// The tensor is one flat stream of 8-element units (16 B of bf16 <-> one packed int32 word:
-// the lane's 8 nibbles ARE word u of the row-major packed tensor, so no LDS staging or
-// cross-lane exchange is needed).  Each lane handles UNROLL units spaced one block-width
-// apart so every global access instruction is a contiguous 1 KiB (x) / 256 B (packed) run per
-// wave, with UNROLL independent 16-byte loads in flight per lane.
+// The tensor is one flat stream of 8-element units: 16 B of bf16 <-> one packed int32 word (a
+// lane's 8 nibbles ARE word u of the row-major packed tensor, so no cross-lane exchange is
+// needed).  Access shapes were chosen by measurement on MI355X (tools/kbench, profiles/):
+//   compress:   a lane owns 4 CONSECUTIVE units = 64 contiguous bytes in (4 x global_load_dwordx4)
+//               and ONE 16-byte store out.  Strided 16-byte loads cost nothing, 4-byte stores do:
+//               29.8-30.9 us vs 43 us for the unit-per-lane layout at 8192^2 (the 16B->4B copy
+//               ceiling on the same box is 29.6 us).
+//   decompress: a lane owns UNROLL units spaced one block apart: 4-byte loads (256 B contiguous
+//               per wave instruction) and 16-byte stores (1 KiB contiguous per wave instruction);
+//               strided stores are what hurts in this direction (49 us), UNROLL=2 is the optimum
+//               (30.1 us; 4B->16B copy ceiling 31.0 us).
+// VALU budget (compress is co-bound): 11 VALU ops per element with a zero point, 9 without —
+// packed multiplies, v_cvt_pk_bf16_f32 for the torch-style rounding to bf16, and the hardware
+// float->int conversion (saturating, NaN -> 0, exactly the reference's int8 cast) + v_med3_i32.
 // ------------------------------------------------------------------------------------------
 struct W4Params {
     const void* x;         // weight (compress) / packed words (decompress)
@@ -317,76 +325,104 @@ __device__ __forceinline__ int64_t w4_scale_index(const W4Params& p, int64_t u) 
     return (row / p.rdiv) * p.scale_cols + (p.upg_shift >= 0 ? (cu >> p.upg_shift) : (cu / p.upg));
 }
 
-template <int DT, bool FAST>
-__device__ __forceinline__ uint32_t w4_quant_word(const float (&v)[8], float s, bool has_zp, float z) {
-    const float rs = 1.0f / s;
-    uint32_t word = 0;
+// v_cvt_i32_f32: saturating, NaN -> 0.  Spelled as an instruction so that clang does not expand
+// the (well-defined under -fno-strict-float-cast-overflow) conversion into compare/select chains.
+__device__ __forceinline__ int cvt_i32_hw(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// two elements of a 16-bit pair as floats
+template <int DT>
+__device__ __forceinline__ void unpack2(uint32_t w, float& a, float& b) {
+    if constexpr (DT == CT_BF16) { a = bits_f(w << 16); b = bits_f(w & 0xffff0000u); }
+    else { a = f16_bits_to_f(w & 0xffffu); b = f16_bits_to_f(w >> 16); }
+}
+
+// round two floats to DT and back (one v_cvt_pk_bf16_f32 for bf16)
+template <int DT>
+__device__ __forceinline__ void round2(float& a, float& b) {
+    if constexpr (DT == CT_BF16) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef bf16_t b2 __attribute__((ext_vector_type(2)));
+        const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, b2));
+        a = bits_f(p << 16); b = bits_f(p & 0xffff0000u);
+    } else {
+        a = round_to<DT>(a); b = round_to<DT>(b);
+    }
+}
+
+// 8 weights (16 B) -> one packed word.  FAST: x * (1/s) instead of x / s — bit-identical after the
+// rounding to bf16 for every bf16 x and every bf16 s with 2^-64 <= |s| <= 2^64 (no quotient of two
+// 8-bit significands lies within 2^-17 relative of a bf16 rounding boundary, while the
+// two-rounding error of x * fl(1/s) is < 2^-22 relative); proven exhaustively on the device by
+// ct_selftest_bf16_div (tests/test_gpu_parity.py).  The codes are accumulated as
+// 0x88888888 + sum(code_k << 4k): code_k in [-8, 7], so the biased nibbles never carry.
+template <int DT, bool FAST, bool ZP>
+__device__ __forceinline__ uint32_t w4_quant_word(const u32x4& raw, float s, float rs, float z) {
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t word = 0x88888888u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        float q = FAST ? v[k] * rs : v[k] / s;
-        float t = round_to<DT>(q);
-        if (has_zp) t = round_to<DT>(t + z);
-        // clamp to [-8, 7] (fmax/fmin drop NaN, restored below), round half-even, bias by 8
-        float c = __builtin_fminf(__builtin_fmaxf(t, -8.0f), 7.0f);
-        int code = (int)__builtin_rintf(c) + 8;
-        code = (t != t) ? 8 : code;  // NaN quantizes to 0 in the reference's int8 cast
-        word |= (uint32_t)code << (4 * k);
+    for (int j = 0; j < 4; ++j) {
+        float x0, x1;
+        unpack2<DT>(ws[j], x0, x1);
+        float t0 = FAST ? x0 * rs : x0 / s, t1 = FAST ? x1 * rs : x1 / s;
+        round2<DT>(t0, t1);
+        if (ZP) {
+            t0 += z; t1 += z;
+            round2<DT>(t0, t1);
+        }
+        int c0 = cvt_i32_hw(__builtin_rintf(t0)), c1 = cvt_i32_hw(__builtin_rintf(t1));
+        c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);  // v_med3_i32
+        c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
+        word += (uint32_t)c0 << (8 * j);
+        word += (uint32_t)c1 << (8 * j + 4);
     }
     return word;
 }
 
-// FAST: hoist one reciprocal per unit.  Valid for DT == bf16 only: rnd_bf16(x * (1/s)) ==
-// rnd_bf16(x / s) for every bf16 x and every bf16 s with 2^-64 <= |s| <= 2^64 (no quotient of
-// two 8-bit significands lies within 2^-17 relative of a bf16 rounding boundary, while the
-// two-rounding error of x * fl(1/s) is < 2^-22 relative); proven exhaustively on the device by
-// ct_selftest_bf16_div (tests/test_gpu_parity.py).  Scales outside that range, zero, inf or
-// NaN take the IEEE divide.
-template <int DT, int UNROLL>
+// Q consecutive units per lane; SHARED: the Q units share one scale (cdiv % (8*Q) == 0)
+template <int DT, bool HAS_ZP, bool SHARED>
 __global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
-    const bool has_zp = p.zp != nullptr;
-    const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
-    uint32_t* out = static_cast<uint32_t*>(p.out);
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
-        u32x4 raw[UNROLL];
+    constexpr int Q = 4;
+    const int64_t groups = p.units / Q;  // host guarantees units % Q == 0
+    const u32x4* in = static_cast<const u32x4*>(p.x);
+    u32x4* out = static_cast<u32x4*>(p.out);
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        u32x4 r[Q];
 #pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u < p.units) raw[i] = reinterpret_cast<const u32x4*>(p.x)[u];
-        }
+        for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
+        uint32_t w[Q];
+        float s = 0.0f, z = 0.0f, rs = 0.0f;
+        bool fast = false, use_zp = false;
 #pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u >= p.units) continue;
-            const int64_t si = w4_scale_index(p, u);
-            const float s = load_as_f<DT>(p.scale, si);
-            const float z = has_zp ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
-            const uint32_t ws[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (DT == CT_BF16) {
-                    v[2 * j] = bits_f(ws[j] << 16);
-                    v[2 * j + 1] = bits_f(ws[j] & 0xffff0000u);
-                } else {
-                    v[2 * j] = f16_bits_to_f(ws[j] & 0xffffu);
-                    v[2 * j + 1] = f16_bits_to_f(ws[j] >> 16);
-                }
+        for (int i = 0; i < Q; ++i) {
+            if (i == 0 || !SHARED) {
+                const int64_t si = w4_scale_index(p, g * Q + i);
+                s = load_as_f<DT>(p.scale, si);
+                z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype)
+                const float as = __builtin_fabsf(s);
+                fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+                rs = 1.0f / s;
+                // adding an all-zero zero point is the identity (t is already rounded): skip the
+                // add + second rounding when every lane of the wave has z == 0 (symmetric schemes)
+                use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
             }
-            const float as = __builtin_fabsf(s);
-            const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
-            uint32_t word;
-            // a real branch (not a select): the IEEE divide is 11 VALU ops per element and must
-            // not be issued on the fast path; lanes of a wave almost always agree
-            if (fast) word = w4_quant_word<DT, true>(v, s, has_zp, z);
-            else word = w4_quant_word<DT, false>(v, s, has_zp, z);
-            out[u] = word;
+            // real branches (not selects): the IEEE divide is 11 VALU ops per element and must not
+            // be issued on the fast path; lanes of a wave almost always agree
+            if (fast) {
+                w[i] = use_zp ? w4_quant_word<DT, true, true>(r[i], s, rs, z) : w4_quant_word<DT, true, false>(r[i], s, rs, z);
+            } else {
+                w[i] = use_zp ? w4_quant_word<DT, false, true>(r[i], s, rs, z) : w4_quant_word<DT, false, false>(r[i], s, rs, z);
+            }
         }
+        out[g] = u32x4{w[0], w[1], w[2], w[3]};
     }
 }
 
-template <int DT, int UNROLL>
+template <int DT, int UNROLL, bool HAS_ZP>
 __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_kernel(W4Params p) {
-    const bool has_zp = p.zp != nullptr;
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
     const uint32_t* in = static_cast<const uint32_t*>(p.x);
     for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
@@ -402,12 +438,12 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_kernel(W4Params p) {
             if (u >= p.units) continue;
             const int64_t si = w4_scale_index(p, u);
             const float s = load_as_f<DT>(p.scale, si);
-            const float z = has_zp ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+            const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
             float v[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float q = (float)((int)((word[i] >> (4 * k)) & 0xfu) - 8);
-                v[k] = dequant_core<DT>(q, has_zp, z, s);
+                v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
             }
             store8<DT>(p.out, u * 8, v);
         }
@@ -547,10 +583,11 @@ static W4Params make_w4(const void* x, const void* scale, const void* zp, int zd
     return p;
 }
 
-static unsigned w4_grid(int64_t units, int unroll) {
-    int64_t g = cdiv64(units, (int64_t)kBlock * unroll);
-    int64_t cap = (int64_t)kCUs * 8 * 4;  // grid-stride beyond ~8k workgroups
-    if (g > cap) g = cap;
+static unsigned w4_grid(int64_t items, int unroll) {
+    // exact grids measured faster than capped + grid-stride on MI355X (tools/kbench); the stride
+    // loop only matters beyond 2^31 / kBlock workgroups
+    int64_t g = cdiv64(items, (int64_t)kBlock * unroll);
+    if (g > (int64_t)1 << 30) g = (int64_t)1 << 30;
     if (g < 1) g = 1;
     return (unsigned)g;
 }
@@ -619,12 +656,19 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
     int rc = fill_qparams(p, x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, packed, CT_I32);
     if (rc) return rc;
     if (rows == 0 || cols == 0) return CT_OK;
-    if (w4_eligible(xdt, sdt, tdt, bits, rows, cols, rdiv, cdiv, col_group, x, packed)) {
+    if (w4_eligible(xdt, sdt, tdt, bits, rows, cols, rdiv, cdiv, col_group, x, packed) && cols % 32 == 0) {
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
-        constexpr int U = 4;
-        dim3 grid(w4_grid(w.units, U));
-        if (xdt == CT_BF16) hipLaunchKernelGGL((w4_quant_pack_kernel<CT_BF16, U>), grid, dim3(kBlock), 0, as_stream(stream), w);
-        else hipLaunchKernelGGL((w4_quant_pack_kernel<CT_F16, U>), grid, dim3(kBlock), 0, as_stream(stream), w);
+        const bool shared = (cdiv % 32 == 0) || cdiv >= cols;  // 4 consecutive units share a scale
+        dim3 grid(w4_grid(w.units / 4, 1));
+#define CT_W4Q(DT, ZP, SH) hipLaunchKernelGGL((w4_quant_pack_kernel<DT, ZP, SH>), grid, dim3(kBlock), 0, as_stream(stream), w)
+        if (xdt == CT_BF16) {
+            if (zp) { if (shared) CT_W4Q(CT_BF16, true, true); else CT_W4Q(CT_BF16, true, false); }
+            else { if (shared) CT_W4Q(CT_BF16, false, true); else CT_W4Q(CT_BF16, false, false); }
+        } else {
+            if (zp) { if (shared) CT_W4Q(CT_F16, true, true); else CT_W4Q(CT_F16, true, false); }
+            else { if (shared) CT_W4Q(CT_F16, false, true); else CT_W4Q(CT_F16, false, false); }
+        }
+#undef CT_W4Q
         CT_LAUNCH_CHECK("ct_quant_pack[w4]");
     }
     p.vec = (cols % 8 == 0) && aligned16(x);
@@ -646,10 +690,15 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
     if (words == cols / 8 && w4_eligible(sdt, sdt, odt, bits, rows, cols, rdiv, cdiv, col_group, packed, out) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        constexpr int U = 4;
+        constexpr int U = 2;
         dim3 grid(w4_grid(w.units, U));
-        if (sdt == CT_BF16) hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U>), grid, dim3(kBlock), 0, as_stream(stream), w);
-        else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_F16, U>), grid, dim3(kBlock), 0, as_stream(stream), w);
+        if (sdt == CT_BF16) {
+            if (zp) hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U, true>), grid, dim3(kBlock), 0, as_stream(stream), w);
+            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U, false>), grid, dim3(kBlock), 0, as_stream(stream), w);
+        } else {
+            if (zp) hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_F16, U, true>), grid, dim3(kBlock), 0, as_stream(stream), w);
+            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_F16, U, false>), grid, dim3(kBlock), 0, as_stream(stream), w);
+        }
         CT_LAUNCH_CHECK("ct_unpack_dequant[w4]");
     }
     p.vec = (cols % 8 == 0) && aligned16(out);

@@ -5,16 +5,18 @@
 // compress:   values = x[x != 0] (row-major), bitmask, row_offsets = exclusive cumsum of row nnz
 // decompress: out = zeros; out[mask] = values
 //
-// Data movement design: every lane owns one 8-element unit (one bitmask byte, one 16-byte
-// vector of 16-bit elements).  Compaction/expansion goes through an LDS staging buffer per
-// 2048-element chunk so that ALL global traffic is contiguous wide accesses: the dense side is
-// 16 B/lane coalesced, the value side is a contiguous run per chunk copied with aligned 16-byte
-// vectors (scalar head/tail), and only LDS sees the 2-byte scattered accesses.
+// Data movement design: a workgroup owns one row "super-chunk" of 8192 columns; every lane owns
+// 4 units of 8 elements spaced one block apart (one bitmask byte and one 16-byte vector of 16-bit
+// elements each), so every dense-side access instruction is a contiguous 1 KiB per wave.
+// Ranks come from wavefront ballots: for bit position k of the lanes' mask bytes,
+// __ballot gives the 64-lane bit plane and v_mbcnt counts the set bits below the lane — 8 planes
+// give the exclusive prefix of a unit with no LDS traffic and no cross-lane dependency chain;
+// the per-wave totals are scalar popcounts.  Compaction/expansion goes through an LDS staging
+// buffer so that the value side is ONE contiguous run per super-chunk moved with aligned
+// 16-byte vectors (scalar head/tail); only LDS sees the 2-byte scattered accesses.
 #include "ct_common.h"
 
 namespace ct {
-
-constexpr int kChunk = kBlock * 8;  // elements per block iteration
 
 // ------------------------------------------------------------------------- element helpers
 template <int ES> struct ElemT;
@@ -80,31 +82,6 @@ __device__ __forceinline__ void store_unit_bits(void* base, int64_t i0, int n, b
     }
 }
 
-// ------------------------------------------------------------------------- block scan
-// exclusive prefix sum of one int per lane across the 256-lane block; returns the prefix and
-// writes the block total to *total.  wave scan by DPP-style shuffles, 4 wave totals via LDS.
-__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /*[4]*/, int* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-        int t = s_wave[w];
-        if (w < wave) wbase += t;
-        tot += t;
-    }
-    *total = tot;
-    __syncthreads();  // s_wave may be reused by the caller's next iteration
-    return wbase + inc - v;
-}
-
 // ------------------------------------------------------------------------- pack / unpack bitmasks
 __global__ __launch_bounds__(kBlock) void pack_bitmasks_kernel(const uint8_t* __restrict__ mask, int64_t rows, int64_t cols,
                                                                uint8_t* __restrict__ out) {
@@ -136,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void unpack_bitmasks_kernel(const uint8_t* 
 }
 
 // ------------------------------------------------------------------------- compress pass 1
-// one workgroup per row (grid-strided): bitmask bytes + row nnz
+// one workgroup per row (grid-strided): bitmask bytes + row nnz.  Streaming read, 16 B per lane.
 template <int ES>
 __global__ __launch_bounds__(kBlock) void bitmask_count_kernel(const void* __restrict__ x, bool is_float, int64_t rows, int64_t cols,
                                                                uint8_t* __restrict__ bitmask, int64_t* __restrict__ row_counts, int vec) {
@@ -145,16 +122,26 @@ __global__ __launch_bounds__(kBlock) void bitmask_count_kernel(const void* __res
     const int64_t bcols = (cols + 7) >> 3;
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         int cnt = 0;
-        for (int64_t u = threadIdx.x; u < bcols; u += kBlock) {
-            const int64_t c0 = u << 3;
-            const int n = (int)((cols - c0) < 8 ? (cols - c0) : 8);
-            T e[8];
-            load_unit<ES>(x, row * cols + c0, n, vec, e);
-            uint32_t m = 0;
+        for (int64_t u0 = 0; u0 < bcols; u0 += 4 * kBlock) {
+            T e[4][8];
+            int n[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) m |= (k < n && nz<ES>(e[k], is_float)) ? (1u << k) : 0u;
-            bitmask[row * bcols + u] = (uint8_t)m;
-            cnt += __popc(m);
+            for (int i = 0; i < 4; ++i) {
+                const int64_t u = u0 + (int64_t)i * kBlock + threadIdx.x;
+                const int64_t rem = cols - (u << 3);
+                n[i] = (u < bcols) ? (rem >= 8 ? 8 : (int)rem) : 0;
+                if (n[i] > 0) load_unit<ES>(x, row * cols + (u << 3), n[i], vec, e[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (n[i] <= 0) continue;
+                const int64_t u = u0 + (int64_t)i * kBlock + threadIdx.x;
+                uint32_t m = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m |= (k < n[i] && nz<ES>(e[i][k], is_float)) ? (1u << k) : 0u;
+                bitmask[row * bcols + u] = (uint8_t)m;
+                cnt += __popc(m);
+            }
         }
         // wave reduction, then 4 partials through LDS
 #pragma unroll
@@ -232,54 +219,101 @@ __global__ __launch_bounds__(1024) void exclusive_scan_i64_kernel(const int64_t*
     if (threadIdx.x == 0 && total) *total = s_carry;
 }
 
+// ------------------------------------------------------------------------- ballot ranks
+constexpr int kUPL = 4;                    // units per lane
+constexpr int kSuper = kBlock * kUPL * 8;  // columns per workgroup iteration (8192)
+
+// exclusive rank of this lane's unit among the wave's units (sum of mask popcounts of lower
+// lanes) and the wave total, from 8 ballot bit planes
+__device__ __forceinline__ void wave_rank(uint32_t m, uint32_t& pre, int& wave_total) {
+    pre = 0;
+    wave_total = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long plane = __ballot((m >> k) & 1u);
+        pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, pre));
+        wave_total += __popcll(plane);
+    }
+}
+
+// ranks of the kUPL units of every lane inside the super-chunk, in unit order i*kBlock + lane.
+// s_tot: [kUPL][waves] wave totals.  Returns the super-chunk total.
+__device__ __forceinline__ int superchunk_ranks(const uint32_t (&m)[kUPL], int (*s_tot)[kBlock / 64], uint32_t (&rank)[kUPL]) {
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kUPL; ++i) {
+        int wt;
+        wave_rank(m[i], rank[i], wt);
+        if ((threadIdx.x & 63) == 0) s_tot[i][wave] = wt;
+    }
+    __syncthreads();
+    int running = 0;
+#pragma unroll
+    for (int i = 0; i < kUPL; ++i) {
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const int t = s_tot[i][w];
+            if (w == wave) rank[i] += running;  // everything before (i, wave) in unit order
+            running += t;
+        }
+    }
+    return running;
+}
+
 // ------------------------------------------------------------------------- compress pass 2
-// one workgroup per row: compact each 2048-element chunk into LDS, then copy the contiguous
-// run to values[] with aligned 16-byte stores
+// one workgroup per row: compact each super-chunk into LDS, then copy the contiguous run to
+// values[] with aligned 16-byte stores
 template <int ES>
 __global__ __launch_bounds__(kBlock) void bitmask_scatter_kernel(const void* __restrict__ x, bool is_float, int64_t rows, int64_t cols,
                                                                  const int64_t* __restrict__ row_offsets, void* __restrict__ values, int vec) {
     typedef typename ElemT<ES>::type T;
-    __shared__ __attribute__((aligned(16))) T s_val[kChunk];
-    __shared__ int s_wave[kBlock / 64];
+    __shared__ __attribute__((aligned(16))) T s_val[kSuper];
+    __shared__ int s_tot[kUPL][kBlock / 64];
     T* vout = static_cast<T*>(values);
     constexpr int VE = 16 / ES;  // elements per 16-byte vector
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         int64_t run = row_offsets[row];
-        for (int64_t cbase = 0; cbase < cols; cbase += kChunk) {
-            const int64_t c0 = cbase + ((int64_t)threadIdx.x << 3);
-            int64_t rem = cols - c0;
-            const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
-            T e[8];
-            uint32_t m = 0;
-            if (n > 0) {
-                load_unit<ES>(x, row * cols + c0, n, vec, e);
+        for (int64_t cbase = 0; cbase < cols; cbase += kSuper) {
+            T e[kUPL][8];
+            uint32_t m[kUPL];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) m |= (k < n && nz<ES>(e[k], is_float)) ? (1u << k) : 0u;
+            for (int i = 0; i < kUPL; ++i) {
+                const int64_t c0 = cbase + (((int64_t)i * kBlock + threadIdx.x) << 3);
+                const int64_t rem = cols - c0;
+                const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
+                m[i] = 0;
+                if (n > 0) {
+                    load_unit<ES>(x, row * cols + c0, n, vec, e[i]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) m[i] |= (k < n && nz<ES>(e[i][k], is_float)) ? (1u << k) : 0u;
+                }
             }
-            int total;
-            const int pre = block_exclusive_scan(__popc(m), s_wave, &total);
-            int pos = pre;
+            uint32_t rank[kUPL];
+            const int total = superchunk_ranks(m, s_tot, rank);
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (m & (1u << k)) s_val[pos++] = e[k];
+            for (int i = 0; i < kUPL; ++i) {
+                int pos = (int)rank[i];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (m[i] & (1u << k)) s_val[pos++] = e[i][k];
+            }
             __syncthreads();
-            // copy s_val[0, total) -> vout[run, run+total): scalar head up to a 16-byte
-            // boundary of the destination, vector body, scalar tail
+            // copy s_val[0, total) -> vout[run, run+total): scalar head up to a 16-byte boundary
+            // of the destination, vector body (LDS side read element-wise: its start is not
+            // 16-byte aligned in general, and LDS is cheap while HBM is not), scalar tail
             const uintptr_t dst = reinterpret_cast<uintptr_t>(vout + run);
             int head = (int)(((16 - (dst & 15u)) & 15u) / ES);
             if (head > total) head = total;
-            // the LDS source of the vector body starts at s_val[head], which is not 16-byte
-            // aligned in general: read it element-wise and assemble (LDS is cheap, HBM is not)
             const int body_vecs = (total - head) / VE;
             for (int i = threadIdx.x; i < head; i += kBlock) vout[run + i] = s_val[i];
             for (int v = threadIdx.x; v < body_vecs; v += kBlock) {
-                const T* s = s_val + head + v * VE;
+                const T* sp = s_val + head + v * VE;
                 uint32_t w[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if constexpr (ES == 2) w[j] = (uint32_t)s[2 * j] | ((uint32_t)s[2 * j + 1] << 16);
-                    else if constexpr (ES == 4) w[j] = s[j];
-                    else w[j] = (uint32_t)s[4 * j] | ((uint32_t)s[4 * j + 1] << 8) | ((uint32_t)s[4 * j + 2] << 16) | ((uint32_t)s[4 * j + 3] << 24);
+                    if constexpr (ES == 2) w[j] = (uint32_t)sp[2 * j] | ((uint32_t)sp[2 * j + 1] << 16);
+                    else if constexpr (ES == 4) w[j] = sp[j];
+                    else w[j] = (uint32_t)sp[4 * j] | ((uint32_t)sp[4 * j + 1] << 8) | ((uint32_t)sp[4 * j + 2] << 16) | ((uint32_t)sp[4 * j + 3] << 24);
                 }
                 *reinterpret_cast<u32x4*>(vout + run + head + (int64_t)v * VE) = u32x4{w[0], w[1], w[2], w[3]};
             }
@@ -291,8 +325,10 @@ __global__ __launch_bounds__(kBlock) void bitmask_scatter_kernel(const void* __r
 }
 
 // ------------------------------------------------------------------------- decompress
-// one workgroup per row: stage the chunk's contiguous value run in LDS (aligned 16-byte
-// loads), then every lane expands its bitmask byte into one 16-byte dense store
+// one workgroup per row: stage the super-chunk's contiguous value run in LDS (aligned 16-byte
+// loads), then every lane expands its 4 bitmask bytes into four 16-byte dense stores.
+// When the row fits one super-chunk the run length is known up front (next row offset), so the
+// value loads are issued before the ballots/ranks and overlap them.
 template <int ES>
 __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* __restrict__ values, int64_t values_len,
                                                                     const uint8_t* __restrict__ bitmask,
@@ -301,55 +337,83 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
                                                                     int vec_in) {
     typedef typename ElemT<ES>::type T;
     constexpr int VE = 16 / ES;
-    __shared__ __attribute__((aligned(16))) T s_val[kChunk + 2 * VE];
-    __shared__ int s_wave[kBlock / 64];
+    __shared__ __attribute__((aligned(16))) T s_val[kSuper + 2 * VE];
+    __shared__ int s_tot[kUPL][kBlock / 64];
     const T* vin = static_cast<const T*>(values);
     const int64_t bcols = (cols + 7) >> 3;
+    const bool single = cols <= kSuper;
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
-        for (int64_t cbase = 0; cbase < cols; cbase += kChunk) {
-            const int64_t c0 = cbase + ((int64_t)threadIdx.x << 3);
-            int64_t rem = cols - c0;
-            const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
-            uint32_t m = 0;
-            if (n > 0) {
-                m = bitmask[row * bcols + (c0 >> 3)];
-                if (n < 8) m &= (1u << n) - 1u;
+        int64_t row_end = values_len;
+        if (single) {
+            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
+            else row_end = run + fixed_row_nnz;
+            if (row_end > values_len) row_end = values_len;
+            if (row_end < run) row_end = run;
+        }
+        for (int64_t cbase = 0; cbase < cols; cbase += kSuper) {
+            uint32_t m[kUPL];
+#pragma unroll
+            for (int i = 0; i < kUPL; ++i) {
+                const int64_t c0 = cbase + (((int64_t)i * kBlock + threadIdx.x) << 3);
+                const int64_t rem = cols - c0;
+                m[i] = 0;
+                if (rem > 0) {
+                    m[i] = bitmask[row * bcols + (c0 >> 3)];
+                    if (rem < 8) m[i] &= (1u << (int)rem) - 1u;
+                }
             }
-            int total;
-            const int pre = block_exclusive_scan(__popc(m), s_wave, &total);
-            // stage vin[run, run+total) at s_val[shift ...] where shift = run's offset inside
-            // its 16-byte vector, so that vector loads are aligned on the global side
-            const uintptr_t src = reinterpret_cast<uintptr_t>(vin + run);
-            const int shift = vec_in ? (int)((src & 15u) / ES) : 0;
-            if (vec_in) {
-                const int nvec = (shift + total + VE - 1) / VE;
-                const int64_t e0 = run - shift;  // element index of the first staged vector (>= 0)
-                const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
-                // the first/last vectors may straddle the run: the head stays inside the buffer
-                // because its base is 16-byte aligned; a tail vector that would cross the end of
-                // the buffer is read element-wise instead
-                for (int v = threadIdx.x; v < nvec; v += kBlock) {
-                    if (e0 + (int64_t)(v + 1) * VE <= values_len) {
-                        reinterpret_cast<u32x4*>(s_val)[v] = g[v];
-                    } else {
-                        for (int j = 0; j < VE; ++j) {
-                            const int64_t gi = e0 + (int64_t)v * VE + j;
-                            s_val[v * VE + j] = gi < values_len ? vin[gi] : (T)0;
+            // stage vin[run, run+len) at s_val[shift ...], shift = run's offset inside its 16-byte
+            // vector, so that the global side of the staging loads is aligned
+            auto stage = [&](int len) -> int {
+                const uintptr_t src = reinterpret_cast<uintptr_t>(vin + run);
+                const int shift = vec_in ? (int)((src & 15u) / ES) : 0;
+                if (vec_in) {
+                    const int nvec = (shift + len + VE - 1) / VE;
+                    const int64_t e0 = run - shift;  // >= 0: the buffer base is 16-byte aligned
+                    const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
+                    for (int v = threadIdx.x; v < nvec; v += kBlock) {
+                        if (e0 + (int64_t)(v + 1) * VE <= values_len) {
+                            reinterpret_cast<u32x4*>(s_val)[v] = g[v];
+                        } else {  // a tail vector that would cross the end of the buffer
+                            for (int j = 0; j < VE; ++j) {
+                                const int64_t gi = e0 + (int64_t)v * VE + j;
+                                s_val[v * VE + j] = gi < values_len ? vin[gi] : (T)0;
+                            }
                         }
                     }
+                } else {
+                    for (int i = threadIdx.x; i < len; i += kBlock) s_val[i] = vin[run + i];
                 }
-            } else {
-                for (int i = threadIdx.x; i < total; i += kBlock) s_val[i] = vin[run + i];
+                return shift;
+            };
+            int shift = 0;
+            if (single) {
+                int len = (int)(row_end - run);
+                if (len > kSuper) len = kSuper;
+                shift = stage(len);
+            }
+            uint32_t rank[kUPL];
+            const int total = superchunk_ranks(m, s_tot, rank);  // contains a __syncthreads
+            if (!single) {
+                int len = total;
+                if (run + len > values_len) len = (int)(values_len > run ? values_len - run : 0);
+                shift = stage(len);
             }
             __syncthreads();
-            if (n > 0) {
+#pragma unroll
+            for (int i = 0; i < kUPL; ++i) {
+                const int64_t c0 = cbase + (((int64_t)i * kBlock + threadIdx.x) << 3);
+                const int64_t rem = cols - c0;
+                const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
+                if (n == 0) continue;
                 T e[8];
-                int pos = shift + pre;
+                int pos = shift + (int)rank[i];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const bool on = (m >> k) & 1u;
-                    e[k] = on ? s_val[pos] : (T)0;
+                    const bool on = (m[i] >> k) & 1u;
+                    // a corrupt bitmask/offset pair must not read outside the staging buffer
+                    e[k] = (on && pos < kSuper + 2 * VE) ? s_val[pos] : (T)0;
                     pos += on ? 1 : 0;
                 }
                 store_unit_bits<ES>(out, row * cols + c0, n, vec_out, e);

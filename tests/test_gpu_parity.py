@@ -261,7 +261,12 @@ def test_w4a16_full_size(cta, dev, N):
     assert torch.equal(c["weight_packed"].cpu(), O.pack_to_int32(q_ref, 4))
     dd = cta.PackedQuantizationCompressor.decompress(c, scheme)
     assert dd["weight"].dtype == BF16 and dd["weight"].shape == (N, N)
-    assert eq(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, num_bits=4, strategy="group", group_size=128))
+    # bitwise against the oracle's decompress; VALUE equality (torch.equal, as the reference's own
+    # test does) against fake_quantize, whose -0.0 results come back as +0.0 through the int codes
+    ref_d = O.pack_quantized_decompress({"weight_packed": c["weight_packed"].cpu(), "weight_scale": scale, "weight_shape": c["weight_shape"]},
+                                        num_bits=4, strategy="group", symmetric=True)
+    assert eq(dd["weight"].cpu(), ref_d["weight"])
+    assert torch.equal(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, num_bits=4, strategy="group", group_size=128))
     # idempotence: re-compressing the decompressed weight reproduces the same words
     c2 = cta.PackedQuantizationCompressor.compress({**sd, "weight": dd["weight"]}, scheme)
     assert torch.equal(c2["weight_packed"], c["weight_packed"])
@@ -280,7 +285,8 @@ def test_int8_per_tensor_full_size(cta, dev):
     q_ref = O.quantize(w, scale, zp, num_bits=8, strategy="tensor", dtype=torch.int8)
     assert c["weight"].dtype == torch.int8 and torch.equal(c["weight"].cpu(), q_ref)
     dd = comp.decompress(c, scheme)
-    assert eq(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, num_bits=8, strategy="tensor"))
+    assert eq(dd["weight"].cpu(), O.dequantize(q_ref, scale, None))
+    assert torch.equal(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, num_bits=8, strategy="tensor"))
 
 
 # ----------------------------------------------------------------------------- sparse
@@ -389,7 +395,7 @@ def test_compress_decompress_module(cta, dev):
     assert lin.quantization_status == cta.QuantizationStatus.DECOMPRESSED
     assert lin.weight.dtype == BF16 and lin.weight.shape == (256, 256) and lin.weight_zero_point.dtype == torch.int8
     fq = O.fake_quantize(w0.cpu(), scale.cpu(), zp.cpu(), num_bits=4, strategy="group", group_size=128)
-    assert eq(lin.weight.data.cpu(), fq)
+    assert torch.equal(lin.weight.data.cpu(), fq)
 
 
 def test_model_compressor_roundtrip(cta, dev):
@@ -411,7 +417,7 @@ def test_model_compressor_roundtrip(cta, dev):
     assert y.shape == (4, 128) and not hasattr(model, "ct_decompress_hook")
     for name, m in model.named_modules():
         if isinstance(m, torch.nn.Linear):
-            assert eq(m.weight.data.cpu(), expect[name])
+            assert torch.equal(m.weight.data.cpu(), expect[name])
 
 
 def test_host_tensors_are_staged_through_the_gpu(cta, dev):

@@ -1,0 +1,365 @@
+// kbench.hip — developer micro-benchmark for kernel variants of the W4A16 hot path (not part of
+// the product library).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 kbench.hip -o kbench
+// Run on the GPU box: ./kbench [N]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <functional>
+#include <string>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16_t;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ float bits_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float rbf(float v) { return bits_f((uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)v) << 16); }
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef bf16_t b2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, b2));
+}
+
+// ---------------------------------------------------------------- calibration copies
+template <int U>
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < n; base += stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) if (base + i * 256 < n) v[i] = in[base + i * 256];
+#pragma unroll
+        for (int i = 0; i < U; ++i) if (base + i * 256 < n) out[base + i * 256] = v[i];
+    }
+}
+// read 4 B, write 16 B per lane (decompress-shaped traffic, no math)
+template <int U>
+__global__ __launch_bounds__(256) void expand_kernel(const uint32_t* __restrict__ in, u32x4* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < n; base += stride) {
+        uint32_t v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) if (base + i * 256 < n) v[i] = in[base + i * 256];
+#pragma unroll
+        for (int i = 0; i < U; ++i) if (base + i * 256 < n) out[base + i * 256] = u32x4{v[i], v[i] + 1, v[i] + 2, v[i] + 3};
+    }
+}
+// read 16 B, write 4 B per lane (compress-shaped traffic, no math)
+template <int U>
+__global__ __launch_bounds__(256) void reduce_kernel(const u32x4* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < n; base += stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) if (base + i * 256 < n) v[i] = in[base + i * 256];
+#pragma unroll
+        for (int i = 0; i < U; ++i) if (base + i * 256 < n) out[base + i * 256] = v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    }
+}
+
+// ---------------------------------------------------------------- decompress variants (bf16, g128 flat scale, no zp)
+__device__ __forceinline__ void dq8_store(uint32_t word, float s, uint16_t* out, int64_t u, bool nt) {
+    uint32_t ws[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = (float)((int)((word >> (8 * j)) & 0xfu) - 8) * s;
+        float b = (float)((int)((word >> (8 * j + 4)) & 0xfu) - 8) * s;
+        ws[j] = pk_bf16(a, b);
+    }
+    u32x4 v = u32x4{ws[0], ws[1], ws[2], ws[3]};
+    u32x4* p = reinterpret_cast<u32x4*>(out + u * 8);
+    if (nt) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+template <int U, int BLOCK, bool NT>
+__global__ __launch_bounds__(BLOCK) void dq_a(const uint32_t* __restrict__ in, const uint16_t* __restrict__ scale, uint16_t* __restrict__ out, int64_t units) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK * U;
+    for (int64_t base = (int64_t)blockIdx.x * BLOCK * U + threadIdx.x; base < units; base += stride) {
+        uint32_t w[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) { int64_t u = base + (int64_t)i * BLOCK; if (u < units) w[i] = NT ? __builtin_nontemporal_load(in + u) : in[u]; }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            int64_t u = base + (int64_t)i * BLOCK;
+            if (u >= units) continue;
+            float s = bits_f((uint32_t)scale[u >> 4] << 16);
+            dq8_store(w[i], s, out, u, NT);
+        }
+    }
+}
+
+// lane loads 4 consecutive words (16 B), writes 64 contiguous bytes (4 x 16 B)
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void dq_b(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, uint16_t* __restrict__ out, int64_t quads) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < quads; base += stride) {
+        u32x4 w[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) { int64_t q = base + (int64_t)i * 256; if (q < quads) w[i] = in[q]; }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            int64_t q = base + (int64_t)i * 256;
+            if (q >= quads) continue;
+            float s = bits_f((uint32_t)scale[q >> 2] << 16);
+            dq8_store(w[i].x, s, out, q * 4 + 0, NT);
+            dq8_store(w[i].y, s, out, q * 4 + 1, NT);
+            dq8_store(w[i].z, s, out, q * 4 + 2, NT);
+            dq8_store(w[i].w, s, out, q * 4 + 3, NT);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- compress variants (bf16, g128 flat scale)
+// production-like: explicit clamp + NaN select
+__device__ __forceinline__ uint32_t q8_word_ref(const u32x4& raw, float s, bool has_zp, float z) {
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    const float rs = 1.0f / s;
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float x = (k & 1) ? bits_f(ws[k >> 1] & 0xffff0000u) : bits_f(ws[k >> 1] << 16);
+        float t = rbf(x * rs);
+        if (has_zp) t = rbf(t + z);
+        float c = __builtin_fminf(__builtin_fmaxf(t, -8.0f), 7.0f);
+        int code = (int)__builtin_rintf(c) + 8;
+        code = (t != t) ? 8 : code;
+        word |= (uint32_t)code << (4 * k);
+    }
+    return word;
+}
+// lean: integer clamp after saturating convert (NaN -> 0 by v_cvt_i32_f32), shift-add accumulate
+__device__ __forceinline__ uint32_t q8_word_lean(const u32x4& raw, float rs, bool has_zp, float z) {
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t word = 0x88888888u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0 = bits_f(ws[j] << 16), x1 = bits_f(ws[j] & 0xffff0000u);
+        uint32_t p = pk_bf16(x0 * rs, x1 * rs);
+        float t0 = bits_f(p << 16), t1 = bits_f(p & 0xffff0000u);
+        if (has_zp) {
+            p = pk_bf16(t0 + z, t1 + z);
+            t0 = bits_f(p << 16); t1 = bits_f(p & 0xffff0000u);
+        }
+        int c0 = (int)__builtin_rintf(t0), c1 = (int)__builtin_rintf(t1);  // saturating, NaN -> 0 (-fno-strict-float-cast-overflow)
+        c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
+        c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
+        word += (uint32_t)c0 << (8 * j);
+        word += (uint32_t)c1 << (8 * j + 4);
+    }
+    return word;
+}
+
+template <int U, int MODE /*0 ref, 1 lean*/, bool ZP>
+__global__ __launch_bounds__(256) void q_a(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, const int8_t* __restrict__ zp,
+                                           uint32_t* __restrict__ out, int64_t units) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < units; base += stride) {
+        u32x4 raw[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) { int64_t u = base + (int64_t)i * 256; if (u < units) raw[i] = in[u]; }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            int64_t u = base + (int64_t)i * 256;
+            if (u >= units) continue;
+            float s = bits_f((uint32_t)scale[u >> 4] << 16);
+            float z = ZP ? (float)zp[u >> 4] : 0.0f;
+            if (MODE == 0) out[u] = q8_word_ref(raw[i], s, ZP, z);
+            else out[u] = q8_word_lean(raw[i], 1.0f / s, ZP, z);
+        }
+    }
+}
+
+// lane handles 4 consecutive units (64 B in, one 16 B store out)
+template <int U, bool ZP>
+__global__ __launch_bounds__(256) void q_b(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, const int8_t* __restrict__ zp,
+                                           u32x4* __restrict__ out, int64_t quads) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * U;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * U + threadIdx.x; base < quads; base += stride) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            int64_t q = base + (int64_t)i * 256;
+            if (q >= quads) continue;
+            u32x4 r0 = in[q * 4], r1 = in[q * 4 + 1], r2 = in[q * 4 + 2], r3 = in[q * 4 + 3];
+            float rs = 1.0f / bits_f((uint32_t)scale[q >> 2] << 16);
+            float z = ZP ? (float)zp[q >> 2] : 0.0f;
+            out[q] = u32x4{q8_word_lean(r0, rs, ZP, z), q8_word_lean(r1, rs, ZP, z), q8_word_lean(r2, rs, ZP, z), q8_word_lean(r3, rs, ZP, z)};
+        }
+    }
+}
+
+// wave-transposed: loads are lane-contiguous 16 B (1 KiB per wave instr), 4 per lane; the 4 words of
+// a lane are exchanged through LDS so that each lane stores 16 B contiguous
+template <bool ZP>
+__global__ __launch_bounds__(256) void q_c(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, const int8_t* __restrict__ zp,
+                                           u32x4* __restrict__ out, int64_t units) {
+    __shared__ uint32_t lds[1024];
+    const int64_t nblk = (units + 1023) / 1024;
+    for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        const int64_t u0 = b * 1024;
+        u32x4 raw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { int64_t u = u0 + i * 256 + threadIdx.x; if (u < units) raw[i] = in[u]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int64_t u = u0 + i * 256 + threadIdx.x;
+            if (u < units) {
+                float rs = 1.0f / bits_f((uint32_t)scale[u >> 4] << 16);
+                float z = ZP ? (float)zp[u >> 4] : 0.0f;
+                lds[i * 256 + threadIdx.x] = q8_word_lean(raw[i], rs, ZP, z);
+            }
+        }
+        __syncthreads();
+        int64_t q = (u0 >> 2) + threadIdx.x;
+        if (q * 4 < units) out[q] = reinterpret_cast<const u32x4*>(lds)[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------- q_d: q_b with hardware float->int (v_cvt_i32_f32 saturates, NaN -> 0)
+__device__ __forceinline__ int cvt_i32_hw(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+template <bool ZP>
+__device__ __forceinline__ uint32_t q8_word_hw(const u32x4& raw, float rs, float z) {
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t word = 0x88888888u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0 = bits_f(ws[j] << 16), x1 = bits_f(ws[j] & 0xffff0000u);
+        uint32_t p = pk_bf16(x0 * rs, x1 * rs);
+        float t0 = bits_f(p << 16), t1 = bits_f(p & 0xffff0000u);
+        if (ZP) {
+            p = pk_bf16(t0 + z, t1 + z);
+            t0 = bits_f(p << 16); t1 = bits_f(p & 0xffff0000u);
+        }
+        int c0 = cvt_i32_hw(__builtin_rintf(t0)), c1 = cvt_i32_hw(__builtin_rintf(t1));
+        c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
+        c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
+        word += (uint32_t)c0 << (8 * j);
+        word += (uint32_t)c1 << (8 * j + 4);
+    }
+    return word;
+}
+
+// Q = consecutive units per lane (4 -> one 16 B store; 8 -> two), ZPMODE: 0 none, 1 always, 2 wave-uniform skip when all zero
+template <int Q, int ZPMODE>
+__global__ __launch_bounds__(256) void q_d(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, const int8_t* __restrict__ zp,
+                                           u32x4* __restrict__ out, int64_t groups /* units / Q */) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += stride) {
+        u32x4 r[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
+        const int64_t si = (g * Q) >> 4;
+        const float rs = 1.0f / bits_f((uint32_t)scale[si] << 16);
+        float z = ZPMODE ? (float)zp[si] : 0.0f;
+        uint32_t w[Q];
+        bool use_zp = ZPMODE == 1;
+        if (ZPMODE == 2) use_zp = __builtin_amdgcn_ballot_w64(z != 0.0f) != 0;
+        if (use_zp) {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) w[i] = q8_word_hw<true>(r[i], rs, z);
+        } else {
+#pragma unroll
+            for (int i = 0; i < Q; ++i) w[i] = q8_word_hw<false>(r[i], rs, z);
+        }
+#pragma unroll
+        for (int i = 0; i < Q / 4; ++i) out[g * (Q / 4) + i] = u32x4{w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]};
+    }
+}
+
+// ---------------------------------------------------------------- host
+struct Bufs { void *w, *scale, *zp, *packed, *out; };
+
+int main(int argc, char** argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : 8192;
+    const int64_t elems = N * N, units = elems / 8;
+    const int NSETS = 4;
+    std::vector<Bufs> sets(NSETS);
+    std::vector<uint16_t> hw(elems), hs(elems / 128);
+    std::vector<int8_t> hz(elems / 128, 0);
+    srand(1);
+    for (int64_t i = 0; i < elems; ++i) { float f = ((rand() & 0xffff) / 65536.0f - 0.5f) * 4.0f; uint32_t u; memcpy(&u, &f, 4); hw[i] = (uint16_t)(u >> 16); }
+    for (int64_t i = 0; i < elems / 128; ++i) { float f = 0.25f + (rand() & 0xff) / 1024.0f; uint32_t u; memcpy(&u, &f, 4); hs[i] = (uint16_t)(u >> 16); }
+    for (auto& b : sets) {
+        CK(hipMalloc(&b.w, elems * 2)); CK(hipMalloc(&b.scale, elems / 128 * 2)); CK(hipMalloc(&b.zp, elems / 128));
+        CK(hipMalloc(&b.packed, elems / 2)); CK(hipMalloc(&b.out, elems * 2));
+        CK(hipMemcpy(b.w, hw.data(), elems * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.scale, hs.data(), elems / 128 * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.zp, hz.data(), elems / 128, hipMemcpyHostToDevice));
+        CK(hipMemset(b.packed, 0x5a, elems / 2));
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double alg = 2.0 * elems + 2.0 * elems / 128 + elems / 2.0;
+
+    auto run = [&](const char* name, double bytes, std::function<void(const Bufs&)> fn) {
+        for (int i = 0; i < 8; ++i) fn(sets[i % NSETS]);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f, tot = 0;
+        const int REP = 5, IT = 20;
+        for (int r = 0; r < REP; ++r) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < IT; ++i) fn(sets[i % NSETS]);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best; tot += ms;
+        }
+        CK(hipGetLastError());
+        double us = best * 1000.0 / IT, usavg = tot * 1000.0 / IT / REP;
+        printf("%-34s  best %7.2f us  avg %7.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)\n", name, us, usavg, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+    };
+    auto grid = [&](int64_t items, int per_block, int64_t cap) { int64_t g = (items + per_block - 1) / per_block; if (cap > 0 && g > cap) g = cap; return dim3((unsigned)g); };
+
+    printf("N=%lld  alg bytes/direction=%.0f\n", (long long)N, alg);
+    // calibration
+    run("copy16 U4 (84MB->84MB)", alg, [&](const Bufs& b) { int64_t n = (int64_t)(alg / 2 / 16); hipLaunchKernelGGL((copy16_kernel<4>), grid(n, 1024, 0), dim3(256), 0, 0, (const u32x4*)b.w, (u32x4*)b.out, n); });
+    run("copy16 U4 (128MB->128MB)", 4.0 * elems, [&](const Bufs& b) { int64_t n = elems * 2 / 16; hipLaunchKernelGGL((copy16_kernel<4>), grid(n, 1024, 0), dim3(256), 0, 0, (const u32x4*)b.w, (u32x4*)b.out, n); });
+    run("expand U4 (4B->16B)", alg, [&](const Bufs& b) { hipLaunchKernelGGL((expand_kernel<4>), grid(units, 1024, 0), dim3(256), 0, 0, (const uint32_t*)b.packed, (u32x4*)b.out, units); });
+    run("expand U8 (4B->16B)", alg, [&](const Bufs& b) { hipLaunchKernelGGL((expand_kernel<8>), grid(units, 2048, 0), dim3(256), 0, 0, (const uint32_t*)b.packed, (u32x4*)b.out, units); });
+    run("reduce U4 (16B->4B)", alg, [&](const Bufs& b) { hipLaunchKernelGGL((reduce_kernel<4>), grid(units, 1024, 0), dim3(256), 0, 0, (const u32x4*)b.w, (uint32_t*)b.packed, units); });
+    run("reduce U8 (16B->4B)", alg, [&](const Bufs& b) { hipLaunchKernelGGL((reduce_kernel<8>), grid(units, 2048, 0), dim3(256), 0, 0, (const u32x4*)b.w, (uint32_t*)b.packed, units); });
+    // decompress
+#define DQA(U, BLK, NT, CAP) run("dq_a U" #U " B" #BLK " nt" #NT " cap" #CAP, alg, [&](const Bufs& b) { hipLaunchKernelGGL((dq_a<U, BLK, NT>), grid(units, BLK * U, CAP), dim3(BLK), 0, 0, (const uint32_t*)b.packed, (const uint16_t*)b.scale, (uint16_t*)b.out, units); })
+    DQA(1, 256, false, 0); DQA(2, 256, false, 0); DQA(4, 256, false, 0); DQA(8, 256, false, 0); DQA(4, 256, false, 2048); DQA(4, 256, false, 8192);
+    DQA(4, 512, false, 0); DQA(4, 1024, false, 0); DQA(4, 256, true, 0); DQA(8, 256, true, 0);
+#define DQB(U, NT) run("dq_b U" #U " nt" #NT, alg, [&](const Bufs& b) { hipLaunchKernelGGL((dq_b<U, NT>), grid(units / 4, 256 * U, 0), dim3(256), 0, 0, (const u32x4*)b.packed, (const uint16_t*)b.scale, (uint16_t*)b.out, units / 4); })
+    DQB(1, false); DQB(2, false); DQB(1, true);
+    // compress
+#define QA(U, MODE, ZP, CAP) run("q_a U" #U " mode" #MODE " zp" #ZP " cap" #CAP, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_a<U, MODE, ZP>), grid(units, 256 * U, CAP), dim3(256), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (const int8_t*)b.zp, (uint32_t*)b.packed, units); })
+    QA(4, 0, true, 0); QA(4, 0, false, 0); QA(4, 1, true, 0); QA(4, 1, false, 0); QA(2, 1, true, 0); QA(8, 1, true, 0); QA(1, 1, true, 0); QA(4, 1, true, 8192);
+#define QB(U, ZP) run("q_b U" #U " zp" #ZP, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_b<U, ZP>), grid(units / 4, 256 * U, 0), dim3(256), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (const int8_t*)b.zp, (u32x4*)b.packed, units / 4); })
+    QB(1, true); QB(1, false); QB(2, true);
+#define QD(Q, ZM, CAP) run("q_d Q" #Q " zpmode" #ZM " cap" #CAP, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_d<Q, ZM>), grid(units / Q, 256, CAP), dim3(256), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (const int8_t*)b.zp, (u32x4*)b.packed, units / Q); })
+    QD(4, 0, 0); QD(4, 1, 0); QD(4, 2, 0); QD(8, 2, 0); QD(8, 1, 0); QD(4, 2, 4096); QD(4, 2, 2048); QD(16, 2, 0);
+    run("q_c lds-transpose zp1", alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_c<true>), grid(units, 1024, 0), dim3(256), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (const int8_t*)b.zp, (u32x4*)b.packed, units); });
+    run("q_c lds-transpose zp0", alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_c<false>), grid(units, 1024, 0), dim3(256), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (const int8_t*)b.zp, (u32x4*)b.packed, units); });
+
+    // cross-check lean vs ref and q_b/q_c vs q_a on set 0
+    {
+        std::vector<uint32_t> a(units), b2(units);
+        hipLaunchKernelGGL((q_a<4, 0, true>), grid(units, 1024, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (uint32_t*)sets[0].packed, units);
+        CK(hipMemcpy(a.data(), sets[0].packed, units * 4, hipMemcpyDeviceToHost));
+        const char* names[6] = {"q_a lean", "q_b", "q_c", "q_d4 zp1", "q_d4 zp2", "q_d8 zp2"};
+        for (int v = 0; v < 6; ++v) {
+            CK(hipMemset(sets[1].packed, 0, units * 4));
+            if (v == 0) hipLaunchKernelGGL((q_a<4, 1, true>), grid(units, 1024, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (uint32_t*)sets[1].packed, units);
+            if (v == 1) hipLaunchKernelGGL((q_b<1, true>), grid(units / 4, 256, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (u32x4*)sets[1].packed, units / 4);
+            if (v == 2) hipLaunchKernelGGL((q_c<true>), grid(units, 1024, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (u32x4*)sets[1].packed, units);
+            if (v == 3) hipLaunchKernelGGL((q_d<4, 1>), grid(units / 4, 256, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (u32x4*)sets[1].packed, units / 4);
+            if (v == 4) hipLaunchKernelGGL((q_d<4, 2>), grid(units / 4, 256, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (u32x4*)sets[1].packed, units / 4);
+            if (v == 5) hipLaunchKernelGGL((q_d<8, 2>), grid(units / 8, 256, 0), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (const int8_t*)sets[0].zp, (u32x4*)sets[1].packed, units / 8);
+            CK(hipMemcpy(b2.data(), sets[1].packed, units * 4, hipMemcpyDeviceToHost));
+            int64_t bad = 0; for (int64_t i = 0; i < units; ++i) bad += a[i] != b2[i];
+            printf("check %-10s vs ref: %lld mismatching words\n", names[v], (long long)bad);
+        }
+    }
+    return 0;
+}
