@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 results database (rocpd sqlite) into a small text table:
+per-kernel call count / average duration, and (if present) per-kernel PMC counter averages.
+
+    python tools/prof_summary.py gpurun_out/prof/run_results.db [--all] > profiles/xyz.txt
+
+Only kernels of this library (ct::*) are listed unless --all is given; names are shortened."""
+import re
+import sqlite3
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"\(.*$", "", name)          # drop the argument list
+    name = name.replace("void ", "")
+    return name if len(name) <= 90 else name[:87] + "..."
+
+
+def main():
+    path = sys.argv[1]
+    show_all = "--all" in sys.argv
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    flt = "" if show_all else "where name like '%ct::%'"
+    rows = list(cur.execute(
+        f"select name, count(*), avg(duration), min(duration), max(duration), sum(duration), "
+        f"max(grid_x), max(workgroup_x), max(vgpr_count), max(sgpr_count), max(lds_size) from kernels {flt} group by name order by sum(duration) desc"))
+    print(f"# rocprofv3 kernel-trace summary of {path}")
+    print(f"{'kernel':<92} {'calls':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'grid':>9} {'wg':>5} {'vgpr':>5} {'sgpr':>5} {'lds':>6}")
+    for name, n, avg, mn, mx, tot, gx, wx, vg, sg, lds in rows:
+        print(f"{short(name):<92} {n:>6} {avg/1e3:>9.2f} {mn/1e3:>9.2f} {mx/1e3:>9.2f} {gx:>9} {wx:>5} {vg:>5} {sg:>5} {lds:>6}")
+    try:
+        flt2 = "" if show_all else "where kernel_name like '%ct::%'"
+        crow = list(cur.execute(
+            f"select kernel_name, counter_name, count(*), avg(value) from counters_collection {flt2} group by kernel_name, counter_name order by kernel_name, counter_name"))
+    except sqlite3.Error:
+        crow = []
+    if crow:
+        print("\n# PMC counters: average value per dispatch")
+        print(f"{'kernel':<92} {'counter':<24} {'dispatches':>10} {'avg_value':>16}")
+        for name, cname, n, avg in crow:
+            print(f"{short(name):<92} {cname:<24} {n:>10} {avg:>16.1f}")
+
+
+if __name__ == "__main__":
+    main()
