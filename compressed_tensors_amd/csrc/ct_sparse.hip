@@ -185,7 +185,8 @@ __global__ __launch_bounds__(kBlock) void bitmask_row_popcount_kernel(const uint
     }
 }
 
-// single-workgroup exclusive scan of int64 counts (n is the number of rows: small)
+// single-workgroup exclusive scan of int64 counts: every lane owns 8 consecutive counts per
+// 8192-element tile (vector loads), wave scan by shuffles, 16 wave totals through LDS
 __global__ __launch_bounds__(1024) void exclusive_scan_i64_kernel(const int64_t* __restrict__ counts, int64_t n,
                                                                   int64_t* __restrict__ offsets, int64_t* __restrict__ total) {
     __shared__ int64_t s_wave[16];
@@ -193,10 +194,16 @@ __global__ __launch_bounds__(1024) void exclusive_scan_i64_kernel(const int64_t*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t v = i < n ? counts[i] : 0;
-        int64_t inc = v;
+    constexpr int PER = 8;
+    for (int64_t base = 0; base < n; base += 1024 * PER) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * PER;
+        int64_t v[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) v[k] = (i0 + k < n) ? counts[i0 + k] : 0;
+        int64_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) sum += v[k];
+        int64_t inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             int64_t t = __shfl_up(inc, d, 64);
@@ -211,7 +218,12 @@ __global__ __launch_bounds__(1024) void exclusive_scan_i64_kernel(const int64_t*
             if (w < wave) wbase += t;
             tot += t;
         }
-        if (i < n) offsets[i] = wbase + inc - v;
+        int64_t run = wbase + inc - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (i0 + k < n) offsets[i0 + k] = run;
+            run += v[k];
+        }
         __syncthreads();
         if (threadIdx.x == 0) s_carry += tot;
         __syncthreads();
@@ -325,10 +337,34 @@ __global__ __launch_bounds__(kBlock) void bitmask_scatter_kernel(const void* __r
 }
 
 // ------------------------------------------------------------------------- decompress
-// one workgroup per row: stage the super-chunk's contiguous value run in LDS (aligned 16-byte
-// loads), then every lane expands its 4 bitmask bytes into four 16-byte dense stores.
+// per-workgroup lookup tables indexed by a bitmask byte: rank of each of its 8 bits (8 bytes) and,
+// for 16-bit payloads, the four dword masks that zero the elements whose bit is clear
+struct ExpandLut {
+    uint32_t rank[256 * 2];
+    uint32_t keep[256 * 4];
+};
+
+__device__ __forceinline__ void build_expand_lut(ExpandLut& lut) {
+    const uint32_t mv = threadIdx.x;  // kBlock == 256 entries
+    uint32_t r_lo = 0, r_hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t rk = __popc(mv & ((1u << k) - 1u));
+        if (k < 4) r_lo |= rk << (8 * k);
+        else r_hi |= rk << (8 * (k - 4));
+    }
+    lut.rank[mv * 2] = r_lo;
+    lut.rank[mv * 2 + 1] = r_hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        lut.keep[mv * 4 + j] = (((mv >> (2 * j)) & 1u) ? 0xffffu : 0u) | (((mv >> (2 * j + 1)) & 1u) ? 0xffff0000u : 0u);
+}
+
+// one workgroup per row: the super-chunk's contiguous value run is staged in LDS with aligned
+// 16-byte loads, then every lane expands its 4 bitmask bytes into four 16-byte dense stores using
+// the lookup tables (8 LDS gathers + 2 table reads per unit, ~4 VALU ops per element).
 // When the row fits one super-chunk the run length is known up front (next row offset), so the
-// value loads are issued before the ballots/ranks and overlap them.
+// value loads are issued together with the mask loads and overlap the ballots/ranks.
 template <int ES>
 __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* __restrict__ values, int64_t values_len,
                                                                     const uint8_t* __restrict__ bitmask,
@@ -337,8 +373,11 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
                                                                     int vec_in) {
     typedef typename ElemT<ES>::type T;
     constexpr int VE = 16 / ES;
-    __shared__ __attribute__((aligned(16))) T s_val[kSuper + 2 * VE];
+    constexpr int kStage = kSuper + 2 * VE;
+    __shared__ __attribute__((aligned(16))) T s_val[kStage];
+    __shared__ __attribute__((aligned(16))) ExpandLut s_lut;
     __shared__ int s_tot[kUPL][kBlock / 64];
+    build_expand_lut(s_lut);  // visible after the first __syncthreads below
     const T* vin = static_cast<const T*>(values);
     const int64_t bcols = (cols + 7) >> 3;
     const bool single = cols <= kSuper;
@@ -399,22 +438,44 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
                 int len = total;
                 if (run + len > values_len) len = (int)(values_len > run ? values_len - run : 0);
                 shift = stage(len);
+                __syncthreads();
             }
-            __syncthreads();
 #pragma unroll
             for (int i = 0; i < kUPL; ++i) {
                 const int64_t c0 = cbase + (((int64_t)i * kBlock + threadIdx.x) << 3);
                 const int64_t rem = cols - c0;
                 const int n = rem >= 8 ? 8 : (rem > 0 ? (int)rem : 0);
                 if (n == 0) continue;
+                const uint32_t mv = m[i];
+                const u32x2 rk = *reinterpret_cast<const u32x2*>(&s_lut.rank[mv * 2]);
+                // a corrupt bitmask / offset pair must not read outside the staging buffer
+                int p = shift + (int)rank[i];
+                p = p > kStage - 8 ? kStage - 8 : p;
+                const T* sp = s_val + p;
                 T e[8];
-                int pos = shift + (int)rank[i];
+                if constexpr (ES == 2) {
+                    const u32x4 keep = *reinterpret_cast<const u32x4*>(&s_lut.keep[mv * 4]);
+                    const uint32_t kk[4] = {keep.x, keep.y, keep.z, keep.w};
+                    uint32_t w[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool on = (m[i] >> k) & 1u;
-                    // a corrupt bitmask/offset pair must not read outside the staging buffer
-                    e[k] = (on && pos < kSuper + 2 * VE) ? s_val[pos] : (T)0;
-                    pos += on ? 1 : 0;
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t rr = j < 2 ? rk.x : rk.y;
+                        const uint32_t r0 = (rr >> (16 * (j & 1))) & 0xffu, r1 = (rr >> (16 * (j & 1) + 8)) & 0xffu;
+                        w[j] = ((uint32_t)sp[r0] | ((uint32_t)sp[r1] << 16)) & kk[j];
+                    }
+                    if (vec_out && n == 8) {
+                        *reinterpret_cast<u32x4*>(static_cast<T*>(out) + row * cols + c0) = u32x4{w[0], w[1], w[2], w[3]};
+                        continue;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { e[2 * j] = (T)(w[j] & 0xffffu); e[2 * j + 1] = (T)(w[j] >> 16); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const uint32_t r = ((k < 4 ? rk.x : rk.y) >> (8 * (k & 3))) & 0xffu;
+                        const T v = sp[r];
+                        e[k] = ((mv >> k) & 1u) ? v : (T)0;
+                    }
                 }
                 store_unit_bits<ES>(out, row * cols + c0, n, vec_out, e);
             }
@@ -577,7 +638,9 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
     // aligned 16-byte loads of the value runs need a 16-byte aligned base; vectors that would
     // cross values_len are read element-wise in the kernel
     const int vec_in = aligned16(values);
-    CT_ES_SWITCH(es, hipLaunchKernelGGL((bitmask_decompress_kernel<ES>), dim3(grid_rows_1d(rows)), dim3(kBlock), 0, as_stream(stream), values,
+    // 4096 resident-ish workgroups, grid-strided over rows: measured best on MI355X (tools/kbench)
+    const unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);
+    CT_ES_SWITCH(es, hipLaunchKernelGGL((bitmask_decompress_kernel<ES>), dim3(grid), dim3(kBlock), 0, as_stream(stream), values,
                                         values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, out, vec_out, vec_in));
     CT_LAUNCH_CHECK("ct_bitmask_decompress");
 }
