@@ -85,8 +85,8 @@ __global__ __launch_bounds__(kBlock) void unpack_rows_kernel(const int32_t* __re
                 for (int i = 0; i < 32; ++i)
                     ws[i >> 2] |= ((uint32_t)unpack_extract<BITS>(words, i) & 0xffu) << (8 * (i & 3));
                 u32x4* o = reinterpret_cast<u32x4*>(orow + c0);
-                o[0] = u32x4{ws[0], ws[1], ws[2], ws[3]};
-                o[1] = u32x4{ws[4], ws[5], ws[6], ws[7]};
+                stream_store16(o, u32x4{ws[0], ws[1], ws[2], ws[3]});
+                stream_store16(o + 1, u32x4{ws[4], ws[5], ws[6], ws[7]});
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i)

@@ -87,7 +87,7 @@ __device__ __forceinline__ void store_unit(void* out, int odt, int64_t i0, const
                     lo |= ((uint32_t)(int)v[k] & 0xffu) << (8 * k);
                     hi |= ((uint32_t)(int)v[4 + k] & 0xffu) << (8 * k);
                 }
-                *reinterpret_cast<u32x2*>(static_cast<int8_t*>(out) + i0) = u32x2{lo, hi};
+                stream_store8(static_cast<int8_t*>(out) + i0, u32x2{lo, hi});
                 return;
             }
             default: break;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
                 w[i] = use_zp ? w4_quant_word<DT, false, true>(r[i], s, rs, z) : w4_quant_word<DT, false, false>(r[i], s, rs, z);
             }
         }
-        out[g] = u32x4{w[0], w[1], w[2], w[3]};
+        stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
     }
 }
 

@@ -65,16 +65,16 @@ __device__ __forceinline__ void store_unit_bits(void* base, int64_t i0, int n, b
     T* p = static_cast<T*>(base) + i0;
     if (vec && n == 8) {
         if constexpr (ES == 2) {
-            *reinterpret_cast<u32x4*>(p) = u32x4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
-                                                 (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)};
+            stream_store16(p, u32x4{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                                    (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16)});
         } else if constexpr (ES == 4) {
-            reinterpret_cast<u32x4*>(p)[0] = u32x4{e[0], e[1], e[2], e[3]};
-            reinterpret_cast<u32x4*>(p)[1] = u32x4{e[4], e[5], e[6], e[7]};
+            stream_store16(p, u32x4{e[0], e[1], e[2], e[3]});
+            stream_store16(p + 4, u32x4{e[4], e[5], e[6], e[7]});
         } else {
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { lo |= (uint32_t)e[k] << (8 * k); hi |= (uint32_t)e[4 + k] << (8 * k); }
-            *reinterpret_cast<u32x2*>(p) = u32x2{lo, hi};
+            stream_store8(p, u32x2{lo, hi});
         }
     } else {
 #pragma unroll
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_scatter_kernel(const void* __r
                     else if constexpr (ES == 4) w[j] = sp[j];
                     else w[j] = (uint32_t)sp[4 * j] | ((uint32_t)sp[4 * j + 1] << 8) | ((uint32_t)sp[4 * j + 2] << 16) | ((uint32_t)sp[4 * j + 3] << 24);
                 }
-                *reinterpret_cast<u32x4*>(vout + run + head + (int64_t)v * VE) = u32x4{w[0], w[1], w[2], w[3]};
+                stream_store16(vout + run + head + (int64_t)v * VE, u32x4{w[0], w[1], w[2], w[3]});
             }
             for (int i = head + body_vecs * VE + threadIdx.x; i < total; i += kBlock) vout[run + i] = s_val[i];
             run += total;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
                         w[j] = ((uint32_t)sp[r0] | ((uint32_t)sp[r1] << 16)) & kk[j];
                     }
                     if (vec_out && n == 8) {
-                        *reinterpret_cast<u32x4*>(static_cast<T*>(out) + row * cols + c0) = u32x4{w[0], w[1], w[2], w[3]};
+                        stream_store16(static_cast<T*>(out) + row * cols + c0, u32x4{w[0], w[1], w[2], w[3]});
                         continue;
                     }
 #pragma unroll
