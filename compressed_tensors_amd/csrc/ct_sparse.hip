@@ -485,6 +485,192 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
     }
 }
 
+// ------------------------------------------------------------------------- decompress, 16-bit fast path
+// The generic kernel above ranks with 8 ballot planes per unit and gathers element by element
+// (~25 VALU lane-ops per element: the kernel was issue-bound, not bandwidth-bound).  For 16-bit
+// payloads with cols % 32 == 0 this kernel does the same job in ~5:
+//  * mask side: a lane loads ONE dword of the bitmask (4 consecutive units), popcounts it; a DPP
+//    wave scan + 4 wave totals give every unit's rank; the owner lane publishes
+//    (rank << 8 | mask byte) per unit in LDS and the consumer lane (unit i*256 + tid, so that every
+//    wave store instruction writes 1 KiB contiguous) reads it back.
+//  * value side: output dword j of a unit (elements 2j, 2j+1) is a 32-bit WINDOW of the staged
+//    value run starting at element q_j = rank + popc(m & ((1 << 2j) - 1)): two aligned LDS dwords
+//    (one ds_read2_b32) and ONE v_perm_b32 whose selector — a LUT keyed by the mask byte and the
+//    parity of the rank — does the funnel shift, places a lone element in the right half and
+//    zeroes the rest.
+// A tile is 8192 columns of one row.  SINGLE (cols <= 8192): the run length is known from the row
+// offsets, so the value loads are issued together with the mask load and there is one barrier.
+// Otherwise the tile's start inside the row is the popcount of the row's earlier mask bytes and
+// the values are staged after the ranks (two barriers).
+// Every LDS address is derived from the mask alone (rank <= 8192), so corrupt offsets can produce
+// wrong data but never an out-of-range access; global reads are guarded by values_len.
+constexpr int kTile16 = 8192;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+struct Expand16Lut {
+    uint32_t sel[2 * 256 * 4];  // [rank parity][mask byte][output dword]: v_perm_b32 selector
+    uint32_t off[256];          // byte j: 2 * popc(mask & ((1 << 2j) - 1)) = byte offset of window j
+};
+
+__device__ __forceinline__ void build_expand16_lut(Expand16Lut& lut) {
+    const uint32_t mv = threadIdx.x;  // kBlock == 256 entries
+    uint32_t off = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t pj = __popc(mv & ((1u << (2 * j)) - 1u));
+        off |= (2u * pj) << (8 * j);
+        const uint32_t b0 = (mv >> (2 * j)) & 1u, b1 = (mv >> (2 * j + 1)) & 1u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const uint32_t x = (p + pj) & 1u;            // window starts at byte 2 of the low dword
+            const uint32_t w01 = x ? 0x0302u : 0x0100u;  // selectors of window bytes 0, 1
+            const uint32_t w23 = x ? 0x0504u : 0x0302u;  // window bytes 2, 3
+            uint32_t sel;
+            if (b0 && b1) sel = w01 | (w23 << 16);
+            else if (b0) sel = w01 | 0x0c0c0000u;        // 0x0c selects the constant 0x00
+            else if (b1) sel = 0x0c0cu | (w01 << 16);
+            else sel = 0x0c0c0c0cu;
+            lut.sel[(p * 256 + mv) * 4 + j] = sel;
+        }
+    }
+    lut.off[mv] = off;
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len,
+                                                                      const uint8_t* __restrict__ bitmask,
+                                                                      const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz,
+                                                                      int64_t rows, int64_t cols, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_val[kTile16 + 32];
+    __shared__ __attribute__((aligned(16))) Expand16Lut s_lut;
+    __shared__ __attribute__((aligned(16))) uint32_t s_unit[kTile16 / 8];
+    __shared__ __attribute__((aligned(16))) int s_tot[4];
+    __shared__ __attribute__((aligned(16))) int s_pre[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    build_expand16_lut(s_lut);  // visible after the first barrier below
+    const int64_t bcols = cols >> 3;
+    const int64_t tiles_per_row = (cols + kTile16 - 1) / kTile16;
+    const int64_t ntiles = rows * tiles_per_row;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = SINGLE ? tile : tile / tiles_per_row;
+        const int64_t u0 = SINGLE ? 0 : (tile - row * tiles_per_row) * (kTile16 / 8);  // first unit of the tile in its row
+        const int64_t left = bcols - u0;
+        const int nu = left < kTile16 / 8 ? (int)left : kTile16 / 8;                    // units in this tile (multiple of 4)
+        const uint8_t* mrow = bitmask + row * bcols;
+        const uint32_t md = (4 * tid < nu) ? *reinterpret_cast<const uint32_t*>(mrow + u0 + 4 * tid) : 0u;
+        int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
+        run = run < 0 ? 0 : (run > values_len ? values_len : run);
+
+        // stage vin[run, run + total) at s_val[shift ...]; shift = offset of `run` inside its 16-byte
+        // vector, so that the global side of the staging loads is aligned
+        int shift = 0, nvec = 0;
+        int64_t e0 = 0;
+        u32x4 vv[4];
+        auto stage_issue = [&](int total) {
+            shift = (int)(run & 7);
+            nvec = (shift + total + 7) >> 3;
+            e0 = run - shift;
+            const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = tid + k * kBlock;
+                if (v < nvec && e0 + (int64_t)(v + 1) * 8 <= values_len) vv[k] = g[v];
+            }
+        };
+        auto stage_commit = [&]() {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = tid + k * kBlock;
+                if (v < nvec) {
+                    if (e0 + (int64_t)(v + 1) * 8 <= values_len) {
+                        reinterpret_cast<u32x4*>(s_val)[v] = vv[k];
+                    } else {  // a tail vector that would cross the end of the buffer
+                        for (int j = 0; j < 8; ++j) {
+                            const int64_t gi = e0 + (int64_t)v * 8 + j;
+                            s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
+                        }
+                    }
+                }
+            }
+            if (tid == 0 && 4 * kBlock < nvec) {  // the one possible 1025th vector (shift > 0, full tile)
+                const int v = 4 * kBlock;
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t gi = e0 + (int64_t)v * 8 + j;
+                    s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
+                }
+            }
+        };
+
+        if constexpr (SINGLE) {
+            int64_t row_end = values_len;
+            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
+            else row_end = run + fixed_row_nnz;
+            int64_t len = row_end - run;
+            len = len < 0 ? 0 : (len > kTile16 ? kTile16 : len);
+            stage_issue((int)len);
+        } else {
+            // popcount of the row's mask bytes before this tile
+            int c = 0;
+            for (int64_t d = tid; d < (u0 >> 2); d += kBlock) c += __popc(reinterpret_cast<const uint32_t*>(mrow)[d]);
+            c = wave_incl_scan(c);
+            if (lane == 63) s_pre[wave] = c;
+        }
+
+        // ranks: wave-local exclusive prefix of the lane's dword + popcounts of its lower bytes
+        const int c = __popc(md);
+        const int incl = wave_incl_scan(c);
+        if (lane == 63) s_tot[wave] = incl;
+        const uint32_t r0 = (uint32_t)(incl - c);
+        const uint32_t r1 = r0 + __popc(md & 0xffu), r2 = r0 + __popc(md & 0xffffu), r3 = r0 + __popc(md & 0xffffffu);
+        reinterpret_cast<u32x4*>(s_unit)[tid] = u32x4{(r0 << 8) | (md & 0xffu), (r1 << 8) | ((md >> 8) & 0xffu),
+                                                      (r2 << 8) | ((md >> 16) & 0xffu), (r3 << 8) | (md >> 24)};
+        if constexpr (SINGLE) stage_commit();
+        __syncthreads();
+        const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2], t3 = s_tot[3];
+        if constexpr (!SINGLE) {
+            run += (int64_t)s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+            run = run > values_len ? values_len : run;
+            stage_issue(t0 + t1 + t2 + t3);
+            stage_commit();
+            __syncthreads();
+        }
+        // the owner lane of unit u = i*256 + tid is lane u/4 = i*64 + tid/4: wave i
+        const int wbase[4] = {0, t0, t0 + t1, t0 + t1 + t2};
+        const char* sv = reinterpret_cast<const char*>(s_val);
+        uint16_t* orow = out + row * cols + (u0 << 3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = i * kBlock + tid;
+            if (u >= nu) continue;
+            const uint32_t info = s_unit[u];
+            const uint32_t mv = info & 0xffu;
+            const uint32_t r = (info >> 8) + (uint32_t)(wbase[i] + shift);
+            const u32x4 sel = *reinterpret_cast<const u32x4*>(&s_lut.sel[((r & 1u) * 256 + mv) * 4]);
+            const uint32_t off = s_lut.off[mv];
+            const uint32_t a0 = 2u * r;
+            const uint32_t sl[4] = {sel.x, sel.y, sel.z, sel.w};
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = (a0 + ((off >> (8 * j)) & 0xffu)) & ~3u;
+                const uint32_t lo = *reinterpret_cast<const uint32_t*>(sv + a), hi = *reinterpret_cast<const uint32_t*>(sv + a + 4);
+                w[j] = __builtin_amdgcn_perm(hi, lo, sl[j]);
+            }
+            stream_store16(orow + ((int64_t)u << 3), u32x4{w[0], w[1], w[2], w[3]});
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------- 2:4
 // magnitude key: |x| as an orderable integer; NaN sorts largest (as torch.topk does)
 template <int ES>
@@ -638,6 +824,17 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
     // aligned 16-byte loads of the value runs need a 16-byte aligned base; vectors that would
     // cross values_len are read element-wise in the kernel
     const int vec_in = aligned16(values);
+    if (es == 2 && cols % 32 == 0 && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0) {
+        const int64_t tiles = rows * cdiv64(cols, kTile16);
+        const unsigned grid = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));  // exact grid measured best
+        if (cols <= kTile16)
+            hipLaunchKernelGGL((bitmask_decompress16_kernel<true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values),
+                               values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out));
+        else
+            hipLaunchKernelGGL((bitmask_decompress16_kernel<false>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values),
+                               values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out));
+        CT_LAUNCH_CHECK("ct_bitmask_decompress[16]");
+    }
     // 4096 resident-ish workgroups, grid-strided over rows: measured best on MI355X (tools/kbench)
     const unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);
     CT_ES_SWITCH(es, hipLaunchKernelGGL((bitmask_decompress_kernel<ES>), dim3(grid), dim3(kBlock), 0, as_stream(stream), values,

@@ -299,7 +299,10 @@ def test_bitmask_primitives_golden(golden, cta, dev, case):
 
 @pytest.mark.parametrize("dtype", [BF16, F16, F32, torch.int8])
 @pytest.mark.parametrize("shape,p", [((1, 1), 0.5), ((3, 10), 0.5), ((16, 64), 0.5), ((7, 129), 0.3), ((64, 4096), 0.5),
-                                     ((5, 2048), 0.0), ((5, 2048), 1.0), ((9, 6000), 0.9)])
+                                     ((5, 2048), 0.0), ((5, 2048), 1.0), ((9, 6000), 0.9),
+                                     # 16-bit fast path (cols % 32 == 0): one tile, exactly one tile, several tiles per row
+                                     ((33, 32), 0.5), ((6, 8192), 0.5), ((3, 8192), 0.0), ((3, 8192), 1.0), ((5, 8192 + 32), 0.4),
+                                     ((3, 3 * 8192 + 4096), 0.5), ((2, 2 * 8192), 0.0), ((257, 96), 0.7)])
 def test_bitmask_codec_vs_oracle(cta, dev, dtype, shape, p):
     g = torch.Generator().manual_seed(shape[1])
     x = torch.randn(shape, generator=g)

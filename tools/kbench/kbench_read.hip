@@ -1,0 +1,181 @@
+// kbench_read.hip — developer micro-benchmark for the read-dominated (compress) direction:
+// read-only ceilings by access shape, block sizes, LDS-transposed contiguous loads, buffer loads
+// with cache-policy bits.  Not part of the product.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 kbench_read.hip -o kbench_read
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <functional>
+#include <vector>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16_t;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+__device__ __forceinline__ float bits_f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef bf16_t b2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, b2));
+}
+__device__ __forceinline__ void st16nt(u32x4* p, u32x4 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ int cvt_i32_hw(float x) { int r; asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t q8_word_hw(const u32x4& raw, float rs) {
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t word = 0x88888888u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0 = bits_f(ws[j] << 16), x1 = bits_f(ws[j] & 0xffff0000u);
+        uint32_t p = pk_bf16(x0 * rs, x1 * rs);
+        float t0 = bits_f(p << 16), t1 = bits_f(p & 0xffff0000u);
+        int c0 = cvt_i32_hw(__builtin_rintf(t0)), c1 = cvt_i32_hw(__builtin_rintf(t1));
+        c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
+        c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
+        word += (uint32_t)c0 << (8 * j);
+        word += (uint32_t)c1 << (8 * j + 4);
+    }
+    return word;
+}
+
+// ---- read-only: every lane xors what it read; one dword store per lane only if the xor is a magic value
+template <int U, int BLOCK, bool LANE64B>
+__global__ __launch_bounds__(BLOCK) void rd_kernel(const u32x4* __restrict__ in, uint32_t* __restrict__ out, int64_t n16) {
+    const int64_t base = LANE64B ? ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * U : (int64_t)blockIdx.x * BLOCK * U + threadIdx.x;
+    u32x4 v[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) { int64_t k = LANE64B ? base + i : base + (int64_t)i * BLOCK; v[i] = k < n16 ? in[k] : u32x4{0, 0, 0, 0}; }
+    uint32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < U; ++i) x ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    if (x == 0x12345678u) out[base & 1023] = x;
+}
+
+// ---- compress, current production shape: lane = 4 consecutive units, BLOCK threads
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void q_kernel(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, u32x4* __restrict__ out, int64_t groups) {
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= groups) return;
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[g * 4 + i];
+    const float rs = 1.0f / bits_f((uint32_t)scale[g >> 2] << 16);
+    st16nt(out + g, u32x4{q8_word_hw(r[0], rs), q8_word_hw(r[1], rs), q8_word_hw(r[2], rs), q8_word_hw(r[3], rs)});
+}
+
+// ---- compress, contiguous loads (lane i-th load = unit i*64 + lane of the wave's 256-unit tile), words
+// exchanged through a wave-private LDS slab (no block barrier), one 16 B nt store per lane
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void q_lds_kernel(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, u32x4* __restrict__ out, int64_t units) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[BLOCK * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u0 = ((int64_t)blockIdx.x * (BLOCK / 64) + wave) * 256;  // wave tile
+    if (u0 >= units) return;
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[u0 + i * 64 + lane];
+    uint32_t* slab = lds + wave * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t u = u0 + i * 64 + lane;
+        const float rs = 1.0f / bits_f((uint32_t)scale[u >> 4] << 16);
+        slab[i * 64 + lane] = q8_word_hw(r[i], rs);
+    }
+    // same-wave LDS ops are ordered; the compiler inserts the lgkmcnt wait
+    __builtin_amdgcn_wave_barrier();
+    const u32x4 w = reinterpret_cast<const u32x4*>(slab)[lane];
+    st16nt(out + (u0 >> 2) + lane, w);
+}
+
+// ---- compress, buffer loads with cache policy aux bits (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__global__ __launch_bounds__(256) void q_buf_kernel(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, u32x4* __restrict__ out, int64_t groups, uint32_t in_bytes) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)in_bytes, 0x00020000);
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)((g * 4 + i) * 16), 0, AUX);
+    const float rs = 1.0f / bits_f((uint32_t)scale[g >> 2] << 16);
+    st16nt(out + g, u32x4{q8_word_hw(r[0], rs), q8_word_hw(r[1], rs), q8_word_hw(r[2], rs), q8_word_hw(r[3], rs)});
+}
+
+// ---- compress, 2 x (4 consecutive units) per lane, the two groups half a block-tile apart
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void q2_kernel(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, u32x4* __restrict__ out, int64_t groups) {
+    const int64_t g0 = (int64_t)blockIdx.x * BLOCK * 2 + threadIdx.x;
+    u32x4 r[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { int64_t g = g0 + k * BLOCK; if (g < groups) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[k][i] = in[g * 4 + i]; } }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { int64_t g = g0 + k * BLOCK; if (g < groups) {
+        const float rs = 1.0f / bits_f((uint32_t)scale[g >> 2] << 16);
+        st16nt(out + g, u32x4{q8_word_hw(r[k][0], rs), q8_word_hw(r[k][1], rs), q8_word_hw(r[k][2], rs), q8_word_hw(r[k][3], rs)}); } }
+}
+
+struct Bufs { void *w, *scale, *packed, *out; };
+
+int main(int argc, char** argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : 8192;
+    const int64_t elems = N * N, units = elems / 8;
+    const int NSETS = 4;
+    std::vector<Bufs> sets(NSETS);
+    std::vector<uint16_t> hw(elems), hs(elems / 128);
+    srand(1);
+    for (int64_t i = 0; i < elems; ++i) { float f = ((rand() & 0xffff) / 65536.0f - 0.5f) * 4.0f; uint32_t u; memcpy(&u, &f, 4); hw[i] = (uint16_t)(u >> 16); }
+    for (int64_t i = 0; i < elems / 128; ++i) { float f = 0.25f + (rand() & 0xff) / 1024.0f; uint32_t u; memcpy(&u, &f, 4); hs[i] = (uint16_t)(u >> 16); }
+    for (auto& b : sets) {
+        CK(hipMalloc(&b.w, elems * 2)); CK(hipMalloc(&b.scale, elems / 128 * 2));
+        CK(hipMalloc(&b.packed, elems / 2)); CK(hipMalloc(&b.out, elems * 2));
+        CK(hipMemcpy(b.w, hw.data(), elems * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(b.scale, hs.data(), elems / 128 * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(b.packed, 0x5a, elems / 2));
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double alg = 2.0 * elems + 2.0 * elems / 128 + elems / 2.0;
+
+    auto run = [&](const char* name, double bytes, std::function<void(const Bufs&)> fn) {
+        for (int i = 0; i < 8; ++i) fn(sets[i % NSETS]);
+        CK(hipDeviceSynchronize());
+        float best = 1e30f, tot = 0;
+        const int REP = 5, IT = 20;
+        for (int r = 0; r < REP; ++r) {
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < IT; ++i) fn(sets[i % NSETS]);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = ms < best ? ms : best; tot += ms;
+        }
+        CK(hipGetLastError());
+        double us = best * 1000.0 / IT, usavg = tot * 1000.0 / IT / REP;
+        printf("%-40s  best %7.2f us  avg %7.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)\n", name, us, usavg, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+    };
+    auto G = [&](int64_t items, int64_t per_block) { return dim3((unsigned)((items + per_block - 1) / per_block)); };
+    const int64_t n16 = elems * 2 / 16;
+    const double rbytes = 2.0 * elems;
+    printf("N=%lld  alg bytes/direction=%.0f  (read-only lines: bytes = %.0f)\n", (long long)N, alg, rbytes);
+#define RD(U, BLK, L64) run("read-only U" #U " B" #BLK " lane64B=" #L64, rbytes, [&](const Bufs& b) { hipLaunchKernelGGL((rd_kernel<U, BLK, L64>), G(n16, (int64_t)BLK * U), dim3(BLK), 0, 0, (const u32x4*)b.w, (uint32_t*)b.packed, n16); })
+    RD(4, 256, false); RD(4, 256, true); RD(8, 256, false); RD(2, 256, false); RD(1, 256, false); RD(4, 64, false); RD(4, 128, false); RD(4, 512, false); RD(4, 1024, false); RD(8, 256, true);
+#define QK(BLK) run("q Q4 B" #BLK, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_kernel<BLK>), G(units / 4, BLK), dim3(BLK), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (u32x4*)b.packed, units / 4); })
+    QK(64); QK(128); QK(256); QK(512); QK(1024);
+#define QL(BLK) run("q_lds (contiguous loads) B" #BLK, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_lds_kernel<BLK>), G(units, (int64_t)BLK * 4), dim3(BLK), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (u32x4*)b.packed, units); })
+    QL(64); QL(128); QL(256); QL(512);
+#define QB(AUX) run("q_buf aux=" #AUX, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q_buf_kernel<AUX>), G(units / 4, 256), dim3(256), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (u32x4*)b.packed, units / 4, (uint32_t)(elems * 2)); })
+    QB(0); QB(1); QB(2); QB(16); QB(17);
+#define Q2(BLK) run("q2 2xQ4 B" #BLK, alg, [&](const Bufs& b) { hipLaunchKernelGGL((q2_kernel<BLK>), G(units / 4, (int64_t)BLK * 2), dim3(BLK), 0, 0, (const u32x4*)b.w, (const uint16_t*)b.scale, (u32x4*)b.packed, units / 4); })
+    Q2(64); Q2(256);
+    // cross-check q_lds against q
+    {
+        std::vector<uint32_t> a(units), c(units);
+        hipLaunchKernelGGL((q_kernel<256>), G(units / 4, 256), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (u32x4*)sets[0].packed, units / 4);
+        hipLaunchKernelGGL((q_lds_kernel<256>), G(units, 1024), dim3(256), 0, 0, (const u32x4*)sets[0].w, (const uint16_t*)sets[0].scale, (u32x4*)sets[1].packed, units);
+        CK(hipMemcpy(a.data(), sets[0].packed, units * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(c.data(), sets[1].packed, units * 4, hipMemcpyDeviceToHost));
+        int64_t bad = 0; for (int64_t i = 0; i < units; ++i) bad += a[i] != c[i];
+        printf("check q_lds vs q: %lld mismatching words\n", (long long)bad);
+    }
+    return 0;
+}

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void dec_v1(const uint16_t* __restrict__ vi
                 const uint32_t r0 = (rr >> (16 * (j & 1))) & 0xffu, r1 = (rr >> (16 * (j & 1) + 8)) & 0xffu;
                 w[j] = (uint32_t)sp[r0] | ((uint32_t)sp[r1] << 16);
             }
-            *reinterpret_cast<u32x4*>(out + row * cols + (u << 3)) = u32x4{w[0] & em.x, w[1] & em.y, w[2] & em.z, w[3] & em.w};
+            __builtin_nontemporal_store(u32x4{w[0] & em.x, w[1] & em.y, w[2] & em.z, w[3] & em.w}, reinterpret_cast<u32x4*>(out + row * cols + (u << 3)));
         }
         __syncthreads();
     }
@@ -206,9 +206,146 @@ __global__ __launch_bounds__(kBlock) void dec_v2(const uint16_t* __restrict__ vi
                 const uint32_t r0 = (rr >> (16 * (j & 1))) & 0xffu, r1 = (rr >> (16 * (j & 1) + 8)) & 0xffu;
                 w[j] = (uint32_t)sp[r0] | ((uint32_t)sp[r1] << 16);
             }
-            *reinterpret_cast<u32x4*>(out + row * cols + (u << 3)) = u32x4{w[0] & em.x, w[1] & em.y, w[2] & em.z, w[3] & em.w};
+            __builtin_nontemporal_store(u32x4{w[0] & em.x, w[1] & em.y, w[2] & em.z, w[3] & em.w}, reinterpret_cast<u32x4*>(out + row * cols + (u << 3)));
         }
         __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------- V3: scan-based ranks + window/perm expansion
+// * mask side: every lane loads ONE dword of the bitmask (4 consecutive units), popcounts it, the
+//   block does a DPP wave scan + 4 wave totals; the owner lane publishes (rank << 8 | mask byte)
+//   for its 4 units in LDS, the consumer lane (unit i*256+tid: contiguous 1 KiB stores per wave)
+//   reads it back.  ~1 VALU op per element instead of 4 for the 8-ballot-plane ranks.
+// * value side: output dword j of a unit (elements 2j, 2j+1) is a 32-bit WINDOW of the staged value
+//   run starting at element q_j = rank + popc(m & ((1 << 2j) - 1)): two aligned LDS dwords and ONE
+//   v_perm_b32 whose selector (LUT keyed by mask byte and rank parity) does the funnel shift, the
+//   placement of a lone element and the zeroing.  3 VALU ops + 1 ds_read2_b32 per output dword.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <bool NTST>
+__global__ __launch_bounds__(kBlock) void dec_v3(const uint16_t* __restrict__ vin, int64_t values_len, const uint8_t* __restrict__ bitmask,
+                                                 const int64_t* __restrict__ row_offsets, int64_t rows, int64_t cols, uint16_t* __restrict__ out) {
+    constexpr int T = 8192;
+    __shared__ __attribute__((aligned(16))) uint16_t s_val[T + 32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_sel[2 * 256 * 4];
+    __shared__ uint32_t s_off[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_unit[1024];
+    __shared__ __attribute__((aligned(16))) int s_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        const uint32_t mv = tid;
+        uint32_t off = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t pj = __popc(mv & ((1u << (2 * j)) - 1u));
+            off |= (2u * pj) << (8 * j);
+            const uint32_t b0 = (mv >> (2 * j)) & 1u, b1 = (mv >> (2 * j + 1)) & 1u;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const uint32_t x = (p + pj) & 1u;                     // window starts at byte 2 of the low dword
+                const uint32_t w01 = x ? 0x0302u : 0x0100u;           // selector of window bytes 0,1
+                const uint32_t w23 = x ? 0x0504u : 0x0302u;           // window bytes 2,3
+                uint32_t sel;
+                if (b0 && b1) sel = w01 | (w23 << 16);
+                else if (b0) sel = w01 | 0x0c0c0000u;
+                else if (b1) sel = 0x0c0cu | (w01 << 16);
+                else sel = 0x0c0c0c0cu;
+                s_sel[(p * 256 + mv) * 4 + j] = sel;
+            }
+        }
+        s_off[mv] = off;
+    }
+    const int64_t bcols = cols >> 3;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {   // single tile per row (cols <= T) in this harness
+        const int nu = (int)bcols;
+        const uint32_t md = (4 * tid < nu) ? *reinterpret_cast<const uint32_t*>(bitmask + row * bcols + 4 * tid) : 0u;
+        const int64_t run = row_offsets[row];
+        const int64_t row_end = row + 1 < rows ? row_offsets[row + 1] : values_len;
+        const int shift = (int)(run & 7);
+        const int total_known = (int)(row_end - run);
+        const int nvec = (shift + total_known + 7) >> 3;
+        const int64_t e0 = run - shift;
+        const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
+        u32x4 vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = tid + k * kBlock;
+            if (v < nvec && e0 + (int64_t)(v + 1) * 8 <= values_len) vv[k] = g[v];
+        }
+        // ranks
+        const int c = __popc(md);
+        const int incl = wave_incl_scan(c);
+        if (lane == 63) s_tot[wave] = incl;
+        const uint32_t r0 = (uint32_t)(incl - c);
+        const uint32_t r1 = r0 + __popc(md & 0xffu), r2 = r0 + __popc(md & 0xffffu), r3 = r0 + __popc(md & 0xffffffu);
+        reinterpret_cast<u32x4*>(s_unit)[tid] = u32x4{(r0 << 8) | (md & 0xffu), (r1 << 8) | ((md >> 8) & 0xffu), (r2 << 8) | ((md >> 16) & 0xffu), (r3 << 8) | (md >> 24)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = tid + k * kBlock;
+            if (v < nvec) {
+                if (e0 + (int64_t)(v + 1) * 8 <= values_len) reinterpret_cast<u32x4*>(s_val)[v] = vv[k];
+                else for (int j = 0; j < 8; ++j) { const int64_t gi = e0 + (int64_t)v * 8 + j; s_val[v * 8 + j] = gi < values_len ? vin[gi] : 0; }
+            }
+        }
+        if (tid == 0 && 4 * kBlock < nvec) {   // the one possible 1025th vector
+            const int v = 4 * kBlock;
+            for (int j = 0; j < 8; ++j) { const int64_t gi = e0 + (int64_t)v * 8 + j; s_val[v * 8 + j] = gi < values_len ? vin[gi] : 0; }
+        }
+        __syncthreads();
+        const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2];
+        const int wbase[4] = {0, t0, t0 + t1, t0 + t1 + t2};
+        const char* sv = reinterpret_cast<const char*>(s_val);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = i * kBlock + tid;
+            if (u >= nu) continue;
+            const uint32_t info = s_unit[u];
+            const uint32_t mv = info & 0xffu;
+            const uint32_t r = (info >> 8) + (uint32_t)(wbase[i] + shift);
+            const u32x4 sel = *reinterpret_cast<const u32x4*>(&s_sel[((r & 1u) * 256 + mv) * 4]);
+            const uint32_t off = s_off[mv];
+            const uint32_t a0 = 2u * r;
+            const uint32_t sl[4] = {sel.x, sel.y, sel.z, sel.w};
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = (a0 + ((off >> (8 * j)) & 0xffu)) & ~3u;
+                const uint32_t lo = *reinterpret_cast<const uint32_t*>(sv + a), hi = *reinterpret_cast<const uint32_t*>(sv + a + 4);
+                w[j] = __builtin_amdgcn_perm(hi, lo, sl[j]);
+            }
+            u32x4* o = reinterpret_cast<u32x4*>(out + row * cols + ((int64_t)u << 3));
+            if (NTST) __builtin_nontemporal_store(u32x4{w[0], w[1], w[2], w[3]}, o); else *o = u32x4{w[0], w[1], w[2], w[3]};
+        }
+        __syncthreads();
+    }
+}
+
+// traffic-shaped ceiling: same bytes in and out as the decompress (mask dword + value vectors in, dense nt out), no logic
+__global__ __launch_bounds__(kBlock) void dec_ceiling(const uint16_t* __restrict__ vin, int64_t values_len, const uint8_t* __restrict__ bitmask,
+                                                      const int64_t* __restrict__ row_offsets, int64_t rows, int64_t cols, uint16_t* __restrict__ out) {
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t bcols = cols >> 3;
+    const uint32_t md = *reinterpret_cast<const uint32_t*>(bitmask + row * bcols + 4 * tid);
+    const int64_t v0 = (row * (values_len >> 3)) / rows;  // this row's share of the value vectors
+    const u32x4* g = reinterpret_cast<const u32x4*>(vin) + v0;
+    u32x4 a = g[tid], b = g[tid + 256];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = i * kBlock + tid;
+        u32x4 w = (i & 1) ? a : b;
+        w.x ^= md + i;
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(out + row * cols + ((int64_t)u << 3)));
     }
 }
 
@@ -262,6 +399,9 @@ int main(int argc, char** argv) {
 #define V1(UPL, CAP) run("dec_v1 UPL" #UPL " cap" #CAP, [&](const Set& s) { int64_t nw = rows * ((cols + 256 * UPL * 8 - 1) / (256 * UPL * 8)); int64_t g = CAP > 0 && nw > CAP ? CAP : nw; \
         hipLaunchKernelGGL((dec_v1<UPL>), dim3((unsigned)g), dim3(256), 0, 0, s.v, nnz, s.m, s.ro, rows, cols, s.out); })
 #define V2(UPL, CAP) run("dec_v2 UPL" #UPL " cap" #CAP, [&](const Set& s) { int64_t g = CAP > 0 && rows > CAP ? CAP : rows; hipLaunchKernelGGL((dec_v2<UPL>), dim3((unsigned)g), dim3(256), 0, 0, s.v, nnz, s.m, s.ro, rows, cols, s.out); })
+    run("ceiling (traffic only)", [&](const Set& s) { hipLaunchKernelGGL(dec_ceiling, dim3((unsigned)rows), dim3(256), 0, 0, s.v, nnz, s.m, s.ro, rows, cols, s.out); });
+#define V3(NT, CAP) run("dec_v3 nt" #NT " cap" #CAP, [&](const Set& s) { int64_t g = CAP > 0 && rows > CAP ? CAP : rows; hipLaunchKernelGGL((dec_v3<NT>), dim3((unsigned)g), dim3(256), 0, 0, s.v, nnz, s.m, s.ro, rows, cols, s.out); })
+    V3(true, 0); V3(false, 0); V3(true, 2048); V3(true, 4096);
     V2(4, 0); V2(4, 2048); V2(4, 4096);
     V1(4, 0); V1(2, 0); V1(1, 0); V1(4, 2048); V1(2, 2048); V1(1, 2048); V1(2, 4096);
     return 0;
