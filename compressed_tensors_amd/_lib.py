@@ -56,6 +56,8 @@ _PROTOTYPES = {
     "ct_exclusive_scan_i64": ([_P, _L, _P, _P, _S], _I),
     "ct_bitmask_scatter": ([_P, _I, _L, _L, _P, _P, _S], _I),
     "ct_bitmask_decompress": ([_P, _L, _P, _P, _L, _I, _L, _L, _P, _S], _I),
+    "ct_bitmask_compress_workspace_bytes": ([_L, _L], _L),
+    "ct_bitmask_compress": ([_P, _I, _L, _L, _P, _L, _P, _P, _P, _P, _L, _S], _I),
     "ct_bitmask_row_popcount": ([_P, _L, _L, _P, _S], _I),
     "ct_sparse24_compress": ([_P, _I, _L, _L, _P, _P, _S], _I),
     "ct_sparse24_mask": ([_P, _I, _L, _P, _S], _I),

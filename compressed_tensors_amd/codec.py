@@ -417,10 +417,13 @@ def unpack_bitmasks(packed_bitmasks: torch.Tensor, original_shape) -> torch.Tens
     return _home(out.view(torch.bool), packed_bitmasks)
 
 
-def bitmask_compress(tensor: torch.Tensor):
+def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
     """sparse-bitmask compression: returns (values, bitmask uint8 (R, ceil(C/8)), row_offsets int64 (R,)).
-    Two passes (count+bitmask, scatter) around a row-count scan; one host read of nnz to size
-    `values`, as unavoidable as the reference's `tensor[mask]`."""
+
+    Default: the fused form (`ct_bitmask_compress`: span / block counts, then a scatter whose
+    prefixes are sums of those counts; no scan kernel) into a worst-case sized value buffer, then one
+    host read of nnz — as unavoidable as the reference's `tensor[mask]` — to narrow it.  `two_pass=True` keeps the
+    count / scan / host read / scatter form that sizes `values` exactly before writing it."""
     if tensor.ndim < 1:
         raise ValueError("bitmask compression expects at least a 1-D tensor")
     dev = _compute_device(tensor)
@@ -429,16 +432,27 @@ def bitmask_compress(tensor: torch.Tensor):
     cols = x.shape[-1]
     rows = math.prod(x.shape[:-1]) if x.ndim > 1 else 1
     bitmask = torch.empty((rows, math.ceil(cols / 8)), dtype=torch.uint8, device=dev)
-    counts = torch.empty(rows + 1, dtype=torch.int64, device=dev)
     row_offsets = torch.empty(rows, dtype=torch.int64, device=dev)
     s = stream_of(x)
-    call("ct_bitmask_count", ptr(x), dt, rows, cols, ptr(bitmask), ptr(counts), s)
-    total = counts[rows:]
-    call("ct_exclusive_scan_i64", ptr(counts), rows, ptr(row_offsets), total.data_ptr(), s)
-    nnz = int(total.item())
-    values = torch.empty(nnz, dtype=x.dtype, device=dev)
-    if nnz:
-        call("ct_bitmask_scatter", ptr(x), dt, rows, cols, ptr(row_offsets), ptr(values), s)
+    if two_pass:
+        counts = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+        call("ct_bitmask_count", ptr(x), dt, rows, cols, ptr(bitmask), ptr(counts), s)
+        total = counts[rows:]
+        call("ct_exclusive_scan_i64", ptr(counts), rows, ptr(row_offsets), total.data_ptr(), s)
+        nnz = int(total.item())
+        values = torch.empty(nnz, dtype=x.dtype, device=dev)
+        if nnz:
+            call("ct_bitmask_scatter", ptr(x), dt, rows, cols, ptr(row_offsets), ptr(values), s)
+    else:
+        numel = rows * cols
+        ws_bytes = int(_lib.load().ct_bitmask_compress_workspace_bytes(rows, cols))
+        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)  # [-1] receives nnz
+        buf = torch.empty(numel, dtype=x.dtype, device=dev)
+        call("ct_bitmask_compress", ptr(x), dt, rows, cols, ptr(buf), numel, ptr(bitmask), ptr(row_offsets),
+             ws[-1:].data_ptr(), ptr(ws), ws_bytes, s)
+        nnz = int(ws[-1].item())
+        # keep the view when it wastes less than half of the buffer, else release the slack
+        values = buf[:nnz] if 2 * nnz >= numel else buf[:nnz].clone()
     return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor), _home(row_offsets, tensor)
 
 

@@ -142,6 +142,17 @@ int ct_exclusive_scan_i64(const int64_t* counts, int64_t n, int64_t* offsets, in
 /* sparse-bitmask compress, pass 2: values[row_offsets[r] + rank] = x[r, c] for non-zero x */
 int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const int64_t* row_offsets,
                        void* values, ct_stream_t stream);
+/* sparse-bitmask compress, fused form: bitmask, row_offsets, values and total[0] = nnz with no host
+ * round trip.  16-bit payloads with cols % 8 == 0: two launches over the flat unit stream (counts per
+ * wave span / block, then a scatter whose prefixes are plain sums of those counts — no scan kernel,
+ * no inter-workgroup waiting).  Other cases: count, scan, scatter.  `values` must hold
+ * `values_capacity` elements (numel is always enough; the 16-bit path never writes beyond the
+ * capacity and still reports the needed size in total).  `workspace` =
+ * ct_bitmask_compress_workspace_bytes(rows, cols) bytes, 8-byte aligned, need not be initialised. */
+int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols);
+int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void* values,
+                        int64_t values_capacity, uint8_t* bitmask, int64_t* row_offsets, int64_t* total,
+                        void* workspace, int64_t workspace_bytes, ct_stream_t stream);
 /* sparse-bitmask decompress: out = zeros; out[mask] = values.  row_offsets may be NULL only if
  * fixed_row_nnz >= 0 (every row holds exactly that many values: the 2:4 codec) */
 int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t* bitmask,

@@ -320,6 +320,38 @@ def test_bitmask_codec_vs_oracle(cta, dev, dtype, shape, p):
     assert eq(cta.codec.bitmask_decompress(values, bitmask, shape).cpu(), ref)
 
 
+@pytest.mark.parametrize("shape", [(300, 8192), (7, 5 * 8192 + 24), (2000, 64), (64, 4096), (1100, 8192 * 2), (1, 8), (3, 8), (5, 40),
+                                   (4099, 264), (2, 1 << 20)])
+def test_bitmask_fused_vs_two_pass(cta, dev, shape):
+    """fused flat form (span / block counts + scatter) and the count / scan / host read / scatter form
+    both match the oracle"""
+    g = torch.Generator().manual_seed(shape[0])
+    x = torch.randn(shape, generator=g).masked_fill(torch.rand(shape, generator=g) < 0.6, 0).to(BF16)
+    rv, rb, ro = O.bitmask_compress(x)
+    for two_pass in (False, True):
+        values, bitmask, row_offsets = cta.codec.bitmask_compress(x.to(dev), two_pass=two_pass)
+        assert eq(values.cpu(), rv) and torch.equal(bitmask.cpu(), rb) and torch.equal(row_offsets.cpu(), ro)
+
+
+def test_bitmask_fused_capacity_guard(cta, dev):
+    """a too-small value buffer is never overrun and the needed size is still reported"""
+    from compressed_tensors_amd import _lib
+    lib = _lib.load()
+    x = torch.randn(64, 8192).masked_fill(torch.rand(64, 8192) < 0.5, 0).to(BF16).to(dev)
+    rv, _, _ = O.bitmask_compress(x.cpu())
+    cap = 1000
+    buf = torch.full((cap + 4096,), 0x7fc0, dtype=torch.int16, device=dev)
+    bm = torch.empty(64, 1024, dtype=torch.uint8, device=dev)
+    ro = torch.empty(64, dtype=torch.int64, device=dev)
+    nbytes = int(lib.ct_bitmask_compress_workspace_bytes(64, 8192))
+    ws = torch.empty(nbytes // 8 + 1, dtype=torch.int64, device=dev)
+    _lib.call("ct_bitmask_compress", x.data_ptr(), _lib.BF16, 64, 8192, buf.data_ptr(), cap, bm.data_ptr(), ro.data_ptr(),
+              ws[-1:].data_ptr(), ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    assert int(ws[-1].item()) == rv.numel()
+    assert torch.equal(buf[:cap].cpu(), rv.view(torch.int16)[:cap])
+    assert bool((buf[cap:] == 0x7fc0).all())
+
+
 def test_bitmask_full_size(cta, dev):
     """BASELINE config 3: 50 % unstructured, 8192x8192 bf16"""
     N = 8192

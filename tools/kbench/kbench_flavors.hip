@@ -161,12 +161,34 @@ __global__ __launch_bounds__(256) void q2_kernel(const u32x4* __restrict__ in, c
         st16<SF>(out + g, u32x4{q8_word_hw(r[k][0], rs), q8_word_hw(r[k][1], rs), q8_word_hw(r[k][2], rs), q8_word_hw(r[k][3], rs)}); } }
 }
 
+
+// write-only: U x 16 B per lane, one block apart
+template <int U, int SF, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fill_kernel(u32x4* __restrict__ out, int64_t n, uint32_t seed) {
+    const int64_t base = (int64_t)blockIdx.x * BLOCK * U + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < U; ++i) if (base + i * BLOCK < n) st16<SF>(out + base + i * BLOCK, u32x4{seed, seed + 1, (uint32_t)base, (uint32_t)i});
+}
+// read R bytes : write W bytes mixes, contiguous 16 B per lane both sides (traffic-shape ceilings)
+template <int RU, int WU, int SF>
+__global__ __launch_bounds__(256) void mix_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t nblocks) {
+    const int64_t b = blockIdx.x;
+    u32x4 v[RU];
+#pragma unroll
+    for (int i = 0; i < RU; ++i) v[i] = in[(b * RU + i) * 256 + threadIdx.x];
+    u32x4 x = v[0];
+#pragma unroll
+    for (int i = 1; i < RU; ++i) { x.x ^= v[i].x; x.y ^= v[i].y; x.z ^= v[i].z; x.w ^= v[i].w; }
+#pragma unroll
+    for (int i = 0; i < WU; ++i) { x.x += i; st16<SF>(out + (b * WU + i) * 256 + threadIdx.x, x); }
+}
+
 struct Bufs { void *w, *scale, *packed, *out; };
 
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : 8192;
     const int64_t elems = N * N, units = elems / 8;
-    const int NSETS = 4;
+    const int NSETS = 12;
     std::vector<Bufs> sets(NSETS);
     std::vector<uint16_t> hw(elems), hs(elems / 128);
     srand(1);
@@ -186,7 +208,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 8; ++i) fn(sets[i % NSETS]);
         CK(hipDeviceSynchronize());
         float best = 1e30f, tot = 0;
-        const int REP = 5, IT = 20;
+        const int REP = 5, IT = 24;
         for (int r = 0; r < REP; ++r) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < IT; ++i) fn(sets[i % NSETS]);
@@ -201,6 +223,17 @@ int main(int argc, char** argv) {
     auto G = [&](int64_t items, int per_block) { return dim3((unsigned)((items + per_block - 1) / per_block)); };
 
     printf("N=%lld  alg bytes/direction=%.0f\n", (long long)N, alg);
+
+    {
+        const int64_t n16 = elems * 2 / 16;
+#define FILL(U, SF, BLK) run("fill 134MB U" #U " st" #SF " B" #BLK, 2.0 * elems, [&](const Bufs& b) { hipLaunchKernelGGL((fill_kernel<U, SF, BLK>), G(n16, BLK * U), dim3(BLK), 0, 0, (u32x4*)b.out, n16, 7u); })
+        FILL(1, 0, 256); FILL(1, 1, 256); FILL(2, 1, 256); FILL(4, 1, 256); FILL(2, 2, 256); FILL(2, 4, 256); FILL(2, 1, 1024); FILL(4, 1, 1024); FILL(1, 1, 64);
+        // mixes: bytes = (RU + WU) * 4 KiB per block
+#define MIX(RU, WU, SF) { int64_t nb = (int64_t)(168.0e6 / ((RU + WU) * 4096)); if (nb * WU * 4096 > elems * 2) nb = elems * 2 / (WU * 4096); if (nb * RU * 4096 > elems * 2) nb = elems * 2 / (RU * 4096); \
+        run("mix R" #RU ":W" #WU " st" #SF, (double)nb * (RU + WU) * 4096.0, [&](const Bufs& b) { hipLaunchKernelGGL((mix_kernel<RU, WU, SF>), dim3((unsigned)nb), dim3(256), 0, 0, (const u32x4*)b.w, (u32x4*)b.out, nb); }); }
+        MIX(1, 4, 1); MIX(1, 4, 0); MIX(4, 1, 1); MIX(4, 1, 0); MIX(1, 1, 1); MIX(2, 2, 1); MIX(1, 2, 1); MIX(2, 1, 1);
+    }
+
     // ---- copy ceilings by size (fixed overhead vs asymptote): bytes = 2 * n16 * 16
     for (int64_t mb : {32, 64, 84, 128, 256}) {
         int64_t n16 = mb * 1000000 / 16; if (n16 * 16 > elems * 2) n16 = elems * 2 / 16;

@@ -121,7 +121,7 @@ struct Bufs { void *w, *scale, *packed, *out; };
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : 8192;
     const int64_t elems = N * N, units = elems / 8;
-    const int NSETS = 4;
+    const int NSETS = 12;
     std::vector<Bufs> sets(NSETS);
     std::vector<uint16_t> hw(elems), hs(elems / 128);
     srand(1);
@@ -141,7 +141,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 8; ++i) fn(sets[i % NSETS]);
         CK(hipDeviceSynchronize());
         float best = 1e30f, tot = 0;
-        const int REP = 5, IT = 20;
+        const int REP = 5, IT = 24;
         for (int r = 0; r < REP; ++r) {
             CK(hipEventRecord(e0));
             for (int i = 0; i < IT; ++i) fn(sets[i % NSETS]);

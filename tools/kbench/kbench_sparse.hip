@@ -353,7 +353,7 @@ __global__ __launch_bounds__(kBlock) void dec_ceiling(const uint16_t* __restrict
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : 8192;
     const int64_t rows = N, cols = N, bcols = cols / 8;
-    const int NSETS = 3;
+    const int NSETS = 8;
     std::vector<uint16_t> hw(rows * cols), hv;
     std::vector<uint8_t> hm(rows * bcols, 0);
     std::vector<int64_t> hro(rows);
@@ -383,16 +383,16 @@ int main(int argc, char** argv) {
         fn(sets[0]); CK(hipDeviceSynchronize()); CK(hipGetLastError());
         CK(hipMemcpy(back.data(), sets[0].out, rows * cols * 2, hipMemcpyDeviceToHost));
         int64_t bad = 0; for (int64_t i = 0; i < rows * cols; ++i) bad += back[i] != hw[i];
-        for (int i = 0; i < 6; ++i) fn(sets[i % NSETS]);
+        for (int i = 0; i < 8; ++i) fn(sets[i % NSETS]);
         CK(hipDeviceSynchronize());
         float best = 1e30f;
         for (int r = 0; r < 5; ++r) {
             CK(hipEventRecord(e0));
-            for (int i = 0; i < 12; ++i) fn(sets[i % NSETS]);
+            for (int i = 0; i < 16; ++i) fn(sets[i % NSETS]);
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best;
         }
-        double us = best * 1000.0 / 12;
+        double us = best * 1000.0 / 16;
         printf("%-28s %8.2f us  %7.1f GB/s  (%.1f%% of 8 TB/s)  mismatches=%lld\n", name, us, alg / us / 1e3, alg / us / 1e3 / 80.0, (long long)bad);
     };
     printf("N=%lld nnz=%lld alg=%.0f\n", (long long)N, (long long)nnz, alg);
