@@ -703,7 +703,7 @@ static Flat16Plan flat16_plan(int64_t rows, int64_t cols) {
     p.units = rows * (cols / 8);
     const int64_t wts = cdiv64(p.units, kWT);
     int64_t span = cdiv64(wts, 4 * 4096);  // at most 4096 blocks: the block-prefix pass stays one sweep
-    p.span = (int)(span < 4 ? 4 : span);
+    p.span = (int)(span < 4 ? 4 : span);  // measured flat between 2 and 8 at 8192^2
     p.nblocks = cdiv64(wts, 4 * (int64_t)p.span);
     if (p.nblocks < 1) p.nblocks = 1;
     return p;
@@ -779,7 +779,8 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
                                                                 int64_t rows, uint16_t* __restrict__ vout, int64_t capacity,
                                                                 int64_t* __restrict__ row_offsets, int64_t* __restrict__ total_out,
                                                                 const int64_t* __restrict__ block_tot, const int32_t* __restrict__ span_tot) {
-    constexpr int kSlab = kWT * 8 + 8;
+    constexpr int kSlabData = kWT * 8 + 8;      // compacted run (+ phase shift)
+    constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[kBlock / 64][kSlab];
     __shared__ long long s_part[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -825,14 +826,19 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
             }
         }
         // compact into the wave's slab at the 16-byte phase of the destination
+        // branch-free: every element is written, the zeros go to a per-lane dump slot (predicated
+        // stores compile to an exec-mask save / branch / restore per element: measured slower)
         const int shift = (int)(run & 7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t ws[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
-            int pos = shift + (int)rank[i];
+            uint32_t pos = (uint32_t)shift + rank[i];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (mm[i] & (1u << k)) slab[pos++] = (uint16_t)((k & 1) ? (ws[k >> 1] >> 16) : ws[k >> 1]);
+            for (int k = 0; k < 8; ++k) {
+                const bool keep = (mm[i] >> k) & 1u;
+                slab[keep ? pos : (uint32_t)(kSlabData + lane)] = (uint16_t)((k & 1) ? (ws[k >> 1] >> 16) : ws[k >> 1]);
+                pos += keep ? 1u : 0u;
+            }
         }
         // slab[shift, shift + total) -> vout[run, run + total): aligned 16-byte body, scalar head / tail
         const int64_t end = run + total;
