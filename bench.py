@@ -201,6 +201,150 @@ def bitmask_leg(dev):
     }
 
 
+def int8_leg(dev):
+    """BASELINE config 1 on the GPU: int8 per-tensor symmetric quantize / dequantize of 4096x4096 bf16
+    (IntQuantizationCompressor's two kernels) through the C ABI; 50.3 MB algorithmic per direction."""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n, BF16, I8 = 4096, _lib.BF16, _lib.I8
+    g = torch.Generator(device=dev).manual_seed(11)
+    items = []
+    for _ in range(24):  # 24 x 33.5 MB of weights: HBM-cold
+        w = torch.randn(n, n, dtype=torch.bfloat16, device=dev, generator=g)
+        scale = (w.abs().max().float() / 127.0).to(torch.bfloat16).reshape(1)
+        items.append(dict(w=w, scale=scale, q=torch.empty(n, n, dtype=torch.int8, device=dev), out=torch.empty_like(w)))
+
+    def quant(i):
+        it = items[i % len(items)]
+        lib.ct_quantize(it["w"].data_ptr(), BF16, it["scale"].data_ptr(), BF16, None, -1, n, n, n, n, 1, None, 8, BF16, it["q"].data_ptr(), I8, stream)
+
+    def dequant(i):
+        it = items[i % len(items)]
+        lib.ct_dequantize(it["q"].data_ptr(), I8, it["scale"].data_ptr(), BF16, None, -1, n, n, n, n, 1, None, it["out"].data_ptr(), BF16, stream)
+
+    for i in range(len(items)):
+        quant(i)
+    alg = 3 * n * n
+    us_q, us_d = time_kernel(quant, 48), time_kernel(dequant, 48, offset=12)
+    it = items[0]
+    ok = torch.equal(it["out"].float(), (it["q"].float() * it["scale"].float()).to(torch.bfloat16).float())
+    return {"workload": "int8 per-tensor symmetric quantize / dequantize, 4096x4096 bf16 (IntQuantizationCompressor kernels)",
+            "alg_bytes_per_direction": alg,
+            "quantize_us": round(us_q, 2), "quantize_frac_hbm": round(alg / us_q / 1e3 / HBM_PEAK_GBPS, 4),
+            "dequantize_us": round(us_d, 2), "dequantize_frac_hbm": round(alg / us_d / 1e3 / HBM_PEAK_GBPS, 4),
+            "dequantize_matches_torch": bool(ok)}
+
+
+def marlin24_leg(dev):
+    """BASELINE config 4: 2:4 semi-structured + int4 group-128 in the Marlin-24 layout, 8192x8192 bf16,
+    through the Marlin24Compressor plug-in class (quantize -> 2:4 compress + metadata -> tile-permuted
+    int4 packing -> scale permutation: four kernels plus the host glue)."""
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd import codec
+
+    args = cta.QuantizationArgs(num_bits=4, group_size=GROUP, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    g = torch.Generator(device=dev).manual_seed(13)
+    sds = []
+    for _ in range(4):
+        w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+        w = w * codec.sparse24_mask(w).to(w.dtype)
+        scale, zp = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=True)
+        sds.append({"weight": w, "weight_scale": scale, "weight_zero_point": zp})
+    out = cta.Marlin24Compressor.compress(sds[0], scheme)
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 8
+    start.record()
+    for i in range(iters):
+        cta.Marlin24Compressor.compress(sds[i % len(sds)], scheme)
+    stop.record()
+    torch.cuda.synchronize()
+    us = start.elapsed_time(stop) * 1000.0 / iters
+    alg = 2 * N * N + 2 * N * (N // GROUP) + N * N // 4 + N * N // 8 + 2 * N * (N // GROUP)
+    return {"workload": f"marlin-24 compress (2:4 + int4 g128), {N}x{N} bf16, plug-in class API",
+            "alg_bytes": alg, "compress_us": round(us, 1), "compress_GBps": round(alg / us / 1e3, 1),
+            "compress_frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "outputs": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}}
+
+
+TINYLLAMA_LAYER = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048),
+                   ("gate_proj", 5632, 2048), ("up_proj", 5632, 2048), ("down_proj", 2048, 5632))
+
+
+def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
+    """BASELINE config 5: every Linear of a TinyLlama-1.1B-shaped checkpoint (22 layers x 7 = 154
+    modules, 968,884,224 weights, synthetic) W4A16 g128 compressed then decompressed; the modules are
+    split over the ranks with the reference's LPT rule (distributed/assign.py:33-42) and no rank ever
+    exchanges data.  Timed region: this rank's launches through the C ABI, max over ranks."""
+    from compressed_tensors_amd import _lib, codec
+    from compressed_tensors_amd.distributed.shard import shard_items
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    BF16 = _lib.BF16
+    mods = [(f"model.layers.{l}.{name}", r, c) for l in range(22) for (name, r, c) in TINYLLAMA_LAYER]
+    mine = shard_items(mods, weight_fn=lambda m: m[1] * m[2] * 2, rank=rank, world_size=world)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    cargs, dargs, keep = [], [], []
+    my_bytes = 0
+    for _, r, c in mine:
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        scale, zp = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=True)
+        packed = torch.empty(r, c // 8, dtype=torch.int32, device=dev)
+        out = torch.empty_like(w)
+        keep.append((w, scale, zp, packed, out))
+        cargs.append((w.data_ptr(), BF16, scale.data_ptr(), BF16, zp.data_ptr(), _lib.I8, r, c, 1, GROUP, c // GROUP, None, BITS, BF16, packed.data_ptr(), stream))
+        dargs.append((packed.data_ptr(), r, c // 8, c, BITS, scale.data_ptr(), BF16, None, -1, 1, GROUP, c // GROUP, None, out.data_ptr(), BF16, stream))
+        my_bytes += 2 * (2 * r * c + 2 * r * (c // GROUP) + r * c // 2)
+
+    def per_module():
+        for a in cargs:
+            lib.ct_quant_pack(*a)
+        for a in dargs:
+            lib.ct_unpack_dequant(*a)
+
+    # the product path (ModelCompressor -> PackedQuantizationCompressor.compress_modules): ONE launch per
+    # direction over the shard's module table
+    cb = codec.W4Batch([(w, s, z, p, w.shape[0], w.shape[1], GROUP) for (w, s, z, p, o) in keep], "compress", torch.bfloat16)
+    db = codec.W4Batch([(p, s, None, o, w.shape[0], w.shape[1], GROUP) for (w, s, z, p, o) in keep], "decompress", torch.bfloat16)
+
+    def batched():
+        cb.launch(stream)
+        db.launch(stream)
+
+    def timed(fn):
+        fn()
+        best = None
+        for _ in range(5):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = allreduce_max(time.perf_counter() - t0)
+            best = dt if best is None else min(best, dt)
+        return best
+
+    t_loop = timed(per_module)
+    for (w, s, z, p, o) in keep:
+        p.zero_(); o.zero_()
+    best = timed(batched)
+    total_bytes = sum(2 * (2 * r * c + 2 * r * (c // GROUP) + r * c // 2) for _, r, c in mods)
+    w0, s0, z0, p0, o0 = keep[0]
+    fq = codec.fake_quantize_tensor(w0, s0, z0, num_bits=BITS, strategy="group", group_size=GROUP)
+    return {"workload": "TinyLlama-1.1B-shaped checkpoint (154 Linear modules, 1.94 GB bf16), W4A16 g128 compress + decompress, "
+                        f"LPT module shards over {world} rank(s), no collectives",
+            "modules_this_rank": len(mine), "alg_bytes_all_ranks": total_bytes, "rank0_share_of_bytes": round(my_bytes / total_bytes, 4),
+            "launches": "one ct_quant_pack_batch + one ct_unpack_dequant_batch per rank",
+            "ms_whole_checkpoint": round(best * 1e3, 4), "GBps": round(total_bytes / best / 1e9, 1),
+            "ms_whole_checkpoint_one_launch_per_module": round(t_loop * 1e3, 4),
+            "frac_of_hbm_peak_per_gpu": round(total_bytes / best / 1e9 / world / HBM_PEAK_GBPS, 4),
+            "round_trip_equals_fake_quantize": bool(torch.equal(o0, fq))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,14 +460,30 @@ def main():
             "parity_gate": parity_gate(sets),
         }
         if world == 1 and not a.no_extra:
-            try:
-                del sets
+            del sets
+            torch.cuda.empty_cache()
+            for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg)):
+                try:
+                    result[key] = leg(dev)
+                except Exception as e:  # an extra leg must never take the headline line down
+                    result[key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
-                result["bitmask"] = bitmask_leg(dev)
-            except Exception as e:  # the extra leg must never take the headline line down
-                result["bitmask"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+    if not a.no_extra:  # every rank takes part: the checkpoint is sharded over the ranks
+        def allreduce_max(x):
+            if not distributed:
+                return x
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only
+            return float(t.item())
+
+        try:
+            leg = tinyllama_leg(dev, rank, world, barrier, allreduce_max)
+        except Exception as e:
+            leg = {"error": repr(e)}
+        if rank == 0:
+            result["tinyllama_checkpoint"] = leg
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

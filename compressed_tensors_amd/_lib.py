@@ -49,6 +49,9 @@ _PROTOTYPES = {
     "ct_fake_quantize": (_Q + [_I, _I, _P, _I, _S], _I),
     "ct_quant_pack": (_Q + [_I, _I, _P, _S], _I),
     "ct_unpack_dequant": ([_P, _L, _L, _L, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _I, _S], _I),
+    "ct_w4_batch_plan": ([_P, _I, _I], _L),
+    "ct_quant_pack_batch": ([_P, _I, _L, _I, _S], _I),
+    "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_minmax_qparams": ([_P, _I, _L, _L, _L, _I, _I, _P, _P, _S], _I),
     "ct_pack_bitmasks": ([_P, _L, _L, _P, _S], _I),
     "ct_unpack_bitmasks": ([_P, _L, _L, _P, _S], _I),
@@ -67,6 +70,14 @@ _PROTOTYPES = {
     "ct_marlin24_pack_scales": ([_P, _I, _L, _L, _I, _P, _S], _I),
     "ct_selftest_bf16_div": ([_c.c_uint32, _c.c_uint32, _P, _S], _I),
 }
+
+
+
+class W4Item(ctypes.Structure):
+    """struct ct_w4_item of include/ct_hip.h"""
+    _fields_ = [("src", _P), ("scale", _P), ("zp", _P), ("dst", _P), ("rows", _L), ("cols", _L), ("group", _L),
+                ("first_block", _L), ("units", _L), ("upg_shift", _c.c_int32), ("upg", _c.c_int32)]
+
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))
 

@@ -25,6 +25,8 @@ __all__ = [
     "minmax_qparams",
     "pack_bitmasks",
     "unpack_bitmasks",
+    "W4Batch",
+    "w4_batch_eligible",
     "bitmask_compress",
     "bitmask_decompress",
     "sparse24_mask",
@@ -376,6 +378,74 @@ def minmax_qparams(x, *, num_bits, group_size=None, symmetric=True):
     call("ct_minmax_qparams", ptr(xd), DT[xd.dtype], rows, cols, cdiv, int(num_bits), int(bool(symmetric)), ptr(scale),
          ptr(zp), stream_of(xd))
     return _home(scale, x), _home(zp, x)
+
+
+# --------------------------------------------------------------------------- batched W4A16
+def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, strategy, group_size, g_idx=None) -> bool:
+    """can this tensor join a one-launch W4 batch (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`)?
+    int4, 2-D 16-bit weights and scales of the same dtype on a GPU, group or channel scales with
+    cols % 32 == 0 and group % 32 == 0, int8 (or no) zero point, no activation ordering."""
+    if num_bits != 4 or g_idx is not None or len(weight_shape) != 2:
+        return False
+    if w_dtype not in (torch.bfloat16, torch.float16) or scale is None or scale.dtype != w_dtype or not scale.is_cuda:
+        return False
+    rows, cols = int(weight_shape[0]), int(weight_shape[1])
+    st = _strategy_name(strategy)
+    if st == "channel":
+        g = cols
+    elif st == "group" and group_size:
+        g = int(group_size)
+    else:
+        return False
+    if rows <= 0 or cols % 32 or g % 32 or cols % g:
+        return False
+    if tuple(scale.shape) != (rows, cols // g) or not scale.is_contiguous():
+        return False
+    if zero_point is not None and (zero_point.dtype != torch.int8 or tuple(zero_point.shape) != tuple(scale.shape)
+                                   or not zero_point.is_contiguous() or not zero_point.is_cuda):
+        return False
+    return True
+
+
+class W4Batch:
+    """A table of W4A16 tensors processed by ONE kernel launch per direction — the per-module loop
+    of ModelCompressor without a launch (and a ~5 us host call) per module.
+
+    entries: (src, scale, zero_point or None, dst, rows, cols, group) with src / dst the weight and
+    the packed words in the order the direction needs ("compress": weight -> packed)."""
+
+    def __init__(self, entries, direction: str, dtype: torch.dtype):
+        assert direction in ("compress", "decompress")
+        self.direction = 0 if direction == "compress" else 1
+        self.dt = DT[dtype]
+        self.keep = list(entries)  # the table holds raw pointers: keep the tensors alive
+        n = len(self.keep)
+        self.n = n
+        arr = (_lib.W4Item * max(n, 1))()
+        dev = None
+        for i, (src, scale, zp, dst, rows, cols, group) in enumerate(self.keep):
+            dev = src.device
+            it = arr[i]
+            it.src, it.scale, it.zp, it.dst = src.data_ptr(), scale.data_ptr(), (zp.data_ptr() if zp is not None else None), dst.data_ptr()
+            it.rows, it.cols, it.group = int(rows), int(cols), int(group)
+        import ctypes
+
+        self.blocks = int(_lib.load().ct_w4_batch_plan(ctypes.cast(arr, ctypes.c_void_p), n, self.direction)) if n else 0
+        if self.blocks < 0:
+            raise ValueError(_lib.last_error())
+        self.device = dev
+        if n:
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = host.to(dev)
+        else:
+            self.table = None
+
+    def launch(self, stream=None):
+        if not self.n:
+            return
+        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        name = "ct_quant_pack_batch" if self.direction == 0 else "ct_unpack_dequant_batch"
+        call(name, self.table.data_ptr(), self.n, self.blocks, self.dt, s)
 
 
 # --------------------------------------------------------------------------- bitmask codecs

@@ -15,7 +15,7 @@ from ..quantization.quant_args import QuantizationStatus, is_scheme
 from ..registry import RegistryMixin
 from ..utils.module import get_direct_state_dict, replace_direct_state_dict
 
-__all__ = ["BaseCompressor", "compress_module", "decompress_module", "COMPRESSIBLE_MODULE_TYPES"]
+__all__ = ["BaseCompressor", "compress_module", "decompress_module", "compress_modules", "decompress_modules", "COMPRESSIBLE_MODULE_TYPES"]
 
 # reference compressors/base.py:31
 COMPRESSIBLE_MODULE_TYPES = (torch.nn.Linear, torch.nn.Embedding)
@@ -57,6 +57,18 @@ class BaseCompressor(RegistryMixin, ABC):
         module.quantization_status = QuantizationStatus.DECOMPRESSED
 
     @classmethod
+    def compress_modules(cls, modules) -> None:
+        """compress several modules of this format; codecs may override to batch their launches
+        (the reference loops, model_compressor.py:167-169)"""
+        for m in modules:
+            cls.compress_module(m)
+
+    @classmethod
+    def decompress_modules(cls, modules) -> None:
+        for m in modules:
+            cls.decompress_module(m)
+
+    @classmethod
     def _remove_symmetric_zp(cls, state_dict: dict, scheme) -> dict:
         """compressors/base.py:147-167: vLLM cannot load zero points of symmetric schemes"""
         for args_name, key in (
@@ -89,6 +101,27 @@ def compress_module(module: torch.nn.Module, format: Optional[CompressionFormat]
         return
     fmt = _resolve_format(module, scheme, format)
     BaseCompressor.get_value_from_registry(fmt.value).compress_module(module)
+
+
+def _by_format(modules, format):
+    groups = {}
+    for m in modules:
+        scheme = getattr(m, "quantization_scheme", None)
+        if not is_scheme(scheme):
+            continue
+        groups.setdefault(_resolve_format(m, scheme, format).value, []).append(m)
+    return groups
+
+
+def compress_modules(modules, format: Optional[CompressionFormat] = None):
+    """compress_module over a list, grouped by format so that a codec can batch its kernel launches"""
+    for fmt, ms in _by_format(modules, format).items():
+        BaseCompressor.get_value_from_registry(fmt).compress_modules(ms)
+
+
+def decompress_modules(modules, format: Optional[CompressionFormat] = None):
+    for fmt, ms in _by_format(modules, format).items():
+        BaseCompressor.get_value_from_registry(fmt).decompress_modules(ms)
 
 
 def decompress_module(module: torch.nn.Module, format: Optional[CompressionFormat] = None):

@@ -18,7 +18,7 @@ from ...config import CompressionFormat
 from ...distributed import is_distributed, module_size, shard_modules
 from ...quantization.quant_args import QuantizationStatus
 from ...quantization.utils import is_module_quantized
-from ..base import compress_module, decompress_module
+from ..base import compress_modules, decompress_modules
 from ..format import infer_model_format
 
 __all__ = ["ModelCompressor"]
@@ -76,8 +76,8 @@ class ModelCompressor:
         modules = self._quantized_modules(model, skip_compressed)
         if is_distributed():
             modules = shard_modules(modules, module_size)
-        for module in modules:
-            compress_module(module, self.force_compression_format)
+        # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
+        compress_modules(modules, self.force_compression_format)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
         self.add_decompress_hook(model)
@@ -89,8 +89,7 @@ class ModelCompressor:
         if is_distributed():
             modules = [m for m in shard_modules(modules, module_size)
                        if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED]
-        for module in modules:
-            decompress_module(module, self.force_compression_format)
+        decompress_modules(modules, self.force_compression_format)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.DECOMPRESSED
         self.remove_decompression_hook(model)

@@ -45,7 +45,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         return names
 
     @classmethod
-    def compress(cls, state_dict: dict, scheme) -> dict:
+    def compress(cls, state_dict: dict, scheme, _prepacked=None) -> dict:
         """base.py:62-114"""
         state_dict = state_dict.copy()
         weight = state_dict.pop("weight")
@@ -62,7 +62,10 @@ class PackedQuantizationCompressor(BaseCompressor):
 
         if enum_value(getattr(weights, "type", "int")) != "int":
             raise NotImplementedError("pack-quantized requires INT weights")
-        state_dict["weight_packed"] = codec.quantize_and_pack(weight, scale, zero_point, g_idx=g_idx, **_layout_kwargs(weights))
+        if _prepacked is not None:
+            state_dict["weight_packed"] = _prepacked  # produced by the batched launch of compress_modules
+        else:
+            state_dict["weight_packed"] = codec.quantize_and_pack(weight, scale, zero_point, g_idx=g_idx, **_layout_kwargs(weights))
         state_dict["weight_shape"] = torch.tensor(weight.shape)  # int64, CPU: as upstream (:105)
 
         if not weights.symmetric and enum_value(weights.strategy) in PACK_ZP_STRATS:
@@ -73,7 +76,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         return cls._remove_symmetric_zp(state_dict, scheme)
 
     @classmethod
-    def decompress(cls, state_dict: dict, scheme) -> dict:
+    def decompress(cls, state_dict: dict, scheme, _preweight=None) -> dict:
         """base.py:116-163"""
         state_dict = state_dict.copy()
         packed = state_dict.pop("weight_packed")
@@ -96,10 +99,78 @@ class PackedQuantizationCompressor(BaseCompressor):
 
         # dequantize() is called without args upstream: the strategy is inferred from the scale
         # shape (base.py:156-161, lifecycle/forward.py:99-130) and group_size from g_idx-free shapes
-        state_dict["weight"] = codec.unpack_and_dequantize(
-            packed, shape, scale, zero_point, num_bits=int(weights.num_bits), g_idx=g_idx
-        )
+        if _preweight is not None:
+            state_dict["weight"] = _preweight  # produced by the batched launch of decompress_modules
+        else:
+            state_dict["weight"] = codec.unpack_and_dequantize(
+                packed, shape, scale, zero_point, num_bits=int(weights.num_bits), g_idx=g_idx
+            )
         return state_dict
+
+    # ------------------------------------------------------------------ batched module paths
+    @classmethod
+    def compress_modules(cls, modules) -> None:
+        """One launch for every eligible module (int4, 16-bit, group / channel scales), the rest
+        one by one.  State-dict results are identical to compress_module's."""
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+
+        jobs, entries, dtype = [], [], None
+        for m in modules:
+            scheme = m.quantization_scheme
+            sd = get_direct_state_dict(m)
+            w, scale, zp = sd.get("weight"), sd.get("weight_scale"), sd.get("weight_zero_point")
+            wa = scheme.weights
+            ok = (w is not None and w.is_cuda and w.is_contiguous() and enum_value(getattr(wa, "type", "int")) == "int"
+                  and (dtype is None or w.dtype == dtype)
+                  and codec.w4_batch_eligible(w.shape, w.dtype, scale, zp, num_bits=int(wa.num_bits), strategy=wa.strategy,
+                                              group_size=getattr(wa, "group_size", None), g_idx=sd.get("weight_g_idx")))
+            if not ok:
+                cls.compress_module(m)
+                continue
+            dtype = w.dtype
+            rows, cols = w.shape
+            group = cols if enum_value(wa.strategy) == "channel" else int(wa.group_size)
+            packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=w.device)
+            entries.append((w, scale, zp, packed, rows, cols, group))
+            jobs.append((m, sd, scheme, packed))
+        if jobs:
+            codec.W4Batch(entries, "compress", dtype).launch()
+            for m, sd, scheme, packed in jobs:
+                replace_direct_state_dict(m, cls.compress(sd, scheme, _prepacked=packed))
+                m.quantization_status = QuantizationStatus.COMPRESSED
+
+    @classmethod
+    def decompress_modules(cls, modules) -> None:
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+
+        jobs, entries, dtype = [], [], None
+        for m in modules:
+            scheme = m.quantization_scheme
+            sd = get_direct_state_dict(m)
+            packed, scale, shape_t = sd.get("weight_packed"), sd.get("weight_scale"), sd.get("weight_shape")
+            wa = scheme.weights
+            ok = packed is not None and scale is not None and shape_t is not None and packed.is_cuda and packed.is_contiguous() and wa.symmetric
+            if ok:
+                shape = tuple(int(v) for v in shape_t.tolist())
+                # decompress infers the strategy from the scale shape (forward.py:99-130): (R, 1) channel, (R, G) group
+                strategy, group = ("channel", shape[-1]) if scale.shape[-1] == 1 else ("group", shape[-1] // scale.shape[-1])
+                ok = ((dtype is None or scale.dtype == dtype) and len(shape) == 2 and tuple(packed.shape) == (shape[0], shape[1] // 8)
+                      and codec.w4_batch_eligible(shape, scale.dtype, scale, None, num_bits=int(wa.num_bits), strategy=strategy,
+                                                  group_size=group, g_idx=sd.get("weight_g_idx")))
+            if not ok:
+                cls.decompress_module(m)
+                continue
+            dtype = scale.dtype
+            out = torch.empty(shape, dtype=scale.dtype, device=packed.device)
+            entries.append((packed, scale, None, out, shape[0], shape[1], group))
+            jobs.append((m, sd, scheme, out))
+        if jobs:
+            codec.W4Batch(entries, "decompress", dtype).launch()
+            for m, sd, scheme, out in jobs:
+                replace_direct_state_dict(m, cls.decompress(sd, scheme, _preweight=out))
+                m.quantization_status = QuantizationStatus.DECOMPRESSED
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

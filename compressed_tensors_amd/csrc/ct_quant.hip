@@ -382,72 +382,126 @@ __device__ __forceinline__ uint32_t w4_quant_word(const u32x4& raw, float s, flo
     return word;
 }
 
-// Q consecutive units per lane; SHARED: the Q units share one scale (cdiv % (8*Q) == 0)
+// Q = 4 consecutive units per lane; SHARED: the 4 units share one scale (cdiv % 32 == 0)
 template <int DT, bool HAS_ZP, bool SHARED>
-__global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
+__device__ __forceinline__ void w4_quant_pack_group(const W4Params& p, int64_t g) {
     constexpr int Q = 4;
-    const int64_t groups = p.units / Q;  // host guarantees units % Q == 0
     const u32x4* in = static_cast<const u32x4*>(p.x);
     u32x4* out = static_cast<u32x4*>(p.out);
-    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
-        u32x4 r[Q];
+    u32x4 r[Q];
 #pragma unroll
-        for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
-        uint32_t w[Q];
-        float s = 0.0f, z = 0.0f, rs = 0.0f;
-        bool fast = false, use_zp = false;
+    for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
+    uint32_t w[Q];
+    float s = 0.0f, z = 0.0f, rs = 0.0f;
+    bool fast = false, use_zp = false;
 #pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            if (i == 0 || !SHARED) {
-                const int64_t si = w4_scale_index(p, g * Q + i);
-                s = load_as_f<DT>(p.scale, si);
-                z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype)
-                const float as = __builtin_fabsf(s);
-                fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
-                rs = 1.0f / s;
-                // adding an all-zero zero point is the identity (t is already rounded): skip the
-                // add + second rounding when every lane of the wave has z == 0 (symmetric schemes)
-                use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
-            }
-            // real branches (not selects): the IEEE divide is 11 VALU ops per element and must not
-            // be issued on the fast path; lanes of a wave almost always agree
-            if (fast) {
-                w[i] = use_zp ? w4_quant_word<DT, true, true>(r[i], s, rs, z) : w4_quant_word<DT, true, false>(r[i], s, rs, z);
-            } else {
-                w[i] = use_zp ? w4_quant_word<DT, false, true>(r[i], s, rs, z) : w4_quant_word<DT, false, false>(r[i], s, rs, z);
-            }
+    for (int i = 0; i < Q; ++i) {
+        if (i == 0 || !SHARED) {
+            const int64_t si = w4_scale_index(p, g * Q + i);
+            s = load_as_f<DT>(p.scale, si);
+            z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype)
+            const float as = __builtin_fabsf(s);
+            fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+            rs = 1.0f / s;
+            // adding an all-zero zero point is the identity (t is already rounded): skip the
+            // add + second rounding when every lane of the wave has z == 0 (symmetric schemes)
+            use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
         }
-        stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+        // real branches (not selects): the IEEE divide is 11 VALU ops per element and must not
+        // be issued on the fast path; lanes of a wave almost always agree
+        if (fast) {
+            w[i] = use_zp ? w4_quant_word<DT, true, true>(r[i], s, rs, z) : w4_quant_word<DT, true, false>(r[i], s, rs, z);
+        } else {
+            w[i] = use_zp ? w4_quant_word<DT, false, true>(r[i], s, rs, z) : w4_quant_word<DT, false, false>(r[i], s, rs, z);
+        }
+    }
+    stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+}
+
+template <int DT, bool HAS_ZP, bool SHARED>
+__global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
+    const int64_t groups = p.units / 4;  // host guarantees units % 4 == 0
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock)
+        w4_quant_pack_group<DT, HAS_ZP, SHARED>(p, g);
+}
+
+// UNROLL units per lane, one block apart, starting at `base`
+template <int DT, int UNROLL, bool HAS_ZP>
+__device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64_t base) {
+    const uint32_t* in = static_cast<const uint32_t*>(p.x);
+    uint32_t word[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u < p.units) word[i] = in[u];
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u >= p.units) continue;
+        const int64_t si = w4_scale_index(p, u);
+        const float s = load_as_f<DT>(p.scale, si);
+        const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float q = (float)((int)((word[i] >> (4 * k)) & 0xfu) - 8);
+            v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
+        }
+        store8<DT>(p.out, u * 8, v);
     }
 }
 
 template <int DT, int UNROLL, bool HAS_ZP>
 __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_kernel(W4Params p) {
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
-    const uint32_t* in = static_cast<const uint32_t*>(p.x);
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
-        uint32_t word[UNROLL];
-#pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u < p.units) word[i] = in[u];
-        }
-#pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u >= p.units) continue;
-            const int64_t si = w4_scale_index(p, u);
-            const float s = load_as_f<DT>(p.scale, si);
-            const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float q = (float)((int)((word[i] >> (4 * k)) & 0xfu) - 8);
-                v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
-            }
-            store8<DT>(p.out, u * 8, v);
-        }
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride)
+        w4_unpack_dequant_units<DT, UNROLL, HAS_ZP>(p, base);
+}
+
+// ------------------------------------------------------------------------------------------
+// batched W4A16: ONE launch over a table of tensors (a whole checkpoint shard).  A TinyLlama-1.1B
+// shard is 154 modules, some as small as 1 MB: launched one by one the job is bound by the launch
+// path (~5 us per module from the host, ~1.5 us of kernel boundary on the device), not by HBM.
+// Every workgroup finds its tensor by a binary search over the table's running block count
+// (wave-uniform scalar loads), then runs the same per-lane body as the single-tensor kernels.
+// ------------------------------------------------------------------------------------------
+constexpr int kBatchUnroll = 2;
+
+__device__ __forceinline__ const ct_w4_item& batch_find(const ct_w4_item* __restrict__ items, int n, int64_t block) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= block) lo = mid; else hi = mid - 1;
     }
+    return items[lo];
+}
+
+__device__ __forceinline__ W4Params batch_params(const ct_w4_item& it) {
+    W4Params p;
+    p.x = it.src; p.scale = it.scale; p.zp = it.zp; p.out = it.dst; p.zdt = CT_I8;
+    p.units = it.units; p.upr = it.cols >> 3; p.rdiv = 1; p.scale_cols = 0;
+    p.upg_shift = it.upg_shift; p.upg = it.upg; p.flat_scale = 1;
+    return p;
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void w4_quant_pack_batch_kernel(const ct_w4_item* __restrict__ items, int n) {
+    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+    const W4Params p = batch_params(it);
+    const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
+    if (g >= p.units / 4) return;
+    if (p.zp) w4_quant_pack_group<DT, true, true>(p, g);
+    else w4_quant_pack_group<DT, false, true>(p, g);
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n) {
+    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+    const W4Params p = batch_params(it);
+    const int64_t base = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll + threadIdx.x;
+    if (p.zp) w4_unpack_dequant_units<DT, kBatchUnroll, true>(p, base);
+    else w4_unpack_dequant_units<DT, kBatchUnroll, false>(p, base);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -709,6 +763,54 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         default: CT_DISPATCH_BITS(bits, hipLaunchKernelGGL((unpack_dequant_g32_kernel<CT_F32, B>), grid, dim3(kBlock), 0, as_stream(stream), p, words)); break;
     }
     CT_LAUNCH_CHECK("ct_unpack_dequant");
+}
+
+int64_t ct_w4_batch_plan(ct_w4_item* items, int n, int direction) {
+    if (n < 0 || (n > 0 && items == nullptr) || (direction != 0 && direction != 1)) {
+        set_error("ct_w4_batch_plan: bad arguments");
+        return -1;
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ct_w4_item& it = items[i];
+        const int64_t g = (it.group <= 0 || it.group > it.cols) ? it.cols : it.group;
+        const bool ok = it.rows > 0 && it.cols > 0 && it.cols % 32 == 0 && g % 32 == 0 && it.cols % g == 0 && it.src && it.scale && it.dst &&
+                        aligned16(it.src) && aligned16(it.dst);
+        if (!ok) {
+            set_error("ct_w4_batch_plan: item %d (rows %lld, cols %lld, group %lld) is not eligible for the batched W4 path "
+                      "(needs cols %% 32 == 0, group %% 32 == 0, cols %% group == 0, 16-byte aligned buffers)", i, (long long)it.rows,
+                      (long long)it.cols, (long long)it.group);
+            return -1;
+        }
+        it.units = it.rows * (it.cols / 8);
+        it.upg = (int32_t)(g / 8);
+        it.upg_shift = log2_exact(it.upg);
+        it.first_block = blocks;
+        blocks += direction == 0 ? cdiv64(it.units / 4, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll);
+    }
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("ct_w4_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
+        return -1;
+    }
+    return blocks;
+}
+
+int ct_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_BF16 || dt == CT_F16, "batched W4 path: 16-bit weights only, got dtype %d", dt);
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    if (dt == CT_BF16) hipLaunchKernelGGL((w4_quant_pack_batch_kernel<CT_BF16>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    else hipLaunchKernelGGL((w4_quant_pack_batch_kernel<CT_F16>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    CT_LAUNCH_CHECK("ct_quant_pack_batch");
+}
+
+int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_BF16 || dt == CT_F16, "batched W4 path: 16-bit weights only, got dtype %d", dt);
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    if (dt == CT_BF16) hipLaunchKernelGGL((w4_unpack_dequant_batch_kernel<CT_BF16>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    else hipLaunchKernelGGL((w4_unpack_dequant_batch_kernel<CT_F16>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    CT_LAUNCH_CHECK("ct_unpack_dequant_batch");
 }
 
 int ct_selftest_bf16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {

@@ -114,6 +114,28 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
                       int64_t cdiv, int64_t scale_cols, const int32_t* col_group, void* out, int odt,
                       ct_stream_t stream);
 
+/* Batched W4A16 (int4, 16-bit weights and scales of one dtype, group or channel scales, int8 zero
+ * points): one launch for a whole table of tensors — the per-module loop of
+ * ModelCompressor.compress_model / decompress_model (compressors/model_compressors/
+ * model_compressor.py:167-169,196-198) without a launch per module.
+ * The caller fills src / scale / zp / dst / rows / cols / group of every item, calls
+ * ct_w4_batch_plan on the HOST copy (fills the derived fields, returns the workgroup count or -1),
+ * copies the table to the device and launches.  direction: 0 = compress (src = weights,
+ * dst = packed int32), 1 = decompress (src = packed, dst = weights). */
+typedef struct ct_w4_item {
+    const void* src;
+    const void* scale;
+    const void* zp; /* int8, shape of scale, or NULL */
+    void* dst;
+    int64_t rows, cols, group; /* group <= 0 or >= cols: one scale per row */
+    int64_t first_block;       /* derived */
+    int64_t units;             /* derived */
+    int32_t upg_shift, upg;    /* derived */
+} ct_w4_item;
+int64_t ct_w4_batch_plan(ct_w4_item* items_host, int n, int direction);
+int ct_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
+int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
+
 /* Min/max observer + calculate_qparams for weight groups (rows x ceil(cols/cdiv) groups of
  * cdiv consecutive columns).   quantization/utils/helpers.py:50-137
  * scale_out has x's dtype; zp_out is int8 (may be NULL for symmetric). */

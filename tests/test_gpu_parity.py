@@ -460,3 +460,67 @@ def test_host_tensors_are_staged_through_the_gpu(cta, dev):
     v = torch.randint(-8, 8, (32, 200), dtype=torch.int8, generator=g)
     p = cta.codec.pack_to_int32(v, 4)
     assert p.device.type == "cpu" and torch.equal(p, O.pack_to_int32(v, 4).contiguous())
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
+    """ModelCompressor turns the pack-quantized modules into ONE launch per direction
+    (ct_quant_pack_batch / ct_unpack_dequant_batch); every state dict must be identical to the
+    per-module path, including modules the batch cannot take (ragged columns, fp32)."""
+    import copy
+
+    torch.manual_seed(5)
+    shapes = [(256, 2048), (64, 256), (2048, 256), (96, 128), (32, 40 * 4), (128, 384)]
+    model = torch.nn.Sequential(*[torch.nn.Linear(c, r, bias=False) for r, c in shapes]).to(dev).to(BF16)
+    model[5] = model[5].float()  # fp32 weights: not eligible for the batch
+    for i, m in enumerate(model):
+        gs = 32 if shapes[i][1] % 128 else 128
+        if i == 4:
+            gs = 40  # group size not a multiple of 32: per-module path
+        args = cta.QuantizationArgs(num_bits=4, group_size=gs, symmetric=symmetric, strategy="group")
+        if i == 3:
+            args = cta.QuantizationArgs(num_bits=4, symmetric=symmetric, strategy="channel")
+        m.quantization_scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+        s, z = cta.quantization.calculate_qparams_from_weight(m.weight.data, args)
+        m.register_parameter("weight_scale", torch.nn.Parameter(s, requires_grad=False))
+        m.register_parameter("weight_zero_point", torch.nn.Parameter(z, requires_grad=False))
+    ref = copy.deepcopy(model)
+    for m in ref:
+        cta.compress_module(m)
+    cta.ModelCompressor().compress_model(model)
+    for a, b in zip(model, ref):
+        sa, sb = dict(a.named_parameters()), dict(b.named_parameters())
+        assert sa.keys() == sb.keys() and "weight_packed" in sa
+        for k in sa:
+            assert sa[k].dtype == sb[k].dtype and sa[k].device == sb[k].device and torch.equal(sa[k], sb[k]), k
+    for m in ref:
+        cta.decompress_module(m)
+    cta.ModelCompressor().decompress_model(model)
+    for a, b in zip(model, ref):
+        assert eq(a.weight.data.cpu(), b.weight.data.cpu()) and a.weight.dtype == b.weight.dtype
+
+
+def test_w4_batch_vs_oracle(cta, dev):
+    """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
+    for dtype in (BF16, F16):
+        g = torch.Generator().manual_seed(9)
+        items, entries, outs = [], [], []
+        for rows, cols, group in ((40, 256, 128), (7, 64, 32), (300, 1024, 1024), (1, 32, 32), (513, 4096, 128)):
+            w = torch.randn(rows, cols, generator=g).to(dtype)
+            strategy = "channel" if group == cols else "group"
+            scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=None if strategy == "channel" else group, symmetric=False)
+            q = O.quantize(w, scale, zp, num_bits=4, strategy=strategy, group_size=group, dtype=torch.int8)
+            items.append((w, scale, zp, O.pack_to_int32(q, 4), strategy, group))
+            wd, sd, zd = w.to(dev), scale.to(dev), zp.to(dev)
+            packed = torch.empty(rows, cols // 8, dtype=torch.int32, device=dev)
+            entries.append((wd, sd, zd, packed, rows, cols, group))
+        cta.codec.W4Batch(entries, "compress", dtype).launch()
+        dent = []
+        for (w, scale, zp, ref_packed, strategy, group), e in zip(items, entries):
+            assert torch.equal(e[3].cpu(), ref_packed.contiguous())
+            out = torch.empty_like(e[0])
+            dent.append((e[3], e[1], e[2], out, e[4], e[5], e[6]))
+        cta.codec.W4Batch(dent, "decompress", dtype).launch()
+        for (w, scale, zp, ref_packed, strategy, group), e in zip(items, dent):
+            q = O.unpack_from_int32(ref_packed, 4, w.shape)
+            assert eq(e[3].cpu(), O.dequantize(q, scale, zp))

@@ -258,9 +258,13 @@ def test_world_size_2_sharding_gloo(tmp_path):
     script = tmp_path / "dist_check.py"
     script.write_text(_DIST_SCRIPT.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    import socket
+    with socket.socket() as sk:  # a free rendezvous port (a fixed one collides with a run in TIME_WAIT)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-         "--master-port", "29731", str(script)],
+         "--master-port", str(port), str(script)],
         capture_output=True, text=True, env=env, timeout=240,
     )
     assert r.returncode == 0, r.stdout + r.stderr

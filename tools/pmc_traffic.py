@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh into profiles/pmc_traffic.json,
+the per-launch HBM traffic that bench.py reports as roofline.traffic.
+
+    python tools/pmc_traffic.py gpurun_out/profile_<tag> profiles/pmc_traffic.json
+
+Units and corrections (/opt/skills/guides/MI355X_MICROARCH.md, "HBM"): both counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of the bytes of a coalesced streaming read, so it is
+doubled.  Checked on this path against known byte counts: the W4 compress reads 134.2 MB of
+weights + 1.6 MB of scales / zero points and the doubled counter says 136.5 MB."""
+import json
+import re
+import sys
+
+ALIAS = {
+    "ct::w4_quant_pack_kernel<2, true, true>": "w4_quant_pack_kernel<bf16>",
+    "ct::w4_unpack_dequant_kernel<2, 2, false>": "w4_unpack_dequant_kernel<bf16>",
+}
+
+
+def parse(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"^(ct::.*?)\s+" + counter + r"\s+(\d+)\s+([\d.]+)\s*$", line)
+        if m:
+            out[m.group(1).strip()] = float(m.group(3))
+    return out
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    fetch = parse(f"{src}/pmc_fetch.txt", "FETCH_SIZE")
+    write = parse(f"{src}/pmc_write.txt", "WRITE_SIZE")
+    res = {"_source": f"{src}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py",
+           "_formula": "bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950 read under-count) + WRITE_SIZE * 1024"}
+    for k in sorted(set(fetch) & set(write)):
+        b = int(2 * fetch[k] * 1024 + write[k] * 1024)
+        res[ALIAS.get(k, k.replace("ct::", ""))] = b
+    json.dump(res, open(dst, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
