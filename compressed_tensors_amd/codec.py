@@ -27,6 +27,7 @@ __all__ = [
     "unpack_bitmasks",
     "W4Batch",
     "w4_batch_eligible",
+    "marlin24_quant_compress",
     "bitmask_compress",
     "bitmask_decompress",
     "sparse24_mask",
@@ -628,6 +629,23 @@ def cutlass24_to_dense(sparse: torch.Tensor, meta_reordered: torch.Tensor) -> to
     dense = torch.empty((m, 2 * k), dtype=s.dtype, device=dev)
     call("ct_cutlass24_to_dense", ptr(s), DT[s.dtype], ptr(mt), mt.dtype.itemsize, m, k, ptr(dense), stream_of(s))
     return _home(dense, sparse)
+
+
+def marlin24_quant_compress(weight: torch.Tensor, scale: torch.Tensor, zero_point, *, num_bits: int, group_size: Optional[int]):
+    """fused marlin-24 front end: fp16 quantize + 2:4 compress of a 16-bit 2:4-sparse weight.
+    Returns (codes int8 (m, k/2), meta int16 (m, k/16) reordered, violated: bool) — `violated` costs one
+    host read, as the reference pipeline's structure check did."""
+    dev = _compute_device(weight)
+    w, s = _dev(weight, dev).contiguous(), _dev(scale, dev).contiguous()
+    zp = _dev(zero_point, dev).contiguous() if zero_point is not None else None
+    m, k = w.shape
+    g = k if not group_size or group_size > k else int(group_size)
+    comp = torch.empty((m, k // 2), dtype=torch.int8, device=dev)
+    meta = torch.empty((m, k // 16), dtype=torch.int16, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    call("ct_marlin24_quant_compress", ptr(w), DT[w.dtype], ptr(s), DT[s.dtype], ptr(zp), DT[zp.dtype] if zp is not None else -1,
+         m, k, g, int(num_bits), ptr(comp), ptr(meta), ptr(bad), stream_of(w))
+    return _home(comp, weight), _home(meta, weight), bad
 
 
 def marlin24_pack_weights(q: torch.Tensor, num_bits: int, *, transposed: bool = False, add_offset: bool = False):

@@ -10,8 +10,9 @@ class was removed.  Restated pipeline (compress only, as upst
     scale_packed  = scale.T permuted (scale_perm for group, scale_perm_single for channel)
     meta          = meta viewed as (meta_cols / 2, rows * 2)
 
-All device work is HIP: one quantize kernel, one 2:4 compress kernel, one packing kernel that
-reads the un-transposed compressed matrix (the transpose is index arithmetic), one scale kernel.
+All device work is HIP: ONE fused front-end kernel (fp16 quantize + 2:4 structure check + 2:4
+compress: `ct_marlin24_quant_compress`, no full-size intermediate), one packing kernel that reads
+the un-transposed int8 codes (the transpose is index arithmetic), one scale kernel.
 """
 import torch
 
@@ -60,16 +61,29 @@ class Marlin24Compressor(BaseCompressor):
         cls.validate_quant_compatability(weights)
 
         scale16 = scale.to(torch.float16)
-        w16 = weight.to(torch.float16)
-        q = codec.quantize_tensor(
-            w16, scale16, zero_point, num_bits=int(weights.num_bits), strategy=enum_value(weights.strategy),
-            group_size=getattr(weights, "group_size", None),
-        )
-        cls.validate_sparsity_structure("weight", q)
-        comp, meta = codec.cutlass24_from_dense(q)
-        size_n, size_k = comp.shape  # the kernel expects input-dim first: packed from comp.T
-        packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
         group_size = getattr(weights, "group_size", None)
+        fused_ok = (weight.dtype in (torch.float16, torch.bfloat16) and weight.dim() == 2 and weight.shape[0] % 64 == 0
+                    and weight.shape[1] % 16 == 0
+                    and (enum_value(weights.strategy) == "channel" or (group_size and group_size % 16 == 0 and weight.shape[1] % group_size == 0)))
+        if fused_ok:
+            # one pass: weight.to(fp16) / quantize in fp16 / 2:4 structure check / cutlass 2:4 compress
+            g = None if enum_value(weights.strategy) == "channel" else group_size
+            comp, meta, bad = codec.marlin24_quant_compress(weight, scale16, zero_point, num_bits=int(weights.num_bits), group_size=g)
+            size_n, size_k = comp.shape
+            packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
+            if int(bad.item()):  # one host read, as the reference pipeline's structure check
+                raise ValueError("Marlin24 Compressor is only compatible with weights that have a 2:4 sparsity structure. "
+                                 "Found segments in weight that do not match the expected structure.")
+        else:
+            w16 = weight.to(torch.float16)
+            q = codec.quantize_tensor(
+                w16, scale16, zero_point, num_bits=int(weights.num_bits), strategy=enum_value(weights.strategy),
+                group_size=group_size,
+            )
+            cls.validate_sparsity_structure("weight", q)
+            comp, meta = codec.cutlass24_from_dense(q)
+            size_n, size_k = comp.shape  # the kernel expects input-dim first: packed from comp.T
+            packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
         is_group = enum_value(weights.strategy) == "group" and group_size is not None and group_size < size_k
         scale2d = scale16.reshape(scale16.shape[0], -1)
         scale_packed = codec.marlin24_pack_scales(scale2d, single=not is_group)

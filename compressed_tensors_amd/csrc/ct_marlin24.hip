@@ -112,6 +112,65 @@ __global__ __launch_bounds__(kBlock) void cutlass24_to_dense_kernel(const void* 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// marlin-24 front end, fused: weight (bf16 / fp16) + scale -> fp16 quantize -> 2:4 compress.
+// Replaces `weight.to(fp16)`, `scale.to(fp16)`, quantize(...) kept in fp16, the 2:4 structure
+// check and sparse_semi_structured_from_dense_cutlass of the restated pipeline (four full-size
+// intermediates, ~900 us of framework kernels at 8192^2) by ONE pass: 2 B/element in, 0.5 B of
+// kept int8 codes + 1/8 B of metadata out.  Arithmetic = the fp16 eager sequence of the
+// reference's quantize (every op rounded to fp16): x16 = fp16(x); t = fp16(x16 / s16);
+// [t = fp16(t + fp16(zp))]; clamp; rint.  A quad with more than two non-zero codes sets *bad.
+// One lane per metadata word = 4 quads = 16 elements (32 B in, 8 B of codes + one int16 out).
+// ------------------------------------------------------------------------------------------
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void marlin24_quant_compress_kernel(const void* __restrict__ w, const void* __restrict__ scale, int sdt,
+                                                                         const void* __restrict__ zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                                                                         int64_t scale_cols, float qmin, float qmax, int8_t* __restrict__ comp,
+                                                                         uint16_t* __restrict__ meta, int* __restrict__ bad) {
+    const int64_t meta_ncols = k / 16;
+    const int64_t total = m * meta_ncols;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / meta_ncols, mc = i - r * meta_ncols;
+        const u32x4* in = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + r * k + mc * 16);
+        const u32x4 a = in[0], b = in[1];
+        const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const int64_t si = r * scale_cols + (mc * 16) / cdiv;
+        const float s16 = round_to<CT_F16>(load_rt(scale, sdt, si));
+        const bool has_zp = zp != nullptr;
+        const float z16 = has_zp ? round_to<CT_F16>(load_rt(zp, zdt, si)) : 0.0f;
+        uint32_t word = 0, lo = 0, hi = 0;
+        bool violation = false;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            int code[4];
+            bool nzf[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t pair = ws[2 * qd + (e >> 1)];
+                const uint32_t bits16 = (e & 1) ? (pair >> 16) : (pair & 0xffffu);
+                float x = XDT == CT_BF16 ? round_to<CT_F16>(bf16_bits_to_f(bits16)) : f16_bits_to_f(bits16);  // weight.to(fp16)
+                float t = round_to<CT_F16>(x / s16);
+                if (has_zp) t = round_to<CT_F16>(t + z16);
+                t = __builtin_rintf(clamp_nan(t, qmin, qmax));
+                nzf[e] = t != 0.0f;  // true for NaN, like torch's `!= 0`
+                code[e] = (int)t;    // NaN -> 0 (v_cvt_i32_f32)
+            }
+            violation |= ((int)nzf[0] + (int)nzf[1] + (int)nzf[2] + (int)nzf[3]) > 2;
+            const uint32_t qc = quad_code(nzf[0], nzf[1], nzf[3]);
+            word |= qc << (4 * qd);
+            const uint32_t i0 = qc & 3u, i1 = (qc >> 2) & 3u;
+            const int v0 = i0 == 0 ? code[0] : (i0 == 1 ? code[1] : (i0 == 2 ? code[2] : code[3]));
+            const int v1 = i1 == 0 ? code[0] : (i1 == 1 ? code[1] : (i1 == 2 ? code[2] : code[3]));
+            const uint32_t two = ((uint32_t)v0 & 0xffu) | (((uint32_t)v1 & 0xffu) << 8);
+            if (qd < 2) lo |= two << (16 * qd); else hi |= two << (16 * (qd - 2));
+        }
+        stream_store8(comp + r * (k / 2) + mc * 8, u32x2{lo, hi});
+        meta[meta_reorder_offset(r, mc, m, 2)] = (uint16_t)word;
+        if (violation) atomicOr(bad, 1);
+    }
+}
+
 // entry `within` of the marlin-24 weight permutation (permutations_24.py:20-45), computed
 // arithmetically instead of from a 1024-entry table
 __host__ __device__ __forceinline__ int marlin24_perm_entry(int within, int bits) {
@@ -218,6 +277,32 @@ int ct_cutlass24_to_dense(const void* sparse, int dt, const void* meta, int meta
     if (dt == CT_I8) hipLaunchKernelGGL((cutlass24_to_dense_kernel<1>), dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), sparse, meta, m, k, dense);
     else hipLaunchKernelGGL((cutlass24_to_dense_kernel<2>), dim3(grid_1d(total)), dim3(kBlock), 0, as_stream(stream), sparse, meta, m, k, dense);
     CT_LAUNCH_CHECK("ct_cutlass24_to_dense");
+}
+
+int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                               int bits, int8_t* comp, int16_t* meta, int* bad, ct_stream_t stream) {
+    CT_REQUIRE(wdt == CT_F16 || wdt == CT_BF16, "marlin-24 weights must be 16-bit floats, got dtype %d", wdt);
+    CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
+    CT_REQUIRE(bits == 4 || bits == 8, "num_bits must be 4 or 8, got %d", bits);
+    CT_REQUIRE(m >= 0 && k >= 0 && m % 64 == 0 && k % 16 == 0, "marlin-24 needs rows %% 64 == 0 and cols %% 16 == 0, got (%lld, %lld)", (long long)m,
+               (long long)k);
+    CT_REQUIRE(cdiv >= 16 && (cdiv % 16 == 0 || cdiv >= k), "group size %lld must be a multiple of 16", (long long)cdiv);
+    CT_REQUIRE(aligned16(w) && (reinterpret_cast<uintptr_t>(comp) & 7u) == 0 && bad != nullptr, "misaligned buffers");
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
+    if (e != hipSuccess) return hip_check(e, "ct_marlin24_quant_compress memset");
+    if (m == 0 || k == 0) return CT_OK;
+    const int64_t c = cdiv > k ? k : cdiv;
+    const int64_t scale_cols = k / c;
+    const float qmax = (float)((1 << bits) / 2 - 1), qmin = -(float)((1 << bits) / 2);
+    const int64_t total = m * (k / 16);
+    const unsigned grid = (unsigned)(cdiv64(total, kBlock) < ((int64_t)1 << 30) ? cdiv64(total, kBlock) : ((int64_t)1 << 30));
+    if (wdt == CT_BF16)
+        hipLaunchKernelGGL((marlin24_quant_compress_kernel<CT_BF16>), dim3(grid), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, scale_cols,
+                           qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
+    else
+        hipLaunchKernelGGL((marlin24_quant_compress_kernel<CT_F16>), dim3(grid), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, scale_cols,
+                           qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
+    CT_LAUNCH_CHECK("ct_marlin24_quant_compress");
 }
 
 int ct_marlin24_pack_weights(const void* q, int dt, int transposed, int add_offset, int64_t size_k, int64_t size_n, int bits, int32_t* packed,

@@ -200,6 +200,16 @@ int ct_cutlass24_from_dense(const void* dense, int dt, int64_t m, int64_t k, voi
 int ct_cutlass24_to_dense(const void* sparse, int dt, const void* meta, int meta_itemsize, int64_t m,
                           int64_t k, void* dense, ct_stream_t stream);
 
+/* marlin-24 front end, fused (restated Marlin24Compressor.compress): fp16 quantize
+ * of a 2:4-sparse 16-bit weight (every op rounded to fp16, like quantize() on weight.to(fp16)),
+ * 2:4 compression of the codes (utils/semi_structured_conversions.py:66-197 on the 16-bit flavour:
+ * int16 metadata, reordered) without any full-size intermediate.  comp: int8 (m, k/2) kept codes
+ * (no offset); meta: int16 (m, k/16) reordered; bad[0] != 0 afterwards if some quad had more than
+ * two non-zero codes (the weight is not 2:4).  scale: (m, k/cdiv), zp nullable. */
+int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
+                               int64_t m, int64_t k, int64_t cdiv, int bits, int8_t* comp, int16_t* meta,
+                               int* bad, ct_stream_t stream);
+
 /* marlin-24 weight packing (historical Marlin24Compressor.pack_weight_24 with the table of
  * utils/permutations_24.py:20-45).  q: codes of dtype dt (CT_I32 / CT_I8 / float holding
  * integers), laid out (size_k, size_n) [transposed == 0] or as the un-transposed 2:4-compressed

@@ -409,6 +409,31 @@ def test_marlin24_vs_oracle(cta, dev, bits, strategy, gs):
     assert torch.equal(perm, O.marlin24_perm(bits).long())
 
 
+def test_marlin24_rejects_dense_weight(cta, dev):
+    """a weight that is not 2:4 must be refused (fused front end: device flag, one host read)"""
+    w = torch.randn(64, 256).to(BF16)
+    scale, zp = O.calculate_qparams_minmax(w.to(F16), num_bits=4, group_size=128, symmetric=True)
+    args = cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    with pytest.raises(ValueError, match="2:4 sparsity structure"):
+        cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+
+
+@pytest.mark.parametrize("wdt", [BF16, F16])
+def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt):
+    """ct_marlin24_quant_compress == weight.to(fp16) -> quantize (fp16) -> cutlass 2:4 compress"""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn((192, 1024), generator=g).to(wdt)
+    w = (w * O.sparse24_mask(w).to(w.dtype)).to(dev)
+    w[0, :4] = 0
+    scale, zp = cta.codec.minmax_qparams(w.to(F16), num_bits=4, group_size=128, symmetric=True)
+    comp, meta, bad = cta.codec.marlin24_quant_compress(w, scale, zp, num_bits=4, group_size=128)
+    q = cta.codec.quantize_tensor(w.to(F16), scale, zp, num_bits=4, strategy="group", group_size=128)
+    comp_ref, meta_ref = cta.codec.cutlass24_from_dense(q)
+    assert int(bad.item()) == 0
+    assert torch.equal(comp.cpu().float(), comp_ref.cpu().float()) and torch.equal(meta.cpu(), meta_ref.cpu())
+
+
 # ----------------------------------------------------------------------------- modules / staging
 def test_compress_decompress_module(cta, dev):
     """reference tests/test_compressors/test_compress_decompress_module.py:24-127"""
