@@ -29,8 +29,12 @@ def parse(path, counter):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
-    fetch = parse(f"{src}/pmc_fetch.txt", "FETCH_SIZE")
-    write = parse(f"{src}/pmc_write.txt", "WRITE_SIZE")
+    # every kernel from the full bench; the W4 headline kernels from the --no-extra run, where each of their
+    # launches is the 8192x8192 workload (the full bench also launches them on small TinyLlama-shaped tensors)
+    fetch = parse(f"{src}/extras_fetch.txt", "FETCH_SIZE")
+    write = parse(f"{src}/extras_write.txt", "WRITE_SIZE")
+    fetch.update(parse(f"{src}/headline_fetch.txt", "FETCH_SIZE"))
+    write.update(parse(f"{src}/headline_write.txt", "WRITE_SIZE"))
     res = {"_source": f"{src}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py",
            "_formula": "bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950 read under-count) + WRITE_SIZE * 1024"}
     for k in sorted(set(fetch) & set(write)):

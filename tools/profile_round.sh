@@ -1,7 +1,9 @@
 #!/bin/bash
-# Run ON THE GPU BOX (through gpurun): kernel-trace stats + separate PMC passes of the default bench
-# command, summaries written to gpurun_out/profile_<tag>/.  Counters are collected in their own
-# runs (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: they do not fit one pass) with --kernel-trace only.
+# Run ON THE GPU BOX (through gpurun): kernel-trace stats + separate PMC passes of the bench command,
+# summaries written to gpurun_out/profile_<tag>/.  Counters are collected in their own runs
+# (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: they do not fit one pass) with --kernel-trace only.
+# "headline": the timed W4A16 8192^2 step only (--no-extra), so that per-kernel averages are not mixed
+# with the small TinyLlama-shaped launches; "extras": the whole default bench (all legs).
 #   usage: tools/profile_round.sh <tag>
 set -u
 TAG=${1:-r01}
@@ -9,13 +11,19 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/trace -o run -- $CMD > "$OUT/bench_under_trace.json" 2> /dev/null
-python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/trace/run_results.db > "$OUT/kernel_trace_stats.txt"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_$TAG/fetch -o run -- $CMD > /dev/null 2>&1
-python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/fetch/run_results.db > "$OUT/pmc_fetch.txt"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_$TAG/write -o run -- $CMD > /dev/null 2>&1
-python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/write/run_results.db > "$OUT/pmc_write.txt"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_$TAG/sq -o run -- $CMD > /dev/null 2>&1
-python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/sq/run_results.db > "$OUT/pmc_sq.txt"
+HEAD="python $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extra"
+FULL="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+run() {  # name, rocprof args..., -- cmd
+    local name=$1; shift
+    rocprofv3 --kernel-trace "$@" > "$OUT/$name.stdout" 2> /dev/null
+    python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/$name/run_results.db > "$OUT/$name.txt"
+}
+run headline_trace --stats -d /tmp/prof_$TAG/headline_trace -o run -- $HEAD
+run headline_fetch --pmc FETCH_SIZE -d /tmp/prof_$TAG/headline_fetch -o run -- $HEAD
+run headline_write --pmc WRITE_SIZE -d /tmp/prof_$TAG/headline_write -o run -- $HEAD
+run headline_sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_$TAG/headline_sq -o run -- $HEAD
+run extras_trace --stats -d /tmp/prof_$TAG/extras_trace -o run -- $FULL
+run extras_fetch --pmc FETCH_SIZE -d /tmp/prof_$TAG/extras_fetch -o run -- $FULL
+run extras_write --pmc WRITE_SIZE -d /tmp/prof_$TAG/extras_write -o run -- $FULL
+rm -f "$OUT"/*_fetch.stdout "$OUT"/*_write.stdout "$OUT"/*_sq.stdout
 ls -la "$OUT"
