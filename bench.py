@@ -8,7 +8,9 @@ A "step" is one pass of the hot path over one batch of synthetic input: W4A16 pa
 8192x8192 packed weight (BASELINE.json configs[1]), through the C ABI of libct_hip.so with all
 inputs resident in HBM.  Buffers rotate over 16 disjoint sets (4.8 GiB; even the smallest stream,
 the packed words, is 537 MB across the sets) so the 256 MiB Infinity Cache cannot serve re-reads:
-numbers are HBM-cold.
+numbers are HBM-cold.  The timed loop issues the step's two independent launches on two HIP streams
+(`value`); the same loop on one stream is reported as `value_one_stream`, and the per-kernel
+roofline figures are single-stream HIP-event timings of back-to-back launches.
 
 value = algorithmic bytes of all ranks / max-over-ranks wall time, in GB/s; algorithmic bytes
 per step = 2 x (2 N^2 + 2 N^2/128 + N^2/2) = 337,641,472 B at N = 8192.
@@ -51,8 +53,10 @@ def make_sets(dev, rank):
     return sets
 
 
-def make_launchers(sets, stream):
-    """direct C-ABI launches with precomputed arguments (what a C host would do)"""
+def make_launchers(sets, stream, stream_d=None):
+    """direct C-ABI launches with precomputed arguments (what a C host would do); compress goes to
+    `stream`, decompress to `stream_d` (default: the same stream)"""
+    stream_d = stream if stream_d is None else stream_d
     from compressed_tensors_amd import _lib
 
     lib = _lib.load()
@@ -64,7 +68,7 @@ def make_launchers(sets, stream):
         comp_args.append((s["w"].data_ptr(), BF16, s["scale"].data_ptr(), BF16, s["zp"].data_ptr(), _lib.I8,
                           N, N, 1, GROUP, N // GROUP, None, BITS, BF16, s["packed"].data_ptr(), stream))
         decomp_args.append((s["packed"].data_ptr(), N, N // 8, N, BITS, s["scale"].data_ptr(), BF16, None, -1,
-                            1, GROUP, N // GROUP, None, s["out"].data_ptr(), BF16, stream))
+                            1, GROUP, N // GROUP, None, s["out"].data_ptr(), BF16, stream_d))
 
     def compress(i):
         rc = lib.ct_quant_pack(*comp_args[i % NSETS])
@@ -352,6 +356,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--one-stream", action="store_true", help="issue the step's two launches on one HIP stream")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -364,13 +369,22 @@ def main():
         raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # CT_BENCH_SHARE_GPU=1 (test knob): every rank uses cuda:0 and the timing collectives go over gloo, so
+    # that the N > 1 code path can be exercised on a one-GPU box
+    share_gpu = os.environ.get("CT_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if share_gpu else dev
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        if share_gpu:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
 
     import __graft_entry__ as ge
 
@@ -378,32 +392,41 @@ def main():
     sets = make_sets(dev, rank)
     stream = torch.cuda.current_stream(dev).cuda_stream
     compress, decompress = make_launchers(sets, stream)
-
-    def step(i):
-        compress(i)
-        decompress(i + NSETS // 2)  # a packed buffer written 8 steps (1.3 GB of traffic) ago: evicted from the Infinity Cache
-
-    for i in range(NSETS):  # populate every packed buffer once
-        compress(i)
-    for i in range(a.warmup):
-        step(i)
+    # the step's two operations are independent (different tensors): the timed loop issues the compress
+    # on one HIP stream and the decompress on another, so the ramp / tail of one launch overlaps the
+    # other; --one-stream keeps both on a single stream.  (The decompress reads a
+    # packed buffer whose last rewrite, with identical bytes, was issued 8 steps earlier on the other stream.)
+    s_c, s_d = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    compress2, decompress2 = make_launchers(sets, s_c.cuda_stream, s_d.cuda_stream)
 
     def barrier():
         if distributed:
             dist.barrier()
 
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only; the data path has no collective
-        elapsed = float(t.item())
+    def timed_steps(c, d):
+        for i in range(NSETS):  # populate every packed buffer once
+            c(i)
+        torch.cuda.synchronize()
+        for i in range(a.warmup):
+            c(i)
+            d(i + NSETS // 2)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            c(i)
+            d(i + NSETS // 2)  # a packed buffer written 8 steps (1.3 GB of traffic) ago: evicted from the Infinity Cache
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only; the data path has no collective
+            el = float(t.item())
+        return el
+
+    elapsed_one = timed_steps(compress, decompress)
+    elapsed = elapsed_one if a.one_stream else timed_steps(compress2, decompress2)
 
     step_bytes = 2 * alg_bytes_one_direction()
     value = world * step_bytes * a.steps / elapsed / 1e9
@@ -443,9 +466,11 @@ def main():
                 "alg_bytes_per_step_per_gpu": step_bytes,
                 "buffers": f"{NSETS} rotating sets (HBM-cold)",
                 "boundary": "C ABI (ct_quant_pack + ct_unpack_dequant), inputs resident in HBM",
+                "streams": 1 if a.one_stream else 2,
                 "parallelism": f"{world} independent weight shards, no collectives",
             },
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
+            "value_one_stream": round(world * step_bytes * a.steps / elapsed_one / 1e9, 1),
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom,
@@ -474,7 +499,7 @@ def main():
         def allreduce_max(x):
             if not distributed:
                 return x
-            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            t = torch.tensor([x], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only
             return float(t.item())
 
