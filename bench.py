@@ -274,6 +274,22 @@ def marlin24_leg(dev):
             "outputs": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}}
 
 
+def qparams_leg(dev):
+    """SURVEY 8f N1, the step before compress: min-max observer + calculate_qparams (group 128, symmetric)
+    over 8192x8192 bf16 — one streaming read of the weight (134.2 MB) + 1.6 MB of scales / zero points"""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = [torch.randn(N, N, dtype=torch.bfloat16, device=dev) for _ in range(8)]
+    sc = torch.empty(N, N // GROUP, dtype=torch.bfloat16, device=dev)
+    zp = torch.empty(N, N // GROUP, dtype=torch.int8, device=dev)
+    us = time_kernel(lambda i: lib.ct_minmax_qparams(ws[i % 8].data_ptr(), _lib.BF16, N, N, GROUP, BITS, 1, sc.data_ptr(), zp.data_ptr(), stream), 48)
+    alg = 2 * N * N + 3 * N * (N // GROUP)
+    return {"workload": f"min-max observer + calculate_qparams, int4 g128 symmetric, {N}x{N} bf16", "alg_bytes": alg,
+            "us": round(us, 2), "GBps": round(alg / us / 1e3, 1), "frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4)}
+
+
 TINYLLAMA_LAYER = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048),
                    ("gate_proj", 5632, 2048), ("up_proj", 5632, 2048), ("down_proj", 2048, 5632))
 
@@ -487,7 +503,7 @@ def main():
         if world == 1 and not a.no_extra:
             del sets
             torch.cuda.empty_cache()
-            for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg)):
+            for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down

@@ -59,36 +59,66 @@ __device__ __forceinline__ void emit_qparams(MinMax m, int bits, int symmetric, 
     }
 }
 
-// groups of LPG lanes x 8 elements (cdiv = 8 * LPG, LPG a power of two <= 64), cols % cdiv == 0
-template <int XDT>
-__global__ __launch_bounds__(kBlock) void qparams_subwave_kernel(const void* __restrict__ x, int64_t units, int lpg, int bits, int symmetric,
+// all-lanes reduction over aligned groups of `lpg` lanes (power of two).  Inside a 16-lane row the
+// exchange is DPP (no LDS crossbar traffic): quad_perm xor 1, xor 2, then row_half_mirror and
+// row_mirror, which pair the quads / halves — any pairing that covers the group reduces it.
+// Wider groups finish with ds_bpermute (xor 16, 32).  The shuffle form cost 12 ds_bpermute per
+// 8-element unit and held the kernel at 36.6 us for 134 MB; the read-only ceiling is 21.3 us.
+template <int CTRL>
+__device__ __forceinline__ MinMax mm_dpp(MinMax m) {
+    MinMax o;
+    o.mn = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m.mn), CTRL, 0xf, 0xf, false));
+    o.mx = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m.mx), CTRL, 0xf, 0xf, false));
+    o.nan = __builtin_amdgcn_update_dpp(0, m.nan, CTRL, 0xf, 0xf, false);
+    return mm_merge(m, o);
+}
+
+__device__ __forceinline__ MinMax group_reduce(MinMax m, int lpg) {
+    if (lpg >= 2) m = mm_dpp<0xB1>(m);   // quad_perm [1,0,3,2]
+    if (lpg >= 4) m = mm_dpp<0x4E>(m);   // quad_perm [2,3,0,1]
+    if (lpg >= 8) m = mm_dpp<0x141>(m);  // row_half_mirror
+    if (lpg >= 16) m = mm_dpp<0x140>(m); // row_mirror
+    for (int d = 16; d < lpg; d <<= 1) {
+        MinMax o;
+        o.mn = __shfl_xor(m.mn, d, 64);
+        o.mx = __shfl_xor(m.mx, d, 64);
+        o.nan = __shfl_xor(m.nan, d, 64);
+        m = mm_merge(m, o);
+    }
+    return m;
+}
+
+// groups of LPG lanes x Q units x 8 elements (cdiv = 64 * LPG for Q = 8 ...; LPG a power of two <= 64),
+// cols % cdiv == 0.  A lane owns Q CONSECUTIVE units (Q x 16 B loads in flight: with one unit per lane
+// a CU had only 32 KB outstanding and the kernel sat at 3.3 TB/s) and reduces them locally, the group is
+// finished with DPP, and one lane in LPG runs the (divide-heavy, divergent) scale / zero-point math.
+template <int XDT, int Q>
+__global__ __launch_bounds__(kBlock) void qparams_subwave_kernel(const void* __restrict__ x, int64_t lanes_total, int lpg, int bits, int symmetric,
                                                                  void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
-    // units is a multiple of lpg, and kBlock is a multiple of lpg: groups never straddle waves
+    // lanes_total is a multiple of lpg, and kBlock is a multiple of lpg: groups never straddle waves
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    const int64_t nloops = (units + stride - 1) / stride;
-    int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    for (int64_t it = 0; it < nloops; ++it, u += stride) {
+    const int64_t nloops = (lanes_total + stride - 1) / stride;
+    int64_t l = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int64_t it = 0; it < nloops; ++it, l += stride) {
         MinMax m;
         m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
-        const bool live = u < units;
+        const bool live = l < lanes_total;
         if (live) {
-            float v[8];
-            load8<XDT>(x, u << 3, v);
+            float v[Q][8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                m.nan |= (v[k] != v[k]);
-                m.mn = __builtin_fminf(m.mn, v[k]);
-                m.mx = __builtin_fmaxf(m.mx, v[k]);
+            for (int q = 0; q < Q; ++q) load8<XDT>(x, (l * Q + q) << 3, v[q]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    m.nan |= (v[q][k] != v[q][k]);
+                    m.mn = __builtin_fminf(m.mn, v[q][k]);
+                    m.mx = __builtin_fmaxf(m.mx, v[q][k]);
+                }
             }
         }
-        for (int d = 1; d < lpg; d <<= 1) {
-            MinMax o;
-            o.mn = __shfl_xor(m.mn, d, 64);
-            o.mx = __shfl_xor(m.mx, d, 64);
-            o.nan = __shfl_xor(m.nan, d, 64);
-            m = mm_merge(m, o);
-        }
-        if (live && (threadIdx.x & (lpg - 1)) == 0) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, u / lpg);
+        m = group_reduce(m, lpg);
+        if (live && (threadIdx.x & (lpg - 1)) == 0) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, l / lpg);
     }
 }
 
@@ -136,17 +166,22 @@ int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_
     CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
     CT_REQUIRE(rows >= 0 && cols >= 0 && cdiv >= 1, "bad shape");
     if (rows == 0 || cols == 0) return CT_OK;
-    const int64_t lpg = cdiv / 8;
-    const bool subwave = (cdiv % 8 == 0) && (cols % cdiv == 0) && lpg >= 1 && lpg <= 64 && log2_exact(lpg) >= 0 && aligned16(x);
+    const int64_t upg = cdiv / 8;  // units per group
+    const bool subwave = (cdiv % 8 == 0) && (cols % cdiv == 0) && upg >= 1 && upg <= 256 && log2_exact(upg) >= 0 && aligned16(x);
     if (subwave) {
         const int64_t units = rows * (cols / 8);
-        int64_t g = cdiv64(units, kBlock);
-        if (g > kCUs * 32) g = kCUs * 32;
+        const int q = upg >= 4 ? 4 : 1;  // consecutive units per lane
+        const int64_t lpg = upg / q, lanes = units / q;
+        int64_t g = cdiv64(lanes, kBlock);  // exact grid: many small workgroups stream best
+        if (g > ((int64_t)1 << 30)) g = (int64_t)1 << 30;
+#define CT_QP(DT) do { if (q == 4) hipLaunchKernelGGL((qparams_subwave_kernel<DT, 4>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, lanes, (int)lpg, bits, symmetric, scale_out, zp_out); \
+                       else hipLaunchKernelGGL((qparams_subwave_kernel<DT, 1>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, lanes, (int)lpg, bits, symmetric, scale_out, zp_out); } while (0)
         switch (xdt) {
-            case CT_BF16: hipLaunchKernelGGL((qparams_subwave_kernel<CT_BF16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, units, (int)lpg, bits, symmetric, scale_out, zp_out); break;
-            case CT_F16: hipLaunchKernelGGL((qparams_subwave_kernel<CT_F16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, units, (int)lpg, bits, symmetric, scale_out, zp_out); break;
-            default: hipLaunchKernelGGL((qparams_subwave_kernel<CT_F32>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, units, (int)lpg, bits, symmetric, scale_out, zp_out); break;
+            case CT_BF16: CT_QP(CT_BF16); break;
+            case CT_F16: CT_QP(CT_F16); break;
+            default: CT_QP(CT_F32); break;
         }
+#undef CT_QP
         CT_LAUNCH_CHECK("ct_minmax_qparams[subwave]");
     }
     const int64_t total = rows * cdiv64(cols, cdiv);
