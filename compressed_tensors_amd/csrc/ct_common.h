@@ -198,6 +198,62 @@ __device__ __forceinline__ void store_rt(void* base, int dt, int64_t i, float v)
     }
 }
 
+// BITS consecutive int32 words of a pack group: 16-byte / 8-byte vectors when the width and the
+// address allow (a lane owns BITS words; scalar stores at a BITS-word stride waste the store path:
+// W8 generic compress 94 us -> see DESIGN.md)
+template <int BITS>
+__device__ __forceinline__ void store_words(int32_t* o, const uint32_t* words, int64_t limit /*words still inside the row*/) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(o);
+    if (limit >= BITS) {
+        if constexpr (BITS % 4 == 0) {
+            if ((a & 15u) == 0) {
+#pragma unroll
+                for (int j = 0; j < BITS; j += 4) stream_store16(o + j, u32x4{words[j], words[j + 1], words[j + 2], words[j + 3]});
+                return;
+            }
+        }
+        if constexpr (BITS % 2 == 0) {
+            if ((a & 7u) == 0) {
+#pragma unroll
+                for (int j = 0; j < BITS; j += 2) stream_store8(o + j, u32x2{words[j], words[j + 1]});
+                return;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BITS; ++j)
+        if (j < limit) o[j] = (int32_t)words[j];
+}
+
+template <int BITS>
+__device__ __forceinline__ void load_words(const int32_t* in, uint32_t* words, int64_t limit) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(in);
+    if (limit >= BITS) {
+        if constexpr (BITS % 4 == 0) {
+            if ((a & 15u) == 0) {
+#pragma unroll
+                for (int j = 0; j < BITS; j += 4) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(in + j);
+                    words[j] = v.x; words[j + 1] = v.y; words[j + 2] = v.z; words[j + 3] = v.w;
+                }
+                return;
+            }
+        }
+        if constexpr (BITS % 2 == 0) {
+            if ((a & 7u) == 0) {
+#pragma unroll
+                for (int j = 0; j < BITS; j += 2) {
+                    const u32x2 v = *reinterpret_cast<const u32x2*>(in + j);
+                    words[j] = v.x; words[j + 1] = v.y;
+                }
+                return;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BITS; ++j) words[j] = j < limit ? (uint32_t)in[j] : 0u;
+}
+
 // ------------------------------------------------------------------------- quantization layout
 struct QLayout {
     int64_t rows, cols;

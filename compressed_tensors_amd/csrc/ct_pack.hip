@@ -55,10 +55,7 @@ __global__ __launch_bounds__(kBlock) void pack_rows_kernel(const int8_t* __restr
                 for (int i = 0; i < 32; ++i)
                     if (c0 + i < cols) pack_insert<BITS>(words, i, (int)qr[c0 + i]);
             }
-            int32_t* o = out + row * out_stride + g * BITS;
-#pragma unroll
-            for (int j = 0; j < BITS; ++j)
-                if (g * BITS + j < packed_cols) o[j] = (int32_t)words[j];
+            store_words<BITS>(out + row * out_stride + g * BITS, words, packed_cols - g * BITS);
         }
     }
 }
@@ -73,8 +70,7 @@ __global__ __launch_bounds__(kBlock) void unpack_rows_kernel(const int32_t* __re
         int8_t* orow = out + row * cols;
         for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < gpr; g += (int64_t)gridDim.x * kBlock) {
             uint32_t words[BITS + 1];
-#pragma unroll
-            for (int j = 0; j < BITS; ++j) words[j] = (g * BITS + j < words_per_row) ? (uint32_t)pr[g * BITS + j] : 0u;
+            load_words<BITS>(pr + g * BITS, words, words_per_row - g * BITS);
             words[BITS] = 0;
             const int64_t c0 = g << 5;
             if (vec && c0 + 32 <= cols) {

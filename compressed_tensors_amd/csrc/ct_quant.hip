@@ -28,10 +28,17 @@ struct QParams {
 // ------------------------------------------------------------------------------------------
 // cores
 // ------------------------------------------------------------------------------------------
+// reciprocal of a bf16 scale, or 0 when the shortcut x * fl(1/s) is not proven equal to x / s after the
+// rounding to bf16 (see w4_quant_word / ct_selftest_bf16_div): the caller then divides
+__device__ __forceinline__ float bf16_fast_rcp(float s) {
+    const float as = __builtin_fabsf(s);
+    return ((as >= 0x1p-64f) && (as <= 0x1p64f)) ? 1.0f / s : 0.0f;
+}
+
 template <int TDT>
 __device__ __forceinline__ float quant_core(float x, float s, bool has_zp, float zf, float qmin,
-                                            float qmax) {
-    float t = round_to<TDT>(x / s);  // IEEE-correct fp32 divide, then RNE to T
+                                            float qmax, float rs = 0.0f) {
+    float t = round_to<TDT>(rs != 0.0f ? x * rs : x / s);  // IEEE-correct fp32 divide (or the proven bf16 shortcut), RNE to T
     if (has_zp) t = round_to<TDT>(t + zf);
     t = clamp_nan(t, qmin, qmax);
     return __builtin_rintf(t);  // v_rndne_f32: round half to even
@@ -122,11 +129,14 @@ __global__ __launch_bounds__(kBlock) void quant_units_kernel(QParams p) {
             }
             const bool uni = unit_uniform(p.L, c0, n);
             SZ sz = load_sz_q<XDT>(p, srow, c0);
+            // one reciprocal per unit instead of eight divides when x, T and the scale are all bf16
+            const bool can_rcp = XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16;
+            float rs = (can_rcp && uni) ? bf16_fast_rcp(sz.s) : 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (k < n) {
                     if (!uni && k > 0) sz = load_sz_q<XDT>(p, srow, c0 + k);
-                    float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax);
+                    float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax, rs);
                     if constexpr (MODE == MODE_FQ) {
                         // dequantize in S = scale dtype (forward_helpers.py:207-215)
                         float zs = has_zp ? round_to_rt(p.sdt, load_rt(p.zp, p.zdt, srow + col_group_of(p.L, c0 + k))) : 0.0f;
@@ -218,10 +228,12 @@ __global__ __launch_bounds__(kBlock) void quant_pack_g32_kernel(QParams p, int64
                 }
                 const bool uni = unit_uniform(p.L, c0, n);
                 SZ sz = load_sz_q<XDT>(p, srow, c0);
+                const bool can_rcp = XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16;
+                const float rs = (can_rcp && uni) ? bf16_fast_rcp(sz.s) : 0.0f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (!uni && k > 0 && k < n) sz = load_sz_q<XDT>(p, srow, c0 + k);
-                    float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax);
+                    float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax, rs);
                     // NaN -> code of 0 (cvt saturates NaN to 0), padding elements contribute 0
                     uint32_t code = (k < n) ? (uint32_t)((int)t + (int)kOff) : 0u;
                     constexpr int dummy = 0;
@@ -232,10 +244,7 @@ __global__ __launch_bounds__(kBlock) void quant_pack_g32_kernel(QParams p, int64
                     if (sh + BITS > 32) words[w + 1] |= code >> (32 - sh);
                 }
             }
-            int32_t* o = packed + row * packed_cols + g * BITS;
-#pragma unroll
-            for (int j = 0; j < BITS; ++j)
-                if (g * BITS + j < packed_cols) o[j] = (int32_t)words[j];
+            store_words<BITS>(packed + row * packed_cols + g * BITS, words, packed_cols - g * BITS);
         }
     }
 }
@@ -257,9 +266,7 @@ __global__ __launch_bounds__(kBlock) void unpack_dequant_g32_kernel(QParams p, i
         for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < gpr;
              g += (int64_t)gridDim.x * kBlock) {
             uint32_t words[BITS + 1];
-            const int32_t* in = packed + row * words_per_row + g * BITS;
-#pragma unroll
-            for (int j = 0; j < BITS; ++j) words[j] = (g * BITS + j < words_per_row) ? (uint32_t)in[j] : 0u;
+            load_words<BITS>(packed + row * words_per_row + g * BITS, words, words_per_row - g * BITS);
             words[BITS] = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -605,6 +612,43 @@ __global__ __launch_bounds__(kBlock) void q8_dequant_kernel(W4Params p) {
     }
 }
 
+
+// fake_quantize fast path (forward_helpers.py:180-215): x, scale and the result share one 16-bit dtype.
+// Same flat unit stream: lane = UNROLL units one block apart, 16 B in, 16 B out.
+template <int DT, int UNROLL, bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, float qmax) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
+    const u32x4* in = static_cast<const u32x4*>(p.x);
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
+        u32x4 raw[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u = base + (int64_t)i * kBlock;
+            if (u < p.units) raw[i] = in[u];
+        }
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u = base + (int64_t)i * kBlock;
+            if (u >= p.units) continue;
+            const int64_t si = w4_scale_index(p, u);
+            const float s = load_as_f<DT>(p.scale, si);
+            const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype) == zp.to(scale.dtype) here
+            const float rs = DT == CT_BF16 ? bf16_fast_rcp(s) : 0.0f;
+            const uint32_t ws[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0, x1;
+                unpack2<DT>(ws[j], x0, x1);
+                const float t0 = quant_core<DT>(x0, s, HAS_ZP, z, qmin, qmax, rs), t1 = quant_core<DT>(x1, s, HAS_ZP, z, qmin, qmax, rs);
+                v[2 * j] = dequant_core<DT>(t0, HAS_ZP, z, s);
+                v[2 * j + 1] = dequant_core<DT>(t1, HAS_ZP, z, s);
+            }
+            store8<DT>(p.out, u * 8, v);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // diagnostics: exhaustive check of the reciprocal fast path
 // ------------------------------------------------------------------------------------------
@@ -807,6 +851,17 @@ int ct_fake_quantize(const void* x, int xdt, const void* scale, int sdt, const v
     int rc = fill_qparams(p, x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, out, odt);
     if (rc) return rc;
     if (rows == 0 || cols == 0) return CT_OK;
+    if (odt == xdt && !col_group && (xdt == CT_BF16 || xdt == CT_F16) && sdt == xdt && tdt == xdt && cols % 8 == 0 &&
+        (cdiv % 8 == 0 || cdiv >= cols) && aligned16(x) && aligned16(out)) {
+        W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        constexpr int U = 2;
+        dim3 gf(w4_grid(w.units, U));
+#define CT_FQ(DT, ZP) hipLaunchKernelGGL((fq16_kernel<DT, U, ZP>), gf, dim3(kBlock), 0, as_stream(stream), w, p.qmin, p.qmax)
+        if (xdt == CT_BF16) { if (zp) CT_FQ(CT_BF16, true); else CT_FQ(CT_BF16, false); }
+        else { if (zp) CT_FQ(CT_F16, true); else CT_FQ(CT_F16, false); }
+#undef CT_FQ
+        CT_LAUNCH_CHECK("ct_fake_quantize[fq16]");
+    }
     dim3 grid = grid_2d(rows, cdiv64(cols, 8));
     CT_DISPATCH_XT(xdt, tdt, hipLaunchKernelGGL((quant_units_kernel<X, T, MODE_FQ>), grid, dim3(kBlock), 0, as_stream(stream), p));
     CT_LAUNCH_CHECK("ct_fake_quantize");
@@ -866,6 +921,22 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
 #undef CT_W4Q
         CT_LAUNCH_CHECK("ct_quant_pack[w4]");
     }
+    if (bits == 8 && cols % 32 == 0 && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, packed)) {
+        // 8-bit words are four (code + 128) bytes: the int8 stream kernel with OFF = 128
+        W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
+        const bool shared = (cdiv % 16 == 0) || cdiv >= cols;
+        dim3 g8(w4_grid(w.units / 2, 1));
+#define CT_Q8P(DT, ZP, SH) hipLaunchKernelGGL((q8_quant_kernel<DT, ZP, SH, 128>), g8, dim3(kBlock), 0, as_stream(stream), w, -128, 127)
+        if (xdt == CT_BF16) {
+            if (zp) { if (shared) CT_Q8P(CT_BF16, true, true); else CT_Q8P(CT_BF16, true, false); }
+            else { if (shared) CT_Q8P(CT_BF16, false, true); else CT_Q8P(CT_BF16, false, false); }
+        } else {
+            if (zp) { if (shared) CT_Q8P(CT_F16, true, true); else CT_Q8P(CT_F16, true, false); }
+            else { if (shared) CT_Q8P(CT_F16, false, true); else CT_Q8P(CT_F16, false, false); }
+        }
+#undef CT_Q8P
+        CT_LAUNCH_CHECK("ct_quant_pack[w8]");
+    }
     p.vec = (cols % 8 == 0) && aligned16(x);
     const int64_t packed_cols = cdiv64(cols * bits, 32);
     dim3 grid = grid_2d(rows, cdiv64(cols, 32));
@@ -895,6 +966,17 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_F16, U, false>), grid, dim3(kBlock), 0, as_stream(stream), w);
         }
         CT_LAUNCH_CHECK("ct_unpack_dequant[w4]");
+    }
+    if (bits == 8 && words == cols / 4 && cols % 32 == 0 && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 &&
+        (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(packed) & 7u) == 0) {
+        W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        constexpr int U = 2;
+        dim3 g8(w4_grid(w.units, U));
+#define CT_Q8U(DT, ZP) hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 128>), g8, dim3(kBlock), 0, as_stream(stream), w)
+        if (sdt == CT_BF16) { if (zp) CT_Q8U(CT_BF16, true); else CT_Q8U(CT_BF16, false); }
+        else { if (zp) CT_Q8U(CT_F16, true); else CT_Q8U(CT_F16, false); }
+#undef CT_Q8U
+        CT_LAUNCH_CHECK("ct_unpack_dequant[w8]");
     }
     p.vec = (cols % 8 == 0) && aligned16(out);
     dim3 grid = grid_2d(rows, cdiv64(cols, 32));
