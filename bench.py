@@ -453,7 +453,7 @@ def main():
         us_c = time_kernel(compress, 60)
         us_d = time_kernel(decompress, 60, offset=NSETS // 2)
         kernels = {
-            "w4_quant_pack_kernel<bf16>": {"avg_us": round(us_c, 2), "GBps": round(one / us_c / 1e3, 1), "frac": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4)},
+            "w4_quant_pack_lean_kernel<bf16>": {"avg_us": round(us_c, 2), "GBps": round(one / us_c / 1e3, 1), "frac": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4)},
             "w4_unpack_dequant_kernel<bf16>": {"avg_us": round(us_d, 2), "GBps": round(one / us_d / 1e3, 1), "frac": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4)},
         }
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"])

@@ -432,6 +432,54 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
         w4_quant_pack_group<DT, HAS_ZP, SHARED>(p, g);
 }
 
+
+// lean compress body for the common layout (flat scale index = lane >> gshift, one scale per lane, int8
+// zero point): no grid-stride loop, no generic index arithmetic, and the scale / zero point are loaded
+// BEFORE the 64 bytes of weights so that the reciprocal is ready when they land.  30.3 -> 29.4 us at 8192^2.
+template <int DT, bool HAS_ZP>
+__device__ __forceinline__ void w4_quant_pack_lean(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale,
+                                                   const int8_t* __restrict__ zp, u32x4* __restrict__ out, int64_t g, int gshift) {
+    const int64_t si = g >> gshift;
+    const uint32_t sbits = __builtin_nontemporal_load(scale + si);
+    const float z = HAS_ZP ? (float)__builtin_nontemporal_load(zp + si) : 0.0f;  // int8 -> exact in bf16 / fp16
+    asm volatile("" ::: "memory");  // keep the small loads ahead of the big ones
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[g * 4 + i];
+    const float s = DT == CT_BF16 ? bf16_bits_to_f(sbits) : f16_bits_to_f(sbits);
+    const float as = __builtin_fabsf(s);
+    const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+    const float rs = 1.0f / s;
+    const bool use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
+    uint32_t w[4];
+    if (fast) {
+        if (use_zp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = w4_quant_word<DT, true, true>(r[i], s, rs, z);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = w4_quant_word<DT, true, false>(r[i], s, rs, z);
+        }
+    } else {
+        if (use_zp) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = w4_quant_word<DT, false, true>(r[i], s, rs, z);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = w4_quant_word<DT, false, false>(r[i], s, rs, z);
+        }
+    }
+    stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+}
+
+template <int DT, bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void w4_quant_pack_lean_kernel(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale,
+                                                                    const int8_t* __restrict__ zp, u32x4* __restrict__ out, int64_t groups,
+                                                                    int gshift /* log2(lanes per scale group) */) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g < groups) w4_quant_pack_lean<DT, HAS_ZP>(in, scale, zp, out, g, gshift);
+}
+
 // UNROLL units per lane, one block apart, starting at `base`
 template <int DT, int UNROLL, bool HAS_ZP>
 __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64_t base) {
@@ -498,6 +546,12 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_batch_kernel(const ct_w4
     const W4Params p = batch_params(it);
     const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
     if (g >= p.units / 4) return;
+    if (it.upg_shift >= 2) {  // power-of-two group of at least 32 columns: the lean body
+        const int gshift = it.upg_shift - 2;
+        if (p.zp) w4_quant_pack_lean<DT, true>(static_cast<const u32x4*>(p.x), static_cast<const uint16_t*>(p.scale), static_cast<const int8_t*>(p.zp), static_cast<u32x4*>(p.out), g, gshift);
+        else w4_quant_pack_lean<DT, false>(static_cast<const u32x4*>(p.x), static_cast<const uint16_t*>(p.scale), nullptr, static_cast<u32x4*>(p.out), g, gshift);
+        return;
+    }
     if (p.zp) w4_quant_pack_group<DT, true, true>(p, g);
     else w4_quant_pack_group<DT, false, true>(p, g);
 }
@@ -910,6 +964,16 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
         const bool shared = (cdiv % 32 == 0) || cdiv >= cols;  // 4 consecutive units share a scale
         dim3 grid(w4_grid(w.units / 4, 1));
+        if (shared && w.flat_scale && w.upg_shift >= 2 && w.upg_shift < 62 && (zp == nullptr || zdt == CT_I8) && w.units / 4 < ((int64_t)1 << 38)) {
+            const int gshift = w.upg_shift - 2;
+            const int64_t groups = w.units / 4;
+            dim3 gl((unsigned)cdiv64(groups, kBlock));
+#define CT_W4L(DT, ZP) hipLaunchKernelGGL((w4_quant_pack_lean_kernel<DT, ZP>), gl, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), static_cast<const uint16_t*>(scale), static_cast<const int8_t*>(zp), reinterpret_cast<u32x4*>(packed), groups, gshift)
+            if (xdt == CT_BF16) { if (zp) CT_W4L(CT_BF16, true); else CT_W4L(CT_BF16, false); }
+            else { if (zp) CT_W4L(CT_F16, true); else CT_W4L(CT_F16, false); }
+#undef CT_W4L
+            CT_LAUNCH_CHECK("ct_quant_pack[w4 lean]");
+        }
 #define CT_W4Q(DT, ZP, SH) hipLaunchKernelGGL((w4_quant_pack_kernel<DT, ZP, SH>), grid, dim3(kBlock), 0, as_stream(stream), w)
         if (xdt == CT_BF16) {
             if (zp) { if (shared) CT_W4Q(CT_BF16, true, true); else CT_W4Q(CT_BF16, true, false); }
@@ -958,6 +1022,8 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         constexpr int U = 2;
         dim3 grid(w4_grid(w.units, U));
+        // (a scales-first lean variant of this kernel measured SLOWER: 39-42 us vs 30 us)
+        // units per lane re-swept with non-temporal stores: U = 1 / 2 / 4 / 8 -> 33.4 / 29.2 / 33.0 / 30.5 us
         if (sdt == CT_BF16) {
             if (zp) hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U, true>), grid, dim3(kBlock), 0, as_stream(stream), w);
             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U, false>), grid, dim3(kBlock), 0, as_stream(stream), w);
