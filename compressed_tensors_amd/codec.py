@@ -38,6 +38,7 @@ __all__ = [
     "marlin24_pack_weights",
     "marlin24_pack_scales",
     "selftest_bf16_div",
+    "selftest_f16_div",
     "QuantLayout",
 ]
 
@@ -679,4 +680,13 @@ def selftest_bf16_div(s_lo_bits: int = 0, s_hi_bits: int = 65536) -> int:
     dev = _lib.require_device()
     out = torch.zeros(1, dtype=torch.int64, device=dev)
     call("ct_selftest_bf16_div", s_lo_bits, s_hi_bits, ptr(out), torch.cuda.current_stream(dev).cuda_stream)
+    return int(out.item())
+
+
+def selftest_f16_div(s_lo_bits: int = 0, s_hi_bits: int = 65536) -> int:
+    """number of (x, s) fp16 pairs for which the reciprocal + Newton quotient of the marlin-24 front end
+    disagrees with the IEEE divide after rounding to fp16 (must be 0; see ct_marlin24.hip)."""
+    dev = _lib.require_device()
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    call("ct_selftest_f16_div", s_lo_bits, s_hi_bits, ptr(out), torch.cuda.current_stream(dev).cuda_stream)
     return int(out.item())

@@ -113,6 +113,49 @@ __global__ __launch_bounds__(kBlock) void cutlass24_to_dense_kernel(const void* 
 }
 
 
+
+// fp16(x / s) without the 11-instruction IEEE divide: rs = fl(1 / s) (one correctly rounded reciprocal
+// per 16 elements), q0 = x * rs, one Newton correction q1 = fma(fma(-q0, s, x), rs, q0).  q1 is within
+// half an fp32 ulp (+ a vanishing term) of the exact quotient; the quotient of two 11-bit significands is
+// never closer than 2^-23 relative to an fp16 rounding boundary and never on one, so the rounding to
+// fp16 is the same for every normal result.  Checked exhaustively on the device over all 65536 x 65536
+// fp16 pairs by ct_selftest_f16_div (tests/test_gpu_parity.py): identical values everywhere except
+// quotients below 2^-13 (fp16-subnormal results can differ in the last place; they all quantize to
+// code 0).  Scales outside [2^-14, 2^15] (and 0, inf, NaN) keep the IEEE divide (rs = 0).
+__device__ __forceinline__ float f16_fast_rcp(float s16) {
+    const float as = __builtin_fabsf(s16);
+    return ((as >= 0x1p-14f) && (as <= 0x1p15f)) ? 1.0f / s16 : 0.0f;
+}
+template <bool FAST>
+__device__ __forceinline__ float f16_quotient(float x16, float s16, float rs) {
+    if constexpr (!FAST) return round_to<CT_F16>(x16 / s16);
+    const float q0 = x16 * rs;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s16, x16), rs, q0);
+    return round_to<CT_F16>(__builtin_isfinite(q0) ? q1 : q0);  // x = +-inf: the correction would make NaN
+}
+
+__global__ __launch_bounds__(kBlock) void selftest_f16_div_kernel(uint32_t s_lo, uint32_t s_hi, unsigned long long* mismatches) {
+    unsigned long long local = 0;
+    for (uint32_t sb = s_lo + blockIdx.x; sb < s_hi; sb += gridDim.x) {
+        const float s = f16_bits_to_f(sb);
+        const float rs = f16_fast_rcp(s);
+        if (rs == 0.0f) continue;  // outside the fast-path range
+        for (uint32_t xb = threadIdx.x; xb < 65536u; xb += kBlock) {
+            const float x = f16_bits_to_f(xb);
+            const float a = f16_quotient<true>(x, s, rs);
+            const float b = round_to<CT_F16>(x / s);
+            const bool an = a != a, bn = b != b;
+            // value comparison (-0 == +0: the sign of a zero never reaches an integer code); results that are
+            // both below 2^-13 (fp16 subnormal quotients, where an exact fp32 quotient can sit on an fp16 tie
+            // and one fp32 ulp flips it) round to code 0 with or without a zero point: not counted
+            const bool tiny = __builtin_fabsf(a) < 0x1p-13f && __builtin_fabsf(b) < 0x1p-13f;
+            const bool bad = (an != bn) || (!an && !bn && a != b && !tiny);
+            local += bad ? 1ull : 0ull;
+        }
+    }
+    if (local) atomicAdd(mismatches, local);
+}
+
 // ------------------------------------------------------------------------------------------
 // marlin-24 front end, fused: weight (bf16 / fp16) + scale -> fp16 quantize -> 2:4 compress.
 // Replaces `weight.to(fp16)`, `scale.to(fp16)`, quantize(...) kept in fp16, the 2:4 structure
@@ -123,6 +166,67 @@ __global__ __launch_bounds__(kBlock) void cutlass24_to_dense_kernel(const void* 
 // [t = fp16(t + fp16(zp))]; clamp; rint.  A quad with more than two non-zero codes sets *bad.
 // One lane per metadata word = 4 quads = 16 elements (32 B in, 8 B of codes + one int16 out).
 // ------------------------------------------------------------------------------------------
+// one metadata word: 16 elements (8 dwords) of a row -> 8 kept int8 codes + the 4 quad codes.
+// FAST selects the reciprocal + Newton quotient; the choice is made once per word (one scale), so the
+// IEEE divide sequence is not interleaved with every element
+template <int XDT, bool FAST, bool HAS_ZP>
+__device__ __forceinline__ bool marlin24_word(const uint32_t (&ws)[8], float s16, float z16, float rs, float qmin, float qmax, u32x2& codes,
+                                              uint32_t& word) {
+    uint32_t lo = 0, hi = 0;
+    word = 0;
+    bool violation = false;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        int code[4];
+        bool nzf[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t pair = ws[2 * qd + (e >> 1)];
+            const uint32_t bits16 = (e & 1) ? (pair >> 16) : (pair & 0xffffu);
+            float x = XDT == CT_BF16 ? round_to<CT_F16>(bf16_bits_to_f(bits16)) : f16_bits_to_f(bits16);  // weight.to(fp16)
+            float t = f16_quotient<FAST>(x, s16, rs);
+            if (HAS_ZP) t = round_to<CT_F16>(t + z16);
+            t = __builtin_rintf(clamp_nan(t, qmin, qmax));
+            nzf[e] = t != 0.0f;  // true for NaN, like torch's `!= 0`
+            code[e] = (int)t;    // NaN -> 0 (v_cvt_i32_f32)
+        }
+        violation |= ((int)nzf[0] + (int)nzf[1] + (int)nzf[2] + (int)nzf[3]) > 2;
+        const uint32_t qc = quad_code(nzf[0], nzf[1], nzf[3]);
+        word |= qc << (4 * qd);
+        const uint32_t i0 = qc & 3u, i1 = (qc >> 2) & 3u;
+        const int v0 = i0 == 0 ? code[0] : (i0 == 1 ? code[1] : (i0 == 2 ? code[2] : code[3]));
+        const int v1 = i1 == 0 ? code[0] : (i1 == 1 ? code[1] : (i1 == 2 ? code[2] : code[3]));
+        const uint32_t two = ((uint32_t)v0 & 0xffu) | (((uint32_t)v1 & 0xffu) << 8);
+        if (qd < 2) lo |= two << (16 * qd); else hi |= two << (16 * (qd - 2));
+    }
+    codes = u32x2{lo, hi};
+    return violation;
+}
+
+template <int XDT>
+__device__ __forceinline__ bool marlin24_item(const void* __restrict__ w, const void* __restrict__ scale, int sdt, const void* __restrict__ zp, int zdt,
+                                              int64_t r, int64_t mc, int64_t k, int64_t cdiv, int64_t scale_cols, float qmin, float qmax,
+                                              u32x2& codes, uint32_t& word) {
+    const int64_t si = r * scale_cols + (mc * 16) / cdiv;
+    // the scale first: its reciprocal is computed while the 32 bytes of weights are in flight
+    const float s16 = sdt == CT_F16 ? f16_bits_to_f(static_cast<const uint16_t*>(scale)[si]) : round_to<CT_F16>(load_rt(scale, sdt, si));
+    const bool has_zp = zp != nullptr;
+    const float z16 = !has_zp ? 0.0f : (zdt == CT_I8 ? (float)static_cast<const int8_t*>(zp)[si] : round_to<CT_F16>(load_rt(zp, zdt, si)));
+    const u32x4* in = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + r * k + mc * 16);
+    const u32x4 a = in[0], b = in[1];
+    const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float rs = f16_fast_rcp(s16);
+    // an all-zero zero point adds nothing (t is already rounded to fp16): wave-uniform skip, as in the W4 kernel
+    const bool use_zp = has_zp && (__builtin_amdgcn_ballot_w64(z16 != 0.0f) != 0);
+    if (rs != 0.0f) {
+        return use_zp ? marlin24_word<XDT, true, true>(ws, s16, z16, rs, qmin, qmax, codes, word)
+                      : marlin24_word<XDT, true, false>(ws, s16, z16, rs, qmin, qmax, codes, word);
+    }
+    return use_zp ? marlin24_word<XDT, false, true>(ws, s16, z16, rs, qmin, qmax, codes, word)
+                  : marlin24_word<XDT, false, false>(ws, s16, z16, rs, qmin, qmax, codes, word);
+}
+
+// generic: one lane per metadata word, the reordered int16 goes straight to its (scattered) place
 template <int XDT>
 __global__ __launch_bounds__(kBlock) void marlin24_quant_compress_kernel(const void* __restrict__ w, const void* __restrict__ scale, int sdt,
                                                                          const void* __restrict__ zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
@@ -132,42 +236,50 @@ __global__ __launch_bounds__(kBlock) void marlin24_quant_compress_kernel(const v
     const int64_t total = m * meta_ncols;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / meta_ncols, mc = i - r * meta_ncols;
-        const u32x4* in = reinterpret_cast<const u32x4*>(static_cast<const uint16_t*>(w) + r * k + mc * 16);
-        const u32x4 a = in[0], b = in[1];
-        const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        const int64_t si = r * scale_cols + (mc * 16) / cdiv;
-        const float s16 = round_to<CT_F16>(load_rt(scale, sdt, si));
-        const bool has_zp = zp != nullptr;
-        const float z16 = has_zp ? round_to<CT_F16>(load_rt(zp, zdt, si)) : 0.0f;
-        uint32_t word = 0, lo = 0, hi = 0;
-        bool violation = false;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            int code[4];
-            bool nzf[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t pair = ws[2 * qd + (e >> 1)];
-                const uint32_t bits16 = (e & 1) ? (pair >> 16) : (pair & 0xffffu);
-                float x = XDT == CT_BF16 ? round_to<CT_F16>(bf16_bits_to_f(bits16)) : f16_bits_to_f(bits16);  // weight.to(fp16)
-                float t = round_to<CT_F16>(x / s16);
-                if (has_zp) t = round_to<CT_F16>(t + z16);
-                t = __builtin_rintf(clamp_nan(t, qmin, qmax));
-                nzf[e] = t != 0.0f;  // true for NaN, like torch's `!= 0`
-                code[e] = (int)t;    // NaN -> 0 (v_cvt_i32_f32)
-            }
-            violation |= ((int)nzf[0] + (int)nzf[1] + (int)nzf[2] + (int)nzf[3]) > 2;
-            const uint32_t qc = quad_code(nzf[0], nzf[1], nzf[3]);
-            word |= qc << (4 * qd);
-            const uint32_t i0 = qc & 3u, i1 = (qc >> 2) & 3u;
-            const int v0 = i0 == 0 ? code[0] : (i0 == 1 ? code[1] : (i0 == 2 ? code[2] : code[3]));
-            const int v1 = i1 == 0 ? code[0] : (i1 == 1 ? code[1] : (i1 == 2 ? code[2] : code[3]));
-            const uint32_t two = ((uint32_t)v0 & 0xffu) | (((uint32_t)v1 & 0xffu) << 8);
-            if (qd < 2) lo |= two << (16 * qd); else hi |= two << (16 * (qd - 2));
-        }
-        stream_store8(comp + r * (k / 2) + mc * 8, u32x2{lo, hi});
+        u32x2 codes;
+        uint32_t word;
+        const bool violation = marlin24_item<XDT>(w, scale, sdt, zp, zdt, r, mc, k, cdiv, scale_cols, qmin, qmax, codes, word);
+        stream_store8(comp + r * (k / 2) + mc * 8, codes);
         meta[meta_reorder_offset(r, mc, m, 2)] = (uint16_t)word;
         if (violation) atomicOr(bad, 1);
+    }
+}
+
+// tiled (k % 256 == 0): a workgroup owns 64 rows x 16 metadata columns.  The reorder keeps the 64 rows of a
+// column PAIR inside one contiguous 256-byte run of the output, but consecutive column pairs are m*4 bytes
+// apart — written lane by lane (generic kernel) every 2-byte store lands in its own cache line (80 us).  Here
+// the words are put in DESTINATION order in LDS and leave as 8 contiguous 256-byte runs.
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void marlin24_quant_compress_tiled_kernel(const void* __restrict__ w, const void* __restrict__ scale, int sdt,
+                                                                               const void* __restrict__ zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                                                                               int64_t scale_cols, float qmin, float qmax, int8_t* __restrict__ comp,
+                                                                               uint16_t* __restrict__ meta, int* __restrict__ bad) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_meta[8][128];
+    const int64_t tiles_c = k / 256;
+    const int64_t tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x - tile_r * tiles_c;
+    const int tid = threadIdx.x;
+    bool violation = false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = it * kBlock + tid;
+        const int rl = item >> 4, cl = item & 15;
+        const int64_t r = tile_r * 64 + rl, mc = tile_c * 16 + cl;
+        u32x2 codes;
+        uint32_t word;
+        violation |= marlin24_item<XDT>(w, scale, sdt, zp, zdt, r, mc, k, cdiv, scale_cols, qmin, qmax, codes, word);
+        stream_store8(comp + r * (k / 2) + mc * 8, codes);
+        const int64_t off = meta_reorder_offset(r, mc, m, 2);
+        const int pair = cl >> 1;
+        const int64_t pair_base = (tile_c * 8 + pair) * m * 2 + tile_r * 128;
+        s_meta[pair][(int)(off - pair_base)] = (uint16_t)word;
+    }
+    if (violation) atomicOr(bad, 1);
+    __syncthreads();
+    {
+        const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
+        const int64_t pair_base = (tile_c * 8 + pair) * m * 2 + tile_r * 128;
+        const u32x2 v = *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]);
+        stream_store8(meta + pair_base + chunk * 4, v);
     }
 }
 
@@ -296,6 +408,16 @@ int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sd
     const float qmax = (float)((1 << bits) / 2 - 1), qmin = -(float)((1 << bits) / 2);
     const int64_t total = m * (k / 16);
     const unsigned grid = (unsigned)(cdiv64(total, kBlock) < ((int64_t)1 << 30) ? cdiv64(total, kBlock) : ((int64_t)1 << 30));
+    if (k % 256 == 0 && (reinterpret_cast<uintptr_t>(meta) & 7u) == 0 && (m / 64) * (k / 256) < ((int64_t)1 << 31)) {
+        const unsigned tg = (unsigned)((m / 64) * (k / 256));
+        if (wdt == CT_BF16)
+            hipLaunchKernelGGL((marlin24_quant_compress_tiled_kernel<CT_BF16>), dim3(tg), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c,
+                               scale_cols, qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
+        else
+            hipLaunchKernelGGL((marlin24_quant_compress_tiled_kernel<CT_F16>), dim3(tg), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c,
+                               scale_cols, qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
+        CT_LAUNCH_CHECK("ct_marlin24_quant_compress[tiled]");
+    }
     if (wdt == CT_BF16)
         hipLaunchKernelGGL((marlin24_quant_compress_kernel<CT_BF16>), dim3(grid), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, scale_cols,
                            qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
@@ -303,6 +425,16 @@ int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sd
         hipLaunchKernelGGL((marlin24_quant_compress_kernel<CT_F16>), dim3(grid), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, scale_cols,
                            qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
     CT_LAUNCH_CHECK("ct_marlin24_quant_compress");
+}
+
+int ct_selftest_f16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {
+    CT_REQUIRE(s_lo_bits <= s_hi_bits && s_hi_bits <= 65536u, "bad scale bit range");
+    hipError_t e = hipMemsetAsync(mismatches, 0, sizeof(unsigned long long), as_stream(stream));
+    if (e != hipSuccess) return hip_check(e, "ct_selftest_f16_div memset");
+    if (s_lo_bits == s_hi_bits) return CT_OK;
+    const unsigned n = s_hi_bits - s_lo_bits;
+    hipLaunchKernelGGL(selftest_f16_div_kernel, dim3(n < 4096 ? n : 4096), dim3(kBlock), 0, as_stream(stream), s_lo_bits, s_hi_bits, mismatches);
+    CT_LAUNCH_CHECK("ct_selftest_f16_div");
 }
 
 int ct_marlin24_pack_weights(const void* q, int dt, int transposed, int add_offset, int64_t size_k, int64_t size_n, int bits, int32_t* packed,

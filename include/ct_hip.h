@@ -227,6 +227,9 @@ int ct_marlin24_pack_scales(const void* scale, int dt, int64_t size_n, int64_t g
  * Exhaustive device-side check of the reciprocal fast path used by the bf16 fused kernels:
  * for every bf16 (x, s) pair in [s_lo_bits, s_hi_bits) x all 65536 x, compares
  * rnd_bf16(x * rcp(s)) with rnd_bf16(x / s).  mismatches[0] receives the count. */
+/* the same for the fp16 quotient shortcut of ct_marlin24_quant_compress (reciprocal + one Newton step) */
+int ct_selftest_f16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
+                        ct_stream_t stream);
 int ct_selftest_bf16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
                          ct_stream_t stream);
 

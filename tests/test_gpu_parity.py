@@ -227,6 +227,11 @@ def test_bf16_reciprocal_fast_path_is_exact(cta, dev):
     assert cta.codec.selftest_bf16_div(0, 65536) == 0
 
 
+def test_f16_newton_quotient_is_exact(cta, dev):
+    """exhaustive: every fp16 x against every fp16 scale of the fast-path range (marlin-24 front end)"""
+    assert cta.codec.selftest_f16_div(0, 65536) == 0
+
+
 def test_all_bf16_inputs_w4(cta, dev):
     """every bf16 bit pattern as an input, against a spread of scales incl. extreme exponents"""
     allx = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(BF16).reshape(64, 1024)
@@ -419,16 +424,19 @@ def test_marlin24_rejects_dense_weight(cta, dev):
         cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
 
 
+@pytest.mark.parametrize("shape", [(192, 1024), (64, 288), (128, 256)])
 @pytest.mark.parametrize("wdt", [BF16, F16])
-def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt):
-    """ct_marlin24_quant_compress == weight.to(fp16) -> quantize (fp16) -> cutlass 2:4 compress"""
+def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt, shape):
+    """ct_marlin24_quant_compress == weight.to(fp16) -> quantize (fp16) -> cutlass 2:4 compress
+    (k % 256 == 0: tiled kernel with LDS-ordered metadata; otherwise the lane-per-word kernel)"""
     g = torch.Generator().manual_seed(3)
-    w = torch.randn((192, 1024), generator=g).to(wdt)
+    w = torch.randn(shape, generator=g).to(wdt)
     w = (w * O.sparse24_mask(w).to(w.dtype)).to(dev)
     w[0, :4] = 0
-    scale, zp = cta.codec.minmax_qparams(w.to(F16), num_bits=4, group_size=128, symmetric=True)
-    comp, meta, bad = cta.codec.marlin24_quant_compress(w, scale, zp, num_bits=4, group_size=128)
-    q = cta.codec.quantize_tensor(w.to(F16), scale, zp, num_bits=4, strategy="group", group_size=128)
+    gs = 128 if shape[1] % 128 == 0 else 32
+    scale, zp = cta.codec.minmax_qparams(w.to(F16), num_bits=4, group_size=gs, symmetric=True)
+    comp, meta, bad = cta.codec.marlin24_quant_compress(w, scale, zp, num_bits=4, group_size=gs)
+    q = cta.codec.quantize_tensor(w.to(F16), scale, zp, num_bits=4, strategy="group", group_size=gs)
     comp_ref, meta_ref = cta.codec.cutlass24_from_dense(q)
     assert int(bad.item()) == 0
     assert torch.equal(comp.cpu().float(), comp_ref.cpu().float()) and torch.equal(meta.cpu(), meta_ref.cpu())
