@@ -495,9 +495,11 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
 //    wave store instruction writes 1 KiB contiguous) reads it back.
 //  * value side: output dword j of a unit (elements 2j, 2j+1) is a 32-bit WINDOW of the staged
 //    value run starting at element q_j = rank + popc(m & ((1 << 2j) - 1)): two aligned LDS dwords
-//    (one ds_read2_b32) and ONE v_perm_b32 whose selector — a LUT keyed by the mask byte and the
-//    parity of the rank — does the funnel shift, places a lone element in the right half and
-//    zeroes the rest.
+//    (one ds_read2_b32) and ONE v_perm_b32 whose selector does the funnel shift, places a lone
+//    element in the right half and zeroes the rest.  The selector depends only on the two mask bits
+//    and on whether the window starts mid-dword: an 8-entry LDS table (8 banks, conflict-free).  A
+//    256 x 2-parity x 4 table keyed by the whole mask byte was 6 % slower: random 16-byte LUT reads
+//    were half of all LDS cycles as bank conflicts, and its 9 KB cost two workgroups per CU.
 // A tile is 8192 columns of one row.  SINGLE (cols <= 8192): the run length is known from the row
 // offsets, so the value loads are issued together with the mask load and there is one barrier.
 // Otherwise the tile's start inside the row is the popcount of the row's earlier mask bytes and
@@ -516,47 +518,22 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-struct Expand16Lut {
-    uint32_t sel[2 * 256 * 4];  // [rank parity][mask byte][output dword]: v_perm_b32 selector
-    uint32_t off[256];          // byte j: 2 * popc(mask & ((1 << 2j) - 1)) = byte offset of window j
-};
-
-__device__ __forceinline__ void build_expand16_lut(Expand16Lut& lut) {
-    const uint32_t mv = threadIdx.x;  // kBlock == 256 entries
-    uint32_t off = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t pj = __popc(mv & ((1u << (2 * j)) - 1u));
-        off |= (2u * pj) << (8 * j);
-        const uint32_t b0 = (mv >> (2 * j)) & 1u, b1 = (mv >> (2 * j + 1)) & 1u;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const uint32_t x = (p + pj) & 1u;            // window starts at byte 2 of the low dword
-            const uint32_t w01 = x ? 0x0302u : 0x0100u;  // selectors of window bytes 0, 1
-            const uint32_t w23 = x ? 0x0504u : 0x0302u;  // window bytes 2, 3
-            uint32_t sel;
-            if (b0 && b1) sel = w01 | (w23 << 16);
-            else if (b0) sel = w01 | 0x0c0c0000u;        // 0x0c selects the constant 0x00
-            else if (b1) sel = 0x0c0cu | (w01 << 16);
-            else sel = 0x0c0c0c0cu;
-            lut.sel[(p * 256 + mv) * 4 + j] = sel;
-        }
-    }
-    lut.off[mv] = off;
-}
-
 template <bool SINGLE>
 __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len,
                                                                       const uint8_t* __restrict__ bitmask,
                                                                       const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz,
                                                                       int64_t rows, int64_t cols, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint16_t s_val[kTile16 + 32];
-    __shared__ __attribute__((aligned(16))) Expand16Lut s_lut;
+    __shared__ uint32_t s_sel8[8];  // v_perm_b32 selectors indexed by (window misaligned) << 2 | (b1 << 1) | b0
     __shared__ __attribute__((aligned(16))) uint32_t s_unit[kTile16 / 8];
     __shared__ __attribute__((aligned(16))) int s_tot[4];
     __shared__ __attribute__((aligned(16))) int s_pre[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    build_expand16_lut(s_lut);  // visible after the first barrier below
+    if (threadIdx.x < 8) {  // visible after the first barrier below
+        const uint32_t x = threadIdx.x >> 2, b0 = threadIdx.x & 1u, b1 = (threadIdx.x >> 1) & 1u;
+        const uint32_t w01 = x ? 0x0302u : 0x0100u, w23 = x ? 0x0504u : 0x0302u;  // window bytes 0,1 / 2,3 (0x0c selects 0x00)
+        s_sel8[threadIdx.x] = (b0 && b1) ? (w01 | (w23 << 16)) : b0 ? (w01 | 0x0c0c0000u) : b1 ? (0x0c0cu | (w01 << 16)) : 0x0c0c0c0cu;
+    }
     const int64_t bcols = cols >> 3;
     const int64_t tiles_per_row = (cols + kTile16 - 1) / kTile16;
     const int64_t ntiles = rows * tiles_per_row;
@@ -654,16 +631,16 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             const uint32_t info = s_unit[u];
             const uint32_t mv = info & 0xffu;
             const uint32_t r = (info >> 8) + (uint32_t)(wbase[i] + shift);
-            const u32x4 sel = *reinterpret_cast<const u32x4*>(&s_lut.sel[((r & 1u) * 256 + mv) * 4]);
-            const uint32_t off = s_lut.off[mv];
             const uint32_t a0 = 2u * r;
-            const uint32_t sl[4] = {sel.x, sel.y, sel.z, sel.w};
             uint32_t w[4];
+            // selectors from the 8-entry table (8 distinct banks: conflict-free), window offsets from popcounts
+            const uint32_t offs[4] = {0u, 2u * __popc(mv & 3u), 2u * __popc(mv & 15u), 2u * __popc(mv & 63u)};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t a = (a0 + ((off >> (8 * j)) & 0xffu)) & ~3u;
+                const uint32_t aj = a0 + offs[j];
+                const uint32_t a = aj & ~3u;
                 const uint32_t lo = *reinterpret_cast<const uint32_t*>(sv + a), hi = *reinterpret_cast<const uint32_t*>(sv + a + 4);
-                w[j] = __builtin_amdgcn_perm(hi, lo, sl[j]);
+                w[j] = __builtin_amdgcn_perm(hi, lo, s_sel8[((aj & 2u) << 1) | ((mv >> (2 * j)) & 3u)]);
             }
             stream_store16(orow + ((int64_t)u << 3), u32x4{w[0], w[1], w[2], w[3]});
         }
