@@ -2,7 +2,8 @@
 # Run ON THE GPU BOX (through gpurun): kernel-trace stats + separate PMC passes of the bench command,
 # summaries written to gpurun_out/profile_<tag>/.  Counters are collected in their own runs
 # (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2: they do not fit one pass) with --kernel-trace only.
-# "headline": the timed W4A16 8192^2 step only (--no-extra), so that per-kernel averages are not mixed
+# "headline": the timed W4A16 8192^2 step only (--no-extra --one-stream: kernels do not overlap, so the
+# per-kernel durations are comparable with the HIP-event figures of bench.py), not mixed
 # with the small TinyLlama-shaped launches; "extras": the whole default bench (all legs).
 #   usage: tools/profile_round.sh <tag>
 set -u
@@ -11,7 +12,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-HEAD="python $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extra"
+HEAD="python $ROOT/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extra --one-stream"
 FULL="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 run() {  # name, rocprof args..., -- cmd
     local name=$1; shift
