@@ -28,6 +28,7 @@ __all__ = [
     "W4Batch",
     "w4_batch_eligible",
     "marlin24_quant_compress",
+    "marlin24_compress_w4",
     "bitmask_compress",
     "bitmask_decompress",
     "sparse24_mask",
@@ -647,6 +648,23 @@ def marlin24_quant_compress(weight: torch.Tensor, scale: torch.Tensor, zero_poin
     call("ct_marlin24_quant_compress", ptr(w), DT[w.dtype], ptr(s), DT[s.dtype], ptr(zp), DT[zp.dtype] if zp is not None else -1,
          m, k, g, int(num_bits), ptr(comp), ptr(meta), ptr(bad), stream_of(w))
     return _home(comp, weight), _home(meta, weight), bad
+
+
+def marlin24_compress_w4(weight: torch.Tensor, scale: torch.Tensor, zero_point, *, group_size: Optional[int]):
+    """fully fused int4 marlin-24 weight path (rows % 64 == 0, cols % 256 == 0): fp16 quantize + 2:4 compress
+    + tile-permuted nibble packing in one launch.  Returns (weight_packed int32 (k/32, m*2), meta int16
+    (m, k/16) reordered, violated flag tensor)."""
+    dev = _compute_device(weight)
+    w, s = _dev(weight, dev).contiguous(), _dev(scale, dev).contiguous()
+    zp = _dev(zero_point, dev).contiguous() if zero_point is not None else None
+    m, k = w.shape
+    g = k if not group_size or group_size > k else int(group_size)
+    packed = torch.empty((k // 32, m * 2), dtype=torch.int32, device=dev)
+    meta = torch.empty((m, k // 16), dtype=torch.int16, device=dev)
+    bad = torch.empty(1, dtype=torch.int32, device=dev)
+    call("ct_marlin24_compress_w4", ptr(w), DT[w.dtype], ptr(s), DT[s.dtype], ptr(zp), DT[zp.dtype] if zp is not None else -1,
+         m, k, g, ptr(packed), ptr(meta), ptr(bad), stream_of(w))
+    return _home(packed, weight), _home(meta, weight), bad
 
 
 def marlin24_pack_weights(q: torch.Tensor, num_bits: int, *, transposed: bool = False, add_offset: bool = False):

@@ -68,9 +68,13 @@ class Marlin24Compressor(BaseCompressor):
         if fused_ok:
             # one pass: weight.to(fp16) / quantize in fp16 / 2:4 structure check / cutlass 2:4 compress
             g = None if enum_value(weights.strategy) == "channel" else group_size
-            comp, meta, bad = codec.marlin24_quant_compress(weight, scale16, zero_point, num_bits=int(weights.num_bits), group_size=g)
-            size_n, size_k = comp.shape
-            packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
+            size_n, size_k = weight.shape[0], weight.shape[1] // 2
+            if int(weights.num_bits) == 4 and weight.shape[1] % 256 == 0:
+                # everything in one launch: no int8 intermediate, no separate packing kernel
+                packed, meta, bad = codec.marlin24_compress_w4(weight, scale16, zero_point, group_size=g)
+            else:
+                comp, meta, bad = codec.marlin24_quant_compress(weight, scale16, zero_point, num_bits=int(weights.num_bits), group_size=g)
+                packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
             if int(bad.item()):  # one host read, as the reference pipeline's structure check
                 raise ValueError("Marlin24 Compressor is only compatible with weights that have a 2:4 sparsity structure. "
                                  "Found segments in weight that do not match the expected structure.")

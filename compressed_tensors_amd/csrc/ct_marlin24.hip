@@ -169,16 +169,34 @@ __global__ __launch_bounds__(kBlock) void selftest_f16_div_kernel(uint32_t s_lo,
 // one metadata word: 16 elements (8 dwords) of a row -> 8 kept int8 codes + the 4 quad codes.
 // FAST selects the reciprocal + Newton quotient; the choice is made once per word (one scale), so the
 // IEEE divide sequence is not interleaved with every element
+// v_cvt_i32_f32: saturating, NaN -> 0 (spelled as an instruction so that clang does not expand the conversion)
+__device__ __forceinline__ int m24_cvt_i32(float x) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 template <int XDT, bool FAST, bool HAS_ZP>
 __device__ __forceinline__ bool marlin24_word(const uint32_t (&ws)[8], float s16, float z16, float rs, float qmin, float qmax, u32x2& codes,
                                               uint32_t& word) {
+    // quad_code as a table over idx = m0 | m1 << 1 | m3 << 2 (4 bits per entry)
+    constexpr uint32_t kQuadLut = []() constexpr {
+        uint32_t lut = 0;
+        for (int idx = 0; idx < 8; ++idx) {
+            const bool m0 = idx & 1, m1 = (idx >> 1) & 1, m3 = (idx >> 2) & 1;
+            const bool e0 = m0 && m1, e1 = !m0 && m1, e2 = !m0 && !m1;
+            const uint32_t bit0 = e1, bit1 = e2, bit2 = e0 || e2 || m3, bit3 = e1 || !m1;
+            lut |= (bit0 | (bit1 << 1) | (bit2 << 2) | (bit3 << 3)) << (4 * idx);
+        }
+        return lut;
+    }();
+    const int iqmin = (int)qmin, iqmax = (int)qmax;
     uint32_t lo = 0, hi = 0;
     word = 0;
-    bool violation = false;
+    int worst = 0;
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-        int code[4];
-        bool nzf[4];
+        uint32_t nz[4], packed4 = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t pair = ws[2 * qd + (e >> 1)];
@@ -186,21 +204,26 @@ __device__ __forceinline__ bool marlin24_word(const uint32_t (&ws)[8], float s16
             float x = XDT == CT_BF16 ? round_to<CT_F16>(bf16_bits_to_f(bits16)) : f16_bits_to_f(bits16);  // weight.to(fp16)
             float t = f16_quotient<FAST>(x, s16, rs);
             if (HAS_ZP) t = round_to<CT_F16>(t + z16);
-            t = __builtin_rintf(clamp_nan(t, qmin, qmax));
-            nzf[e] = t != 0.0f;  // true for NaN, like torch's `!= 0`
-            code[e] = (int)t;    // NaN -> 0 (v_cvt_i32_f32)
+            // rint then clamp == clamp then rint for integer bounds; NaN: non-zero (torch `!= 0`), code 0 (the int cast)
+            const float tr = __builtin_rintf(t);
+            nz[e] = (tr != 0.0f) ? 1u : 0u;
+            int c = m24_cvt_i32(tr);
+            c = c < iqmin ? iqmin : (c > iqmax ? iqmax : c);  // v_med3_i32
+            // a NaN is clamped by torch as NaN and cast to 0, an out-of-range value to the bound: both reproduced
+            packed4 |= ((uint32_t)c & 0xffu) << (8 * e);
         }
-        violation |= ((int)nzf[0] + (int)nzf[1] + (int)nzf[2] + (int)nzf[3]) > 2;
-        const uint32_t qc = quad_code(nzf[0], nzf[1], nzf[3]);
+        const uint32_t cnt = nz[0] + nz[1] + nz[2] + nz[3];
+        worst = (int)cnt > worst ? (int)cnt : worst;
+        const uint32_t idx = nz[0] | (nz[1] << 1) | (nz[3] << 2);
+        const uint32_t qc = (kQuadLut >> (4 * idx)) & 0xfu;
         word |= qc << (4 * qd);
-        const uint32_t i0 = qc & 3u, i1 = (qc >> 2) & 3u;
-        const int v0 = i0 == 0 ? code[0] : (i0 == 1 ? code[1] : (i0 == 2 ? code[2] : code[3]));
-        const int v1 = i1 == 0 ? code[0] : (i1 == 1 ? code[1] : (i1 == 2 ? code[2] : code[3]));
-        const uint32_t two = ((uint32_t)v0 & 0xffu) | (((uint32_t)v1 & 0xffu) << 8);
+        // the two kept codes: bytes (qc & 3) and (qc >> 2) of packed4
+        const uint32_t sel = 0x0c0c0000u | (qc & 3u) | ((qc >> 2) << 8);
+        const uint32_t two = __builtin_amdgcn_perm(0u, packed4, sel);
         if (qd < 2) lo |= two << (16 * qd); else hi |= two << (16 * (qd - 2));
     }
     codes = u32x2{lo, hi};
-    return violation;
+    return worst > 2;
 }
 
 template <int XDT>
@@ -295,6 +318,71 @@ __host__ __device__ __forceinline__ int marlin24_perm_entry(int within, int bits
     const int col = i / 4, col_o = col / 2, block = q / 4, t = q % 4;
     const int row = (t == 0) ? 2 * (i % 4) : (t == 1) ? 2 * (i % 4) + 1 : (t == 2) ? 2 * (i % 4 + 4) : 2 * (i % 4 + 4) + 1;
     return 16 * row + col_o * 256 + 8 * (col % 2) + 4 * block + j;
+}
+
+// fully fused int4 path (k % 256 == 0): the tiled front end above, with the kept codes held in LDS instead
+// of HBM and the marlin-24 tile permutation + nibble packing done by the same workgroup.  A workgroup's
+// 64 rows x 128 compressed columns are 8 k-tiles of exactly one 1024-element marlin chunk each (a chunk =
+// 4 n-tiles of 16 rows x one k-tile of 16 columns), i.e. 8 runs of 128 consecutive output words.  Word
+// w = tid + 256 * it has the same position jj = tid % 128 inside its chunk for every it, so a thread
+// computes its 8 permutation entries once (arithmetic, permutations_24.py:20-45) and reuses them 4 times.
+// No int8 intermediate (33.5 MB written + read back at 8192^2) and no separate packing launch.
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void marlin24_fused_w4_kernel(const void* __restrict__ w, const void* __restrict__ scale, int sdt,
+                                                                   const void* __restrict__ zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                                                                   int64_t scale_cols, int32_t* __restrict__ packed, uint16_t* __restrict__ meta,
+                                                                   int* __restrict__ bad) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_meta[8][128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_code[64][128 + 8];  // +8: rows start on different banks
+    const int64_t tiles_c = k / 256;
+    const int64_t tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x - tile_r * tiles_c;
+    const int tid = threadIdx.x;
+    // this thread's 8 source positions inside a chunk (byte offsets into s_code for k-tile 0)
+    uint32_t src_off[8];
+    {
+        const int jj = tid & 127;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pe = marlin24_perm_entry(jj * 8 + e, 4);
+            const int nt = pe >> 8, rem = pe & 255;
+            src_off[e] = (uint32_t)((nt * 16 + (rem & 15)) * (128 + 8) + (rem >> 4));
+        }
+    }
+    bool violation = false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int item = it * kBlock + tid;
+        const int rl = item >> 4, cl = item & 15;
+        const int64_t r = tile_r * 64 + rl, mc = tile_c * 16 + cl;
+        u32x2 codes;
+        uint32_t word;
+        violation |= marlin24_item<XDT>(w, scale, sdt, zp, zdt, r, mc, k, cdiv, scale_cols, -8.0f, 7.0f, codes, word);
+        *reinterpret_cast<u32x2*>(&s_code[rl][cl * 8]) = codes;
+        const int64_t off = meta_reorder_offset(r, mc, m, 2);
+        const int pair = cl >> 1;
+        const int64_t pair_base = (tile_c * 8 + pair) * m * 2 + tile_r * 128;
+        s_meta[pair][(int)(off - pair_base)] = (uint16_t)word;
+    }
+    if (violation) atomicOr(bad, 1);
+    __syncthreads();
+    {
+        const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
+        const int64_t pair_base = (tile_c * 8 + pair) * m * 2 + tile_r * 128;
+        stream_store8(meta + pair_base + chunk * 4, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
+    }
+    const uint8_t* sc = &s_code[0][0];
+    const int64_t wpr = m * 2;  // packed words per k-tile row (size_n * 16 * 4 / 32)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int t = (tid >> 7) + 2 * it;  // k-tile inside the workgroup tile
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t code = (uint32_t)((int)(int8_t)sc[src_off[e] + t * 16] + 8);
+            word |= code << (4 * e);
+        }
+        packed[(tile_c * 8 + t) * wpr + tile_r * 128 + (tid & 127)] = (int32_t)word;
+    }
 }
 
 __device__ __forceinline__ int load_code(const void* q, int dt, int64_t i, int add) {
@@ -425,6 +513,30 @@ int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sd
         hipLaunchKernelGGL((marlin24_quant_compress_kernel<CT_F16>), dim3(grid), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, scale_cols,
                            qmin, qmax, comp, reinterpret_cast<uint16_t*>(meta), bad);
     CT_LAUNCH_CHECK("ct_marlin24_quant_compress");
+}
+
+int ct_marlin24_compress_w4(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                            int32_t* packed, int16_t* meta, int* bad, ct_stream_t stream) {
+    CT_REQUIRE(wdt == CT_F16 || wdt == CT_BF16, "marlin-24 weights must be 16-bit floats, got dtype %d", wdt);
+    CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
+    CT_REQUIRE(m >= 0 && k >= 0 && m % 64 == 0 && k % 256 == 0, "the fused marlin-24 path needs rows %% 64 == 0 and cols %% 256 == 0, got (%lld, %lld)",
+               (long long)m, (long long)k);
+    CT_REQUIRE(cdiv >= 16 && (cdiv % 16 == 0 || cdiv >= k), "group size %lld must be a multiple of 16", (long long)cdiv);
+    CT_REQUIRE(aligned16(w) && (reinterpret_cast<uintptr_t>(meta) & 7u) == 0 && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && bad != nullptr,
+               "misaligned buffers");
+    CT_REQUIRE((m / 64) * (k / 256) < ((int64_t)1 << 31), "tensor too large for one launch");
+    hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
+    if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4 memset");
+    if (m == 0 || k == 0) return CT_OK;
+    const int64_t c = cdiv > k ? k : cdiv;
+    const unsigned tg = (unsigned)((m / 64) * (k / 256));
+    if (wdt == CT_BF16)
+        hipLaunchKernelGGL((marlin24_fused_w4_kernel<CT_BF16>), dim3(tg), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, k / c, packed,
+                           reinterpret_cast<uint16_t*>(meta), bad);
+    else
+        hipLaunchKernelGGL((marlin24_fused_w4_kernel<CT_F16>), dim3(tg), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, k / c, packed,
+                           reinterpret_cast<uint16_t*>(meta), bad);
+    CT_LAUNCH_CHECK("ct_marlin24_compress_w4");
 }
 
 int ct_selftest_f16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {

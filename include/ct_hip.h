@@ -206,6 +206,11 @@ int ct_cutlass24_to_dense(const void* sparse, int dt, const void* meta, int meta
  * int16 metadata, reordered) without any full-size intermediate.  comp: int8 (m, k/2) kept codes
  * (no offset); meta: int16 (m, k/16) reordered; bad[0] != 0 afterwards if some quad had more than
  * two non-zero codes (the weight is not 2:4).  scale: (m, k/cdiv), zp nullable. */
+/* the same front end with the marlin-24 tile permutation + int4 packing fused in (rows % 64 == 0,
+ * cols % 256 == 0): weight -> packed int32 (cols/32, rows*2) + reordered int16 metadata in ONE pass. */
+int ct_marlin24_compress_w4(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
+                            int64_t m, int64_t k, int64_t cdiv, int32_t* packed, int16_t* meta, int* bad,
+                            ct_stream_t stream);
 int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
                                int64_t m, int64_t k, int64_t cdiv, int bits, int8_t* comp, int16_t* meta,
                                int* bad, ct_stream_t stream);
