@@ -250,14 +250,15 @@ assert total == sum(module_size(m) for m in mods)
 a, b = shard_rows(1000)
 assert (a, b) == ((0, 500) if rank == 0 else (500, 1000))
 dist.barrier()
-print("rank", rank, "ok")
+# one marker file per rank: two processes printing to the same pipe can interleave their characters
+open(os.path.join(os.environ["CT_TEST_OUT"], f"rank{{rank}}.ok"), "w").write("ok")
 """
 
 
 def test_world_size_2_sharding_gloo(tmp_path):
     script = tmp_path / "dist_check.py"
     script.write_text(_DIST_SCRIPT.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", CT_TEST_OUT=str(tmp_path))
     import socket
     with socket.socket() as sk:  # a free rendezvous port (a fixed one collides with a run in TIME_WAIT)
         sk.bind(("127.0.0.1", 0))
@@ -268,4 +269,4 @@ def test_world_size_2_sharding_gloo(tmp_path):
         capture_output=True, text=True, env=env, timeout=240,
     )
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
