@@ -1,0 +1,97 @@
+"""The drop-in route of INTEGRATION.md §A against the REAL upstream package (CPU-only here: the build
+container has the reference but no GPU, the GPU box has a GPU but no reference — so this checks the
+plug-in plumbing, not the kernels): install() swaps the registry entries with subclasses of the
+upstream codecs, registers the `_quantize` ImplBackend backend, hands CPU tensors to the upstream
+implementation unchanged, and uninstall() restores the registry."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ref_import  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not ref_import.available(), reason="upstream reference sources not present on this machine")
+
+
+@pytest.fixture()
+def upstream():
+    ct = ref_import.import_reference()
+    import compressed_tensors_amd.install as ct_amd
+
+    yield ct, ct_amd
+    ct_amd.uninstall()
+
+
+def test_install_swaps_registry_and_falls_through_on_cpu(upstream):
+    ct, ct_amd = upstream
+    from compressed_tensors.compressors import BaseCompressor
+    from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme
+    from compressed_tensors.utils.impl_backend import ImplBackend
+
+    before = {f: BaseCompressor.get_value_from_registry(f) for f in ("pack-quantized", "naive-quantized", "int-quantized")}
+    ct_amd.install()
+    ct_amd.install()  # idempotent
+    after = {f: BaseCompressor.get_value_from_registry(f) for f in before}
+    for f in before:
+        assert after[f] is not before[f] and issubclass(after[f], before[f]), f
+        assert after[f].__name__.endswith("MI355X")
+    assert "_quantize_mi355x" in ImplBackend._fn_registry
+
+    # CPU tensors: the subclass defers to upstream, results identical to upstream's own
+    torch.manual_seed(0)
+    w = torch.randn(32, 256, dtype=torch.bfloat16)
+    args = QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = QuantizationScheme(targets=["Linear"], weights=args)
+    amax = w.reshape(32, 2, 128).abs().amax(dim=-1).float()
+    scale = (amax / 7.5).to(torch.bfloat16)
+    sd = {"weight": w, "weight_scale": scale, "weight_zero_point": torch.zeros(32, 2, dtype=torch.int8)}
+    ref = before["pack-quantized"].compress(sd, scheme)
+    got = after["pack-quantized"].compress(sd, scheme)
+    assert ref.keys() == got.keys()
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    back_ref = before["pack-quantized"].decompress(ref, scheme)["weight"]
+    back_got = after["pack-quantized"].decompress(got, scheme)["weight"]
+    assert torch.equal(back_ref, back_got)
+
+    # the upstream module-level entry points resolve to the swapped classes (lookup by format string at call time)
+    lin = torch.nn.Linear(256, 32, bias=False).to(torch.bfloat16)
+    lin.weight.data.copy_(w)
+    lin.quantization_scheme = scheme
+    lin.register_parameter("weight_scale", torch.nn.Parameter(scale, requires_grad=False))
+    lin.register_parameter("weight_zero_point", torch.nn.Parameter(torch.zeros(32, 2, dtype=torch.int8), requires_grad=False))
+    from compressed_tensors.compressors import compress_module, decompress_module
+
+    compress_module(lin)
+    assert torch.equal(lin.weight_packed.data, ref["weight_packed"])
+    decompress_module(lin)
+    assert torch.equal(lin.weight.data, back_ref)
+
+    ct_amd.uninstall()
+    for f in before:
+        assert BaseCompressor.get_value_from_registry(f) is before[f]
+
+
+def test_amd_scheme_objects_are_duck_compatible_with_upstream(upstream):
+    """our host package consumes upstream's pydantic QuantizationArgs / QuantizationScheme unchanged"""
+    ct, _ = upstream
+    from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme
+
+    import compressed_tensors_amd as cta
+
+    args = QuantizationArgs(num_bits=4, group_size=128, symmetric=False, strategy="group")
+    scheme = QuantizationScheme(targets=["Linear"], weights=args)
+    assert cta.PackedQuantizationCompressor.compression_param_names(scheme) == \
+        ct.compressors.BaseCompressor.get_value_from_registry("pack-quantized").compression_param_names(scheme)
+    assert cta.PackedQuantizationCompressor.can_compress(torch.nn.Linear, scheme)
+    # meta tensors take the shape-only path without touching the GPU
+    sd = {"weight": torch.empty(64, 256, dtype=torch.bfloat16, device="meta"), "weight_scale": torch.empty(64, 2, dtype=torch.bfloat16, device="meta"),
+          "weight_zero_point": torch.empty(64, 2, dtype=torch.int8, device="meta")}
+    out = cta.PackedQuantizationCompressor.compress(sd, scheme)
+    ref = ct.compressors.BaseCompressor.get_value_from_registry("pack-quantized").compress(sd, scheme)
+    assert out.keys() == ref.keys()
+    for k in out:
+        assert out[k].shape == ref[k].shape and out[k].dtype == ref[k].dtype and out[k].device.type == ref[k].device.type, k
