@@ -491,8 +491,8 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
 // payloads with cols % 32 == 0 this kernel does the same job in ~5:
 //  * mask side: a lane loads ONE dword of the bitmask (4 consecutive units), popcounts it; a DPP
 //    wave scan + 4 wave totals give every unit's rank; the owner lane publishes
-//    (rank << 8 | mask byte) per unit in LDS and the consumer lane (unit i*256 + tid, so that every
-//    wave store instruction writes 1 KiB contiguous) reads it back.
+//    the 4 ranks in LDS and the consumer lane (unit i*256 + tid, so that every wave store
+//    instruction writes 1 KiB contiguous) reads its rank back and loads its own mask byte.
 //  * value side: output dword j of a unit (elements 2j, 2j+1) is a 32-bit WINDOW of the staged
 //    value run starting at element q_j = rank + popc(m & ((1 << 2j) - 1)): two aligned LDS dwords
 //    (one ds_read2_b32) and ONE v_perm_b32 whose selector does the funnel shift, places a lone
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
                                                                       int64_t rows, int64_t cols, uint16_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint16_t s_val[kTile16 + 32];
     __shared__ uint32_t s_sel8[8];  // v_perm_b32 selectors indexed by (window misaligned) << 2 | (b1 << 1) | b0
-    __shared__ __attribute__((aligned(16))) uint32_t s_unit[kTile16 / 8];
+    __shared__ __attribute__((aligned(16))) uint16_t s_rank[kTile16 / 8];  // wave-local rank of every unit
     __shared__ __attribute__((aligned(16))) int s_tot[4];
     __shared__ __attribute__((aligned(16))) int s_pre[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -544,6 +544,10 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         const int nu = left < kTile16 / 8 ? (int)left : kTile16 / 8;                    // units in this tile (multiple of 4)
         const uint8_t* mrow = bitmask + row * bcols;
         const uint32_t md = (4 * tid < nu) ? *reinterpret_cast<const uint32_t*>(mrow + u0 + 4 * tid) : 0u;
+        // the consumer lane's own mask bytes (unit i*256 + tid): same cache lines as the dword above
+        uint32_t mb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mb[i] = (i * kBlock + tid < nu) ? (uint32_t)mrow[u0 + i * kBlock + tid] : 0u;
         int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
         run = run < 0 ? 0 : (run > values_len ? values_len : run);
 
@@ -608,8 +612,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         if (lane == 63) s_tot[wave] = incl;
         const uint32_t r0 = (uint32_t)(incl - c);
         const uint32_t r1 = r0 + __popc(md & 0xffu), r2 = r0 + __popc(md & 0xffffu), r3 = r0 + __popc(md & 0xffffffu);
-        reinterpret_cast<u32x4*>(s_unit)[tid] = u32x4{(r0 << 8) | (md & 0xffu), (r1 << 8) | ((md >> 8) & 0xffu),
-                                                      (r2 << 8) | ((md >> 16) & 0xffu), (r3 << 8) | (md >> 24)};
+        reinterpret_cast<u32x2*>(s_rank)[tid] = u32x2{r0 | (r1 << 16), r2 | (r3 << 16)};
         if constexpr (SINGLE) stage_commit();
         __syncthreads();
         const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2], t3 = s_tot[3];
@@ -628,9 +631,8 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         for (int i = 0; i < 4; ++i) {
             const int u = i * kBlock + tid;
             if (u >= nu) continue;
-            const uint32_t info = s_unit[u];
-            const uint32_t mv = info & 0xffu;
-            const uint32_t r = (info >> 8) + (uint32_t)(wbase[i] + shift);
+            const uint32_t mv = mb[i];
+            const uint32_t r = (uint32_t)s_rank[u] + (uint32_t)(wbase[i] + shift);
             const uint32_t a0 = 2u * r;
             uint32_t w[4];
             // selectors from the 8-entry table (8 distinct banks: conflict-free), window offsets from popcounts
