@@ -126,6 +126,23 @@ __device__ __forceinline__ float f16_fast_rcp(float s16) {
     const float as = __builtin_fabsf(s16);
     return ((as >= 0x1p-14f) && (as <= 0x1p15f)) ? 1.0f / s16 : 0.0f;
 }
+// round two floats to fp16 and back: one v_cvt_pk_f16_f32 + two v_cvt_f32_f16 (3 ops for 2 elements)
+__device__ __forceinline__ void round2_f16(float& a, float& b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef f16_t h2 __attribute__((ext_vector_type(2)));
+    const f2 r = __builtin_convertvector(__builtin_convertvector(f2{a, b}, h2), f2);
+    a = r.x; b = r.y;
+}
+
+// unrounded quotient (the caller rounds pairs with round2_f16)
+template <bool FAST>
+__device__ __forceinline__ float f16_quotient_raw(float x16, float s16, float rs) {
+    if constexpr (!FAST) return x16 / s16;
+    const float q0 = x16 * rs;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s16, x16), rs, q0);
+    return __builtin_isfinite(q0) ? q1 : q0;  // x = +-inf: the correction would make NaN
+}
+
 template <bool FAST>
 __device__ __forceinline__ float f16_quotient(float x16, float s16, float rs) {
     if constexpr (!FAST) return round_to<CT_F16>(x16 / s16);
@@ -197,13 +214,25 @@ __device__ __forceinline__ bool marlin24_word(const uint32_t (&ws)[8], float s16
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
         uint32_t nz[4], packed4 = 0;
+        float tq[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // element pairs: the fp16 roundings go through the packed conversion
+            const uint32_t pair = ws[2 * qd + h];
+            float x0, x1;
+            if constexpr (XDT == CT_BF16) {
+                x0 = bf16_bits_to_f(pair & 0xffffu); x1 = bits_f(pair & 0xffff0000u);
+                round2_f16(x0, x1);  // weight.to(fp16)
+            } else {
+                x0 = f16_bits_to_f(pair & 0xffffu); x1 = f16_bits_to_f(pair >> 16);
+            }
+            float t0 = f16_quotient_raw<FAST>(x0, s16, rs), t1 = f16_quotient_raw<FAST>(x1, s16, rs);
+            round2_f16(t0, t1);
+            if (HAS_ZP) { t0 += z16; t1 += z16; round2_f16(t0, t1); }
+            tq[2 * h] = t0; tq[2 * h + 1] = t1;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t pair = ws[2 * qd + (e >> 1)];
-            const uint32_t bits16 = (e & 1) ? (pair >> 16) : (pair & 0xffffu);
-            float x = XDT == CT_BF16 ? round_to<CT_F16>(bf16_bits_to_f(bits16)) : f16_bits_to_f(bits16);  // weight.to(fp16)
-            float t = f16_quotient<FAST>(x, s16, rs);
-            if (HAS_ZP) t = round_to<CT_F16>(t + z16);
+            const float t = tq[e];
             // rint then clamp == clamp then rint for integer bounds; NaN: non-zero (torch `!= 0`), code 0 (the int cast)
             const float tr = __builtin_rintf(t);
             nz[e] = (tr != 0.0f) ? 1u : 0u;
