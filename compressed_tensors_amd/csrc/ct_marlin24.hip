@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_quant_compress_tiled_kernel(c
 
 // entry `within` of the marlin-24 weight permutation (permutations_24.py:20-45), computed
 // arithmetically instead of from a 1024-entry table
-__host__ __device__ __forceinline__ int marlin24_perm_entry(int within, int bits) {
+__host__ __device__ constexpr int marlin24_perm_entry(int within, int bits) {
     const int ilen = bits == 4 ? 8 : 4;
     const int grp = within / ilen, jj = within % ilen;
     const int src_in_grp = bits == 4 ? ((jj < 4) ? 2 * jj : 2 * (jj - 4) + 1) : ((jj == 0) ? 0 : (jj == 1 ? 2 : (jj == 2 ? 1 : 3)));
@@ -348,6 +348,24 @@ __host__ __device__ __forceinline__ int marlin24_perm_entry(int within, int bits
     const int row = (t == 0) ? 2 * (i % 4) : (t == 1) ? 2 * (i % 4) + 1 : (t == 2) ? 2 * (i % 4 + 4) : 2 * (i % 4 + 4) + 1;
     return 16 * row + col_o * 256 + 8 * (col % 2) + 4 * block + j;
 }
+
+
+// byte offsets into the fused kernel's code tile (row stride 136) of the 8 source codes of the word at
+// position jj inside a marlin chunk: the permutation evaluated at compile time (it cost 240 VALU ops per thread)
+struct Marlin4SrcTable {
+    uint16_t off[128][8];
+};
+constexpr Marlin4SrcTable make_marlin4_src_table() {
+    Marlin4SrcTable t{};
+    for (int jj = 0; jj < 128; ++jj)
+        for (int e = 0; e < 8; ++e) {
+            const int pe = marlin24_perm_entry(jj * 8 + e, 4);
+            const int nt = pe >> 8, rem = pe & 255;
+            t.off[jj][e] = (uint16_t)((nt * 16 + (rem & 15)) * (128 + 8) + (rem >> 4));
+        }
+    return t;
+}
+__device__ const Marlin4SrcTable kMarlin4Src = make_marlin4_src_table();
 
 // fully fused int4 path (k % 256 == 0): the tiled front end above, with the kept codes held in LDS instead
 // of HBM and the marlin-24 tile permutation + nibble packing done by the same workgroup.  A workgroup's
@@ -366,17 +384,9 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_kernel(const void* _
     const int64_t tiles_c = k / 256;
     const int64_t tile_r = blockIdx.x / tiles_c, tile_c = blockIdx.x - tile_r * tiles_c;
     const int tid = threadIdx.x;
-    // this thread's 8 source positions inside a chunk (byte offsets into s_code for k-tile 0)
-    uint32_t src_off[8];
-    {
-        const int jj = tid & 127;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int pe = marlin24_perm_entry(jj * 8 + e, 4);
-            const int nt = pe >> 8, rem = pe & 255;
-            src_off[e] = (uint32_t)((nt * 16 + (rem & 15)) * (128 + 8) + (rem >> 4));
-        }
-    }
+    // this thread's 8 source positions inside a chunk (byte offsets into s_code for k-tile 0): one 16-byte load
+    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
+    const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
     bool violation = false;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
