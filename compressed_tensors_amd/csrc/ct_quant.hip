@@ -500,7 +500,8 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float q = (float)((int)((word[i] >> (4 * k)) & 0xfu) - 8);
+            // code - 8 as a float without v_cvt_f32_i32: 0x4B000000 | nibble is 2^23 + nibble exactly
+            const float q = bits_f(0x4B000000u | ((word[i] >> (4 * k)) & 0xfu)) - 8388616.0f;
             v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
         }
         store8<DT>(p.out, u * 8, v);
