@@ -51,6 +51,13 @@ __device__ __forceinline__ float dequant_core(float q, bool has_zp, float zf, fl
     return round_to<SDT>(d * s);
 }
 
+// int8 zero point and an int8 code: |q - z| <= 255 is an integer every supported float dtype holds exactly,
+// so the reference's rounding of the difference is the identity and is not issued
+template <int SDT>
+__device__ __forceinline__ float dequant_core_zexact(float q, float zf, float s) {
+    return round_to<SDT>((q - zf) * s);
+}
+
 // scale / zero point of element (row, c)
 struct SZ {
     float s, z;
@@ -498,11 +505,19 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
         const float s = load_as_f<DT>(p.scale, si);
         const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
         float v[8];
+        if (HAS_ZP && p.zdt == CT_I8) {  // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            // code - 8 as a float without v_cvt_f32_i32: 0x4B000000 | nibble is 2^23 + nibble exactly
-            const float q = bits_f(0x4B000000u | ((word[i] >> (4 * k)) & 0xfu)) - 8388616.0f;
-            v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
+            for (int k = 0; k < 8; ++k) {
+                const float q = bits_f(0x4B000000u | ((word[i] >> (4 * k)) & 0xfu)) - 8388616.0f;
+                v[k] = dequant_core_zexact<DT>(q, z, s);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // code - 8 as a float without v_cvt_f32_i32: 0x4B000000 | nibble is 2^23 + nibble exactly
+                const float q = bits_f(0x4B000000u | ((word[i] >> (4 * k)) & 0xfu)) - 8388616.0f;
+                v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
+            }
         }
         store8<DT>(p.out, u * 8, v);
     }
@@ -667,10 +682,18 @@ __global__ __launch_bounds__(kBlock) void q8_dequant_kernel(W4Params p) {
             const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
             const uint32_t ws[2] = {word[i].x ^ kFlip, word[i].y ^ kFlip};
             float v[8];
+            if (HAS_ZP && p.zdt == CT_I8) {  // wave-uniform
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float q = (float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f;  // v_cvt_f32_ubyteN
-                v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
+                for (int k = 0; k < 8; ++k) {
+                    const float q = (float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f;
+                    v[k] = dequant_core_zexact<DT>(q, z, s);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float q = (float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f;  // v_cvt_f32_ubyteN
+                    v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
+                }
             }
             store8<DT>(p.out, u * 8, v);
         }
