@@ -69,6 +69,12 @@ class BaseCompressor(RegistryMixin, ABC):
             cls.decompress_module(m)
 
     @classmethod
+    def decompress_many(cls, state_dicts, scheme) -> list:
+        """decompress several local-name state dicts of one scheme (the model-free path: one safetensors
+        shard, converters/ct_dequantizer.py:63-99); codecs may override to batch their launches"""
+        return [cls.decompress(sd, scheme) for sd in state_dicts]
+
+    @classmethod
     def _remove_symmetric_zp(cls, state_dict: dict, scheme) -> dict:
         """compressors/base.py:147-167: vLLM cannot load zero points of symmetric schemes"""
         for args_name, key in (

@@ -141,36 +141,51 @@ class PackedQuantizationCompressor(BaseCompressor):
                 m.quantization_status = QuantizationStatus.COMPRESSED
 
     @classmethod
-    def decompress_modules(cls, modules) -> None:
-        from ...quantization.quant_args import QuantizationStatus
-        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
-
-        jobs, entries, dtype = [], [], None
-        for m in modules:
-            scheme = m.quantization_scheme
-            sd = get_direct_state_dict(m)
+    def _batch_decompress(cls, state_dicts, schemes):
+        """weights of every eligible state dict from ONE launch (None for the others)"""
+        outs, entries, slots, dtype = [None] * len(state_dicts), [], [], None
+        for i, (sd, scheme) in enumerate(zip(state_dicts, schemes)):
             packed, scale, shape_t = sd.get("weight_packed"), sd.get("weight_scale"), sd.get("weight_shape")
             wa = scheme.weights
-            ok = packed is not None and scale is not None and shape_t is not None and packed.is_cuda and packed.is_contiguous() and wa.symmetric
-            if ok:
-                shape = tuple(int(v) for v in shape_t.tolist())
-                # decompress infers the strategy from the scale shape (forward.py:99-130): (R, 1) channel, (R, G) group
-                strategy, group = ("channel", shape[-1]) if scale.shape[-1] == 1 else ("group", shape[-1] // scale.shape[-1])
-                ok = ((dtype is None or scale.dtype == dtype) and len(shape) == 2 and tuple(packed.shape) == (shape[0], shape[1] // 8)
-                      and codec.w4_batch_eligible(shape, scale.dtype, scale, None, num_bits=int(wa.num_bits), strategy=strategy,
-                                                  group_size=group, g_idx=sd.get("weight_g_idx")))
+            ok = (packed is not None and scale is not None and shape_t is not None and packed.is_cuda and packed.is_contiguous()
+                  and wa.symmetric and sd.get("weight_g_idx") is None)
             if not ok:
-                cls.decompress_module(m)
+                continue
+            shape = tuple(int(v) for v in shape_t.tolist())
+            if len(shape) != 2 or scale.ndim != 2:
+                continue
+            # decompress infers the strategy from the scale shape (forward.py:99-130): (R, 1) channel, (R, G) group
+            strategy, group = ("channel", shape[-1]) if scale.shape[-1] == 1 else ("group", shape[-1] // scale.shape[-1])
+            if not ((dtype is None or scale.dtype == dtype) and tuple(packed.shape) == (shape[0], shape[1] // 8)
+                    and codec.w4_batch_eligible(shape, scale.dtype, scale, None, num_bits=int(wa.num_bits), strategy=strategy,
+                                                group_size=group)):
                 continue
             dtype = scale.dtype
             out = torch.empty(shape, dtype=scale.dtype, device=packed.device)
             entries.append((packed, scale, None, out, shape[0], shape[1], group))
-            jobs.append((m, sd, scheme, out))
-        if jobs:
+            slots.append((i, out))
+        if entries:
             codec.W4Batch(entries, "decompress", dtype).launch()
-            for m, sd, scheme, out in jobs:
-                replace_direct_state_dict(m, cls.decompress(sd, scheme, _preweight=out))
-                m.quantization_status = QuantizationStatus.DECOMPRESSED
+            for i, out in slots:
+                outs[i] = out
+        return outs
+
+    @classmethod
+    def decompress_many(cls, state_dicts, scheme) -> list:
+        pre = cls._batch_decompress(state_dicts, [scheme] * len(state_dicts))
+        return [cls.decompress(sd, scheme, _preweight=w) for sd, w in zip(state_dicts, pre)]
+
+    @classmethod
+    def decompress_modules(cls, modules) -> None:
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+
+        modules = list(modules)
+        sds = [get_direct_state_dict(m) for m in modules]
+        pre = cls._batch_decompress(sds, [m.quantization_scheme for m in modules])
+        for m, sd, w in zip(modules, sds, pre):
+            replace_direct_state_dict(m, cls.decompress(sd, m.quantization_scheme, _preweight=w))
+            m.quantization_status = QuantizationStatus.DECOMPRESSED
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

@@ -1,0 +1,155 @@
+"""Model-free checkpoint conversion (reference entrypoints/convert/).  CPU tests cover the
+planning logic (and compare it with the upstream functions when the reference is present); the GPU test
+converts a synthetic two-shard compressed checkpoint and checks every tensor against the oracle."""
+import json
+import os
+import sys
+
+import pytest
+import torch
+from safetensors.torch import load_file, save_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from compressed_tensors_amd.entrypoints.convert import CompressedTensorsDequantizer, build_inverse_weight_maps, convert_checkpoint  # noqa: E402
+from compressed_tensors_amd.entrypoints.convert.converters import match_name, match_quantizable_tensors  # noqa: E402
+
+QCFG = {
+    "quant_method": "compressed-tensors", "format": "pack-quantized", "ignore": ["lm_head"],
+    "config_groups": {"group_0": {"targets": ["Linear"], "input_activations": None, "output_activations": None,
+                                  "weights": {"num_bits": 4, "type": "int", "symmetric": True, "strategy": "group", "group_size": 128}}},
+}
+SHAPES = {"model.layers.0.q_proj": (256, 512), "model.layers.0.down_proj": (128, 1024), "model.layers.1.q_proj": (256, 512),
+          "model.layers.1.odd_proj": (64, 160)}
+
+
+def _names(mod):
+    return [f"{mod}.weight_packed", f"{mod}.weight_scale", f"{mod}.weight_shape"]
+
+
+def _write_config(d):
+    with open(d / "config.json", "w") as f:
+        json.dump({"architectures": ["Toy"], "quantization_config": QCFG}, f)
+
+
+def test_planning_logic(tmp_path):
+    _write_config(tmp_path)
+    conv = CompressedTensorsDequantizer(tmp_path, ignore=["re:.*odd_proj"])
+    assert conv.schemes[0].format == "pack-quantized"
+    assert conv.get_dependencies("model.layers.0.q_proj.weight_packed") == {"model.layers.0.q_proj.weight_scale", "model.layers.0.q_proj.weight_shape"}
+    assert conv.get_dependencies("model.layers.0.q_proj.weight_scale") == set()
+    assert conv.get_dependencies("lm_head.weight") == set() and conv.get_dependencies("model.layers.1.odd_proj.weight_packed") == set()
+    assert match_name("a.b", "a.b") and match_name("a.b", "re:a\\..*") and not match_name("a.b", "a")
+
+    # partners living in another shard are loaded with their primary tensor
+    weight_map = {}
+    for i, mod in enumerate(SHAPES):
+        for n in _names(mod):
+            weight_map[n] = "model-00001.safetensors" if (i % 2 == 0 or n.endswith("scale")) else "model-00002.safetensors"
+    weight_map["model.norm.weight"] = "model-00002.safetensors"
+    files = {"model-00001.safetensors": "/x/1", "model-00002.safetensors": "/x/2"}
+    inv = build_inverse_weight_maps(weight_map, files, [conv])
+    assert set(inv) == {"model-00001.safetensors", "model-00002.safetensors"}
+    assert sorted(inv["model-00002.safetensors"]["/x/1"]) == ["model.layers.0.down_proj.weight_scale"]
+    assert "model.layers.0.down_proj.weight_packed" in inv["model-00002.safetensors"]["/x/2"]
+    got = sorted(n for per_file in inv.values() for names in per_file.values() for n in names)
+    assert got == sorted(weight_map)  # every tensor is loaded exactly once
+
+    names = {n: None for n in weight_map}
+    conv.validate(names)
+    bad = dict(names)
+    del bad["model.layers.0.q_proj.weight_scale"]
+    with pytest.raises(ValueError, match="Expected key"):
+        conv.validate(bad)
+    extra = dict(names)
+    extra["model.layers.0.q_proj.weight_extra"] = None
+    with pytest.raises(ValueError, match="unconsumed"):
+        conv.validate(extra)
+    assert [m for m, _ in match_quantizable_tensors(names, conv.ignore, ["Linear"], ["weight_packed"])] == \
+        ["model.layers.0.q_proj", "model.layers.0.down_proj", "model.layers.1.q_proj"]
+
+
+def test_planning_matches_upstream(tmp_path):
+    import ref_import
+
+    if not ref_import.available():
+        pytest.skip("upstream reference sources not present on this machine")
+    ref_import.import_reference()
+    from compressed_tensors.entrypoints.convert.converters import build_inverse_weight_maps as up_build
+    from compressed_tensors.utils.match import match_quantizable_tensors as up_match
+
+    _write_config(tmp_path)
+    conv = CompressedTensorsDequantizer(tmp_path)
+    weight_map = {}
+    for i, mod in enumerate(SHAPES):
+        for j, n in enumerate(_names(mod)):
+            weight_map[n] = f"model-0000{1 + (i + j) % 3}.safetensors"
+    weight_map["model.norm.weight"] = "model-00001.safetensors"
+    weight_map["lm_head.weight"] = "model-00003.safetensors"
+    files = {f"model-0000{k}.safetensors": f"/x/{k}" for k in (1, 2, 3)}
+    mine, theirs = build_inverse_weight_maps(weight_map, files, [conv]), up_build(weight_map=weight_map, model_files=files, converters=[conv])
+    assert {s: {f: sorted(v) for f, v in m.items()} for s, m in mine.items()} == {s: {f: sorted(v) for f, v in m.items()} for s, m in theirs.items()}
+    names = {n: None for n in weight_map}
+    for targets in (["Linear"], ["re:.*q_proj"], []):
+        assert list(match_quantizable_tensors(names, ["lm_head"], targets, ["weight_packed"])) == \
+            list(up_match(names, ["lm_head"], targets, ["weight_packed"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_workers", [1, 3])
+def test_convert_checkpoint_dequantizes_on_the_gpu(tmp_path, max_workers):
+    import oracle as O
+
+    import compressed_tensors_amd as cta
+
+    dev = torch.device("cuda:0")
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir()
+    _write_config(src)
+    (src / "tokenizer.json").write_text("{}")
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    odd = cta.QuantizationArgs(num_bits=4, group_size=32, symmetric=True, strategy="group")
+    torch.manual_seed(0)
+    expect, shards = {}, {"model-00001-of-00002.safetensors": {}, "model-00002-of-00002.safetensors": {}}
+    for i, (mod, shape) in enumerate(SHAPES.items()):
+        w = torch.randn(shape).to(torch.bfloat16)
+        a = odd if "odd" in mod else args
+        scheme = cta.QuantizationScheme(targets=["Linear"], weights=a)
+        scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=a.group_size, symmetric=True)
+        c = cta.PackedQuantizationCompressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+        expect[f"{mod}.weight"] = O.fake_quantize(w, scale, zp, num_bits=4, strategy="group", group_size=a.group_size)
+        # the scale of every second module lives in the OTHER shard (cross-shard dependency)
+        first, second = list(shards)[i % 2], list(shards)[(i + 1) % 2]
+        for k, v in c.items():
+            (shards[second] if (k == "weight_scale" and i % 2) else shards[first])[f"{mod}.{k}"] = v.cpu().contiguous()
+    shards["model-00001-of-00002.safetensors"]["model.norm.weight"] = torch.ones(512, dtype=torch.bfloat16)
+    shards["model-00002-of-00002.safetensors"]["lm_head.weight"] = torch.randn(32, 512).to(torch.bfloat16)
+    shards["model-00002-of-00002.safetensors"]["model.layers.0.self_attn.k_scale"] = torch.ones(1)
+    wm = {}
+    for fn, t in shards.items():
+        save_file(t, str(src / fn))
+        wm.update({k: fn for k in t})
+    with open(src / "model.safetensors.index.json", "w") as f:
+        json.dump({"metadata": {"total_size": 0}, "weight_map": wm}, f)
+
+    # the 160-column module has group size 32 in the file but the config says 128: give it its own config group
+    cfg = json.load(open(src / "config.json"))
+    cfg["quantization_config"]["config_groups"]["group_1"] = {"targets": ["re:.*odd_proj"], "weights": dict(QCFG["config_groups"]["group_0"]["weights"], group_size=32)}
+    cfg["quantization_config"]["config_groups"]["group_0"]["targets"] = ["re:.*(q_proj|down_proj)"]
+    json.dump(cfg, open(src / "config.json", "w"))
+
+    conv = CompressedTensorsDequantizer(src, dtype=torch.bfloat16, device=dev)
+    convert_checkpoint(src, dst, conv, max_workers=max_workers)
+
+    out = {}
+    for fn in shards:
+        out.update(load_file(str(dst / fn)))
+    for name, ref in expect.items():
+        assert out[name].dtype == torch.bfloat16 and torch.equal(out[name], ref), name
+    assert torch.equal(out["lm_head.weight"], shards["model-00002-of-00002.safetensors"]["lm_head.weight"])
+    assert "model.norm.weight" in out and not any(k.endswith(("weight_packed", "weight_scale", "weight_shape", "k_scale")) for k in out)
+    index = json.load(open(dst / "model.safetensors.index.json"))
+    assert set(index["weight_map"]) == set(out) and index["metadata"]["total_size"] == sum(t.numel() * t.element_size() for t in out.values())
+    assert "quantization_config" not in json.load(open(dst / "config.json")) and (dst / "tokenizer.json").exists()
