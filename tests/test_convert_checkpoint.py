@@ -153,3 +153,62 @@ def test_convert_checkpoint_dequantizes_on_the_gpu(tmp_path, max_workers):
     index = json.load(open(dst / "model.safetensors.index.json"))
     assert set(index["weight_map"]) == set(out) and index["metadata"]["total_size"] == sum(t.numel() * t.element_size() for t in out.values())
     assert "quantization_config" not in json.load(open(dst / "config.json")) and (dst / "tokenizer.json").exists()
+
+
+_DIST_CONVERT = r"""
+import json, os, sys, torch
+sys.path.insert(0, {root!r})
+from compressed_tensors_amd.distributed import init_dist, rank_and_world
+from compressed_tensors_amd.entrypoints.convert import Converter, convert_checkpoint
+
+class Rename(Converter):  # a host-only converter: the sharding / index merging is what is under test
+    def process(self, tensors):
+        return {{k.replace("old.", "new."): v for k, v in tensors.items()}}
+    def validate(self, tensors):
+        assert all(k.startswith("old.") for k in tensors)
+    def create_config(self):
+        return None
+    def get_dependencies(self, name):
+        return set()
+
+init_dist()
+rank, world = rank_and_world()
+convert_checkpoint({src!r}, {dst!r}, Rename(), max_workers=2)
+open(os.path.join(os.environ["CT_TEST_OUT"], f"rank{{rank}}.ok"), "w").write("ok")
+"""
+
+
+def test_convert_checkpoint_shards_files_over_ranks(tmp_path):
+    """world_size 2 over gloo: every rank converts its own files, rank 0 merges the index fragments"""
+    import socket
+    import subprocess
+
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir()
+    wm, total = {}, 0
+    for i, n in enumerate((40, 10, 25, 5)):
+        t = {f"old.layer{i}.w{j}": torch.full((n, 8), float(i * 10 + j)) for j in range(3)}
+        fn = f"model-{i + 1:05d}-of-00004.safetensors"
+        save_file(t, str(src / fn))
+        wm.update({k: fn for k in t})
+        total += sum(v.numel() * 4 for v in t.values())
+    json.dump({"metadata": {"total_size": total}, "weight_map": wm}, open(src / "model.safetensors.index.json", "w"))
+    json.dump({"quantization_config": {"x": 1}, "a": 2}, open(src / "config.json", "w"))
+    script = tmp_path / "dist_convert.py"
+    script.write_text(_DIST_CONVERT.format(root=ROOT, src=str(src), dst=str(dst)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", CT_TEST_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+    out = {}
+    for i in range(4):
+        out.update(load_file(str(dst / f"model-{i + 1:05d}-of-00004.safetensors")))
+    assert set(out) == {k.replace("old.", "new.") for k in wm}
+    assert all(torch.equal(out[k.replace("old.", "new.")], torch.full_like(out[k.replace("old.", "new.")], float(int(k.split("layer")[1][0]) * 10 + int(k[-1])))) for k in wm)
+    index = json.load(open(dst / "model.safetensors.index.json"))
+    assert set(index["weight_map"]) == set(out) and index["metadata"]["total_size"] == total
+    assert json.load(open(dst / "config.json")) == {"a": 2} and not list(dst.glob(".index_fragment*"))
