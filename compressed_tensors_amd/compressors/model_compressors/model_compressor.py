@@ -4,9 +4,9 @@ named by its scheme's format.
 
 Multi-GPU: when torch.distributed is initialised, modules are partitioned over ranks with the
 reference's own rule (largest first onto the lightest bin, distributed/assign.py:12-42) and each
-rank compresses its bin on its own MI355X.  No collective is issued: the reference's
-broadcast "recouple" step (distributed/module_parallel.py:74-90) only replicates results and
-is out of scope; `shard_only=False` is therefore not offered.
+rank compresses its bin on its own MI355X.  By default no collective is issued (BASELINE north_star);
+`recouple=True` adds the reference's replication step (distributed/module_parallel.py:74-90) as one
+flat-buffer RCCL broadcast per owner rank (distributed/module_parallel.py here).
 """
 import json
 import os
@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from ...config import CompressionFormat
-from ...distributed import is_distributed, module_size, shard_modules
+from ...distributed import is_distributed, module_size, replace_module_parallel, shard_modules
 from ...quantization.quant_args import QuantizationStatus
 from ...quantization.utils import is_module_quantized
 from ..base import compress_modules, decompress_modules
@@ -71,25 +71,29 @@ class ModelCompressor:
             and (not skip_compressed or getattr(m, "quantization_status", None) != QuantizationStatus.COMPRESSED)
         ]
 
-    def compress_model(self, model: torch.nn.Module, skip_compressed: bool = False) -> None:
-        """model_compressor.py:138-181"""
+    def compress_model(self, model: torch.nn.Module, skip_compressed: bool = False, recouple: bool = False) -> None:
+        """model_compressor.py:138-181.  Under torch.distributed every rank compresses its own LPT share; with
+        `recouple=True` the results are then replicated on every rank (what upstream's replace_module_parallel
+        does by default, at the price of one RCCL broadcast per owner rank)."""
         modules = self._quantized_modules(model, skip_compressed)
-        if is_distributed():
-            modules = shard_modules(modules, module_size)
+        fmt = self.force_compression_format
         # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
-        compress_modules(modules, self.force_compression_format)
+        replace_module_parallel(modules, lambda ms: compress_modules(ms, fmt), module_size, recouple=recouple)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
         self.add_decompress_hook(model)
 
-    def decompress_model(self, model: torch.nn.Module) -> None:
-        """model_compressor.py:183-207.  Under torch.distributed each rank decompresses the
-        modules of its own shard (upstream has no distributed decompression at all, :196)."""
+    def decompress_model(self, model: torch.nn.Module, recouple: bool = False) -> None:
+        """model_compressor.py:183-207.  Under torch.distributed each rank decompresses the modules of its own
+        share (upstream has no distributed decompression at all, :196); `recouple=True` replicates the
+        decompressed weights on every rank."""
         modules = self._quantized_modules(model)
-        if is_distributed():
-            modules = [m for m in shard_modules(modules, module_size)
-                       if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED]
-        decompress_modules(modules, self.force_compression_format)
+        fmt = self.force_compression_format
+
+        def apply(ms):
+            decompress_modules([m for m in ms if not is_distributed() or getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
+
+        replace_module_parallel(modules, apply, module_size, recouple=recouple)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.DECOMPRESSED
         self.remove_decompression_hook(model)

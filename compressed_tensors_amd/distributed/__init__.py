@@ -1,8 +1,11 @@
 from .assign import greedy_bin_packing
+from .module_parallel import recouple_modules, replace_module_parallel
 from .shard import init_dist, is_distributed, module_size, rank_and_world, shard_items, shard_modules, shard_rows
 
 __all__ = [
     "greedy_bin_packing",
+    "replace_module_parallel",
+    "recouple_modules",
     "init_dist",
     "is_distributed",
     "rank_and_world",

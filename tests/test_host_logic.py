@@ -270,3 +270,66 @@ def test_world_size_2_sharding_gloo(tmp_path):
     )
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
+
+
+_RECOUPLE_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from compressed_tensors_amd.distributed import init_dist, rank_and_world, replace_module_parallel
+from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+from compressed_tensors_amd.utils.module import get_direct_state_dict, replace_direct_state_dict
+init_dist()
+rank, world = rank_and_world()
+torch.manual_seed(0)  # identical models on every rank
+mods = [torch.nn.Linear(8 * (i + 1), 16 + i, bias=(i % 2 == 0)) for i in range(7)]
+ref = [m.weight.data.clone() for m in mods]
+
+def fake_compress(ms):  # what a codec does to a module: new keys, dropped keys, a small host tensor, a status
+    for m in ms:
+        sd = get_direct_state_dict(m)
+        w = sd.pop("weight")
+        sd.pop("bias", None)
+        sd["weight_packed"] = (w * 2 + rank * 0).to(torch.float16)   # owner-independent content
+        sd["weight_shape"] = torch.tensor(w.shape)
+        sd["owner"] = torch.full((3,), float(rank))
+        replace_direct_state_dict(m, sd)
+        m.quantization_status = QuantizationStatus.COMPRESSED
+
+mine = replace_module_parallel(list(mods), fake_compress, recouple=True)
+assert 0 < len(mine) < len(mods)
+owners = set()
+for m, w in zip(mods, ref):
+    sd = get_direct_state_dict(m)
+    assert sorted(sd) == ["owner", "weight_packed", "weight_shape"], sorted(sd)
+    assert torch.equal(sd["weight_packed"], (w * 2).to(torch.float16)) and sd["weight_packed"].dtype == torch.float16
+    assert sd["weight_shape"].tolist() == list(w.shape) and sd["weight_shape"].dtype == torch.int64
+    assert m.quantization_status == QuantizationStatus.COMPRESSED
+    assert all(isinstance(p, torch.nn.Parameter) and not p.requires_grad for p in m._parameters.values())
+    owners.add(int(sd["owner"][0]))
+assert owners == {{0, 1}}  # both ranks contributed and both see the other's work
+# without recouple only the own share changes
+mods2 = [torch.nn.Linear(8, 8) for _ in range(4)]
+mine2 = replace_module_parallel(list(mods2), fake_compress, recouple=False)
+assert sum(hasattr(m, "weight_packed") for m in mods2) == len(mine2) == 2
+dist.barrier()
+open(os.path.join(os.environ["CT_TEST_OUT"], f"rank{{rank}}.ok"), "w").write("ok")
+"""
+
+
+def test_world_size_2_recouple_gloo(tmp_path):
+    """N3: module-parallel apply + recouple (one flat-buffer broadcast per owner rank) over two gloo ranks"""
+    import socket
+
+    script = tmp_path / "recouple_check.py"
+    script.write_text(_RECOUPLE_SCRIPT.format(root=ROOT))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", CT_TEST_OUT=str(tmp_path))
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script)],
+        capture_output=True, text=True, env=env, timeout=240,
+    )
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
