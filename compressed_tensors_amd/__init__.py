@@ -12,6 +12,8 @@ from .compressors import (
     IntQuantizationCompressor,
     Marlin24Compressor,
     ModelCompressor,
+    MXFP4PackedCompressor,
+    NVFP4PackedCompressor,
     NaiveQuantizationCompressor,
     PackedQuantizationCompressor,
     Sparse24BitMaskCompressor,
@@ -44,6 +46,8 @@ __all__ = [
     "BitmaskCompressor",
     "Sparse24BitMaskCompressor",
     "Marlin24Compressor",
+    "NVFP4PackedCompressor",
+    "MXFP4PackedCompressor",
     "CompressionFormat",
     "SparsityStructure",
     "QuantizationArgs",

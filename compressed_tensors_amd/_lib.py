@@ -52,6 +52,8 @@ _PROTOTYPES = {
     "ct_w4_batch_plan": ([_P, _I, _I], _L),
     "ct_quant_pack_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
+    "ct_fp4_quant_pack": ([_P, _I, _P, _I, _P, _L, _L, _L, _P, _S], _I),
+    "ct_fp4_unpack_dequant": ([_P, _L, _L, _P, _I, _I, _P, _L, _P, _I, _S], _I),
     "ct_minmax_qparams": ([_P, _I, _L, _L, _L, _I, _I, _P, _P, _S], _I),
     "ct_pack_bitmasks": ([_P, _L, _L, _P, _S], _I),
     "ct_unpack_bitmasks": ([_P, _L, _L, _P, _S], _I),

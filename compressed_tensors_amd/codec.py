@@ -27,6 +27,8 @@ __all__ = [
     "unpack_bitmasks",
     "W4Batch",
     "w4_batch_eligible",
+    "fp4_quantize_and_pack",
+    "fp4_unpack_and_dequantize",
     "marlin24_quant_compress",
     "marlin24_compress_w4",
     "bitmask_compress",
@@ -689,6 +691,52 @@ def marlin24_pack_scales(scale: torch.Tensor, *, single: bool):
     out = torch.empty((groups, size_n), dtype=s.dtype, device=dev)
     call("ct_marlin24_pack_scales", ptr(s), DT[s.dtype], size_n, groups, int(single), ptr(out), stream_of(s))
     return _home(out, scale)
+
+
+# --------------------------------------------------------------------------- FP4 (E2M1) codecs
+_FP4_SCALE_KIND = {"plain": 0, "f8e4m3": 1, "e8m0": 2}
+
+
+def fp4_quantize_and_pack(weight: torch.Tensor, scale: torch.Tensor, global_scale: Optional[torch.Tensor], *, group_size: int) -> torch.Tensor:
+    """quantize(x, scale, global_scale, FP4 args) -> cast_to_fp4 -> pack_fp4_to_uint8 in one launch
+    (compressors/nvfp4/base.py:88-95): uint8 (rows, cols / 2)."""
+    if weight.dim() != 2:
+        raise ValueError("FP4 compression expects a 2-D weight")
+    if weight.shape[1] % 2 != 0:
+        raise ValueError("tensor must have an even number of columns for nvfp4 compression")
+    if weight.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"the MI355X FP4 path compresses 16-bit float weights, got {weight.dtype}")
+    dev = _compute_device(weight)
+    w, s = _dev(weight, dev).contiguous(), _dev(scale, dev).contiguous()
+    rows, cols = w.shape
+    if tuple(s.shape) != (rows, cols // group_size):
+        raise ValueError(f"scale shape {tuple(s.shape)} does not match ({rows}, {cols // group_size}) for group size {group_size}")
+    gs = None
+    if global_scale is not None:
+        gs = _dev(global_scale, dev).to(torch.float32).reshape(-1)[:1].contiguous()
+    out = torch.empty((rows, cols // 2), dtype=torch.uint8, device=dev)
+    call("ct_fp4_quant_pack", ptr(w), DT[w.dtype], ptr(s), DT[s.dtype], ptr(gs), rows, cols, int(group_size), ptr(out), stream_of(w))
+    return _home(out, weight)
+
+
+def fp4_unpack_and_dequantize(packed: torch.Tensor, scale: torch.Tensor, global_scale: Optional[torch.Tensor], *, group_size: int,
+                              scale_kind: str = "plain", dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """unpack_fp4_from_uint8 -> dequantize(x_q, scale, global_scale) in one launch (nvfp4/base.py:118-131).  `scale` is
+    the STORED scale: float8-e4m3 (scale_kind "f8e4m3"), E8M0 uint8 ("e8m0") or a float tensor ("plain")."""
+    if packed.dtype != torch.uint8 or packed.dim() != 2:
+        raise ValueError("packed FP4 weights are 2-D uint8 tensors")
+    dev = _compute_device(packed)
+    p, s = _dev(packed, dev).contiguous(), _dev(scale, dev).contiguous()
+    rows, cols = p.shape[0], p.shape[1] * 2
+    kind = _FP4_SCALE_KIND[scale_kind]
+    sview = s.view(torch.uint8) if kind == 1 else s
+    sdt = DT[sview.dtype] if kind == 0 else -1
+    gs = None
+    if global_scale is not None:
+        gs = _dev(global_scale, dev).to(torch.float32).reshape(-1)[:1].contiguous()
+    out = torch.empty((rows, cols), dtype=dtype, device=dev)
+    call("ct_fp4_unpack_dequant", ptr(p), rows, cols, ptr(sview), kind, sdt, ptr(gs), int(group_size), ptr(out), DT[dtype], stream_of(p))
+    return _home(out, packed)
 
 
 # --------------------------------------------------------------------------- diagnostics

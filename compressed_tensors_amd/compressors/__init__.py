@@ -1,5 +1,6 @@
 from .base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor, compress_module, decompress_module
 from .dense import DenseCompressor
+from .fp4 import MXFP4PackedCompressor, NVFP4PackedCompressor
 from .format import infer_model_format, infer_module_format
 from .model_compressors import ModelCompressor
 from .naive_quantized import FloatQuantizationCompressor, IntQuantizationCompressor, NaiveQuantizationCompressor
@@ -32,4 +33,6 @@ __all__ = [
     "Sparse24BitMaskCompressor",
     "Sparse24BitMaskTensor",
     "Marlin24Compressor",
+    "NVFP4PackedCompressor",
+    "MXFP4PackedCompressor",
 ]

@@ -4,8 +4,10 @@ from ..quantization.utils import is_module_quantized
 
 __all__ = ["infer_module_format", "infer_model_format", "COMPRESSION_FORMAT_PRIORITY"]
 
-# more specific formats first; FP4/MX formats are out of scope for this package and absent
+# more specific formats first (format.py:18-27; mxfp8-quantized is not part of this package's path)
 COMPRESSION_FORMAT_PRIORITY = [
+    CompressionFormat.mxfp4_pack_quantized,
+    CompressionFormat.nvfp4_pack_quantized,
     CompressionFormat.int_quantized,
     CompressionFormat.pack_quantized,
     CompressionFormat.float_quantized,

@@ -1,0 +1,114 @@
+"""FP4 pack-quantized codecs (reference compressors/nvfp4/base.py:27-139, mxfp4/base.py:27-65).
+
+nvfp4-pack-quantized: E2M1 weights in groups of 16 under float8-e4m3 group scales and a float32 global scale;
+mxfp4-pack-quantized: groups of 32 under E8M0 power-of-two scales.  The weight path of each direction is ONE fused
+HIP kernel (`ct_fp4_quant_pack`: scale / global -> divide -> E2M1 rounding by v_cvt_scalef32_pk_fp4_f32 -> nibble
+pack; `ct_fp4_unpack_dequant` reads the stored fp8 / E8M0 scale bytes directly); only the small scale tensors are
+converted with torch ops."""
+import torch
+
+from ... import codec
+from ...config import CompressionFormat
+from ...quantization.quant_args import enum_value
+from ...utils import getattr_chain
+from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor
+
+__all__ = ["NVFP4PackedCompressor", "MXFP4PackedCompressor"]
+
+
+def _is_fp4(scheme, group_size) -> bool:
+    w = getattr(scheme, "weights", None)
+    return w is not None and int(w.num_bits) == 4 and enum_value(w.type) == "float" and getattr(w, "group_size", None) == group_size
+
+
+@BaseCompressor.register(name=CompressionFormat.nvfp4_pack_quantized.value)
+class NVFP4PackedCompressor(BaseCompressor):
+    GROUP = 16
+
+    @classmethod
+    def compression_param_names(cls, scheme) -> tuple:
+        """nvfp4/base.py:36-47"""
+        names = ("weight_packed", "weight_scale", "weight_global_scale")
+        if not getattr_chain(scheme, "weights.symmetric", True):
+            names += ("weight_zero_point",)
+        if not getattr_chain(scheme, "input_activations.dynamic", True):
+            names += ("input_global_scale",)
+        return names
+
+    @classmethod
+    def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:
+        return scale.to(getattr(weights, "scale_dtype", None) or torch.float8_e4m3fn)
+
+    @classmethod
+    def _scale_kind(cls):
+        return "f8e4m3"
+
+    @classmethod
+    def _decompress_scale(cls, scale: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        return scale.to(dtype)
+
+    @classmethod
+    def compress(cls, state_dict: dict, scheme) -> dict:
+        """nvfp4/base.py:68-104"""
+        state_dict = state_dict.copy()
+        weight = state_dict.pop("weight")
+        scale = state_dict.pop("weight_scale")
+        global_scale = state_dict.get("weight_global_scale", None)
+        if state_dict.get("weight_zero_point") is not None and not getattr_chain(scheme, "weights.symmetric", True):
+            raise NotImplementedError("Asymmetric Quantization is not supported for FP4")
+        state_dict["weight_packed"] = codec.fp4_quantize_and_pack(weight, scale, global_scale, group_size=cls.GROUP)
+        state_dict["weight_scale"] = cls._compress_scale(scale, scheme.weights)
+        return cls._remove_symmetric_zp(state_dict, scheme)
+
+    @classmethod
+    def decompress(cls, state_dict: dict, scheme) -> dict:
+        """nvfp4/base.py:106-139: the weight comes back as bfloat16 (unpack_fp4_from_uint8's default), the scale as a
+        bfloat16 tensor"""
+        state_dict = state_dict.copy()
+        packed = state_dict.pop("weight_packed")
+        scale = state_dict.get("weight_scale")
+        global_scale = state_dict.get("weight_global_scale", None)
+        state_dict["weight"] = codec.fp4_unpack_and_dequantize(packed, scale, global_scale, group_size=cls.GROUP, scale_kind=cls._scale_kind(),
+                                                               dtype=torch.bfloat16)
+        state_dict["weight_scale"] = cls._decompress_scale(scale, torch.bfloat16)
+        return state_dict
+
+    @classmethod
+    def can_compress(cls, module_type: type, scheme) -> bool:
+        """nvfp4/base.py:130-139: FP4 with group_size 16"""
+        return module_type in COMPRESSIBLE_MODULE_TYPES and _is_fp4(scheme, 16)
+
+
+@BaseCompressor.register(name=CompressionFormat.mxfp4_pack_quantized.value)
+class MXFP4PackedCompressor(NVFP4PackedCompressor):
+    GROUP = 32
+
+    @classmethod
+    def compression_param_names(cls, scheme) -> tuple:
+        """mxfp4/base.py:34-44: GROUP strategy, no global scale"""
+        names = ("weight_packed", "weight_scale")
+        if not getattr_chain(scheme, "weights.symmetric", True):
+            names += ("weight_zero_point",)
+        if not getattr_chain(scheme, "input_activations.dynamic", True):
+            names += ("input_global_scale",)
+        return names
+
+    @classmethod
+    def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:
+        """mx_utils.py:18-31"""
+        dtype = getattr(weights, "scale_dtype", None) or torch.uint8
+        return (127 + torch.floor(torch.log2(scale)).to(torch.int32)).to(dtype)
+
+    @classmethod
+    def _scale_kind(cls):
+        return "e8m0"
+
+    @classmethod
+    def _decompress_scale(cls, scale: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """mx_utils.py:34-44"""
+        return (2.0 ** (scale.to(torch.int32) - 127).to(torch.bfloat16)).to(dtype)
+
+    @classmethod
+    def can_compress(cls, module_type: type, scheme) -> bool:
+        """mxfp4/base.py:57-65: FP4 with group_size 32"""
+        return module_type in COMPRESSIBLE_MODULE_TYPES and _is_fp4(scheme, 32)

@@ -63,6 +63,8 @@ class QuantizationArgs:
     block_structure: Optional[List[int]] = None
     dynamic: bool = False
     actorder: Optional[ActivationOrdering] = None
+    scale_dtype: Optional[torch.dtype] = None  # quant_args.py:201-202
+    zp_dtype: Optional[torch.dtype] = None
 
     def __post_init__(self):
         self.type = QuantizationType(getattr(self.type, "value", self.type))

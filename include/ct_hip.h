@@ -142,6 +142,20 @@ int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_bl
 int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits,
                       int symmetric, void* scale_out, int8_t* zp_out, ct_stream_t stream);
 
+/* ---------------------------------------------------------------------------- FP4 (E2M1) codecs
+ * nvfp4-pack-quantized / mxfp4-pack-quantized weight paths (compressors/nvfp4/base.py:68-139,
+ * mxfp4/base.py:27-65): quantize(x, scale, global_scale) -> cast_to_fp4 -> pack_fp4_to_uint8 fused, and the
+ * inverse.  group: 16 (nvfp4) or 32 (mxfp4); cols % 32 == 0.  global_scale: device float32[1] or NULL.
+ * packed: uint8 (rows, cols/2), element 2i in the low nibble of byte i.
+ * compress: scale is the float scale tensor (rows, cols/group) the reference passes to quantize().
+ * decompress: scale_kind 0 = float tensor of dtype sdt, 1 = the stored fp8-e4m3fn bytes (nvfp4), 2 = the stored
+ * E8M0 exponent bytes (mxfp4); odt in {CT_BF16, CT_F16} (the reference always produces bf16). */
+int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const float* global_scale,
+                      int64_t rows, int64_t cols, int64_t group, uint8_t* packed, ct_stream_t stream);
+int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind,
+                          int sdt, const float* global_scale, int64_t group, void* out, int odt,
+                          ct_stream_t stream);
+
 /* ---------------------------------------------------------------------------- sparse codecs
  * The compressor classes for these formats were removed from the reference snapshot
  * (compressors/base.py:43-44); the formats and primitives remain: config/base.py:17-18,23,

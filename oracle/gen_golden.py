@@ -286,14 +286,87 @@ def gen_sparse():
     save("sparse", tensors, {"cases": cases})
 
 
+# ----------------------------------------------------------------------------- FP4 (NVFP4 / MXFP4), SURVEY §8f N4
+def gen_fp4():
+    """nvfp4-pack-quantized / mxfp4-pack-quantized codecs: the reference's compress / decompress on weights that
+    contain every rounding boundary of the E2M1 grid, plus the primitives (cast_to_fp4, pack / unpack, E8M0)."""
+    from compressed_tensors.compressors.mx_utils import compress_mx_scale, decompress_mx_scale
+    from compressed_tensors.compressors.nvfp4.helpers import pack_fp4_to_uint8, unpack_fp4_from_uint8
+    from compressed_tensors.quantization.quant_args import FP4_E2M1_DATA
+    from compressed_tensors.quantization.quant_scheme import preset_name_to_scheme
+    from compressed_tensors.quantization.utils import generate_gparam
+
+    g = torch.Generator().manual_seed(4242)
+    tensors, cases = {}, []
+    # primitives
+    grid = torch.tensor([0.0, -0.0, 0.1, 0.25, 0.26, 0.5, 0.74, 0.75, 1.0, 1.25, 1.26, 1.5, 1.74, 1.75, 2.0, 2.5, 2.51, 3.0, 3.49,
+                         3.5, 4.0, 5.0, 5.01, 6.0, -0.1, -0.25, -0.3, -0.75, -1.25, -1.75, -2.5, -3.5, -5.0, -6.0, 5.5, -5.5], dtype=torch.float32)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        x = torch.cat([grid, (torch.rand(92, generator=g) * 12 - 6)]).to(dt)
+        tensors[f"cast_{dt}.in"] = x
+        tensors[f"cast_{dt}.out"] = FP4_E2M1_DATA.cast_to_fp4(x.clone())
+    vals = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+    q = torch.cat([vals, -vals]).repeat(8).reshape(8, 16).to(torch.bfloat16)
+    tensors["pack.in"] = q
+    tensors["pack.out"] = pack_fp4_to_uint8(q)
+    tensors["unpack.out"] = unpack_fp4_from_uint8(tensors["pack.out"], 8, 16)
+    sc = torch.tensor([2.0 ** e for e in range(-20, 12)] + [3.0, 0.7, 1.99, 1e-3], dtype=torch.float32)
+    tensors["e8m0.in"] = sc
+    tensors["e8m0.out"] = compress_mx_scale(sc, torch.uint8)
+    tensors["e8m0.back"] = decompress_mx_scale(tensors["e8m0.out"])
+
+    for preset, fmt, gs in (("NVFP4A16", "nvfp4-pack-quantized", 16), ("MXFP4A16", "mxfp4-pack-quantized", 32)):
+        scheme = preset_name_to_scheme(preset, ["Linear"])
+        args = scheme.weights
+        comp = BaseCompressor.get_value_from_registry(fmt)
+        for dt in (torch.bfloat16, torch.float16):
+            for shape in ((8, 64), (16, 256)):
+                key = f"{fmt}_{str(dt).split('.')[-1]}_{shape[0]}x{shape[1]}"
+                w = torch.randn(shape, generator=g, dtype=torch.float32)
+                w[0, :8] = torch.tensor([0.0, -0.0, 1e-6, -1e-6, 3.0, -3.0, 100.0, -100.0])
+                w = w.to(dt)
+                wg = w.reshape(shape[0], shape[1] // gs, gs)
+                mn, mx = wg.amin(-1), wg.amax(-1)
+                sd = {"weight": w}
+                if preset.startswith("NV"):
+                    gsc = generate_gparam(w.min().reshape(1), w.max().reshape(1))
+                    sd["weight_global_scale"] = gsc
+                    scale, zp = calculate_qparams(mn, mx, args, global_scale=gsc)
+                else:
+                    scale, zp = calculate_qparams(mn, mx, args)
+                sd["weight_scale"] = scale
+                sd["weight_zero_point"] = zp
+                # put exact rounding boundaries of the first group into the weight: k * effective scale
+                eff = (scale[0, 0].float() / sd["weight_global_scale"][0].float()) if "weight_global_scale" in sd else scale[0, 0].float()
+                sd["weight"][0, 8:16] = (torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, -2.5]) * eff).to(dt)
+                c = comp.compress(sd, scheme)
+                d = comp.decompress(c, scheme)
+                tensors[key + ".in.weight"] = sd["weight"]
+                tensors[key + ".in.weight_scale"] = scale
+                if "weight_global_scale" in sd:
+                    tensors[key + ".in.weight_global_scale"] = sd["weight_global_scale"]
+                for k, v in c.items():
+                    tensors[key + ".comp." + k] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+                for k, v in d.items():
+                    tensors[key + ".dec." + k] = v.data if isinstance(v, torch.nn.Parameter) else v
+                cases.append({"key": key, "format": fmt, "group_size": gs, "shape": list(shape), "dtype": str(dt).split(".")[-1],
+                              "scale_dtype": str(scale.dtype).split(".")[-1], "compressed_keys": sorted(c), "decompressed_keys": sorted(d),
+                              "compressed_scale_dtype": str(c["weight_scale"].dtype).split(".")[-1]})
+    save("fp4", tensors, {"cases": cases})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    gen_pack()
-    gen_quant()
-    gen_qparams()
-    gen_compressors()
-    gen_sparse()
-    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+    families = {"pack": gen_pack, "quant": gen_quant, "qparams": gen_qparams, "compressors": gen_compressors, "sparse": gen_sparse,
+                "fp4": gen_fp4}
+    wanted = sys.argv[1:] or list(families)  # `python oracle/gen_golden.py fp4` regenerates one family only
+    mpath = os.path.join(OUT, "manifest.json")
+    if os.path.exists(mpath) and sys.argv[1:]:
+        with open(mpath) as f:
+            manifest.update(json.load(f))
+    for name in wanted:
+        families[name]()
+    with open(mpath, "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     total = sum(os.path.getsize(os.path.join(OUT, n)) for n in os.listdir(OUT))
-    print(f"wrote {len(manifest)} golden files, {total/1e6:.2f} MB -> {OUT}")
+    print(f"wrote {len(wanted)} golden families ({len(manifest)} in the manifest), {total/1e6:.2f} MB -> {OUT}")

@@ -23,6 +23,7 @@ import math
 import os
 import subprocess
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -428,3 +429,106 @@ def pack_quantized_decompress(state_dict, *, num_bits, strategy, symmetric=True)
     unpacked = unpack_from_int32(packed, num_bits, shape)
     sd["weight"] = dequantize(unpacked, scale, zp, g_idx=g_idx)
     return sd
+
+
+# --------------------------------------------------------------------------- FP4 (E2M1) codecs, SURVEY §8f N4
+# Restated with index arithmetic instead of the reference's masked assignments; pinned against
+# tests/golden/fp4.safetensors (generated by running the reference: oracle/gen_golden.py fp4).
+_E2M1 = (0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0)
+
+
+def _fp4_index(a: torch.Tensor) -> torch.Tensor:
+    """magnitude index of |value| after the clamp to 6 (quant_args.py:478): ties go to the even mantissa, exactly
+    cast_to_fp4's thresholds (utils/fp4_utils.py:88-98): <= 0.25 -> 0, < 0.75 -> 0.5, <= 1.25 -> 1, < 1.75 -> 1.5,
+    <= 2.5 -> 2, < 3.5 -> 3, <= 5 -> 4, else 6"""
+    a = a.double().clamp(max=6.0)
+    return ((a > 0.25).to(torch.uint8) + (a >= 0.75).to(torch.uint8) + (a > 1.25).to(torch.uint8) + (a >= 1.75).to(torch.uint8)
+            + (a > 2.5).to(torch.uint8) + (a >= 3.5).to(torch.uint8) + (a > 5.0).to(torch.uint8))
+
+
+def fp4_values(nib: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """nvfp4/helpers.py:157-193: magnitude table, negated (also the zero) when bit 3 is set"""
+    mag = torch.tensor(_E2M1, dtype=torch.float32)[(nib & 7).long()]
+    return torch.where((nib & 8) != 0, -mag, mag).to(dtype)
+
+
+def cast_to_fp4(x: torch.Tensor) -> torch.Tensor:
+    """quant_args.py:49-68 / fp4_utils.py:77-98: |x| rounded to the grid, times torch.sign(x) — so a negative input
+    that rounds to zero gives -0.0, while -0.0 itself gives +0.0 (sign(-0.0) == 0)"""
+    xf = x.float()
+    mag = torch.tensor(_E2M1, dtype=torch.float32)[_fp4_index(xf.abs()).long()]
+    return torch.where(xf < 0, -mag, mag).to(x.dtype)
+
+
+def fp4_nibbles_of_values(q: torch.Tensor) -> torch.Tensor:
+    """pack_fp4_to_uint8's index of an E2M1-valued tensor (nvfp4/helpers.py:139-145): sign from torch.signbit"""
+    return _fp4_index(q.float().abs()) | (torch.signbit(q).to(torch.uint8) << 3)
+
+
+def fp4_nibbles(t: torch.Tensor) -> torch.Tensor:
+    """cast_to_fp4 followed by the pack index: the code of the scaled, float tensor `t`"""
+    return fp4_nibbles_of_values(cast_to_fp4(t.float()))
+
+
+def pack_fp4(nib: torch.Tensor) -> torch.Tensor:
+    """helpers.py:147-150: element 2i in the low nibble of byte i"""
+    n = nib.reshape(*nib.shape[:-1], nib.shape[-1] // 2, 2)
+    return (n[..., 0] | (n[..., 1] << 4)).contiguous()
+
+
+def unpack_fp4(packed: torch.Tensor) -> torch.Tensor:
+    return torch.stack((packed & 0xF, packed >> 4), dim=-1).reshape(*packed.shape[:-1], packed.shape[-1] * 2)
+
+
+def e8m0_encode(scale: torch.Tensor) -> torch.Tensor:
+    """mx_utils.py:18-31: 127 + floor(log2(scale)) as uint8.  log2 is evaluated in the scale's own dtype (float32
+    math rounded to that dtype), so a bfloat16 scale just below a power of two at a large exponent rounds UP to the
+    next integer before the floor; MX scales are powers of two, where it is exact."""
+    l = torch.from_numpy(np.log2(scale.float().numpy().astype(np.float64)).astype(np.float32)).to(scale.dtype)
+    return (127 + torch.floor(l.float()).to(torch.int32)).to(torch.uint8)
+
+
+def e8m0_decode(code: torch.Tensor) -> torch.Tensor:
+    """mx_utils.py:34-44: 2^(code - 127) as bfloat16"""
+    return torch.ldexp(torch.ones(code.shape, dtype=torch.float64), code.to(torch.int32) - 127).to(torch.bfloat16)
+
+
+def _group_expand(s: torch.Tensor, cols: int) -> torch.Tensor:
+    return s.repeat_interleave(cols // s.shape[-1], dim=-1)
+
+
+def fp4_compress(weight, scale, global_scale=None, *, fmt):
+    """NVFP4PackedCompressor.compress / MXFP4PackedCompressor.compress (nvfp4/base.py:68-104, mxfp4/base.py:47-51).
+    forward_helpers.py:535-538: s_eff = scale / global_scale (float32 by promotion), t = x / s_eff in the promoted
+    dtype T (float32 with a float32 scale; x.dtype when the scale has x.dtype, as for MXFP4)."""
+    w, s = _cpu(weight), _cpu(scale)
+    cols = w.shape[-1]
+    if global_scale is not None:
+        s_eff = (s.float() / _cpu(global_scale).float())  # float32 division, rounded to float32
+        t = w.float() / _group_expand(s_eff, cols)
+    else:
+        T = torch.promote_types(w.dtype, s.dtype)
+        t = (w.to(T) / _group_expand(s.to(T), cols)).float()  # rounded to T by torch, then widened exactly
+    out = {"weight_packed": pack_fp4(fp4_nibbles(t))}
+    out["weight_scale"] = s.to(torch.float8_e4m3fn) if fmt == "nvfp4-pack-quantized" else e8m0_encode(s)
+    if global_scale is not None:
+        out["weight_global_scale"] = _cpu(global_scale)
+    return out
+
+
+def fp4_decompress(state, *, fmt):
+    """nvfp4/base.py:106-139 / mxfp4/base.py:53-55: the result is always bfloat16 (unpack's default dtype)"""
+    nib = unpack_fp4(_cpu(state["weight_packed"]))
+    v = fp4_values(nib, torch.bfloat16)
+    cols = v.shape[-1]
+    if fmt == "nvfp4-pack-quantized":
+        s = _cpu(state["weight_scale"]).to(torch.bfloat16)
+        s_eff = s.float() / _cpu(state["weight_global_scale"]).float()
+        w = (v.float() * _group_expand(s_eff, cols)).to(torch.bfloat16)
+    else:
+        s = e8m0_decode(_cpu(state["weight_scale"]))
+        w = (v.float() * _group_expand(s.float(), cols)).to(torch.bfloat16)
+    out = {"weight": w, "weight_scale": s}
+    if "weight_global_scale" in state:
+        out["weight_global_scale"] = _cpu(state["weight_global_scale"])
+    return out

@@ -557,3 +557,145 @@ def test_w4_batch_vs_oracle(cta, dev):
         for (w, scale, zp, ref_packed, strategy, group), e in zip(items, dent):
             q = O.unpack_from_int32(ref_packed, 4, w.shape)
             assert eq(e[3].cpu(), O.dequantize(q, scale, zp))
+
+
+# ----------------------------------------------------------------------------- FP4 codecs
+def _fp4_scheme(cta, fmt):
+    from compressed_tensors_amd.quantization import QuantizationArgs, QuantizationScheme
+
+    if fmt == "nvfp4-pack-quantized":
+        w = QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=torch.float8_e4m3fn)
+    else:
+        w = QuantizationArgs(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)
+    return QuantizationScheme(targets=["Linear"], weights=w)
+
+
+@pytest.mark.parametrize("case", cases("fp4"), ids=lambda c: c["key"])
+def test_fp4_compressor_golden(golden, cta, dev, case):
+    """the reference's own outputs (tests/golden/fp4.safetensors, oracle/gen_golden.py) through the compressor classes"""
+    t = golden.case("fp4", case["key"])
+    fmt = case["format"]
+    comp = cta.BaseCompressor.get_value_from_registry(fmt)
+    scheme = _fp4_scheme(cta, fmt)
+    sd = {k[3:]: d(v, dev) for k, v in t.items() if k.startswith("in.")}
+    c = comp.compress(sd, scheme)
+    assert sorted(c) == case["compressed_keys"]
+    assert c["weight_packed"].is_cuda and c["weight_packed"].dtype == torch.uint8
+    assert torch.equal(c["weight_packed"].cpu(), t["comp.weight_packed"])
+    assert str(c["weight_scale"].dtype) == "torch." + case["compressed_scale_dtype"]
+    assert torch.equal(c["weight_scale"].cpu().view(torch.uint8), t["comp.weight_scale"])
+    back = comp.decompress(c, scheme)
+    assert sorted(back) == case["decompressed_keys"]
+    for name in ("weight", "weight_scale"):
+        assert eq(back[name].cpu(), t[f"dec.{name}"]), name
+
+
+def _all_16bit(dtype):
+    bits = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dtype)
+    return bits[~torch.isnan(bits)]
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_fp4_hardware_conversion_all_inputs(cta, dev, xdt):
+    """v_cvt_scalef32_pk_fp4_f32 against cast_to_fp4's thresholds: EVERY non-NaN 16-bit input (ties, +-0, subnormals,
+    +-inf, saturation), through both the in-dtype (mxfp4) and the float32 (nvfp4) quotient paths, at several scales"""
+    x = _all_16bit(xdt)
+    n = (x.numel() // 32) * 32
+    x = x[torch.randperm(x.numel(), generator=torch.Generator().manual_seed(0))][:n].reshape(-1, 32).contiguous()
+    rows = x.shape[0]
+    for sval in (1.0, 0.25, 2.0 ** -9, 64.0):  # mxfp4: power-of-two scales in x's dtype
+        s = torch.full((rows, 1), sval, dtype=xdt)
+        got = cta.codec.fp4_quantize_and_pack(d(x, dev), d(s, dev), None, group_size=32)
+        ref = O.fp4_compress(x, s, None, fmt="mxfp4-pack-quantized")["weight_packed"]
+        assert torch.equal(got.cpu(), ref), sval
+    g = torch.Generator().manual_seed(1)
+    for gsval in (1.0, 2688.0 / 7.3, 0.37):  # nvfp4: fp8-representable float32 scales under a float32 global scale
+        s = (torch.rand((rows, 2), generator=g) * 400 + 0.002).to(torch.float8_e4m3fn).to(torch.float32)
+        gs = torch.tensor([gsval], dtype=torch.float32)
+        got = cta.codec.fp4_quantize_and_pack(d(x, dev), d(s, dev), d(gs, dev), group_size=16)
+        ref = O.fp4_compress(x, s, gs, fmt="nvfp4-pack-quantized")["weight_packed"]
+        assert torch.equal(got.cpu(), ref), gsval
+
+
+def test_fp4_decode_all_codes_all_scales(cta, dev):
+    """every packed byte under every fp8-e4m3 scale (nvfp4) and every E8M0 exponent (mxfp4)"""
+    codes = torch.arange(256, dtype=torch.uint8)
+    # nvfp4: row r uses fp8 scale byte r for its single group of 16 (8 bytes); 32 rows of byte patterns per scale
+    sbytes = torch.arange(256, dtype=torch.uint8)
+    sbytes = sbytes[~torch.isnan(sbytes.view(torch.float8_e4m3fn).float())]
+    packed = codes.reshape(32, 8).repeat(sbytes.numel(), 1).contiguous()
+    scale = sbytes.repeat_interleave(32).reshape(-1, 1).view(torch.float8_e4m3fn)
+    for gsval in (1.0, 0.37, 2688.0 / 7.3):
+        gs = torch.tensor([gsval], dtype=torch.float32)
+        got = cta.codec.fp4_unpack_and_dequantize(d(packed, dev), d(scale, dev), d(gs, dev), group_size=16, scale_kind="f8e4m3")
+        ref = O.fp4_decompress({"weight_packed": packed, "weight_scale": scale, "weight_global_scale": gs}, fmt="nvfp4-pack-quantized")["weight"]
+        assert got.dtype == BF16 and eq(got.cpu(), ref), gsval
+    e = torch.arange(256, dtype=torch.uint8)
+    packed = codes.reshape(16, 16).repeat(256, 1).contiguous()
+    scale = e.repeat_interleave(16).reshape(-1, 1)
+    got = cta.codec.fp4_unpack_and_dequantize(d(packed, dev), d(scale, dev), None, group_size=32, scale_kind="e8m0")
+    ref = O.fp4_decompress({"weight_packed": packed, "weight_scale": scale}, fmt="mxfp4-pack-quantized")["weight"]
+    assert eq(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("fmt,group", [("nvfp4-pack-quantized", 16), ("mxfp4-pack-quantized", 32)])
+@pytest.mark.parametrize("xdt", [BF16, F16])
+@pytest.mark.parametrize("shape", [(1, 32), (3, 96), (5, 160), (64, 4096), (33, 1056)])
+def test_fp4_codec_vs_oracle(cta, dev, fmt, group, xdt, shape):
+    if shape[1] % group:
+        pytest.skip("columns not a multiple of the group")
+    g = torch.Generator().manual_seed(shape[0] * 131 + shape[1])
+    x = (torch.randn(shape, generator=g) * 3).to(xdt)
+    x.view(-1)[: special_values(xdt).numel()] = special_values(xdt)[: x.numel()]
+    x = torch.where(torch.isnan(x), torch.zeros_like(x), x)
+    amax = x.float().reshape(shape[0], -1, group).abs().amax(-1).clamp(min=1e-3, max=1e4)
+    if fmt.startswith("nvfp4"):
+        gs = torch.tensor([448.0 * 6.0 / float(amax.max())], dtype=torch.float32)
+        s = (gs * amax / 6.0).to(torch.float8_e4m3fn).to(torch.float32)
+        s = torch.where(s == 0, torch.full_like(s, 2.0 ** -9), s)
+    else:
+        gs = None
+        s = torch.exp2(torch.floor(torch.log2(amax)) - 2).to(xdt)
+    comp = cta.BaseCompressor.get_value_from_registry(fmt)
+    scheme = _fp4_scheme(cta, fmt)
+    sd = {"weight": d(x, dev), "weight_scale": d(s, dev)}
+    if gs is not None:
+        sd["weight_global_scale"] = d(gs, dev)
+    c = comp.compress(sd, scheme)
+    ref = O.fp4_compress(x, s, gs, fmt=fmt)
+    assert torch.equal(c["weight_packed"].cpu(), ref["weight_packed"])
+    assert torch.equal(c["weight_scale"].cpu().view(torch.uint8), ref["weight_scale"].view(torch.uint8))
+    back = comp.decompress(c, scheme)
+    rback = O.fp4_decompress(ref, fmt=fmt)
+    assert back["weight"].dtype == BF16 and eq(back["weight"].cpu(), rback["weight"])
+    assert eq(back["weight_scale"].cpu(), rback["weight_scale"])
+
+
+def test_fp4_full_size_roundtrip(cta, dev):
+    """8192 x 8192: decompress(compress(x)) re-compresses to the same bytes (idempotence), and E2M1-valued inputs
+    under unit scales survive exactly"""
+    N = 8192
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((N, N), generator=g, device=dev, dtype=BF16)
+    s = torch.full((N, N // 32), 0.5, dtype=BF16, device=dev)
+    p = cta.codec.fp4_quantize_and_pack(x, s, None, group_size=32)
+    y = cta.codec.fp4_unpack_and_dequantize(p, s, None, group_size=32)
+    p2 = cta.codec.fp4_quantize_and_pack(y, s, None, group_size=32)
+    # a negative value that rounded to -0.0 comes back as -0.0, which compresses to +0 (sign(-0.0) == 0 upstream)
+    neg_zero = ((p & 0x0F) == 0x08) | ((p & 0xF0) == 0x80)
+    fixed = torch.where((p & 0x0F) == 0x08, p & 0xF0, p)
+    fixed = torch.where((fixed & 0xF0) == 0x80, fixed & 0x0F, fixed)
+    assert torch.equal(p2, fixed) and bool(neg_zero.any())
+    grid = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0, -0.5, -1.0, -1.5, -2.0, -3.0, -4.0, -6.0], device=dev)
+    v = grid[torch.randint(0, grid.numel(), (N, N), generator=g, device=dev)].to(BF16)
+    one = torch.ones((N, N // 32), dtype=BF16, device=dev)
+    assert torch.equal(cta.codec.fp4_unpack_and_dequantize(cta.codec.fp4_quantize_and_pack(v, one, None, group_size=32), one, None, group_size=32), v)
+
+
+def test_fp4_format_inference_and_errors(cta, dev):
+    from compressed_tensors_amd.compressors.format import infer_module_format
+
+    assert infer_module_format(torch.nn.Linear, _fp4_scheme(cta, "nvfp4-pack-quantized")).value == "nvfp4-pack-quantized"
+    assert infer_module_format(torch.nn.Linear, _fp4_scheme(cta, "mxfp4-pack-quantized")).value == "mxfp4-pack-quantized"
+    with pytest.raises(ValueError):
+        cta.codec.fp4_quantize_and_pack(torch.zeros((2, 31), dtype=BF16, device=dev), torch.ones((2, 1), dtype=BF16, device=dev), None, group_size=32)

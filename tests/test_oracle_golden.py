@@ -250,3 +250,31 @@ def test_marlin24_pack_matches_torch_restatement():
     for i in range(pf):
         expect |= t[:, i::pf] << (bits * i)
     assert torch.equal(O.marlin24_pack_weights(q, bits), expect)
+
+
+# ----------------------------------------------------------------------------- FP4 codecs
+def test_fp4_primitives_golden(golden):
+    t = golden.tensors("fp4")
+    for dt in ("torch.float32", "torch.bfloat16", "torch.float16"):
+        x, ref = t[f"cast_{dt}.in"], t[f"cast_{dt}.out"]
+        got = O.cast_to_fp4(x)
+        assert got.dtype == ref.dtype and torch.equal(got, ref)  # values (-0.0 == 0.0 here) ...
+        assert torch.equal(torch.signbit(got), torch.signbit(ref))  # ... and the sign of the zeros
+    nib = O.fp4_nibbles_of_values(t["pack.in"])
+    assert torch.equal(O.pack_fp4(nib), t["pack.out"])
+    assert torch.equal(O.fp4_values(O.unpack_fp4(t["pack.out"])), t["unpack.out"])
+    assert torch.equal(O.e8m0_encode(t["e8m0.in"]), t["e8m0.out"]) and torch.equal(O.e8m0_decode(t["e8m0.out"]), t["e8m0.back"])
+
+
+@pytest.mark.parametrize("case", cases("fp4"), ids=lambda c: c["key"])
+def test_fp4_compressors_golden(golden, case):
+    t = golden.case("fp4", case["key"])
+    fmt = case["format"]
+    c = O.fp4_compress(t["in.weight"], t["in.weight_scale"], t.get("in.weight_global_scale"), fmt=fmt)
+    assert sorted(c) == case["compressed_keys"]
+    assert torch.equal(c["weight_packed"], t["comp.weight_packed"])
+    assert torch.equal(c["weight_scale"].view(torch.uint8), t["comp.weight_scale"])
+    d = O.fp4_decompress(c, fmt=fmt)
+    assert sorted(d) == case["decompressed_keys"]
+    for name in ("weight", "weight_scale"):
+        assert eq(d[name], t[f"dec.{name}"]), name
