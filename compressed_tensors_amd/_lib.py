@@ -54,6 +54,10 @@ _PROTOTYPES = {
     "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_fp4_quant_pack": ([_P, _I, _P, _I, _P, _L, _L, _L, _P, _S], _I),
     "ct_fp4_unpack_dequant": ([_P, _L, _L, _P, _I, _I, _P, _L, _P, _I, _S], _I),
+    "ct_fp4_cast": ([_P, _I, _P, _L, _S], _I),
+    "ct_fp4_pack": ([_P, _I, _P, _L, _S], _I),
+    "ct_fp4_unpack": ([_P, _L, _P, _I, _S], _I),
+    "ct_selftest_fp4_div": ([_I, _c.c_uint32, _c.c_uint32, _P, _S], _I),
     "ct_minmax_qparams": ([_P, _I, _L, _L, _L, _I, _I, _P, _P, _S], _I),
     "ct_pack_bitmasks": ([_P, _L, _L, _P, _S], _I),
     "ct_unpack_bitmasks": ([_P, _L, _L, _P, _S], _I),

@@ -27,6 +27,11 @@ __all__ = [
     "unpack_bitmasks",
     "W4Batch",
     "w4_batch_eligible",
+    "cast_to_fp4",
+    "pack_fp4_to_uint8",
+    "unpack_fp4_from_uint8",
+    "compress_mx_scale",
+    "decompress_mx_scale",
     "fp4_quantize_and_pack",
     "fp4_unpack_and_dequantize",
     "marlin24_quant_compress",
@@ -42,6 +47,7 @@ __all__ = [
     "marlin24_pack_scales",
     "selftest_bf16_div",
     "selftest_f16_div",
+    "selftest_fp4_div",
     "QuantLayout",
 ]
 
@@ -697,6 +703,57 @@ def marlin24_pack_scales(scale: torch.Tensor, *, single: bool):
 _FP4_SCALE_KIND = {"plain": 0, "f8e4m3": 1, "e8m0": 2}
 
 
+def cast_to_fp4(x: torch.Tensor) -> torch.Tensor:
+    """quantization/utils/fp4_utils.py:77-98: nearest E2M1 value (0, 0.5, 1, 1.5, 2, 3, 4, 6 and negatives), same dtype."""
+    if x.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise NotImplementedError(f"cast_to_fp4 takes float tensors, got {x.dtype}")
+    dev = _compute_device(x)
+    xin = _dev(x, dev).contiguous()
+    out = torch.empty_like(xin)
+    call("ct_fp4_cast", ptr(xin), DT[xin.dtype], ptr(out), xin.numel(), stream_of(xin))
+    return _home(out, x)
+
+
+def pack_fp4_to_uint8(x: torch.Tensor) -> torch.Tensor:
+    """compressors/nvfp4/helpers.py:108-150 (same argument, same error): (m, n) E2M1-valued -> uint8 (m, n / 2)."""
+    m, n = x.shape
+    if n % 2 != 0:
+        raise ValueError("tensor must have an even number of columns for nvfp4 compression")
+    if x.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        x = x.to(torch.bfloat16)
+    dev = _compute_device(x)
+    xin = _dev(x, dev).contiguous()
+    out = torch.empty((m, n // 2), dtype=torch.uint8, device=dev)
+    call("ct_fp4_pack", ptr(xin), DT[xin.dtype], ptr(out), xin.numel(), stream_of(xin))
+    return _home(out, x)
+
+
+def unpack_fp4_from_uint8(a: torch.Tensor, m: int, n: int, dtype: Optional[torch.dtype] = torch.bfloat16) -> torch.Tensor:
+    """compressors/nvfp4/helpers.py:153-193 (same arguments): uint8 (m, n / 2) -> (m, n) E2M1 values of `dtype`."""
+    assert a.dtype == torch.uint8
+    dtype = dtype or torch.float32  # upstream's lookup table is float32
+    if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise NotImplementedError(f"unpack_fp4_from_uint8 produces float tensors, got {dtype}")
+    if a.numel() * 2 != m * n:
+        raise ValueError(f"{a.numel()} packed bytes do not hold a {m} x {n} tensor")
+    dev = _compute_device(a)
+    ain = _dev(a, dev).contiguous()
+    out = torch.empty((m, n), dtype=dtype, device=dev)
+    call("ct_fp4_unpack", ptr(ain), m * n, ptr(out), DT[dtype], stream_of(ain))
+    return _home(out, a)
+
+
+def compress_mx_scale(scale: torch.Tensor, scale_dtype: torch.dtype = torch.uint8) -> torch.Tensor:
+    """compressors/mx_utils.py:18-31: E8M0 code 127 + floor(log2(scale)); log2 is evaluated in the scale's dtype, as
+    upstream (a small tensor: one element per 32 weights)."""
+    return (127 + torch.floor(torch.log2(scale)).to(torch.int32)).to(scale_dtype)
+
+
+def decompress_mx_scale(scale: torch.Tensor) -> torch.Tensor:
+    """compressors/mx_utils.py:34-44: 2 ** (code - 127) as bfloat16"""
+    return 2.0 ** (scale.to(torch.int32) - 127).to(torch.bfloat16)
+
+
 def fp4_quantize_and_pack(weight: torch.Tensor, scale: torch.Tensor, global_scale: Optional[torch.Tensor], *, group_size: int) -> torch.Tensor:
     """quantize(x, scale, global_scale, FP4 args) -> cast_to_fp4 -> pack_fp4_to_uint8 in one launch
     (compressors/nvfp4/base.py:88-95): uint8 (rows, cols / 2)."""
@@ -755,4 +812,13 @@ def selftest_f16_div(s_lo_bits: int = 0, s_hi_bits: int = 65536) -> int:
     dev = _lib.require_device()
     out = torch.zeros(1, dtype=torch.int64, device=dev)
     call("ct_selftest_f16_div", s_lo_bits, s_hi_bits, ptr(out), torch.cuda.current_stream(dev).cuda_stream)
+    return int(out.item())
+
+
+def selftest_fp4_div(x_dtype: torch.dtype = torch.bfloat16, m_lo: int = 0, m_hi: int = 1 << 23) -> int:
+    """number of (x mantissa, s mantissa) pairs for which the shared-reciprocal quotient of the FP4 compress kernel
+    differs from the IEEE fp32 divide (must be 0; see ct_fp4.hip)."""
+    dev = _lib.require_device()
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    call("ct_selftest_fp4_div", DT[x_dtype], m_lo, m_hi, ptr(out), torch.cuda.current_stream(dev).cuda_stream)
     return int(out.item())

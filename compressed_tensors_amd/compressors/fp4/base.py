@@ -96,8 +96,7 @@ class MXFP4PackedCompressor(NVFP4PackedCompressor):
     @classmethod
     def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:
         """mx_utils.py:18-31"""
-        dtype = getattr(weights, "scale_dtype", None) or torch.uint8
-        return (127 + torch.floor(torch.log2(scale)).to(torch.int32)).to(dtype)
+        return codec.compress_mx_scale(scale, getattr(weights, "scale_dtype", None) or torch.uint8)
 
     @classmethod
     def _scale_kind(cls):
@@ -106,7 +105,7 @@ class MXFP4PackedCompressor(NVFP4PackedCompressor):
     @classmethod
     def _decompress_scale(cls, scale: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
         """mx_utils.py:34-44"""
-        return (2.0 ** (scale.to(torch.int32) - 127).to(torch.bfloat16)).to(dtype)
+        return codec.decompress_mx_scale(scale).to(dtype)
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

@@ -33,6 +33,93 @@ __device__ __forceinline__ uint32_t fp4_word(const float (&t)[8]) {
     return w;
 }
 
+// code word of 8 values WITHOUT the -0.0 fold: bit 3 is the IEEE sign bit, which is pack_fp4_to_uint8's
+// torch.signbit (helpers.py:139-145)
+__device__ __forceinline__ uint32_t fp4_word_signbit(const float (&t)[8]) {
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, t[0], t[1], 1.0f, 0);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, t[2], t[3], 1.0f, 1);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, t[4], t[5], 1.0f, 2);
+    w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, t[6], t[7], 1.0f, 3);
+    return w;
+}
+
+// ---- the quotient t = x / s_eff --------------------------------------------------------------------------------
+// The IEEE divide costs ~10 VALU instructions per element (the first form of this kernel: 48.8 us for 8192^2 against
+// ~30 us of memory time).  Per unit of 8 elements that share one scale, two exact shortcuts:
+//  * s_eff a power of two in [2^-100, 2^100] (every MX scale): x * (1 / s_eff) is the same real number, rounded once.
+//    When the reference keeps the quotient in x's own dtype (scale dtype == x dtype) the only visible effect of that
+//    extra rounding is a quotient that underflows to zero, which loses its sign: |q| <= half the dtype's smallest
+//    subnormal -> +0 (this also folds -0.0 inputs).
+//  * any s_eff in [2^-20, 2^10] (NVFP4: fl32(scale / global_scale)): r = rcp(s) refined once (shared by the unit),
+//    q0 = x * r, q1 = fma(fma(-s, q0, x), r, q0).  q1 == fl32(x / s) bit for bit whenever |q0| >= 2^-4: shown by
+//    ct_selftest_fp4_div over ALL 2^23 mantissas of s x all mantissas of x (the sequence is invariant under powers
+//    of two while every intermediate is normal, which the ranges guarantee); below 2^-4 both are < 0.25 and non-zero
+//    with the sign of x (s <= 2^10 keeps x * r above the fp32 underflow), which is all the code depends on.
+//    +-0 in gives +0 out of the fma chain; |x| is clamped to 8 * s first (code 7 either way; keeps inf out of the fma).
+template <int XDT>
+__device__ __forceinline__ float fp4_tiny_half() {
+    return XDT == CT_BF16 ? 0x1p-134f : 0x1p-25f;
+}
+
+__device__ __forceinline__ float fp4_refined_rcp(float s) {
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    return __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+}
+
+__device__ __forceinline__ float fp4_fast_quotient(float x, float s, float r, float lim) {
+    const float xc = __builtin_amdgcn_fmed3f(x, -lim, lim);
+    const float q0 = xc * r;
+    return __builtin_fmaf(__builtin_fmaf(-s, q0, xc), r, q0);
+}
+
+template <int XDT>
+__device__ __forceinline__ void fp4_unpack_pair(uint32_t w, float& x0, float& x1) {
+    if constexpr (XDT == CT_BF16) { x0 = bits_f(w << 16); x1 = bits_f(w & 0xffff0000u); }
+    else { x0 = f16_bits_to_f(w & 0xffffu); x1 = f16_bits_to_f(w >> 16); }
+}
+
+// one unit: 8 elements (4 dwords) under one scale -> one word of 8 nibbles
+template <int XDT, bool GLOBAL>
+__device__ __forceinline__ uint32_t fp4_quant_unit(const uint32_t (&ws)[4], float s, float gs, bool in_dtype) {
+    const float s_eff = GLOBAL ? s / gs : s;  // fl32(scale / global_scale)
+    const uint32_t sb = f_bits(s_eff);
+    float t[8];
+    if (!GLOBAL && (sb & 0x807fffffu) == 0 && sb >= (27u << 23) && sb <= (227u << 23)) {
+        const float rinv = bits_f(0x7f000000u - sb);
+        const float tiny = in_dtype ? fp4_tiny_half<XDT>() : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x0, x1;
+            fp4_unpack_pair<XDT>(ws[j], x0, x1);
+            const float q0 = x0 * rinv, q1 = x1 * rinv;
+            t[2 * j] = __builtin_fabsf(q0) > tiny ? q0 : 0.0f;
+            t[2 * j + 1] = __builtin_fabsf(q1) > tiny ? q1 : 0.0f;
+        }
+        return fp4_word_signbit(t);
+    }
+    if (GLOBAL && s_eff >= 0x1p-20f && s_eff <= 0x1p10f) {
+        const float r = fp4_refined_rcp(s_eff), lim = 8.0f * s_eff;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x0, x1;
+            fp4_unpack_pair<XDT>(ws[j], x0, x1);
+            t[2 * j] = fp4_fast_quotient(x0, s_eff, r, lim);
+            t[2 * j + 1] = fp4_fast_quotient(x1, s_eff, r, lim);
+        }
+        return fp4_word_signbit(t);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0, x1;
+        fp4_unpack_pair<XDT>(ws[j], x0, x1);
+        float q0 = x0 / s_eff, q1 = x1 / s_eff;
+        if (in_dtype) { q0 = round_to<XDT>(q0); q1 = round_to<XDT>(q1); }  // the quotient stays in x.dtype
+        t[2 * j] = q0; t[2 * j + 1] = q1;
+    }
+    return fp4_word(t);
+}
+
 // lane = 4 consecutive units (32 elements = 64 B in, 16 B out); upg = units per scale group (2: group 16, 4: group 32)
 template <int XDT, bool GLOBAL>
 __global__ __launch_bounds__(kBlock) void fp4_quant_pack_kernel(const u32x4* __restrict__ in, const void* __restrict__ scale, int sdt,
@@ -42,27 +129,18 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_kernel(const u32x4* __r
     if (g * 4 >= units) return;
     const int64_t left = units - g * 4;  // < 4 only in the last lane of a tensor whose unit count is not a multiple of 4
     const float gs = GLOBAL ? global_scale[0] : 1.0f;
+    const bool in_dtype = !GLOBAL && sdt == XDT;
+    float s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] = load_rt(scale, sdt, (i < left ? g * 4 + i : g * 4) >> upg_shift);
     u32x4 r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = i < left ? in[g * 4 + i] : u32x4{0, 0, 0, 0};
     uint32_t w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t si = (i < left ? g * 4 + i : g * 4) >> upg_shift;
-        const float s = load_rt(scale, sdt, si);
-        const float s_eff = GLOBAL ? s / gs : s;  // fl32(scale / global_scale)
         const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-        float t[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x0, x1;
-            if constexpr (XDT == CT_BF16) { x0 = bits_f(ws[j] << 16); x1 = bits_f(ws[j] & 0xffff0000u); }
-            else { x0 = f16_bits_to_f(ws[j] & 0xffffu); x1 = f16_bits_to_f(ws[j] >> 16); }
-            float q0 = x0 / s_eff, q1 = x1 / s_eff;
-            if (!GLOBAL && sdt == XDT) { q0 = round_to<XDT>(q0); q1 = round_to<XDT>(q1); }  // the quotient stays in x.dtype
-            t[2 * j] = q0; t[2 * j + 1] = q1;
-        }
-        w[i] = fp4_word(t);
+        w[i] = fp4_quant_unit<XDT, GLOBAL>(ws, s[i], gs, in_dtype);
     }
     if (left >= 4) {
         stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
@@ -70,6 +148,21 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_kernel(const u32x4* __r
         uint32_t* o = reinterpret_cast<uint32_t*>(out + g);
         for (int i = 0; i < left; ++i) o[i] = w[i];
     }
+}
+
+// every mantissa of s in [1, 2) against every mantissa of x in [1, 2) (7 bits bf16, 10 bits fp16; `xbits` of them):
+// the fast quotient must equal the IEEE quotient bit for bit.  With x < s the quotient lies in [0.5, 1), else [1, 2).
+__global__ __launch_bounds__(kBlock) void selftest_fp4_div_kernel(int xbits, uint32_t m_lo, uint32_t m_hi, unsigned long long* mismatches) {
+    unsigned long long local = 0;
+    for (uint32_t m = m_lo + blockIdx.x * kBlock + threadIdx.x; m < m_hi; m += gridDim.x * kBlock) {
+        const float s = bits_f(0x3f800000u | m);
+        const float r = fp4_refined_rcp(s), lim = 8.0f * s;
+        for (uint32_t xm = 0; xm < (1u << xbits); ++xm) {
+            const float x = bits_f(0x3f800000u | (xm << (23 - xbits)));
+            local += f_bits(fp4_fast_quotient(x, s, r, lim)) != f_bits(x / s) ? 1ull : 0ull;
+        }
+    }
+    if (local) atomicAdd(mismatches, local);
 }
 
 __device__ __forceinline__ float decode_scale(const void* scale, int kind, int sdt, int64_t si) {
@@ -119,6 +212,78 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32
             }
             store8<ODT>(out, u * 8, v);  // RNE to the output dtype
         }
+    }
+}
+
+// ---- the stand-alone primitives behind the reference's ImplBackend entry points --------------------------------
+__device__ __forceinline__ void fp4_word_values(uint32_t w, float (&v)[8]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p;
+    p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 0); v[0] = p.x; v[1] = p.y;
+    p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1); v[2] = p.x; v[3] = p.y;
+    p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2); v[4] = p.x; v[5] = p.y;
+    p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3); v[6] = p.x; v[7] = p.y;
+}
+
+// MODE 0: cast_to_fp4 (x -> nearest E2M1 value, same dtype; |x| rounded, times sign(x): -0.0 in gives +0.0 out, a
+//         negative that rounds to zero gives -0.0, NaN stays NaN)       fp4_utils.py:77-98
+// MODE 1: pack_fp4_to_uint8 (E2M1-valued x -> one nibble each)           nvfp4/helpers.py:108-150
+// one lane = one unit of 8 elements; the last, partial unit of a tensor whose element count is not a multiple of
+// 8 is handled element-wise by the lane that owns it
+template <int XDT, int MODE>
+__global__ __launch_bounds__(kBlock) void fp4_prim_kernel(const void* __restrict__ x, void* __restrict__ out, int64_t n) {
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i0 = u * 8;
+    if (i0 >= n) return;
+    const int live = n - i0 >= 8 ? 8 : (int)(n - i0);
+    float v[8];
+    if (live == 8) {
+        load8<XDT>(x, i0, v);
+    } else {
+        for (int k = 0; k < 8; ++k) v[k] = k < live ? load_as_f<XDT>(x, i0 + k) : 0.0f;
+    }
+    if constexpr (MODE == 0) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[k] + 0.0f;
+        float q[8];
+        fp4_word_values(fp4_word_signbit(t), q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = v[k] != v[k] ? v[k] : q[k];
+        if (live == 8) {
+            store8<XDT>(out, i0, q);
+        } else {
+            for (int k = 0; k < live; ++k) store1<XDT>(out, i0 + k, q[k]);
+        }
+    } else {
+        const uint32_t w = fp4_word_signbit(v);
+        if (live == 8) {
+            static_cast<uint32_t*>(out)[u] = w;
+        } else {
+            for (int k = 0; k < live / 2; ++k) static_cast<uint8_t*>(out)[u * 4 + k] = (uint8_t)(w >> (8 * k));
+        }
+    }
+}
+
+// unpack_fp4_from_uint8 (nvfp4/helpers.py:153-193): n elements from n / 2 bytes, code 8 decodes to -0.0
+template <int ODT>
+__global__ __launch_bounds__(kBlock) void fp4_unpack_kernel(const uint8_t* __restrict__ in, void* __restrict__ out, int64_t n) {
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i0 = u * 8;
+    if (i0 >= n) return;
+    const int live = n - i0 >= 8 ? 8 : (int)(n - i0);
+    uint32_t w = 0;
+    if (live == 8) {
+        w = reinterpret_cast<const uint32_t*>(in)[u];
+    } else {
+        for (int k = 0; k < live / 2; ++k) w |= (uint32_t)in[u * 4 + k] << (8 * k);
+    }
+    float v[8];
+    fp4_word_values(w, v);
+    if (live == 8) {
+        store8<ODT>(out, i0, v);
+    } else {
+        for (int k = 0; k < live; ++k) store1<ODT>(out, i0 + k, v[k]);
     }
 }
 
@@ -173,6 +338,61 @@ int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, con
     else { if (global_scale) CT_FP4D(CT_F16, true); else CT_FP4D(CT_F16, false); }
 #undef CT_FP4D
     CT_LAUNCH_CHECK("ct_fp4_unpack_dequant");
+}
+
+static int fp4_prim(const void* x, int xdt, void* out, int64_t n, int mode, ct_stream_t stream, const char* what) {
+    CT_REQUIRE(is_float_dt(xdt), "%s: dtype code %d is not a float type", what, xdt);
+    CT_REQUIRE(n >= 0, "%s: negative size", what);
+    CT_REQUIRE(aligned16(x) && aligned16(out), "%s: buffers must be 16-byte aligned", what);
+    if (n == 0) return CT_OK;
+    const int64_t units = cdiv64(n, 8);
+    CT_REQUIRE(cdiv64(units, kBlock) < ((int64_t)1 << 31), "%s: tensor too large for one launch", what);
+    dim3 grid((unsigned)cdiv64(units, kBlock));
+#define CT_FP4P(DT) do { if (mode == 0) hipLaunchKernelGGL((fp4_prim_kernel<DT, 0>), grid, dim3(kBlock), 0, as_stream(stream), x, out, n); \
+                         else hipLaunchKernelGGL((fp4_prim_kernel<DT, 1>), grid, dim3(kBlock), 0, as_stream(stream), x, out, n); } while (0)
+    switch (xdt) {
+        case CT_BF16: CT_FP4P(CT_BF16); break;
+        case CT_F16: CT_FP4P(CT_F16); break;
+        default: CT_FP4P(CT_F32); break;
+    }
+#undef CT_FP4P
+    CT_LAUNCH_CHECK(what);
+}
+
+int ct_fp4_cast(const void* x, int xdt, void* out, int64_t n, ct_stream_t stream) { return fp4_prim(x, xdt, out, n, 0, stream, "ct_fp4_cast"); }
+
+int ct_fp4_pack(const void* x, int xdt, uint8_t* packed, int64_t n, ct_stream_t stream) {
+    CT_REQUIRE(n % 2 == 0, "tensor must have an even number of columns for nvfp4 compression");
+    return fp4_prim(x, xdt, packed, n, 1, stream, "ct_fp4_pack");
+}
+
+int ct_fp4_unpack(const uint8_t* packed, int64_t n, void* out, int odt, ct_stream_t stream) {
+    CT_REQUIRE(is_float_dt(odt), "ct_fp4_unpack: dtype code %d is not a float type", odt);
+    CT_REQUIRE(n >= 0 && n % 2 == 0, "ct_fp4_unpack: element count must be even and non-negative");
+    CT_REQUIRE(aligned16(packed) && aligned16(out), "ct_fp4_unpack: buffers must be 16-byte aligned");
+    if (n == 0) return CT_OK;
+    const int64_t units = cdiv64(n, 8);
+    CT_REQUIRE(cdiv64(units, kBlock) < ((int64_t)1 << 31), "ct_fp4_unpack: tensor too large for one launch");
+    dim3 grid((unsigned)cdiv64(units, kBlock));
+    switch (odt) {
+        case CT_BF16: hipLaunchKernelGGL((fp4_unpack_kernel<CT_BF16>), grid, dim3(kBlock), 0, as_stream(stream), packed, out, n); break;
+        case CT_F16: hipLaunchKernelGGL((fp4_unpack_kernel<CT_F16>), grid, dim3(kBlock), 0, as_stream(stream), packed, out, n); break;
+        default: hipLaunchKernelGGL((fp4_unpack_kernel<CT_F32>), grid, dim3(kBlock), 0, as_stream(stream), packed, out, n); break;
+    }
+    CT_LAUNCH_CHECK("ct_fp4_unpack");
+}
+
+int ct_selftest_fp4_div(int xdt, uint32_t m_lo, uint32_t m_hi, unsigned long long* mismatches, ct_stream_t stream) {
+    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "ct_selftest_fp4_div: x dtype must be bf16 or fp16");
+    CT_REQUIRE(m_lo <= m_hi && m_hi <= (1u << 23), "ct_selftest_fp4_div: mantissa range must lie in [0, 2^23]");
+    hipError_t e = hipMemsetAsync(mismatches, 0, sizeof(unsigned long long), as_stream(stream));
+    if (e != hipSuccess) return hip_check(e, "ct_selftest_fp4_div memset");
+    if (m_lo == m_hi) return CT_OK;
+    const int64_t n = m_hi - m_lo;
+    int64_t g = cdiv64(n, kBlock);
+    if (g > kCUs * 64) g = kCUs * 64;
+    hipLaunchKernelGGL(selftest_fp4_div_kernel, dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), xdt == CT_BF16 ? 7 : 10, m_lo, m_hi, mismatches);
+    CT_LAUNCH_CHECK("ct_selftest_fp4_div");
 }
 
 }  // extern "C"

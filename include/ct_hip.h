@@ -145,7 +145,7 @@ int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_
 /* ---------------------------------------------------------------------------- FP4 (E2M1) codecs
  * nvfp4-pack-quantized / mxfp4-pack-quantized weight paths (compressors/nvfp4/base.py:68-139,
  * mxfp4/base.py:27-65): quantize(x, scale, global_scale) -> cast_to_fp4 -> pack_fp4_to_uint8 fused, and the
- * inverse.  group: 16 (nvfp4) or 32 (mxfp4); cols % 32 == 0.  global_scale: device float32[1] or NULL.
+ * inverse.  group: 16 (nvfp4) or 32 (mxfp4); cols % group == 0.  global_scale: device float32[1] or NULL.
  * packed: uint8 (rows, cols/2), element 2i in the low nibble of byte i.
  * compress: scale is the float scale tensor (rows, cols/group) the reference passes to quantize().
  * decompress: scale_kind 0 = float tensor of dtype sdt, 1 = the stored fp8-e4m3fn bytes (nvfp4), 2 = the stored
@@ -155,6 +155,22 @@ int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const 
 int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind,
                           int sdt, const float* global_scale, int64_t group, void* out, int odt,
                           ct_stream_t stream);
+
+/* The stand-alone primitives the reference exposes as ImplBackend entry points (utils/impl_backend.py:50-79):
+ * cast_to_fp4 (quantization/utils/fp4_utils.py:77-98): n float elements -> the nearest E2M1 value in the same
+ *   dtype; ties as upstream's thresholds, -0.0 -> +0.0, negative-rounds-to-zero -> -0.0, NaN -> NaN.
+ * pack_fp4_to_uint8 (compressors/nvfp4/helpers.py:108-150): n (even) E2M1-valued elements -> n / 2 bytes,
+ *   bit 3 of a nibble = the IEEE sign bit.  Values off the E2M1 grid are rounded to it (upstream leaves them
+ *   undefined).
+ * unpack_fp4_from_uint8 (helpers.py:153-193): n / 2 bytes -> n elements of dtype odt; code 8 -> -0.0. */
+int ct_fp4_cast(const void* x, int xdt, void* out, int64_t n, ct_stream_t stream);
+int ct_fp4_pack(const void* x, int xdt, uint8_t* packed, int64_t n, ct_stream_t stream);
+int ct_fp4_unpack(const uint8_t* packed, int64_t n, void* out, int odt, ct_stream_t stream);
+
+/* Proof obligation of ct_fp4_quant_pack's reciprocal quotient (ct_fp4.hip): counts the (x, s) pairs, s = 1.m for
+ * every 23-bit mantissa m in [m_lo, m_hi) and x = every mantissa of dtype xdt (CT_BF16 / CT_F16) in [1, 2), for which
+ * it differs from the IEEE fp32 quotient.  *mismatches (device uint64) must come back 0. */
+int ct_selftest_fp4_div(int xdt, uint32_t m_lo, uint32_t m_hi, unsigned long long* mismatches, ct_stream_t stream);
 
 /* ---------------------------------------------------------------------------- sparse codecs
  * The compressor classes for these formats were removed from the reference snapshot

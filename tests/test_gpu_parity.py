@@ -699,3 +699,75 @@ def test_fp4_format_inference_and_errors(cta, dev):
     assert infer_module_format(torch.nn.Linear, _fp4_scheme(cta, "mxfp4-pack-quantized")).value == "mxfp4-pack-quantized"
     with pytest.raises(ValueError):
         cta.codec.fp4_quantize_and_pack(torch.zeros((2, 31), dtype=BF16, device=dev), torch.ones((2, 1), dtype=BF16, device=dev), None, group_size=32)
+
+
+def test_fp4_primitives_golden(golden, cta, dev):
+    """cast_to_fp4 / pack_fp4_to_uint8 / unpack_fp4_from_uint8 / E8M0 scales against the reference's own outputs"""
+    t = golden.tensors("fp4")
+    for dt in ("torch.float32", "torch.bfloat16", "torch.float16"):
+        x, ref = t[f"cast_{dt}.in"], t[f"cast_{dt}.out"]
+        got = cta.codec.cast_to_fp4(d(x, dev)).cpu()
+        assert got.dtype == ref.dtype and torch.equal(got, ref) and torch.equal(torch.signbit(got), torch.signbit(ref))
+    assert torch.equal(cta.codec.pack_fp4_to_uint8(d(t["pack.in"], dev)).cpu(), t["pack.out"])
+    m, n = t["unpack.out"].shape
+    un = cta.codec.unpack_fp4_from_uint8(d(t["pack.out"], dev), m, n, dtype=t["unpack.out"].dtype).cpu()
+    assert torch.equal(un, t["unpack.out"]) and torch.equal(torch.signbit(un), torch.signbit(t["unpack.out"]))
+    assert torch.equal(cta.codec.compress_mx_scale(d(t["e8m0.in"], dev)).cpu(), t["e8m0.out"])
+    assert torch.equal(cta.codec.decompress_mx_scale(d(t["e8m0.out"], dev)).cpu(), t["e8m0.back"])
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32])
+def test_fp4_primitives_vs_oracle(cta, dev, dtype):
+    """every 16-bit pattern (NaNs included for the cast), float32 neighbours of every rounding threshold, ragged sizes"""
+    if dtype == F32:
+        th = torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 6.0, 0.0, 1e-45, 3e38], dtype=F32)
+        x = torch.cat([torch.nextafter(th, torch.full_like(th, 10.0)), th, torch.nextafter(th, torch.full_like(th, -10.0))])
+        x = torch.cat([x, -x, torch.tensor([float("inf"), -float("inf"), float("nan"), -0.0]), torch.randn(4097) * 3])
+    else:
+        x = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dtype)
+    for n in (x.numel(), 1, 7, 9, 1001):
+        xs = x[:n].contiguous()
+        got = cta.codec.cast_to_fp4(d(xs, dev)).cpu()
+        ref = O.cast_to_fp4(xs)
+        nan = torch.isnan(xs)
+        assert torch.equal(torch.isnan(got), nan)
+        assert torch.equal(got[~nan], ref[~nan]) and torch.equal(torch.signbit(got[~nan]), torch.signbit(ref[~nan]))
+    vals = O.cast_to_fp4(x[~torch.isnan(x)])
+    for cols in (2, 6, 8, 30, 1024):
+        v = vals[: (vals.numel() // cols) * cols].reshape(-1, cols).contiguous()
+        packed = cta.codec.pack_fp4_to_uint8(d(v, dev))
+        assert torch.equal(packed.cpu(), O.pack_fp4(O.fp4_nibbles_of_values(v)))
+        for odt in (BF16, F16, F32):
+            un = cta.codec.unpack_fp4_from_uint8(packed, v.shape[0], cols, dtype=odt).cpu()
+            assert un.dtype == odt and torch.equal(un, v.to(odt)) and torch.equal(torch.signbit(un), torch.signbit(v))
+    with pytest.raises(ValueError):
+        cta.codec.pack_fp4_to_uint8(torch.zeros((2, 3), dtype=dtype, device=dev))
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_fp4_reciprocal_quotient_is_exact(cta, dev, xdt):
+    """all 2^23 scale mantissas x all weight mantissas: the shared-reciprocal quotient == the IEEE fp32 divide"""
+    assert cta.codec.selftest_fp4_div(xdt) == 0
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_fp4_quotient_range_guards(cta, dev, xdt):
+    """effective scales on both sides of the fast-path ranges, tiny / huge / subnormal weights, non-power-of-two MX
+    scales: every branch of the quotient against the oracle"""
+    x = _all_16bit(xdt)
+    n = (x.numel() // 32) * 32
+    x = x[:n].reshape(-1, 32).contiguous()
+    rows = x.shape[0]
+    g = torch.Generator().manual_seed(5)
+    for gsval in (2.0 ** -30, 2.0 ** -19.5, 2.0 ** -9, 1.0, 2.0 ** 12, 2.0 ** 21, 3e30):  # s_eff = s / gs sweeps 2^-40 .. 2^40
+        s = (torch.rand((rows, 2), generator=g) * 3 + 0.5).to(torch.float8_e4m3fn).to(torch.float32)
+        gs = torch.tensor([gsval], dtype=torch.float32)
+        got = cta.codec.fp4_quantize_and_pack(d(x, dev), d(s, dev), d(gs, dev), group_size=16)
+        assert torch.equal(got.cpu(), O.fp4_compress(x, s, gs, fmt="nvfp4-pack-quantized")["weight_packed"]), gsval
+    for sdt in (xdt, F32):  # in-dtype quotient and float32 quotient; powers of two and not
+        lo, hi = (-14, 15) if sdt == F16 else (-110, 110)
+        e = torch.randint(lo, hi, (rows, 1), generator=g).double()
+        for mant in (1.0, 1.5):
+            s = (mant * torch.exp2(e)).to(sdt)
+            got = cta.codec.fp4_quantize_and_pack(d(x, dev), d(s, dev), None, group_size=32)
+            assert torch.equal(got.cpu(), O.fp4_compress(x, s, None, fmt="mxfp4-pack-quantized")["weight_packed"]), (sdt, mant)
