@@ -7,10 +7,10 @@ After this, every upstream caller that looks a codec up by its format string
 (`BaseCompressor.get_value_from_registry(...)`: compress_module / decompress_module,
 ModelCompressor, transformers' DecompressExperts, CompressedTensorsDequantizer) receives a
 subclass of the upstream codec whose `compress` / `decompress` run the HIP kernels whenever
-the weight lives on the GPU; anything else (CPU tensors, FP8/FP4 types, meta tensors) is handed
-to the upstream implementation it inherits from.  `_quantize` is additionally registered as an
-`ImplBackend` backend (upstream utils/impl_backend.py:50-79), which is the reference's own
-plug-in point for that function.
+the weight lives on the GPU; anything else (CPU tensors, FP8 types, meta tensors) is handed
+to the upstream implementation it inherits from.  `_quantize`, `pack_fp4_to_uint8` and `cast_to_fp4`
+are additionally registered as `ImplBackend` backends (upstream utils/impl_backend.py:50-79), which
+is the reference's own plug-in point for those functions.
 
 The registry is overwritten directly because re-registering a name with a different class
 raises upstream (registry/registry.py:215-223); see SURVEY.md §8b.
@@ -34,6 +34,17 @@ def _int_weights(scheme) -> bool:
     return w is not None and enum_value(getattr(w, "type", "int")) == "int" and 1 <= int(w.num_bits) <= 8
 
 
+def _fp4_weights(scheme) -> bool:
+    w = getattr(scheme, "weights", None)
+    return w is not None and enum_value(getattr(w, "type", "int")) == "float" and int(w.num_bits) == 4
+
+
+def _fp4_compressible(state_dict, group) -> bool:
+    w = state_dict.get("weight")
+    return (w is not None and w.is_cuda and w.dim() == 2 and w.dtype in (torch.bfloat16, torch.float16)
+            and w.shape[1] % group == 0)
+
+
 def install():
     import compressed_tensors  # the upstream package; ImportError if it is not installed
     from compressed_tensors.compressors import BaseCompressor
@@ -45,18 +56,32 @@ def install():
 
     table = up_registry._REGISTRY[BaseCompressor]
 
+    from .compressors.fp4 import MXFP4PackedCompressor as _AmdMXFP4
+    from .compressors.fp4 import NVFP4PackedCompressor as _AmdNVFP4
+
     def subclass(up_cls, amd_cls, name):
+        fp4_group = getattr(amd_cls, "GROUP", None)  # set on the FP4 codecs only
+
         class _Hip(up_cls):  # inherits can_compress / compression_param_names / *_module
             @classmethod
             def compress(cls, state_dict, scheme):
-                if _int_weights(scheme) and _on_gpu(state_dict.get("weight")):
+                if fp4_group is not None:
+                    ours = _fp4_weights(scheme) and _fp4_compressible(state_dict, fp4_group)
+                else:
+                    ours = _int_weights(scheme) and _on_gpu(state_dict.get("weight"))
+                if ours and fp4_group is not None:
+                    return amd_cls.compress(state_dict, scheme)  # uses the FP4 class's own scale hooks
+                if ours:
                     return amd_cls.compress.__func__(cls, state_dict, scheme)
                 return up_cls.compress.__func__(cls, state_dict, scheme)
 
             @classmethod
             def decompress(cls, state_dict, scheme):
                 probe = state_dict.get("weight_packed", state_dict.get("weight"))
-                if _int_weights(scheme) and _on_gpu(probe):
+                ours = _fp4_weights(scheme) if fp4_group is not None else _int_weights(scheme)
+                if ours and _on_gpu(probe) and fp4_group is not None:
+                    return amd_cls.decompress(state_dict, scheme)
+                if ours and _on_gpu(probe):
                     return amd_cls.decompress.__func__(cls, state_dict, scheme)
                 return up_cls.decompress.__func__(cls, state_dict, scheme)
 
@@ -64,7 +89,10 @@ def install():
         _Hip.__qualname__ = _Hip.__name__
         return _Hip
 
-    for fmt, amd_cls in (("pack-quantized", _AmdPacked), ("naive-quantized", _AmdNaive), ("int-quantized", _AmdNaive)):
+    for fmt, amd_cls in (("pack-quantized", _AmdPacked), ("naive-quantized", _AmdNaive), ("int-quantized", _AmdNaive),
+                         ("nvfp4-pack-quantized", _AmdNVFP4), ("mxfp4-pack-quantized", _AmdMXFP4)):
+        if fmt not in table and fmt not in _SAVED:
+            continue  # an older upstream without the FP4 codecs
         up_cls = table[fmt]
         if fmt not in _SAVED:
             _SAVED[fmt] = up_cls
@@ -90,6 +118,19 @@ def install():
                 dtype=dtype if dtype is not None else torch.result_type(x, scale),
             )
             return out.reshape(x.shape)
+
+    _floats = (torch.float32, torch.float16, torch.bfloat16)
+    if "pack_fp4_to_uint8_mi355x" not in ImplBackend._fn_registry:
+
+        @ImplBackend.register("pack_fp4_to_uint8", req=lambda x: x.is_cuda and x.dim() == 2 and x.dtype in _floats and x.shape[1] % 2 == 0, priority=0)
+        def pack_fp4_to_uint8_mi355x(x):
+            return codec.pack_fp4_to_uint8(x)
+
+    if "cast_to_fp4_mi355x" not in ImplBackend._fn_registry:
+
+        @ImplBackend.register("cast_to_fp4", req=lambda x: x.is_cuda and x.dtype in _floats, priority=0)
+        def cast_to_fp4_mi355x(x):
+            return codec.cast_to_fp4(x)
 
     return compressed_tensors
 

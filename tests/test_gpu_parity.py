@@ -771,3 +771,36 @@ def test_fp4_quotient_range_guards(cta, dev, xdt):
             s = (mant * torch.exp2(e)).to(sdt)
             got = cta.codec.fp4_quantize_and_pack(d(x, dev), d(s, dev), None, group_size=32)
             assert torch.equal(got.cpu(), O.fp4_compress(x, s, None, fmt="mxfp4-pack-quantized")["weight_packed"]), (sdt, mant)
+
+
+@pytest.mark.parametrize("fmt,group", [("nvfp4-pack-quantized", 16), ("mxfp4-pack-quantized", 32)])
+def test_fp4_model_compressor_roundtrip(cta, dev, fmt, group):
+    """ModelCompressor infers the FP4 format per module, compresses, and the first forward decompresses"""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 512, bias=False), torch.nn.ReLU(), torch.nn.Linear(512, 128, bias=False)).to(dev).to(BF16)
+    expect = {}
+    for name, m in model.named_modules():
+        if not isinstance(m, torch.nn.Linear):
+            continue
+        m.quantization_scheme = _fp4_scheme(cta, fmt)
+        w = m.weight.data.cpu()
+        amax = w.float().reshape(w.shape[0], -1, group).abs().amax(-1).clamp(min=1e-4)
+        if fmt.startswith("nvfp4"):
+            gs = torch.tensor([448.0 * 6.0 / float(amax.max())], dtype=torch.float32)
+            s = (gs * amax / 6.0).to(torch.float8_e4m3fn).to(torch.float32)
+            m.register_parameter("weight_global_scale", torch.nn.Parameter(gs.to(dev), requires_grad=False))
+        else:
+            gs, s = None, torch.exp2(torch.floor(torch.log2(amax)) - 2).to(BF16)
+        m.register_parameter("weight_scale", torch.nn.Parameter(s.to(dev), requires_grad=False))
+        expect[name] = O.fp4_decompress(O.fp4_compress(w, s, gs, fmt=fmt), fmt=fmt)["weight"]
+    mc = cta.ModelCompressor()
+    mc.compress_model(model)
+    for m in model:
+        if isinstance(m, torch.nn.Linear):
+            assert m.weight_packed.dtype == torch.uint8 and m.quantization_scheme.format.value == fmt
+            assert m.weight_scale.dtype == (torch.float8_e4m3fn if fmt.startswith("nvfp4") else torch.uint8)
+    y = model(torch.randn(4, 256, device=dev, dtype=BF16))
+    assert y.shape == (4, 128)
+    for name, m in model.named_modules():
+        if isinstance(m, torch.nn.Linear):
+            assert eq(m.weight.data.cpu(), expect[name]) and m.weight_scale.dtype == BF16

@@ -95,3 +95,37 @@ def test_amd_scheme_objects_are_duck_compatible_with_upstream(upstream):
     assert out.keys() == ref.keys()
     for k in out:
         assert out[k].shape == ref[k].shape and out[k].dtype == ref[k].dtype and out[k].device.type == ref[k].device.type, k
+
+
+def test_install_covers_the_fp4_codecs(upstream):
+    """nvfp4 / mxfp4 registry entries are swapped too and the FP4 primitives get ImplBackend backends; CPU inputs
+    still take upstream's own code"""
+    ct, ct_amd = upstream
+    from compressed_tensors.compressors import BaseCompressor
+    from compressed_tensors.compressors.nvfp4.helpers import pack_fp4_to_uint8
+    from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme
+    from compressed_tensors.utils.impl_backend import ImplBackend
+
+    fmts = ("nvfp4-pack-quantized", "mxfp4-pack-quantized")
+    before = {f: BaseCompressor.get_value_from_registry(f) for f in fmts}
+    ct_amd.install()
+    for f in fmts:
+        after = BaseCompressor.get_value_from_registry(f)
+        assert after is not before[f] and issubclass(after, before[f])
+    assert {"pack_fp4_to_uint8_mi355x", "cast_to_fp4_mi355x"} <= set(ImplBackend._fn_registry)
+    assert [fn.__name__ for fn, _, _ in ImplBackend._backends["pack_fp4_to_uint8"]] == ["pack_fp4_to_uint8_mi355x"]
+
+    torch.manual_seed(0)
+    w = torch.randn(8, 64, dtype=torch.bfloat16)
+    s = torch.exp2(torch.floor(torch.log2(w.float().reshape(8, 2, 32).abs().amax(-1))) - 2).to(torch.bfloat16)
+    args = QuantizationArgs(num_bits=4, type="float", strategy="group", group_size=32, symmetric=True, scale_dtype=torch.uint8, zp_dtype=torch.uint8)
+    scheme = QuantizationScheme(targets=["Linear"], weights=args)
+    sd = {"weight": w, "weight_scale": s}
+    ref = before["mxfp4-pack-quantized"].compress(sd, scheme)
+    got = BaseCompressor.get_value_from_registry("mxfp4-pack-quantized").compress(sd, scheme)
+    assert ref.keys() == got.keys() and all(torch.equal(ref[k], got[k]) for k in ref)
+    vals = torch.tensor([[0.5, -6.0, 0.0, -0.0]], dtype=torch.bfloat16)
+    assert pack_fp4_to_uint8(vals).tolist() == [[0xF1, 0x80]]  # CPU tensor: the backend's req fails, upstream's body runs
+    ct_amd.uninstall()
+    for f in fmts:
+        assert BaseCompressor.get_value_from_registry(f) is before[f]
