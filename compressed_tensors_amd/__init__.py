@@ -13,6 +13,7 @@ from .compressors import (
     Marlin24Compressor,
     ModelCompressor,
     MXFP4PackedCompressor,
+    MXFP8QuantizationCompressor,
     NVFP4PackedCompressor,
     NaiveQuantizationCompressor,
     PackedQuantizationCompressor,
@@ -48,6 +49,7 @@ __all__ = [
     "Marlin24Compressor",
     "NVFP4PackedCompressor",
     "MXFP4PackedCompressor",
+    "MXFP8QuantizationCompressor",
     "CompressionFormat",
     "SparsityStructure",
     "QuantizationArgs",

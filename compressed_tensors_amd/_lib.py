@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libct_hip.so")
 
 # element type codes of include/ct_hip.h
-F32, F16, BF16, I8, I32, U8, I16, I64 = range(8)
+F32, F16, BF16, I8, I32, U8, I16, I64, F8 = range(9)
 DT = {
     torch.float32: F32,
     torch.float16: F16,
@@ -27,9 +27,10 @@ DT = {
     torch.int16: I16,
     torch.int64: I64,
 }
-for _name in ("float8_e4m3fn", "float8_e5m2"):
-    if hasattr(torch, _name):
-        DT[getattr(torch, _name)] = I8  # fp8 payloads travel as raw bytes through the copy codecs
+if hasattr(torch, "float8_e4m3fn"):
+    DT[torch.float8_e4m3fn] = F8  # FLOAT 8-bit quantization type (the copy codecs view fp8 payloads as raw bytes first)
+if hasattr(torch, "float8_e5m2"):
+    DT[torch.float8_e5m2] = I8  # raw bytes only
 
 CT_OK, CT_ERR_INVALID_ARG, CT_ERR_UNSUPPORTED, CT_ERR_HIP = range(4)
 
@@ -47,6 +48,8 @@ _PROTOTYPES = {
     "ct_quantize": (_Q + [_I, _I, _P, _I, _S], _I),
     "ct_dequantize": (_Q + [_P, _I, _S], _I),
     "ct_fake_quantize": (_Q + [_I, _I, _P, _I, _S], _I),
+    "ct_quantize_fp8": (_Q + [_I, _P, _I, _S], _I),
+    "ct_fake_quantize_fp8": (_Q + [_I, _P, _I, _S], _I),
     "ct_quant_pack": (_Q + [_I, _I, _P, _S], _I),
     "ct_unpack_dequant": ([_P, _L, _L, _L, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _I, _S], _I),
     "ct_w4_batch_plan": ([_P, _I, _I], _L),

@@ -254,32 +254,51 @@ def _check_sz(layout: QuantLayout, scale, zp):
         raise ValueError(f"zero_point shape {tuple(zp.shape)} does not match scale shape {tuple(scale.shape)}")
 
 
+_F8 = torch.float8_e4m3fn
+
+
+def _check_qtype(qtype, num_bits):
+    qtype = getattr(qtype, "value", qtype)
+    if qtype not in ("int", "float"):
+        raise ValueError(f"Invalid quantization type {qtype}")
+    if qtype == "float" and int(num_bits) != 8:
+        raise NotImplementedError("FLOAT quantization through quantize()/fake_quantize() is 8-bit (float8_e4m3fn); the 4-bit "
+                                  "formats have their own fused codecs (fp4_quantize_and_pack)")
+    return qtype
+
+
 def quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-                    dtype=None, g_idx=None) -> torch.Tensor:
-    """quantization/lifecycle/forward.py:36-73 for INT types: returns `dtype` (int8/int32 or a
-    float type) or, when dtype is None, x.dtype for group strategies and the promoted type
-    otherwise."""
+                    dtype=None, g_idx=None, qtype="int") -> torch.Tensor:
+    """quantization/lifecycle/forward.py:36-73: returns `dtype` (int8/int32, float8_e4m3fn for FLOAT args, or a float
+    type) or, when dtype is None, x.dtype for group strategies and the promoted type otherwise.  qtype "float" is the
+    8-bit FLOAT type: clamp to +-448 and round to float8_e4m3fn instead of rint."""
+    qtype = _check_qtype(qtype, num_bits)
     _check_float(x, "x")
     _check_float(scale, "scale")
     layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
     _check_sz(layout, scale, zero_point)
     T = _result_dtype(x, scale, layout.scale_zero_dim)
     out_dtype = dtype if dtype is not None else (x.dtype if layout.is_group else T)
-    if out_dtype not in (torch.int8, torch.int32, *_FLOATS):
-        raise NotImplementedError(f"quantize to {out_dtype} is not supported by the MI355X path")
+    if out_dtype not in ((_F8, *_FLOATS) if qtype == "float" else (torch.int8, torch.int32, *_FLOATS)):
+        raise NotImplementedError(f"quantize ({qtype}) to {out_dtype} is not supported by the MI355X path")
     dev = _compute_device(x, scale)
     xd, sd = _dev(x, dev), _dev(scale, dev)
     zd, zdt = _zp_arg(zero_point, dev)
     out = torch.empty(x.shape, dtype=out_dtype, device=dev)
     largs, _keep = layout.args(dev)
-    call("ct_quantize", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
-         ptr(out), DT[out_dtype], stream_of(xd))
+    if qtype == "float":
+        call("ct_quantize_fp8", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, DT[T],
+             ptr(out), DT[out_dtype], stream_of(xd))
+    else:
+        call("ct_quantize", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
+             ptr(out), DT[out_dtype], stream_of(xd))
     return _home(out, x)
 
 
 def fake_quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-                         g_idx=None) -> torch.Tensor:
-    """quantization/lifecycle/forward.py:148-181 (forward_helpers.py:180-215) for INT types."""
+                         g_idx=None, qtype="int") -> torch.Tensor:
+    """quantization/lifecycle/forward.py:148-181 (forward_helpers.py:180-215); qtype as in quantize_tensor."""
+    qtype = _check_qtype(qtype, num_bits)
     _check_float(x, "x")
     _check_float(scale, "scale")
     layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
@@ -291,8 +310,12 @@ def fake_quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size
     zd, zdt = _zp_arg(zero_point, dev)
     out = torch.empty(x.shape, dtype=out_dtype, device=dev)
     largs, _keep = layout.args(dev)
-    call("ct_fake_quantize", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
-         ptr(out), DT[out_dtype], stream_of(xd))
+    if qtype == "float":
+        call("ct_fake_quantize_fp8", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, DT[T],
+             ptr(out), DT[out_dtype], stream_of(xd))
+    else:
+        call("ct_fake_quantize", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, int(num_bits), DT[T],
+             ptr(out), DT[out_dtype], stream_of(xd))
     return _home(out, x)
 
 
@@ -300,7 +323,7 @@ def dequantize_tensor(x_q, scale, zero_point=None, *, strategy=None, group_size=
                       dtype=None, g_idx=None) -> torch.Tensor:
     """quantization/lifecycle/forward.py:76-145 (forward_helpers.py:549-572)."""
     _check_float(scale, "scale")
-    if x_q.dtype not in (torch.int8, torch.int32, *_FLOATS):
+    if x_q.dtype not in (torch.int8, torch.int32, _F8, *_FLOATS):
         raise NotImplementedError(f"dequantize from {x_q.dtype} is not supported by the MI355X path")
     if strategy is None:
         strategy, group_size, block_structure = infer_dequant_layout(x_q.shape, scale)

@@ -3,6 +3,7 @@ from .dense import DenseCompressor
 from .fp4 import MXFP4PackedCompressor, NVFP4PackedCompressor
 from .format import infer_model_format, infer_module_format
 from .model_compressors import ModelCompressor
+from .mxfp8 import MXFP8QuantizationCompressor
 from .naive_quantized import FloatQuantizationCompressor, IntQuantizationCompressor, NaiveQuantizationCompressor
 from .pack_quantized import PackedQuantizationCompressor, pack_to_int32, unpack_from_int32
 from .sparse import (
@@ -35,4 +36,5 @@ __all__ = [
     "Marlin24Compressor",
     "NVFP4PackedCompressor",
     "MXFP4PackedCompressor",
+    "MXFP8QuantizationCompressor",
 ]

@@ -4,9 +4,10 @@ from ..quantization.utils import is_module_quantized
 
 __all__ = ["infer_module_format", "infer_model_format", "COMPRESSION_FORMAT_PRIORITY"]
 
-# more specific formats first (format.py:18-27; mxfp8-quantized is not part of this package's path)
+# more specific formats first (format.py:18-27)
 COMPRESSION_FORMAT_PRIORITY = [
     CompressionFormat.mxfp4_pack_quantized,
+    CompressionFormat.mxfp8_quantized,
     CompressionFormat.nvfp4_pack_quantized,
     CompressionFormat.int_quantized,
     CompressionFormat.pack_quantized,

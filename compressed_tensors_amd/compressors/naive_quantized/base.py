@@ -1,7 +1,7 @@
 """naive-quantized / int-quantized / float-quantized codecs
 (reference compressors/naive_quantized/base.py:27-164).  INT weights are quantized to int8 by
-the HIP quantize kernel and dequantized by the HIP dequantize kernel; FLOAT (fp8) weights are
-outside this package's scope and raise."""
+the HIP quantize kernel and dequantized by the HIP dequantize kernel; FLOAT 8-bit weights become
+float8_e4m3fn through the same kernels (clamp to +-448, v_cvt_pk_fp8_f32)."""
 from ... import codec
 from ...config import CompressionFormat
 from ...quantization.quant_args import enum_value
@@ -32,10 +32,8 @@ class NaiveQuantizationCompressor(BaseCompressor):
         zero_point = state_dict.get("weight_zero_point", None)
         g_idx = state_dict.get("weight_g_idx", None)
         weights = scheme.weights
-        if enum_value(getattr(weights, "type", "int")) != "int":
-            raise NotImplementedError("FLOAT (fp8) naive quantization is not on the MI355X hot path")
         state_dict["weight"] = codec.quantize_tensor(
-            weight, scale, zero_point,
+            weight, scale, zero_point, qtype=enum_value(getattr(weights, "type", "int")),
             num_bits=int(weights.num_bits), strategy=enum_value(weights.strategy),
             group_size=getattr(weights, "group_size", None), block_structure=getattr(weights, "block_structure", None),
             dtype=weights.pytorch_dtype(), g_idx=g_idx,

@@ -44,7 +44,7 @@ inline int dt_size(int dt) {
     switch (dt) {
         case CT_F32: case CT_I32: return 4;
         case CT_F16: case CT_BF16: case CT_I16: return 2;
-        case CT_I8: case CT_U8: return 1;
+        case CT_I8: case CT_U8: case CT_F8E4M3: return 1;
         case CT_I64: return 8;
     }
     return 0;
@@ -93,6 +93,17 @@ __device__ __forceinline__ uint32_t f_to_f16_bits(float v) {
     return (uint32_t)__builtin_bit_cast(uint16_t, (f16_t)v);
 }
 
+// float8_e4m3fn <-> float: gfx950's conversions are the OCP ones (RNE, subnormals; 0x7f = NaN).  Callers clamp to
+// +-448 first (torch.clamp precedes the cast upstream), so the overflow behaviour of the instruction is never reached.
+__device__ __forceinline__ float fp8_to_f(uint32_t byte) { return __builtin_amdgcn_cvt_f32_fp8((int)byte, 0); }
+__device__ __forceinline__ uint32_t f2_to_fp8x2(float a, float b) {  // two bytes in the low half
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+__device__ __forceinline__ float fp8_round(float t) {  // value of float8(t) for |t| <= 448; NaN stays NaN
+    const float r = fp8_to_f(f2_to_fp8x2(t, 0.0f) & 0xffu);
+    return (t != t) ? t : r;
+}
+
 // round a float to dtype DT and back: "every torch op rounds to the tensor dtype"
 template <int DT>
 __device__ __forceinline__ float round_to(float v) {
@@ -101,11 +112,30 @@ __device__ __forceinline__ float round_to(float v) {
     else return v;
 }
 
+// rnd_DT(a * b).  For fp16 the product is pinned in a register first: clang otherwise selects
+// v_fma_mixlo_f16 a, b, +0 for "convert the product to half", and (-0.0 * s) + (+0.0) is +0.0 — the sign of a
+// zero product (a -0.0 float8 / FP4 code, or a zero code under a negative scale) would be lost.  The empty asm
+// emits nothing.
+template <int DT>
+__device__ __forceinline__ float mul_round_to(float a, float b) {
+    float p = a * b;
+    if constexpr (DT == CT_F16) asm("" : "+v"(p));
+    return round_to<DT>(p);
+}
+
 __device__ __forceinline__ float round_to_rt(int dt, float v) {
     switch (dt) {
         case CT_BF16: return round_to<CT_BF16>(v);
         case CT_F16: return round_to<CT_F16>(v);
         default: return v;
+    }
+}
+
+__device__ __forceinline__ float mul_round_to_rt(int dt, float a, float b) {
+    switch (dt) {
+        case CT_BF16: return mul_round_to<CT_BF16>(a, b);
+        case CT_F16: return mul_round_to<CT_F16>(a, b);
+        default: return a * b;
     }
 }
 
@@ -120,6 +150,7 @@ __device__ __forceinline__ float load_rt(const void* p, int dt, int64_t i) {
         case CT_U8: return (float)static_cast<const uint8_t*>(p)[i];
         case CT_I16: return (float)static_cast<const int16_t*>(p)[i];
         case CT_I64: return (float)static_cast<const int64_t*>(p)[i];
+        case CT_F8E4M3: return fp8_to_f(static_cast<const uint8_t*>(p)[i]);
     }
     return 0.0f;
 }
@@ -195,6 +226,7 @@ __device__ __forceinline__ void store_rt(void* base, int dt, int64_t i, float v)
         // which is also what the reference's CPU cast produces
         case CT_I8: static_cast<int8_t*>(base)[i] = (int8_t)(int)v; break;
         case CT_I32: static_cast<int32_t*>(base)[i] = (int)v; break;
+        case CT_F8E4M3: static_cast<uint8_t*>(base)[i] = (uint8_t)(f2_to_fp8x2(v, 0.0f) & 0xffu); break;
     }
 }
 

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32
                 }
                 v[2 * j] = p.x * s_eff;
                 v[2 * j + 1] = p.y * s_eff;
+                if constexpr (ODT == CT_F16) { asm("" : "+v"(v[2 * j])); asm("" : "+v"(v[2 * j + 1])); }  // see mul_round_to
             }
             store8<ODT>(out, u * 8, v);  // RNE to the output dtype
         }

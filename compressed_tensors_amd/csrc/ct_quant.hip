@@ -23,6 +23,7 @@ struct QParams {
     QLayout L;
     float qmin, qmax;
     int vec;            // 16-byte vector path allowed (cols % 8 == 0, pointers aligned)
+    int fkind;          // 0: INT codes (rint); 1: FLOAT 8-bit (round to float8_e4m3fn)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -37,25 +38,27 @@ __device__ __forceinline__ float bf16_fast_rcp(float s) {
 
 template <int TDT>
 __device__ __forceinline__ float quant_core(float x, float s, bool has_zp, float zf, float qmin,
-                                            float qmax, float rs = 0.0f) {
+                                            float qmax, float rs = 0.0f, int fkind = 0) {
     float t = round_to<TDT>(rs != 0.0f ? x * rs : x / s);  // IEEE-correct fp32 divide (or the proven bf16 shortcut), RNE to T
     if (has_zp) t = round_to<TDT>(t + zf);
     t = clamp_nan(t, qmin, qmax);
-    return __builtin_rintf(t);  // v_rndne_f32: round half to even
+    // INT: v_rndne_f32 (round half to even).  FLOAT 8-bit: tensor.to(float8_e4m3fn) (quant_args.py:463-486); the
+    // value is exact in every T
+    return fkind ? fp8_round(t) : __builtin_rintf(t);
 }
 
 template <int SDT>
 __device__ __forceinline__ float dequant_core(float q, bool has_zp, float zf, float s) {
     float d = q;
     if (has_zp) d = round_to<SDT>(d - zf);
-    return round_to<SDT>(d * s);
+    return mul_round_to<SDT>(d, s);
 }
 
 // int8 zero point and an int8 code: |q - z| <= 255 is an integer every supported float dtype holds exactly,
 // so the reference's rounding of the difference is the identity and is not issued
 template <int SDT>
 __device__ __forceinline__ float dequant_core_zexact(float q, float zf, float s) {
-    return round_to<SDT>((q - zf) * s);
+    return mul_round_to<SDT>(q - zf, s);
 }
 
 // scale / zero point of element (row, c)
@@ -104,6 +107,12 @@ __device__ __forceinline__ void store_unit(void* out, int odt, int64_t i0, const
                 stream_store8(static_cast<int8_t*>(out) + i0, u32x2{lo, hi});
                 return;
             }
+            case CT_F8E4M3: {
+                const uint32_t lo = f2_to_fp8x2(v[0], v[1]) | (f2_to_fp8x2(v[2], v[3]) << 16);
+                const uint32_t hi = f2_to_fp8x2(v[4], v[5]) | (f2_to_fp8x2(v[6], v[7]) << 16);
+                stream_store8(static_cast<uint8_t*>(out) + i0, u32x2{lo, hi});
+                return;
+            }
             default: break;
         }
     }
@@ -143,13 +152,13 @@ __global__ __launch_bounds__(kBlock) void quant_units_kernel(QParams p) {
             for (int k = 0; k < 8; ++k) {
                 if (k < n) {
                     if (!uni && k > 0) sz = load_sz_q<XDT>(p, srow, c0 + k);
-                    float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax, rs);
+                    float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax, rs, p.fkind);
                     if constexpr (MODE == MODE_FQ) {
                         // dequantize in S = scale dtype (forward_helpers.py:207-215)
                         float zs = has_zp ? round_to_rt(p.sdt, load_rt(p.zp, p.zdt, srow + col_group_of(p.L, c0 + k))) : 0.0f;
                         float d = round_to_rt(p.sdt, t);
                         if (has_zp) d = round_to_rt(p.sdt, d - zs);
-                        t = round_to_rt(p.sdt, d * sz.s);
+                        t = mul_round_to_rt(p.sdt, d, sz.s);
                     }
                     v[k] = t;
                 }
@@ -181,6 +190,13 @@ __global__ __launch_bounds__(kBlock) void dequant_units_kernel(QParams p) {
                 for (int k = 0; k < 4; ++k) {
                     v[k] = (float)(int8_t)(w.x >> (8 * k));
                     v[4 + k] = (float)(int8_t)(w.y >> (8 * k));
+                }
+            } else if (p.vec && n == 8 && p.xdt == CT_F8E4M3) {
+                u32x2 w = *reinterpret_cast<const u32x2*>(static_cast<const uint8_t*>(p.x) + i0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {  // float8 -> S is exact for every S
+                    v[k] = fp8_to_f((w.x >> (8 * k)) & 0xffu);
+                    v[4 + k] = fp8_to_f((w.y >> (8 * k)) & 0xffu);
                 }
             } else {
 #pragma unroll
@@ -701,10 +717,98 @@ __global__ __launch_bounds__(kBlock) void q8_dequant_kernel(W4Params p) {
 }
 
 
+// ------------------------------------------------------------------------------------------
+// FLOAT 8-bit (float-quantized / mxfp8-quantized weights): same flat unit stream as the int8 kernels.
+//   quantize:   lane = 2 units (32 B in, 16 B out): t = rnd_T(x / s) [+ zp], clamp to +-448, v_cvt_pk_fp8_f32
+//   dequantize: lane = UNROLL units one block apart (8 B in, 16 B out each): v_cvt_pk_f32_fp8, (q - z) * s
+// ------------------------------------------------------------------------------------------
+template <int DT, bool FAST, bool ZP>
+__device__ __forceinline__ void f8_quant_words(const u32x4& raw, float s, float rs, float z, uint32_t& lo, uint32_t& hi) {
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    int acc[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float x0, x1;
+        unpack2<DT>(ws[j], x0, x1);
+        float t0 = FAST ? x0 * rs : x0 / s, t1 = FAST ? x1 * rs : x1 / s;
+        round2<DT>(t0, t1);
+        if (ZP) {
+            t0 += z; t1 += z;
+            round2<DT>(t0, t1);
+        }
+        t0 = clamp_nan(t0, -448.0f, 448.0f);
+        t1 = clamp_nan(t1, -448.0f, 448.0f);
+        if (j & 1) acc[j >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(t0, t1, acc[j >> 1], true);
+        else acc[j >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(t0, t1, acc[j >> 1], false);
+    }
+    lo = (uint32_t)acc[0]; hi = (uint32_t)acc[1];
+}
+
+template <int DT, bool HAS_ZP, bool SHARED>
+__global__ __launch_bounds__(kBlock) void f8_quant_kernel(W4Params p) {
+    constexpr int Q = 2;
+    const int64_t groups = p.units / Q;
+    const u32x4* in = static_cast<const u32x4*>(p.x);
+    u32x4* out = static_cast<u32x4*>(p.out);
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        u32x4 r[Q];
+#pragma unroll
+        for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
+        uint32_t w[2 * Q];
+        float s = 0.0f, z = 0.0f, rs = 0.0f;
+        bool fast = false;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            if (i == 0 || !SHARED) {
+                const int64_t si = w4_scale_index(p, g * Q + i);
+                s = load_as_f<DT>(p.scale, si);
+                z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+                const float as = __builtin_fabsf(s);
+                fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+                rs = 1.0f / s;
+            }
+            // the zero-point add is kept even for z == 0: it turns a -0.0 quotient into +0.0, as upstream's `+=`
+            if (fast) f8_quant_words<DT, true, HAS_ZP>(r[i], s, rs, z, w[2 * i], w[2 * i + 1]);
+            else f8_quant_words<DT, false, HAS_ZP>(r[i], s, rs, z, w[2 * i], w[2 * i + 1]);
+        }
+        stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+    }
+}
+
+template <int DT, int UNROLL, bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void f8_dequant_kernel(W4Params p) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
+    const u32x2* in = static_cast<const u32x2*>(p.x);
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
+        u32x2 word[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u = base + (int64_t)i * kBlock;
+            if (u < p.units) word[i] = in[u];
+        }
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u = base + (int64_t)i * kBlock;
+            if (u >= p.units) continue;
+            const int64_t si = w4_scale_index(p, u);
+            const float s = load_as_f<DT>(p.scale, si);
+            const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+            const f2 q01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].x, false), q23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].x, true);
+            const f2 q45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].y, false), q67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].y, true);
+            const float q[8] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y};
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = dequant_core<DT>(q[k], HAS_ZP, z, s);
+            store8<DT>(p.out, u * 8, v);
+        }
+    }
+}
+
 // fake_quantize fast path (forward_helpers.py:180-215): x, scale and the result share one 16-bit dtype.
 // Same flat unit stream: lane = UNROLL units one block apart, 16 B in, 16 B out.
 template <int DT, int UNROLL, bool HAS_ZP>
-__global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, float qmax) {
+__global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, float qmax, int fkind) {
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
     const u32x4* in = static_cast<const u32x4*>(p.x);
     for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
@@ -728,7 +832,7 @@ __global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, fl
             for (int j = 0; j < 4; ++j) {
                 float x0, x1;
                 unpack2<DT>(ws[j], x0, x1);
-                const float t0 = quant_core<DT>(x0, s, HAS_ZP, z, qmin, qmax, rs), t1 = quant_core<DT>(x1, s, HAS_ZP, z, qmin, qmax, rs);
+                const float t0 = quant_core<DT>(x0, s, HAS_ZP, z, qmin, qmax, rs, fkind), t1 = quant_core<DT>(x1, s, HAS_ZP, z, qmin, qmax, rs, fkind);
                 v[2 * j] = dequant_core<DT>(t0, HAS_ZP, z, s);
                 v[2 * j + 1] = dequant_core<DT>(t1, HAS_ZP, z, s);
             }
@@ -798,7 +902,7 @@ static dim3 grid_2d(int64_t rows, int64_t items_per_row) {
 
 static bool zdt_ok(int zdt) {
     return zdt == CT_I8 || zdt == CT_I32 || zdt == CT_F32 || zdt == CT_F16 || zdt == CT_BF16 ||
-           zdt == CT_I64 || zdt == CT_U8 || zdt == CT_I16;
+           zdt == CT_I64 || zdt == CT_U8 || zdt == CT_I16 || zdt == CT_F8E4M3;
 }
 
 // valid (xdt, tdt) pairs: T is the promotion of x.dtype with the scale dtype
@@ -841,6 +945,7 @@ static int fill_qparams(QParams& p, const void* x, int xdt, const void* scale, i
     p.qmax = (float)((1 << bits) / 2 - 1);
     p.qmin = -(float)((1 << bits) / 2);
     p.vec = (cols % 8 == 0) && aligned16(x) && aligned16(out);
+    p.fkind = 0;
     return CT_OK;
 }
 
@@ -898,22 +1003,25 @@ using namespace ct;
 
 extern "C" {
 
-int ct_quantize(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
-                int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
-                int bits, int tdt, void* out, int odt, ct_stream_t stream) {
+static int quantize_impl(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                         int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                         int bits, int fkind, int tdt, void* out, int odt, ct_stream_t stream) {
     CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
     CT_REQUIRE(xt_ok(xdt, tdt), "unsupported (x dtype, result dtype) = (%d, %d)", xdt, tdt);
-    CT_REQUIRE(odt == CT_I8 || odt == CT_I32 || is_float_dt(odt), "unsupported output dtype %d", odt);
+    if (fkind) CT_REQUIRE(odt == CT_F8E4M3 || is_float_dt(odt), "unsupported output dtype %d", odt);
+    else CT_REQUIRE(odt == CT_I8 || odt == CT_I32 || is_float_dt(odt), "unsupported output dtype %d", odt);
     QParams p;
     int rc = fill_qparams(p, x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, out, odt);
     if (rc) return rc;
+    if (fkind) { p.fkind = 1; p.qmin = -448.0f; p.qmax = 448.0f; }  // torch.finfo(float8_e4m3fn) (helpers.py:212-214)
     if (rows == 0 || cols == 0) return CT_OK;
-    if (odt == CT_I8 && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, out)) {
+    if ((fkind ? odt == CT_F8E4M3 : odt == CT_I8) && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         const bool shared = (cdiv % 16 == 0) || cdiv >= cols;
         dim3 g8(w4_grid(w.units / 2, 1));
         const int qmin = -(1 << (bits - 1)), qmax = (1 << (bits - 1)) - 1;
-#define CT_Q8Q(DT, ZP, SH) hipLaunchKernelGGL((q8_quant_kernel<DT, ZP, SH, 0>), g8, dim3(kBlock), 0, as_stream(stream), w, qmin, qmax)
+#define CT_Q8Q(DT, ZP, SH) do { if (fkind) hipLaunchKernelGGL((f8_quant_kernel<DT, ZP, SH>), g8, dim3(kBlock), 0, as_stream(stream), w); \
+                                else hipLaunchKernelGGL((q8_quant_kernel<DT, ZP, SH, 0>), g8, dim3(kBlock), 0, as_stream(stream), w, qmin, qmax); } while (0)
         if (xdt == CT_BF16) {
             if (zp) { if (shared) CT_Q8Q(CT_BF16, true, true); else CT_Q8Q(CT_BF16, true, false); }
             else { if (shared) CT_Q8Q(CT_BF16, false, true); else CT_Q8Q(CT_BF16, false, false); }
@@ -922,29 +1030,30 @@ int ct_quantize(const void* x, int xdt, const void* scale, int sdt, const void* 
             else { if (shared) CT_Q8Q(CT_F16, false, true); else CT_Q8Q(CT_F16, false, false); }
         }
 #undef CT_Q8Q
-        CT_LAUNCH_CHECK("ct_quantize[q8]");
+        CT_LAUNCH_CHECK("ct_quantize[flat8]");
     }
     dim3 grid = grid_2d(rows, cdiv64(cols, 8));
     CT_DISPATCH_XT(xdt, tdt, hipLaunchKernelGGL((quant_units_kernel<X, T, MODE_Q>), grid, dim3(kBlock), 0, as_stream(stream), p));
     CT_LAUNCH_CHECK("ct_quantize");
 }
 
-int ct_fake_quantize(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
-                     int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
-                     int bits, int tdt, void* out, int odt, ct_stream_t stream) {
+static int fake_quantize_impl(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                              int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                              int bits, int fkind, int tdt, void* out, int odt, ct_stream_t stream) {
     CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
     CT_REQUIRE(xt_ok(xdt, tdt), "unsupported (x dtype, result dtype) = (%d, %d)", xdt, tdt);
     CT_REQUIRE(is_float_dt(odt), "unsupported output dtype %d", odt);
     QParams p;
     int rc = fill_qparams(p, x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, out, odt);
     if (rc) return rc;
+    if (fkind) { p.fkind = 1; p.qmin = -448.0f; p.qmax = 448.0f; }
     if (rows == 0 || cols == 0) return CT_OK;
     if (odt == xdt && !col_group && (xdt == CT_BF16 || xdt == CT_F16) && sdt == xdt && tdt == xdt && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(x) && aligned16(out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         constexpr int U = 2;
         dim3 gf(w4_grid(w.units, U));
-#define CT_FQ(DT, ZP) hipLaunchKernelGGL((fq16_kernel<DT, U, ZP>), gf, dim3(kBlock), 0, as_stream(stream), w, p.qmin, p.qmax)
+#define CT_FQ(DT, ZP) hipLaunchKernelGGL((fq16_kernel<DT, U, ZP>), gf, dim3(kBlock), 0, as_stream(stream), w, p.qmin, p.qmax, p.fkind)
         if (xdt == CT_BF16) { if (zp) CT_FQ(CT_BF16, true); else CT_FQ(CT_BF16, false); }
         else { if (zp) CT_FQ(CT_F16, true); else CT_FQ(CT_F16, false); }
 #undef CT_FQ
@@ -955,26 +1064,51 @@ int ct_fake_quantize(const void* x, int xdt, const void* scale, int sdt, const v
     CT_LAUNCH_CHECK("ct_fake_quantize");
 }
 
+int ct_quantize(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                int bits, int tdt, void* out, int odt, ct_stream_t stream) {
+    return quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, 0, tdt, out, odt, stream);
+}
+
+int ct_fake_quantize(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                     int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                     int bits, int tdt, void* out, int odt, ct_stream_t stream) {
+    return fake_quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, 0, tdt, out, odt, stream);
+}
+
+int ct_quantize_fp8(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                    int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                    int tdt, void* out, int odt, ct_stream_t stream) {
+    return quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, 8, 1, tdt, out, odt, stream);
+}
+
+int ct_fake_quantize_fp8(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                         int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                         int tdt, void* out, int odt, ct_stream_t stream) {
+    return fake_quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, 8, 1, tdt, out, odt, stream);
+}
+
 int ct_dequantize(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
                   int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
                   void* out, int odt, ct_stream_t stream) {
     CT_REQUIRE(is_float_dt(odt), "unsupported output dtype %d", odt);
-    CT_REQUIRE(qdt == CT_I8 || qdt == CT_I32 || is_float_dt(qdt), "unsupported x_q dtype %d", qdt);
+    CT_REQUIRE(qdt == CT_I8 || qdt == CT_I32 || qdt == CT_F8E4M3 || is_float_dt(qdt), "unsupported x_q dtype %d", qdt);
     QParams p;
     int rc = fill_qparams(p, xq, qdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, 8, out, odt);
     if (rc) return rc;
     if (rows == 0 || cols == 0) return CT_OK;
     p.vec = (cols % 8 == 0) && aligned16(out) && ((reinterpret_cast<uintptr_t>(xq) & 7u) == 0);
-    if (qdt == CT_I8 && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
+    if ((qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         constexpr int U = 2;
         dim3 g8(w4_grid(w.units, U));
-#define CT_Q8D(DT, ZP) hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 0>), g8, dim3(kBlock), 0, as_stream(stream), w)
+#define CT_Q8D(DT, ZP) do { if (qdt == CT_F8E4M3) hipLaunchKernelGGL((f8_dequant_kernel<DT, U, ZP>), g8, dim3(kBlock), 0, as_stream(stream), w); \
+                            else hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 0>), g8, dim3(kBlock), 0, as_stream(stream), w); } while (0)
         if (sdt == CT_BF16) { if (zp) CT_Q8D(CT_BF16, true); else CT_Q8D(CT_BF16, false); }
         else { if (zp) CT_Q8D(CT_F16, true); else CT_Q8D(CT_F16, false); }
 #undef CT_Q8D
-        CT_LAUNCH_CHECK("ct_dequantize[q8]");
+        CT_LAUNCH_CHECK("ct_dequantize[flat8]");
     }
     dim3 grid = grid_2d(rows, cdiv64(cols, 8));
     switch (sdt) {

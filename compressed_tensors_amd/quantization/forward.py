@@ -1,9 +1,10 @@
 """quantize / dequantize / fake_quantize with the reference's signatures
 (quantization/lifecycle/forward.py:36-181), executed by the HIP kernels.
 
-Scope: INT quantization (num_bits 1..8), strategies tensor / channel / token / group / block,
-optional activation ordering (g_idx).  FLOAT types (fp8 / fp4) and `global_scale` belong to
-the FP4/MX formats, which SURVEY.md §8 marks out of scope; they raise NotImplementedError.
+Scope: INT quantization (num_bits 1..8) and FLOAT 8-bit (float8_e4m3fn), strategies tensor / channel /
+token / group / block, optional activation ordering (g_idx).  The 4-bit FLOAT formats (`global_scale`,
+tensor-group) are served by their own fused codecs (compressors/fp4, codec.fp4_quantize_and_pack) and
+raise NotImplementedError here.
 """
 from typing import Optional
 
@@ -17,10 +18,9 @@ __all__ = ["quantize", "dequantize", "fake_quantize", "calculate_range"]
 
 def _int_args(args, global_scale):
     if global_scale is not None:
-        raise NotImplementedError("global_scale (FP4 tensor-group quantization) is not on the MI355X hot path")
-    if enum_value(getattr(args, "type", "int")) != "int":
-        raise NotImplementedError("only INT quantization is implemented by the MI355X hot path")
+        raise NotImplementedError("global_scale (FP4 tensor-group quantization) goes through codec.fp4_quantize_and_pack")
     return dict(
+        qtype=enum_value(getattr(args, "type", "int")),
         num_bits=int(args.num_bits),
         strategy=enum_value(args.strategy),
         group_size=getattr(args, "group_size", None),
@@ -29,10 +29,14 @@ def _int_args(args, global_scale):
 
 
 def calculate_range(quantization_args, device=None):
-    """quantization/utils/helpers.py:198-226 for INT types, as python floats (the kernels take
-    immediates; no device tensors are created)."""
-    if enum_value(getattr(quantization_args, "type", "int")) != "int":
-        raise NotImplementedError("only INT ranges are implemented")
+    """quantization/utils/helpers.py:198-226, as python floats (the kernels take immediates; no device
+    tensors are created)."""
+    if enum_value(getattr(quantization_args, "type", "int")) == "float":
+        if quantization_args.num_bits == 8:
+            return -448.0, 448.0
+        if quantization_args.num_bits == 4:
+            return -6.0, 6.0
+        raise NotImplementedError("Range calculation only supported for 4 and 8 bits")
     bit_range = 2.0 ** quantization_args.num_bits
     return -bit_range / 2, bit_range / 2 - 1
 
@@ -52,6 +56,7 @@ def dequantize(x_q: torch.Tensor, scale: torch.Tensor, zero_point: Optional[torc
     if args is not None:
         kw = _int_args(args, None)
         kw.pop("num_bits")
+        kw.pop("qtype")
     return codec.dequantize_tensor(x_q, scale, zero_point, dtype=dtype, g_idx=g_idx, **kw)
 
 

@@ -34,7 +34,8 @@ enum ct_dtype {
     CT_I32 = 4,
     CT_U8 = 5,
     CT_I16 = 6,
-    CT_I64 = 7
+    CT_I64 = 7,
+    CT_F8E4M3 = 8 /* float8_e4m3fn (OCP: max 448, 0x7f / 0xff = NaN, no inf) */
 };
 
 enum ct_status {
@@ -89,7 +90,7 @@ int ct_quantize(const void* x, int xdt, const void* scale, int sdt, const void* 
                 const int32_t* col_group, int bits, int tdt, void* out, int odt, ct_stream_t stream);
 
 /* dequantize(x_q, scale, zero_point, ...)   forward.py:76-145; forward_helpers.py:549-572
- * xq: qdt in {CT_I8, CT_I32, float types}; arithmetic in sdt; odt in {CT_F32, CT_F16, CT_BF16} */
+ * xq: qdt in {CT_I8, CT_I32, CT_F8E4M3, float types}; arithmetic in sdt; odt in {CT_F32, CT_F16, CT_BF16} */
 int ct_dequantize(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt,
                   int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
                   const int32_t* col_group, void* out, int odt, ct_stream_t stream);
@@ -99,6 +100,18 @@ int ct_fake_quantize(const void* x, int xdt, const void* scale, int sdt, const v
                      int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
                      const int32_t* col_group, int bits, int tdt, void* out, int odt,
                      ct_stream_t stream);
+
+/* The same three for FLOAT 8-bit args (QuantizationType.FLOAT, num_bits 8; quant_args.py:463-486,
+ * utils/helpers.py:212-214): clamp to +-448 and round to float8_e4m3fn instead of rint.  odt of
+ * ct_quantize_fp8 in {CT_F8E4M3, CT_F32, CT_F16, CT_BF16}; zero points may be CT_F8E4M3 too.  Dequantize is
+ * ct_dequantize with qdt = CT_F8E4M3.  These are the weight paths of float-quantized / naive-quantized(float)
+ * (compressors/naive_quantized/base.py:48-126) and mxfp8-quantized (compressors/mxfp8/base.py:47-101). */
+int ct_quantize_fp8(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                    int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                    const int32_t* col_group, int tdt, void* out, int odt, ct_stream_t stream);
+int ct_fake_quantize_fp8(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                         int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                         const int32_t* col_group, int tdt, void* out, int odt, ct_stream_t stream);
 
 /* Fused PackedQuantizationCompressor.compress weight path: quantize(dtype=int8) followed by
  * pack_to_int32, without the int8 intermediate.   compressors/pack_quantized/base.py:96-104

@@ -355,10 +355,121 @@ def gen_fp4():
     save("fp4", tensors, {"cases": cases})
 
 
+# ----------------------------------------------------------------------------- FP8 (float-quantized, mxfp8-quantized)
+def gen_fp8():
+    """FLOAT 8-bit (float8_e4m3fn) quantize / dequantize / fake_quantize for every strategy, and the float-quantized,
+    naive-quantized(float) and mxfp8-quantized codecs.  Weights carry NaN / inf / signed zeros / the 448 clamp edge."""
+    g = torch.Generator().manual_seed(8888)
+    tensors, cases = {}, []
+    configs = [
+        ("t", dict(strategy="tensor"), (16, 96)),
+        ("ch", dict(strategy="channel"), (9, 200)),
+        ("g128", dict(strategy="group", group_size=128), (8, 512)),
+        ("g32", dict(strategy="group", group_size=32), (6, 128)),
+        ("blk", dict(strategy="block", block_structure=[4, 32]), (8, 128)),
+    ]
+    for name, kw0, shape in configs:
+        kw = dict(num_bits=8, type="float", symmetric=True, **kw0)
+        args = QuantizationArgs(**kw)
+        for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+            for scale_dt_name, sdt in (("same", None), ("f32", torch.float32)):
+                if dt is torch.float32 and sdt is not None:
+                    continue
+                key = f"{name}_{dt_name}_s{scale_dt_name}"
+                x = torch.randn(shape, generator=g).mul(3.0).to(dt)
+                sp = special_values(dt)
+                x.view(-1)[: sp.numel()] = sp
+                xf = torch.nan_to_num(x.float(), nan=0.0, posinf=4.0, neginf=-4.0).clamp(-9, 9).to(dt)
+                scale, zp = make_qparams(xf, args)
+                if sdt is not None:
+                    scale = scale.to(sdt)
+                if name == "t" and scale_dt_name == "f32":
+                    scale, zp = scale.reshape(()), zp.reshape(())
+                # put values that land exactly on fp8 ties and on the clamp edge into the first row / group
+                s0 = scale.reshape(-1)[0].float()
+                edge = torch.tensor([448.0, 449.0, 464.0, 480.0, -448.0, -500.0, 17.0, 18.0, 19.0, 0.0009765625, 0.00292969, 2.0 ** -10, 1.0625, 1.1875, -1.0625, 240.0])
+                x.view(-1)[sp.numel(): sp.numel() + edge.numel()] = (edge * s0).to(dt)
+                q = quantize(x, scale, zp, args, dtype=args.pytorch_dtype())
+                qf = quantize(x, scale, zp, args)
+                fq = fake_quantize(x, scale, zp, args)
+                dq = dequantize(q, scale, zp, args=args)
+                dq_inferred = dequantize(q, scale, zp) if name != "blk" else dq
+                q_nozp = quantize(x, scale, None, args, dtype=args.pytorch_dtype())
+                tensors.update({
+                    key + ".x": x, key + ".scale": scale, key + ".zp": zp.view(torch.uint8) if zp.dtype == torch.float8_e4m3fn else zp,
+                    key + ".q": q.view(torch.uint8), key + ".qf": qf, key + ".fq": fq, key + ".dq": dq, key + ".dq_inferred": dq_inferred,
+                    key + ".q_nozp": q_nozp.view(torch.uint8),
+                })
+                cases.append({"key": key, "args": kw0, "shape": list(shape), "zp_dtype": str(zp.dtype).split(".")[-1]})
+
+    # codecs
+    from compressed_tensors.quantization.quant_scheme import preset_name_to_scheme
+
+    codec_cases = []
+    act = QuantizationArgs(num_bits=8, type="float", strategy="tensor", symmetric=True, dynamic=False)
+    for key, fmt, wkw, shape, dt in (
+        ("fq_ch_bf16", "float-quantized", dict(strategy="channel"), (64, 128), torch.bfloat16),
+        ("fq_t_f16", "float-quantized", dict(strategy="tensor"), (32, 96), torch.float16),
+        ("fq_blk_bf16", "float-quantized", dict(strategy="block", block_structure=[128, 128]), (300, 400), torch.bfloat16),
+        ("nq_g64_f32", "naive-quantized", dict(strategy="group", group_size=64), (16, 128), torch.float32),
+    ):
+        args = QuantizationArgs(num_bits=8, type="float", symmetric=True, **wkw)
+        scheme = QuantizationScheme(targets=["Linear"], weights=args, input_activations=act if fmt == "float-quantized" else None)
+        w = torch.randn(shape, generator=g).to(dt)
+        if wkw.get("strategy") == "block":
+            bh, bw = wkw["block_structure"]
+            rows_p, cols_p = -(-shape[0] // bh) * bh, -(-shape[1] // bw) * bw
+            wp = torch.zeros((rows_p, cols_p), dtype=dt)
+            wp[: shape[0], : shape[1]] = w
+            scale, zp = make_qparams(wp, args)
+        else:
+            scale, zp = make_qparams(w, args)
+        sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+        comp = BaseCompressor.get_value_from_registry(fmt)
+        cdict = comp.compress(sd, scheme)
+        ddict = comp.decompress(cdict, scheme)
+        for k, v in sd.items():
+            tensors[f"{key}.in.{k}"] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+        for k, v in cdict.items():
+            tensors[f"{key}.c.{k}"] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+        for k, v in ddict.items():
+            tensors[f"{key}.d.{k}"] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+        codec_cases.append({"key": key, "format": fmt, "args": wkw, "shape": list(shape), "dtype": str(dt).split(".")[-1],
+                            "compressed_keys": sorted(cdict), "decompressed_keys": sorted(ddict),
+                            "compressed_dtypes": {k: str(v.dtype).split(".")[-1] for k, v in cdict.items()},
+                            "decompressed_dtypes": {k: str(v.dtype).split(".")[-1] for k, v in ddict.items()}})
+    # mxfp8: group 32, E8M0 scales
+    scheme = preset_name_to_scheme("MXFP8A16", ["Linear"])
+    args = scheme.weights
+    comp = BaseCompressor.get_value_from_registry("mxfp8-quantized")
+    for dt in (torch.bfloat16, torch.float16):
+        for shape in ((8, 64), (16, 256)):
+            key = f"mxfp8_{str(dt).split('.')[-1]}_{shape[0]}x{shape[1]}"
+            w = torch.randn(shape, generator=g).to(dt)
+            w[0, :4] = torch.tensor([0.0, -0.0, 1e-6, 300.0]).to(dt)
+            wg = w.reshape(shape[0], shape[1] // 32, 32)
+            scale, zp = calculate_qparams(wg.amin(-1), wg.amax(-1), args)
+            sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+            cdict = comp.compress(sd, scheme)
+            ddict = comp.decompress(cdict, scheme)
+            for k, v in sd.items():
+                tensors[f"{key}.in.{k}"] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+            for k, v in cdict.items():
+                tensors[f"{key}.c.{k}"] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+            for k, v in ddict.items():
+                tensors[f"{key}.d.{k}"] = v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v
+            codec_cases.append({"key": key, "format": "mxfp8-quantized", "args": dict(strategy="group", group_size=32), "shape": list(shape),
+                                "dtype": str(dt).split(".")[-1], "compressed_keys": sorted(cdict), "decompressed_keys": sorted(ddict),
+                                "scale_dtype": str(scale.dtype).split(".")[-1],
+                                "compressed_dtypes": {k: str(v.dtype).split(".")[-1] for k, v in cdict.items()},
+                                "decompressed_dtypes": {k: str(v.dtype).split(".")[-1] for k, v in ddict.items()}})
+    save("fp8", tensors, {"cases": cases, "codecs": codec_cases})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     families = {"pack": gen_pack, "quant": gen_quant, "qparams": gen_qparams, "compressors": gen_compressors, "sparse": gen_sparse,
-                "fp4": gen_fp4}
+                "fp4": gen_fp4, "fp8": gen_fp8}
     wanted = sys.argv[1:] or list(families)  # `python oracle/gen_golden.py fp4` regenerates one family only
     mpath = os.path.join(OUT, "manifest.json")
     if os.path.exists(mpath) and sys.argv[1:]:

@@ -29,7 +29,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libct_oracle.so")
 
-F32, F16, BF16, I8, I32, U8, I16, I64 = range(8)
+F32, F16, BF16, I8, I32, U8, I16, I64, F8 = range(9)
 _DT = {
     torch.float32: F32,
     torch.float16: F16,
@@ -40,6 +40,7 @@ _DT = {
     torch.int16: I16,
     torch.int64: I64,
     torch.bool: U8,
+    torch.float8_e4m3fn: F8,
 }
 _FLOAT_CODE_TO_TORCH = {F32: torch.float32, F16: torch.float16, BF16: torch.bfloat16}
 
@@ -165,7 +166,7 @@ def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size,
     rows, cols, rdiv, cdiv, scols, zero_dim = _resolve(x, scale, strategy, group_size, block_structure)
     is_group = str(getattr(strategy, "value", strategy)) in ("group", "tensor_group")
     cg = _col_group(g_idx, group_size) if is_group else None
-    tdt = _result_code(x, scale, zero_dim)
+    tdt = _result_code(x, scale, zero_dim) if with_bits else None
     if callable(out_dtype):
         out_dtype = out_dtype(_FLOAT_CODE_TO_TORCH[tdt])
     if out_dtype not in _DT:
@@ -173,7 +174,9 @@ def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size,
     out = torch.empty(x.shape, dtype=out_dtype)
     args = [_p(x), _DT[x.dtype], _p(scale), _DT[scale.dtype], _p(zp), _DT[zp.dtype] if zp is not None else -1,
             _i64(rows), _i64(cols), _i64(rdiv), _i64(cdiv), _i64(scols), _p(cg)]
-    if with_bits:
+    if with_bits == "tdt":
+        args += [tdt]
+    elif with_bits:
         args += [num_bits, tdt]
     args += [_p(out), _DT[out_dtype]]
     rc = getattr(lib(), fn_name)(*args)
@@ -182,7 +185,7 @@ def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size,
 
 
 def quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-             dtype=None, g_idx=None):
+             dtype=None, g_idx=None, qtype="int"):
     """forward.py:36-73.  Output dtype: `dtype`; else x.dtype for group strategies
     (forward_helpers.py:134,171) and the promoted float type T of x / scale otherwise."""
     is_group = str(getattr(strategy, "value", strategy)) in ("group", "tensor_group")
@@ -192,6 +195,10 @@ def quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, block
             return dtype
         return x.dtype if is_group else T
 
+    if qtype == "float":  # FLOAT 8-bit: clamp to +-448, round to float8_e4m3fn (quant_args.py:463-486)
+        assert num_bits == 8
+        return _quant_common("cto_quantize_f8", x, scale, zero_point, 8, strategy, group_size,
+                             block_structure, g_idx, out_dtype, with_bits="tdt")
     return _quant_common("cto_quantize", x, scale, zero_point, num_bits, strategy, group_size,
                          block_structure, g_idx, out_dtype)
 
@@ -221,11 +228,15 @@ def dequantize(x_q, scale, zero_point=None, *, strategy=None, group_size=None, b
 
 
 def fake_quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-                  g_idx=None):
+                  g_idx=None, qtype="int"):
     """forward.py:148-181.  Group strategies cast back to x.dtype (forward_helpers.py:134,171);
     the others return scale.dtype (dequant * scale)."""
     st = str(getattr(strategy, "value", strategy))
     out_dtype = x.dtype if st in ("group", "tensor_group") else scale.dtype
+    if qtype == "float":
+        assert num_bits == 8
+        return _quant_common("cto_fake_quantize_f8", x, scale, zero_point, 8, strategy, group_size,
+                             block_structure, g_idx, out_dtype, with_bits="tdt")
     return _quant_common("cto_fake_quantize", x, scale, zero_point, num_bits, strategy, group_size,
                          block_structure, g_idx, out_dtype)
 

@@ -29,6 +29,6 @@ class Golden:
         return {k[len(pre):]: v for k, v in t.items() if k.startswith(pre)}
 
 
-def cases(name):
+def cases(name, section="cases"):
     with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
-        return json.load(f)[name]["cases"]
+        return json.load(f)[name][section]

@@ -804,3 +804,113 @@ def test_fp4_model_compressor_roundtrip(cta, dev, fmt, group):
     for name, m in model.named_modules():
         if isinstance(m, torch.nn.Linear):
             assert eq(m.weight.data.cpu(), expect[name]) and m.weight_scale.dtype == BF16
+
+
+# ----------------------------------------------------------------------------- FP8 (float-quantized / mxfp8-quantized)
+from test_oracle_golden import _f8, _fp8_kw, eq_f8  # noqa: E402
+
+F8 = torch.float8_e4m3fn
+
+
+def _fp8_args(cta, a, **extra):
+    return cta.QuantizationArgs(num_bits=8, type="float", symmetric=True, strategy=a["strategy"], group_size=a.get("group_size"),
+                                block_structure=a.get("block_structure"), **extra)
+
+
+@pytest.mark.parametrize("case", cases("fp8"), ids=lambda c: c["key"])
+def test_fp8_quant_golden(golden, cta, dev, case):
+    """quantize / dequantize / fake_quantize with FLOAT 8-bit args against the reference's outputs"""
+    from compressed_tensors_amd.quantization import dequantize, fake_quantize, quantize
+
+    t = golden.case("fp8", case["key"])
+    args = _fp8_args(cta, case["args"])
+    zp = _f8(t["zp"]) if case["zp_dtype"] == "float8_e4m3fn" else t["zp"]
+    x, s, z = d(t["x"], dev), d(t["scale"], dev), d(zp, dev)
+    q = quantize(x, s, z, args, dtype=F8)
+    assert q.dtype == F8 and eq_f8(q.cpu(), t["q"])
+    assert eq_f8(quantize(x, s, None, args, dtype=F8).cpu(), t["q_nozp"])
+    assert eq(quantize(x, s, z, args).cpu(), t["qf"])
+    assert eq(fake_quantize(x, s, z, args).cpu(), t["fq"])
+    assert eq(dequantize(d(_f8(t["q"]), dev), s, z, args=args).cpu(), t["dq"])
+    if case["args"]["strategy"] != "block":
+        assert eq(dequantize(d(_f8(t["q"]), dev), s, z).cpu(), t["dq_inferred"])
+
+
+@pytest.mark.parametrize("case", cases("fp8", "codecs"), ids=lambda c: c["key"])
+def test_fp8_codecs_golden(golden, cta, dev, case):
+    t = golden.case("fp8", case["key"])
+    fmt = case["format"]
+    extra = dict(scale_dtype=torch.uint8) if fmt == "mxfp8-quantized" else {}
+    args = _fp8_args(cta, case["args"], **extra)
+    act = cta.QuantizationArgs(num_bits=8, type="float", strategy="tensor", symmetric=True) if fmt == "float-quantized" else None
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args, input_activations=act)
+    comp = cta.BaseCompressor.get_value_from_registry(fmt)
+    assert comp.can_compress(torch.nn.Linear, scheme)
+    sd = {k[3:]: d(_f8(v) if k.endswith("zero_point") else v, dev) for k, v in t.items() if k.startswith("in.")}
+    c = comp.compress(sd, scheme)
+    assert sorted(c) == case["compressed_keys"]
+    assert {k: str(v.dtype).split(".")[-1] for k, v in c.items()} == case["compressed_dtypes"]
+    assert eq_f8(c["weight"].cpu(), t["c.weight"])
+    assert torch.equal(c["weight_scale"].cpu().view(torch.uint8) if c["weight_scale"].dtype == torch.uint8 else c["weight_scale"].cpu(), t["c.weight_scale"])
+    back = comp.decompress(c, scheme)
+    assert sorted(back) == case["decompressed_keys"]
+    assert {k: str(v.dtype).split(".")[-1] for k, v in back.items()} == case["decompressed_dtypes"]
+    assert eq(back["weight"].cpu(), t["d.weight"]) and eq(back["weight_scale"].cpu(), t["d.weight_scale"])
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_fp8_hardware_conversion_all_inputs(cta, dev, xdt):
+    """v_cvt_pk_fp8_f32 / v_cvt_pk_f32_fp8 against the oracle's float8_e4m3fn cast: every 16-bit input, through the flat
+    kernel (16-bit scale) and the generic one (float32 scale), with and without a zero point"""
+    x = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(xdt).reshape(256, 256)
+    g = torch.Generator().manual_seed(7)
+    for sdt in (xdt, F32):
+        for strategy, shape, gs in (("tensor", (1,), None), ("channel", (256, 1), None), ("group", (256, 8), 32)):
+            s = (torch.rand(shape, generator=g) * 4 + 0.01).to(sdt)
+            if strategy == "tensor":
+                s = torch.ones(shape, dtype=sdt)
+            for z in (None, torch.zeros(shape, dtype=F8)):
+                kw = dict(num_bits=8, strategy=strategy, group_size=gs, qtype="float")
+                got = cta.codec.quantize_tensor(d(x, dev), d(s, dev), d(z, dev), dtype=F8, **kw)
+                ref = O.quantize(x, s, z, dtype=F8, **kw)
+                assert eq_f8(got.cpu(), ref), (sdt, strategy, z is None)
+                fq = cta.codec.fake_quantize_tensor(d(x, dev), d(s, dev), d(z, dev), **kw)
+                assert eq(fq.cpu(), O.fake_quantize(x, s, z, **kw)), (sdt, strategy, z is None)
+    codes = torch.arange(256, dtype=torch.uint8).repeat(64).reshape(64, 256).view(F8)
+    for sdt in (BF16, F16, F32):
+        s = (torch.rand((64, 8), generator=g) * 4 + 0.01).to(sdt)
+        got = cta.codec.dequantize_tensor(d(codes, dev), d(s, dev), None)
+        assert eq(got.cpu(), O.dequantize(codes, s, None))
+
+
+def test_fp8_full_size_roundtrip(cta, dev):
+    """8192 x 8192 bf16, channel scales: dequantize(quantize(x)) is idempotent under a second round trip and every
+    code is a finite float8 value"""
+    N = 8192
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn((N, N), generator=g, device=dev, dtype=BF16)
+    s = (x.abs().amax(dim=1, keepdim=True).float() / 448.0).to(BF16)
+    kw = dict(num_bits=8, strategy="channel", qtype="float")
+    q = cta.codec.quantize_tensor(x, s, None, dtype=F8, **kw)
+    y = cta.codec.dequantize_tensor(q, s, None)
+    assert not bool(torch.isnan(y).any()) and y.dtype == BF16
+    q2 = cta.codec.quantize_tensor(y, s, None, dtype=F8, **kw)
+    y2 = cta.codec.dequantize_tensor(q2, s, None)
+    assert torch.equal(y2, y)
+    rel = ((y.float() - x.float()).abs() / s.float()).max()
+    # half a float8 step at the top binade (32 / 2) + the clamp excess of a bf16-rounded scale (448 * 2^-8) + bf16 rounding of y
+    assert float(rel) <= 20.0
+
+
+@pytest.mark.parametrize("sdt", [BF16, F16, F32])
+def test_dequantize_keeps_the_sign_of_a_zero_product(cta, dev, sdt):
+    """0 * (negative scale) = -0.0 and (-0.0 code) * scale = -0.0, in every scale dtype (fp16 products are not fused
+    into a +0 accumulate)"""
+    q = torch.zeros((4, 64), dtype=torch.int8)
+    s = torch.full((4, 1), -0.5, dtype=sdt)
+    got = cta.codec.dequantize_tensor(d(q, dev), d(s, dev), None)
+    assert eq(got.cpu(), O.dequantize(q, s, None)) and bool(torch.signbit(got).all())
+    q8 = torch.full((4, 64), 0x80, dtype=torch.uint8).view(F8)
+    s = torch.full((4, 1), 0.5, dtype=sdt)
+    got = cta.codec.dequantize_tensor(d(q8, dev), d(s, dev), None)
+    assert eq(got.cpu(), O.dequantize(q8, s, None)) and bool(torch.signbit(got).all())

@@ -87,7 +87,7 @@ def test_argument_errors_match_reference(cta):
     with pytest.raises(ValueError, match="divisble"):
         cta.codec.QuantLayout((4, 100), torch.ones(4, 1), "group", group_size=64)
     with pytest.raises(NotImplementedError):
-        args = cta.QuantizationArgs(num_bits=8, type="float")
+        args = cta.QuantizationArgs(num_bits=4, type="float")  # FLOAT 4-bit goes through the fused FP4 codecs
         cta.quantize(torch.zeros(2, 2), torch.ones(1), None, args)
     with pytest.raises(ValueError, match="Could not infer"):
         from compressed_tensors_amd.codec import infer_dequant_layout

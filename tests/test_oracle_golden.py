@@ -278,3 +278,83 @@ def test_fp4_compressors_golden(golden, case):
     assert sorted(d) == case["decompressed_keys"]
     for name in ("weight", "weight_scale"):
         assert eq(d[name], t[f"dec.{name}"]), name
+
+
+# ----------------------------------------------------------------------------- FP8 (float-quantized / mxfp8-quantized)
+F8 = torch.float8_e4m3fn
+
+
+def _f8(t):
+    """golden fp8 tensors are stored as their bytes"""
+    return t.view(F8) if t.dtype == torch.uint8 else t
+
+
+def eq_f8(a, b):
+    """fp8 byte equality; the sign of a NaN is not pinned (torch's own casts disagree between its scalar and
+    vectorised paths), every other byte is, -0 included"""
+    a, b = a.view(torch.uint8), b.view(torch.uint8)
+    an, bn = (a & 0x7F) == 0x7F, (b & 0x7F) == 0x7F
+    return a.shape == b.shape and torch.equal(an, bn) and torch.equal(a[~an], b[~bn])
+
+
+def _fp8_kw(case):
+    a = case["args"]
+    return dict(num_bits=8, strategy=a["strategy"], group_size=a.get("group_size"), block_structure=a.get("block_structure"), qtype="float")
+
+
+def test_fp8_cast_matches_torch_for_every_value():
+    """the restated float8_e4m3fn cast against torch's own, over every bf16 / fp16 input and a float32 sweep"""
+    for dt in (BF16, torch.float16):
+        x = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dt)
+        one = torch.ones((), dtype=dt)
+        q = O.quantize(x.reshape(256, 256), one.reshape(1), None, num_bits=8, strategy="tensor", dtype=F8, qtype="float")
+        ref = torch.clamp(x / one, -448.0, 448.0).to(F8).reshape(256, 256)
+        assert eq_f8(q, ref)
+        back = O.dequantize(ref, one.reshape(1), None, strategy="tensor")
+        assert eq(back, ref.to(dt))
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(1 << 16, generator=g) * 100, torch.randn(1 << 16, generator=g) * 0.01,
+                   torch.arange(0, 520, dtype=torch.float32) * 2.0 ** -9 * 0.5, torch.arange(0, 4096, dtype=torch.float32) * 0.125])
+    x = x[: (x.numel() // 64) * 64].reshape(-1, 64)
+    q = O.quantize(x, torch.ones(1), None, num_bits=8, strategy="tensor", dtype=F8, qtype="float")
+    assert eq_f8(q, torch.clamp(x, -448.0, 448.0).to(F8))
+
+
+@pytest.mark.parametrize("case", cases("fp8"), ids=lambda c: c["key"])
+def test_fp8_quant_golden(golden, case):
+    t = golden.case("fp8", case["key"])
+    kw = _fp8_kw(case)
+    zp = _f8(t["zp"]) if case["zp_dtype"] == "float8_e4m3fn" else t["zp"]
+    assert eq_f8(O.quantize(t["x"], t["scale"], zp, dtype=F8, **kw), t["q"])
+    assert eq_f8(O.quantize(t["x"], t["scale"], None, dtype=F8, **kw), t["q_nozp"])
+    assert eq(O.quantize(t["x"], t["scale"], zp, **kw), t["qf"])
+    assert eq(O.fake_quantize(t["x"], t["scale"], zp, **kw), t["fq"])
+    dkw = {k: v for k, v in kw.items() if k not in ("num_bits", "qtype")}
+    assert eq(O.dequantize(_f8(t["q"]), t["scale"], zp, **dkw), t["dq"])
+    if kw["strategy"] != "block":
+        assert eq(O.dequantize(_f8(t["q"]), t["scale"], zp), t["dq_inferred"])
+
+
+@pytest.mark.parametrize("case", cases("fp8", "codecs"), ids=lambda c: c["key"])
+def test_fp8_codecs_golden(golden, case):
+    """float-quantized / naive-quantized(float) (naive_quantized/base.py:48-126) and mxfp8-quantized (mxfp8/base.py:47-101)"""
+    t = golden.case("fp8", case["key"])
+    a = case["args"]
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("in.")}
+    exp_c = {k[2:]: v for k, v in t.items() if k.startswith("c.")}
+    exp_d = {k[2:]: v for k, v in t.items() if k.startswith("d.")}
+    q = O.quantize(sd["weight"], sd["weight_scale"], _f8(sd["weight_zero_point"]), num_bits=8, strategy=a["strategy"],
+                   group_size=a.get("group_size"), block_structure=a.get("block_structure"), dtype=F8, qtype="float")
+    assert eq_f8(q, exp_c["weight"])
+    assert "weight_zero_point" not in exp_c  # symmetric: dropped
+    if case["format"] == "mxfp8-quantized":
+        assert torch.equal(O.e8m0_encode(sd["weight_scale"]), exp_c["weight_scale"])
+        scale = O.e8m0_decode(exp_c["weight_scale"])
+        assert eq(scale, exp_d["weight_scale"])
+    else:
+        scale = exp_c["weight_scale"]
+        assert eq(scale, sd["weight_scale"])
+    # decompress never sees the args: the strategy is inferred from the scale shape (forward.py:99-130), which for a
+    # padded block layout (300 x 400 under 128 x 128 blocks -> scale 3 x 4) means 100 x 100 blocks, as upstream
+    d = O.dequantize(_f8(exp_c["weight"]), scale, None)
+    assert eq(d, exp_d["weight"])
