@@ -290,6 +290,61 @@ def qparams_leg(dev):
             "us": round(us, 2), "GBps": round(alg / us / 1e3, 1), "frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4)}
 
 
+def float_formats_leg(dev):
+    """the float formats at 8192x8192 bf16 through the C ABI, HBM-cold rotation.
+    float-quantized (float8_e4m3fn, channel scales): 2 + 1 B/element; nvfp4 (group 16, float32 scales in, fp8 scales
+    stored): 2 + 0.5 + 4/16 resp. 1/16; mxfp4 (group 32, bf16 scales in, E8M0 stored): 2 + 0.5 + 2/32 resp. 1/32."""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    BF16, F32, F8 = _lib.BF16, _lib.F32, _lib.F8
+    nsets = 12  # 12 x 134 MB of weights per format: HBM-cold
+    g = torch.Generator(device=dev).manual_seed(17)
+    ws = [torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g) for _ in range(nsets)]
+    out = {}
+
+    def rate(alg, us):
+        return {"us": round(us, 2), "GBps": round(alg / us / 1e3, 1), "frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4)}
+
+    # float8_e4m3fn, per-channel
+    sc = [(w.abs().amax(dim=1, keepdim=True).float() / 448.0).to(torch.bfloat16) for w in ws]
+    q8 = [torch.empty(N, N, dtype=torch.uint8, device=dev) for _ in range(nsets)]
+    back = torch.empty(N, N, dtype=torch.bfloat16, device=dev)
+    fq = lambda i: lib.ct_quantize_fp8(ws[i % nsets].data_ptr(), BF16, sc[i % nsets].data_ptr(), BF16, None, -1, N, N, 1, N, 1, None, BF16,
+                                       q8[i % nsets].data_ptr(), F8, stream)
+    fd = lambda i: lib.ct_dequantize(q8[i % nsets].data_ptr(), F8, sc[i % nsets].data_ptr(), BF16, None, -1, N, N, 1, N, 1, None, back.data_ptr(), BF16, stream)
+    for i in range(nsets):
+        fq(i)
+    alg = 3 * N * N + 2 * N
+    out["float8_channel"] = {"alg_bytes_per_direction": alg, "quantize": rate(alg, time_kernel(fq, 36)), "dequantize": rate(alg, time_kernel(fd, 36, offset=6))}
+    del q8
+    # FP4
+    p4 = [torch.empty(N, N // 2, dtype=torch.uint8, device=dev) for _ in range(nsets)]
+    for name, group, sdt, sbytes_in in (("nvfp4", 16, torch.float32, 4), ("mxfp4", 32, torch.bfloat16, 2)):
+        if name == "nvfp4":
+            gs = torch.tensor([448.0 * 6.0 / 6.0], dtype=torch.float32, device=dev)
+            ss = [(w.view(N, N // group, group).abs().amax(-1).float() * gs / 6.0).to(torch.float8_e4m3fn).float().clamp_(min=2.0 ** -9) for w in ws]
+            stored = [s.to(torch.float8_e4m3fn).view(torch.uint8) for s in ss]
+            gptr, kind = gs.data_ptr(), 1
+        else:
+            ss = [torch.exp2(torch.floor(torch.log2(w.view(N, N // group, group).abs().amax(-1).float().clamp_(min=1e-6))) - 2).to(torch.bfloat16) for w in ws]
+            stored = [(127 + torch.floor(torch.log2(s.float()))).to(torch.uint8) for s in ss]
+            gptr, kind = None, 2
+        code = _lib.DT[sdt]
+        cq = lambda i: lib.ct_fp4_quant_pack(ws[i % nsets].data_ptr(), BF16, ss[i % nsets].data_ptr(), code, gptr, N, N, group, p4[i % nsets].data_ptr(), stream)
+        cd = lambda i: lib.ct_fp4_unpack_dequant(p4[i % nsets].data_ptr(), N, N, stored[i % nsets].data_ptr(), kind, -1, gptr, group, back.data_ptr(), BF16, stream)
+        for i in range(nsets):
+            cq(i)
+        alg_c = int(N * N * (2.5 + sbytes_in / group))
+        alg_d = int(N * N * (2.5 + 1.0 / group))
+        out[name] = {"alg_bytes_compress": alg_c, "alg_bytes_decompress": alg_d, "compress": rate(alg_c, time_kernel(cq, 36)),
+                     "decompress": rate(alg_d, time_kernel(cd, 36, offset=6))}
+        del ss, stored
+    out["workload"] = f"float-quantized (float8_e4m3fn, channel), nvfp4- and mxfp4-pack-quantized weight paths, {N}x{N} bf16, C ABI"
+    return out
+
+
 TINYLLAMA_LAYER = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048),
                    ("gate_proj", 5632, 2048), ("up_proj", 5632, 2048), ("down_proj", 2048, 5632))
 
@@ -503,7 +558,8 @@ def main():
         if world == 1 and not a.no_extra:
             del sets
             torch.cuda.empty_cache()
-            for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg)):
+            for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
+                             ("float_formats", float_formats_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down

@@ -7,7 +7,7 @@ After this, every upstream caller that looks a codec up by its format string
 (`BaseCompressor.get_value_from_registry(...)`: compress_module / decompress_module,
 ModelCompressor, transformers' DecompressExperts, CompressedTensorsDequantizer) receives a
 subclass of the upstream codec whose `compress` / `decompress` run the HIP kernels whenever
-the weight lives on the GPU; anything else (CPU tensors, FP8 types, meta tensors) is handed
+the weight lives on the GPU; anything else (CPU tensors, meta tensors) is handed
 to the upstream implementation it inherits from.  `_quantize`, `pack_fp4_to_uint8` and `cast_to_fp4`
 are additionally registered as `ImplBackend` backends (upstream utils/impl_backend.py:50-79), which
 is the reference's own plug-in point for those functions.
@@ -30,8 +30,13 @@ def _on_gpu(*tensors) -> bool:
 
 
 def _int_weights(scheme) -> bool:
+    """INT 1..8 bits, or FLOAT 8 bits (float8_e4m3fn): the types the quantize / dequantize kernels implement"""
     w = getattr(scheme, "weights", None)
-    return w is not None and enum_value(getattr(w, "type", "int")) == "int" and 1 <= int(w.num_bits) <= 8
+    if w is None:
+        return False
+    if enum_value(getattr(w, "type", "int")) == "float":
+        return int(w.num_bits) == 8
+    return 1 <= int(w.num_bits) <= 8
 
 
 def _fp4_weights(scheme) -> bool:
@@ -58,6 +63,7 @@ def install():
 
     from .compressors.fp4 import MXFP4PackedCompressor as _AmdMXFP4
     from .compressors.fp4 import NVFP4PackedCompressor as _AmdNVFP4
+    from .compressors.mxfp8 import MXFP8QuantizationCompressor as _AmdMXFP8
 
     def subclass(up_cls, amd_cls, name):
         fp4_group = getattr(amd_cls, "GROUP", None)  # set on the FP4 codecs only
@@ -90,6 +96,7 @@ def install():
         return _Hip
 
     for fmt, amd_cls in (("pack-quantized", _AmdPacked), ("naive-quantized", _AmdNaive), ("int-quantized", _AmdNaive),
+                         ("float-quantized", _AmdNaive), ("mxfp8-quantized", _AmdMXFP8),
                          ("nvfp4-pack-quantized", _AmdNVFP4), ("mxfp4-pack-quantized", _AmdMXFP4)):
         if fmt not in table and fmt not in _SAVED:
             continue  # an older upstream without the FP4 codecs
@@ -102,9 +109,10 @@ def install():
 
         def _req(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
             return (
-                x.is_cuda and global_scale is None and enum_value(getattr(args, "type", "int")) == "int"
+                x.is_cuda and global_scale is None
+                and (enum_value(getattr(args, "type", "int")) == "int" or int(args.num_bits) == 8)
                 and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
-                and dtype in (None, torch.int8, torch.int32, torch.float32, torch.float16, torch.bfloat16)
+                and dtype in (None, torch.int8, torch.int32, torch.float8_e4m3fn, torch.float32, torch.float16, torch.bfloat16)
                 and x.is_contiguous() and _broadcast_layout(x, scale) is not None
             )
 
@@ -115,6 +123,7 @@ def install():
             out = codec.quantize_tensor(
                 x2, scale.reshape(layout["scale_shape"]), None if zero_point is None else zero_point.reshape(layout["scale_shape"]),
                 num_bits=int(args.num_bits), strategy=layout["strategy"], group_size=layout.get("group_size"),
+                qtype=enum_value(getattr(args, "type", "int")),
                 dtype=dtype if dtype is not None else torch.result_type(x, scale),
             )
             return out.reshape(x.shape)
