@@ -150,6 +150,46 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_kernel(const u32x4* __r
     }
 }
 
+// the common shape, lean: every lane owns 4 full units (tensor size % 32 == 0) and the scale dtype is a template
+// parameter, so the lane's one (group 32) or two (group 16) scales are fetched by a single small load BEFORE the 64
+// bytes of weights (same idea as w4_quant_pack_lean), and the fast / slow quotient choice is made once per lane.
+template <int XDT, int SDT, int GROUP, bool GLOBAL>
+__global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4* __restrict__ in, const void* __restrict__ scale,
+                                                                     const float* __restrict__ global_scale, u32x4* __restrict__ out, int64_t lanes) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= lanes) return;
+    constexpr int NS = 32 / GROUP;  // scales per lane
+    float s[2];
+    if constexpr (SDT == CT_F32) {
+        if constexpr (NS == 2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 v = __builtin_nontemporal_load(reinterpret_cast<const f2*>(scale) + g);
+            s[0] = v.x; s[1] = v.y;
+        } else {
+            s[0] = s[1] = __builtin_nontemporal_load(static_cast<const float*>(scale) + g);
+        }
+    } else {
+        uint32_t b;
+        if constexpr (NS == 2) b = __builtin_nontemporal_load(static_cast<const uint32_t*>(scale) + g);
+        else b = __builtin_nontemporal_load(static_cast<const uint16_t*>(scale) + g);
+        if constexpr (SDT == CT_BF16) { s[0] = bits_f(b << 16); s[1] = NS == 2 ? bits_f(b & 0xffff0000u) : s[0]; }
+        else { s[0] = f16_bits_to_f(b & 0xffffu); s[1] = NS == 2 ? f16_bits_to_f(b >> 16) : s[0]; }
+    }
+    const float gs = GLOBAL ? global_scale[0] : 1.0f;
+    asm volatile("" ::: "memory");  // keep the small loads ahead of the big ones
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[g * 4 + i];
+    constexpr bool in_dtype = !GLOBAL && SDT == XDT;
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        w[i] = fp4_quant_unit<XDT, GLOBAL>(ws, s[NS == 2 ? i >> 1 : 0], gs, in_dtype);
+    }
+    stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+}
+
 // every mantissa of s in [1, 2) against every mantissa of x in [1, 2) (7 bits bf16, 10 bits fp16; `xbits` of them):
 // the fast quotient must equal the IEEE quotient bit for bit.  With x < s the quotient lies in [0.5, 1), else [1, 2).
 __global__ __launch_bounds__(kBlock) void selftest_fp4_div_kernel(int xbits, uint32_t m_lo, uint32_t m_hi, unsigned long long* mismatches) {
@@ -288,6 +328,41 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_kernel(const uint8_t* __res
     }
 }
 
+// nvfp4: there are only 256 possible scale bytes, so s_eff = fl32(float(fp8) / global) is tabulated once per block
+// (one IEEE divide per thread) and every unit replaces decode + divide by one LDS read
+template <int ODT, int UNROLL>
+__global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_nv_kernel(const uint32_t* __restrict__ in, const uint8_t* __restrict__ scale,
+                                                                       const float* __restrict__ global_scale, void* __restrict__ out, int64_t units,
+                                                                       int64_t stride) {
+    __shared__ float s_eff[256];
+    static_assert(kBlock == 256, "one table entry per thread");
+    s_eff[threadIdx.x] = __builtin_amdgcn_cvt_f32_fp8((int)threadIdx.x, 0) / global_scale[0];
+    __syncthreads();
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < units; base += stride) {
+        uint32_t word[UNROLL];
+        uint32_t sb[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u = base + (int64_t)i * kBlock;
+            if (u < units) { word[i] = in[u]; sb[i] = scale[u >> 1]; }
+        }
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u = base + (int64_t)i * kBlock;
+            if (u >= units) continue;
+            const float s = s_eff[sb[i]];
+            float v[8];
+            fp4_word_values(word[i], v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] *= s;
+                if constexpr (ODT == CT_F16) asm("" : "+v"(v[k]));  // see mul_round_to
+            }
+            store8<ODT>(out, u * 8, v);
+        }
+    }
+}
+
 }  // namespace ct
 
 using namespace ct;
@@ -309,6 +384,19 @@ int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const 
     const int shift = group == 16 ? 1 : 2;
     CT_REQUIRE(cdiv64(lanes, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
     dim3 grid((unsigned)cdiv64(lanes, kBlock));
+    if (units % 4 == 0 && (reinterpret_cast<uintptr_t>(scale) & 7u) == 0) {
+        dim3 lg((unsigned)cdiv64(lanes, kBlock));
+#define CT_FP4L(XD, SD, G, GL) hipLaunchKernelGGL((fp4_quant_pack_lean_kernel<XD, SD, G, GL>), lg, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), scale, \
+                                                  global_scale, reinterpret_cast<u32x4*>(packed), lanes)
+#define CT_FP4L_G(XD, SD) do { if (group == 16) { if (global_scale) CT_FP4L(XD, SD, 16, true); else CT_FP4L(XD, SD, 16, false); } \
+                               else { if (global_scale) CT_FP4L(XD, SD, 32, true); else CT_FP4L(XD, SD, 32, false); } } while (0)
+#define CT_FP4L_S(XD) do { if (sdt == CT_F32) CT_FP4L_G(XD, CT_F32); else if (sdt == CT_BF16) CT_FP4L_G(XD, CT_BF16); else CT_FP4L_G(XD, CT_F16); } while (0)
+        if (xdt == CT_BF16) CT_FP4L_S(CT_BF16); else CT_FP4L_S(CT_F16);
+#undef CT_FP4L_S
+#undef CT_FP4L_G
+#undef CT_FP4L
+        CT_LAUNCH_CHECK("ct_fp4_quant_pack[lean]");
+    }
 #define CT_FP4Q(DT, GL) hipLaunchKernelGGL((fp4_quant_pack_kernel<DT, GL>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), scale, sdt, \
                                           global_scale, reinterpret_cast<u32x4*>(packed), units, shift)
     if (xdt == CT_BF16) { if (global_scale) CT_FP4Q(CT_BF16, true); else CT_FP4Q(CT_BF16, false); }
@@ -333,6 +421,13 @@ int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, con
     CT_REQUIRE(cdiv64(units, (int64_t)kBlock * U) < ((int64_t)1 << 31), "tensor too large for one launch");
     dim3 grid((unsigned)cdiv64(units, (int64_t)kBlock * U));
     const int64_t stride = (int64_t)1 << 40;  // one trip; the loop form schedules better (see ct_quant.hip)
+    if (scale_kind == SC_F8E4M3 && global_scale && group == 16) {
+        if (odt == CT_BF16) hipLaunchKernelGGL((fp4_unpack_dequant_nv_kernel<CT_BF16, U>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(packed),
+                                               static_cast<const uint8_t*>(scale), global_scale, out, units, stride);
+        else hipLaunchKernelGGL((fp4_unpack_dequant_nv_kernel<CT_F16, U>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(packed),
+                                static_cast<const uint8_t*>(scale), global_scale, out, units, stride);
+        CT_LAUNCH_CHECK("ct_fp4_unpack_dequant[nvfp4]");
+    }
 #define CT_FP4D(DT, GL) hipLaunchKernelGGL((fp4_unpack_dequant_kernel<DT, U, GL>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(packed), \
                                           scale, scale_kind, sdt, global_scale, out, units, shift, stride)
     if (odt == CT_BF16) { if (global_scale) CT_FP4D(CT_BF16, true); else CT_FP4D(CT_BF16, false); }

@@ -640,7 +640,7 @@ def test_fp4_decode_all_codes_all_scales(cta, dev):
 
 @pytest.mark.parametrize("fmt,group", [("nvfp4-pack-quantized", 16), ("mxfp4-pack-quantized", 32)])
 @pytest.mark.parametrize("xdt", [BF16, F16])
-@pytest.mark.parametrize("shape", [(1, 32), (3, 96), (5, 160), (64, 4096), (33, 1056)])
+@pytest.mark.parametrize("shape", [(1, 32), (3, 96), (5, 160), (64, 4096), (33, 1056), (1, 16), (3, 48), (7, 80)])
 def test_fp4_codec_vs_oracle(cta, dev, fmt, group, xdt, shape):
     if shape[1] % group:
         pytest.skip("columns not a multiple of the group")
