@@ -94,6 +94,12 @@ def _args_from_dict(d: Optional[dict]) -> Optional[QuantizationArgs]:
     known = {k: d[k] for k in ("num_bits", "type", "symmetric", "group_size", "strategy", "block_structure", "dynamic", "actorder") if k in d}
     if known.get("dynamic") not in (True, False):
         known["dynamic"] = bool(known.get("dynamic")) if known.get("dynamic") != "local" else False
+    for key in ("scale_dtype", "zp_dtype"):  # serialised as str(dtype), e.g. "torch.uint8" (quant_args.py:209-224)
+        v = d.get(key)
+        if isinstance(v, str):
+            v = getattr(torch, v.split(".")[-1], None)
+        if isinstance(v, torch.dtype):
+            known[key] = v
     return QuantizationArgs(**known)
 
 

@@ -155,6 +155,72 @@ def test_convert_checkpoint_dequantizes_on_the_gpu(tmp_path, max_workers):
     assert "quantization_config" not in json.load(open(dst / "config.json")) and (dst / "tokenizer.json").exists()
 
 
+@pytest.mark.gpu
+def test_convert_checkpoint_float_formats(tmp_path):
+    """the same converter over float-quantized (fp8), mxfp8-, nvfp4- and mxfp4-pack-quantized modules: the format of
+    every config group is inferred from its scheme, the weights come back as the oracle's decompress"""
+    import oracle as O
+
+    import compressed_tensors_amd as cta
+
+    dev = torch.device("cuda:0")
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir()
+    f8 = {"num_bits": 8, "type": "float", "symmetric": True}
+    groups = {
+        "fp8": {"targets": ["re:.*q_proj"], "weights": dict(f8, strategy="channel"), "input_activations": dict(f8, strategy="tensor", dynamic=False)},
+        "mxfp8": {"targets": ["re:.*k_proj"], "weights": dict(f8, strategy="group", group_size=32, scale_dtype="torch.uint8", zp_dtype="torch.uint8")},
+        "nvfp4": {"targets": ["re:.*v_proj"], "weights": {"num_bits": 4, "type": "float", "symmetric": True, "strategy": "tensor_group", "group_size": 16,
+                                                          "scale_dtype": "torch.float8_e4m3fn", "zp_dtype": "torch.float8_e4m3fn"}},
+        "mxfp4": {"targets": ["re:.*o_proj"], "weights": {"num_bits": 4, "type": "float", "symmetric": True, "strategy": "group", "group_size": 32,
+                                                          "scale_dtype": "torch.uint8", "zp_dtype": "torch.uint8"}},
+    }
+    with open(src / "config.json", "w") as f:
+        json.dump({"architectures": ["Toy"], "quantization_config": {"quant_method": "compressed-tensors", "format": "mixed-precision", "ignore": ["lm_head"],
+                                                                     "config_groups": groups}}, f)
+    conv = CompressedTensorsDequantizer(src, dtype=torch.bfloat16, device=dev)
+    assert [s.format for s in conv.schemes] == ["float-quantized", "mxfp8-quantized", "nvfp4-pack-quantized", "mxfp4-pack-quantized"]
+    torch.manual_seed(0)
+    tensors, expect = {}, {}
+    for layer in range(2):
+        for (proj, scheme), shape in zip(zip(("q_proj", "k_proj", "v_proj", "o_proj"), conv.schemes), ((128, 256), (64, 256), (64, 256), (256, 128))):
+            mod = f"model.layers.{layer}.{proj}"
+            w = torch.randn(shape).to(torch.bfloat16)
+            comp = cta.BaseCompressor.get_value_from_registry(scheme.format)
+            if proj == "q_proj":
+                s = (w.abs().amax(dim=1, keepdim=True).float() / 448.0).to(torch.bfloat16)
+                sd = {"weight": w, "weight_scale": s}
+                q = O.quantize(w, s, None, num_bits=8, strategy="channel", dtype=torch.float8_e4m3fn, qtype="float")
+                expect[mod] = O.dequantize(q, s, None)
+            elif proj == "k_proj":
+                s = torch.exp2(torch.floor(torch.log2(w.float().reshape(shape[0], -1, 32).abs().amax(-1))) - 8).to(torch.bfloat16)
+                sd = {"weight": w, "weight_scale": s}
+                q = O.quantize(w, s, None, num_bits=8, strategy="group", group_size=32, dtype=torch.float8_e4m3fn, qtype="float")
+                expect[mod] = O.dequantize(q, O.e8m0_decode(O.e8m0_encode(s)), None)
+            else:
+                group = 16 if proj == "v_proj" else 32
+                amax = w.float().reshape(shape[0], -1, group).abs().amax(-1)
+                if proj == "v_proj":
+                    gs = torch.tensor([448.0 * 6.0 / float(amax.max())], dtype=torch.float32)
+                    s = (gs * amax / 6.0).to(torch.float8_e4m3fn).to(torch.float32)
+                    sd = {"weight": w, "weight_scale": s, "weight_global_scale": gs}
+                else:
+                    gs, s = None, torch.exp2(torch.floor(torch.log2(amax)) - 2).to(torch.bfloat16)
+                    sd = {"weight": w, "weight_scale": s}
+                expect[mod] = O.fp4_decompress(O.fp4_compress(w, s, gs, fmt=scheme.format), fmt=scheme.format)["weight"]
+            c = comp.compress({k: v.to(dev) for k, v in sd.items()}, scheme)
+            assert sorted(c) == sorted(comp.compression_param_names(scheme))
+            for k, v in c.items():
+                tensors[f"{mod}.{k}"] = v.cpu().contiguous()
+    tensors["lm_head.weight"] = torch.randn(32, 256).to(torch.bfloat16)
+    save_file(tensors, str(src / "model.safetensors"))
+    convert_checkpoint(src, dst, conv, max_workers=2)
+    out = load_file(str(dst / "model.safetensors"))
+    for mod, ref in expect.items():
+        assert out[f"{mod}.weight"].dtype == torch.bfloat16 and torch.equal(out[f"{mod}.weight"], ref.to(torch.bfloat16)), mod
+    assert set(out) == {f"{m}.weight" for m in expect} | {"lm_head.weight"}
+
+
 _DIST_CONVERT = r"""
 import json, os, sys, torch
 sys.path.insert(0, {root!r})
