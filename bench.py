@@ -286,8 +286,15 @@ def qparams_leg(dev):
     zp = torch.empty(N, N // GROUP, dtype=torch.int8, device=dev)
     us = time_kernel(lambda i: lib.ct_minmax_qparams(ws[i % 8].data_ptr(), _lib.BF16, N, N, GROUP, BITS, 1, sc.data_ptr(), zp.data_ptr(), stream), 48)
     alg = 2 * N * N + 3 * N * (N // GROUP)
+    # the same observer fused with the W4 compress (ct_rtn_quant_pack_w4): the weight is read once
+    packed = [torch.empty(N, N // 8, dtype=torch.int32, device=dev) for _ in range(8)]
+    us_f = time_kernel(lambda i: lib.ct_rtn_quant_pack_w4(ws[i % 8].data_ptr(), _lib.BF16, N, N, GROUP, 1, packed[i % 8].data_ptr(), sc.data_ptr(), zp.data_ptr(),
+                                                           stream), 48)
+    alg_f = alg + N * N // 2
     return {"workload": f"min-max observer + calculate_qparams, int4 g128 symmetric, {N}x{N} bf16", "alg_bytes": alg,
-            "us": round(us, 2), "GBps": round(alg / us / 1e3, 1), "frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4)}
+            "us": round(us, 2), "GBps": round(alg / us / 1e3, 1), "frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "fused_with_compress": {"entry": "ct_rtn_quant_pack_w4 (observer + quantize + pack in one pass)", "alg_bytes": alg_f, "us": round(us_f, 2),
+                                    "GBps": round(alg_f / us_f / 1e3, 1), "frac_hbm": round(alg_f / us_f / 1e3 / HBM_PEAK_GBPS, 4)}}
 
 
 def float_formats_leg(dev):

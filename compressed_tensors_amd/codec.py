@@ -23,6 +23,7 @@ __all__ = [
     "quantize_and_pack",
     "unpack_and_dequantize",
     "minmax_qparams",
+    "rtn_quantize_and_pack",
     "pack_bitmasks",
     "unpack_bitmasks",
     "W4Batch",
@@ -415,6 +416,30 @@ def minmax_qparams(x, *, num_bits, group_size=None, symmetric=True):
 
 
 # --------------------------------------------------------------------------- batched W4A16
+def rtn_quantize_and_pack(x: torch.Tensor, *, group_size: Optional[int] = None, symmetric: bool = True):
+    """Round-to-nearest int4 compress in ONE pass over the weight: min-max observer + calculate_qparams
+    (quantization/utils/helpers.py:50-137) + quantize + pack_to_int32 (compressors/pack_quantized/base.py:96-104).
+    Returns (packed int32 (R, C/8), scale (R, C/group) in x.dtype, zero_point int8 (R, C/group)) — bit-identical to
+    `minmax_qparams` followed by `quantize_and_pack`.  group_size None = one group per row (channel)."""
+    if x.dim() != 2:
+        raise ValueError("rtn_quantize_and_pack expects a 2-D weight")
+    if x.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"the one-pass compress takes 16-bit float weights, got {x.dtype}")
+    rows, cols = x.shape
+    group = int(group_size) if group_size else cols
+    if group <= 0 or cols % group != 0:
+        raise ValueError(f"tensor column shape must be divisble by the given group_size {group} but got {cols}")
+    if group % 32 != 0 or group > 2048 or (group // 32) & (group // 32 - 1):
+        raise NotImplementedError(f"the one-pass compress needs group sizes 32 * 2^k <= 2048, got {group}; use minmax_qparams + quantize_and_pack")
+    dev = _compute_device(x)
+    xd = _dev(x, dev).contiguous()
+    packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=dev)
+    scale = torch.empty((rows, cols // group), dtype=x.dtype, device=dev)
+    zp = torch.empty((rows, cols // group), dtype=torch.int8, device=dev)
+    call("ct_rtn_quant_pack_w4", ptr(xd), DT[xd.dtype], rows, cols, group, int(bool(symmetric)), ptr(packed), ptr(scale), ptr(zp), stream_of(xd))
+    return _home(packed, x), _home(scale, x), _home(zp, x)
+
+
 def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, strategy, group_size, g_idx=None) -> bool:
     """can this tensor join a one-launch W4 batch (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`)?
     int4, 2-D 16-bit weights and scales of the same dtype on a GPU, group or channel scales with

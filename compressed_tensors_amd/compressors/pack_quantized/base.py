@@ -107,6 +107,29 @@ class PackedQuantizationCompressor(BaseCompressor):
             )
         return state_dict
 
+    @classmethod
+    def compress_rtn(cls, weight: torch.Tensor, scheme) -> dict:
+        """Round-to-nearest compression straight from the dense weight (min-max qparams): the state dict
+        `compress` returns for {"weight", "weight_scale", "weight_zero_point"} with `calculate_qparams` of the weight's
+        group min / max — one pass over the weight for int4 group / channel schemes (codec.rtn_quantize_and_pack), the
+        two-kernel composition otherwise."""
+        weights = scheme.weights
+        strategy = enum_value(weights.strategy)
+        group = getattr(weights, "group_size", None) if strategy == "group" else None
+        one_pass = (int(weights.num_bits) == 4 and enum_value(getattr(weights, "type", "int")) == "int" and strategy in ("group", "channel")
+                    and weight.dim() == 2 and weight.dtype in (torch.bfloat16, torch.float16))
+        cols = weight.shape[-1]
+        g = int(group) if group else cols
+        one_pass = one_pass and g > 0 and cols % g == 0 and g % 32 == 0 and g <= 2048 and ((g // 32) & (g // 32 - 1)) == 0
+        if not one_pass:
+            scale, zp = codec.minmax_qparams(weight, num_bits=int(weights.num_bits), group_size=group, symmetric=bool(weights.symmetric))
+            return cls.compress({"weight": weight, "weight_scale": scale, "weight_zero_point": zp}, scheme)
+        packed, scale, zp = codec.rtn_quantize_and_pack(weight, group_size=group, symmetric=bool(weights.symmetric))
+        out = {"weight_packed": packed, "weight_scale": scale, "weight_shape": torch.tensor(weight.shape)}
+        if not weights.symmetric:
+            out["weight_zero_point"] = codec.pack_to_int32(zp, weights.num_bits, packed_dim=0)
+        return out
+
     # ------------------------------------------------------------------ batched module paths
     @classmethod
     def compress_modules(cls, modules) -> None:

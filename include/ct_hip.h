@@ -120,6 +120,14 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
                   int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
                   const int32_t* col_group, int bits, int tdt, int32_t* packed, ct_stream_t stream);
 
+/* Round-to-nearest W4 compress in one pass: the min-max observer + calculate_qparams
+ * (quantization/utils/helpers.py:50-137) and PackedQuantizationCompressor's weight path
+ * (compressors/pack_quantized/base.py:96-104) fused: x is read once, packed int32 (rows, cols/8), scale
+ * (rows, cols/group) in x's dtype and zero point int8 (rows, cols/group) come out.  Bit-identical to
+ * ct_minmax_qparams followed by ct_quant_pack.  group = 32 * 2^k <= 2048, cols % group == 0, int4. */
+int ct_rtn_quant_pack_w4(const void* x, int xdt, int64_t rows, int64_t cols, int64_t group, int symmetric,
+                         int32_t* packed, void* scale_out, int8_t* zp_out, ct_stream_t stream);
+
 /* Fused PackedQuantizationCompressor.decompress weight path: unpack_from_int32 followed by
  * dequantize.   base.py:155-161.  zp is the UNPACKED zero point (int8) or NULL. */
 int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_t cols, int bits,

@@ -914,3 +914,61 @@ def test_dequantize_keeps_the_sign_of_a_zero_product(cta, dev, sdt):
     s = torch.full((4, 1), 0.5, dtype=sdt)
     got = cta.codec.dequantize_tensor(d(q8, dev), d(s, dev), None)
     assert eq(got.cpu(), O.dequantize(q8, s, None)) and bool(torch.signbit(got).all())
+
+
+# ----------------------------------------------------------------------------- one-pass round-to-nearest compress (N1 fused)
+@pytest.mark.parametrize("xdt", [BF16, F16])
+@pytest.mark.parametrize("symmetric", [True, False])
+@pytest.mark.parametrize("shape,gs", [((8, 512), 128), ((5, 256), 32), ((3, 2048), 2048), ((64, 4096), 128), ((7, 1024), None), ((16, 64), 64)])
+def test_rtn_one_pass_equals_observer_plus_compress(cta, dev, xdt, symmetric, shape, gs):
+    """ct_rtn_quant_pack_w4 against the oracle's calculate_qparams + pack-quantized compress, and against the two-kernel
+    composition on the device; weights carry special values, an all-zero group and a strictly positive group"""
+    g = torch.Generator().manual_seed(shape[0] * 7 + shape[1])
+    x = (torch.randn(shape, generator=g) * 0.05).to(xdt)
+    group = gs or shape[1]
+    sp = special_values(xdt)
+    sp = sp[torch.isfinite(sp.float())]
+    x.view(-1)[: min(sp.numel(), x.numel())] = sp[: x.numel()]
+    if shape[0] > 2:
+        x[1, :group] = 0
+        x[2, :group] = x[2, :group].abs() + 0.01
+    packed, scale, zp = cta.codec.rtn_quantize_and_pack(d(x, dev), group_size=gs, symmetric=symmetric)
+    s_ref, z_ref = O.calculate_qparams_minmax(x, num_bits=4, group_size=gs, symmetric=symmetric)
+    assert eq(scale.cpu(), s_ref) and torch.equal(zp.cpu(), z_ref)
+    strategy = "group" if gs else "channel"
+    q = O.quantize(x, s_ref, z_ref, num_bits=4, strategy=strategy, group_size=gs, dtype=torch.int8)
+    assert torch.equal(packed.cpu(), O.pack_to_int32(q, 4).contiguous())
+    s2, z2 = cta.codec.minmax_qparams(d(x, dev), num_bits=4, group_size=gs, symmetric=symmetric)
+    p2 = cta.codec.quantize_and_pack(d(x, dev), s2, z2, num_bits=4, strategy=strategy, group_size=gs)
+    assert torch.equal(packed, p2) and eq(scale.cpu(), s2.cpu()) and torch.equal(zp, z2)
+
+
+def test_rtn_nan_group_and_class_api(cta, dev):
+    x = torch.randn((4, 256), dtype=BF16)
+    x[0, 3] = float("nan")
+    packed, scale, zp = cta.codec.rtn_quantize_and_pack(d(x, dev), group_size=128, symmetric=False)
+    s_ref, z_ref = O.calculate_qparams_minmax(x, num_bits=4, group_size=128, symmetric=False)
+    assert eq(scale.cpu(), s_ref) and torch.equal(zp.cpu(), z_ref)
+    q = O.quantize(x, s_ref, z_ref, num_bits=4, strategy="group", group_size=128, dtype=torch.int8)
+    assert torch.equal(packed.cpu(), O.pack_to_int32(q, 4).contiguous())
+    for sym, gs, strategy in ((True, 128, "group"), (False, 128, "group"), (True, None, "channel"), (True, 48, "group")):
+        shape = (8, 96 if gs == 48 else 512)
+        w = torch.randn(shape, dtype=BF16, device=dev)
+        args = cta.QuantizationArgs(num_bits=4, group_size=gs, symmetric=sym, strategy=strategy)
+        scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+        got = cta.PackedQuantizationCompressor.compress_rtn(w, scheme)
+        s2, z2 = cta.codec.minmax_qparams(w, num_bits=4, group_size=gs, symmetric=sym)
+        ref = cta.PackedQuantizationCompressor.compress({"weight": w, "weight_scale": s2, "weight_zero_point": z2}, scheme)
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert torch.equal(got[k].cpu(), ref[k].cpu()), (sym, gs, k)
+
+
+def test_rtn_full_size(cta, dev):
+    N = 8192
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn((N, N), generator=g, device=dev, dtype=BF16)
+    packed, scale, zp = cta.codec.rtn_quantize_and_pack(x, group_size=128, symmetric=True)
+    s2, z2 = cta.codec.minmax_qparams(x, num_bits=4, group_size=128, symmetric=True)
+    p2 = cta.codec.quantize_and_pack(x, s2, z2, num_bits=4, strategy="group", group_size=128)
+    assert torch.equal(packed, p2) and torch.equal(scale.view(torch.int16), s2.view(torch.int16)) and torch.equal(zp, z2)
