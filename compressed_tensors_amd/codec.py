@@ -262,32 +262,46 @@ def _check_qtype(qtype, num_bits):
     qtype = getattr(qtype, "value", qtype)
     if qtype not in ("int", "float"):
         raise ValueError(f"Invalid quantization type {qtype}")
-    if qtype == "float" and int(num_bits) != 8:
-        raise NotImplementedError("FLOAT quantization through quantize()/fake_quantize() is 8-bit (float8_e4m3fn); the 4-bit "
-                                  "formats have their own fused codecs (fp4_quantize_and_pack)")
+    if qtype == "float" and int(num_bits) not in (4, 8):
+        raise NotImplementedError("Only num_bits in (4, 8) are supported")  # quant_args.py:479
     return qtype
 
 
+def _gs_arg(global_scale, dev):
+    if global_scale is None:
+        return None
+    return _dev(global_scale, dev).to(torch.float32).reshape(-1)[:1].contiguous()
+
+
 def quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-                    dtype=None, g_idx=None, qtype="int") -> torch.Tensor:
+                    dtype=None, g_idx=None, qtype="int", global_scale=None) -> torch.Tensor:
     """quantization/lifecycle/forward.py:36-73: returns `dtype` (int8/int32, float8_e4m3fn for FLOAT args, or a float
-    type) or, when dtype is None, x.dtype for group strategies and the promoted type otherwise.  qtype "float" is the
-    8-bit FLOAT type: clamp to +-448 and round to float8_e4m3fn instead of rint."""
+    type) or, when dtype is None, x.dtype for group strategies and the promoted type otherwise.  qtype "float": 8 bits
+    clamp to +-448 and round to float8_e4m3fn, 4 bits clamp to +-6 and cast_to_fp4 (values stay in a float dtype), instead
+    of rint.  global_scale (FLOAT 4-bit tensor_group): the effective scale is scale / global_scale in float32."""
     qtype = _check_qtype(qtype, num_bits)
+    if global_scale is not None and not (qtype == "float" and int(num_bits) == 4):
+        raise NotImplementedError("global_scale is implemented for FLOAT 4-bit quantization")
     _check_float(x, "x")
     _check_float(scale, "scale")
     layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
     _check_sz(layout, scale, zero_point)
-    T = _result_dtype(x, scale, layout.scale_zero_dim)
+    T = _result_dtype(x, scale, layout.scale_zero_dim) if global_scale is None else torch.float32
     out_dtype = dtype if dtype is not None else (x.dtype if layout.is_group else T)
-    if out_dtype not in ((_F8, *_FLOATS) if qtype == "float" else (torch.int8, torch.int32, *_FLOATS)):
-        raise NotImplementedError(f"quantize ({qtype}) to {out_dtype} is not supported by the MI355X path")
+    fp4 = qtype == "float" and int(num_bits) == 4
+    allowed = _FLOATS if fp4 else (_F8, *_FLOATS) if qtype == "float" else (torch.int8, torch.int32, *_FLOATS)
+    if out_dtype not in allowed:
+        raise NotImplementedError(f"quantize ({qtype}, {num_bits} bits) to {out_dtype} is not supported by the MI355X path")
     dev = _compute_device(x, scale)
     xd, sd = _dev(x, dev), _dev(scale, dev)
     zd, zdt = _zp_arg(zero_point, dev)
     out = torch.empty(x.shape, dtype=out_dtype, device=dev)
     largs, _keep = layout.args(dev)
-    if qtype == "float":
+    if fp4:
+        gs = _gs_arg(global_scale, dev)
+        call("ct_quantize_fp4", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, ptr(gs), DT[T],
+             ptr(out), DT[out_dtype], stream_of(xd))
+    elif qtype == "float":
         call("ct_quantize_fp8", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, DT[T],
              ptr(out), DT[out_dtype], stream_of(xd))
     else:
@@ -297,21 +311,27 @@ def quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None
 
 
 def fake_quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-                         g_idx=None, qtype="int") -> torch.Tensor:
-    """quantization/lifecycle/forward.py:148-181 (forward_helpers.py:180-215); qtype as in quantize_tensor."""
+                         g_idx=None, qtype="int", global_scale=None) -> torch.Tensor:
+    """quantization/lifecycle/forward.py:148-181 (forward_helpers.py:180-215); qtype / global_scale as in quantize_tensor."""
     qtype = _check_qtype(qtype, num_bits)
+    if global_scale is not None and not (qtype == "float" and int(num_bits) == 4):
+        raise NotImplementedError("global_scale is implemented for FLOAT 4-bit quantization")
     _check_float(x, "x")
     _check_float(scale, "scale")
     layout = QuantLayout(x.shape, scale, strategy, group_size, block_structure, g_idx)
     _check_sz(layout, scale, zero_point)
-    T = _result_dtype(x, scale, layout.scale_zero_dim)
-    out_dtype = x.dtype if layout.is_group else scale.dtype
+    T = _result_dtype(x, scale, layout.scale_zero_dim) if global_scale is None else torch.float32
+    out_dtype = x.dtype if layout.is_group else (scale.dtype if global_scale is None else torch.float32)
     dev = _compute_device(x, scale)
     xd, sd = _dev(x, dev), _dev(scale, dev)
     zd, zdt = _zp_arg(zero_point, dev)
     out = torch.empty(x.shape, dtype=out_dtype, device=dev)
     largs, _keep = layout.args(dev)
-    if qtype == "float":
+    if qtype == "float" and int(num_bits) == 4:
+        gs = _gs_arg(global_scale, dev)
+        call("ct_fake_quantize_fp4", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, ptr(gs), DT[T],
+             ptr(out), DT[out_dtype], stream_of(xd))
+    elif qtype == "float":
         call("ct_fake_quantize_fp8", ptr(xd), DT[xd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, DT[T],
              ptr(out), DT[out_dtype], stream_of(xd))
     else:
@@ -321,7 +341,7 @@ def fake_quantize_tensor(x, scale, zero_point, *, num_bits, strategy, group_size
 
 
 def dequantize_tensor(x_q, scale, zero_point=None, *, strategy=None, group_size=None, block_structure=None,
-                      dtype=None, g_idx=None) -> torch.Tensor:
+                      dtype=None, g_idx=None, global_scale=None) -> torch.Tensor:
     """quantization/lifecycle/forward.py:76-145 (forward_helpers.py:549-572)."""
     _check_float(scale, "scale")
     if x_q.dtype not in (torch.int8, torch.int32, _F8, *_FLOATS):
@@ -338,8 +358,13 @@ def dequantize_tensor(x_q, scale, zero_point=None, *, strategy=None, group_size=
     zd, zdt = _zp_arg(zero_point, dev)
     out = torch.empty(x_q.shape, dtype=out_dtype, device=dev)
     largs, _keep = layout.args(dev)
-    call("ct_dequantize", ptr(qd), DT[qd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, ptr(out), DT[out_dtype],
-         stream_of(qd))
+    if global_scale is not None:
+        gs = _gs_arg(global_scale, dev)
+        call("ct_dequantize_gs", ptr(qd), DT[qd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, ptr(gs), ptr(out), DT[out_dtype],
+             stream_of(qd))
+    else:
+        call("ct_dequantize", ptr(qd), DT[qd.dtype], ptr(sd), DT[sd.dtype], ptr(zd), zdt, *largs, ptr(out), DT[out_dtype],
+             stream_of(qd))
     return _home(out, x_q)
 
 

@@ -104,6 +104,15 @@ __device__ __forceinline__ float fp8_round(float t) {  // value of float8(t) for
     return (t != t) ? t : r;
 }
 
+// cast_to_fp4 (quantization/utils/fp4_utils.py:77-98) of a clamped value: the E2M1 grid with RNE ties (upstream's
+// thresholds), a negative that rounds to zero gives -0.0, -0.0 itself gives +0.0 (sign(-0.0) == 0), NaN stays NaN
+__device__ __forceinline__ float fp4_round(float t) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const uint32_t b = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(0u, t + 0.0f, 0.0f, 1.0f, 0);
+    const f2 p = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(b, 1.0f, 0);
+    return (t != t) ? t : p.x;
+}
+
 // round a float to dtype DT and back: "every torch op rounds to the tensor dtype"
 template <int DT>
 __device__ __forceinline__ float round_to(float v) {

@@ -24,7 +24,9 @@ struct QParams {
     QLayout L;
     float qmin, qmax;
     int vec;            // 16-byte vector path allowed (cols % 8 == 0, pointers aligned)
-    int fkind;          // 0: INT codes (rint); 1: FLOAT 8-bit (round to float8_e4m3fn)
+    int fkind;          // 0: INT codes (rint); 1: FLOAT 8-bit (round to float8_e4m3fn); 2: FLOAT 4-bit (cast_to_fp4)
+    const float* gscale;  // nullable: effective scale = fl32(scale / gscale[0]), arithmetic in float32
+    int sdt_arith;      // dtype the dequantize arithmetic runs in: sdt, or CT_F32 under a global scale
 };
 
 // ------------------------------------------------------------------------------------------
@@ -45,7 +47,7 @@ __device__ __forceinline__ float quant_core(float x, float s, bool has_zp, float
     t = clamp_nan(t, qmin, qmax);
     // INT: v_rndne_f32 (round half to even).  FLOAT 8-bit: tensor.to(float8_e4m3fn) (quant_args.py:463-486); the
     // value is exact in every T
-    return fkind ? fp8_round(t) : __builtin_rintf(t);
+    return fkind == 2 ? fp4_round(t) : fkind ? fp8_round(t) : __builtin_rintf(t);
 }
 
 template <int SDT>
@@ -72,6 +74,7 @@ __device__ __forceinline__ SZ load_sz_q(const QParams& p, int64_t srow, int64_t 
     int64_t si = srow + col_group_of(p.L, c);
     SZ r;
     r.s = load_rt(p.scale, p.sdt, si);
+    if (p.gscale) r.s = r.s / p.gscale[0];  // scale / global_scale, float32 (forward_helpers.py:535-538)
     r.z = p.zp ? round_to<XDT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype)
     return r;
 }
@@ -80,7 +83,8 @@ template <int SDT>
 __device__ __forceinline__ SZ load_sz_dq(const QParams& p, int64_t srow, int64_t c) {
     int64_t si = srow + col_group_of(p.L, c);
     SZ r;
-    r.s = load_as_f<SDT>(p.scale, si);
+    r.s = load_rt(p.scale, p.sdt, si);  // SDT is the arithmetic dtype; the storage dtype differs under a global scale
+    if (p.gscale) r.s = r.s / p.gscale[0];
     r.z = p.zp ? round_to<SDT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
     return r;
 }
@@ -156,10 +160,10 @@ __global__ __launch_bounds__(kBlock) void quant_units_kernel(QParams p) {
                     float t = quant_core<TDT>(v[k], sz.s, has_zp, sz.z, p.qmin, p.qmax, rs, p.fkind);
                     if constexpr (MODE == MODE_FQ) {
                         // dequantize in S = scale dtype (forward_helpers.py:207-215)
-                        float zs = has_zp ? round_to_rt(p.sdt, load_rt(p.zp, p.zdt, srow + col_group_of(p.L, c0 + k))) : 0.0f;
-                        float d = round_to_rt(p.sdt, t);
-                        if (has_zp) d = round_to_rt(p.sdt, d - zs);
-                        t = mul_round_to_rt(p.sdt, d, sz.s);
+                        float zs = has_zp ? round_to_rt(p.sdt_arith, load_rt(p.zp, p.zdt, srow + col_group_of(p.L, c0 + k))) : 0.0f;
+                        float d = round_to_rt(p.sdt_arith, t);
+                        if (has_zp) d = round_to_rt(p.sdt_arith, d - zs);
+                        t = mul_round_to_rt(p.sdt_arith, d, sz.s);
                     }
                     v[k] = t;
                 }
@@ -1014,6 +1018,8 @@ static int fill_qparams(QParams& p, const void* x, int xdt, const void* scale, i
     p.qmin = -(float)((1 << bits) / 2);
     p.vec = (cols % 8 == 0) && aligned16(x) && aligned16(out);
     p.fkind = 0;
+    p.gscale = nullptr;
+    p.sdt_arith = sdt;
     return CT_OK;
 }
 
@@ -1071,9 +1077,18 @@ using namespace ct;
 
 extern "C" {
 
+static void set_float_kind(QParams& p, int fkind, const float* gscale) {
+    p.fkind = fkind;
+    if (fkind == 1) { p.qmin = -448.0f; p.qmax = 448.0f; }  // torch.finfo(float8_e4m3fn) (utils/helpers.py:212-214)
+    if (fkind == 2) { p.qmin = -6.0f; p.qmax = 6.0f; }      // FP4_E2M1_DATA (utils/helpers.py:215-217)
+    p.gscale = gscale;
+    if (gscale) p.sdt_arith = CT_F32;
+}
+
 static int quantize_impl(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
                          int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
-                         int bits, int fkind, int tdt, void* out, int odt, ct_stream_t stream) {
+                         int bits, int fkind, int tdt, void* out, int odt, ct_stream_t stream, const float* gscale = nullptr) {
+    CT_REQUIRE(gscale == nullptr || tdt == CT_F32, "a global scale makes the quotient float32; got result dtype %d", tdt);
     CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
     CT_REQUIRE(xt_ok(xdt, tdt), "unsupported (x dtype, result dtype) = (%d, %d)", xdt, tdt);
     if (fkind) CT_REQUIRE(odt == CT_F8E4M3 || is_float_dt(odt), "unsupported output dtype %d", odt);
@@ -1081,9 +1096,9 @@ static int quantize_impl(const void* x, int xdt, const void* scale, int sdt, con
     QParams p;
     int rc = fill_qparams(p, x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, out, odt);
     if (rc) return rc;
-    if (fkind) { p.fkind = 1; p.qmin = -448.0f; p.qmax = 448.0f; }  // torch.finfo(float8_e4m3fn) (helpers.py:212-214)
+    set_float_kind(p, fkind, gscale);
     if (rows == 0 || cols == 0) return CT_OK;
-    if ((fkind ? odt == CT_F8E4M3 : odt == CT_I8) && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, out)) {
+    if (!gscale && fkind != 2 && (fkind ? odt == CT_F8E4M3 : odt == CT_I8) && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         const bool shared = (cdiv % 16 == 0) || cdiv >= cols;
         dim3 g8(w4_grid(w.units / 2, 1));
@@ -1107,16 +1122,17 @@ static int quantize_impl(const void* x, int xdt, const void* scale, int sdt, con
 
 static int fake_quantize_impl(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
                               int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
-                              int bits, int fkind, int tdt, void* out, int odt, ct_stream_t stream) {
+                              int bits, int fkind, int tdt, void* out, int odt, ct_stream_t stream, const float* gscale = nullptr) {
     CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
     CT_REQUIRE(xt_ok(xdt, tdt), "unsupported (x dtype, result dtype) = (%d, %d)", xdt, tdt);
     CT_REQUIRE(is_float_dt(odt), "unsupported output dtype %d", odt);
+    CT_REQUIRE(gscale == nullptr || tdt == CT_F32, "a global scale makes the quotient float32; got result dtype %d", tdt);
     QParams p;
     int rc = fill_qparams(p, x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, bits, out, odt);
     if (rc) return rc;
-    if (fkind) { p.fkind = 1; p.qmin = -448.0f; p.qmax = 448.0f; }
+    set_float_kind(p, fkind, gscale);
     if (rows == 0 || cols == 0) return CT_OK;
-    if (odt == xdt && !col_group && (xdt == CT_BF16 || xdt == CT_F16) && sdt == xdt && tdt == xdt && cols % 8 == 0 &&
+    if (!gscale && odt == xdt && !col_group && (xdt == CT_BF16 || xdt == CT_F16) && sdt == xdt && tdt == xdt && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(x) && aligned16(out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         constexpr int U = 2;
@@ -1156,9 +1172,39 @@ int ct_fake_quantize_fp8(const void* x, int xdt, const void* scale, int sdt, con
     return fake_quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, 8, 1, tdt, out, odt, stream);
 }
 
+int ct_quantize_fp4(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                    int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                    const float* global_scale, int tdt, void* out, int odt, ct_stream_t stream) {
+    CT_REQUIRE(is_float_dt(odt), "FLOAT 4-bit values are returned in a float dtype, got %d", odt);
+    return quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, 4, 2, tdt, out, odt, stream, global_scale);
+}
+
+int ct_fake_quantize_fp4(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                         int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                         const float* global_scale, int tdt, void* out, int odt, ct_stream_t stream) {
+    return fake_quantize_impl(x, xdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, 4, 2, tdt, out, odt, stream, global_scale);
+}
+
+static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                           int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                           void* out, int odt, ct_stream_t stream, const float* gscale);
+
 int ct_dequantize(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
                   int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
                   void* out, int odt, ct_stream_t stream) {
+    return dequantize_impl(xq, qdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, out, odt, stream, nullptr);
+}
+
+int ct_dequantize_gs(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                     int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                     const float* global_scale, void* out, int odt, ct_stream_t stream) {
+    CT_REQUIRE(global_scale != nullptr, "ct_dequantize_gs needs a global scale");
+    return dequantize_impl(xq, qdt, scale, sdt, zp, zdt, rows, cols, rdiv, cdiv, scale_cols, col_group, out, odt, stream, global_scale);
+}
+
+static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt, int64_t rows,
+                           int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols, const int32_t* col_group,
+                           void* out, int odt, ct_stream_t stream, const float* gscale) {
     CT_REQUIRE(is_float_dt(odt), "unsupported output dtype %d", odt);
     CT_REQUIRE(qdt == CT_I8 || qdt == CT_I32 || qdt == CT_F8E4M3 || is_float_dt(qdt), "unsupported x_q dtype %d", qdt);
     QParams p;
@@ -1166,7 +1212,8 @@ int ct_dequantize(const void* xq, int qdt, const void* scale, int sdt, const voi
     if (rc) return rc;
     if (rows == 0 || cols == 0) return CT_OK;
     p.vec = (cols % 8 == 0) && aligned16(out) && ((reinterpret_cast<uintptr_t>(xq) & 7u) == 0);
-    if ((qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
+    set_float_kind(p, 0, gscale);
+    if (!gscale && (qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         constexpr int U = 2;
@@ -1179,7 +1226,7 @@ int ct_dequantize(const void* xq, int qdt, const void* scale, int sdt, const voi
         CT_LAUNCH_CHECK("ct_dequantize[flat8]");
     }
     dim3 grid = grid_2d(rows, cdiv64(cols, 8));
-    switch (sdt) {
+    switch (p.sdt_arith) {
         case CT_BF16: hipLaunchKernelGGL((dequant_units_kernel<CT_BF16>), grid, dim3(kBlock), 0, as_stream(stream), p); break;
         case CT_F16: hipLaunchKernelGGL((dequant_units_kernel<CT_F16>), grid, dim3(kBlock), 0, as_stream(stream), p); break;
         default: hipLaunchKernelGGL((dequant_units_kernel<CT_F32>), grid, dim3(kBlock), 0, as_stream(stream), p); break;

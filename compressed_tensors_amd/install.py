@@ -109,8 +109,9 @@ def install():
 
         def _req(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
             return (
-                x.is_cuda and global_scale is None
-                and (enum_value(getattr(args, "type", "int")) == "int" or int(args.num_bits) == 8)
+                x.is_cuda
+                and (enum_value(getattr(args, "type", "int")) == "int" or int(args.num_bits) in (4, 8))
+                and (global_scale is None or (enum_value(getattr(args, "type", "int")) == "float" and int(args.num_bits) == 4))
                 and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
                 and dtype in (None, torch.int8, torch.int32, torch.float8_e4m3fn, torch.float32, torch.float16, torch.bfloat16)
                 and x.is_contiguous() and _broadcast_layout(x, scale) is not None
@@ -123,8 +124,8 @@ def install():
             out = codec.quantize_tensor(
                 x2, scale.reshape(layout["scale_shape"]), None if zero_point is None else zero_point.reshape(layout["scale_shape"]),
                 num_bits=int(args.num_bits), strategy=layout["strategy"], group_size=layout.get("group_size"),
-                qtype=enum_value(getattr(args, "type", "int")),
-                dtype=dtype if dtype is not None else torch.result_type(x, scale),
+                qtype=enum_value(getattr(args, "type", "int")), global_scale=global_scale,
+                dtype=dtype if dtype is not None else (torch.float32 if global_scale is not None else torch.result_type(x, scale)),
             )
             return out.reshape(x.shape)
 

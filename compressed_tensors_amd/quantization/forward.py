@@ -1,10 +1,9 @@
 """quantize / dequantize / fake_quantize with the reference's signatures
 (quantization/lifecycle/forward.py:36-181), executed by the HIP kernels.
 
-Scope: INT quantization (num_bits 1..8) and FLOAT 8-bit (float8_e4m3fn), strategies tensor / channel /
-token / group / block, optional activation ordering (g_idx).  The 4-bit FLOAT formats (`global_scale`,
-tensor-group) are served by their own fused codecs (compressors/fp4, codec.fp4_quantize_and_pack) and
-raise NotImplementedError here.
+Scope: INT quantization (num_bits 1..8), FLOAT 8-bit (float8_e4m3fn) and FLOAT 4-bit (E2M1, optionally under a
+`global_scale`: the tensor_group strategy), strategies tensor / channel / token / group / tensor_group / block,
+optional activation ordering (g_idx).
 """
 from typing import Optional
 
@@ -17,9 +16,8 @@ __all__ = ["quantize", "dequantize", "fake_quantize", "calculate_range"]
 
 
 def _int_args(args, global_scale):
-    if global_scale is not None:
-        raise NotImplementedError("global_scale (FP4 tensor-group quantization) goes through codec.fp4_quantize_and_pack")
     return dict(
+        global_scale=global_scale,
         qtype=enum_value(getattr(args, "type", "int")),
         num_bits=int(args.num_bits),
         strategy=enum_value(args.strategy),
@@ -50,11 +48,9 @@ def quantize(x: torch.Tensor, scale: torch.Tensor, zero_point: Optional[torch.Te
 @torch.no_grad()
 def dequantize(x_q: torch.Tensor, scale: torch.Tensor, zero_point: Optional[torch.Tensor] = None, args=None, dtype=None,
                g_idx: Optional[torch.Tensor] = None, global_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    if global_scale is not None:
-        raise NotImplementedError("global_scale (FP4 tensor-group quantization) is not on the MI355X hot path")
-    kw = {}
+    kw = {"global_scale": global_scale}
     if args is not None:
-        kw = _int_args(args, None)
+        kw = _int_args(args, global_scale)
         kw.pop("num_bits")
         kw.pop("qtype")
     return codec.dequantize_tensor(x_q, scale, zero_point, dtype=dtype, g_idx=g_idx, **kw)

@@ -113,6 +113,25 @@ int ct_fake_quantize_fp8(const void* x, int xdt, const void* scale, int sdt, con
                          int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
                          const int32_t* col_group, int tdt, void* out, int odt, ct_stream_t stream);
 
+/* FLOAT 4-bit args (E2M1; quant_args.py:463-486 -> cast_to_fp4, range +-6 utils/helpers.py:215-217), optionally
+ * under a global scale (tensor_group strategy: effective scale = fl32(scale / global_scale[0]), the quotient and the
+ * dequantize arithmetic are float32 then, forward_helpers.py:535-538,560-563; tdt must be CT_F32).  Values come back
+ * in a float dtype (upstream has no 4-bit storage dtype; the packed weight path is ct_fp4_quant_pack).
+ * global_scale: device float32[1] or NULL. */
+int ct_quantize_fp4(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                    int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                    const int32_t* col_group, const float* global_scale, int tdt, void* out, int odt,
+                    ct_stream_t stream);
+int ct_fake_quantize_fp4(const void* x, int xdt, const void* scale, int sdt, const void* zp, int zdt,
+                         int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                         const int32_t* col_group, const float* global_scale, int tdt, void* out, int odt,
+                         ct_stream_t stream);
+/* dequantize(x_q, scale, zero_point, global_scale=...): arithmetic in float32 */
+int ct_dequantize_gs(const void* xq, int qdt, const void* scale, int sdt, const void* zp, int zdt,
+                     int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                     const int32_t* col_group, const float* global_scale, void* out, int odt,
+                     ct_stream_t stream);
+
 /* Fused PackedQuantizationCompressor.compress weight path: quantize(dtype=int8) followed by
  * pack_to_int32, without the int8 intermediate.   compressors/pack_quantized/base.py:96-104
  * packed: int32 (rows, ceil(cols*bits/32)) contiguous */

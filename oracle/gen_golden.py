@@ -466,10 +466,62 @@ def gen_fp8():
     save("fp8", tensors, {"cases": cases, "codecs": codec_cases})
 
 
+# ----------------------------------------------------------------------------- FLOAT 4-bit quantize / dequantize / fake_quantize
+def gen_fp4q():
+    """quantize / dequantize / fake_quantize with FLOAT 4-bit args (the QDQ form of the NVFP4 / MXFP4 schemes): with and
+    without a global scale, group / tensor_group / channel / tensor strategies."""
+    from compressed_tensors.quantization.utils import generate_gparam
+
+    g = torch.Generator().manual_seed(4444)
+    tensors, cases = {}, []
+    configs = [
+        ("nv_tg16", dict(strategy="tensor_group", group_size=16, scale_dtype=torch.float8_e4m3fn, zp_dtype=torch.float8_e4m3fn), (8, 64), True),
+        ("mx_g32", dict(strategy="group", group_size=32, scale_dtype=torch.uint8, zp_dtype=torch.uint8), (6, 128), False),
+        ("g16_plain", dict(strategy="group", group_size=16), (5, 64), False),
+        ("ch", dict(strategy="channel"), (9, 40), False),
+        ("t", dict(strategy="tensor"), (4, 24), False),
+    ]
+    for name, kw0, shape, use_gs in configs:
+        kw = dict(num_bits=4, type="float", symmetric=True, **kw0)
+        args = QuantizationArgs(**kw)
+        for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+            key = f"{name}_{dt_name}"
+            x = torch.randn(shape, generator=g).mul(2.0).to(dt)
+            sp = special_values(dt)
+            x.view(-1)[: sp.numel()] = sp[: x.numel()]
+            xf = torch.nan_to_num(x.float(), nan=0.0, posinf=4.0, neginf=-4.0).clamp(-9, 9).to(dt)
+            gs = generate_gparam(xf.min().reshape(1), xf.max().reshape(1)) if use_gs else None
+            st = kw0["strategy"]
+            if st in ("group", "tensor_group"):
+                xg = xf.unflatten(-1, (shape[1] // kw0["group_size"], kw0["group_size"]))
+                mn, mx = torch.aminmax(xg, dim=-1)
+            elif st == "channel":
+                mn, mx = torch.aminmax(xf, dim=-1, keepdim=True)
+            else:
+                mn, mx = torch.aminmax(xf)
+            scale, zp = calculate_qparams(mn, mx, args, global_scale=gs)
+            s0 = (scale.reshape(-1)[0].float() / (gs[0].float() if gs is not None else 1.0))
+            edge = torch.tensor([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 6.0, 7.0, -0.25, -0.2, -2.5, 0.26, 0.74, -6.5, 1e-4])
+            n0 = min(sp.numel(), x.numel() - edge.numel())
+            x.view(-1)[n0: n0 + edge.numel()] = (edge * s0).to(dt)
+            qf = quantize(x, scale, zp, args, global_scale=gs)
+            qf_nozp = quantize(x, scale, None, args, global_scale=gs)
+            fq = fake_quantize(x, scale, zp, args, global_scale=gs)
+            dq = dequantize(qf, scale, zp, args=args, global_scale=gs)
+            tensors.update({key + ".x": x, key + ".scale": scale.view(torch.uint8) if scale.dtype == torch.float8_e4m3fn else scale,
+                            key + ".zp": zp.view(torch.uint8) if zp.dtype == torch.float8_e4m3fn else zp,
+                            key + ".qf": qf, key + ".qf_nozp": qf_nozp, key + ".fq": fq, key + ".dq": dq})
+            if gs is not None:
+                tensors[key + ".gs"] = gs
+            cases.append({"key": key, "args": {k: v for k, v in kw0.items() if not k.endswith("_dtype")}, "shape": list(shape), "global_scale": use_gs,
+                          "scale_dtype": str(scale.dtype).split(".")[-1], "zp_dtype": str(zp.dtype).split(".")[-1]})
+    save("fp4q", tensors, {"cases": cases})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     families = {"pack": gen_pack, "quant": gen_quant, "qparams": gen_qparams, "compressors": gen_compressors, "sparse": gen_sparse,
-                "fp4": gen_fp4, "fp8": gen_fp8}
+                "fp4": gen_fp4, "fp8": gen_fp8, "fp4q": gen_fp4q}
     wanted = sys.argv[1:] or list(families)  # `python oracle/gen_golden.py fp4` regenerates one family only
     mpath = os.path.join(OUT, "manifest.json")
     if os.path.exists(mpath) and sys.argv[1:]:

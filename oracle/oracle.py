@@ -158,7 +158,7 @@ def _result_code(x, scale, zero_dim):
 
 
 def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size, block_structure,
-                  g_idx, out_dtype, with_bits=True):
+                  g_idx, out_dtype, with_bits=True, global_scale=None):
     """`out_dtype` may be a torch dtype or a callable mapping T (torch dtype) -> torch dtype."""
     x = _cpu(x)
     scale = _cpu(scale)
@@ -166,7 +166,10 @@ def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size,
     rows, cols, rdiv, cdiv, scols, zero_dim = _resolve(x, scale, strategy, group_size, block_structure)
     is_group = str(getattr(strategy, "value", strategy)) in ("group", "tensor_group")
     cg = _col_group(g_idx, group_size) if is_group else None
-    tdt = _result_code(x, scale, zero_dim) if with_bits else None
+    tdt = _result_code(x, scale, zero_dim) if with_bits in (True, "fl", "tdt") else None
+    gs = _cpu(global_scale).to(torch.float32).reshape(-1)[:1].contiguous() if global_scale is not None else None
+    if gs is not None and with_bits:
+        tdt = F32  # scale / global_scale is float32, and so is x / that
     if callable(out_dtype):
         out_dtype = out_dtype(_FLOAT_CODE_TO_TORCH[tdt])
     if out_dtype not in _DT:
@@ -174,7 +177,11 @@ def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size,
     out = torch.empty(x.shape, dtype=out_dtype)
     args = [_p(x), _DT[x.dtype], _p(scale), _DT[scale.dtype], _p(zp), _DT[zp.dtype] if zp is not None else -1,
             _i64(rows), _i64(cols), _i64(rdiv), _i64(cdiv), _i64(scols), _p(cg)]
-    if with_bits == "tdt":
+    if with_bits == "fl":  # (fkind, global scale, tdt)
+        args += [num_bits, _p(gs), tdt]
+    elif with_bits == "gs":
+        args += [_p(gs)]
+    elif with_bits == "tdt":
         args += [tdt]
     elif with_bits:
         args += [num_bits, tdt]
@@ -185,7 +192,7 @@ def _quant_common(fn_name, x, scale, zero_point, num_bits, strategy, group_size,
 
 
 def quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-             dtype=None, g_idx=None, qtype="int"):
+             dtype=None, g_idx=None, qtype="int", global_scale=None):
     """forward.py:36-73.  Output dtype: `dtype`; else x.dtype for group strategies
     (forward_helpers.py:134,171) and the promoted float type T of x / scale otherwise."""
     is_group = str(getattr(strategy, "value", strategy)) in ("group", "tensor_group")
@@ -195,16 +202,16 @@ def quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, block
             return dtype
         return x.dtype if is_group else T
 
-    if qtype == "float":  # FLOAT 8-bit: clamp to +-448, round to float8_e4m3fn (quant_args.py:463-486)
-        assert num_bits == 8
-        return _quant_common("cto_quantize_f8", x, scale, zero_point, 8, strategy, group_size,
-                             block_structure, g_idx, out_dtype, with_bits="tdt")
+    if qtype == "float":  # FLOAT 8-bit: clamp to +-448, round to float8_e4m3fn; 4-bit: +-6, cast_to_fp4 (quant_args.py:463-486)
+        assert num_bits in (8, 4)
+        return _quant_common("cto_quantize_fl", x, scale, zero_point, 1 if num_bits == 8 else 2, strategy, group_size,
+                             block_structure, g_idx, out_dtype, with_bits="fl", global_scale=global_scale)
     return _quant_common("cto_quantize", x, scale, zero_point, num_bits, strategy, group_size,
                          block_structure, g_idx, out_dtype)
 
 
 def dequantize(x_q, scale, zero_point=None, *, strategy=None, group_size=None, block_structure=None,
-               dtype=None, g_idx=None):
+               dtype=None, g_idx=None, global_scale=None):
     """forward.py:76-145 (strategy inferred from the scale shape when not given)."""
     if strategy is None:
         if scale.ndim in (0, 1):
@@ -223,20 +230,23 @@ def dequantize(x_q, scale, zero_point=None, *, strategy=None, group_size=None, b
                 "dimmensions. Expected 0 or 2 dimmensions."
             )
     out_dtype = dtype if dtype is not None else scale.dtype
+    if global_scale is not None:
+        return _quant_common("cto_dequantize_gs", x_q, scale, zero_point, 0, strategy, group_size,
+                             block_structure, g_idx, out_dtype, with_bits="gs", global_scale=global_scale)
     return _quant_common("cto_dequantize", x_q, scale, zero_point, 0, strategy, group_size,
                          block_structure, g_idx, out_dtype, with_bits=False)
 
 
 def fake_quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, block_structure=None,
-                  g_idx=None, qtype="int"):
+                  g_idx=None, qtype="int", global_scale=None):
     """forward.py:148-181.  Group strategies cast back to x.dtype (forward_helpers.py:134,171);
     the others return scale.dtype (dequant * scale)."""
     st = str(getattr(strategy, "value", strategy))
     out_dtype = x.dtype if st in ("group", "tensor_group") else scale.dtype
     if qtype == "float":
-        assert num_bits == 8
-        return _quant_common("cto_fake_quantize_f8", x, scale, zero_point, 8, strategy, group_size,
-                             block_structure, g_idx, out_dtype, with_bits="tdt")
+        assert num_bits in (8, 4)
+        return _quant_common("cto_fake_quantize_fl", x, scale, zero_point, 1 if num_bits == 8 else 2, strategy, group_size,
+                             block_structure, g_idx, out_dtype, with_bits="fl", global_scale=global_scale)
     return _quant_common("cto_fake_quantize", x, scale, zero_point, num_bits, strategy, group_size,
                          block_structure, g_idx, out_dtype)
 

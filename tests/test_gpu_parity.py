@@ -972,3 +972,38 @@ def test_rtn_full_size(cta, dev):
     s2, z2 = cta.codec.minmax_qparams(x, num_bits=4, group_size=128, symmetric=True)
     p2 = cta.codec.quantize_and_pack(x, s2, z2, num_bits=4, strategy="group", group_size=128)
     assert torch.equal(packed, p2) and torch.equal(scale.view(torch.int16), s2.view(torch.int16)) and torch.equal(zp, z2)
+
+
+# ----------------------------------------------------------------------------- FLOAT 4-bit quantize / dequantize / fake_quantize
+@pytest.mark.parametrize("case", cases("fp4q"), ids=lambda c: c["key"])
+def test_fp4_quant_golden(golden, cta, dev, case):
+    """quantize / fake_quantize / dequantize with FLOAT 4-bit args (NVFP4's tensor_group + global scale, MXFP4's group 32,
+    plain group / channel / tensor) against the reference's outputs"""
+    from compressed_tensors_amd.quantization import dequantize, fake_quantize, quantize
+
+    t = golden.case("fp4q", case["key"])
+    a = case["args"]
+    args = cta.QuantizationArgs(num_bits=4, type="float", symmetric=True, strategy=a["strategy"], group_size=a.get("group_size"))
+    zp = _f8(t["zp"]) if case["zp_dtype"] == "float8_e4m3fn" else t["zp"]
+    x, s, z, gs = d(t["x"], dev), d(t["scale"], dev), d(zp, dev), d(t.get("gs"), dev)
+    assert eq(quantize(x, s, z, args, global_scale=gs).cpu(), t["qf"])
+    assert eq(quantize(x, s, None, args, global_scale=gs).cpu(), t["qf_nozp"])
+    assert eq(fake_quantize(x, s, z, args, global_scale=gs).cpu(), t["fq"])
+    assert eq(dequantize(d(t["qf"], dev), s, z, args=args, global_scale=gs).cpu(), t["dq"])
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_fp4_quantize_all_inputs(cta, dev, xdt):
+    """every 16-bit input through the generic FLOAT 4-bit path: in-dtype scales (fq16 fast path and the unit kernel) and
+    float32 scales under a global scale"""
+    x = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(xdt).reshape(256, 256)
+    g = torch.Generator().manual_seed(9)
+    for sdt, gsval in ((xdt, None), (F32, None), (F32, 37.5)):
+        s = (torch.rand((256, 16), generator=g) * 2 + 0.05).to(sdt)
+        gs = None if gsval is None else torch.tensor([gsval], dtype=F32)
+        for z in (None, torch.zeros((256, 16), dtype=F8)):
+            kw = dict(num_bits=4, strategy="group", group_size=16, qtype="float", global_scale=gs)
+            got = cta.codec.quantize_tensor(d(x, dev), d(s, dev), d(z, dev), **{**kw, "global_scale": d(gs, dev)})
+            assert eq(got.cpu(), O.quantize(x, s, z, **kw)), (sdt, gsval, z is None)
+            fq = cta.codec.fake_quantize_tensor(d(x, dev), d(s, dev), d(z, dev), **{**kw, "global_scale": d(gs, dev)})
+            assert eq(fq.cpu(), O.fake_quantize(x, s, z, **kw)), (sdt, gsval, z is None)

@@ -87,7 +87,7 @@ def test_argument_errors_match_reference(cta):
     with pytest.raises(ValueError, match="divisble"):
         cta.codec.QuantLayout((4, 100), torch.ones(4, 1), "group", group_size=64)
     with pytest.raises(NotImplementedError):
-        args = cta.QuantizationArgs(num_bits=4, type="float")  # FLOAT 4-bit goes through the fused FP4 codecs
+        args = cta.QuantizationArgs(num_bits=6, type="float")  # FLOAT types exist for 4 and 8 bits only (quant_args.py:479)
         cta.quantize(torch.zeros(2, 2), torch.ones(1), None, args)
     with pytest.raises(ValueError, match="Could not infer"):
         from compressed_tensors_amd.codec import infer_dequant_layout

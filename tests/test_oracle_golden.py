@@ -358,3 +358,23 @@ def test_fp8_codecs_golden(golden, case):
     # padded block layout (300 x 400 under 128 x 128 blocks -> scale 3 x 4) means 100 x 100 blocks, as upstream
     d = O.dequantize(_f8(exp_c["weight"]), scale, None)
     assert eq(d, exp_d["weight"])
+
+
+# ----------------------------------------------------------------------------- FLOAT 4-bit quantize / dequantize / fake_quantize
+def _fp4q_inputs(t, case):
+    zp = _f8(t["zp"]) if case["zp_dtype"] == "float8_e4m3fn" else t["zp"]
+    a = case["args"]
+    kw = dict(num_bits=4, strategy=a["strategy"], group_size=a.get("group_size"), qtype="float", global_scale=t.get("gs"))
+    return zp, kw
+
+
+@pytest.mark.parametrize("case", cases("fp4q"), ids=lambda c: c["key"])
+def test_fp4_quant_golden(golden, case):
+    """quantize / fake_quantize / dequantize with FLOAT 4-bit args, with and without a global scale"""
+    t = golden.case("fp4q", case["key"])
+    zp, kw = _fp4q_inputs(t, case)
+    assert eq(O.quantize(t["x"], t["scale"], zp, **kw), t["qf"])
+    assert eq(O.quantize(t["x"], t["scale"], None, **kw), t["qf_nozp"])
+    assert eq(O.fake_quantize(t["x"], t["scale"], zp, **kw), t["fq"])
+    dkw = {k: v for k, v in kw.items() if k not in ("num_bits", "qtype")}
+    assert eq(O.dequantize(t["qf"], t["scale"], zp, **dkw), t["dq"])
