@@ -670,7 +670,14 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
 // Measured alternatives at 8192^2 bf16 (profiles/): count + single-block scan + scatter
 // 87 us; single-kernel decoupled look-back 171 us and count + non-blocking look-back scatter 133 us
 // (a cross-CU status poll costs 3-5 us on the consumer under streaming load and the nearest resolved
-// prefix is ~1000 tiles back, so every tile paid several dependent polls).
+// prefix is ~1000 tiles back, so every tile paid several dependent polls).  A second single-pass form — tile
+// kept in registers, counts published, a TWO-LEVEL prefix (64-tile group sums + in-group counts: two independent
+// 64-lane loads, no chain) — was bit-exact but no faster: 327 us with an atomic ticket per tile (4096 same-address
+// device-scope atomics serialise at ~40 ns each), 267 us with agent-scope relaxed stores (they sit in the writer's
+// XCD-local L2 until evicted), 102 us with system-scope write-through stores and loads; the same kernel WITHOUT
+// waiting for the prefix runs in 45 us, so the 8-XCD hand-off alone costs more than the second read it saves
+// (~130 KB of tile data per CU can be held in registers; at 22 GB/s per CU that allows a 6 us tile lifetime,
+// the publish -> visible -> poll round trip is longer).
 constexpr int kWT = 256;  // units per wave-tile
 
 struct Flat16Plan {
