@@ -466,6 +466,10 @@ def main():
 
     import __graft_entry__ as ge
 
+    if distributed:  # one rank (re)builds if the in-tree library is stale, the others wait: no concurrent writers
+        if rank == 0:
+            ge.build_hip()
+        dist.barrier()
     ge.build_hip()  # no-op when the in-tree library is current
     sets = make_sets(dev, rank)
     stream = torch.cuda.current_stream(dev).cuda_stream
