@@ -1007,3 +1007,30 @@ def test_fp4_quantize_all_inputs(cta, dev, xdt):
             assert eq(got.cpu(), O.quantize(x, s, z, **kw)), (sdt, gsval, z is None)
             fq = cta.codec.fake_quantize_tensor(d(x, dev), d(s, dev), d(z, dev), **{**kw, "global_scale": d(gs, dev)})
             assert eq(fq.cpu(), O.fake_quantize(x, s, z, **kw)), (sdt, gsval, z is None)
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """the N > 1 path of bench.py (launch contract, barrier, max-over-ranks timing, rank-sharded checkpoint leg) with
+    both ranks on cuda:0 and the timing collectives over gloo (CT_BENCH_SHARE_GPU=1)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CT_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2 and out["scaling"] == "weak" and out["parity_gate"] is True
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+    leg = out["tinyllama_checkpoint"]
+    assert leg["round_trip_equals_fake_quantize"] is True and 0 < leg["modules_this_rank"] < 154
