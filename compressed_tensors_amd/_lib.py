@@ -83,6 +83,7 @@ _PROTOTYPES = {
     "ct_marlin24_compress_w4": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _P, _S], _I),
     "ct_marlin24_pack_weights": ([_P, _I, _I, _I, _L, _L, _I, _P, _S], _I),
     "ct_marlin24_pack_scales": ([_P, _I, _L, _L, _I, _P, _S], _I),
+    "ct_marlin24_pack_scales_f16": ([_P, _I, _L, _L, _I, _P, _S], _I),
     "ct_selftest_bf16_div": ([_c.c_uint32, _c.c_uint32, _P, _S], _I),
     "ct_selftest_f16_div": ([_c.c_uint32, _c.c_uint32, _P, _S], _I),
 }

@@ -762,13 +762,14 @@ def marlin24_pack_weights(q: torch.Tensor, num_bits: int, *, transposed: bool = 
     return _home(out, q)
 
 
-def marlin24_pack_scales(scale: torch.Tensor, *, single: bool):
-    """marlin-24 scale packing: (size_n, groups) -> permuted (groups, size_n)."""
+def marlin24_pack_scales(scale: torch.Tensor, *, single: bool, to_float16: bool = False):
+    """marlin-24 scale packing: (size_n, groups) -> permuted (groups, size_n); to_float16 folds the reference's
+    `scale.to(torch.float16)` into the same kernel (a bfloat16 scale comes out as float16)."""
     dev = _compute_device(scale)
     s = _dev(scale, dev)
     size_n, groups = s.shape
-    out = torch.empty((groups, size_n), dtype=s.dtype, device=dev)
-    call("ct_marlin24_pack_scales", ptr(s), DT[s.dtype], size_n, groups, int(single), ptr(out), stream_of(s))
+    out = torch.empty((groups, size_n), dtype=torch.float16 if to_float16 else s.dtype, device=dev)
+    call("ct_marlin24_pack_scales_f16" if to_float16 else "ct_marlin24_pack_scales", ptr(s), DT[s.dtype], size_n, groups, int(single), ptr(out), stream_of(s))
     return _home(out, scale)
 
 

@@ -60,25 +60,24 @@ class Marlin24Compressor(BaseCompressor):
         weights = scheme.weights
         cls.validate_quant_compatability(weights)
 
-        scale16 = scale.to(torch.float16)
         group_size = getattr(weights, "group_size", None)
-        fused_ok = (weight.dtype in (torch.float16, torch.bfloat16) and weight.dim() == 2 and weight.shape[0] % 64 == 0
-                    and weight.shape[1] % 16 == 0
+        fused_ok = (weight.dtype in (torch.float16, torch.bfloat16) and scale.dtype in (torch.float16, torch.bfloat16) and weight.dim() == 2
+                    and weight.shape[0] % 64 == 0 and weight.shape[1] % 16 == 0
                     and (enum_value(weights.strategy) == "channel" or (group_size and group_size % 16 == 0 and weight.shape[1] % group_size == 0)))
+        bad = None
         if fused_ok:
-            # one pass: weight.to(fp16) / quantize in fp16 / 2:4 structure check / cutlass 2:4 compress
+            # one pass: weight.to(fp16) / scale.to(fp16) / quantize in fp16 / 2:4 structure check / cutlass 2:4 compress.
+            # Everything is queued before the flag is read, so the host work below overlaps the kernels
             g = None if enum_value(weights.strategy) == "channel" else group_size
             size_n, size_k = weight.shape[0], weight.shape[1] // 2
             if int(weights.num_bits) == 4 and weight.shape[1] % 256 == 0:
                 # everything in one launch: no int8 intermediate, no separate packing kernel
-                packed, meta, bad = codec.marlin24_compress_w4(weight, scale16, zero_point, group_size=g)
+                packed, meta, bad = codec.marlin24_compress_w4(weight, scale, zero_point, group_size=g)
             else:
-                comp, meta, bad = codec.marlin24_quant_compress(weight, scale16, zero_point, num_bits=int(weights.num_bits), group_size=g)
+                comp, meta, bad = codec.marlin24_quant_compress(weight, scale, zero_point, num_bits=int(weights.num_bits), group_size=g)
                 packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
-            if int(bad.item()):  # one host read, as the reference pipeline's structure check
-                raise ValueError("Marlin24 Compressor is only compatible with weights that have a 2:4 sparsity structure. "
-                                 "Found segments in weight that do not match the expected structure.")
         else:
+            scale16 = scale.to(torch.float16)
             w16 = weight.to(torch.float16)
             q = codec.quantize_tensor(
                 w16, scale16, zero_point, num_bits=int(weights.num_bits), strategy=enum_value(weights.strategy),
@@ -89,9 +88,15 @@ class Marlin24Compressor(BaseCompressor):
             size_n, size_k = comp.shape  # the kernel expects input-dim first: packed from comp.T
             packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
         is_group = enum_value(weights.strategy) == "group" and group_size is not None and group_size < size_k
-        scale2d = scale16.reshape(scale16.shape[0], -1)
-        scale_packed = codec.marlin24_pack_scales(scale2d, single=not is_group)
+        scale2d = scale.reshape(scale.shape[0], -1)
+        if scale2d.dtype in (torch.float16, torch.bfloat16):
+            scale_packed = codec.marlin24_pack_scales(scale2d, single=not is_group, to_float16=True)
+        else:
+            scale_packed = codec.marlin24_pack_scales(scale2d.to(torch.float16), single=not is_group)
         meta = meta.reshape(-1).reshape(meta.shape[1] // 2, meta.shape[0] * 2)
+        if bad is not None and int(bad.item()):  # one host read, as the reference pipeline's structure check
+            raise ValueError("Marlin24 Compressor is only compatible with weights that have a 2:4 sparsity structure. "
+                             "Found segments in weight that do not match the expected structure.")
 
         state_dict["weight_packed"] = packed
         state_dict["scale_packed"] = scale_packed

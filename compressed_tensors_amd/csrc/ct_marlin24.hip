@@ -255,11 +255,86 @@ __device__ __forceinline__ bool marlin24_word(const uint32_t (&ws)[8], float s16
     return worst > 2;
 }
 
+// ---- packed-fp16 back end of the fast path ---------------------------------------------------------------------
+// The exact form above spends ~20 VALU per element and the fused kernel is VALU-bound (60 us at 8192^2 against ~30 us
+// of memory time; dropping 4 ops per element moved it to 52.6 us).  Same arithmetic, fewer instructions:
+//   * the quotient stays the proven fp32 reciprocal + Newton step, but its fp16 rounding is the packed conversion
+//     (v_cvt_pk_f16_f32) and everything after it works on fp16 PAIRS;
+//   * clamp = v_pk_max_f16 / v_pk_min_f16; round-half-even + integer cast in ONE v_pk_add_f16: for t in [-128, 127],
+//     fl16(t + 1536) = 1536 + rint(t) exactly (ulp(1536) = 1, ties to the even significand = the even integer), and
+//     the low byte of each half of the sum IS the two's-complement code;
+//   * the four codes of a quad are gathered with one v_perm_b32, their non-zero flags with a carry trick, the table
+//     index and the count with two v_dot4_u32_u8.
+// What the packed clamp cannot reproduce is NaN (maxnum drops it) and the inf / NaN guard of the Newton step: any
+// non-finite first quotient in the 16 elements sends that lane to the exact form (rare, divergent).
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+template <int XDT, bool HAS_ZP>
+__device__ __forceinline__ bool marlin24_word_packed(const uint32_t (&ws)[8], float s16, float z16, float rs, float qmin, float qmax, u32x2& codes,
+                                                     uint32_t& word, bool& special) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr uint32_t kQuadLut = []() constexpr {
+        uint32_t lut = 0;
+        for (int idx = 0; idx < 8; ++idx) {
+            const bool m0 = idx & 1, m1 = (idx >> 1) & 1, m3 = (idx >> 2) & 1;
+            const bool e0 = m0 && m1, e1 = !m0 && m1, e2 = !m0 && !m1;
+            const uint32_t bit0 = e1, bit1 = e2, bit2 = e0 || e2 || m3, bit3 = e1 || !m1;
+            lut |= (bit0 | (bit1 << 1) | (bit2 << 2) | (bit3 << 3)) << (4 * idx);
+        }
+        return lut;
+    }();
+    const h2_t lo2 = {(_Float16)qmin, (_Float16)qmin}, hi2 = {(_Float16)qmax, (_Float16)qmax};
+    const h2_t magic = {(_Float16)1536.0f, (_Float16)1536.0f};
+    const h2_t z2 = {(_Float16)z16, (_Float16)z16};
+    uint32_t lo = 0, hi = 0;
+    word = 0;
+    uint32_t worst = 0;
+    special = false;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        uint32_t u[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t pair = ws[2 * qd + h];
+            float x0, x1;
+            if constexpr (XDT == CT_BF16) {
+                x0 = bf16_bits_to_f(pair & 0xffffu); x1 = bits_f(pair & 0xffff0000u);
+                round2_f16(x0, x1);  // weight.to(fp16)
+            } else {
+                x0 = f16_bits_to_f(pair & 0xffffu); x1 = f16_bits_to_f(pair >> 16);
+            }
+            const float a0 = x0 * rs, a1 = x1 * rs;
+            special |= !__builtin_isfinite(a0) | !__builtin_isfinite(a1);
+            const float t0 = __builtin_fmaf(__builtin_fmaf(-a0, s16, x0), rs, a0), t1 = __builtin_fmaf(__builtin_fmaf(-a1, s16, x1), rs, a1);
+            h2_t t = __builtin_convertvector(f2{t0, t1}, h2_t);  // fp16(x16 / s16)
+            if (HAS_ZP) t = t + z2;                              // fp16(t + zp)
+            t = __builtin_elementwise_min(__builtin_elementwise_max(t, lo2), hi2);
+            u[h] = __builtin_bit_cast(uint32_t, t + magic);
+        }
+        const uint32_t packed4 = __builtin_amdgcn_perm(u[1], u[0], 0x06040200u);  // codes of elements 0..3
+        const uint32_t nzb = ((((packed4 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | packed4) & 0x80808080u) >> 7;  // one 0/1 byte per element
+        const uint32_t cnt = __builtin_amdgcn_udot4(nzb, 0x01010101u, 0u, false);
+        const uint32_t idx = __builtin_amdgcn_udot4(nzb, 0x04000201u, 0u, false);
+        worst = cnt > worst ? cnt : worst;
+        const uint32_t qc = (kQuadLut >> (4 * idx)) & 0xfu;
+        word |= qc << (4 * qd);
+        const uint32_t sel = 0x0c0c0000u | (qc & 3u) | ((qc >> 2) << 8);
+        const uint32_t two = __builtin_amdgcn_perm(0u, packed4, sel);
+        if (qd < 2) lo |= two << (16 * qd); else hi |= two << (16 * (qd - 2));
+    }
+    codes = u32x2{lo, hi};
+    return worst > 2;
+}
+
 template <int XDT>
 __device__ __forceinline__ bool marlin24_item(const void* __restrict__ w, const void* __restrict__ scale, int sdt, const void* __restrict__ zp, int zdt,
                                               int64_t r, int64_t mc, int64_t k, int64_t cdiv, int64_t scale_cols, float qmin, float qmax,
                                               u32x2& codes, uint32_t& word) {
-    const int64_t si = r * scale_cols + (mc * 16) / cdiv;
+    // group of the word's 16 columns: cdiv is a multiple of 16 (or the whole row), so this is mc / (cdiv / 16) — a shift for
+    // the usual power-of-two groups, a 32-bit divide otherwise (the 64-bit software divide cost ~80 VALU per word)
+    const uint32_t per = (uint32_t)(cdiv >> 4);
+    const uint32_t grp = (per & (per - 1)) == 0 ? ((uint32_t)mc >> __builtin_ctz(per)) : ((uint32_t)mc / per);
+    const int64_t si = r * scale_cols + grp;
     // the scale first: its reciprocal is computed while the 32 bytes of weights are in flight
     const float s16 = sdt == CT_F16 ? f16_bits_to_f(static_cast<const uint16_t*>(scale)[si]) : round_to<CT_F16>(load_rt(scale, sdt, si));
     const bool has_zp = zp != nullptr;
@@ -271,6 +346,10 @@ __device__ __forceinline__ bool marlin24_item(const void* __restrict__ w, const 
     // an all-zero zero point adds nothing (t is already rounded to fp16): wave-uniform skip, as in the W4 kernel
     const bool use_zp = has_zp && (__builtin_amdgcn_ballot_w64(z16 != 0.0f) != 0);
     if (rs != 0.0f) {
+        bool special;
+        const bool v = use_zp ? marlin24_word_packed<XDT, true>(ws, s16, z16, rs, qmin, qmax, codes, word, special)
+                              : marlin24_word_packed<XDT, false>(ws, s16, z16, rs, qmin, qmax, codes, word, special);
+        if (!special) return v;
         return use_zp ? marlin24_word<XDT, true, true>(ws, s16, z16, rs, qmin, qmax, codes, word)
                       : marlin24_word<XDT, true, false>(ws, s16, z16, rs, qmin, qmax, codes, word);
     }
@@ -320,10 +399,12 @@ __global__ __launch_bounds__(kBlock) void marlin24_quant_compress_tiled_kernel(c
         uint32_t word;
         violation |= marlin24_item<XDT>(w, scale, sdt, zp, zdt, r, mc, k, cdiv, scale_cols, qmin, qmax, codes, word);
         stream_store8(comp + r * (k / 2) + mc * 8, codes);
-        const int64_t off = meta_reorder_offset(r, mc, m, 2);
-        const int pair = cl >> 1;
-        const int64_t pair_base = (tile_c * 8 + pair) * m * 2 + tile_r * 128;
-        s_meta[pair][(int)(off - pair_base)] = (uint16_t)word;
+        // meta_reorder_offset(r, mc, m, 2) relative to the pair's base, in 32-bit local terms: the row permutation only
+        // involves the row inside its 64-row group, the column swap stays inside the column pair
+        int dr = (rl & 1) * 2 + ((rl & 7) >> 2) + ((rl & 3) >> 1) * 32 + (rl >> 3) * 4;
+        const int adj = (((dr & 1) == 0) && (cl & 1)) - (((dr & 1) == 1) && !(cl & 1));
+        dr += adj;
+        s_meta[cl >> 1][dr * 2 + ((cl - adj) & 1)] = (uint16_t)word;
     }
     if (violation) atomicOr(bad, 1);
     __syncthreads();
@@ -463,6 +544,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_pack_kernel(const void* __res
 
 // marlin-24 scale packing: scales (size_n, groups) -> transpose -> reshape(-1, 64)[:, perm]
 // -> (groups, size_n).  perm: group table or identity ("single", channel-wise)
+template <bool BF16_TO_F16>
 __global__ __launch_bounds__(kBlock) void marlin24_pack_scales_kernel(const uint16_t* __restrict__ scale, int64_t size_n, int64_t groups, int single,
                                                                       uint16_t* __restrict__ out) {
     const int64_t total = size_n * groups;
@@ -473,7 +555,8 @@ __global__ __launch_bounds__(kBlock) void marlin24_pack_scales_kernel(const uint
         const int pj = single ? j : (8 * (j >> 3) + tbl[j & 7]);
         const int64_t src = (i << 6) + pj;  // flat index into the transposed (groups, size_n) matrix
         const int64_t g = src / size_n, n = src - g * size_n;
-        out[f] = scale[n * groups + g];
+        const uint16_t v = scale[n * groups + g];
+        out[f] = BF16_TO_F16 ? (uint16_t)f_to_f16_bits(bf16_bits_to_f(v)) : v;  // scale.to(torch.float16), RNE
     }
 }
 
@@ -605,9 +688,22 @@ int ct_marlin24_pack_scales(const void* scale, int dt, int64_t size_n, int64_t g
     CT_REQUIRE(dt == CT_F16 || dt == CT_BF16, "marlin-24 scales must be 16-bit floats, got dtype %d", dt);
     CT_REQUIRE(size_n >= 0 && groups >= 0 && (size_n * groups) % 64 == 0, "scale count must be a multiple of 64");
     if (size_n == 0 || groups == 0) return CT_OK;
-    hipLaunchKernelGGL(marlin24_pack_scales_kernel, dim3(grid_1d(size_n * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale), size_n,
-                       groups, single, static_cast<uint16_t*>(out));
+    hipLaunchKernelGGL(marlin24_pack_scales_kernel<false>, dim3(grid_1d(size_n * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale),
+                       size_n, groups, single, static_cast<uint16_t*>(out));
     CT_LAUNCH_CHECK("ct_marlin24_pack_scales");
+}
+
+int ct_marlin24_pack_scales_f16(const void* scale, int dt, int64_t size_n, int64_t groups, int single, void* out, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_F16 || dt == CT_BF16, "marlin-24 scales must be 16-bit floats, got dtype %d", dt);
+    CT_REQUIRE(size_n >= 0 && groups >= 0 && (size_n * groups) % 64 == 0, "scale count must be a multiple of 64");
+    if (size_n == 0 || groups == 0) return CT_OK;
+    if (dt == CT_BF16)
+        hipLaunchKernelGGL(marlin24_pack_scales_kernel<true>, dim3(grid_1d(size_n * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale),
+                           size_n, groups, single, static_cast<uint16_t*>(out));
+    else
+        hipLaunchKernelGGL(marlin24_pack_scales_kernel<false>, dim3(grid_1d(size_n * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale),
+                           size_n, groups, single, static_cast<uint16_t*>(out));
+    CT_LAUNCH_CHECK("ct_marlin24_pack_scales_f16");
 }
 
 }  // extern "C"

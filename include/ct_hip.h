@@ -297,6 +297,9 @@ int ct_marlin24_pack_weights(const void* q, int dt, int transposed, int add_offs
  * -> (groups, size_n) */
 int ct_marlin24_pack_scales(const void* scale, int dt, int64_t size_n, int64_t groups, int single,
                             void* out, ct_stream_t stream);
+/* the same with the reference's `scale.to(torch.float16)` folded in: scale may be bfloat16, out is float16 */
+int ct_marlin24_pack_scales_f16(const void* scale, int dt, int64_t size_n, int64_t groups, int single,
+                                void* out, ct_stream_t stream);
 
 /* ---------------------------------------------------------------------------- diagnostics
  * Exhaustive device-side check of the reciprocal fast path used by the bf16 fused kernels:

@@ -1034,3 +1034,38 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
     leg = out["tinyllama_checkpoint"]
     assert leg["round_trip_equals_fake_quantize"] is True and 0 < leg["modules_this_rank"] < 154
+
+
+@pytest.mark.parametrize("wdt", [BF16, F16])
+@pytest.mark.parametrize("bits", [4, 8])
+def test_marlin24_front_end_special_values(cta, dev, wdt, bits):
+    """the packed-fp16 back end of the fused front end against quantize (fp16) + cutlass 2:4 compress: kept values that are
+    inf / NaN / huge / fp16-subnormal / on rounding ties, scales at both ends of the fast range and outside it, a non-zero
+    zero point, every fp16 value once"""
+    g = torch.Generator().manual_seed(17 + bits)
+    rows, cols = 128, 1024
+    # every 16-bit pattern of the weight dtype in the kept slots of a 2:4 layout (two values, two zeros)
+    allv = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(wdt)
+    w = torch.zeros((rows, cols), dtype=wdt)
+    w.view(-1, 4)[:, 0] = allv[: rows * cols // 4]
+    w.view(-1, 4)[:, 2] = allv[rows * cols // 4: rows * cols // 2] if rows * cols // 2 <= 65536 else 0
+    half = 2.0 ** (bits - 1)
+    ties = (torch.arange(-2 * half - 2, 2 * half + 2, dtype=torch.float32) + 0.5)
+    for case, smaker in (("mid", lambda: (torch.rand((rows, cols // 128), generator=g) * 0.2 + 0.01)),
+                         ("tiny", lambda: torch.full((rows, cols // 128), 2.0 ** -14)), ("big", lambda: torch.full((rows, cols // 128), 2.0 ** 15)),
+                         ("subnormal", lambda: torch.full((rows, cols // 128), 2.0 ** -20)), ("ones", lambda: torch.full((rows, cols // 128), 1.0))):
+        s = smaker().to(F16)
+        ww = w.clone()
+        if case == "ones":
+            ww.view(-1, 4)[: ties.numel(), 1] = ties.to(wdt)  # exact .5 ties under a unit scale
+            ww.view(-1, 4)[: ties.numel(), 0] = 0
+            ww.view(-1, 4)[: ties.numel(), 2] = 0
+        for z in (torch.zeros_like(s, dtype=torch.int8), torch.full(s.shape, 3, dtype=torch.int8)):
+            comp, meta, bad = cta.codec.marlin24_quant_compress(d(ww, dev), d(s, dev), d(z, dev), num_bits=bits, group_size=128)
+            q = cta.codec.quantize_tensor(d(ww, dev).to(F16), d(s, dev), d(z, dev), num_bits=bits, strategy="group", group_size=128)
+            ok24 = bool(((q != 0).view(-1, 4).sum(-1) <= 2).all())
+            assert bool(bad.item()) == (not ok24), (case, int(z[0, 0]))
+            if ok24:
+                comp_ref, meta_ref = cta.codec.cutlass24_from_dense(q)
+                # a NaN is kept as a non-zero by the 2:4 selection and becomes code 0 in the integer cast (as the exact form)
+                assert torch.equal(comp.cpu().float(), torch.nan_to_num(comp_ref.cpu().float(), nan=0.0)) and torch.equal(meta.cpu(), meta_ref.cpu()), (case, int(z[0, 0]))
