@@ -23,6 +23,8 @@ __all__ = [
     "quantize_and_pack",
     "unpack_and_dequantize",
     "minmax_qparams",
+    "minmax_qparams_float",
+    "generate_gparam",
     "rtn_quantize_and_pack",
     "pack_bitmasks",
     "unpack_bitmasks",
@@ -441,6 +443,49 @@ def minmax_qparams(x, *, num_bits, group_size=None, symmetric=True):
 
 
 # --------------------------------------------------------------------------- batched W4A16
+_QP_KIND = {"fp8": 1, "nvfp4": 2, "mxfp4": 3, "mxfp8": 4}
+
+
+def minmax_qparams_float(x, *, kind: str, group_size=None, global_scale=None) -> torch.Tensor:
+    """Min-max observer + calculate_qparams for the symmetric FLOAT schemes (quantization/utils/helpers.py:50-137,
+    mxfp_utils.py:37-143): kind "fp8" (scale in x.dtype), "nvfp4" (fp8-representable float32 scale under `global_scale`),
+    "mxfp4" / "mxfp8" (power-of-two scale in x.dtype, group 32).  Returns the scale (R, G); the zero points of these schemes
+    are zeros of the scheme's zp_dtype."""
+    _check_float(x, "weight")
+    if x.ndim != 2:
+        raise ValueError("minmax_qparams_float expects a 2-D weight")
+    if kind not in _QP_KIND:
+        raise ValueError(f"unknown float qparams kind {kind!r}")
+    if kind == "nvfp4" and global_scale is None:
+        raise ValueError("nvfp4 scales need the global scale")
+    dev = _compute_device(x)
+    xd = _dev(x, dev)
+    rows, cols = xd.shape
+    cdiv = int(group_size) if group_size else max(cols, 1)
+    ng = math.ceil(cols / cdiv) if cols else 0
+    scale = torch.empty((rows, ng), dtype=torch.float32 if kind == "nvfp4" else xd.dtype, device=dev)
+    gs = _gs_arg(global_scale, dev) if kind == "nvfp4" else None
+    call("ct_minmax_qparams_float", ptr(xd), DT[xd.dtype], rows, cols, cdiv, _QP_KIND[kind], ptr(gs), ptr(scale), stream_of(xd))
+    return _home(scale, x)
+
+
+def generate_gparam(x: torch.Tensor) -> torch.Tensor:
+    """generate_gparam (quantization/utils/helpers.py:308-337) of a whole weight: 448 * 6 / amax evaluated in x's dtype
+    exactly as the eager expression does on the CPU (`float / tensor` = reciprocal, then product: two roundings), float32
+    (1,), non-finite -> 1.  The tensor-wide amax is the row-wise min-max kernel followed by a reduction of one value per row."""
+    _check_float(x, "weight")
+    x2 = x.reshape(-1, x.shape[-1]) if x.ndim != 2 else x
+    dev = _compute_device(x2)
+    xd = _dev(x2, dev)
+    rows, cols = xd.shape
+    row_amax = torch.empty((rows, 1), dtype=xd.dtype, device=dev)
+    call("ct_minmax_qparams_float", ptr(xd), DT[xd.dtype], rows, cols, max(cols, 1), 5, None, ptr(row_amax), stream_of(xd))
+    amax = row_amax.amax().reshape(1).clamp(min=torch.finfo(xd.dtype).tiny)  # clamp does not propagate NaN upstream either
+    recip = (torch.ones(1, dtype=torch.float32, device=dev) / amax.float()).to(xd.dtype)
+    gs = (recip.float() * (448.0 * 6.0)).to(xd.dtype).float()
+    return _home(torch.nan_to_num(gs, nan=1.0, posinf=1.0, neginf=1.0), x)
+
+
 def rtn_quantize_and_pack(x: torch.Tensor, *, group_size: Optional[int] = None, symmetric: bool = True):
     """Round-to-nearest int4 compress in ONE pass over the weight: min-max observer + calculate_qparams
     (quantization/utils/helpers.py:50-137) + quantize + pack_to_int32 (compressors/pack_quantized/base.py:96-104).

@@ -86,4 +86,54 @@ __device__ __forceinline__ MinMax group_reduce(MinMax m, int lpg) {
     return m;
 }
 
+// calculate_qparams of the symmetric FLOAT schemes (helpers.py:50-137, mxfp_utils.py:37-143); see ct_hip.h for the kinds.
+// One lane per group runs this.
+enum { QP_INT = 0, QP_FP8 = 1, QP_NVFP4 = 2, QP_MXFP4 = 3, QP_MXFP8 = 4, QP_AMAX = 5 };
+
+template <int XDT>
+__device__ __forceinline__ float compute_qparams_float(MinMax m, int kind, float gs) {
+    float amax;
+    if (m.nan) {
+        amax = __builtin_nanf("");
+    } else {
+        const float mn = m.mn < 0.0f ? m.mn : 0.0f, mx = m.mx > 0.0f ? m.mx : 0.0f;
+        const float a = __builtin_fabsf(mn), b = __builtin_fabsf(mx);
+        amax = a > b ? a : b;
+    }
+    if (kind == QP_AMAX) return amax;  // the raw reduction (generate_gparam's input)
+    if (kind == QP_FP8) {
+        const float eps = XDT == CT_BF16 ? 0.0078125f : (XDT == CT_F16 ? 0.0009765625f : 1.1920928955078125e-07f);
+        const float s = round_to<XDT>(amax / 448.0f);
+        return s == 0.0f ? eps : s;
+    }
+    if (kind == QP_NVFP4) {
+        const float s2 = gs * round_to<XDT>(amax / 6.0f);           // float32: global * local
+        const float s = fp8_round(clamp_nan(s2, -448.0f, 448.0f));  // round_to_quantized_type_dtype(float8_e4m3fn)
+        return s == 0.0f ? 0.125f : s;
+    }
+    // MX: the significand is rounded at a quarter and masked off (round_to_power_2), the exponent goes through uint8
+    constexpr int mant = XDT == CT_BF16 ? 7 : (XDT == CT_F16 ? 10 : 23);
+    constexpr int expo = XDT == CT_F16 ? 5 : 8;
+    uint32_t bits = XDT == CT_BF16 ? f_to_bf16_bits(amax) : (XDT == CT_F16 ? f_to_f16_bits(amax) : f_bits(amax));
+    bits = (bits + (1u << (mant - 2))) & (((1u << (expo + 1)) - 1u) << mant);
+    if (XDT != CT_F32) bits &= 0xffffu;
+    const float p = XDT == CT_BF16 ? bf16_bits_to_f(bits) : (XDT == CT_F16 ? f16_bits_to_f(bits) : bits_f(bits));
+    // floor(log2(p)) of a power of two is its exponent; 0 -> -inf, inf -> inf, NaN -> NaN, as torch.log2.  p is never a
+    // non-zero subnormal: the mask keeps sign and exponent only, so an exponent field of zero is the value zero
+    float l;
+    if (p != p) l = p;
+    else if (p == 0.0f) l = -__builtin_inff();
+    else if (__builtin_isinf(p)) l = __builtin_inff();
+    else l = (float)((int)((f_bits(p) >> 23) & 0xffu) - 127);
+    const float offset = kind == QP_MXFP4 ? 2.0f : 8.0f;
+    const float e = round_to<XDT>(round_to<XDT>(127.0f + l) - offset);
+    float ec = clamp_nan(e, 0.0f, 255.0f);
+    ec = __builtin_rintf(ec);
+    const int code = (ec != ec) ? 0 : (int)ec;
+    // 2^(code - 127) as float32 (2^-127 is a float32 subnormal, 2^128 is inf), then to X
+    const float two = code == 0 ? 0x1p-127f : (code == 255 ? __builtin_inff() : bits_f((uint32_t)code << 23));
+    const float s = round_to<XDT>(two);
+    return s == 0.0f ? 1.0f : s;
+}
+
 }  // namespace ct

@@ -15,13 +15,22 @@
 
 namespace ct {
 
+// FLOAT kinds: the scale is float32 for NVFP4 (fp8-representable values), x's dtype otherwise; no zero point (symmetric)
+template <int XDT>
+__device__ __forceinline__ void emit_qparams_float(MinMax m, int kind, const float* gscale, void* scale_out, int64_t idx) {
+    const float s = compute_qparams_float<XDT>(m, kind, kind == QP_NVFP4 ? gscale[0] : 1.0f);
+    if (kind == QP_NVFP4) static_cast<float*>(scale_out)[idx] = s;
+    else store1<XDT>(scale_out, idx, s);
+}
+
 // groups of LPG lanes x Q units x 8 elements (cdiv = 64 * LPG for Q = 8 ...; LPG a power of two <= 64),
 // cols % cdiv == 0.  A lane owns Q CONSECUTIVE units (Q x 16 B loads in flight: with one unit per lane
 // a CU had only 32 KB outstanding and the kernel sat at 3.3 TB/s) and reduces them locally, the group is
 // finished with DPP, and one lane in LPG runs the (divide-heavy, divergent) scale / zero-point math.
 template <int XDT, int Q>
 __global__ __launch_bounds__(kBlock) void qparams_subwave_kernel(const void* __restrict__ x, int64_t lanes_total, int lpg, int bits, int symmetric,
-                                                                 void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
+                                                                 void* __restrict__ scale_out, int8_t* __restrict__ zp_out, int kind,
+                                                                 const float* __restrict__ gscale) {
     // lanes_total is a multiple of lpg, and kBlock is a multiple of lpg: groups never straddle waves
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     const int64_t nloops = (lanes_total + stride - 1) / stride;
@@ -45,14 +54,18 @@ __global__ __launch_bounds__(kBlock) void qparams_subwave_kernel(const void* __r
             }
         }
         m = group_reduce(m, lpg);
-        if (live && (threadIdx.x & (lpg - 1)) == 0) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, l / lpg);
+        if (live && (threadIdx.x & (lpg - 1)) == 0) {
+            if (kind == QP_INT) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, l / lpg);
+            else emit_qparams_float<XDT>(m, kind, gscale, scale_out, l / lpg);
+        }
     }
 }
 
 // generic: one wave per group, lanes stride over the group's columns
 template <int XDT>
 __global__ __launch_bounds__(kBlock) void qparams_wave_kernel(const void* __restrict__ x, int64_t rows, int64_t cols, int64_t cdiv, int bits,
-                                                              int symmetric, void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
+                                                              int symmetric, void* __restrict__ scale_out, int8_t* __restrict__ zp_out, int kind,
+                                                              const float* __restrict__ gscale) {
     const int64_t ngroups = (cols + cdiv - 1) / cdiv;
     const int64_t total = rows * ngroups;
     const int lane = threadIdx.x & 63;
@@ -77,7 +90,10 @@ __global__ __launch_bounds__(kBlock) void qparams_wave_kernel(const void* __rest
             o.nan = __shfl_xor(m.nan, d, 64);
             m = mm_merge(m, o);
         }
-        if (lane == 0) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, gi);
+        if (lane == 0) {
+            if (kind == QP_INT) emit_qparams<XDT>(m, bits, symmetric, scale_out, zp_out, gi);
+            else emit_qparams_float<XDT>(m, kind, gscale, scale_out, gi);
+        }
     }
 }
 
@@ -87,8 +103,8 @@ using namespace ct;
 
 extern "C" {
 
-int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits, int symmetric, void* scale_out, int8_t* zp_out,
-                      ct_stream_t stream) {
+static int minmax_qparams_impl(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits, int symmetric, void* scale_out, int8_t* zp_out,
+                               int kind, const float* gscale, ct_stream_t stream) {
     CT_REQUIRE(is_float_dt(xdt), "weight dtype code %d is not a float type", xdt);
     CT_REQUIRE(bits >= 1 && bits <= 8, "num_bits must be in [1, 8], got %d", bits);
     CT_REQUIRE(rows >= 0 && cols >= 0 && cdiv >= 1, "bad shape");
@@ -101,8 +117,8 @@ int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_
         const int64_t lpg = upg / q, lanes = units / q;
         int64_t g = cdiv64(lanes, kBlock);  // exact grid: many small workgroups stream best
         if (g > ((int64_t)1 << 30)) g = (int64_t)1 << 30;
-#define CT_QP(DT) do { if (q == 4) hipLaunchKernelGGL((qparams_subwave_kernel<DT, 4>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, lanes, (int)lpg, bits, symmetric, scale_out, zp_out); \
-                       else hipLaunchKernelGGL((qparams_subwave_kernel<DT, 1>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, lanes, (int)lpg, bits, symmetric, scale_out, zp_out); } while (0)
+#define CT_QP(DT) do { if (q == 4) hipLaunchKernelGGL((qparams_subwave_kernel<DT, 4>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, lanes, (int)lpg, bits, symmetric, scale_out, zp_out, kind, gscale); \
+                       else hipLaunchKernelGGL((qparams_subwave_kernel<DT, 1>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, lanes, (int)lpg, bits, symmetric, scale_out, zp_out, kind, gscale); } while (0)
         switch (xdt) {
             case CT_BF16: CT_QP(CT_BF16); break;
             case CT_F16: CT_QP(CT_F16); break;
@@ -115,11 +131,23 @@ int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_
     int64_t g = cdiv64(total, kBlock / 64);
     if (g > kCUs * 32) g = kCUs * 32;
     switch (xdt) {
-        case CT_BF16: hipLaunchKernelGGL((qparams_wave_kernel<CT_BF16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out); break;
-        case CT_F16: hipLaunchKernelGGL((qparams_wave_kernel<CT_F16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out); break;
-        default: hipLaunchKernelGGL((qparams_wave_kernel<CT_F32>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out); break;
+        case CT_BF16: hipLaunchKernelGGL((qparams_wave_kernel<CT_BF16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out, kind, gscale); break;
+        case CT_F16: hipLaunchKernelGGL((qparams_wave_kernel<CT_F16>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out, kind, gscale); break;
+        default: hipLaunchKernelGGL((qparams_wave_kernel<CT_F32>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), x, rows, cols, cdiv, bits, symmetric, scale_out, zp_out, kind, gscale); break;
     }
     CT_LAUNCH_CHECK("ct_minmax_qparams");
+}
+
+int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits, int symmetric, void* scale_out, int8_t* zp_out,
+                      ct_stream_t stream) {
+    return minmax_qparams_impl(x, xdt, rows, cols, cdiv, bits, symmetric, scale_out, zp_out, QP_INT, nullptr, stream);
+}
+
+int ct_minmax_qparams_float(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int kind, const float* global_scale, void* scale_out,
+                            ct_stream_t stream) {
+    CT_REQUIRE(kind >= QP_FP8 && kind <= QP_AMAX, "float qparams kind must be 1 (fp8), 2 (nvfp4), 3 (mxfp4), 4 (mxfp8) or 5 (amax), got %d", kind);
+    CT_REQUIRE(kind != QP_NVFP4 || global_scale != nullptr, "nvfp4 scales need the global scale");
+    return minmax_qparams_impl(x, xdt, rows, cols, cdiv, 8, 1, scale_out, nullptr, kind, global_scale, stream);
 }
 
 }  // extern "C"

@@ -182,6 +182,17 @@ int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_bl
 int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits,
                       int symmetric, void* scale_out, int8_t* zp_out, ct_stream_t stream);
 
+/* The same reduction for the symmetric FLOAT schemes (helpers.py:50-137, mxfp_utils.py:37-143); amax = max(|min(mn, 0)|,
+ * |max(mx, 0)|) of each group:
+ *   kind 1 FP8    scale = rnd_X(amax / 448), zero -> eps(X)                                     scale_out: x's dtype
+ *   kind 2 NVFP4  scale = float8_e4m3fn(clamp(global_scale * rnd_X(amax / 6), +-448)), 0 -> 1/8  scale_out: float32
+ *   kind 3 MXFP4 / 4 MXFP8 (group 32): amax's significand rounded at a quarter and masked off, E8M0 exponent
+ *          127 + log2 - 2 (resp. - 8) through uint8, scale = 2^(e - 127) in x's dtype, zero -> 1 scale_out: x's dtype
+ *   kind 5 the raw amax of each group in x's dtype (the input of generate_gparam, helpers.py:308-337)
+ * Zero points of these schemes are all-zero tensors of the scheme's zp_dtype (made by the host). */
+int ct_minmax_qparams_float(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int kind,
+                            const float* global_scale, void* scale_out, ct_stream_t stream);
+
 /* ---------------------------------------------------------------------------- FP4 (E2M1) codecs
  * nvfp4-pack-quantized / mxfp4-pack-quantized weight paths (compressors/nvfp4/base.py:68-139,
  * mxfp4/base.py:27-65): quantize(x, scale, global_scale) -> cast_to_fp4 -> pack_fp4_to_uint8 fused, and the

@@ -518,10 +518,50 @@ def gen_fp4q():
     save("fp4q", tensors, {"cases": cases})
 
 
+# ----------------------------------------------------------------------------- qparams of the FLOAT schemes
+def gen_qparams_float():
+    """calculate_qparams for FLOAT args from per-group min / max (what a min-max observer feeds it): FP8 (channel,
+    group 128), NVFP4 (tensor_group 16 under generate_gparam's global scale), MXFP4 / MXFP8 (group 32, E8M0 scales)."""
+    from compressed_tensors.quantization.utils import generate_gparam
+
+    g = torch.Generator().manual_seed(555)
+    tensors, cases = {}, []
+    configs = [
+        ("fp8_ch", dict(num_bits=8, type="float", strategy="channel", symmetric=True), None, False),
+        ("fp8_g128", dict(num_bits=8, type="float", strategy="group", group_size=128, symmetric=True), 128, False),
+        ("nvfp4", dict(num_bits=4, type="float", strategy="tensor_group", group_size=16, symmetric=True, scale_dtype=torch.float8_e4m3fn,
+                       zp_dtype=torch.float8_e4m3fn), 16, True),
+        ("mxfp4", dict(num_bits=4, type="float", strategy="group", group_size=32, symmetric=True, scale_dtype=torch.uint8, zp_dtype=torch.uint8), 32, False),
+        ("mxfp8", dict(num_bits=8, type="float", strategy="group", group_size=32, symmetric=True, scale_dtype=torch.uint8, zp_dtype=torch.uint8), 32, False),
+    ]
+    for name, kw, gs, use_g in configs:
+        args = QuantizationArgs(**kw)
+        for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+            key = f"{name}_{dt_name}"
+            x = torch.randn((8, 256), generator=g).mul(0.05).to(dt)
+            x[0, :128] = 0                       # all-zero groups -> eps substitution
+            x[1, :32] = x[1, :32].abs()          # strictly positive group
+            x[2, :32] = (torch.rand(32, generator=g) * 1e-6).to(dt)   # tiny values
+            x[3, :32] = (torch.randn(32, generator=g) * 3000).to(dt)  # large values
+            x[4, 0:16] = torch.tensor([0.74, 0.75, 0.76, 1.24, 1.25, 1.26, 1.49, 1.5, 1.51, 1.74, 1.75, 1.76, 1.99, 2.0, 3.0, 0.0]).to(dt)  # power-of-two rounding
+            if gs:
+                xg = x.unflatten(-1, (256 // gs, gs))
+                mn, mx = torch.aminmax(xg, dim=-1)
+            else:
+                mn, mx = torch.aminmax(x, dim=-1, keepdim=True)
+            gsc = generate_gparam(x.min().reshape(1), x.max().reshape(1)) if use_g else None
+            scale, zp = calculate_qparams(mn, mx, args, global_scale=gsc)
+            tensors.update({key + ".x": x, key + ".scale": scale, key + ".zp": zp.view(torch.uint8) if zp.dtype == torch.float8_e4m3fn else zp})
+            if gsc is not None:
+                tensors[key + ".gs"] = gsc
+            cases.append({"key": key, "kind": name, "group_size": gs, "scale_dtype": str(scale.dtype).split(".")[-1], "zp_dtype": str(zp.dtype).split(".")[-1]})
+    save("qparams_float", tensors, {"cases": cases})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     families = {"pack": gen_pack, "quant": gen_quant, "qparams": gen_qparams, "compressors": gen_compressors, "sparse": gen_sparse,
-                "fp4": gen_fp4, "fp8": gen_fp8, "fp4q": gen_fp4q}
+                "fp4": gen_fp4, "fp8": gen_fp8, "fp4q": gen_fp4q, "qparams_float": gen_qparams_float}
     wanted = sys.argv[1:] or list(families)  # `python oracle/gen_golden.py fp4` regenerates one family only
     mpath = os.path.join(OUT, "manifest.json")
     if os.path.exists(mpath) and sys.argv[1:]:

@@ -266,6 +266,37 @@ def calculate_qparams_minmax(x, *, num_bits, group_size=None, symmetric=True):
     return scale, zp
 
 
+_QP_KIND = {"fp8": 1, "nvfp4": 2, "mxfp4": 3, "mxfp8": 4}
+
+
+def calculate_qparams_float(x, *, kind, group_size=None, global_scale=None):
+    """calculate_qparams of the symmetric FLOAT schemes over each group's min / max (helpers.py:50-137,
+    mxfp_utils.py:37-143): kind "fp8" (scale in x.dtype), "nvfp4" (fp8-representable float32 scale under the global
+    scale), "mxfp4" / "mxfp8" (power-of-two scale in x.dtype from the E8M0 exponent)."""
+    x = _cpu(x)
+    rows, cols = x.shape
+    cdiv = group_size or cols
+    ng = math.ceil(cols / cdiv)
+    out_dtype = torch.float32 if kind == "nvfp4" else x.dtype
+    scale = torch.empty((rows, ng), dtype=out_dtype)
+    gs = _cpu(global_scale).to(torch.float32).reshape(-1)[:1].contiguous() if global_scale is not None else None
+    rc = lib().cto_calculate_qparams_float(_p(x), _DT[x.dtype], _i64(rows), _i64(cols), _i64(cdiv), _QP_KIND[kind], _p(gs), _p(scale), _DT[out_dtype])
+    assert rc == 0
+    return scale
+
+
+def generate_gparam(x):
+    """helpers.py:308-337 for a whole tensor: 448 * 6 / amax evaluated in x's dtype, returned as float32; non-finite -> 1.
+    `python_float / tensor` is evaluated by torch as tensor.reciprocal() * float: TWO roundings to x's dtype."""
+    x = _cpu(x)
+    xf = x.float()
+    mn, mx = min(float(xf.min()), 0.0), max(float(xf.max()), 0.0)
+    amax = torch.tensor([max(abs(mn), abs(mx))], dtype=x.dtype).clamp(min=torch.finfo(x.dtype).tiny)
+    recip = (torch.ones(1, dtype=torch.float32) / amax.float()).to(x.dtype)
+    gs = (recip.float() * (448.0 * 6.0)).to(x.dtype).float()
+    return torch.nan_to_num(gs, nan=1.0, posinf=1.0, neginf=1.0)
+
+
 # --------------------------------------------------------------------------- bitmask
 def pack_bitmasks(bytemasks: torch.Tensor) -> torch.Tensor:
     m = _cpu(bytemasks.to(torch.uint8))

@@ -378,3 +378,18 @@ def test_fp4_quant_golden(golden, case):
     assert eq(O.fake_quantize(t["x"], t["scale"], zp, **kw), t["fq"])
     dkw = {k: v for k, v in kw.items() if k not in ("num_bits", "qtype")}
     assert eq(O.dequantize(t["qf"], t["scale"], zp, **dkw), t["dq"])
+
+
+# ----------------------------------------------------------------------------- qparams of the FLOAT schemes
+def _qpf_kind(case):
+    return "fp8" if case["kind"].startswith("fp8") else case["kind"]
+
+
+@pytest.mark.parametrize("case", cases("qparams_float"), ids=lambda c: c["key"])
+def test_qparams_float_golden(golden, case):
+    t = golden.case("qparams_float", case["key"])
+    s = O.calculate_qparams_float(t["x"], kind=_qpf_kind(case), group_size=case["group_size"], global_scale=t.get("gs"))
+    assert eq(s, t["scale"])
+    assert not bool(t["zp"].view(torch.uint8).any())  # symmetric: all-zero zero points of the scheme's zp_dtype
+    if "gs" in t:
+        assert eq(O.generate_gparam(t["x"]), t["gs"])
