@@ -348,6 +348,16 @@ def float_formats_leg(dev):
         out[name] = {"alg_bytes_compress": alg_c, "alg_bytes_decompress": alg_d, "compress": rate(alg_c, time_kernel(cq, 36)),
                      "decompress": rate(alg_d, time_kernel(cd, 36, offset=6))}
         del ss, stored
+    # observer + E8M0 scale + quantize + pack in one pass (ct_rtn_mxfp4_quant_pack)
+    codes = torch.empty(N, N // 32, dtype=torch.uint8, device=dev)
+    rq = lambda i: lib.ct_rtn_mxfp4_quant_pack(ws[i % nsets].data_ptr(), BF16, N, N, p4[i % nsets].data_ptr(), codes.data_ptr(), None, stream)
+    alg_r = int(N * N * (2.5 + 1.0 / 32))
+    out["mxfp4_rtn_one_pass"] = dict(alg_bytes=alg_r, **rate(alg_r, time_kernel(rq, 36)))
+    gs1 = torch.tensor([448.0], dtype=torch.float32, device=dev)
+    s8 = torch.empty(N, N // 16, dtype=torch.uint8, device=dev)
+    nq = lambda i: lib.ct_rtn_nvfp4_quant_pack(ws[i % nsets].data_ptr(), BF16, N, N, gs1.data_ptr(), p4[i % nsets].data_ptr(), s8.data_ptr(), None, stream)
+    alg_n = int(N * N * (2.5 + 1.0 / 16))
+    out["nvfp4_rtn_one_pass_given_global_scale"] = dict(alg_bytes=alg_n, **rate(alg_n, time_kernel(nq, 36)))
     out["workload"] = f"float-quantized (float8_e4m3fn, channel), nvfp4- and mxfp4-pack-quantized weight paths, {N}x{N} bf16, C ABI"
     return out
 

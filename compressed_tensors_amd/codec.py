@@ -26,6 +26,8 @@ __all__ = [
     "minmax_qparams_float",
     "generate_gparam",
     "rtn_quantize_and_pack",
+    "rtn_mxfp4_quantize_and_pack",
+    "rtn_nvfp4_quantize_and_pack",
     "pack_bitmasks",
     "unpack_bitmasks",
     "W4Batch",
@@ -508,6 +510,51 @@ def rtn_quantize_and_pack(x: torch.Tensor, *, group_size: Optional[int] = None, 
     zp = torch.empty((rows, cols // group), dtype=torch.int8, device=dev)
     call("ct_rtn_quant_pack_w4", ptr(xd), DT[xd.dtype], rows, cols, group, int(bool(symmetric)), ptr(packed), ptr(scale), ptr(zp), stream_of(xd))
     return _home(packed, x), _home(scale, x), _home(zp, x)
+
+
+def rtn_mxfp4_quantize_and_pack(x: torch.Tensor, *, return_scale: bool = False):
+    """Round-to-nearest MXFP4 compress in ONE pass over the weight (group 32): min-max observer + calculate_qparams' MX
+    branch + quantize + cast_to_fp4 + pack + compress_mx_scale.  Returns (packed uint8 (R, C/2), scale uint8 (R, C/32))
+    [, the float scale in x.dtype] — bit-identical to minmax_qparams_float("mxfp4") -> fp4_quantize_and_pack ->
+    compress_mx_scale."""
+    if x.dim() != 2:
+        raise ValueError("rtn_mxfp4_quantize_and_pack expects a 2-D weight")
+    if x.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"the one-pass MXFP4 compress takes 16-bit float weights, got {x.dtype}")
+    rows, cols = x.shape
+    if cols % 32 != 0:
+        raise ValueError(f"tensor column shape must be divisble by the given group_size 32 but got {cols}")
+    dev = _compute_device(x)
+    xd = _dev(x, dev).contiguous()
+    packed = torch.empty((rows, cols // 2), dtype=torch.uint8, device=dev)
+    code = torch.empty((rows, cols // 32), dtype=torch.uint8, device=dev)
+    scale = torch.empty((rows, cols // 32), dtype=x.dtype, device=dev) if return_scale else None
+    call("ct_rtn_mxfp4_quant_pack", ptr(xd), DT[xd.dtype], rows, cols, ptr(packed), ptr(code), ptr(scale), stream_of(xd))
+    if return_scale:
+        return _home(packed, x), _home(code, x), _home(scale, x)
+    return _home(packed, x), _home(code, x)
+
+
+def rtn_nvfp4_quantize_and_pack(x: torch.Tensor, global_scale: Optional[torch.Tensor] = None, *, return_scale: bool = False):
+    """Round-to-nearest NVFP4 compress (groups of 16): generate_gparam of the weight unless `global_scale` is given, then ONE
+    pass: min-max observer + calculate_qparams (float8 scales under the global scale) + quantize + cast_to_fp4 + pack.
+    Returns (packed uint8 (R, C/2), scale float8_e4m3fn (R, C/16), global_scale float32 (1,)) [, the float32 scales]."""
+    if x.dim() != 2:
+        raise ValueError("rtn_nvfp4_quantize_and_pack expects a 2-D weight")
+    if x.dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError(f"the one-pass NVFP4 compress takes 16-bit float weights, got {x.dtype}")
+    rows, cols = x.shape
+    if cols % 32 != 0:
+        raise NotImplementedError(f"the one-pass NVFP4 compress needs cols % 32 == 0, got {cols}; use minmax_qparams_float + fp4_quantize_and_pack")
+    dev = _compute_device(x)
+    xd = _dev(x, dev).contiguous()
+    gs = generate_gparam(xd) if global_scale is None else _gs_arg(global_scale, dev)
+    packed = torch.empty((rows, cols // 2), dtype=torch.uint8, device=dev)
+    s8 = torch.empty((rows, cols // 16), dtype=torch.float8_e4m3fn, device=dev)
+    scale = torch.empty((rows, cols // 16), dtype=torch.float32, device=dev) if return_scale else None
+    call("ct_rtn_nvfp4_quant_pack", ptr(xd), DT[xd.dtype], rows, cols, ptr(gs), ptr(packed), ptr(s8), ptr(scale), stream_of(xd))
+    out = (_home(packed, x), _home(s8, x), _home(gs, x))
+    return out + (_home(scale, x),) if return_scale else out
 
 
 def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, strategy, group_size, g_idx=None) -> bool:

@@ -61,6 +61,19 @@ class NVFP4PackedCompressor(BaseCompressor):
         return cls._remove_symmetric_zp(state_dict, scheme)
 
     @classmethod
+    def compress_rtn(cls, weight: torch.Tensor, scheme, global_scale=None) -> dict:
+        """Round-to-nearest compression straight from the dense weight: generate_gparam (unless given), then observer +
+        calculate_qparams + compress in ONE pass over the weight (codec.rtn_nvfp4_quantize_and_pack) — the state dict
+        `compress` returns for {"weight", "weight_scale", "weight_global_scale"} of the min-max qparams."""
+        if weight.dim() == 2 and weight.dtype in (torch.bfloat16, torch.float16) and weight.shape[1] % 32 == 0:
+            packed, s8, gs = codec.rtn_nvfp4_quantize_and_pack(weight, global_scale)
+            return {"weight_packed": packed, "weight_scale": s8.to(getattr(scheme.weights, "scale_dtype", None) or torch.float8_e4m3fn),
+                    "weight_global_scale": gs}
+        gs = codec.generate_gparam(weight) if global_scale is None else global_scale
+        scale = codec.minmax_qparams_float(weight, kind="nvfp4", group_size=16, global_scale=gs)
+        return cls.compress({"weight": weight, "weight_scale": scale, "weight_global_scale": gs}, scheme)
+
+    @classmethod
     def decompress(cls, state_dict: dict, scheme) -> dict:
         """nvfp4/base.py:106-139: the weight comes back as bfloat16 (unpack_fp4_from_uint8's default), the scale as a
         bfloat16 tensor"""
@@ -92,6 +105,17 @@ class MXFP4PackedCompressor(NVFP4PackedCompressor):
         if not getattr_chain(scheme, "input_activations.dynamic", True):
             names += ("input_global_scale",)
         return names
+
+    @classmethod
+    def compress_rtn(cls, weight: torch.Tensor, scheme) -> dict:
+        """Round-to-nearest compression straight from the dense weight (min-max qparams): the state dict `compress` returns
+        for {"weight", "weight_scale"} with calculate_qparams of the weight's group min / max, in ONE pass over the weight
+        (codec.rtn_mxfp4_quantize_and_pack) for 16-bit weights."""
+        if weight.dim() == 2 and weight.dtype in (torch.bfloat16, torch.float16) and weight.shape[1] % 32 == 0:
+            packed, code = codec.rtn_mxfp4_quantize_and_pack(weight)
+            return {"weight_packed": packed, "weight_scale": code.to(getattr(scheme.weights, "scale_dtype", None) or torch.uint8)}
+        scale = codec.minmax_qparams_float(weight, kind="mxfp4", group_size=32)
+        return cls.compress({"weight": weight, "weight_scale": scale}, scheme)
 
     @classmethod
     def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:

@@ -18,6 +18,7 @@
 // +-6) and v_cvt_scalef32_pk_f32_fp4 back; both are checked against the oracle over every bf16 input on the device
 // (tests/test_gpu_parity.py).  -0.0 inputs are folded to +0.0 with one add before the conversion.
 #include "ct_common.h"
+#include "ct_minmax.h"
 
 namespace ct {
 
@@ -188,6 +189,90 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4
         w[i] = fp4_quant_unit<XDT, GLOBAL>(ws, s[NS == 2 ? i >> 1 : 0], gs, in_dtype);
     }
     stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Round-to-nearest MXFP4 in ONE pass (the microscaling format gfx950's matrix cores consume): a lane owns exactly one
+// MX group (32 elements = 64 B in flight), so the min-max observer needs no cross-lane step: local amax -> E8M0 scale
+// (calculate_qparams' MX branch: compute_qparams_float) -> x / scale -> cast_to_fp4 -> 16 bytes of nibbles + one
+// exponent byte.  2 + 0.5 + 1/32 B per element instead of (2 + 2/32) + (2 + 0.5 + 2/32); bit-identical to
+// ct_minmax_qparams_float(kind 3) + ct_fp4_quant_pack + compress_mx_scale by construction (same helpers).
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void rtn_mxfp4_kernel(const u32x4* __restrict__ in, int64_t lanes, u32x4* __restrict__ out, uint8_t* __restrict__ e8m0,
+                                                           void* __restrict__ scale_out) {
+    const int64_t l = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (l >= lanes) return;
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[l * 4 + i];
+    MinMax m;
+    m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a, b;
+            fp4_unpack_pair<XDT>(ws[j], a, b);
+            m.nan |= (a != a) | (b != b);
+            m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
+            m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+        }
+    }
+    const float s = compute_qparams_float<XDT>(m, QP_MXFP4, 1.0f);
+    // compress_mx_scale: 127 + floor(log2(s)); s is a power of two (2^-127, the only subnormal one, is code 0), or inf / NaN
+    const uint32_t ef = (f_bits(s) >> 23) & 0xffu;
+    e8m0[l] = (uint8_t)((s != s) ? 0u : ef);  // inf: 255 = its exponent field; the int cast of NaN is 0 upstream
+    if (scale_out) store1<XDT>(scale_out, l, s);
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        w[i] = fp4_quant_unit<XDT, false>(ws, s, 1.0f, true);
+    }
+    stream_store16(out + l, u32x4{w[0], w[1], w[2], w[3]});
+}
+
+// The NVFP4 counterpart: a lane owns two groups of 16; the global scale (generate_gparam: a tensor-wide amax, i.e. one
+// read-only pass before this one) is an input.  Writes the nibbles, the float8_e4m3fn group scales (the stored form) and
+// optionally the float32 scales calculate_qparams returns.
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void rtn_nvfp4_kernel(const u32x4* __restrict__ in, int64_t lanes, const float* __restrict__ global_scale,
+                                                           u32x4* __restrict__ out, uint16_t* __restrict__ scale_f8, float* __restrict__ scale_out) {
+    const int64_t l = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (l >= lanes) return;
+    const float gs = global_scale[0];
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[l * 4 + i];
+    float s[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        MinMax m;
+        m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+#pragma unroll
+        for (int i = 2 * h; i < 2 * h + 2; ++i) {
+            const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a, b;
+                fp4_unpack_pair<XDT>(ws[j], a, b);
+                m.nan |= (a != a) | (b != b);
+                m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
+                m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+            }
+        }
+        s[h] = compute_qparams_float<XDT>(m, QP_NVFP4, gs);
+    }
+    scale_f8[l] = (uint16_t)f2_to_fp8x2(s[0], s[1]);  // scale.to(float8_e4m3fn): exact, the values are float8 already
+    if (scale_out) { scale_out[2 * l] = s[0]; scale_out[2 * l + 1] = s[1]; }
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        w[i] = fp4_quant_unit<XDT, true>(ws, s[i >> 1], gs, false);
+    }
+    stream_store16(out + l, u32x4{w[0], w[1], w[2], w[3]});
 }
 
 // every mantissa of s in [1, 2) against every mantissa of x in [1, 2) (7 bits bf16, 10 bits fp16; `xbits` of them):
@@ -489,6 +574,38 @@ int ct_selftest_fp4_div(int xdt, uint32_t m_lo, uint32_t m_hi, unsigned long lon
     if (g > kCUs * 64) g = kCUs * 64;
     hipLaunchKernelGGL(selftest_fp4_div_kernel, dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), xdt == CT_BF16 ? 7 : 10, m_lo, m_hi, mismatches);
     CT_LAUNCH_CHECK("ct_selftest_fp4_div");
+}
+
+int ct_rtn_mxfp4_quant_pack(const void* x, int xdt, int64_t rows, int64_t cols, uint8_t* packed, uint8_t* scale_e8m0, void* scale_out, ct_stream_t stream) {
+    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "the one-pass MXFP4 compress takes 16-bit float weights, got dtype %d", xdt);
+    CT_REQUIRE(rows >= 0 && cols >= 0 && cols % 32 == 0, "columns (%lld) must be a multiple of the MX group size 32", (long long)cols);
+    CT_REQUIRE(aligned16(x) && aligned16(packed) && scale_e8m0 != nullptr, "buffers must be 16-byte aligned and the scale output present");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int64_t lanes = rows * (cols / 32);
+    CT_REQUIRE(cdiv64(lanes, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
+    dim3 grid((unsigned)cdiv64(lanes, kBlock));
+    if (xdt == CT_BF16) hipLaunchKernelGGL((rtn_mxfp4_kernel<CT_BF16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes,
+                                           reinterpret_cast<u32x4*>(packed), scale_e8m0, scale_out);
+    else hipLaunchKernelGGL((rtn_mxfp4_kernel<CT_F16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes,
+                            reinterpret_cast<u32x4*>(packed), scale_e8m0, scale_out);
+    CT_LAUNCH_CHECK("ct_rtn_mxfp4_quant_pack");
+}
+
+int ct_rtn_nvfp4_quant_pack(const void* x, int xdt, int64_t rows, int64_t cols, const float* global_scale, uint8_t* packed, uint8_t* scale_f8,
+                            float* scale_out, ct_stream_t stream) {
+    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "the one-pass NVFP4 compress takes 16-bit float weights, got dtype %d", xdt);
+    CT_REQUIRE(rows >= 0 && cols >= 0 && cols % 32 == 0, "columns (%lld) must be a multiple of 32 (two groups of 16 per lane)", (long long)cols);
+    CT_REQUIRE(global_scale != nullptr && scale_f8 != nullptr, "the global scale and the scale output are required");
+    CT_REQUIRE(aligned16(x) && aligned16(packed) && (reinterpret_cast<uintptr_t>(scale_f8) & 1u) == 0, "misaligned buffers");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int64_t lanes = rows * (cols / 32);
+    CT_REQUIRE(cdiv64(lanes, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
+    dim3 grid((unsigned)cdiv64(lanes, kBlock));
+    if (xdt == CT_BF16) hipLaunchKernelGGL((rtn_nvfp4_kernel<CT_BF16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes, global_scale,
+                                           reinterpret_cast<u32x4*>(packed), reinterpret_cast<uint16_t*>(scale_f8), scale_out);
+    else hipLaunchKernelGGL((rtn_nvfp4_kernel<CT_F16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes, global_scale,
+                            reinterpret_cast<u32x4*>(packed), reinterpret_cast<uint16_t*>(scale_f8), scale_out);
+    CT_LAUNCH_CHECK("ct_rtn_nvfp4_quant_pack");
 }
 
 }  // extern "C"

@@ -207,6 +207,18 @@ int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, con
                           int sdt, const float* global_scale, int64_t group, void* out, int odt,
                           ct_stream_t stream);
 
+/* Round-to-nearest MXFP4 in one pass: per 32-element group the min-max observer, calculate_qparams' MX branch
+ * (helpers.py:50-137, mxfp_utils.py:118-143), quantize -> cast_to_fp4 -> pack (nvfp4/base.py:88-95) and
+ * compress_mx_scale (mx_utils.py:18-31).  packed: uint8 (rows, cols/2); scale_e8m0: uint8 (rows, cols/32), the
+ * stored form of the scale; scale_out (nullable): the float scale (x's dtype) calculate_qparams would return.
+ * Bit-identical to ct_minmax_qparams_float(kind 3) + ct_fp4_quant_pack + the E8M0 encoding. */
+int ct_rtn_mxfp4_quant_pack(const void* x, int xdt, int64_t rows, int64_t cols, uint8_t* packed,
+                            uint8_t* scale_e8m0, void* scale_out, ct_stream_t stream);
+/* The NVFP4 counterpart (groups of 16 under `global_scale`, device float32[1], e.g. generate_gparam of the weight):
+ * scale_f8: float8_e4m3fn bytes (rows, cols/16), the stored form; scale_out (nullable): the float32 scales. cols % 32 == 0. */
+int ct_rtn_nvfp4_quant_pack(const void* x, int xdt, int64_t rows, int64_t cols, const float* global_scale,
+                            uint8_t* packed, uint8_t* scale_f8, float* scale_out, ct_stream_t stream);
+
 /* The stand-alone primitives the reference exposes as ImplBackend entry points (utils/impl_backend.py:50-79):
  * cast_to_fp4 (quantization/utils/fp4_utils.py:77-98): n float elements -> the nearest E2M1 value in the same
  *   dtype; ties as upstream's thresholds, -0.0 -> +0.0, negative-rounds-to-zero -> -0.0, NaN -> NaN.

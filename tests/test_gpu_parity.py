@@ -1147,3 +1147,68 @@ def test_float_schemes_end_to_end_from_the_dense_weight(cta, dev):
             ref = O.dequantize(q, sdec, None)
         assert eq(back.cpu(), ref), fmt
         assert float((back.float().cpu() - w.float()).abs().max()) < (0.05 if kind in ("nvfp4", "mxfp4") else 0.02)
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_rtn_mxfp4_one_pass(cta, dev, xdt):
+    """ct_rtn_mxfp4_quant_pack == observer (MX branch of calculate_qparams) -> fp4 compress -> E8M0 encoding, against the
+    oracle and against the kernels it fuses; group maxima sweep every exponent and significand quarter"""
+    g = torch.Generator().manual_seed(21)
+    for shape in ((64, 256), (7, 96), (1, 32), (33, 4096)):
+        x = (torch.randn(shape, generator=g) * 0.3).to(xdt)
+        ngroups = x.numel() // 32
+        lo, hi = (-30, 17) if xdt == BF16 else (-20, 14)
+        mags = (2.0 ** torch.linspace(lo, hi, ngroups)) * (1 + 0.25 * (torch.arange(ngroups) % 5))
+        xv = x.view(-1, 32)
+        xv[:, 0] = torch.where(torch.arange(ngroups) % 2 == 0, mags, -mags).to(xdt)
+        xv[:, 1:] = (xv[:, 1:].float().clamp(-1, 1) * mags[:, None] * 0.9).to(xdt)
+        xv[0] = 0
+        if ngroups > 2:
+            xv[1] = torch.finfo(xdt).tiny / 4
+        packed, code, scale = cta.codec.rtn_mxfp4_quantize_and_pack(d(x, dev), return_scale=True)
+        s_ref = O.calculate_qparams_float(x, kind="mxfp4", group_size=32)
+        ref = O.fp4_compress(x, s_ref, None, fmt="mxfp4-pack-quantized")
+        assert eq(scale.cpu(), s_ref), shape
+        assert torch.equal(code.cpu(), ref["weight_scale"]) and torch.equal(packed.cpu(), ref["weight_packed"]), shape
+        s2 = cta.codec.minmax_qparams_float(d(x, dev), kind="mxfp4", group_size=32)
+        assert torch.equal(packed, cta.codec.fp4_quantize_and_pack(d(x, dev), s2, None, group_size=32))
+        assert torch.equal(code, cta.codec.compress_mx_scale(s2))
+    scheme = _fp4_scheme(cta, "mxfp4-pack-quantized")
+    w = torch.randn((128, 512), generator=g).to(xdt).to(dev)
+    got = cta.MXFP4PackedCompressor.compress_rtn(w, scheme)
+    s2 = cta.codec.minmax_qparams_float(w, kind="mxfp4", group_size=32)
+    ref = cta.MXFP4PackedCompressor.compress({"weight": w, "weight_scale": s2}, scheme)
+    assert sorted(got) == sorted(ref) and all(torch.equal(got[k], ref[k]) for k in ref)
+    back = cta.MXFP4PackedCompressor.decompress(got, scheme)["weight"]
+    assert float((back.float() - w.float()).abs().max()) <= float(w.float().abs().max()) * 0.26
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_rtn_nvfp4_one_pass(cta, dev, xdt):
+    """ct_rtn_nvfp4_quant_pack == generate_gparam -> observer (float8 scales under the global scale) -> fp4 compress"""
+    g = torch.Generator().manual_seed(23)
+    for shape in ((64, 256), (7, 96), (1, 32), (33, 4096)):
+        x = (torch.randn(shape, generator=g) * 0.3).to(xdt)
+        ngroups = x.numel() // 16
+        mags = (2.0 ** torch.linspace(-12, 3, ngroups)) * (1 + 0.25 * (torch.arange(ngroups) % 5))
+        xv = x.view(-1, 16)
+        xv[:, 0] = torch.where(torch.arange(ngroups) % 2 == 0, mags, -mags).to(xdt)
+        xv[:, 1:] = (xv[:, 1:].float().clamp(-1, 1) * mags[:, None] * 0.9).to(xdt)
+        xv[0] = 0
+        packed, s8, gs, scale = cta.codec.rtn_nvfp4_quantize_and_pack(d(x, dev), return_scale=True)
+        gs_ref = O.generate_gparam(x)
+        s_ref = O.calculate_qparams_float(x, kind="nvfp4", group_size=16, global_scale=gs_ref)
+        ref = O.fp4_compress(x, s_ref, gs_ref, fmt="nvfp4-pack-quantized")
+        assert eq(gs.cpu(), gs_ref) and eq(scale.cpu(), s_ref), shape
+        assert torch.equal(s8.cpu().view(torch.uint8), ref["weight_scale"].view(torch.uint8)) and torch.equal(packed.cpu(), ref["weight_packed"]), shape
+    scheme = _fp4_scheme(cta, "nvfp4-pack-quantized")
+    w = torch.randn((128, 512), generator=g).to(xdt).to(dev)
+    got = cta.NVFP4PackedCompressor.compress_rtn(w, scheme)
+    gs2 = cta.codec.generate_gparam(w)
+    s2 = cta.codec.minmax_qparams_float(w, kind="nvfp4", group_size=16, global_scale=gs2)
+    ref = cta.NVFP4PackedCompressor.compress({"weight": w, "weight_scale": s2, "weight_global_scale": gs2}, scheme)
+    assert sorted(got) == sorted(ref)
+    for k in ref:
+        assert torch.equal(got[k].view(torch.uint8) if got[k].dtype == F8 else got[k], ref[k].view(torch.uint8) if ref[k].dtype == F8 else ref[k]), k
+    back = cta.NVFP4PackedCompressor.decompress(got, scheme)["weight"]
+    assert float((back.float() - w.float()).abs().max()) <= float(w.float().abs().max()) * 0.26
