@@ -325,6 +325,8 @@ def float_formats_leg(dev):
         fq(i)
     alg = 3 * N * N + 2 * N
     out["float8_channel"] = {"alg_bytes_per_direction": alg, "quantize": rate(alg, time_kernel(fq, 36)), "dequantize": rate(alg, time_kernel(fd, 36, offset=6))}
+    rc = lambda i: lib.ct_rtn_quant_channel8(ws[i % nsets].data_ptr(), BF16, N, N, 1, 1, q8[i % nsets].data_ptr(), sc[i % nsets].data_ptr(), None, stream)
+    out["float8_channel"]["rtn_one_pass"] = rate(alg, time_kernel(rc, 36))  # observer + scale + quantize in one pass over the weight
     del q8
     # FP4
     p4 = [torch.empty(N, N // 2, dtype=torch.uint8, device=dev) for _ in range(nsets)]

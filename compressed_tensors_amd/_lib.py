@@ -54,6 +54,7 @@ _PROTOTYPES = {
     "ct_fake_quantize_fp4": (_Q + [_P, _I, _P, _I, _S], _I),
     "ct_dequantize_gs": (_Q + [_P, _P, _I, _S], _I),
     "ct_quant_pack": (_Q + [_I, _I, _P, _S], _I),
+    "ct_rtn_quant_channel8": ([_P, _I, _L, _L, _I, _I, _P, _P, _P, _S], _I),
     "ct_rtn_quant_pack_w4": ([_P, _I, _L, _L, _L, _I, _P, _P, _P, _S], _I),
     "ct_unpack_dequant": ([_P, _L, _L, _L, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _I, _S], _I),
     "ct_w4_batch_plan": ([_P, _I, _I], _L),

@@ -27,6 +27,7 @@ __all__ = [
     "generate_gparam",
     "rtn_quantize_and_pack",
     "rtn_mxfp4_quantize_and_pack",
+    "rtn_quantize_channel8",
     "rtn_nvfp4_quantize_and_pack",
     "pack_bitmasks",
     "unpack_bitmasks",
@@ -555,6 +556,27 @@ def rtn_nvfp4_quantize_and_pack(x: torch.Tensor, global_scale: Optional[torch.Te
     call("ct_rtn_nvfp4_quant_pack", ptr(xd), DT[xd.dtype], rows, cols, ptr(gs), ptr(packed), ptr(s8), ptr(scale), stream_of(xd))
     out = (_home(packed, x), _home(s8, x), _home(gs, x))
     return out + (_home(scale, x),) if return_scale else out
+
+
+def rtn_quantize_channel8(x: torch.Tensor, *, qtype: str = "int", symmetric: bool = True):
+    """Channel-wise 8-bit round-to-nearest in ONE pass over the weight: per-row min-max observer + calculate_qparams +
+    quantize to int8 (qtype "int") or float8_e4m3fn ("float").  Returns (codes (R, C), scale (R, 1) in x.dtype, zero_point):
+    the zero point is int8 (R, 1) for INT, float8 zeros for FLOAT — bit-identical to the observer kernel followed by
+    quantize_tensor."""
+    if x.dim() != 2:
+        raise ValueError("rtn_quantize_channel8 expects a 2-D weight")
+    qtype = getattr(qtype, "value", qtype)
+    if x.dtype not in (torch.bfloat16, torch.float16) or x.shape[1] % 8 != 0 or x.shape[1] > 16384 or (qtype == "float" and not symmetric):
+        raise NotImplementedError("the one-pass channel-wise compress takes 16-bit weights with cols % 8 == 0 and cols <= 16384 (symmetric for FLOAT)")
+    rows, cols = x.shape
+    dev = _compute_device(x)
+    xd = _dev(x, dev).contiguous()
+    fp8 = qtype == "float"
+    out = torch.empty((rows, cols), dtype=_F8 if fp8 else torch.int8, device=dev)
+    scale = torch.empty((rows, 1), dtype=x.dtype, device=dev)
+    zp = torch.zeros((rows, 1), dtype=_F8, device=dev) if fp8 else torch.empty((rows, 1), dtype=torch.int8, device=dev)
+    call("ct_rtn_quant_channel8", ptr(xd), DT[xd.dtype], rows, cols, int(fp8), int(bool(symmetric)), ptr(out), ptr(scale), None if fp8 else ptr(zp), stream_of(xd))
+    return _home(out, x), _home(scale, x), _home(zp, x)
 
 
 def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, strategy, group_size, g_idx=None) -> bool:

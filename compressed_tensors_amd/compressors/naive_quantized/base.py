@@ -41,6 +41,27 @@ class NaiveQuantizationCompressor(BaseCompressor):
         return cls._remove_symmetric_zp(state_dict, scheme)
 
     @classmethod
+    def compress_rtn(cls, weight, scheme) -> dict:
+        """Round-to-nearest compression straight from the dense weight (min-max qparams): what `compress` returns for
+        {"weight", "weight_scale", "weight_zero_point"} of calculate_qparams over the weight's min / max.  Channel-wise
+        8-bit schemes (W8A8 int8 / FP8) take ONE pass over the weight (codec.rtn_quantize_channel8); the rest composes the
+        observer kernel with `compress`."""
+        import torch
+
+        from ...quantization.utils import calculate_qparams_from_weight
+
+        weights = scheme.weights
+        qtype = enum_value(getattr(weights, "type", "int"))
+        one_pass = (enum_value(weights.strategy) == "channel" and int(weights.num_bits) == 8 and weight.dim() == 2
+                    and weight.dtype in (torch.bfloat16, torch.float16) and weight.shape[1] % 8 == 0 and weight.shape[1] <= 16384
+                    and (qtype == "int" or (weights.symmetric and getattr(weights, "scale_dtype", None) is None)))
+        if not one_pass:
+            scale, zp = calculate_qparams_from_weight(weight, weights)
+            return cls.compress({"weight": weight, "weight_scale": scale, "weight_zero_point": zp}, scheme)
+        q, scale, zp = codec.rtn_quantize_channel8(weight, qtype=qtype, symmetric=bool(weights.symmetric))
+        return cls._remove_symmetric_zp({"weight": q, "weight_scale": scale, "weight_zero_point": zp}, scheme)
+
+    @classmethod
     def decompress(cls, state_dict: dict, scheme) -> dict:
         """naive_quantized/base.py:102-126"""
         state_dict = state_dict.copy()

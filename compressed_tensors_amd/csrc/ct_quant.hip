@@ -877,6 +877,81 @@ __global__ __launch_bounds__(kBlock) void f8_dequant_kernel(W4Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Channel-wise 8-bit round-to-nearest in ONE pass (W8A8 int8 / FP8 weights: the per-output-channel min-max observer +
+// calculate_qparams + quantize): one workgroup per row holds the row in registers (MAXU 16-byte units per thread,
+// one block apart: every wave load reads 1 KiB contiguous), reduces min / max through DPP + LDS, every thread
+// evaluates the identical scale and quantizes its own units.  2 + 1 B per element instead of 2 + (2 + 1).
+// ------------------------------------------------------------------------------------------
+template <int DT, int MAXU, bool FP8>
+__global__ __launch_bounds__(kBlock) void rtn_channel8_kernel(const u32x4* __restrict__ in, int64_t rows, int upr /* units per row */, int symmetric,
+                                                              u32x2* __restrict__ out, void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
+    __shared__ float s_mn[kBlock / 64], s_mx[kBlock / 64];
+    __shared__ int s_nan[kBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const u32x4* rin = in + row * upr;
+        u32x4 r[MAXU];
+        MinMax m;
+        m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = i * kBlock + tid;
+            if (u < upr) r[i] = rin[u];
+        }
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = i * kBlock + tid;
+            if (u < upr) {
+                const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a, b;
+                    unpack2<DT>(ws[j], a, b);
+                    m.nan |= (a != a) | (b != b);
+                    m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
+                    m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+                }
+            }
+        }
+        m = group_reduce(m, 64);
+        if (lane == 0) { s_mn[wave] = m.mn; s_mx[wave] = m.mx; s_nan[wave] = m.nan; }
+        __syncthreads();
+        m.mn = __builtin_fminf(__builtin_fminf(s_mn[0], s_mn[1]), __builtin_fminf(s_mn[2], s_mn[3]));
+        m.mx = __builtin_fmaxf(__builtin_fmaxf(s_mx[0], s_mx[1]), __builtin_fmaxf(s_mx[2], s_mx[3]));
+        m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
+        float s, z = 0.0f;
+        if constexpr (FP8) s = compute_qparams_float<DT>(m, QP_FP8, 1.0f);
+        else compute_qparams<DT>(m, 8, symmetric, s, z);
+        if (tid == 0) {
+            store1<DT>(scale_out, row, s);
+            if (zp_out) zp_out[row] = (int8_t)(int)z;
+        }
+        const float as = __builtin_fabsf(s);
+        const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+        const float rs = 1.0f / s;
+        const bool use_zp = !FP8 && !symmetric && z != 0.0f;  // block-uniform
+        u32x2* rout = out + row * upr;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int u = i * kBlock + tid;
+            if (u >= upr) continue;
+            uint32_t lo, hi;
+            if constexpr (FP8) {
+                // with the (all-zero) zero point of a calibrated scheme present, as in the compressor's call: -0.0 + 0 = +0.0
+                if (fast) f8_quant_words<DT, true, true>(r[i], s, rs, 0.0f, lo, hi);
+                else f8_quant_words<DT, false, true>(r[i], s, rs, 0.0f, lo, hi);
+            } else {
+                if (fast) { if (use_zp) q8_quant_words<DT, true, true>(r[i], s, rs, z, -128, 127, lo, hi); else q8_quant_words<DT, true, false>(r[i], s, rs, z, -128, 127, lo, hi); }
+                else { if (use_zp) q8_quant_words<DT, false, true>(r[i], s, rs, z, -128, 127, lo, hi); else q8_quant_words<DT, false, false>(r[i], s, rs, z, -128, 127, lo, hi); }
+                lo ^= 0x80808080u; hi ^= 0x80808080u;  // (code + 128) -> two's-complement code
+            }
+            stream_store8(rout + u, u32x2{lo, hi});
+        }
+        __syncthreads();  // the reduction scratch is reused by the next row
+    }
+}
+
 // fake_quantize fast path (forward_helpers.py:180-215): x, scale and the result share one 16-bit dtype.
 // Same flat unit stream: lane = UNROLL units one block apart, 16 B in, 16 B out.
 template <int DT, int UNROLL, bool HAS_ZP>
@@ -1309,6 +1384,28 @@ int ct_rtn_quant_pack_w4(const void* x, int xdt, int64_t rows, int64_t cols, int
     else hipLaunchKernelGGL((rtn_w4_kernel<CT_F16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes, lpg, symmetric,
                             reinterpret_cast<u32x4*>(packed), scale_out, zp_out);
     CT_LAUNCH_CHECK("ct_rtn_quant_pack_w4");
+}
+
+int ct_rtn_quant_channel8(const void* x, int xdt, int64_t rows, int64_t cols, int fp8, int symmetric, void* out, void* scale_out, int8_t* zp_out,
+                          ct_stream_t stream) {
+    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "the one-pass channel-wise compress takes 16-bit float weights, got dtype %d", xdt);
+    CT_REQUIRE(rows >= 0 && cols >= 0 && cols % 8 == 0 && cols <= 8 * 8 * kBlock, "columns (%lld) must be a multiple of 8 and at most %d", (long long)cols,
+               8 * 8 * kBlock);
+    CT_REQUIRE(!fp8 || symmetric, "FLOAT 8-bit round-to-nearest is symmetric");
+    CT_REQUIRE(aligned16(x) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && scale_out != nullptr, "misaligned buffers");
+    CT_REQUIRE(symmetric || zp_out != nullptr, "asymmetric quantization needs the zero-point output");
+    if (rows == 0 || cols == 0) return CT_OK;
+    const int upr = (int)(cols / 8);
+    const int need = (upr + kBlock - 1) / kBlock;
+    const unsigned grid = (unsigned)(rows < ((int64_t)1 << 30) ? rows : ((int64_t)1 << 30));
+#define CT_RC8(DT, MU, F8) hipLaunchKernelGGL((rtn_channel8_kernel<DT, MU, F8>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), rows, upr, \
+                                              symmetric, static_cast<u32x2*>(out), scale_out, zp_out)
+#define CT_RC8_U(DT, F8) do { if (need <= 1) CT_RC8(DT, 1, F8); else if (need <= 2) CT_RC8(DT, 2, F8); else if (need <= 4) CT_RC8(DT, 4, F8); else CT_RC8(DT, 8, F8); } while (0)
+    if (xdt == CT_BF16) { if (fp8) CT_RC8_U(CT_BF16, true); else CT_RC8_U(CT_BF16, false); }
+    else { if (fp8) CT_RC8_U(CT_F16, true); else CT_RC8_U(CT_F16, false); }
+#undef CT_RC8_U
+#undef CT_RC8
+    CT_LAUNCH_CHECK("ct_rtn_quant_channel8");
 }
 
 int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_t cols, int bits,

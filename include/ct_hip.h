@@ -147,6 +147,13 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
 int ct_rtn_quant_pack_w4(const void* x, int xdt, int64_t rows, int64_t cols, int64_t group, int symmetric,
                          int32_t* packed, void* scale_out, int8_t* zp_out, ct_stream_t stream);
 
+/* Channel-wise 8-bit round-to-nearest in one pass (W8A8 int8 / FP8 weights): per-row min-max observer +
+ * calculate_qparams (helpers.py:50-137) + quantize(dtype = int8 resp. float8_e4m3fn) (forward.py:36-73).  out: one
+ * byte per element; scale_out (rows, 1) in x's dtype; zp_out int8 (rows, 1), required when !symmetric (int8 only).
+ * cols % 8 == 0, cols <= 16384.  Bit-identical to ct_minmax_qparams(_float) followed by ct_quantize(_fp8). */
+int ct_rtn_quant_channel8(const void* x, int xdt, int64_t rows, int64_t cols, int fp8, int symmetric, void* out,
+                          void* scale_out, int8_t* zp_out, ct_stream_t stream);
+
 /* Fused PackedQuantizationCompressor.decompress weight path: unpack_from_int32 followed by
  * dequantize.   base.py:155-161.  zp is the UNPACKED zero point (int8) or NULL. */
 int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_t cols, int bits,

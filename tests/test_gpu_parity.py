@@ -1212,3 +1212,52 @@ def test_rtn_nvfp4_one_pass(cta, dev, xdt):
         assert torch.equal(got[k].view(torch.uint8) if got[k].dtype == F8 else got[k], ref[k].view(torch.uint8) if ref[k].dtype == F8 else ref[k]), k
     back = cta.NVFP4PackedCompressor.decompress(got, scheme)["weight"]
     assert float((back.float() - w.float()).abs().max()) <= float(w.float().abs().max()) * 0.26
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+@pytest.mark.parametrize("qtype,symmetric", [("int", True), ("int", False), ("float", True)])
+def test_rtn_channel8_one_pass(cta, dev, xdt, qtype, symmetric):
+    """ct_rtn_quant_channel8 == per-row observer + calculate_qparams + quantize (int8 / float8), for every row width class"""
+    g = torch.Generator().manual_seed(29)
+    for shape in ((16, 8), (9, 2048), (5, 2056), (7, 4096), (3, 11008), (4, 16384), (300, 512)):
+        x = (torch.randn(shape, generator=g) * torch.logspace(-3, 2, shape[0]).reshape(-1, 1)).to(xdt)
+        sp = special_values(xdt)
+        sp = sp[torch.isfinite(sp.float())]
+        n = min(sp.numel(), shape[1])
+        x[0, :n] = sp[:n]
+        if shape[0] > 2:
+            x[1] = 0
+            x[2] = x[2].abs() + 0.01
+        q, scale, zp = cta.codec.rtn_quantize_channel8(d(x, dev), qtype=qtype, symmetric=symmetric)
+        if qtype == "int":
+            s_ref, z_ref = O.calculate_qparams_minmax(x, num_bits=8, group_size=None, symmetric=symmetric)
+            q_ref = O.quantize(x, s_ref, z_ref, num_bits=8, strategy="channel", dtype=torch.int8)
+            assert eq(scale.cpu(), s_ref) and torch.equal(zp.cpu(), z_ref) and torch.equal(q.cpu(), q_ref), shape
+        else:
+            s_ref = O.calculate_qparams_float(x, kind="fp8")
+            q_ref = O.quantize(x, s_ref, torch.zeros_like(s_ref, dtype=F8), num_bits=8, strategy="channel", dtype=F8, qtype="float")
+            assert eq(scale.cpu(), s_ref) and eq_f8(q.cpu(), q_ref) and not bool(zp.view(torch.uint8).any()), shape
+            s2 = cta.codec.minmax_qparams_float(d(x, dev), kind="fp8")
+            q2 = cta.codec.quantize_tensor(d(x, dev), s2, torch.zeros_like(s2, dtype=F8), num_bits=8, strategy="channel", dtype=F8, qtype="float")
+            assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8))
+
+
+def test_naive_compress_rtn_matches_observer_plus_compress(cta, dev):
+    from compressed_tensors_amd.quantization import calculate_qparams_from_weight
+
+    torch.manual_seed(5)
+    w = torch.randn((96, 1024), dtype=BF16, device=dev)
+    act = cta.QuantizationArgs(num_bits=8, type="float", strategy="tensor")
+    for fmt, wargs in (("float-quantized", cta.QuantizationArgs(num_bits=8, type="float", strategy="channel")),
+                       ("int-quantized", cta.QuantizationArgs(num_bits=8, strategy="channel", symmetric=True)),
+                       ("int-quantized", cta.QuantizationArgs(num_bits=8, strategy="channel", symmetric=False)),
+                       ("naive-quantized", cta.QuantizationArgs(num_bits=8, strategy="group", group_size=128, symmetric=True))):
+        scheme = cta.QuantizationScheme(targets=["Linear"], weights=wargs, input_activations=act)
+        comp = cta.BaseCompressor.get_value_from_registry(fmt)
+        got = comp.compress_rtn(w, scheme)
+        scale, zp = calculate_qparams_from_weight(w, wargs)
+        ref = comp.compress({"weight": w, "weight_scale": scale, "weight_zero_point": zp}, scheme)
+        assert sorted(got) == sorted(ref), fmt
+        for k in ref:
+            a, b = got[k], ref[k]
+            assert torch.equal(a.view(torch.uint8) if a.dtype == F8 else a, b.view(torch.uint8) if b.dtype == F8 else b), (fmt, k)
