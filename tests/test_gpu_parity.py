@@ -1261,3 +1261,41 @@ def test_naive_compress_rtn_matches_observer_plus_compress(cta, dev):
         for k in ref:
             a, b = got[k], ref[k]
             assert torch.equal(a.view(torch.uint8) if a.dtype == F8 else a, b.view(torch.uint8) if b.dtype == F8 else b), (fmt, k)
+
+
+def test_model_compressor_rtn_mixed_schemes(cta, dev):
+    """compress_model_rtn: a model with W4A16, MXFP4, NVFP4 and FP8 modules compressed straight from the dense weights; the first
+    forward decompresses; every weight equals the oracle's observer -> compress -> decompress of that scheme"""
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(256, 512, bias=True), torch.nn.Linear(512, 256, bias=False), torch.nn.Linear(256, 384, bias=False),
+                                torch.nn.Linear(384, 128, bias=False)).to(dev).to(BF16)
+    act = cta.QuantizationArgs(num_bits=8, type="float", strategy="tensor")
+    schemes = [cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True)),
+               _fp4_scheme(cta, "mxfp4-pack-quantized"), _fp4_scheme(cta, "nvfp4-pack-quantized"),
+               cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=8, type="float", strategy="channel"), input_activations=act)]
+    expect = []
+    for m, scheme in zip(model, schemes):
+        m.quantization_scheme = scheme
+        w = m.weight.data.cpu()
+        wa = scheme.weights
+        if wa.type.value == "int":
+            s, z = O.calculate_qparams_minmax(w, num_bits=4, group_size=128, symmetric=True)
+            expect.append(O.fake_quantize(w, s, z, num_bits=4, strategy="group", group_size=128))
+        elif wa.num_bits == 4:
+            fmt = "mxfp4-pack-quantized" if wa.group_size == 32 else "nvfp4-pack-quantized"
+            gs = O.generate_gparam(w) if wa.group_size == 16 else None
+            s = O.calculate_qparams_float(w, kind="mxfp4" if gs is None else "nvfp4", group_size=wa.group_size, global_scale=gs)
+            expect.append(O.fp4_decompress(O.fp4_compress(w, s, gs, fmt=fmt), fmt=fmt)["weight"])
+        else:
+            s = O.calculate_qparams_float(w, kind="fp8")
+            q = O.quantize(w, s, torch.zeros_like(s, dtype=F8), num_bits=8, strategy="channel", dtype=F8, qtype="float")
+            expect.append(O.dequantize(q, s, None))
+    bias0 = model[0].bias.data.clone()
+    cta.ModelCompressor().compress_model_rtn(model)
+    assert [m.quantization_scheme.format.value for m in model] == ["pack-quantized", "mxfp4-pack-quantized", "nvfp4-pack-quantized", "float-quantized"]
+    assert model[0].weight_packed.dtype == torch.int32 and model[1].weight_scale.dtype == torch.uint8 and model[2].weight_scale.dtype == F8
+    assert model[3].weight.dtype == F8 and torch.equal(model[0].bias.data, bias0)
+    y = model(torch.randn(4, 256, device=dev, dtype=BF16))
+    assert y.shape == (4, 128)
+    for m, ref in zip(model, expect):
+        assert torch.equal(m.weight.data.cpu(), ref)
