@@ -11,9 +11,35 @@ from ..naive_quantized import NaiveQuantizationCompressor
 
 __all__ = ["MXFP8QuantizationCompressor"]
 
+_naive_compress = NaiveQuantizationCompressor.compress.__func__
+_naive_decompress = NaiveQuantizationCompressor.decompress.__func__
+
 
 @BaseCompressor.register(name=CompressionFormat.mxfp8_quantized.value)
 class MXFP8QuantizationCompressor(NaiveQuantizationCompressor):
+    @classmethod
+    def can_compress(cls, module_type: type, scheme) -> bool:
+        """mxfp8/base.py:103-118: FLOAT, 8 bits, groups of 32, uint8 (E8M0) scales"""
+        w = getattr(scheme, "weights", None)
+        if module_type not in COMPRESSIBLE_MODULE_TYPES or w is None:
+            return False
+        signature = (enum_value(w.type), int(w.num_bits), getattr(w, "group_size", None), getattr(w, "scale_dtype", None))
+        return signature == ("float", 8, 32, torch.uint8)
+
+    @classmethod
+    def compress(cls, state_dict: dict, scheme) -> dict:
+        """mxfp8/base.py:47-72: quantize against the float scale, then keep only the scale's exponent"""
+        out = _naive_compress(cls, state_dict, scheme)
+        out["weight_scale"] = cls._compress_scale(out["weight_scale"], scheme.weights)
+        return out
+
+    @classmethod
+    def decompress(cls, state_dict: dict, scheme) -> dict:
+        """mxfp8/base.py:74-101: the exponent comes back as a bfloat16 power of two, so the weight is bfloat16 too"""
+        widened = dict(state_dict, weight_scale=cls._decompress_scale(state_dict["weight_scale"]))
+        return _naive_decompress(cls, widened, scheme)
+
+    # the two hooks keep upstream's names: install() lets upstream's subclass call them
     @classmethod
     def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:
         return codec.compress_mx_scale(scale, getattr(weights, "scale_dtype", None) or torch.uint8)
@@ -21,30 +47,3 @@ class MXFP8QuantizationCompressor(NaiveQuantizationCompressor):
     @classmethod
     def _decompress_scale(cls, scale: torch.Tensor) -> torch.Tensor:
         return codec.decompress_mx_scale(scale)
-
-    @classmethod
-    def compress(cls, state_dict: dict, scheme) -> dict:
-        """mxfp8/base.py:47-72: quantize with the float scale, then store the scale as its E8M0 exponent"""
-        state_dict = NaiveQuantizationCompressor.compress.__func__(cls, state_dict, scheme)
-        state_dict["weight_scale"] = cls._compress_scale(state_dict["weight_scale"], scheme.weights)
-        return state_dict
-
-    @classmethod
-    def decompress(cls, state_dict: dict, scheme) -> dict:
-        """mxfp8/base.py:74-101: the scale comes back as bfloat16, so the weight does too"""
-        state_dict = state_dict.copy()
-        state_dict["weight_scale"] = cls._decompress_scale(state_dict["weight_scale"])
-        return NaiveQuantizationCompressor.decompress.__func__(cls, state_dict, scheme)
-
-    @classmethod
-    def can_compress(cls, module_type: type, scheme) -> bool:
-        """mxfp8/base.py:103-118: FP8 with group_size 32 and uint8 scales"""
-        w = getattr(scheme, "weights", None)
-        return (
-            module_type in COMPRESSIBLE_MODULE_TYPES
-            and w is not None
-            and int(w.num_bits) == 8
-            and enum_value(w.type) == "float"
-            and getattr(w, "group_size", None) == 32
-            and getattr(w, "scale_dtype", None) == torch.uint8
-        )
