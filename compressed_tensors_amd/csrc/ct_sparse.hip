@@ -555,7 +555,9 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         // vector, so that the global side of the staging loads is aligned
         int shift = 0, nvec = 0;
         int64_t e0 = 0;
-        u32x4 vv[4];
+        // the value run goes global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass; the
+        // LDS image is lane-linear, which is exactly the order of the 16-byte vectors).  Vectors that would cross the end
+        // of the buffer are filled element-wise afterwards.
         auto stage_issue = [&](int total) {
             shift = (int)(run & 7);
             nvec = (shift + total + 7) >> 3;
@@ -564,21 +566,18 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int v = tid + k * kBlock;
-                if (v < nvec && e0 + (int64_t)(v + 1) * 8 <= values_len) vv[k] = g[v];
+                if (v < nvec && e0 + (int64_t)(v + 1) * 8 <= values_len)
+                    __builtin_amdgcn_global_load_lds(g + v, (__attribute__((address_space(3))) void*)(s_val + (k * kBlock + wave * 64) * 8), 16, 0, 0);
             }
         };
         auto stage_commit = [&]() {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int v = tid + k * kBlock;
-                if (v < nvec) {
-                    if (e0 + (int64_t)(v + 1) * 8 <= values_len) {
-                        reinterpret_cast<u32x4*>(s_val)[v] = vv[k];
-                    } else {  // a tail vector that would cross the end of the buffer
-                        for (int j = 0; j < 8; ++j) {
-                            const int64_t gi = e0 + (int64_t)v * 8 + j;
-                            s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
-                        }
+                if (v < nvec && e0 + (int64_t)(v + 1) * 8 > values_len) {  // a tail vector that would cross the end of the buffer
+                    for (int j = 0; j < 8; ++j) {
+                        const int64_t gi = e0 + (int64_t)v * 8 + j;
+                        s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
                     }
                 }
             }
@@ -591,14 +590,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             }
         };
 
-        if constexpr (SINGLE) {
-            int64_t row_end = values_len;
-            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
-            else row_end = run + fixed_row_nnz;
-            int64_t len = row_end - run;
-            len = len < 0 ? 0 : (len > kTile16 ? kTile16 : len);
-            stage_issue((int)len);
-        } else {
+        if constexpr (!SINGLE) {
             // popcount of the row's mask bytes before this tile
             int c = 0;
             for (int64_t d = tid; d < (u0 >> 2); d += kBlock) c += __popc(reinterpret_cast<const uint32_t*>(mrow)[d]);
@@ -606,13 +598,26 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             if (lane == 63) s_pre[wave] = c;
         }
 
-        // ranks: wave-local exclusive prefix of the lane's dword + popcounts of its lower bytes
+        // ranks: wave-local exclusive prefix of the lane's dword + popcounts of its lower bytes.  Every ordinary load of
+        // this tile (mask dword, mask bytes, row offsets) is consumed BEFORE the LDS-direct loads are issued: hipcc waits
+        // vmcnt(0) at the first use of an ordinary load while an LDS-direct load is in flight
         const int c = __popc(md);
         const int incl = wave_incl_scan(c);
         if (lane == 63) s_tot[wave] = incl;
         const uint32_t r0 = (uint32_t)(incl - c);
         const uint32_t r1 = r0 + __popc(md & 0xffu), r2 = r0 + __popc(md & 0xffffu), r3 = r0 + __popc(md & 0xffffffu);
         reinterpret_cast<u32x2*>(s_rank)[tid] = u32x2{r0 | (r1 << 16), r2 | (r3 << 16)};
+        uint32_t offs4[4];  // window offsets of the lane's four units, from its mask bytes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) offs4[i] = (2u * __popc(mb[i] & 3u)) | ((2u * __popc(mb[i] & 15u)) << 8) | ((2u * __popc(mb[i] & 63u)) << 16) | (mb[i] << 24);
+        if constexpr (SINGLE) {
+            int64_t row_end = values_len;
+            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
+            else row_end = run + fixed_row_nnz;
+            int64_t len = row_end - run;
+            len = len < 0 ? 0 : (len > kTile16 ? kTile16 : len);
+            stage_issue((int)len);
+        }
         if constexpr (SINGLE) stage_commit();
         __syncthreads();
         const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2], t3 = s_tot[3];
@@ -631,12 +636,12 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         for (int i = 0; i < 4; ++i) {
             const int u = i * kBlock + tid;
             if (u >= nu) continue;
-            const uint32_t mv = mb[i];
+            const uint32_t mv = offs4[i] >> 24;
             const uint32_t r = (uint32_t)s_rank[u] + (uint32_t)(wbase[i] + shift);
             const uint32_t a0 = 2u * r;
             uint32_t w[4];
             // selectors from the 8-entry table (8 distinct banks: conflict-free), window offsets from popcounts
-            const uint32_t offs[4] = {0u, 2u * __popc(mv & 3u), 2u * __popc(mv & 15u), 2u * __popc(mv & 63u)};
+            const uint32_t offs[4] = {0u, offs4[i] & 0xffu, (offs4[i] >> 8) & 0xffu, (offs4[i] >> 16) & 0xffu};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t aj = a0 + offs[j];
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             }
             stream_store16(orow + ((int64_t)u << 3), u32x4{w[0], w[1], w[2], w[3]});
         }
-        __syncthreads();
+        __syncthreads();  // (skipping this barrier on the last tile measured 1 us SLOWER)
     }
 }
 
