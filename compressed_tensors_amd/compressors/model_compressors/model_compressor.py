@@ -83,32 +83,36 @@ class ModelCompressor:
             self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
         self.add_decompress_hook(model)
 
-    def compress_model_rtn(self, model: torch.nn.Module) -> None:
+    def compress_model_rtn(self, model: torch.nn.Module, recouple: bool = False) -> None:
         """Data-free (round-to-nearest) compression of a model whose modules carry a `quantization_scheme` but no scales yet:
         for every quantized module the min-max observer, calculate_qparams and the codec run fused — one pass over each
         weight where the scheme allows it (int4 group / channel, MXFP4, NVFP4, channel-wise int8 / float8; see the codecs'
-        `compress_rtn`).  Bias and other parameters are kept.  No upstream counterpart: upstream separates calibration
-        (observers, llm-compressor) from `compress_model`; the result equals that two-step flow with min-max observers."""
+        `compress_rtn`).  Bias and other parameters are kept.  Under torch.distributed the modules are sharded over the
+        ranks exactly like `compress_model`.  No upstream counterpart: upstream separates calibration (observers,
+        llm-compressor) from `compress_model`; the result equals that two-step flow with min-max observers."""
         from ...utils.module import get_direct_state_dict, replace_direct_state_dict
         from ..base import BaseCompressor
         from ..format import infer_module_format
 
-        for module in self._quantized_modules(model, skip_compressed=True):
-            scheme = module.quantization_scheme
-            fmt = self.force_compression_format or getattr(scheme, "format", None) or infer_module_format(type(module), scheme)
-            fmt = CompressionFormat(getattr(fmt, "value", fmt))
-            comp = BaseCompressor.get_value_from_registry(fmt.value)
-            if not hasattr(comp, "compress_rtn"):
-                raise NotImplementedError(f"round-to-nearest compression is not implemented for format {fmt.value}")
-            sd = get_direct_state_dict(module)
-            new = {k: v for k, v in sd.items() if not k.startswith("weight")}
-            new.update(comp.compress_rtn(sd["weight"], scheme))
-            replace_direct_state_dict(module, new)
-            try:
-                scheme.format = fmt
-            except Exception:
-                scheme.format = fmt.value
-            module.quantization_status = QuantizationStatus.COMPRESSED
+        def apply(modules):
+            for module in modules:
+                scheme = module.quantization_scheme
+                fmt = self.force_compression_format or getattr(scheme, "format", None) or infer_module_format(type(module), scheme)
+                fmt = CompressionFormat(getattr(fmt, "value", fmt))
+                comp = BaseCompressor.get_value_from_registry(fmt.value)
+                if not hasattr(comp, "compress_rtn"):
+                    raise NotImplementedError(f"round-to-nearest compression is not implemented for format {fmt.value}")
+                sd = get_direct_state_dict(module)
+                new = {k: v for k, v in sd.items() if not k.startswith("weight")}
+                new.update(comp.compress_rtn(sd["weight"], scheme))
+                replace_direct_state_dict(module, new)
+                try:
+                    scheme.format = fmt
+                except Exception:
+                    scheme.format = fmt.value
+                module.quantization_status = QuantizationStatus.COMPRESSED
+
+        replace_module_parallel(self._quantized_modules(model, skip_compressed=True), apply, module_size, recouple=recouple)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
         self.add_decompress_hook(model)
