@@ -92,6 +92,52 @@ __global__ __launch_bounds__(kBlock) void unpack_rows_kernel(const int32_t* __re
     }
 }
 
+// flat forms of the two common widths (contiguous rows, cols % 32 == 0: the packed tensor is one stream of words).
+// The lane-per-group kernel above stores 32 bytes per lane (two lane-strided 16-byte stores: 21.9 us for 8192^2 int4);
+// here a lane owns HALF a group resp. one word pair -> exactly one 16-byte store, 1 KiB contiguous per wave instruction.
+//   4 bits: 2 words (8 B) in -> 16 codes: nibbles split with two masks, interleaved with v_perm_b32, un-biased per byte
+//           as (u + 0x78) ^ 0x80 (no carry between bytes: u <= 15).
+//   8 bits: 4 words (16 B) in -> 16 codes: u ^ 0x80.
+template <int BITS, int UNROLL>
+__global__ __launch_bounds__(kBlock) void unpack_flat_kernel(const uint32_t* __restrict__ p, int64_t items, u32x4* __restrict__ out) {
+    const int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x;
+    if constexpr (BITS == 4) {
+        u32x2 w[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t it = base + (int64_t)i * kBlock;
+            if (it < items) w[i] = reinterpret_cast<const u32x2*>(p)[it];
+        }
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t it = base + (int64_t)i * kBlock;
+            if (it >= items) continue;
+            uint32_t o[4];
+            const uint32_t ws[2] = {w[i].x, w[i].y};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t lo = ws[h] & 0x0f0f0f0fu, hi = (ws[h] >> 4) & 0x0f0f0f0fu;
+                const uint32_t a = __builtin_amdgcn_perm(hi, lo, 0x05010400u), b = __builtin_amdgcn_perm(hi, lo, 0x07030602u);
+                o[2 * h] = (a + 0x78787878u) ^ 0x80808080u;
+                o[2 * h + 1] = (b + 0x78787878u) ^ 0x80808080u;
+            }
+            stream_store16(out + it, u32x4{o[0], o[1], o[2], o[3]});
+        }
+    } else {
+        u32x4 w[UNROLL];
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t it = base + (int64_t)i * kBlock;
+            if (it < items) w[i] = reinterpret_cast<const u32x4*>(p)[it];
+        }
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t it = base + (int64_t)i * kBlock;
+            if (it < items) stream_store16(out + it, u32x4{w[i].x ^ 0x80808080u, w[i].y ^ 0x80808080u, w[i].z ^ 0x80808080u, w[i].w ^ 0x80808080u});
+        }
+    }
+}
+
 // packed along rows: lane (g, c) packs rows [32g, 32g+32) of column c; lanes are consecutive
 // in c so every access is coalesced across the wave.
 template <int BITS>
@@ -171,6 +217,17 @@ int ct_pack_int32(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t
     CT_REQUIRE(out_row_stride >= packed_cols, "output row stride %lld < %lld packed words", (long long)out_row_stride,
                (long long)packed_cols);
     if (rows == 0 || cols == 0) return CT_OK;
+    if (bits == 8 && cols % 32 == 0 && out_row_stride == packed_cols && aligned16(q) && aligned16(out)) {
+        // 8 bits: u = q + 128 fits its byte for every int8 input, so the word is the four bytes with their sign bits flipped —
+        // the same 16 bytes in, 16 bytes out shape as unpack_flat_kernel<8> (26.3 us for the lane-per-group form at 8192^2)
+        constexpr int U = 2;
+        const int64_t items = rows * cols / 16;
+        const int64_t g = cdiv64(items, (int64_t)kBlock * U);
+        CT_REQUIRE(g < ((int64_t)1 << 31), "tensor too large for one launch");
+        hipLaunchKernelGGL((unpack_flat_kernel<8, U>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(q), items,
+                           reinterpret_cast<u32x4*>(out));
+        CT_LAUNCH_CHECK("ct_pack_int32[flat8]");
+    }
     const int vec = (cols % 16 == 0) && aligned16(q);
     dim3 grid = grid_rows(rows, cdiv64(cols, 32));
     CT_BITS_SWITCH(bits, hipLaunchKernelGGL((pack_rows_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), q, rows, cols, out,
@@ -184,6 +241,17 @@ int ct_unpack_int32(const int32_t* p, int64_t rows, int64_t words, int64_t p_row
     CT_REQUIRE(rows >= 0 && cols >= 0 && words >= 0, "negative shape");
     CT_REQUIRE(p_row_stride >= words, "packed row stride smaller than the row");
     if (rows == 0 || cols == 0) return CT_OK;
+    if ((bits == 4 || bits == 8) && cols % 32 == 0 && p_row_stride == words && words == cols * bits / 32 && aligned16(out) && aligned16(p)) {
+        constexpr int U = 2;
+        const int64_t items = rows * cols / 16;  // 16 codes -> one 16-byte store
+        const int64_t g = cdiv64(items, (int64_t)kBlock * U);
+        CT_REQUIRE(g < ((int64_t)1 << 31), "tensor too large for one launch");
+        if (bits == 4) hipLaunchKernelGGL((unpack_flat_kernel<4, U>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(p), items,
+                                          reinterpret_cast<u32x4*>(out));
+        else hipLaunchKernelGGL((unpack_flat_kernel<8, U>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(p), items,
+                                reinterpret_cast<u32x4*>(out));
+        CT_LAUNCH_CHECK("ct_unpack_int32[flat]");
+    }
     const int vec = (cols % 16 == 0) && aligned16(out);
     dim3 grid = grid_rows(rows, cdiv64(cols, 32));
     CT_BITS_SWITCH(bits, hipLaunchKernelGGL((unpack_rows_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), p, rows, words,
