@@ -1,0 +1,137 @@
+"""Randomised differential test of the HIP path against the CPU oracle (developer tool; the fixed cases live in tests/).
+    python tools/fuzz_parity.py [seconds] [seed]
+Random shapes / dtypes / strategies / special values through the public codec entry points; stops at the first mismatch."""
+import os, sys, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import oracle as O
+from compressed_tensors_amd import codec
+from test_oracle_golden import eq, eq_f8
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = random.Random(seed)
+dev = torch.device("cuda:0")
+BF16, F16, F32, F8 = torch.bfloat16, torch.float16, torch.float32, torch.float8_e4m3fn
+SPECIAL = [0.0, -0.0, 0.5, 1.5, 2.5, -0.5, -2.5, 7.5, -8.5, 127.5, -128.5, 448.0, 464.0, 6.0, 1e-8, -1e-8, 3e4, float("inf"), -float("inf"), float("nan")]
+
+
+def rand_x(shape, dt, g, allow_nonfinite=True):
+    x = (torch.randn(shape, generator=g) * 10 ** rng.uniform(-3, 2)).to(dt)
+    n = rng.randint(0, min(x.numel(), len(SPECIAL)))
+    if n:
+        vals = [v for v in SPECIAL if allow_nonfinite or v == v and abs(v) != float("inf")]
+        idx = torch.randint(0, x.numel(), (n,), generator=g)
+        x.view(-1)[idx] = torch.tensor([rng.choice(vals) for _ in range(n)], dtype=torch.float32).to(dt)
+    return x
+
+
+def case_quant(g):
+    dt = rng.choice([BF16, F16, F32])
+    sdt = rng.choice([dt, F32])
+    strategy = rng.choice(["tensor", "channel", "group", "group", "block"])
+    bits = rng.choice([2, 3, 4, 4, 4, 5, 8, 8])
+    qtype = rng.choice(["int", "int", "float"])
+    if qtype == "float":
+        bits = 8
+    rows = rng.choice([1, 3, 8, 33, 64, 200])
+    gs = rng.choice([16, 32, 64, 128]) if strategy == "group" else None
+    cols = (rng.choice([1, 2, 3, 5, 8, 17]) * (gs or 8)) if strategy == "group" else rng.choice([8, 24, 40, 96, 200, 256, 1000, 1024])
+    block = None
+    if strategy == "block":
+        bh, bw = rng.choice([(4, 32), (8, 16), (16, 64)])
+        rows, cols = bh * rng.randint(1, 5), bw * rng.randint(1, 6)
+        block = [bh, bw]
+    x = rand_x((rows, cols), dt, g)
+    sshape = {"tensor": (1,), "channel": (rows, 1), "group": (rows, cols // (gs or 1)) if gs else None, "block": (rows // block[0], cols // block[1]) if block else None}[strategy]
+    s = (torch.rand(sshape, generator=g) * 10 ** rng.uniform(-3, 1) + 1e-4).to(sdt)
+    sym = rng.random() < 0.5
+    if qtype == "float":
+        z = rng.choice([None, torch.zeros(sshape, dtype=F8)])
+    else:
+        z = torch.zeros(sshape, dtype=torch.int8) if sym else torch.randint(-2 ** (bits - 1), 2 ** (bits - 1), sshape, generator=g, dtype=torch.int8)
+    kw = dict(num_bits=bits, strategy=strategy, group_size=gs, block_structure=block, qtype=qtype)
+    d = lambda t: None if t is None else t.to(dev)
+    odt = F8 if qtype == "float" else torch.int8
+    q = codec.quantize_tensor(d(x), d(s), d(z), dtype=odt, **kw)
+    qr = O.quantize(x, s, z, dtype=odt, **kw)
+    assert (eq_f8(q.cpu(), qr) if qtype == "float" else torch.equal(q.cpu(), qr)), ("quantize", kw, dt, sdt, x.shape)
+    fq = codec.fake_quantize_tensor(d(x), d(s), d(z), **kw)
+    assert eq(fq.cpu(), O.fake_quantize(x, s, z, **kw)), ("fake_quantize", kw, dt, sdt, x.shape)
+    dkw = {k: v for k, v in kw.items() if k not in ("num_bits", "qtype")}
+    dq = codec.dequantize_tensor(d(qr), d(s), d(z), **dkw)
+    assert eq(dq.cpu(), O.dequantize(qr, s, z, **dkw)), ("dequantize", kw, dt, sdt, x.shape)
+    if qtype == "int" and strategy != "block":
+        packed = codec.quantize_and_pack(d(x), d(s), d(z), **{k: v for k, v in kw.items() if k != "qtype"})
+        assert torch.equal(packed.cpu(), O.pack_to_int32(O.quantize(x, s, z, dtype=torch.int8, **kw), bits).contiguous()), ("quant_pack", kw, dt, sdt, x.shape)
+        back = codec.unpack_and_dequantize(packed, x.shape, d(s), d(z), num_bits=bits, strategy=strategy, group_size=gs)
+        assert eq(back.cpu(), O.dequantize(O.quantize(x, s, z, dtype=torch.int8, **kw), s, z, **dkw)), ("unpack_dequant", kw, dt, sdt, x.shape)
+
+
+def case_pack(g):
+    bits = rng.randint(1, 8)
+    rows, cols = rng.choice([1, 5, 32, 77]), rng.choice([1, 7, 32, 33, 64, 100, 256, 1024])
+    v = torch.randint(-2 ** (bits - 1), 2 ** (bits - 1), (rows, cols), generator=g, dtype=torch.int8)
+    p = codec.pack_to_int32(v.to(dev), bits)
+    assert torch.equal(p.cpu(), O.pack_to_int32(v, bits).contiguous()), ("pack", bits, rows, cols)
+    assert torch.equal(codec.unpack_from_int32(p, bits, v.shape).cpu(), v), ("unpack", bits, rows, cols)
+
+
+def case_bitmask(g):
+    dt = rng.choice([BF16, F16, F32, torch.int8])
+    rows, cols = rng.choice([1, 3, 17, 64, 300]), rng.choice([1, 8, 24, 40, 64, 1000, 4096, 8192, 8200, 16384 + 32])
+    x = torch.randn((rows, cols), generator=g)
+    x = x.masked_fill(torch.rand((rows, cols), generator=g) < rng.choice([0.0, 0.1, 0.5, 0.9, 1.0]), 0)
+    x = (x * 50).to(dt) if dt == torch.int8 else x.to(dt)
+    values, bitmask, ro = codec.bitmask_compress(x.to(dev), two_pass=rng.random() < 0.3)
+    rv, rb, rro = O.bitmask_compress(x)
+    n = rv.numel()
+    assert torch.equal(values.cpu()[:n].view(torch.uint8), rv.view(torch.uint8)) and torch.equal(bitmask.cpu(), rb) and torch.equal(ro.cpu(), rro), ("bitmask_compress", dt, rows, cols)
+    back = codec.bitmask_decompress(values, bitmask, x.shape, ro)
+    assert torch.equal(back.cpu().view(torch.uint8), x.view(torch.uint8).reshape(back.cpu().view(torch.uint8).shape)) or torch.equal(back.cpu(), x), ("bitmask_decompress", dt, rows, cols)
+
+
+def case_fp4(g):
+    dt = rng.choice([BF16, F16])
+    fmt, group = rng.choice([("nvfp4-pack-quantized", 16), ("mxfp4-pack-quantized", 32)])
+    rows, cols = rng.choice([1, 3, 16, 65]), group * rng.choice([1, 2, 3, 5, 8, 64])
+    x = rand_x((rows, cols), dt, g, allow_nonfinite=False)
+    if fmt.startswith("nvfp4"):
+        gs = O.generate_gparam(x)
+        s = O.calculate_qparams_float(x, kind="nvfp4", group_size=16, global_scale=gs)
+        p, s8, gsd, sd = codec.rtn_nvfp4_quantize_and_pack(x.to(dev), return_scale=True) if cols % 32 == 0 else (None, None, None, None)
+    else:
+        gs = None
+        s = O.calculate_qparams_float(x, kind="mxfp4", group_size=32)
+        p, code, sd = codec.rtn_mxfp4_quantize_and_pack(x.to(dev), return_scale=True)
+    ref = O.fp4_compress(x, s, gs, fmt=fmt)
+    got = codec.fp4_quantize_and_pack(x.to(dev), s.to(dev), None if gs is None else gs.to(dev), group_size=group)
+    assert torch.equal(got.cpu(), ref["weight_packed"]), ("fp4 compress", fmt, dt, rows, cols)
+    if p is not None:
+        assert torch.equal(p.cpu(), ref["weight_packed"]) and eq(sd.cpu(), s), ("fp4 rtn", fmt, dt, rows, cols)
+    kind = "f8e4m3" if gs is not None else "e8m0"
+    dec = codec.fp4_unpack_and_dequantize(got, ref["weight_scale"].to(dev), None if gs is None else gs.to(dev), group_size=group, scale_kind=kind)
+    assert eq(dec.cpu(), O.fp4_decompress(ref, fmt=fmt)["weight"]), ("fp4 decompress", fmt, dt, rows, cols)
+
+
+def case_rtn(g):
+    dt = rng.choice([BF16, F16])
+    sym = rng.random() < 0.5
+    gs = rng.choice([32, 64, 128, 256, None])
+    rows, cols = rng.choice([1, 4, 37]), (gs or 32) * rng.choice([1, 2, 8]) if gs else rng.choice([32, 512, 2048])
+    x = rand_x((rows, cols), dt, g, allow_nonfinite=False)
+    packed, scale, zp = codec.rtn_quantize_and_pack(x.to(dev), group_size=gs, symmetric=sym)
+    s, z = O.calculate_qparams_minmax(x, num_bits=4, group_size=gs, symmetric=sym)
+    assert eq(scale.cpu(), s) and torch.equal(zp.cpu(), z), ("rtn qparams", dt, sym, gs, rows, cols)
+    q = O.quantize(x, s, z, num_bits=4, strategy="group" if gs else "channel", group_size=gs, dtype=torch.int8)
+    assert torch.equal(packed.cpu(), O.pack_to_int32(q, 4).contiguous()), ("rtn pack", dt, sym, gs, rows, cols)
+
+
+CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn]
+t0, n = time.time(), 0
+while time.time() - t0 < budget:
+    g = torch.Generator().manual_seed(rng.randint(0, 2 ** 31))
+    rng.choice(CASES)(g)
+    n += 1
+print(f"fuzz: {n} random cases, no mismatch (seed {seed}, {budget:.0f} s)")
