@@ -303,6 +303,30 @@ def qparams_leg(dev):
                                     "GBps": round(alg_f / us_f / 1e3, 1), "frac_hbm": round(alg_f / us_f / 1e3 / HBM_PEAK_GBPS, 4)}}
 
 
+def pack_unpack_leg(dev):
+    """R1 / R2 unfused: pack_to_int32 / unpack_from_int32 (4 bits) on 8192x8192 int8 codes through the C ABI:
+    N^2 + N^2 / 2 bytes per direction"""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    K = 16  # the smallest stream (the packed words, 33.5 MB each) must exceed 2 x the 256 MiB Infinity Cache: HBM-cold
+    g = torch.Generator(device=dev).manual_seed(19)
+    q = [torch.randint(-8, 8, (N, N), dtype=torch.int8, device=dev, generator=g) for _ in range(K)]
+    pk = [torch.empty(N, N // 8, dtype=torch.int32, device=dev) for _ in range(K)]
+    back = [torch.empty(N, N, dtype=torch.int8, device=dev) for _ in range(K)]
+    pack = lambda i: lib.ct_pack_int32(q[i % K].data_ptr(), N, N, BITS, pk[i % K].data_ptr(), N // 8, stream)
+    unpack = lambda i: lib.ct_unpack_int32(pk[i % K].data_ptr(), N, N // 8, N // 8, N, BITS, back[i % K].data_ptr(), stream)
+    for i in range(K):
+        pack(i)
+    alg = N * N + N * N // 2
+    us_p, us_u = time_kernel(pack, 36), time_kernel(unpack, 36, offset=3)
+    ok = all(torch.equal(a, b) for a, b in zip(q, back))
+    return {"workload": f"pack_to_int32 / unpack_from_int32, int4, {N}x{N} int8 codes", "alg_bytes_per_direction": alg,
+            "pack_us": round(us_p, 2), "pack_frac_hbm": round(alg / us_p / 1e3 / HBM_PEAK_GBPS, 4),
+            "unpack_us": round(us_u, 2), "unpack_frac_hbm": round(alg / us_u / 1e3 / HBM_PEAK_GBPS, 4), "round_trip_bit_exact": bool(ok)}
+
+
 def float_formats_leg(dev):
     """the float formats at 8192x8192 bf16 through the C ABI, HBM-cold rotation.
     float-quantized (float8_e4m3fn, channel scales): 2 + 1 B/element; nvfp4 (group 16, float32 scales in, fp8 scales
@@ -593,7 +617,7 @@ def main():
             del sets
             torch.cuda.empty_cache()
             for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
-                             ("float_formats", float_formats_leg)):
+                             ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down
