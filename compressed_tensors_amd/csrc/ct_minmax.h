@@ -86,6 +86,45 @@ __device__ __forceinline__ MinMax group_reduce(MinMax m, int lpg) {
     return m;
 }
 
+// ---- symmetric schemes on 16-bit weights: the observer only needs max |x| --------------------------------------
+// For a symmetric scheme amax = max(|min(mn, 0)|, |max(mx, 0)|) = max |x|, and for non-negative floats the integer order
+// of the bit patterns IS the float order, with every NaN above inf.  So the reduction runs on the raw 16-bit PAIRS:
+// one v_and_b32 (drop the sign bits) and one v_pk_max_u16 per two elements — 1 VALU per element instead of 5
+// (unpack, NaN test, min, max) — and one packed max per DPP step instead of three.  The result converts back exactly.
+typedef uint16_t u16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t absmax_acc(uint32_t acc, uint32_t pair_bits) {
+    const u16x2_t a = __builtin_bit_cast(u16x2_t, acc), b = __builtin_bit_cast(u16x2_t, pair_bits & 0x7fff7fffu);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(a, b));
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t absmax_dpp(uint32_t acc) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, CTRL, 0xf, 0xf, false);
+    return absmax_acc(acc, o);
+}
+
+__device__ __forceinline__ uint32_t absmax_group_reduce(uint32_t acc, int lpg) {
+    if (lpg >= 2) acc = absmax_dpp<0xB1>(acc);
+    if (lpg >= 4) acc = absmax_dpp<0x4E>(acc);
+    if (lpg >= 8) acc = absmax_dpp<0x141>(acc);
+    if (lpg >= 16) acc = absmax_dpp<0x140>(acc);
+    for (int d = 16; d < lpg; d <<= 1) acc = absmax_acc(acc, (uint32_t)__shfl_xor((int)acc, d, 64));
+    return acc;
+}
+
+// the MinMax the float reduction would have produced, as far as a symmetric scheme can tell: {0, amax, nan}
+template <int XDT>
+__device__ __forceinline__ MinMax absmax_finish(uint32_t acc) {
+    static_assert(XDT == CT_BF16 || XDT == CT_F16, "16-bit weights only");
+    const uint32_t h = (acc & 0xffffu) > (acc >> 16) ? (acc & 0xffffu) : (acc >> 16);
+    MinMax m;
+    m.nan = h > (XDT == CT_BF16 ? 0x7f80u : 0x7c00u);
+    m.mn = 0.0f;
+    m.mx = XDT == CT_BF16 ? bits_f(h << 16) : f16_bits_to_f(h);
+    return m;
+}
+
 // calculate_qparams of the symmetric FLOAT schemes (helpers.py:50-137, mxfp_utils.py:37-143); see ct_hip.h for the kinds.
 // One lane per group runs this.
 enum { QP_INT = 0, QP_FP8 = 1, QP_NVFP4 = 2, QP_MXFP4 = 3, QP_MXFP8 = 4, QP_AMAX = 5 };
