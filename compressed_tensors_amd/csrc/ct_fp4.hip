@@ -205,20 +205,10 @@ __global__ __launch_bounds__(kBlock) void rtn_mxfp4_kernel(const u32x4* __restri
     u32x4 r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = in[l * 4 + i];
-    MinMax m;
-    m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+    uint32_t acc = 0;  // max |x| on the raw bit pairs (ct_minmax.h): the MX schemes are symmetric
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float a, b;
-            fp4_unpack_pair<XDT>(ws[j], a, b);
-            m.nan |= (a != a) | (b != b);
-            m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
-            m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
-        }
-    }
+    for (int i = 0; i < 4; ++i) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, r[i].x), r[i].y), r[i].z), r[i].w);
+    const MinMax m = absmax_finish<XDT>(acc);
     const float s = compute_qparams_float<XDT>(m, QP_MXFP4, 1.0f);
     // compress_mx_scale: 127 + floor(log2(s)); s is a power of two (2^-127, the only subnormal one, is code 0), or inf / NaN
     const uint32_t ef = (f_bits(s) >> 23) & 0xffu;
@@ -248,20 +238,10 @@ __global__ __launch_bounds__(kBlock) void rtn_nvfp4_kernel(const u32x4* __restri
     float s[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        MinMax m;
-        m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+        uint32_t acc = 0;
 #pragma unroll
-        for (int i = 2 * h; i < 2 * h + 2; ++i) {
-            const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a, b;
-                fp4_unpack_pair<XDT>(ws[j], a, b);
-                m.nan |= (a != a) | (b != b);
-                m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
-                m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
-            }
-        }
+        for (int i = 2 * h; i < 2 * h + 2; ++i) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, r[i].x), r[i].y), r[i].z), r[i].w);
+        const MinMax m = absmax_finish<XDT>(acc);
         s[h] = compute_qparams_float<XDT>(m, QP_NVFP4, gs);
     }
     scale_f8[l] = (uint16_t)f2_to_fp8x2(s[0], s[1]);  // scale.to(float8_e4m3fn): exact, the values are float8 already

@@ -310,9 +310,10 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_lean_kernel(const u32x4*
 // traffic for 8192^2 g128, one launch instead of two.  Results are bit-identical to ct_minmax_qparams followed by
 // ct_quant_pack by construction (same helpers), and tested against that composition.
 // ------------------------------------------------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(kBlock) void rtn_w4_kernel(const u32x4* __restrict__ in, int64_t lanes, int lpg, int symmetric, u32x4* __restrict__ out,
+template <int DT, bool SYM>
+__global__ __launch_bounds__(kBlock) void rtn_w4_kernel(const u32x4* __restrict__ in, int64_t lanes, int lpg, u32x4* __restrict__ out,
                                                         void* __restrict__ scale_out, int8_t* __restrict__ zp_out) {
+    constexpr int symmetric = SYM ? 1 : 0;
     const int64_t l = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // lanes is a multiple of lpg, kBlock too: groups never straddle blocks
     const bool live = l < lanes;
     u32x4 r[4];
@@ -321,20 +322,32 @@ __global__ __launch_bounds__(kBlock) void rtn_w4_kernel(const u32x4* __restrict_
     if (live) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) r[i] = in[l * 4 + i];
+    }
+    if constexpr (SYM) {
+        // symmetric: max |x| on the raw bit pairs (ct_minmax.h): 1 VALU per element for the observer part
+        uint32_t acc = 0;
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+            for (int i = 0; i < 4; ++i) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, r[i].x), r[i].y), r[i].z), r[i].w);
+        }
+        m = absmax_finish<DT>(absmax_group_reduce(acc, lpg));
+    } else {
+        if (live) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a, b;
-                unpack2<DT>(ws[j], a, b);
-                m.nan |= (a != a) | (b != b);
-                m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
-                m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a, b;
+                    unpack2<DT>(ws[j], a, b);
+                    m.nan |= (a != a) | (b != b);
+                    m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
+                    m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+                }
             }
         }
+        m = group_reduce(m, lpg);
     }
-    m = group_reduce(m, lpg);
     if (!live) return;
     float s, z;
     compute_qparams<DT>(m, 4, symmetric, s, z);
@@ -691,27 +704,43 @@ __global__ __launch_bounds__(kBlock) void rtn_channel8_kernel(const u32x4* __res
             const int u = i * kBlock + tid;
             if (u < upr) r[i] = rin[u];
         }
+        if (FP8 || symmetric) {  // block-uniform: max |x| on the raw bit pairs (ct_minmax.h)
+            uint32_t acc = 0;
 #pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            const int u = i * kBlock + tid;
-            if (u < upr) {
-                const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+            for (int i = 0; i < MAXU; ++i) {
+                const int u = i * kBlock + tid;
+                if (u < upr) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, r[i].x), r[i].y), r[i].z), r[i].w);
+            }
+            acc = absmax_group_reduce(acc, 64);
+            if (lane == 0) s_mn[wave] = __builtin_bit_cast(float, acc);
+            __syncthreads();
+            uint32_t all = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a, b;
-                    unpack2<DT>(ws[j], a, b);
-                    m.nan |= (a != a) | (b != b);
-                    m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
-                    m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+            for (int w = 0; w < kBlock / 64; ++w) all = absmax_acc(all, __builtin_bit_cast(uint32_t, s_mn[w]));
+            m = absmax_finish<DT>(all);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXU; ++i) {
+                const int u = i * kBlock + tid;
+                if (u < upr) {
+                    const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float a, b;
+                        unpack2<DT>(ws[j], a, b);
+                        m.nan |= (a != a) | (b != b);
+                        m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
+                        m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
+                    }
                 }
             }
+            m = group_reduce(m, 64);
+            if (lane == 0) { s_mn[wave] = m.mn; s_mx[wave] = m.mx; s_nan[wave] = m.nan; }
+            __syncthreads();
+            m.mn = __builtin_fminf(__builtin_fminf(s_mn[0], s_mn[1]), __builtin_fminf(s_mn[2], s_mn[3]));
+            m.mx = __builtin_fmaxf(__builtin_fmaxf(s_mx[0], s_mx[1]), __builtin_fmaxf(s_mx[2], s_mx[3]));
+            m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
         }
-        m = group_reduce(m, 64);
-        if (lane == 0) { s_mn[wave] = m.mn; s_mx[wave] = m.mx; s_nan[wave] = m.nan; }
-        __syncthreads();
-        m.mn = __builtin_fminf(__builtin_fminf(s_mn[0], s_mn[1]), __builtin_fminf(s_mn[2], s_mn[3]));
-        m.mx = __builtin_fmaxf(__builtin_fmaxf(s_mx[0], s_mx[1]), __builtin_fmaxf(s_mx[2], s_mx[3]));
-        m.nan = s_nan[0] | s_nan[1] | s_nan[2] | s_nan[3];
         float s, z = 0.0f;
         if constexpr (FP8) s = compute_qparams_float<DT>(m, QP_FP8, 1.0f);
         else compute_qparams<DT>(m, 8, symmetric, s, z);
@@ -1088,10 +1117,11 @@ int ct_rtn_quant_pack_w4(const void* x, int xdt, int64_t rows, int64_t cols, int
     const int lpg = (int)(group / 32);
     CT_REQUIRE(cdiv64(lanes, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
     dim3 grid((unsigned)cdiv64(lanes, kBlock));
-    if (xdt == CT_BF16) hipLaunchKernelGGL((rtn_w4_kernel<CT_BF16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes, lpg, symmetric,
-                                           reinterpret_cast<u32x4*>(packed), scale_out, zp_out);
-    else hipLaunchKernelGGL((rtn_w4_kernel<CT_F16>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes, lpg, symmetric,
-                            reinterpret_cast<u32x4*>(packed), scale_out, zp_out);
+#define CT_RTN4(DT, SY) hipLaunchKernelGGL((rtn_w4_kernel<DT, SY>), grid, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), lanes, lpg, \
+                                           reinterpret_cast<u32x4*>(packed), scale_out, zp_out)
+    if (xdt == CT_BF16) { if (symmetric) CT_RTN4(CT_BF16, true); else CT_RTN4(CT_BF16, false); }
+    else { if (symmetric) CT_RTN4(CT_F16, true); else CT_RTN4(CT_F16, false); }
+#undef CT_RTN4
     CT_LAUNCH_CHECK("ct_rtn_quant_pack_w4");
 }
 
