@@ -128,7 +128,68 @@ def case_rtn(g):
     assert torch.equal(packed.cpu(), O.pack_to_int32(q, 4).contiguous()), ("rtn pack", dt, sym, gs, rows, cols)
 
 
-CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn]
+
+def case_qparams_float(g):
+    dt = rng.choice([BF16, F16, F32])
+    kind, gs = rng.choice([("fp8", None), ("fp8", 64), ("nvfp4", 16), ("mxfp4", 32), ("mxfp8", 32)])
+    rows, cols = rng.choice([1, 5, 40]), (gs or 8) * rng.choice([1, 3, 16, 64])
+    x = rand_x((rows, cols), dt, g)
+    gsc = O.generate_gparam(torch.nan_to_num(x.float(), nan=0.0, posinf=1.0, neginf=-1.0).to(dt)) if kind == "nvfp4" else None
+    got = codec.minmax_qparams_float(x.to(dev), kind=kind, group_size=gs, global_scale=None if gsc is None else gsc.to(dev))
+    assert eq(got.cpu(), O.calculate_qparams_float(x, kind=kind, group_size=gs, global_scale=gsc)), ("qparams_float", kind, dt, rows, cols)
+    xf = rand_x((rows, cols), dt, g, allow_nonfinite=False)
+    assert eq(codec.generate_gparam(xf.to(dev)).cpu(), O.generate_gparam(xf)), ("gparam", dt, rows, cols)
+
+
+def case_channel8(g):
+    dt = rng.choice([BF16, F16])
+    qtype, sym = rng.choice([("int", True), ("int", False), ("float", True)])
+    rows, cols = rng.choice([1, 6, 50]), 8 * rng.choice([1, 5, 64, 256, 1000, 2048])
+    x = rand_x((rows, cols), dt, g, allow_nonfinite=False)
+    q, scale, zp = codec.rtn_quantize_channel8(x.to(dev), qtype=qtype, symmetric=sym)
+    if qtype == "int":
+        s, z = O.calculate_qparams_minmax(x, num_bits=8, group_size=None, symmetric=sym)
+        assert eq(scale.cpu(), s) and torch.equal(zp.cpu(), z), ("channel8 qparams", dt, sym, rows, cols)
+        assert torch.equal(q.cpu(), O.quantize(x, s, z, num_bits=8, strategy="channel", dtype=torch.int8)), ("channel8 int", dt, sym, rows, cols)
+    else:
+        s = O.calculate_qparams_float(x, kind="fp8")
+        ref = O.quantize(x, s, torch.zeros_like(s, dtype=F8), num_bits=8, strategy="channel", dtype=F8, qtype="float")
+        assert eq(scale.cpu(), s) and eq_f8(q.cpu(), ref), ("channel8 fp8", dt, rows, cols)
+
+
+def case_sparse24(g):
+    dt = rng.choice([BF16, F16, torch.int8])
+    rows, cols = rng.choice([1, 4, 33, 64]), 8 * rng.choice([1, 2, 9, 64, 512])
+    x = torch.randn((rows, cols), generator=g)
+    x = (x * 40).to(dt) if dt == torch.int8 else x.to(dt)
+    mask = codec.sparse24_mask(x.to(dev))
+    assert torch.equal(mask.cpu(), O.sparse24_mask(x)), ("sparse24 mask", dt, rows, cols)
+    v, b = codec.sparse24_bitmask_compress(x.to(dev))
+    rv, rb = O.sparse24_bitmask_compress(x)
+    assert torch.equal(v.cpu().view(torch.uint8), rv.view(torch.uint8)) and torch.equal(b.cpu(), rb), ("sparse24 compress", dt, rows, cols)
+    back = codec.sparse24_bitmask_decompress(v, b, x.shape)
+    assert torch.equal(back.cpu().view(torch.uint8), O.sparse24_bitmask_decompress(rv, rb, x.shape).view(torch.uint8)), ("sparse24 decompress", dt, rows, cols)
+
+
+def case_marlin(g):
+    import compressed_tensors_amd as cta
+    bits, strategy, gs = rng.choice([(4, "group", 128), (4, "channel", None), (8, "channel", None), (4, "group", 64)])
+    rows, cols = 64 * rng.choice([1, 2, 3]), 256 * rng.choice([1, 2, 3]) if rng.random() < 0.7 else 64 * rng.choice([1, 3, 5])
+    if gs and cols % gs:
+        return
+    dt = rng.choice([BF16, F16])
+    w = (torch.randn((rows, cols), generator=g) * 10 ** rng.uniform(-2, 1)).to(dt)
+    w = w * O.sparse24_mask(w).to(w.dtype)
+    scale, zp = O.calculate_qparams_minmax(w.to(F16), num_bits=bits, group_size=gs, symmetric=True)
+    ref = O.marlin24_compress(w, scale, zp, num_bits=bits, strategy=strategy, group_size=gs)
+    args = cta.QuantizationArgs(num_bits=bits, strategy=strategy, group_size=gs, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    got = cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+    for k in ref:
+        assert eq(got[k].cpu().contiguous(), ref[k].contiguous()), ("marlin24", k, bits, strategy, gs, dt, rows, cols)
+
+
+CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn, case_qparams_float, case_channel8, case_sparse24, case_marlin]
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     g = torch.Generator().manual_seed(rng.randint(0, 2 ** 31))
