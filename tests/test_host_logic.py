@@ -333,3 +333,41 @@ def test_world_size_2_recouple_gloo(tmp_path):
     )
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
+
+
+def test_float_scheme_format_inference_and_param_names(cta):
+    """the FLOAT formats resolve in upstream's priority order (compressors/format.py:18-27) and declare upstream's
+    parameter names (nvfp4/base.py:36-47, mxfp4/base.py:34-44, naive_quantized/base.py:27-46)"""
+    from compressed_tensors_amd.compressors import infer_module_format
+    from compressed_tensors_amd.entrypoints.convert.converters import _args_from_dict
+    from compressed_tensors_amd.quantization.utils import _float_kind
+
+    QA, QS, F = cta.QuantizationArgs, cta.QuantizationScheme, cta.CompressionFormat
+    f8 = torch.float8_e4m3fn
+    act = QA(num_bits=8, type="float", strategy="tensor")
+    nv = QA(num_bits=4, type="float", strategy="tensor_group", group_size=16, scale_dtype=f8, zp_dtype=f8)
+    mx4 = QA(num_bits=4, type="float", strategy="group", group_size=32, scale_dtype=torch.uint8, zp_dtype=torch.uint8)
+    mx8 = QA(num_bits=8, type="float", strategy="group", group_size=32, scale_dtype=torch.uint8, zp_dtype=torch.uint8)
+    fp8 = QA(num_bits=8, type="float", strategy="channel")
+    lin = torch.nn.Linear
+    assert infer_module_format(lin, QS(weights=nv)) == F.nvfp4_pack_quantized
+    assert infer_module_format(lin, QS(weights=mx4)) == F.mxfp4_pack_quantized
+    assert infer_module_format(lin, QS(weights=mx8)) == F.mxfp8_quantized
+    assert infer_module_format(lin, QS(weights=fp8, input_activations=act)) == F.float_quantized
+    assert infer_module_format(lin, QS(weights=fp8)) == F.naive_quantized  # weight-only FP8 falls to the generic codec, as upstream
+    assert infer_module_format(lin, QS(weights=QA(num_bits=8, type="float", strategy="group", group_size=32))) == F.naive_quantized  # float scales: not MX
+    assert [_float_kind(a) for a in (nv, mx4, mx8, fp8)] == ["nvfp4", "mxfp4", "mxfp8", "fp8"]
+    assert cta.NVFP4PackedCompressor.compression_param_names(QS(weights=nv)) == ("weight_packed", "weight_scale", "weight_global_scale")
+    static_in = QA(num_bits=4, type="float", strategy="tensor_group", group_size=16, dynamic=False)
+    assert cta.NVFP4PackedCompressor.compression_param_names(QS(weights=nv, input_activations=static_in))[-1] == "input_global_scale"
+    assert cta.MXFP4PackedCompressor.compression_param_names(QS(weights=mx4)) == ("weight_packed", "weight_scale")
+    assert cta.MXFP8QuantizationCompressor.compression_param_names(QS(weights=mx8)) == ("weight", "weight_scale")
+    assert not cta.MXFP8QuantizationCompressor.can_compress(lin, QS(weights=fp8)) and not cta.MXFP4PackedCompressor.can_compress(lin, QS(weights=nv))
+    # config.json round trip of the dtype fields (serialised as str(dtype), quant_args.py:209-224)
+    parsed = _args_from_dict({"num_bits": 4, "type": "float", "strategy": "group", "group_size": 32, "scale_dtype": "torch.uint8", "zp_dtype": "torch.uint8",
+                              "symmetric": True, "dynamic": False})
+    assert parsed.scale_dtype is torch.uint8 and parsed.zp_dtype is torch.uint8 and _float_kind(parsed) == "mxfp4"
+    assert cta.quantization.calculate_range(fp8) == (-448.0, 448.0) and cta.quantization.calculate_range(nv) == (-6.0, 6.0)
+    assert fp8.pytorch_dtype() is f8
+    with pytest.raises(NotImplementedError):
+        nv.pytorch_dtype()
