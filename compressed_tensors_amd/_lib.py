@@ -149,8 +149,23 @@ def check(status: int):
     raise RuntimeError(msg)
 
 
+class StreamHandle(int):
+    """a raw hipStream_t plus the index of the device it belongs to.  The handle of PyTorch's default stream is 0 — the
+    null stream — which HIP resolves against the CURRENT device, not the tensors' device: `call` switches the current
+    device for the launch when they differ (e.g. an HF `device_map` model spread over several GPUs in one process)."""
+    device_index = None
+
+
 def call(name: str, *args):
-    check(getattr(load(), name)(*args))
+    """launch one C-ABI entry; the trailing argument is the stream (`stream_of(tensor)`), whose device becomes the
+    current device for the duration of the call"""
+    fn = getattr(load(), name)
+    dev = getattr(args[-1], "device_index", None) if args else None
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            check(fn(*args))
+    else:
+        check(fn(*args))
 
 
 def ptr(t):
@@ -159,8 +174,15 @@ def ptr(t):
 
 
 def stream_of(t: torch.Tensor):
-    """the caller's current HIP stream on the tensor's device, as an integer handle"""
-    return torch.cuda.current_stream(t.device).cuda_stream
+    """the caller's current HIP stream on the tensor's device, as an integer handle that remembers its device"""
+    return stream_on(t.device)
+
+
+def stream_on(device, handle=None):
+    device = torch.device(device)
+    h = StreamHandle(torch.cuda.current_stream(device).cuda_stream if handle is None else int(handle))
+    h.device_index = device.index if device.index is not None else torch.cuda.current_device()
+    return h
 
 
 def require_device() -> torch.device:

@@ -579,13 +579,22 @@ def rtn_quantize_channel8(x: torch.Tensor, *, qtype: str = "int", symmetric: boo
     return _home(out, x), _home(scale, x), _home(zp, x)
 
 
-def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, strategy, group_size, g_idx=None) -> bool:
+def _aligned16(*tensors) -> bool:
+    return all(t is None or t.data_ptr() % 16 == 0 for t in tensors)
+
+
+def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, strategy, group_size, g_idx=None, device=None) -> bool:
     """can this tensor join a one-launch W4 batch (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`)?
-    int4, 2-D 16-bit weights and scales of the same dtype on a GPU, group or channel scales with
-    cols % 32 == 0 and group % 32 == 0, int8 (or no) zero point, no activation ordering."""
+    int4, 2-D 16-bit weights and scales of the same dtype on the same GPU (`device`: where the weight / packed words
+    live), group or channel scales with cols % 32 == 0 and group % 32 == 0, int8 (or no) zero point, 16-byte aligned
+    parameters, no activation ordering.  Anything else takes the per-module path."""
     if num_bits != 4 or g_idx is not None or len(weight_shape) != 2:
         return False
     if w_dtype not in (torch.bfloat16, torch.float16) or scale is None or scale.dtype != w_dtype or not scale.is_cuda:
+        return False
+    if device is not None and (scale.device != device or (zero_point is not None and zero_point.device != device)):
+        return False
+    if not _aligned16(scale, zero_point):
         return False
     rows, cols = int(weight_shape[0]), int(weight_shape[1])
     st = _strategy_name(strategy)
@@ -639,9 +648,10 @@ class W4Batch:
             self.table = None
 
     def launch(self, stream=None):
+        """`stream`: a raw hipStream_t of self.device (default: the caller's current stream there)"""
         if not self.n:
             return
-        s = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        s = _lib.stream_on(self.device, stream)
         name = "ct_quant_pack_batch" if self.direction == 0 else "ct_unpack_dequant_batch"
         call(name, self.table.data_ptr(), self.n, self.blocks, self.dt, s)
 

@@ -4,9 +4,18 @@ named by its scheme's format.
 
 Multi-GPU: when torch.distributed is initialised, modules are partitioned over ranks with the
 reference's own rule (largest first onto the lightest bin, distributed/assign.py:12-42) and each
-rank compresses its bin on its own MI355X.  By default no collective is issued (BASELINE north_star);
-`recouple=True` adds the reference's replication step (distributed/module_parallel.py:74-90) as one
-flat-buffer RCCL broadcast per owner rank (distributed/module_parallel.py here).
+rank compresses its bin on its own MI355X.  Two modes:
+
+* `recouple=True` (default, the reference's semantics): afterwards every rank holds the full compressed model
+  (distributed/module_parallel.py:74-90), here as one flat-buffer RCCL broadcast per owner rank.
+* `recouple=False` (BASELINE north_star: one weight shard per rank, no collective): every rank keeps ONLY its own
+  share compressed — the mode for writing one checkpoint shard per rank.  The result is partial by design, so under
+  torch.distributed with more than one rank the model-wide status is left alone and no decompress hook is attached;
+  the owned modules are returned.
+
+`decompress_model` decompresses every locally compressed module on every rank (as the reference, which has no
+distributed decompression: model_compressor.py:196); `recouple=True` is the opt-in distributed form (each rank
+decompresses its share, then the results are replicated) and requires the compressed model to be replicated.
 """
 import json
 import os
@@ -15,7 +24,7 @@ from typing import Optional
 import torch
 
 from ...config import CompressionFormat
-from ...distributed import is_distributed, module_size, replace_module_parallel, shard_modules
+from ...distributed import is_distributed, module_size, rank_and_world, replace_module_parallel
 from ...quantization.quant_args import QuantizationStatus
 from ...quantization.utils import is_module_quantized
 from ..base import compress_modules, decompress_modules
@@ -71,19 +80,26 @@ class ModelCompressor:
             and (not skip_compressed or getattr(m, "quantization_status", None) != QuantizationStatus.COMPRESSED)
         ]
 
-    def compress_model(self, model: torch.nn.Module, skip_compressed: bool = False, recouple: bool = False) -> None:
-        """model_compressor.py:138-181.  Under torch.distributed every rank compresses its own LPT share; with
-        `recouple=True` the results are then replicated on every rank (what upstream's replace_module_parallel
-        does by default, at the price of one RCCL broadcast per owner rank)."""
-        modules = self._quantized_modules(model, skip_compressed)
-        fmt = self.force_compression_format
-        # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
-        replace_module_parallel(modules, lambda ms: compress_modules(ms, fmt), module_size, recouple=recouple)
+    def _finish_compress(self, model, recouple: bool) -> None:
+        if not recouple and is_distributed() and rank_and_world()[1] > 1:
+            return  # shard-per-rank mode: this rank holds a partial result, the model as a whole is not "compressed"
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
         self.add_decompress_hook(model)
 
-    def compress_model_rtn(self, model: torch.nn.Module, recouple: bool = False) -> None:
+    def compress_model(self, model: torch.nn.Module, skip_compressed: bool = False, recouple: bool = True):
+        """model_compressor.py:138-181.  Under torch.distributed every rank compresses its own LPT share; with
+        `recouple=True` (default, as upstream's replace_module_parallel) the results are then replicated on every
+        rank at the price of one RCCL broadcast per owner rank; `recouple=False` is the collective-free
+        shard-per-rank mode (see the module docstring).  Returns the modules this rank compressed."""
+        modules = self._quantized_modules(model, skip_compressed)
+        fmt = self.force_compression_format
+        # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
+        mine = replace_module_parallel(modules, lambda ms: compress_modules(ms, fmt), module_size, recouple=recouple)
+        self._finish_compress(model, recouple)
+        return mine
+
+    def compress_model_rtn(self, model: torch.nn.Module, recouple: bool = True):
         """Data-free (round-to-nearest) compression of a model whose modules carry a `quantization_scheme` but no scales yet:
         for every quantized module the min-max observer, calculate_qparams and the codec run fused — one pass over each
         weight where the scheme allows it (int4 group / channel, MXFP4, NVFP4, channel-wise int8 / float8; see the codecs'
@@ -112,22 +128,26 @@ class ModelCompressor:
                     scheme.format = fmt.value
                 module.quantization_status = QuantizationStatus.COMPRESSED
 
-        replace_module_parallel(self._quantized_modules(model, skip_compressed=True), apply, module_size, recouple=recouple)
-        if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
-            self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
-        self.add_decompress_hook(model)
+        mine = replace_module_parallel(self._quantized_modules(model, skip_compressed=True), apply, module_size, recouple=recouple)
+        self._finish_compress(model, recouple)
+        return mine
 
     def decompress_model(self, model: torch.nn.Module, recouple: bool = False) -> None:
-        """model_compressor.py:183-207.  Under torch.distributed each rank decompresses the modules of its own
-        share (upstream has no distributed decompression at all, :196); `recouple=True` replicates the
-        decompressed weights on every rank."""
+        """model_compressor.py:183-207.  Every rank decompresses every module it holds compressed (upstream has no
+        distributed decompression, :196) — also the right thing after a shard-per-rank compress, where each rank
+        holds a different subset.  `recouple=True` (opt-in, needs a replicated compressed model): each rank
+        decompresses its LPT share only and the dense weights are then replicated by one broadcast per owner."""
         modules = self._quantized_modules(model)
         fmt = self.force_compression_format
+        if recouple and is_distributed():
+            def apply(ms):
+                decompress_modules([m for m in ms if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
 
-        def apply(ms):
-            decompress_modules([m for m in ms if not is_distributed() or getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
-
-        replace_module_parallel(modules, apply, module_size, recouple=recouple)
+            replace_module_parallel(modules, apply, module_size, recouple=True)
+        elif is_distributed():
+            decompress_modules([m for m in modules if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
+        else:
+            decompress_modules(modules, fmt)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.DECOMPRESSED
         self.remove_decompression_hook(model)

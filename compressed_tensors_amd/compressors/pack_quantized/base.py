@@ -138,26 +138,26 @@ class PackedQuantizationCompressor(BaseCompressor):
         from ...quantization.quant_args import QuantizationStatus
         from ...utils.module import get_direct_state_dict, replace_direct_state_dict
 
-        jobs, entries, dtype = [], [], None
+        batches = {}  # (device, dtype) -> (entries, jobs): one table and one launch per GPU and weight dtype
         for m in modules:
             scheme = m.quantization_scheme
             sd = get_direct_state_dict(m)
             w, scale, zp = sd.get("weight"), sd.get("weight_scale"), sd.get("weight_zero_point")
             wa = scheme.weights
-            ok = (w is not None and w.is_cuda and w.is_contiguous() and enum_value(getattr(wa, "type", "int")) == "int"
-                  and (dtype is None or w.dtype == dtype)
+            ok = (w is not None and w.is_cuda and w.is_contiguous() and w.data_ptr() % 16 == 0
+                  and enum_value(getattr(wa, "type", "int")) == "int"
                   and codec.w4_batch_eligible(w.shape, w.dtype, scale, zp, num_bits=int(wa.num_bits), strategy=wa.strategy,
-                                              group_size=getattr(wa, "group_size", None), g_idx=sd.get("weight_g_idx")))
+                                              group_size=getattr(wa, "group_size", None), g_idx=sd.get("weight_g_idx"), device=w.device))
             if not ok:
                 cls.compress_module(m)
                 continue
-            dtype = w.dtype
             rows, cols = w.shape
             group = cols if enum_value(wa.strategy) == "channel" else int(wa.group_size)
             packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=w.device)
+            entries, jobs = batches.setdefault((w.device, w.dtype), ([], []))
             entries.append((w, scale, zp, packed, rows, cols, group))
             jobs.append((m, sd, scheme, packed))
-        if jobs:
+        for (_, dtype), (entries, jobs) in batches.items():
             codec.W4Batch(entries, "compress", dtype).launch()
             for m, sd, scheme, packed in jobs:
                 replace_direct_state_dict(m, cls.compress(sd, scheme, _prepacked=packed))
@@ -166,12 +166,15 @@ class PackedQuantizationCompressor(BaseCompressor):
     @classmethod
     def _batch_decompress(cls, state_dicts, schemes):
         """weights of every eligible state dict from ONE launch (None for the others)"""
-        outs, entries, slots, dtype = [None] * len(state_dicts), [], [], None
+        outs, batches = [None] * len(state_dicts), {}
         for i, (sd, scheme) in enumerate(zip(state_dicts, schemes)):
             packed, scale, shape_t = sd.get("weight_packed"), sd.get("weight_scale"), sd.get("weight_shape")
             wa = scheme.weights
+            # anything unusual (a wrongly typed weight_packed, which must raise as upstream; a zero point kept next to a
+            # symmetric scheme, which the per-module path applies; misaligned views) goes through `decompress`
             ok = (packed is not None and scale is not None and shape_t is not None and packed.is_cuda and packed.is_contiguous()
-                  and wa.symmetric and sd.get("weight_g_idx") is None)
+                  and packed.dtype == torch.int32 and packed.data_ptr() % 16 == 0
+                  and wa.symmetric and sd.get("weight_zero_point") is None and sd.get("weight_g_idx") is None)
             if not ok:
                 continue
             shape = tuple(int(v) for v in shape_t.tolist())
@@ -179,15 +182,15 @@ class PackedQuantizationCompressor(BaseCompressor):
                 continue
             # decompress infers the strategy from the scale shape (forward.py:99-130): (R, 1) channel, (R, G) group
             strategy, group = ("channel", shape[-1]) if scale.shape[-1] == 1 else ("group", shape[-1] // scale.shape[-1])
-            if not ((dtype is None or scale.dtype == dtype) and tuple(packed.shape) == (shape[0], shape[1] // 8)
+            if not (tuple(packed.shape) == (shape[0], shape[1] // 8)
                     and codec.w4_batch_eligible(shape, scale.dtype, scale, None, num_bits=int(wa.num_bits), strategy=strategy,
-                                                group_size=group)):
+                                                group_size=group, device=packed.device)):
                 continue
-            dtype = scale.dtype
             out = torch.empty(shape, dtype=scale.dtype, device=packed.device)
+            entries, slots = batches.setdefault((packed.device, scale.dtype), ([], []))
             entries.append((packed, scale, None, out, shape[0], shape[1], group))
             slots.append((i, out))
-        if entries:
+        for (_, dtype), (entries, slots) in batches.items():
             codec.W4Batch(entries, "decompress", dtype).launch()
             for i, out in slots:
                 outs[i] = out

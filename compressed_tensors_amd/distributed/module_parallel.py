@@ -104,6 +104,13 @@ def replace_module_parallel(modules: List[torch.nn.Module], apply_many_fn: Calla
         return modules
     rank, world = rank_and_world()
     order = list(modules)
+    if recouple and world > 1:
+        # ownership must be identical on every rank even if the replicas have drifted apart (e.g. after a
+        # shard-per-rank compress the byte sizes differ per rank): rank 0's sizes decide.  A few hundred ints.
+        box = [[int(weight_fn(m)) for m in order]]
+        dist.broadcast_object_list(box, src=0)
+        size_of = dict(zip(order, box[0]))
+        weight_fn = size_of.__getitem__
     _, bins, owner = greedy_bin_packing(order, world, weight_fn)
     mine = bins[rank]
     apply_many_fn(mine)

@@ -16,6 +16,10 @@ import types
 
 REFERENCE_SRC = "/root/reference/src"
 
+# set at import time, before anything can import the reference: never drop __pycache__ into the read-only tree
+sys.dont_write_bytecode = True
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
 
 def available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_SRC, "compressed_tensors"))

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+sys.dont_write_bytecode = True  # some tests import the read-only reference tree
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__))):
     if p not in sys.path:

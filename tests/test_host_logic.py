@@ -335,6 +335,102 @@ def test_world_size_2_recouple_gloo(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
 
 
+_MODEL_DIST_SCRIPT = r"""
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+import compressed_tensors_amd as cta
+from compressed_tensors_amd.distributed import init_dist, rank_and_world
+from compressed_tensors_amd.quantization.quant_args import QuantizationStatus as St
+from compressed_tensors_amd.compressors.model_compressors import model_compressor as mc
+from compressed_tensors_amd.utils.module import get_direct_state_dict, replace_direct_state_dict
+init_dist()
+rank, world = rank_and_world()
+
+# stand-ins for the codec (no GPU on this host): the state-dict transformation a codec performs
+def fake_compress(ms, fmt=None):
+    for m in ms:
+        sd = get_direct_state_dict(m)
+        w = sd.pop("weight")
+        sd["weight_packed"] = w * 4   # exact
+        sd["weight_shape"] = torch.tensor(w.shape)
+        replace_direct_state_dict(m, sd)
+        m.quantization_status = St.COMPRESSED
+
+def fake_decompress(ms, fmt=None):
+    for m in ms:
+        sd = get_direct_state_dict(m)   # KeyError on a module that is not compressed, like the real codecs
+        w = sd.pop("weight_packed") / 4
+        sd.pop("weight_shape")
+        sd["weight"] = w
+        replace_direct_state_dict(m, sd)
+        m.quantization_status = St.DECOMPRESSED
+
+mc.compress_modules, mc.decompress_modules = fake_compress, fake_decompress
+
+def model():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(16 * (i + 1), 8, bias=False) for i in range(6)])
+    for m in net:
+        m.quantization_scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, group_size=8))
+    return net
+
+cfg = types.SimpleNamespace(quantization_status=St.FROZEN)
+comp = cta.ModelCompressor(quantization_config=cfg)
+
+# 1. default compress = the reference's semantics: every rank ends with the whole model compressed
+net = model(); ref = [m.weight.data.clone() for m in net]
+mine = comp.compress_model(net)
+assert 0 < len(mine) < 6
+assert all(hasattr(m, "weight_packed") and not hasattr(m, "weight") and m.quantization_status == St.COMPRESSED for m in net)
+assert cfg.quantization_status == St.COMPRESSED and hasattr(net, "ct_decompress_hook")
+# 2. default decompress: every rank restores every module locally (this is what the forward pre-hook calls)
+comp.decompress_model(net)
+assert all(torch.equal(m.weight.data, w) for m, w in zip(net, ref)) and not hasattr(net, "ct_decompress_hook")
+assert cfg.quantization_status == St.DECOMPRESSED
+
+# 3. shard-per-rank mode: a partial result, so no model-wide status and no hook; decompress still restores a full model
+cfg.quantization_status = St.FROZEN
+net = model()
+mine = comp.compress_model(net, recouple=False)
+assert sum(hasattr(m, "weight_packed") for m in net) == len(mine) and 0 < len(mine) < 6
+assert cfg.quantization_status == St.FROZEN and not hasattr(net, "ct_decompress_hook")
+flags = torch.tensor([int(hasattr(m, "weight_packed")) for m in net]); dist.all_reduce(flags)
+assert flags.tolist() == [1] * 6   # the shards partition the model
+comp.decompress_model(net)
+assert all(torch.equal(m.weight.data, w) for m, w in zip(net, ref))
+
+# 4. distributed decompression (opt-in): each rank decompresses its share, one broadcast per owner replicates it
+net = model(); comp.compress_model(net)
+comp.decompress_model(net, recouple=True)
+assert all(torch.equal(m.weight.data, w) and m.quantization_status == St.DECOMPRESSED for m, w in zip(net, ref))
+# ... and ownership is agreed even when the replicas' byte sizes have drifted apart
+net = model(); comp.compress_model(net, recouple=False); comp.compress_model(net, skip_compressed=True)
+assert all(hasattr(m, "weight_packed") for m in net)
+dist.barrier()
+open(os.path.join(os.environ["CT_TEST_OUT"], f"rank{{rank}}.ok"), "w").write("ok")
+"""
+
+
+def test_world_size_2_model_compressor_semantics_gloo(tmp_path):
+    """compress_model replicates by default (reference model_compressor.py:167-172 -> replace_module_parallel), decompress_model
+    decompresses everything on every rank (:196), the collective-free shard mode leaves the model-wide status alone"""
+    import socket
+
+    script = tmp_path / "model_dist_check.py"
+    script.write_text(_MODEL_DIST_SCRIPT.format(root=ROOT))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", CT_TEST_OUT=str(tmp_path))
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script)],
+        capture_output=True, text=True, env=env, timeout=240,
+    )
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
+
+
 def test_float_scheme_format_inference_and_param_names(cta):
     """the FLOAT formats resolve in upstream's priority order (compressors/format.py:18-27) and declare upstream's
     parameter names (nvfp4/base.py:36-47, mxfp4/base.py:34-44, naive_quantized/base.py:27-46)"""

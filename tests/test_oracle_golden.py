@@ -393,3 +393,80 @@ def test_qparams_float_golden(golden, case):
     assert not bool(t["zp"].view(torch.uint8).any())  # symmetric: all-zero zero points of the scheme's zp_dtype
     if "gs" in t:
         assert eq(O.generate_gparam(t["x"]), t["gs"])
+
+
+# ----------------------------------------------------------------------------- torch-eager restatement (the CPU baseline of bench.py)
+@pytest.mark.parametrize("case", cases("pack"), ids=lambda c: c["key"])
+def test_eager_ref_pack_unpack_golden(golden, case):
+    """oracle/eager_ref.py (the reference's op sequence, timed as bench.py's cpu_baseline) against the reference-generated goldens"""
+    import eager_ref as E
+
+    t = golden.case("pack", case["key"])
+    bits, pd = case["bits"], case["packed_dim"]
+    assert eq(E.pack_to_int32(t["value"], bits, packed_dim=pd).contiguous(), t["packed"])
+    if not case.get("oob"):
+        assert eq(E.unpack_from_int32(t["packed"], bits, torch.Size(case["shape"]), packed_dim=pd).contiguous(), t["value"])
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32])
+@pytest.mark.parametrize("bits,strategy,gs,sym", [(4, "group", 128, True), (4, "group", 32, False), (4, "channel", None, True),
+                                                  (8, "tensor", None, True), (8, "channel", None, False), (3, "group", 64, False)])
+def test_eager_ref_matches_the_oracle(dtype, bits, strategy, gs, sym):
+    import eager_ref as E
+
+    g = torch.Generator().manual_seed(bits * 7 + (gs or 0))
+    w = torch.randn(96, 256, generator=g).to(dtype)
+    w[0, :8] = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e-8, -1e-8, 3.0]).to(dtype)
+    finite = torch.nan_to_num(w, nan=0.0, posinf=4.0, neginf=-4.0)  # the observer never sees non-finite values
+    scale, zp = O.calculate_qparams_minmax(finite.reshape(1, -1) if strategy == "tensor" else finite, num_bits=bits,
+                                           group_size=gs, symmetric=sym)
+    if strategy == "tensor":
+        scale, zp = scale.reshape(1), zp.reshape(1)
+    q_e = E.quantize(w, scale, zp, num_bits=bits, strategy=strategy, group_size=gs)
+    q_o = O.quantize(w, scale, zp, num_bits=bits, strategy=strategy, group_size=gs, dtype=torch.int8)
+    assert eq(q_e, q_o)
+    assert eq(E.dequantize(q_e, scale, zp), O.dequantize(q_o, scale, zp))
+    sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+    if strategy != "tensor":
+        c_e = E.pack_quantized_compress(sd, num_bits=bits, strategy=strategy, group_size=gs, symmetric=sym)
+        c_o = O.pack_quantized_compress(sd, num_bits=bits, strategy=strategy, group_size=gs, symmetric=sym)
+        assert sorted(c_e) == sorted(c_o)
+        assert all(eq(c_e[k].contiguous(), c_o[k].contiguous()) for k in c_o)
+        d_e = E.pack_quantized_decompress(c_e, num_bits=bits, strategy=strategy, symmetric=sym)
+        d_o = O.pack_quantized_decompress(c_o, num_bits=bits, strategy=strategy, symmetric=sym)
+        assert eq(d_e["weight"], d_o["weight"])
+
+
+def test_eager_ref_matches_the_reference_itself():
+    """where the reference is importable (the build container): same state dicts from PackedQuantizationCompressor / IntQuantizationCompressor"""
+    import ref_import
+
+    if not ref_import.available():
+        pytest.skip("upstream reference sources not present on this machine")
+    import eager_ref as E
+
+    ref_import.import_reference()
+    from compressed_tensors.compressors.naive_quantized.base import IntQuantizationCompressor as RI
+    from compressed_tensors.compressors.pack_quantized.base import PackedQuantizationCompressor as RP
+    from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme
+
+    torch.manual_seed(3)
+    w = torch.randn(128, 512, dtype=BF16)
+    for sym in (True, False):
+        scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=128, symmetric=sym)
+        sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+        sch = QuantizationScheme(targets=["Linear"], weights=QuantizationArgs(num_bits=4, group_size=128, symmetric=sym, strategy="group"))
+        rc = RP.compress(sd, sch)
+        ec = E.pack_quantized_compress(sd, num_bits=4, strategy="group", group_size=128, symmetric=sym)
+        assert sorted(rc) == sorted(ec) and all(eq(rc[k].contiguous(), ec[k].contiguous()) for k in rc)
+        rd = RP.decompress(rc, sch)
+        ed = E.pack_quantized_decompress(ec, num_bits=4, strategy="group", symmetric=sym)
+        assert sorted(rd) == sorted(ed) and all(eq(rd[k].contiguous(), ed[k].contiguous()) for k in rd)
+    s1 = (w.abs().max().float() / 127).to(BF16).reshape(1)
+    z1 = torch.zeros(1, dtype=torch.int8)
+    a8 = QuantizationArgs(num_bits=8, strategy="tensor", symmetric=True)
+    sch8 = QuantizationScheme(targets=["Linear"], weights=a8, input_activations=a8)
+    sd8 = {"weight": w, "weight_scale": s1, "weight_zero_point": z1}
+    rc, ec = RI.compress(sd8, sch8), E.int_quantized_compress(sd8)
+    assert sorted(rc) == sorted(ec) and all(eq(rc[k], ec[k]) for k in rc)
+    assert eq(RI.decompress(rc, sch8)["weight"], E.int_quantized_decompress(ec)["weight"])
