@@ -97,6 +97,59 @@ def time_kernel(fn, iters, offset=0):
     return start.elapsed_time(stop) * 1000.0 / iters
 
 
+def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60):
+    """HBM-cold per-kernel timing of the fused W4A16 g128 compress / decompress at another size, weight dtype or with
+    an asymmetric scheme (int8 zero points): enough rotating sets that the smallest read stream (the packed words) is
+    >= 2x the 256 MiB Infinity Cache.  Parity: decompress(compress(W)) == fake_quantize(W) on one set."""
+    from compressed_tensors_amd import _lib, codec
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    dt = _lib.DT[dtype]
+    nsets = max(4, -(-(2 * 256 * 2 ** 20) // (n * n // 2)))
+    g = torch.Generator(device=dev).manual_seed(31 + n)
+    sets = []
+    for _ in range(nsets):
+        w = torch.randn(n, n, dtype=torch.float32, device=dev, generator=g).to(dtype)
+        scale, zp = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=symmetric)
+        sets.append((w, scale, zp, torch.empty(n, n // 8, dtype=torch.int32, device=dev), torch.empty(n, n, dtype=dtype, device=dev)))
+    ca = [(w.data_ptr(), dt, sc.data_ptr(), dt, zp.data_ptr(), _lib.I8, n, n, 1, GROUP, n // GROUP, None, BITS, dt, pk.data_ptr(), stream)
+          for (w, sc, zp, pk, out) in sets]
+    da = [(pk.data_ptr(), n, n // 8, n, BITS, sc.data_ptr(), dt, None if symmetric else zp.data_ptr(), -1 if symmetric else _lib.I8,
+           1, GROUP, n // GROUP, None, out.data_ptr(), dt, stream) for (w, sc, zp, pk, out) in sets]
+
+    def compress(i):
+        rc = lib.ct_quant_pack(*ca[i % nsets])
+        if rc:
+            _lib.check(rc)
+
+    def decompress(i):
+        rc = lib.ct_unpack_dequant(*da[i % nsets])
+        if rc:
+            _lib.check(rc)
+
+    for i in range(nsets):
+        compress(i)
+    one = alg_bytes_one_direction(n) + (0 if symmetric else n * (n // GROUP))  # + the int8 zero points
+    us_c, us_d = time_kernel(compress, iters), time_kernel(decompress, iters, offset=nsets // 2)
+    w, sc, zp, pk, out = sets[0]
+    ok = torch.equal(out, codec.fake_quantize_tensor(w, sc, zp, num_bits=BITS, strategy="group", group_size=GROUP))
+    return {"alg_bytes_per_direction": one, "sets": nsets,
+            "compress_us": round(us_c, 2), "compress_GBps": round(one / us_c / 1e3, 1), "compress_frac_hbm": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4),
+            "decompress_us": round(us_d, 2), "decompress_GBps": round(one / us_d / 1e3, 1), "decompress_frac_hbm": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4),
+            "round_trip_equals_fake_quantize": bool(ok)}
+
+
+def w4_variants_leg(dev):
+    """north_star's second size (4096x4096) and the other weight dtypes / schemes of the same two kernels at 8192x8192"""
+    out = {"workload": "W4A16 g128 fused compress / decompress kernels through the C ABI, HBM-cold rotation"}
+    for key, kw in (("bf16_4096", dict(n=4096)), ("fp16_8192", dict(n=N, dtype=torch.float16)),
+                    ("bf16_8192_asymmetric", dict(n=N, symmetric=False)), ("fp16_8192_asymmetric", dict(n=N, dtype=torch.float16, symmetric=False))):
+        out[key] = w4_kernel_point(dev, **kw)
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_gate(sets):
     """every benchmark run re-checks the timed kernels against INDEPENDENT kernels of the same library on the full
     8192 x 8192 tensor: fused compress == quantize(int8) -> pack_to_int32, and decompress(compress(W)) ==
@@ -114,40 +167,116 @@ def parity_gate(sets):
     return bool(ok_c and ok_d)
 
 
-def cpu_baseline(dev):
-    """the oracle (C restatement, OpenMP over rows) on the host cores: one compress+decompress of
-    the same 8192x8192 workload, best of 2.  Its outputs double as the checker of the GPU path on that tensor."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
 
+    return O
+
+
+def oracle_slice_check(dev, rows=512):
+    """the real checker on a bounded slice (runs in every configuration, also with --no-cpu-baseline): the GPU path's packed
+    words, decompressed weight and observer outputs of `rows` x 8192 against the CPU oracle, bit for bit"""
+    O = _oracle()
     from compressed_tensors_amd import codec
 
-    torch.manual_seed(0)
-    w = torch.randn(N, N, dtype=torch.bfloat16)
+    torch.manual_seed(1)
+    w = torch.randn(rows, N, dtype=torch.bfloat16)
     scale, zp = O.calculate_qparams_minmax(w, num_bits=BITS, group_size=GROUP, symmetric=True)
-    sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        c = O.pack_quantized_compress(sd, num_bits=BITS, strategy="group", group_size=GROUP, symmetric=True)
-        d = O.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+    c = O.pack_quantized_compress({"weight": w, "weight_scale": scale, "weight_zero_point": zp}, num_bits=BITS, strategy="group", group_size=GROUP, symmetric=True)
+    d = O.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True)
     kw = dict(num_bits=BITS, strategy="group", group_size=GROUP)
     g_packed = codec.quantize_and_pack(w.to(dev), scale.to(dev), zp.to(dev), **kw)
-    g_dec = codec.unpack_and_dequantize(g_packed, (N, N), scale.to(dev), None, **kw)
+    g_dec = codec.unpack_and_dequantize(g_packed, (rows, N), scale.to(dev), None, **kw)
     g_scale, g_zp = codec.minmax_qparams(w.to(dev), num_bits=BITS, group_size=GROUP, symmetric=True)
-    matches = (torch.equal(g_packed.cpu(), c["weight_packed"]) and torch.equal(g_dec.cpu().view(torch.int16), d["weight"].view(torch.int16))
-               and torch.equal(g_scale.cpu().view(torch.int16), scale.view(torch.int16)) and torch.equal(g_zp.cpu(), zp))
-    return {
-        "value": round(2 * alg_bytes_one_direction() / best / 1e9, 3),
+    return bool(torch.equal(g_packed.cpu(), c["weight_packed"]) and torch.equal(g_dec.cpu().view(torch.int16), d["weight"].view(torch.int16))
+                and torch.equal(g_scale.cpu().view(torch.int16), scale.view(torch.int16)) and torch.equal(g_zp.cpu(), zp))
+
+
+def cpu_baseline(dev):
+    """The reference's CPU path on this box's host cores, next to the GPU number (baseline, not the target).
+
+    /root/reference does not exist on the GPU box, so what is timed is oracle/eager_ref.py: the reference's own eager torch
+    op sequence (quantize: divide / add / clamp / round / cast passes in bf16; pack: int32 upcast, shifts, scatter_add_;
+    unpack: gather of a (rows x groups, 32) int32 matrix; dequantize), pinned bit-for-bit against the reference itself in the
+    build container (tests/test_oracle_golden.py) and measured there within 10 % of the reference's own time.
+    torch.set_num_threads(os.cpu_count()); 1 warm-up + min of 3.  Its outputs check the GPU path on the same tensor.
+    The C/OpenMP oracle (a stronger baseline than the reference) is reported as `cpu_baseline_port`."""
+    O = _oracle()
+    import eager_ref as E
+
+    from compressed_tensors_amd import codec
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    kw = dict(num_bits=BITS, strategy="group", group_size=GROUP)
+
+    def best_of(fn, n=3):
+        fn()
+        best, res = None, None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            res = fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, res
+
+    points = {}
+    for n in (N, 4096):
+        torch.manual_seed(0)
+        w = torch.randn(n, n, dtype=torch.bfloat16)
+        scale, zp = O.calculate_qparams_minmax(w, num_bits=BITS, group_size=GROUP, symmetric=True)
+        sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+        t_c, c = best_of(lambda: E.pack_quantized_compress(sd, symmetric=True, **kw))
+        t_d, d = best_of(lambda: E.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True))
+        t_pc, pc = best_of(lambda: O.pack_quantized_compress(sd, symmetric=True, **kw), 2)
+        t_pd, pd = best_of(lambda: O.pack_quantized_decompress(pc, num_bits=BITS, strategy="group", symmetric=True), 2)
+        g_packed = codec.quantize_and_pack(w.to(dev), scale.to(dev), zp.to(dev), **kw)
+        g_dec = codec.unpack_and_dequantize(g_packed, (n, n), scale.to(dev), None, **kw)
+        g_scale, g_zp = codec.minmax_qparams(w.to(dev), num_bits=BITS, group_size=GROUP, symmetric=True)
+        same = (torch.equal(c["weight_packed"], pc["weight_packed"]) and torch.equal(d["weight"].view(torch.int16), pd["weight"].view(torch.int16)))
+        matches = (torch.equal(g_packed.cpu(), c["weight_packed"]) and torch.equal(g_dec.cpu().view(torch.int16), d["weight"].view(torch.int16))
+                   and torch.equal(g_scale.cpu().view(torch.int16), scale.view(torch.int16)) and torch.equal(g_zp.cpu(), zp))
+        points[n] = dict(t_c=t_c, t_d=t_d, t_pc=t_pc, t_pd=t_pd, same=bool(same), matches=bool(matches))
+    # BASELINE config 1, the reference's own CPU-runnable case: int8 per-tensor symmetric IntQuantizationCompressor round trip
+    torch.manual_seed(0)
+    w = torch.randn(4096, 4096, dtype=torch.bfloat16)
+    s1 = (w.abs().max().float() / 127.0).to(torch.bfloat16).reshape(1)
+    sd8 = {"weight": w, "weight_scale": s1, "weight_zero_point": torch.zeros(1, dtype=torch.int8)}
+    t_c8, c8 = best_of(lambda: E.int_quantized_compress(sd8))
+    t_d8, d8 = best_of(lambda: E.int_quantized_decompress(c8))
+    g_q8 = codec.quantize_tensor(w.to(dev), s1.to(dev), sd8["weight_zero_point"].to(dev), num_bits=8, strategy="tensor", dtype=torch.int8)
+    g_d8 = codec.dequantize_tensor(g_q8, s1.to(dev), None)
+    ok8 = bool(torch.equal(g_q8.cpu(), c8["weight"]) and torch.equal(g_d8.cpu().view(torch.int16), d8["weight"].view(torch.int16)))
+
+    def gbps(n, t):
+        return round(2 * alg_bytes_one_direction(n) / t / 1e9, 3)
+
+    p = points[N]
+    eager = {
+        "value": gbps(N, p["t_c"] + p["t_d"]),
         "unit": "GB/s",
-        "cores": O.num_threads(),
+        "cores": cores,
         "kind": "port",
-        "sample": f"1 compress + 1 decompress of W4A16 g128 {N}x{N} bf16 (best of 2, {best:.3f} s), "
-                  "C oracle with OpenMP over rows (unfused quantize->pack / unpack->dequantize like the reference)",
-        "gpu_bit_exact_vs_oracle": bool(matches),
+        "impl": "torch-eager: oracle/eager_ref.py restates the reference's op sequence (pack_quantized/base.py:62-163, helpers.py:20-180, "
+                "forward_helpers.py:118-177,523-572) on CPU tensors, torch.set_num_threads(os.cpu_count()); bit-identical to the reference "
+                "in the build container",
+        "sample": f"PackedQuantizationCompressor-shaped compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 3 "
+                  f"(compress {p['t_c']:.3f} s, decompress {p['t_d']:.3f} s)",
+        "compress_s": round(p["t_c"], 4), "decompress_s": round(p["t_d"], 4),
+        "at_4096": {"value": gbps(4096, points[4096]["t_c"] + points[4096]["t_d"]), "compress_s": round(points[4096]["t_c"], 4),
+                    "decompress_s": round(points[4096]["t_d"], 4)},
+        "config1_int8_per_tensor_4096": {"compress_s": round(t_c8, 4), "decompress_s": round(t_d8, 4),
+                                         "GBps": round(2 * 3 * 4096 * 4096 / (t_c8 + t_d8) / 1e9, 3), "gpu_bit_exact": ok8},
+        "gpu_bit_exact_vs_oracle": bool(all(q["matches"] and q["same"] for q in points.values()) and ok8),
     }
+    port = {
+        "value": gbps(N, p["t_pc"] + p["t_pd"]), "unit": "GB/s", "cores": O.num_threads(), "kind": "port",
+        "impl": "C restatement with OpenMP over rows (oracle/ct_oracle.c), unfused quantize->pack / unpack->dequantize",
+        "sample": f"the same {N}x{N} weight, best of 2 ({p['t_pc'] + p['t_pd']:.3f} s)",
+        "at_4096": {"value": gbps(4096, points[4096]["t_pc"] + points[4096]["t_pd"])},
+    }
+    return eager, port
 
 
 def bitmask_leg(dev):
@@ -265,6 +394,13 @@ def marlin24_leg(dev):
         sds.append({"weight": w, "weight_scale": scale, "weight_zero_point": zp})
     out = cta.Marlin24Compressor.compress(sds[0], scheme)
     torch.cuda.synchronize()
+    # gate: all three outputs of the full 8192 x 8192 tensor against the CPU oracle (about 2 s of host time)
+    O = _oracle()
+    ref = O.marlin24_compress(sds[0]["weight"].cpu(), sds[0]["weight_scale"].cpu(), sds[0]["weight_zero_point"].cpu(),
+                              num_bits=BITS, strategy="group", group_size=GROUP)
+    exact = all(out[k].shape == ref[k].shape and torch.equal(out[k].cpu().contiguous().view(torch.int16 if out[k].dtype == torch.float16 else out[k].dtype),
+                                                             ref[k].contiguous().view(torch.int16 if ref[k].dtype == torch.float16 else ref[k].dtype))
+                for k in ("weight_packed", "scale_packed", "meta"))
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     iters = 8
     start.record()
@@ -277,6 +413,7 @@ def marlin24_leg(dev):
     return {"workload": f"marlin-24 compress (2:4 + int4 g128), {N}x{N} bf16, plug-in class API",
             "alg_bytes": alg, "compress_us": round(us, 1), "compress_GBps": round(alg / us / 1e3, 1),
             "compress_frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "bit_exact_vs_oracle": bool(exact),
             "outputs": {k: list(v.shape) for k, v in out.items() if hasattr(v, "shape")}}
 
 
@@ -469,6 +606,87 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
             "round_trip_equals_fake_quantize": bool(torch.equal(o0, fq))}
 
 
+def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters=20):
+    """SURVEY 8e for the single-tensor configs: ONE 8192x8192 tensor split by row blocks (`shard_rows`, multiples of 64
+    rows) over the ranks — strong scaling, no data-path collective.  Config 2 (W4A16 compress + decompress of the rank's
+    rows) and config 3 (sparse-bitmask compress + decompress; the shard's row_offsets are local, the global ones are
+    local + the number of non-zeros in the earlier shards).  Every rank also computes the whole tensor by itself once and
+    checks that its shard's outputs are exactly the corresponding slice of the single-rank result."""
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.distributed.shard import shard_rows
+
+    a, b = shard_rows(N, rank=rank, world_size=world, multiple=64)
+    g = torch.Generator(device=dev).manual_seed(4242)  # the same tensor on every rank
+    kw = dict(num_bits=BITS, strategy="group", group_size=GROUP)
+    nsets = 6
+    full = [torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g) for _ in range(nsets)]
+    scales = [codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=True) for w in full]
+    out = {"rows_this_rank": [a, b], "ranks": world}
+
+    # config 2
+    w0, (s0, z0) = full[0], scales[0]
+    p_full = codec.quantize_and_pack(w0, s0, z0, **kw)
+    d_full = codec.unpack_and_dequantize(p_full, (N, N), s0, None, **kw)
+    p_mine = codec.quantize_and_pack(w0[a:b], s0[a:b], z0[a:b], **kw)
+    d_mine = codec.unpack_and_dequantize(p_mine, (b - a, N), s0[a:b], None, **kw)
+    ok = torch.equal(p_mine, p_full[a:b]) and torch.equal(d_mine.view(torch.int16), d_full[a:b].view(torch.int16))
+    del p_full, d_full, d_mine
+    packs = [codec.quantize_and_pack(w[a:b], s[a:b], z[a:b], **kw) for w, (s, z) in zip(full, scales)]
+
+    def step2(i):
+        w, (s, z) = full[i % nsets], scales[i % nsets]
+        codec.quantize_and_pack(w[a:b], s[a:b], z[a:b], **kw)
+        codec.unpack_and_dequantize(packs[(i + nsets // 2) % nsets], (b - a, N), s[a:b], None, **kw)
+
+    def timed(step):
+        for i in range(3):
+            step(i)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            step(i)
+        torch.cuda.synchronize()
+        return allreduce_max(time.perf_counter() - t0) / iters
+
+    t2 = timed(step2)
+    alg2 = 2 * alg_bytes_one_direction()
+    out["w4a16"] = {"us_per_tensor": round(t2 * 1e6, 2), "GBps_all_ranks": round(alg2 / t2 / 1e9, 1),
+                    "frac_of_hbm_peak_per_gpu": round(alg2 / t2 / 1e9 / world / HBM_PEAK_GBPS, 4),
+                    "shard_equals_slice_of_single_rank_result": bool(allreduce_min(1.0 if ok else 0.0) == 1.0)}
+    del packs, scales
+    torch.cuda.empty_cache()
+
+    # config 3
+    sparse = [w.masked_fill_(torch.rand(N, N, device=dev, generator=g) < 0.5, 0) for w in full]
+    x0 = sparse[0]
+    v_full, bm_full, ro_full = codec.bitmask_compress(x0)
+    v, bm, ro = codec.bitmask_compress(x0[a:b])
+    base = int(ro_full[a].item())
+    stop = int(ro_full[b].item()) if b < N else v_full.numel()
+    back = codec.bitmask_decompress(v, bm, (b - a, N), ro)
+    ok3 = (torch.equal(v.view(torch.int16), v_full[base:stop].view(torch.int16)) and torch.equal(bm, bm_full[a:b])
+           and torch.equal(ro + base, ro_full[a:b]) and torch.equal(back.view(torch.int16), x0[a:b].view(torch.int16)))
+    nnz = v_full.numel()
+    del v_full, bm_full, back
+    comp = [codec.bitmask_compress(x[a:b]) for x in sparse]
+
+    def step3(i):
+        codec.bitmask_compress(sparse[i % nsets][a:b])
+        cv, cb, co = comp[(i + nsets // 2) % nsets]
+        codec.bitmask_decompress(cv, cb, (b - a, N), co)
+
+    t3 = timed(step3)
+    alg3 = 2 * (2 * N * N + 2 * nnz + N * N // 8 + 8 * N)
+    out["sparse_bitmask"] = {"us_per_tensor": round(t3 * 1e6, 2), "GBps_all_ranks": round(alg3 / t3 / 1e9, 1),
+                             "frac_of_hbm_peak_per_gpu": round(alg3 / t3 / 1e9 / world / HBM_PEAK_GBPS, 4),
+                             "row_offsets": "local per shard; global = local + nnz of the earlier shards",
+                             "shard_equals_slice_of_single_rank_result": bool(allreduce_min(1.0 if ok3 else 0.0) == 1.0)}
+    out["workload"] = (f"ONE {N}x{N} bf16 tensor split by row blocks over {world} rank(s) (strong scaling, no collectives), through the "
+                       "plug-in's tensor-level API (allocation + launch per call)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -477,6 +695,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--one-stream", action="store_true", help="issue the step's two launches on one HIP stream")
+    ap.add_argument("--shard", choices=("tensors", "rows"), default="tensors",
+                    help="tensors (default): one 8192^2 weight shard per rank, weak scaling.  rows: additionally force the row-block leg "
+                         "(ONE tensor split by rows over the ranks, strong scaling) — it always runs when N > 1")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -616,22 +837,31 @@ def main():
         if world == 1 and not a.no_extra:
             del sets
             torch.cuda.empty_cache()
-            for key, leg in (("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
+            for key, leg in (("kernels_other", w4_variants_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
                              ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down
                     result[key] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            if isinstance(result.get("kernels_other"), dict) and "bf16_4096" in result["kernels_other"]:
+                result["kernels_4096"] = result["kernels_other"]["bf16_4096"]  # north_star names both sizes
         if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(dev)
+            result["cpu_baseline"], result["cpu_baseline_port"] = cpu_baseline(dev)
+        result["oracle_slice_check"] = oracle_slice_check(dev)  # never skipped: no configuration runs without the real checker
     if not a.no_extra:  # every rank takes part: the checkpoint is sharded over the ranks
-        def allreduce_max(x):
+        def _allreduce(x, op):
             if not distributed:
                 return x
             t = torch.tensor([x], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only
+            dist.all_reduce(t, op=op)  # timing / pass-fail flags only
             return float(t.item())
+
+        def allreduce_max(x):
+            return _allreduce(x, dist.ReduceOp.MAX) if distributed else x
+
+        def allreduce_min(x):
+            return _allreduce(x, dist.ReduceOp.MIN) if distributed else x
 
         try:
             leg = tinyllama_leg(dev, rank, world, barrier, allreduce_max)
@@ -639,6 +869,14 @@ def main():
             leg = {"error": repr(e)}
         if rank == 0:
             result["tinyllama_checkpoint"] = leg
+        if distributed or a.shard == "rows":
+            torch.cuda.empty_cache()
+            try:
+                leg = row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min)
+            except Exception as e:
+                leg = {"error": repr(e)}
+            if rank == 0:
+                result["row_sharded"] = leg
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 from .assign import greedy_bin_packing
 from .module_parallel import recouple_modules, replace_module_parallel
-from .shard import init_dist, is_distributed, module_size, rank_and_world, shard_items, shard_modules, shard_rows
+from .shard import init_dist, is_distributed, merge_bitmask_row_shards, module_size, rank_and_world, shard_items, shard_modules, shard_rows
 
 __all__ = [
     "greedy_bin_packing",
@@ -13,4 +13,5 @@ __all__ = [
     "shard_items",
     "shard_modules",
     "shard_rows",
+    "merge_bitmask_row_shards",
 ]

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 from .assign import greedy_bin_packing
 
-__all__ = ["init_dist", "is_distributed", "rank_and_world", "module_size", "shard_modules", "shard_rows", "shard_items"]
+__all__ = ["init_dist", "is_distributed", "rank_and_world", "module_size", "shard_modules", "shard_rows", "shard_items", "merge_bitmask_row_shards"]
 
 
 def is_distributed() -> bool:
@@ -82,3 +82,17 @@ def shard_rows(rows: int, rank: Optional[int] = None, world_size: Optional[int] 
     start_u = rank * per + min(rank, extra)
     stop_u = start_u + per + (1 if rank < extra else 0)
     return min(start_u * multiple, rows), min(stop_u * multiple, rows)
+
+
+def merge_bitmask_row_shards(shards):
+    """Reassemble the sparse-bitmask encoding of ONE tensor from its row-block shards, given in row order as
+    (values, bitmask, row_offsets) triples with shard-local row offsets: values and bitmask rows concatenate, and a shard's
+    offsets are rebased by the number of non-zeros in the shards before it.  Pure bookkeeping (torch.cat on
+    whatever device the shards live on); the result equals compressing the whole tensor on one rank."""
+    values, bitmasks, offsets, base = [], [], [], 0
+    for v, bm, ro in shards:
+        values.append(v)
+        bitmasks.append(bm)
+        offsets.append(ro + base)
+        base += v.numel()
+    return torch.cat(values), torch.cat(bitmasks), torch.cat(offsets)

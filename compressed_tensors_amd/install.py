@@ -20,7 +20,7 @@ import torch
 from . import codec
 from .quantization.quant_args import enum_value
 
-__all__ = ["install", "uninstall"]
+__all__ = ["install", "uninstall", "install_into", "uninstall_from", "make_hip_subclass", "quantize_backend", "quantize_backend_req"]
 
 _SAVED = {}
 
@@ -50,98 +50,133 @@ def _fp4_compressible(state_dict, group) -> bool:
             and w.shape[1] % group == 0)
 
 
+def make_hip_subclass(up_cls, amd_cls):
+    """A subclass of the upstream codec `up_cls` (so `can_compress`, `compression_param_names`, `compress_module`,
+    `decompress_module` and any upstream helper are inherited) whose `compress` / `decompress` run `amd_cls`'s HIP
+    path for GPU tensors of a type the kernels implement, and upstream's own code for everything else."""
+    fp4_group = getattr(amd_cls, "GROUP", None)  # set on the FP4 codecs only
+
+    class _Hip(up_cls):
+        @classmethod
+        def compress(cls, state_dict, scheme):
+            if fp4_group is not None:
+                ours = _fp4_weights(scheme) and _fp4_compressible(state_dict, fp4_group)
+            else:
+                ours = _int_weights(scheme) and _on_gpu(state_dict.get("weight"))
+            if ours and fp4_group is not None:
+                return amd_cls.compress(state_dict, scheme)  # uses the FP4 class's own scale hooks
+            if ours:
+                return amd_cls.compress.__func__(cls, state_dict, scheme)
+            return up_cls.compress.__func__(cls, state_dict, scheme)
+
+        @classmethod
+        def decompress(cls, state_dict, scheme):
+            probe = state_dict.get("weight_packed", state_dict.get("weight"))
+            ours = _fp4_weights(scheme) if fp4_group is not None else _int_weights(scheme)
+            if ours and _on_gpu(probe) and fp4_group is not None:
+                return amd_cls.decompress(state_dict, scheme)
+            if ours and _on_gpu(probe):
+                return amd_cls.decompress.__func__(cls, state_dict, scheme)
+            return up_cls.decompress.__func__(cls, state_dict, scheme)
+
+    _Hip.__name__ = up_cls.__name__ + "MI355X"
+    _Hip.__qualname__ = _Hip.__name__
+    return _Hip
+
+
+def quantize_backend_req(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None) -> bool:
+    """`req` of the `_quantize` backend: receives exactly `_quantize`'s arguments (forward_helpers.py:525-534)"""
+    return (
+        x.is_cuda
+        and (enum_value(getattr(args, "type", "int")) == "int" or int(args.num_bits) in (4, 8))
+        and (global_scale is None or (enum_value(getattr(args, "type", "int")) == "float" and int(args.num_bits) == 4))
+        and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
+        and dtype in (None, torch.int8, torch.int32, torch.float8_e4m3fn, torch.float32, torch.float16, torch.bfloat16)
+        and x.is_contiguous() and _broadcast_layout(x, scale) is not None
+    )
+
+
+def quantize_backend(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
+    """HIP `_quantize` (replaces the disabled Triton backend registered at forward_helpers.py:404): `x` arrives already
+    reshaped by `_process_group` — (R, G, gs) with scale (R, G, 1) — or as (R, C) with a (R, 1) / one-element scale.
+    q_min / q_max are recomputed from `args` on the host (they are 0-dim device tensors upstream: reading them would sync)."""
+    layout = _broadcast_layout(x, scale)
+    x2 = x.reshape(-1, x.shape[-1]) if layout["strategy"] != "group" else x.reshape(-1, x.shape[-2] * x.shape[-1])
+    out = codec.quantize_tensor(
+        x2, scale.reshape(layout["scale_shape"]), None if zero_point is None else zero_point.reshape(layout["scale_shape"]),
+        num_bits=int(args.num_bits), strategy=layout["strategy"], group_size=layout.get("group_size"),
+        qtype=enum_value(getattr(args, "type", "int")), global_scale=global_scale,
+        dtype=dtype if dtype is not None else (torch.float32 if global_scale is not None else torch.result_type(x, scale)),
+    )
+    return out.reshape(x.shape)
+
+
+_FORMATS = ("pack-quantized", "naive-quantized", "int-quantized", "float-quantized", "mxfp8-quantized",
+            "nvfp4-pack-quantized", "mxfp4-pack-quantized")
+
+
+def _amd_codecs():
+    from .compressors.fp4 import MXFP4PackedCompressor, NVFP4PackedCompressor
+    from .compressors.mxfp8 import MXFP8QuantizationCompressor
+    from .compressors.naive_quantized import NaiveQuantizationCompressor
+    from .compressors.pack_quantized import PackedQuantizationCompressor
+
+    return dict(zip(_FORMATS, (PackedQuantizationCompressor, NaiveQuantizationCompressor, NaiveQuantizationCompressor,
+                               NaiveQuantizationCompressor, MXFP8QuantizationCompressor, NVFP4PackedCompressor, MXFP4PackedCompressor)))
+
+
+def install_into(table: dict, impl_backend, saved: dict = None) -> dict:
+    """The wiring itself, independent of where the host library lives: `table` is the format-string -> codec-class
+    dict that `BaseCompressor.get_value_from_registry` reads (upstream: `registry._REGISTRY[BaseCompressor]`),
+    `impl_backend` the `ImplBackend` class whose entrypoints dispatch `_quantize`, `pack_fp4_to_uint8`, `cast_to_fp4`
+    (upstream utils/impl_backend.py:50-123).  Returns {format: original class} for `uninstall_from`.  `install()` calls
+    this with upstream's objects; the GPU tests call it with stand-ins, because the GPU box has no upstream install."""
+    saved = {} if saved is None else saved
+    for fmt, amd_cls in _amd_codecs().items():
+        if fmt not in table and fmt not in saved:
+            continue  # an older upstream without the FP4 codecs
+        if fmt not in saved:
+            saved[fmt] = table[fmt]
+        table[fmt] = make_hip_subclass(saved[fmt], amd_cls)
+
+    def register(op, name, req, fn):
+        if name in impl_backend._fn_registry:
+            return
+        fn = _renamed(fn, name)  # backend __name__s must be globally unique upstream (:126-134)
+        impl_backend.register(op, req=req, priority=0)(fn)
+
+    floats = (torch.float32, torch.float16, torch.bfloat16)
+    register("_quantize", "_quantize_mi355x", quantize_backend_req, quantize_backend)
+    register("pack_fp4_to_uint8", "pack_fp4_to_uint8_mi355x",
+             lambda x: x.is_cuda and x.dim() == 2 and x.dtype in floats and x.shape[1] % 2 == 0, codec.pack_fp4_to_uint8)
+    register("cast_to_fp4", "cast_to_fp4_mi355x", lambda x: x.is_cuda and x.dtype in floats, codec.cast_to_fp4)
+    return saved
+
+
+def _renamed(fn, name):
+    import functools
+
+    @functools.wraps(fn)
+    def backend(*args, **kwargs):
+        return fn(*args, **kwargs)
+
+    backend.__name__ = backend.__qualname__ = name
+    return backend
+
+
+def uninstall_from(table: dict, saved: dict) -> None:
+    for fmt, cls in saved.items():
+        table[fmt] = cls
+    saved.clear()
+
+
 def install():
     import compressed_tensors  # the upstream package; ImportError if it is not installed
     from compressed_tensors.compressors import BaseCompressor
     from compressed_tensors.registry import registry as up_registry
     from compressed_tensors.utils.impl_backend import ImplBackend
 
-    from .compressors.naive_quantized import NaiveQuantizationCompressor as _AmdNaive
-    from .compressors.pack_quantized import PackedQuantizationCompressor as _AmdPacked
-
-    table = up_registry._REGISTRY[BaseCompressor]
-
-    from .compressors.fp4 import MXFP4PackedCompressor as _AmdMXFP4
-    from .compressors.fp4 import NVFP4PackedCompressor as _AmdNVFP4
-    from .compressors.mxfp8 import MXFP8QuantizationCompressor as _AmdMXFP8
-
-    def subclass(up_cls, amd_cls, name):
-        fp4_group = getattr(amd_cls, "GROUP", None)  # set on the FP4 codecs only
-
-        class _Hip(up_cls):  # inherits can_compress / compression_param_names / *_module
-            @classmethod
-            def compress(cls, state_dict, scheme):
-                if fp4_group is not None:
-                    ours = _fp4_weights(scheme) and _fp4_compressible(state_dict, fp4_group)
-                else:
-                    ours = _int_weights(scheme) and _on_gpu(state_dict.get("weight"))
-                if ours and fp4_group is not None:
-                    return amd_cls.compress(state_dict, scheme)  # uses the FP4 class's own scale hooks
-                if ours:
-                    return amd_cls.compress.__func__(cls, state_dict, scheme)
-                return up_cls.compress.__func__(cls, state_dict, scheme)
-
-            @classmethod
-            def decompress(cls, state_dict, scheme):
-                probe = state_dict.get("weight_packed", state_dict.get("weight"))
-                ours = _fp4_weights(scheme) if fp4_group is not None else _int_weights(scheme)
-                if ours and _on_gpu(probe) and fp4_group is not None:
-                    return amd_cls.decompress(state_dict, scheme)
-                if ours and _on_gpu(probe):
-                    return amd_cls.decompress.__func__(cls, state_dict, scheme)
-                return up_cls.decompress.__func__(cls, state_dict, scheme)
-
-        _Hip.__name__ = up_cls.__name__ + "MI355X"
-        _Hip.__qualname__ = _Hip.__name__
-        return _Hip
-
-    for fmt, amd_cls in (("pack-quantized", _AmdPacked), ("naive-quantized", _AmdNaive), ("int-quantized", _AmdNaive),
-                         ("float-quantized", _AmdNaive), ("mxfp8-quantized", _AmdMXFP8),
-                         ("nvfp4-pack-quantized", _AmdNVFP4), ("mxfp4-pack-quantized", _AmdMXFP4)):
-        if fmt not in table and fmt not in _SAVED:
-            continue  # an older upstream without the FP4 codecs
-        up_cls = table[fmt]
-        if fmt not in _SAVED:
-            _SAVED[fmt] = up_cls
-        table[fmt] = subclass(_SAVED[fmt], amd_cls, fmt)
-
-    if "_quantize_mi355x" not in ImplBackend._fn_registry:
-
-        def _req(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
-            return (
-                x.is_cuda
-                and (enum_value(getattr(args, "type", "int")) == "int" or int(args.num_bits) in (4, 8))
-                and (global_scale is None or (enum_value(getattr(args, "type", "int")) == "float" and int(args.num_bits) == 4))
-                and x.dtype in (torch.float32, torch.float16, torch.bfloat16)
-                and dtype in (None, torch.int8, torch.int32, torch.float8_e4m3fn, torch.float32, torch.float16, torch.bfloat16)
-                and x.is_contiguous() and _broadcast_layout(x, scale) is not None
-            )
-
-        @ImplBackend.register("_quantize", req=_req, priority=0)
-        def _quantize_mi355x(x, scale, zero_point, q_min, q_max, args, dtype=None, global_scale=None):
-            layout = _broadcast_layout(x, scale)
-            x2 = x.reshape(-1, x.shape[-1]) if layout["strategy"] != "group" else x.reshape(-1, x.shape[-2] * x.shape[-1])
-            out = codec.quantize_tensor(
-                x2, scale.reshape(layout["scale_shape"]), None if zero_point is None else zero_point.reshape(layout["scale_shape"]),
-                num_bits=int(args.num_bits), strategy=layout["strategy"], group_size=layout.get("group_size"),
-                qtype=enum_value(getattr(args, "type", "int")), global_scale=global_scale,
-                dtype=dtype if dtype is not None else (torch.float32 if global_scale is not None else torch.result_type(x, scale)),
-            )
-            return out.reshape(x.shape)
-
-    _floats = (torch.float32, torch.float16, torch.bfloat16)
-    if "pack_fp4_to_uint8_mi355x" not in ImplBackend._fn_registry:
-
-        @ImplBackend.register("pack_fp4_to_uint8", req=lambda x: x.is_cuda and x.dim() == 2 and x.dtype in _floats and x.shape[1] % 2 == 0, priority=0)
-        def pack_fp4_to_uint8_mi355x(x):
-            return codec.pack_fp4_to_uint8(x)
-
-    if "cast_to_fp4_mi355x" not in ImplBackend._fn_registry:
-
-        @ImplBackend.register("cast_to_fp4", req=lambda x: x.is_cuda and x.dtype in _floats, priority=0)
-        def cast_to_fp4_mi355x(x):
-            return codec.cast_to_fp4(x)
-
+    install_into(up_registry._REGISTRY[BaseCompressor], ImplBackend, _SAVED)
     return compressed_tensors
 
 
@@ -164,7 +199,4 @@ def uninstall():
     from compressed_tensors.compressors import BaseCompressor
     from compressed_tensors.registry import registry as up_registry
 
-    table = up_registry._REGISTRY[BaseCompressor]
-    for fmt, cls in _SAVED.items():
-        table[fmt] = cls
-    _SAVED.clear()
+    uninstall_from(up_registry._REGISTRY[BaseCompressor], _SAVED)

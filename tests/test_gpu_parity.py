@@ -414,6 +414,48 @@ def test_marlin24_vs_oracle(cta, dev, bits, strategy, gs):
     assert torch.equal(perm, O.marlin24_perm(bits).long())
 
 
+def _marlin24_case(cta, dev, out_f, in_f, bits, strategy, gs, wdt=BF16, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn((out_f, in_f), generator=g).to(wdt)
+    w = w * O.sparse24_mask(w).to(w.dtype)
+    scale, zp = O.calculate_qparams_minmax(w.to(F16), num_bits=bits, group_size=gs, symmetric=True)
+    ref = O.marlin24_compress(w, scale, zp, num_bits=bits, strategy=strategy, group_size=gs)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=bits, strategy=strategy, group_size=gs, symmetric=True))
+    got = cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+    assert sorted(got.keys()) == ["meta", "scale_packed", "weight_packed"]
+    for k in ref:
+        assert got[k].shape == ref[k].shape and got[k].dtype == ref[k].dtype, (k, got[k].shape, ref[k].shape)
+        assert eq(got[k].cpu().contiguous(), ref[k].contiguous()), k
+    return got
+
+
+def test_marlin24_full_size(cta, dev):
+    """BASELINE config 4 at its stated size: 2:4 + int4 g128 marlin-24 packing of 8192x8192 bf16 — packed words,
+    permuted fp16 scales and reordered 2:4 metadata bit-exact with the oracle (64-bit offsets, all 1 048 576 threads
+    of marlin24_fused_w4_kernel).  Spec: utils/semi_structured_conversions.py:66-197, utils/permutations_24.py:20-53."""
+    got = _marlin24_case(cta, dev, 8192, 8192, 4, "group", 128)
+    assert got["weight_packed"].shape == (8192 // 2 // 16, 8192 * 16 // 8) and got["meta"].shape == (8192 // 16 // 2, 8192 * 2)
+    assert got["scale_packed"].shape == (64, 8192) and got["scale_packed"].dtype == F16
+
+
+@pytest.mark.parametrize("out_f,in_f,bits,strategy,gs", [
+    (512, 2048, 4, "group", 128), (2048, 512, 4, "group", 128),   # non-square, fused one-launch path (in % 256 == 0)
+    (192, 1024, 4, "channel", None), (1024, 320, 4, "group", 32),  # in % 256 != 0: front end + packing kernel
+    (256, 2048, 8, "group", 128), (2048, 256, 8, "channel", None),  # int8 codes
+    (128, 256, 4, "group", 128),   # group_size == in/2 == size_k of the compressed weight: the single-column scale permutation
+    (128, 512, 4, "group", 256),   # same boundary, one level up
+])
+@pytest.mark.parametrize("wdt", [BF16, F16])
+def test_marlin24_non_square(cta, dev, out_f, in_f, bits, strategy, gs, wdt):
+    """`scale_packed` is (groups, out_features) and the group permutation applies iff group_size < in_features / 2
+    (size_k of the compressed, transposed weight) — the layout vLLM's marlin-24 loader expects; see DESIGN.md 5.6"""
+    got = _marlin24_case(cta, dev, out_f, in_f, bits, strategy, gs, wdt=wdt, seed=out_f + in_f)
+    groups = in_f // gs if strategy == "group" else 1
+    assert got["scale_packed"].shape == (groups, out_f)
+    assert got["weight_packed"].shape == (in_f // 2 // 16, out_f * 16 // (32 // bits))
+    assert got["meta"].shape == (in_f // 16 // 2, out_f * 2)
+
+
 def test_marlin24_rejects_dense_weight(cta, dev):
     """a weight that is not 2:4 must be refused (fused front end: device flag, one host read)"""
     w = torch.randn(64, 256).to(BF16)
@@ -1034,6 +1076,11 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
     leg = out["tinyllama_checkpoint"]
     assert leg["round_trip_equals_fake_quantize"] is True and 0 < leg["modules_this_rank"] < 154
+    assert out["oracle_slice_check"] is True
+    rs = out["row_sharded"]  # ONE tensor split by row blocks over the ranks; each shard is a slice of the single-rank result
+    assert rs["ranks"] == 2 and rs["rows_this_rank"] == [0, 4096]
+    assert rs["w4a16"]["shard_equals_slice_of_single_rank_result"] is True and rs["w4a16"]["GBps_all_ranks"] > 0
+    assert rs["sparse_bitmask"]["shard_equals_slice_of_single_rank_result"] is True
 
 
 @pytest.mark.parametrize("wdt", [BF16, F16])

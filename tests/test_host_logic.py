@@ -272,6 +272,61 @@ def test_world_size_2_sharding_gloo(tmp_path):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
 
 
+_ROWSHARD_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle"))
+import oracle as O   # the CPU checker stands in for the kernels on this GPU-less host: what is tested is the sharding logic
+from compressed_tensors_amd.distributed import init_dist, rank_and_world, shard_rows, merge_bitmask_row_shards
+init_dist()
+rank, world = rank_and_world()
+torch.manual_seed(0)  # the same tensor on every rank
+R, C = 320, 256
+w = torch.randn(R, C, dtype=torch.bfloat16)
+a, b = shard_rows(R, multiple=64)
+assert (a, b) == ((0, 192) if rank == 0 else (192, 320))  # multiples of 64 rows, remainder on the last rank
+# config 2: rows are independent -> the shard's packed words / dequantized rows are a slice of the single-rank result
+scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=128, symmetric=True)
+kw = dict(num_bits=4, strategy="group", group_size=128, symmetric=True)
+full = O.pack_quantized_compress({{"weight": w, "weight_scale": scale, "weight_zero_point": zp}}, **kw)
+mine = O.pack_quantized_compress({{"weight": w[a:b], "weight_scale": scale[a:b], "weight_zero_point": zp[a:b]}}, **kw)
+gathered = [None] * world
+dist.all_gather_object(gathered, mine["weight_packed"])   # test-only collective
+assert torch.equal(torch.cat(gathered), full["weight_packed"])
+# config 3: values / bitmask concatenate, row_offsets are rebased by the earlier shards' nnz
+x = w.masked_fill(torch.rand(R, C) < 0.5, 0)
+v, bm, ro = O.bitmask_compress(x[a:b])
+assert int(ro[0]) == 0
+shards = [None] * world
+dist.all_gather_object(shards, (v, bm, ro))
+mv, mb, mo = merge_bitmask_row_shards(shards)
+fv, fb, fo = O.bitmask_compress(x)
+assert torch.equal(mv.view(torch.int16), fv.view(torch.int16)) and torch.equal(mb, fb) and torch.equal(mo, fo) and mo.dtype == torch.int64
+assert torch.equal(O.bitmask_decompress(mv, mb, x.shape).view(torch.int16), x.view(torch.int16))
+dist.barrier()
+open(os.path.join(os.environ["CT_TEST_OUT"], f"rank{{rank}}.ok"), "w").write("ok")
+"""
+
+
+def test_world_size_2_row_block_shards_gloo(tmp_path):
+    """SURVEY 8e, single-tensor configs: row-block shards of ONE tensor reassemble to the single-rank result bit for bit
+    (W4A16 packed words; sparse-bitmask values / bitmask / rebased row_offsets)"""
+    import socket
+
+    script = tmp_path / "rowshard_check.py"
+    script.write_text(_ROWSHARD_SCRIPT.format(root=ROOT))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", CT_TEST_OUT=str(tmp_path))
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script)],
+        capture_output=True, text=True, env=env, timeout=240,
+    )
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists(), r.stdout + r.stderr
+
+
 _RECOUPLE_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
