@@ -85,6 +85,8 @@ _PROTOTYPES = {
     "ct_cutlass24_to_dense": ([_P, _I, _P, _I, _L, _L, _P, _S], _I),
     "ct_marlin24_quant_compress": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _S], _I),
     "ct_marlin24_compress_w4": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _P, _S], _I),
+    "ct_marlin24_compress_w4_full": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _P, _I, _S], _I),
+    "ct_selftest_m24_div": ([_I, _c.c_uint32, _c.c_uint32, _P, _S], _I),
     "ct_marlin24_pack_weights": ([_P, _I, _I, _I, _L, _L, _I, _P, _S], _I),
     "ct_marlin24_pack_scales": ([_P, _I, _L, _L, _I, _P, _S], _I),
     "ct_marlin24_pack_scales_f16": ([_P, _I, _L, _L, _I, _P, _S], _I),
@@ -176,6 +178,10 @@ def ptr(t):
 def stream_of(t: torch.Tensor):
     """the caller's current HIP stream on the tensor's device, as an integer handle that remembers its device"""
     return stream_on(t.device)
+
+
+def stream_of_device(device):
+    return stream_on(device)
 
 
 def stream_on(device, handle=None):

@@ -42,6 +42,8 @@ __all__ = [
     "fp4_unpack_and_dequantize",
     "marlin24_quant_compress",
     "marlin24_compress_w4",
+    "marlin24_compress_w4_full",
+    "selftest_m24_div",
     "bitmask_compress",
     "bitmask_decompress",
     "sparse24_mask",
@@ -870,6 +872,38 @@ def marlin24_compress_w4(weight: torch.Tensor, scale: torch.Tensor, zero_point, 
     call("ct_marlin24_compress_w4", ptr(w), DT[w.dtype], ptr(s), DT[s.dtype], ptr(zp), DT[zp.dtype] if zp is not None else -1,
          m, k, g, ptr(packed), ptr(meta), ptr(bad), stream_of(w))
     return _home(packed, weight), _home(meta, weight), bad
+
+
+def marlin24_compress_w4_full(weight: torch.Tensor, scale: torch.Tensor, zero_point, *, group_size: Optional[int], group_perm: bool,
+                              flag_ptr: Optional[int] = None, stream=None):
+    """the whole int4 marlin-24 compress in ONE host call and (16-bit scales) ONE launch (`ct_marlin24_compress_w4_full`): the
+    weight path of `marlin24_compress_w4` plus the permuted fp16 scales.  `flag_ptr`: device address of a pre-zeroed int32 the
+    violation is OR-ed into (a slot of the caller's ring; nothing is cleared or read here); None allocates and clears one.
+    GPU tensors only — no staging, this is the fast path, kept to three allocations and one ctypes call.  Returns
+    (weight_packed, meta already in the stored (k/32, 2m) shape, scale_packed fp16 (groups, m), flag tensor or None)."""
+    m, k = weight.shape
+    dev = weight.device
+    g = k if not group_size or group_size > k else int(group_size)
+    packed = torch.empty((k // 32, m * 2), dtype=torch.int32, device=dev)
+    meta = torch.empty((k // 32, m * 2), dtype=torch.int16, device=dev)  # the (m, k/16) reordered matrix, viewed as upstream stores it
+    scale_packed = torch.empty((k // g, m), dtype=torch.float16, device=dev)
+    flag = None
+    if flag_ptr is None:
+        flag = torch.empty(1, dtype=torch.int32, device=dev)
+        flag_ptr = flag.data_ptr()
+    call("ct_marlin24_compress_w4_full", weight.data_ptr(), DT[weight.dtype], scale.data_ptr(), DT[scale.dtype],
+         None if zero_point is None else zero_point.data_ptr(), -1 if zero_point is None else DT[zero_point.dtype], m, k, g, int(group_perm),
+         packed.data_ptr(), meta.data_ptr(), scale_packed.data_ptr(), flag_ptr, int(flag is not None), stream if stream is not None else stream_of(weight))
+    return packed, meta, scale_packed, flag
+
+
+def selftest_m24_div(mode: int, s_lo_bits: int = 0, s_hi_bits: int = 65536) -> int:
+    """mismatch count of the lean marlin-24 quotients against the IEEE divide (mode 0: fp16 / fp16 with the Newton step,
+    mode 1: bf16 / bf16 by one multiply)"""
+    dev = _lib.require_device()
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    call("ct_selftest_m24_div", int(mode), s_lo_bits, s_hi_bits, ptr(out), stream_of(out))
+    return int(out.item())
 
 
 def marlin24_pack_weights(q: torch.Tensor, num_bits: int, *, transposed: bool = False, add_offset: bool = False):

@@ -10,13 +10,23 @@ class was removed.  Restated pipeline (compress only, as upst
     scale_packed  = scale.T permuted (scale_perm for group, scale_perm_single for channel)
     meta          = meta viewed as (meta_cols / 2, rows * 2)
 
-All device work is HIP: ONE fused front-end kernel (fp16 quantize + 2:4 structure check + 2:4
-compress: `ct_marlin24_quant_compress`, no full-size intermediate), one packing kernel that reads
-the un-transposed int8 codes (the transpose is index arithmetic), one scale kernel.
+All device work is HIP.  int4 weights with cols % 256 == 0 take ONE host call (`ct_marlin24_compress_w4_full`: the fused
+weight kernel — fp16 quantize + 2:4 structure check + 2:4 compress + tile-permuted nibble packing — and the scale kernel);
+other shapes / int8 use the fused front end (`ct_marlin24_quant_compress`, no full-size intermediate), the packing kernel
+that reads the un-transposed int8 codes (the transpose is index arithmetic) and the scale kernel.
+
+The 2:4 structure check.  Upstream validates the quantized weight on the host before compressing (a blocking device read on
+a GPU).  Here the kernels OR a violation into one int32 slot of a per-stream flag ring and the class reads it back:
+immediately in `compress` (default: the ValueError is raised by the call, as upstream), or — inside
+`with Marlin24Compressor.deferred_structure_check():`, which `compress_modules` uses for a whole batch — once when the
+context exits, so that a checkpoint's worth of launches is queued without a host round trip per tensor.
 """
+import contextlib
+import threading
+
 import torch
 
-from ... import codec
+from ... import _lib, codec
 from ...config import CompressionFormat
 from ...quantization.quant_args import enum_value
 from ...utils.helpers import tensor_follows_mask_structure
@@ -25,9 +35,93 @@ from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor
 __all__ = ["Marlin24Compressor"]
 
 
+_STRUCTURE_ERROR = ("Marlin24 Compressor is only compatible with weights that have a 2:4 sparsity structure. "
+                    "Found segments in weight that do not match the expected structure.")
+
+
+class _FlagRing:
+    """int32 violation flags of the launches issued on one (device, stream): zeroed once, one slot per compress call, read back
+    by `check` (one device reduction + one host read for all slots in use).  Slots are handed out as raw device addresses."""
+
+    SLOTS = 1024
+
+    def __init__(self, device, stream):
+        self.flags = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+        self.base = self.flags.data_ptr()
+        self.stream = stream  # _lib.StreamHandle: the raw hipStream_t + its device
+        self.used = 0
+
+    def take(self) -> int:
+        if self.used == self.SLOTS:
+            self.check()
+        self.used += 1
+        return self.base + 4 * (self.used - 1)
+
+    def check(self) -> None:
+        if not self.used:
+            return
+        live = self.flags[:self.used]
+        bad = bool((live if self.used == 1 else live.any()).item())  # one slot: a plain 4-byte read, no reduction kernel
+        live.zero_()
+        self.used = 0
+        if bad:
+            raise ValueError(_STRUCTURE_ERROR)
+
+
+_rings = {}
+_local = threading.local()
+
+
+def _ring(device) -> _FlagRing:
+    stream = _lib.stream_of_device(device)
+    key = (device.index, int(stream), threading.get_ident())
+    ring = _rings.get(key)
+    if ring is None:
+        ring = _rings[key] = _FlagRing(device, stream)
+    return ring
+
+
 @BaseCompressor.register(name=CompressionFormat.marlin_24.value)
 class Marlin24Compressor(BaseCompressor):
     COMPRESSION_PARAM_NAMES = ("weight_packed", "scale_packed", "meta")
+
+    @classmethod
+    @contextlib.contextmanager
+    def deferred_structure_check(cls):
+        """Inside this context `compress` only queues work; the 2:4 structure violations of every call made in it (on this
+        thread) raise ONE ValueError when the context exits."""
+        depth = getattr(_local, "depth", 0)
+        _local.depth = depth + 1
+        if depth == 0:
+            _local.rings = []
+        try:
+            yield
+        finally:
+            _local.depth = depth
+            if depth == 0:
+                rings, _local.rings = _local.rings, []
+                first = None
+                for ring in rings:  # read every ring even if one raises: their slots must be released
+                    try:
+                        ring.check()
+                    except ValueError as e:
+                        first = first or e
+                if first is not None:
+                    raise first
+
+    @classmethod
+    def _flag(cls, device):
+        ring = _ring(device)
+        deferred = getattr(_local, "depth", 0) > 0
+        if deferred and ring not in _local.rings:
+            _local.rings.append(ring)
+        return ring, deferred
+
+    @classmethod
+    def compress_modules(cls, modules) -> None:
+        with cls.deferred_structure_check():
+            for m in modules:
+                cls.compress_module(m)
 
     @staticmethod
     def validate_quant_compatability(weights) -> bool:
@@ -64,19 +158,31 @@ class Marlin24Compressor(BaseCompressor):
         fused_ok = (weight.dtype in (torch.float16, torch.bfloat16) and scale.dtype in (torch.float16, torch.bfloat16) and weight.dim() == 2
                     and weight.shape[0] % 64 == 0 and weight.shape[1] % 16 == 0
                     and (enum_value(weights.strategy) == "channel" or (group_size and group_size % 16 == 0 and weight.shape[1] % group_size == 0)))
-        bad = None
+        is_channel = enum_value(weights.strategy) == "channel"
+        g = None if is_channel else group_size
+        ring = None
         if fused_ok:
             # one pass: weight.to(fp16) / scale.to(fp16) / quantize in fp16 / 2:4 structure check / cutlass 2:4 compress.
-            # Everything is queued before the flag is read, so the host work below overlaps the kernels
-            g = None if enum_value(weights.strategy) == "channel" else group_size
             size_n, size_k = weight.shape[0], weight.shape[1] // 2
-            if int(weights.num_bits) == 4 and weight.shape[1] % 256 == 0:
-                # everything in one launch: no int8 intermediate, no separate packing kernel
-                packed, meta, bad = codec.marlin24_compress_w4(weight, scale, zero_point, group_size=g)
-            else:
-                comp, meta, bad = codec.marlin24_quant_compress(weight, scale, zero_point, num_bits=int(weights.num_bits), group_size=g)
-                packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
+            is_group = not is_channel and group_size < size_k
+            scale2d = scale if scale.dim() == 2 else scale.reshape(scale.shape[0], -1)
+            if (int(weights.num_bits) == 4 and weight.shape[1] % 256 == 0 and weight.is_cuda and weight.is_contiguous() and weight.data_ptr() % 16 == 0
+                    and scale2d.is_cuda and scale2d.is_contiguous() and (zero_point is None or (zero_point.is_cuda and zero_point.is_contiguous()))
+                    and (size_n * scale2d.shape[1]) % 64 == 0):
+                # everything in one host call: no int8 intermediate, no separate packing / scale launches
+                ring, deferred = cls._flag(weight.device)
+                packed, meta, scale_packed, _ = codec.marlin24_compress_w4_full(weight, scale2d, zero_point, group_size=g, group_perm=is_group,
+                                                                                flag_ptr=ring.take(), stream=ring.stream)
+                state_dict["weight_packed"] = packed
+                state_dict["scale_packed"] = scale_packed
+                state_dict["meta"] = meta
+                if not deferred:
+                    ring.check()  # one host read, as the reference pipeline's structure check
+                return state_dict
+            comp, meta, bad = codec.marlin24_quant_compress(weight, scale, zero_point, num_bits=int(weights.num_bits), group_size=g)
+            packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
         else:
+            bad = None
             scale16 = scale.to(torch.float16)
             w16 = weight.to(torch.float16)
             q = codec.quantize_tensor(
@@ -87,6 +193,8 @@ class Marlin24Compressor(BaseCompressor):
             comp, meta = codec.cutlass24_from_dense(q)
             size_n, size_k = comp.shape  # the kernel expects input-dim first: packed from comp.T
             packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)
+        # scale_packed is (groups, out_features) and the group permutation applies iff group_size < size_k, the in-dimension of
+        # the COMPRESSED, transposed weight (in_features / 2): the historical pack_scales_24(scale, args, w_shape = value.shape)
         is_group = enum_value(weights.strategy) == "group" and group_size is not None and group_size < size_k
         scale2d = scale.reshape(scale.shape[0], -1)
         if scale2d.dtype in (torch.float16, torch.bfloat16):
@@ -95,8 +203,7 @@ class Marlin24Compressor(BaseCompressor):
             scale_packed = codec.marlin24_pack_scales(scale2d.to(torch.float16), single=not is_group)
         meta = meta.reshape(-1).reshape(meta.shape[1] // 2, meta.shape[0] * 2)
         if bad is not None and int(bad.item()):  # one host read, as the reference pipeline's structure check
-            raise ValueError("Marlin24 Compressor is only compatible with weights that have a 2:4 sparsity structure. "
-                             "Found segments in weight that do not match the expected structure.")
+            raise ValueError(_STRUCTURE_ERROR)
 
         state_dict["weight_packed"] = packed
         state_dict["scale_packed"] = scale_packed

@@ -7,6 +7,9 @@
 // oracle, which in turn is pinned against the surviving reference primitives.
 #include "ct_common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace ct {
 
 // destination linear offset of meta element (r, c) (semi_structured_conversions.py:33-60)
@@ -505,6 +508,231 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_kernel(const void* _
     }
 }
 
+// ---- lean int4 front end (round 2) --------------------------------------------------------------------------------
+// The packed-fp16 form above still spends ~21 VALU per element (1360 instructions per wave for 64 elements per lane) and the
+// fused kernel was VALU-bound: 49 us against a ~34 us traffic floor.  This form needs ~9 per element.  What changed:
+//   * no bf16 -> fp16 -> fp32 round trip and no per-element finiteness test: a bf16 weight with 2^-14 <= |x| <= 65280 IS its
+//     own fp16 image, and with a scale >= 2^-12 anything smaller quantizes to code 0 either way (|x / s| <= 1/4).  The one
+//     range / inf / NaN test for all 16 elements is a sum of squares kept by v_dot2c_f32_bf16 (one instruction per element
+//     PAIR, straight from the raw dword): sum <= 65280^2 implies every |x| <= 65280, and inf / NaN propagate.  A lane that
+//     fails the test (or has a scale outside [2^-12, 2^15], or a non-zero zero point) redoes its word in the exact form;
+//   * bf16 weight AND bf16 scale: the quotient of two 8-bit significands is never within 2^-20 (relative) of an fp16
+//     rounding boundary, so fp16(x * fl(1/s)) == fp16(fl(x/s)) without the Newton step (checked over all 3840 x 3457
+//     in-range pairs on the CPU and by ct_selftest_m24_div on the device); fp16 weights or scales keep the proven
+//     reciprocal + Newton form (ct_selftest_f16_div).  Multiplies and FMAs are the packed fp32 instructions;
+//   * the magic-number rounding adds 1544 = 1536 + 8, so the low byte of each half is the UNSIGNED nibble c + 8 the marlin
+//     word wants (the packing phase no longer sign-extends and re-biases), and a zero code is the byte 8;
+//   * the 2:4 selection runs on all four quads of a metadata word together: per quad one v_dot4_u32_u8 of the non-zero
+//     flags with the weights (9, 10, 8, 12) returns 16 * (idx + 8 * count) — table index and violation count in one
+//     number —, the four 3-bit indices go through v_perm_b32 used as an 8-entry byte table (twice: the positions of the
+//     first and the second kept element), and two more v_perm_b32 per quad pick the kept codes.
+template <bool HI>
+__host__ __device__ constexpr uint64_t quad_position_table() {  // byte idx = position (0..3) of the first / second kept element
+    uint64_t t = 0;
+    for (int idx = 0; idx < 8; ++idx) {
+        const bool m0 = idx & 1, m1 = (idx >> 1) & 1, m3 = (idx >> 2) & 1;
+        const bool e0 = m0 && m1, e1 = !m0 && m1, e2 = !m0 && !m1;
+        const uint32_t bit0 = e1, bit1 = e2, bit2 = e0 || e2 || m3, bit3 = e1 || !m1;
+        const uint64_t pos = HI ? (bit2 | (bit3 << 1)) : (bit0 | (bit1 << 1));
+        t |= pos << (8 * idx);
+    }
+    return t;
+}
+
+__device__ __forceinline__ float m24_sumsq(uint32_t d, float acc, std::integral_constant<int, CT_BF16>) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, d), __builtin_bit_cast(b2, d), acc, false);
+}
+__device__ __forceinline__ float m24_sumsq(uint32_t d, float acc, std::integral_constant<int, CT_F16>) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, d), __builtin_bit_cast(h2_t, d), acc, false);
+}
+
+// 16 elements -> 8 kept codes as unsigned nibbles-in-bytes (c + 8), the 16-bit metadata word, 16 * (8 * count) folded into
+// vmax, the sum of squares of the inputs.  No zero point.
+template <int XDT, bool NEWTON>
+__device__ __forceinline__ void marlin24_word_lean(const uint32_t (&ws)[8], float s16, float rs, u32x2& codes, uint32_t& word, uint32_t& vmax, float& sumsq) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 rs2 = {rs, rs}, s2 = {s16, s16};
+    const h2_t lo2 = {(_Float16)-8.0f, (_Float16)-8.0f}, hi2 = {(_Float16)7.0f, (_Float16)7.0f};
+    const h2_t magic = {(_Float16)1544.0f, (_Float16)1544.0f};
+    uint32_t P[4], R[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t u[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t d = ws[2 * q + h];
+            sumsq = m24_sumsq(d, sumsq, std::integral_constant<int, XDT>{});
+            f2 x;
+            if constexpr (XDT == CT_BF16) x = f2{bits_f(d << 16), bits_f(d & 0xffff0000u)};
+            else x = __builtin_convertvector(__builtin_bit_cast(h2_t, d), f2);
+            f2 t = x * rs2;
+            if constexpr (NEWTON) t = __builtin_elementwise_fma(__builtin_elementwise_fma(-t, s2, x), rs2, t);
+            h2_t t16 = __builtin_convertvector(t, h2_t);  // fp16(x16 / s16), RNE
+            t16 = __builtin_elementwise_min(__builtin_elementwise_max(t16, lo2), hi2) + magic;
+            u[h] = __builtin_bit_cast(uint32_t, t16);
+        }
+        P[q] = __builtin_amdgcn_perm(u[1], u[0], 0x06040200u);  // byte j = c_j + 8
+        const uint32_t nz = ((P[q] ^ 0x08080808u) + 0x0f0f0f0fu) & 0x10101010u;
+        R[q] = __builtin_amdgcn_udot4(nz, 0x0c080a09u, 0u, false);  // 16 * (m0 + 2 m1 + 4 m3 + 8 * count)
+    }
+    const uint32_t r01 = R[0] > R[1] ? R[0] : R[1], r23 = R[2] > R[3] ? R[2] : R[3];
+    vmax = vmax > r01 ? vmax : r01;
+    vmax = vmax > r23 ? vmax : r23;
+    const uint32_t idx4 = ((R[0] >> 4) & 7u) | (((R[1] >> 4) & 7u) << 8) | (((R[2] >> 4) & 7u) << 16) | (((R[3] >> 4) & 7u) << 24);
+    constexpr uint64_t kLo = quad_position_table<false>(), kHi = quad_position_table<true>();
+    const uint32_t lo4 = __builtin_amdgcn_perm((uint32_t)(kLo >> 32), (uint32_t)kLo, idx4);  // first kept position of each quad
+    const uint32_t hi4 = __builtin_amdgcn_perm((uint32_t)(kHi >> 32), (uint32_t)kHi, idx4);  // second kept position
+    uint32_t two[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t sel = __builtin_amdgcn_perm(hi4, lo4, 0x0c0c0000u | ((4u + q) << 8) | (uint32_t)q);
+        two[q] = __builtin_amdgcn_perm(0u, P[q], sel);  // bytes 0, 1 = the kept codes (bytes 2, 3: don't care)
+    }
+    codes = u32x2{__builtin_amdgcn_perm(two[1], two[0], 0x05040100u), __builtin_amdgcn_perm(two[3], two[2], 0x05040100u)};
+    const uint32_t qc4 = (hi4 << 2) | lo4;  // one 4-bit quad code per byte
+    const uint32_t w = qc4 | __builtin_amdgcn_alignbit(qc4, qc4, 4);
+    word = __builtin_amdgcn_perm(0u, w, 0x0c0c0200u);
+}
+
+// the lean scale range: see above (2^-12 keeps sub-fp16-normal weights at code 0)
+__device__ __forceinline__ float m24_lean_rcp(float s16) {
+    const float as = __builtin_fabsf(s16);
+    return ((as >= 0x1p-12f) && (as <= 0x1p15f)) ? 1.0f / s16 : 0.0f;
+}
+template <int XDT> struct m24_limit;  // largest sum of 16 squares that proves every element is an in-range finite value
+template <> struct m24_limit<CT_BF16> { static constexpr float v = 65280.0f * 65280.0f; };
+template <> struct m24_limit<CT_F16> { static constexpr float v = 16.0f * 65504.0f * 65504.0f; };
+
+template <int XDT, int SDT>
+__global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const uint16_t* __restrict__ w, const uint16_t* __restrict__ scale,
+                                                                        const int8_t* __restrict__ zp, int64_t m, int64_t k, int64_t cdiv,
+                                                                        int64_t scale_cols, int32_t* __restrict__ packed, uint16_t* __restrict__ meta,
+                                                                        int* __restrict__ bad, uint16_t* __restrict__ scale_packed, int scale_single) {
+    constexpr bool NEWTON = !(XDT == CT_BF16 && SDT == CT_BF16);
+    __shared__ __attribute__((aligned(16))) uint16_t s_meta[8][128];
+    __shared__ __attribute__((aligned(16))) uint8_t s_code[64][128 + 8];  // +8: rows start on different banks
+    const int tiles_c = (int)(k / 256);
+    const int tile_r = (int)(blockIdx.x / (unsigned)tiles_c), tile_c = (int)(blockIdx.x - (unsigned)tile_r * (unsigned)tiles_c);
+    const int tid = threadIdx.x;
+    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
+    const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
+    const uint32_t per = (uint32_t)(cdiv >> 4);
+    const bool per_pow2 = (per & (per - 1)) == 0;
+    const int per_shift = __builtin_ctz(per);
+    const int cl = tid & 15, rl0 = tid >> 4;
+    const uint32_t mc = (uint32_t)tile_c * 16u + (uint32_t)cl;
+    const uint32_t grp = per_pow2 ? (mc >> per_shift) : (mc / per);
+    // position of this lane's metadata word inside its column pair's 256-byte run (meta_reorder_offset in local terms): the
+    // row permutation only involves the row inside its 64-row group, the column swap stays inside the column pair
+    int dr0 = (rl0 & 1) * 2 + ((rl0 & 7) >> 2) + ((rl0 & 3) >> 1) * 32 + (rl0 >> 3) * 4;
+    const int adj = (((dr0 & 1) == 0) && (cl & 1)) - (((dr0 & 1) == 1) && !(cl & 1));
+    const int mpos0 = (dr0 + adj) * 2 + ((cl - adj) & 1);
+    uint32_t vmax = 0;
+    bool violation = false;
+    // all 128 bytes of this lane's four words are requested before the first one is used
+    u32x4 wa[4], wb[4];
+    uint32_t sbits[4];
+    int zs[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int64_t r = (int64_t)tile_r * 64 + it * 16 + rl0;
+        const int64_t si = r * scale_cols + grp;
+        sbits[it] = scale[si];
+        zs[it] = zp != nullptr ? (int)zp[si] : 0;
+        const u32x4* in = reinterpret_cast<const u32x4*>(w + r * k + (int64_t)mc * 16);
+        wa[it] = in[0];
+        wb[it] = in[1];
+    }
+    uint32_t redo = 0;  // words the range test rejected
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int rl = it * 16 + rl0;  // (rl >> 3) advances by 2 per iteration -> the metadata row by 8
+        const uint32_t ws[8] = {wa[it].x, wa[it].y, wa[it].z, wa[it].w, wb[it].x, wb[it].y, wb[it].z, wb[it].w};
+        const float s16 = SDT == CT_F16 ? f16_bits_to_f(sbits[it]) : round_to<CT_F16>(bf16_bits_to_f(sbits[it]));  // scale.to(fp16)
+        const float rs = m24_lean_rcp(s16);
+        u32x2 codes;
+        uint32_t word;
+        float sumsq = 0.0f;
+        uint32_t vm = 0;
+        marlin24_word_lean<XDT, NEWTON>(ws, s16, rs, codes, word, vm, sumsq);
+        const bool special = !(sumsq <= m24_limit<XDT>::v) || rs == 0.0f || zs[it] != 0;
+        redo |= special ? (1u << it) : 0u;
+        vmax = (!special && vm > vmax) ? vm : vmax;
+        *reinterpret_cast<u32x2*>(&s_code[rl][cl * 8]) = codes;
+        s_meta[cl >> 1][mpos0 + it * 16] = (uint16_t)word;
+    }
+    if (redo != 0) {  // rare and divergent: the exact form (IEEE divide, torch's NaN / inf / zero-point behaviour), one copy, not unrolled
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            if (!((redo >> it) & 1u)) continue;
+            const int rl = it * 16 + rl0;
+            u32x2 c8;
+            uint32_t word;
+            violation |= marlin24_item<XDT>(w, scale, SDT, zp, CT_I8, (int64_t)tile_r * 64 + rl, (int64_t)mc, k, cdiv, scale_cols, -8.0f, 7.0f, c8, word);
+            *reinterpret_cast<u32x2*>(&s_code[rl][cl * 8]) = u32x2{(c8.x & 0x0f0f0f0fu) ^ 0x08080808u, (c8.y & 0x0f0f0f0fu) ^ 0x08080808u};  // int8 code c -> c + 8
+            s_meta[cl >> 1][mpos0 + it * 16] = (uint16_t)word;
+        }
+    }
+    if (violation || vmax >= 16u * 24u) atomicOr(bad, 1);  // a quad with three or more non-zero codes
+    __syncthreads();
+    {
+        const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
+        const int64_t pair_base = ((int64_t)tile_c * 8 + pair) * m * 2 + (int64_t)tile_r * 128;
+        stream_store8(meta + pair_base + chunk * 4, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
+    }
+    const uint8_t* sc = &s_code[0][0];
+    const int64_t wpr = m * 2;  // packed words per k-tile row (size_n * 16 * 4 / 32)
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int t = (tid >> 7) + 2 * it;  // k-tile inside the workgroup tile
+        uint32_t word = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) word |= (uint32_t)sc[src_off[e] + t * 16] << (4 * e);
+        packed[((int64_t)tile_c * 8 + t) * wpr + (int64_t)tile_r * 128 + (tid & 127)] = (int32_t)word;
+    }
+    // scale_packed (marlin24_pack_scales_kernel fused in): the 64 rows of this tile are one 64-entry row of the transposed
+    // (groups, size_n) matrix per group, permuted inside itself — a contiguous 128-byte run.  The tile that holds a group's
+    // first column writes it (groups of <= 256 columns: all of the tile's; wider groups / channel-wise: one tile in several).
+    if (scale_packed != nullptr) {
+        const int64_t col0 = (int64_t)tile_c * 256;
+        const int64_t g_first = (col0 + cdiv - 1) / cdiv;  // first group starting at or after col0
+        const int n_here = (int)(((col0 + 256 + cdiv - 1) / cdiv) - g_first);  // groups starting inside [col0, col0 + 256)
+        for (int e = tid; e < n_here * 64; e += kBlock) {
+            const int gi = e >> 6, j = e & 63;
+            const int pj = scale_single ? j : ((j & ~7) + (((j & 7) >> 1) | ((j & 1) << 2)));  // scale_perm: [0, 4, 1, 5, 2, 6, 3, 7] per 8
+            const int64_t g = g_first + gi;
+            const uint16_t v = scale[((int64_t)tile_r * 64 + pj) * scale_cols + g];
+            scale_packed[g * m + (int64_t)tile_r * 64 + j] = SDT == CT_BF16 ? (uint16_t)f_to_f16_bits(bf16_bits_to_f(v)) : v;
+        }
+    }
+}
+
+// exhaustive check of the lean quotients against the IEEE divide: mode 0 = fp16 x, any fp16 scale in the lean range, reciprocal + Newton;
+// mode 1 = bf16 x in the fp16-exact range, bf16 scale in the lean range, single multiply.  Same pass criterion as selftest_f16_div_kernel.
+__global__ __launch_bounds__(kBlock) void selftest_m24_div_kernel(int mode, uint32_t s_lo, uint32_t s_hi, unsigned long long* mismatches) {
+    unsigned long long local = 0;
+    for (uint32_t sb = s_lo + blockIdx.x; sb < s_hi; sb += gridDim.x) {
+        const float s = mode == 0 ? f16_bits_to_f(sb) : round_to<CT_F16>(bf16_bits_to_f(sb));
+        const float rs = m24_lean_rcp(s);
+        if (rs == 0.0f || (mode == 1 && s != bf16_bits_to_f(sb))) continue;
+        for (uint32_t xb = threadIdx.x; xb < 65536u; xb += kBlock) {
+            const float x = mode == 0 ? f16_bits_to_f(xb) : bf16_bits_to_f(xb);
+            if (!__builtin_isfinite(x) || (mode == 1 && __builtin_fabsf(x) > 65280.0f)) continue;  // the sum-of-squares test sends these to the exact form
+            const float x16 = round_to<CT_F16>(x);  // what the reference divides
+            float t = x * rs;
+            if (mode == 0) t = __builtin_fmaf(__builtin_fmaf(-t, s, x), rs, t);
+            const float a = round_to<CT_F16>(t), b = round_to<CT_F16>(x16 / s);
+            // the codes must agree everywhere; the fp16 values wherever either is at least 2^-13 (smaller ones all round to code 0)
+            const float ca = __builtin_rintf(__builtin_fminf(__builtin_fmaxf(a, -8.0f), 7.0f)), cb = __builtin_rintf(__builtin_fminf(__builtin_fmaxf(b, -8.0f), 7.0f));
+            // (a bf16 weight below 2^-14 is not its own fp16 image: there only the code — always 0, |x / s| <= 1/4 — is compared)
+            const bool tiny = (__builtin_fabsf(a) < 0x1p-13f && __builtin_fabsf(b) < 0x1p-13f) || (mode == 1 && __builtin_fabsf(x) < 0x1p-14f);
+            local += (ca != cb || (a != b && !tiny)) ? 1ull : 0ull;
+        }
+    }
+    if (local) atomicAdd(mismatches, local);
+}
+
 __device__ __forceinline__ int load_code(const void* q, int dt, int64_t i, int add) {
     switch (dt) {
         case CT_I32: return static_cast<const int32_t*>(q)[i] + add;
@@ -637,8 +865,11 @@ int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sd
     CT_LAUNCH_CHECK("ct_marlin24_quant_compress");
 }
 
-int ct_marlin24_compress_w4(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
-                            int32_t* packed, int16_t* meta, int* bad, ct_stream_t stream) {
+// returns CT_OK + 1 when the launch also wrote scale_packed
+static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                                     int32_t* packed, int16_t* meta, int* bad, bool clear_bad, void* scale_packed, int scale_single, bool* fused_scales,
+                                     ct_stream_t stream) {
+    if (fused_scales) *fused_scales = false;
     CT_REQUIRE(wdt == CT_F16 || wdt == CT_BF16, "marlin-24 weights must be 16-bit floats, got dtype %d", wdt);
     CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
     CT_REQUIRE(m >= 0 && k >= 0 && m % 64 == 0 && k % 256 == 0, "the fused marlin-24 path needs rows %% 64 == 0 and cols %% 256 == 0, got (%lld, %lld)",
@@ -647,18 +878,66 @@ int ct_marlin24_compress_w4(const void* w, int wdt, const void* scale, int sdt, 
     CT_REQUIRE(aligned16(w) && (reinterpret_cast<uintptr_t>(meta) & 7u) == 0 && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && bad != nullptr,
                "misaligned buffers");
     CT_REQUIRE((m / 64) * (k / 256) < ((int64_t)1 << 31), "tensor too large for one launch");
-    hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
-    if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4 memset");
+    if (clear_bad) {
+        hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
+        if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4 memset");
+    }
     if (m == 0 || k == 0) return CT_OK;
     const int64_t c = cdiv > k ? k : cdiv;
     const unsigned tg = (unsigned)((m / 64) * (k / 256));
-    if (wdt == CT_BF16)
+    const bool lean = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8) && std::getenv("CT_MARLIN24_LEGACY") == nullptr;
+    if (lean) {
+#define CT_M24_LEAN(X, S)                                                                                                                      \
+    hipLaunchKernelGGL((marlin24_fused_w4_lean_kernel<X, S>), dim3(tg), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(w), \
+                       static_cast<const uint16_t*>(scale), static_cast<const int8_t*>(zp), m, k, c, k / c, packed, reinterpret_cast<uint16_t*>(meta), bad, \
+                       static_cast<uint16_t*>(scale_packed), scale_single)
+        if (wdt == CT_BF16 && sdt == CT_BF16) CT_M24_LEAN(CT_BF16, CT_BF16);
+        else if (wdt == CT_BF16) CT_M24_LEAN(CT_BF16, CT_F16);
+        else if (sdt == CT_BF16) CT_M24_LEAN(CT_F16, CT_BF16);
+        else CT_M24_LEAN(CT_F16, CT_F16);
+#undef CT_M24_LEAN
+        if (fused_scales) *fused_scales = scale_packed != nullptr;
+    } else if (wdt == CT_BF16)
         hipLaunchKernelGGL((marlin24_fused_w4_kernel<CT_BF16>), dim3(tg), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, k / c, packed,
                            reinterpret_cast<uint16_t*>(meta), bad);
     else
         hipLaunchKernelGGL((marlin24_fused_w4_kernel<CT_F16>), dim3(tg), dim3(kBlock), 0, as_stream(stream), w, scale, sdt, zp, zdt, m, k, c, k / c, packed,
                            reinterpret_cast<uint16_t*>(meta), bad);
     CT_LAUNCH_CHECK("ct_marlin24_compress_w4");
+}
+
+int ct_marlin24_compress_w4(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                            int32_t* packed, int16_t* meta, int* bad, ct_stream_t stream) {
+    return marlin24_compress_w4_impl(w, wdt, scale, sdt, zp, zdt, m, k, cdiv, packed, meta, bad, true, nullptr, 0, nullptr, stream);
+}
+
+int ct_marlin24_compress_w4_full(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                                 int group_perm, int32_t* packed, int16_t* meta, void* scale_packed, int* bad, int clear_bad, ct_stream_t stream) {
+    CT_REQUIRE(sdt == CT_F16 || sdt == CT_BF16, "marlin-24 scales must be 16-bit floats, got dtype %d", sdt);
+    CT_REQUIRE(scale_packed != nullptr, "scale_packed is NULL");
+    bool fused = false;
+    const int rc = marlin24_compress_w4_impl(w, wdt, scale, sdt, zp, zdt, m, k, cdiv, packed, meta, bad, clear_bad != 0, scale_packed, group_perm ? 0 : 1, &fused, stream);
+    if (rc != CT_OK || m == 0 || k == 0 || fused) return rc;
+    const int64_t c = cdiv > k ? k : cdiv;
+    const int64_t groups = k / c;
+    CT_REQUIRE((m * groups) % 64 == 0, "scale count must be a multiple of 64");
+    if (sdt == CT_BF16)
+        hipLaunchKernelGGL(marlin24_pack_scales_kernel<true>, dim3(grid_1d(m * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale), m,
+                           groups, group_perm ? 0 : 1, static_cast<uint16_t*>(scale_packed));
+    else
+        hipLaunchKernelGGL(marlin24_pack_scales_kernel<false>, dim3(grid_1d(m * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale), m,
+                           groups, group_perm ? 0 : 1, static_cast<uint16_t*>(scale_packed));
+    CT_LAUNCH_CHECK("ct_marlin24_compress_w4_full");
+}
+
+int ct_selftest_m24_div(int mode, uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {
+    CT_REQUIRE((mode == 0 || mode == 1) && s_lo_bits <= s_hi_bits && s_hi_bits <= 65536u, "bad mode / scale bit range");
+    hipError_t e = hipMemsetAsync(mismatches, 0, sizeof(unsigned long long), as_stream(stream));
+    if (e != hipSuccess) return hip_check(e, "ct_selftest_m24_div memset");
+    if (s_lo_bits == s_hi_bits) return CT_OK;
+    const unsigned n = s_hi_bits - s_lo_bits;
+    hipLaunchKernelGGL(selftest_m24_div_kernel, dim3(n < 4096 ? n : 4096), dim3(kBlock), 0, as_stream(stream), mode, s_lo_bits, s_hi_bits, mismatches);
+    CT_LAUNCH_CHECK("ct_selftest_m24_div");
 }
 
 int ct_selftest_f16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {

@@ -314,6 +314,13 @@ int ct_marlin24_compress_w4(const void* w, int wdt, const void* scale, int sdt, 
 int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
                                int64_t m, int64_t k, int64_t cdiv, int bits, int8_t* comp, int16_t* meta,
                                int* bad, ct_stream_t stream);
+/* the whole restated Marlin24Compressor.compress for int4 in one host call: ct_marlin24_compress_w4 followed by
+ * ct_marlin24_pack_scales_f16 (scale (m, k/cdiv) bf16 / fp16 -> scale_packed fp16 (k/cdiv, m); group_perm != 0 selects
+ * scale_perm, 0 scale_perm_single).  clear_bad == 0 leaves *bad alone (the violation is OR-ed in): the caller owns a
+ * pre-zeroed flag, e.g. one slot of a ring that is read back once per batch instead of once per tensor. */
+int ct_marlin24_compress_w4_full(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
+                                 int64_t m, int64_t k, int64_t cdiv, int group_perm, int32_t* packed, int16_t* meta,
+                                 void* scale_packed, int* bad, int clear_bad, ct_stream_t stream);
 
 /* marlin-24 weight packing (historical Marlin24Compressor.pack_weight_24 with the table of
  * utils/permutations_24.py:20-45).  q: codes of dtype dt (CT_I32 / CT_I8 / float holding
@@ -340,6 +347,10 @@ int ct_selftest_f16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long lo
                         ct_stream_t stream);
 int ct_selftest_bf16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
                          ct_stream_t stream);
+/* the quotients of the lean marlin-24 front end (ct_marlin24_compress_w4): mode 0 = fp16 x / fp16 scale by reciprocal +
+ * Newton step, mode 1 = bf16 x / bf16 scale by ONE multiply with the reciprocal; s bits in [s_lo_bits, s_hi_bits) */
+int ct_selftest_m24_div(int mode, uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
+                        ct_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1118,6 +1118,89 @@ def test_marlin24_front_end_special_values(cta, dev, wdt, bits):
                 assert torch.equal(comp.cpu().float(), torch.nan_to_num(comp_ref.cpu().float(), nan=0.0)) and torch.equal(meta.cpu(), meta_ref.cpu()), (case, int(z[0, 0]))
 
 
+@pytest.mark.parametrize("sdt", [BF16, F16])
+@pytest.mark.parametrize("wdt", [BF16, F16])
+def test_marlin24_lean_w4_special_values(cta, dev, wdt, sdt):
+    """the one-launch int4 kernel (lean front end: raw bf16 -> fp32, sum-of-squares range test, packed fp32 quotient, one multiply
+    for bf16 / bf16, dot4 + v_perm table selection) against the unfused chain it replaces (ct_marlin24_quant_compress, pinned
+    above, + ct_marlin24_pack_weights): every 16-bit weight pattern in the kept slots (inf, NaN, huge, sub-fp16-normal, ties),
+    scales inside, at both ends of and outside the lean range [2^-12, 2^15], a zero / non-zero / absent zero point"""
+    g = torch.Generator().manual_seed(23)
+    rows, cols = 128, 1024
+    allv = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(wdt)
+    w = torch.zeros((rows, cols), dtype=wdt)
+    w.view(-1, 4)[:, 0] = allv[: rows * cols // 4]
+    w.view(-1, 4)[:, 3] = allv[rows * cols // 4: rows * cols // 2]
+    ties = (torch.arange(-18, 18, dtype=torch.float32) + 0.5)
+    G = cols // 128
+    cases = {"mid": lambda: torch.rand((rows, G), generator=g) * 0.2 + 0.01, "ones": lambda: torch.full((rows, G), 1.0),
+             "2^-12": lambda: torch.full((rows, G), 2.0 ** -12), "2^-13": lambda: torch.full((rows, G), 2.0 ** -13),
+             "2^-14": lambda: torch.full((rows, G), 2.0 ** -14), "2^15": lambda: torch.full((rows, G), 2.0 ** 15),
+             "1.5*2^15": lambda: torch.full((rows, G), 1.5 * 2.0 ** 15), "negative": lambda: -(torch.rand((rows, G), generator=g) + 0.5),
+             "mixed": lambda: torch.where(torch.rand((rows, G), generator=g) < 0.5, torch.full((rows, G), 2.0 ** -13), torch.full((rows, G), 0.37))}
+    if sdt == F16:
+        cases["subnormal"] = lambda: torch.full((rows, G), 2.0 ** -20)
+    else:
+        cases["huge"] = lambda: torch.full((rows, G), 2.0 ** 40)   # bf16 scale whose fp16 image is inf
+        cases["vanishing"] = lambda: torch.full((rows, G), 2.0 ** -40)  # ... is zero
+    for case, smaker in cases.items():
+        s = smaker().to(sdt)
+        ww = w.clone()
+        if case == "ones":
+            ww.view(-1, 4)[: ties.numel(), 1] = ties.to(wdt)
+            ww.view(-1, 4)[: ties.numel(), 0] = 0
+            ww.view(-1, 4)[: ties.numel(), 3] = 0
+        zmix = torch.zeros(s.shape, dtype=torch.int8)
+        zmix[::3, 1::2] = 2
+        for z in (torch.zeros(s.shape, dtype=torch.int8), None, zmix):
+            packed, meta, bad = cta.codec.marlin24_compress_w4(d(ww, dev), d(s, dev), d(z, dev), group_size=128)
+            comp, meta_ref, bad_ref = cta.codec.marlin24_quant_compress(d(ww, dev), d(s, dev), d(z, dev), num_bits=4, group_size=128)
+            packed_ref = cta.codec.marlin24_pack_weights(comp, 4, transposed=True, add_offset=True)
+            tag = (case, None if z is None else int(z.abs().sum() > 0))
+            assert bool(bad.item()) == bool(bad_ref.item()), tag
+            if not bool(bad_ref.item()):
+                assert torch.equal(meta.cpu(), meta_ref.cpu()), tag
+                assert torch.equal(packed.cpu(), packed_ref.cpu()), tag
+
+
+def test_marlin24_lean_quotients_are_exact(cta):
+    """ct_selftest_m24_div: fp16 / fp16 by reciprocal + Newton step and bf16 / bf16 by ONE multiply give the fp16 rounding of
+    the IEEE quotient for every scale in the lean range x all 65536 weights"""
+    assert cta.codec.selftest_m24_div(0) == 0
+    assert cta.codec.selftest_m24_div(1) == 0
+
+
+def test_marlin24_deferred_structure_check(cta, dev):
+    """inside `deferred_structure_check()` compress only queues work; ONE ValueError at the exit reports any non-2:4 weight of the
+    batch, the flag ring is clean afterwards, and outside the context the error is raised by the call itself (as upstream)"""
+    M = cta.Marlin24Compressor
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True))
+
+    def sd(sparse, seed):
+        g = torch.Generator().manual_seed(seed)
+        w = torch.randn((64, 512), generator=g).to(BF16)
+        if sparse:
+            w = w * O.sparse24_mask(w).to(w.dtype)
+        scale, zp = O.calculate_qparams_minmax(w.to(F16), num_bits=4, group_size=128, symmetric=True)
+        return {"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}
+
+    good = [sd(True, i) for i in range(3)]
+    with M.deferred_structure_check():
+        outs = [M.compress(x, scheme) for x in good]
+    with pytest.raises(ValueError, match="2:4 sparsity structure"):
+        with M.deferred_structure_check():
+            M.compress(good[0], scheme)
+            M.compress(sd(False, 9), scheme)  # no exception here ...
+            late = M.compress(good[1], scheme)  # ... and later calls still run
+    assert torch.equal(late["weight_packed"], outs[1]["weight_packed"])
+    with M.deferred_structure_check():  # the ring was released: a clean batch passes again
+        again = M.compress(good[2], scheme)
+    assert torch.equal(again["weight_packed"], outs[2]["weight_packed"]) and torch.equal(again["meta"], outs[2]["meta"])
+    with pytest.raises(ValueError, match="2:4 sparsity structure"):
+        M.compress(sd(False, 10), scheme)
+    M.compress(good[0], scheme)
+
+
 # ----------------------------------------------------------------------------- qparams of the FLOAT schemes
 from test_oracle_golden import _qpf_kind  # noqa: E402
 
