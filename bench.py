@@ -636,6 +636,72 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
             "round_trip_equals_fake_quantize": bool(torch.equal(o0, fq))}
 
 
+def tinyllama_w8_leg(dev):
+    """the same TinyLlama-1.1B-shaped checkpoint as W8A8 (int8 weights, channel-wise scales — IntQuantizationCompressor — and
+    float8_e4m3fn — FloatQuantizationCompressor): ONE ct_q8_quant_batch + ONE ct_q8_dequant_batch launch for all 154 modules
+    against one launch per module; 3 B per element and direction"""
+    from compressed_tensors_amd import _lib, codec
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    BF16 = _lib.BF16
+    mods = [(r, c) for _ in range(22) for (_, r, c) in TINYLLAMA_LAYER]
+    g = torch.Generator(device=dev).manual_seed(77)
+    keep = []
+    for r, c in mods:
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        scale, zp = codec.minmax_qparams(w, num_bits=8, group_size=None, symmetric=True)
+        keep.append((w, scale, zp, torch.empty(r, c, dtype=torch.int8, device=dev), torch.empty_like(w)))
+    total = sum(2 * (3 * r * c + 2 * r) for r, c in mods)
+    out = {"workload": "TinyLlama-1.1B-shaped checkpoint (154 Linear modules), W8A8 channel-wise quantize + dequantize, one launch per direction",
+           "alg_bytes": total}
+
+    def timed(fn):
+        fn()
+        best = None
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+
+    for kind, qdt, code in (("int8", torch.int8, _lib.I8), ("fp8", torch.float8_e4m3fn, _lib.F8)):
+        qs = [q.view(qdt) for (_, _, _, q, _) in keep]
+        zps = [None if kind == "fp8" else z for (_, _, z, _, _) in keep]
+        cb = codec.W4Batch([(w, s, z, q, w.shape[0], w.shape[1], w.shape[1]) for (w, s, _, _, _), q, z in zip(keep, qs, zps)], "compress", torch.bfloat16,
+                           kind=kind, bits=8)
+        db = codec.W4Batch([(q, s, z, o, w.shape[0], w.shape[1], w.shape[1]) for (w, s, _, _, o), q, z in zip(keep, qs, zps)], "decompress", torch.bfloat16,
+                           kind=kind)
+
+        def batched():
+            cb.launch(stream)
+            db.launch(stream)
+
+        def per_module():
+            for (w, s, _, _, o), q, z in zip(keep, qs, zps):
+                r, c = w.shape
+                zp_, zdt = (None, -1) if z is None else (z.data_ptr(), _lib.I8)
+                if kind == "fp8":
+                    lib.ct_quantize_fp8(w.data_ptr(), BF16, s.data_ptr(), BF16, zp_, zdt, r, c, 1, c, 1, None, BF16, q.data_ptr(), code, stream)
+                else:
+                    lib.ct_quantize(w.data_ptr(), BF16, s.data_ptr(), BF16, zp_, zdt, r, c, 1, c, 1, None, 8, BF16, q.data_ptr(), code, stream)
+                lib.ct_dequantize(q.data_ptr(), code, s.data_ptr(), BF16, zp_, zdt, r, c, 1, c, 1, None, o.data_ptr(), BF16, stream)
+
+        t_loop = timed(per_module)
+        ref = [(q.clone(), o.clone()) for (_, _, _, _, o), q in zip(keep[:3], qs)]
+        for (_, _, _, q, o) in keep:
+            q.zero_(); o.zero_()
+        t_b = timed(batched)
+        same = all(torch.equal(q.view(torch.uint8), rq.view(torch.uint8)) and torch.equal(o.view(torch.int16), ro.view(torch.int16))
+                   for (_, _, _, _, o), q, (rq, ro) in zip(keep[:3], qs, ref))
+        out[kind] = {"ms_whole_checkpoint": round(t_b * 1e3, 4), "GBps": round(total / t_b / 1e9, 1), "frac_of_hbm_peak": round(total / t_b / 1e9 / HBM_PEAK_GBPS, 4),
+                     "ms_one_launch_per_module": round(t_loop * 1e3, 4), "batch_equals_per_module": bool(same)}
+    return out
+
+
 def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters=20):
     """SURVEY 8e for the single-tensor configs: ONE 8192x8192 tensor split by row blocks (`shard_rows`, multiples of 64
     rows) over the ranks — strong scaling, no data-path collective.  Config 2 (W4A16 compress + decompress of the rank's
@@ -868,7 +934,7 @@ def main():
             del sets
             torch.cuda.empty_cache()
             for key, leg in (("kernels_other", w4_variants_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
-                             ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg)):
+                             ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg), ("tinyllama_w8a8", tinyllama_w8_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down

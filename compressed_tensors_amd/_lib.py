@@ -60,6 +60,9 @@ _PROTOTYPES = {
     "ct_w4_batch_plan": ([_P, _I, _I], _L),
     "ct_quant_pack_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
+    "ct_q8_batch_plan": ([_P, _I, _I], _L),
+    "ct_q8_quant_batch": ([_P, _I, _L, _I, _I, _I, _S], _I),
+    "ct_q8_dequant_batch": ([_P, _I, _L, _I, _I, _S], _I),
     "ct_fp4_quant_pack": ([_P, _I, _P, _I, _P, _L, _L, _L, _P, _S], _I),
     "ct_fp4_unpack_dequant": ([_P, _L, _L, _P, _I, _I, _P, _L, _P, _I, _S], _I),
     "ct_rtn_mxfp4_quant_pack": ([_P, _I, _L, _L, _P, _P, _P, _S], _I),

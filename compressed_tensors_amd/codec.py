@@ -33,6 +33,7 @@ __all__ = [
     "unpack_bitmasks",
     "W4Batch",
     "w4_batch_eligible",
+    "q8_batch_group",
     "cast_to_fp4",
     "pack_fp4_to_uint8",
     "unpack_fp4_from_uint8",
@@ -617,15 +618,18 @@ def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, str
 
 
 class W4Batch:
-    """A table of W4A16 tensors processed by ONE kernel launch per direction — the per-module loop
-    of ModelCompressor without a launch (and a ~5 us host call) per module.
+    """A table of tensors processed by ONE kernel launch per direction — the per-module loop of ModelCompressor without a
+    launch (and a ~5 us host call) per module.
 
-    entries: (src, scale, zero_point or None, dst, rows, cols, group) with src / dst the weight and
-    the packed words in the order the direction needs ("compress": weight -> packed)."""
+    entries: (src, scale, zero_point or None, dst, rows, cols, group) with src / dst in the order the direction needs
+    ("compress": weight -> codes).  kind "w4": W4A16 pack-quantized (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`,
+    dst / src = packed int32 words); kind "int8" / "fp8": the 8-bit codecs (`ct_q8_quant_batch` / `ct_q8_dequant_batch`, one
+    byte per element, `bits` = the INT scheme's num_bits; group may be rows * cols for a per-tensor scale)."""
 
-    def __init__(self, entries, direction: str, dtype: torch.dtype):
-        assert direction in ("compress", "decompress")
+    def __init__(self, entries, direction: str, dtype: torch.dtype, kind: str = "w4", bits: int = 8):
+        assert direction in ("compress", "decompress") and kind in ("w4", "int8", "fp8")
         self.direction = 0 if direction == "compress" else 1
+        self.kind, self.bits = kind, int(bits)
         self.dt = DT[dtype]
         self.keep = list(entries)  # the table holds raw pointers: keep the tensors alive
         n = len(self.keep)
@@ -639,7 +643,8 @@ class W4Batch:
             it.rows, it.cols, it.group = int(rows), int(cols), int(group)
         import ctypes
 
-        self.blocks = int(_lib.load().ct_w4_batch_plan(ctypes.cast(arr, ctypes.c_void_p), n, self.direction)) if n else 0
+        plan = _lib.load().ct_w4_batch_plan if kind == "w4" else _lib.load().ct_q8_batch_plan
+        self.blocks = int(plan(ctypes.cast(arr, ctypes.c_void_p), n, self.direction)) if n else 0
         if self.blocks < 0:
             raise ValueError(_lib.last_error())
         self.device = dev
@@ -654,8 +659,43 @@ class W4Batch:
         if not self.n:
             return
         s = _lib.stream_on(self.device, stream)
-        name = "ct_quant_pack_batch" if self.direction == 0 else "ct_unpack_dequant_batch"
-        call(name, self.table.data_ptr(), self.n, self.blocks, self.dt, s)
+        if self.kind == "w4":
+            call("ct_quant_pack_batch" if self.direction == 0 else "ct_unpack_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, s)
+        elif self.direction == 0:
+            call("ct_q8_quant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), self.bits, s)
+        else:
+            call("ct_q8_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), s)
+
+
+def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, group_size=None, g_idx=None):
+    """Elements per scale (the table's `group`) if this tensor can join a one-launch 8-bit batch, else None.  2-D, 16-bit
+    float dtype equal to the scale's, tensor / channel / group scales (strategy given, or inferred from the scale's shape like
+    `dequantize` does, forward.py:99-130), cols % 16 == 0, group % 16 == 0, int8 or absent zero point of the scale's shape,
+    everything contiguous, 16-byte aligned and on `device`."""
+    if g_idx is not None or len(shape) != 2 or w_dtype not in (torch.bfloat16, torch.float16):
+        return None
+    if scale is None or scale.dtype != w_dtype or scale.device != device or not scale.is_contiguous() or not _aligned16(scale):
+        return None
+    rows, cols = int(shape[0]), int(shape[1])
+    if rows <= 0 or cols % 16:
+        return None
+    st = _strategy_name(strategy)
+    if scale.numel() == 1 and scale.dim() <= 1 and st in (None, "tensor"):
+        group = rows * cols
+    elif scale.dim() == 2 and scale.shape[0] == rows and scale.shape[1] == 1 and st in (None, "channel"):
+        group = cols
+    elif scale.dim() == 2 and scale.shape[0] == rows and scale.shape[1] > 1 and cols % scale.shape[1] == 0 and st in (None, "group"):
+        group = cols // scale.shape[1]
+        if st == "group" and group_size and int(group_size) != group:
+            return None
+    else:
+        return None
+    if group % 16:
+        return None
+    if zero_point is not None and (zero_point.dtype != torch.int8 or zero_point.shape != scale.shape or zero_point.device != device
+                                   or not zero_point.is_contiguous()):
+        return None
+    return group
 
 
 # --------------------------------------------------------------------------- bitmask codecs

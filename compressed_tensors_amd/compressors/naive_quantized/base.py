@@ -1,7 +1,14 @@
 """naive-quantized / int-quantized / float-quantized codecs
 (reference compressors/naive_quantized/base.py:27-164).  INT weights are quantized to int8 by
 the HIP quantize kernel and dequantized by the HIP dequantize kernel; FLOAT 8-bit weights become
-float8_e4m3fn through the same kernels (clamp to +-448, v_cvt_pk_fp8_f32)."""
+float8_e4m3fn through the same kernels (clamp to +-448, v_cvt_pk_fp8_f32).
+
+A list of modules / state dicts (`compress_modules`, `decompress_modules`, `decompress_many`: what ModelCompressor and the
+model-free converter call) goes through ONE launch per direction, device and dtype (`ct_q8_quant_batch` /
+`ct_q8_dequant_batch`) for every eligible tensor (16-bit weight and scale of one dtype, tensor / channel / group scales, int8 or no
+zero point); the rest, one by one.  The state dicts are identical to the per-module path's."""
+import torch
+
 from ... import codec
 from ...config import CompressionFormat
 from ...quantization.quant_args import enum_value
@@ -71,6 +78,118 @@ class NaiveQuantizationCompressor(BaseCompressor):
         g_idx = state_dict.get("weight_g_idx", None)
         state_dict["weight"] = codec.dequantize_tensor(weight, scale, zero_point, g_idx=g_idx)
         return state_dict
+
+    # ------------------------------------------------------------------ batched module paths
+    @classmethod
+    def _batch_compress(cls, state_dicts, schemes):
+        """quantized weights of every eligible state dict from one launch per (device, dtype, kind, bits); None for the others"""
+        outs, batches = [None] * len(state_dicts), {}
+        for i, (sd, scheme) in enumerate(zip(state_dicts, schemes)):
+            w, scale, zp = sd.get("weight"), sd.get("weight_scale"), sd.get("weight_zero_point")
+            wa = scheme.weights
+            qtype, st = enum_value(getattr(wa, "type", "int")), enum_value(wa.strategy)
+            if w is None or not w.is_cuda or not w.is_contiguous() or w.data_ptr() % 16 or st not in ("tensor", "channel", "group"):
+                continue
+            if qtype == "float" and (int(wa.num_bits) != 8 or zp is not None):
+                continue  # a zero point that is present adds (-0.0 -> +0.0) in the float8 path: per module
+            group = codec.q8_batch_group(w.shape, w.dtype, scale, zp, device=w.device, strategy=st, group_size=getattr(wa, "group_size", None),
+                                         g_idx=sd.get("weight_g_idx"))
+            if group is None:
+                continue
+            out = torch.empty(w.shape, dtype=wa.pytorch_dtype(), device=w.device)
+            if out.element_size() != 1:
+                continue
+            key = (w.device, w.dtype, "fp8" if qtype == "float" else "int8", int(wa.num_bits))
+            entries, slots = batches.setdefault(key, ([], []))
+            entries.append((w, scale, zp, out, w.shape[0], w.shape[1], group))
+            slots.append((i, out))
+        for (_, dtype, kind, bits), (entries, slots) in batches.items():
+            codec.W4Batch(entries, "compress", dtype, kind=kind, bits=bits).launch()
+            for i, out in slots:
+                outs[i] = out
+        return outs
+
+    @classmethod
+    def _batch_decompress(cls, state_dicts):
+        outs, batches = [None] * len(state_dicts), {}
+        for i, sd in enumerate(state_dicts):
+            q, scale, zp = sd.get("weight"), sd.get("weight_scale"), sd.get("weight_zero_point")
+            if q is None or scale is None or not q.is_cuda or not q.is_contiguous() or q.data_ptr() % 16 or q.dim() != 2:
+                continue
+            kind = "int8" if q.dtype == torch.int8 else "fp8" if q.dtype == torch.float8_e4m3fn else None
+            if kind is None or (kind == "fp8" and zp is not None):
+                continue
+            group = codec.q8_batch_group(q.shape, scale.dtype, scale, zp, device=q.device, g_idx=sd.get("weight_g_idx"))
+            if group is None:
+                continue
+            out = torch.empty(q.shape, dtype=scale.dtype, device=q.device)
+            entries, slots = batches.setdefault((q.device, scale.dtype, kind), ([], []))
+            entries.append((q, scale, zp, out, q.shape[0], q.shape[1], group))
+            slots.append((i, out))
+        for (_, dtype, kind), (entries, slots) in batches.items():
+            codec.W4Batch(entries, "decompress", dtype, kind=kind).launch()
+            for i, out in slots:
+                outs[i] = out
+        return outs
+
+    @classmethod
+    def _owns_codec(cls) -> bool:
+        """a subclass that overrides compress / decompress (mxfp8: scale conversion around them) keeps the per-module loop"""
+        base = NaiveQuantizationCompressor
+        return cls.compress.__func__ is base.compress.__func__ and cls.decompress.__func__ is base.decompress.__func__
+
+    @classmethod
+    def compress_modules(cls, modules) -> None:
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+
+        modules = list(modules)
+        if not cls._owns_codec():
+            return super().compress_modules(modules)
+        sds = [get_direct_state_dict(m) for m in modules]
+        pre = cls._batch_compress(sds, [m.quantization_scheme for m in modules])
+        for m, sd, q in zip(modules, sds, pre):
+            if q is None:
+                cls.compress_module(m)
+                continue
+            new = dict(sd)
+            new["weight"] = q
+            replace_direct_state_dict(m, cls._remove_symmetric_zp(new, m.quantization_scheme))
+            m.quantization_status = QuantizationStatus.COMPRESSED
+
+    @classmethod
+    def decompress_many(cls, state_dicts, scheme) -> list:
+        if not cls._owns_codec():
+            return super().decompress_many(state_dicts, scheme)
+        pre = cls._batch_decompress(state_dicts)
+        out = []
+        for sd, w in zip(state_dicts, pre):
+            if w is None:
+                out.append(cls.decompress(sd, scheme))
+            else:
+                new = dict(sd)
+                new["weight"] = w
+                out.append(new)
+        return out
+
+    @classmethod
+    def decompress_modules(cls, modules) -> None:
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+
+        modules = list(modules)
+        if not cls._owns_codec():
+            return super().decompress_modules(modules)
+        sds = [get_direct_state_dict(m) for m in modules]
+        pre = cls._batch_decompress(sds)
+        for m, sd, w in zip(modules, sds, pre):
+            if w is None:
+                cls.decompress_module(m)
+                continue
+            new = dict(sd)
+            new["weight"] = w
+            replace_direct_state_dict(m, new)
+            m.quantization_status = QuantizationStatus.DECOMPRESSED
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

@@ -138,6 +138,31 @@ __global__ __launch_bounds__(kBlock) void unpack_flat_kernel(const uint32_t* __r
     }
 }
 
+// flat 4-bit pack (contiguous rows, cols % 32 == 0): a lane owns HALF a pack group — 16 codes = one 16-byte load (1 KiB contiguous
+// per wave instruction; the lane-per-group kernel reads 32 B per lane as two lane-strided 16-byte loads, the shape that measured
+// 13 points lower in DESIGN.md 5.1) -> two words = one 8-byte streaming store.  Same wrapping adds as pack_insert, so
+// out-of-range int8 input stays bit-identical with the reference's scatter_add_.
+template <int UNROLL>
+__global__ __launch_bounds__(kBlock) void pack_flat4_kernel(const u32x4* __restrict__ q, int64_t items, u32x2* __restrict__ out) {
+    const int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x;
+    u32x4 r[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t it = base + (int64_t)i * kBlock;
+        if (it < items) r[i] = q[it];
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t it = base + (int64_t)i * kBlock;
+        if (it >= items) continue;
+        const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+        uint32_t w[2] = {0x88888888u, 0x88888888u};  // the +8 of every code
+#pragma unroll
+        for (int k = 0; k < 16; ++k) w[k >> 3] += (uint32_t)(int)(int8_t)(ws[k >> 2] >> (8 * (k & 3))) << (4 * (k & 7));
+        stream_store8(out + it, u32x2{w[0], w[1]});
+    }
+}
+
 // packed along rows: lane (g, c) packs rows [32g, 32g+32) of column c; lanes are consecutive
 // in c so every access is coalesced across the wave.
 template <int BITS>
@@ -227,6 +252,15 @@ int ct_pack_int32(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t
         hipLaunchKernelGGL((unpack_flat_kernel<8, U>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(q), items,
                            reinterpret_cast<u32x4*>(out));
         CT_LAUNCH_CHECK("ct_pack_int32[flat8]");
+    }
+    if (bits == 4 && cols % 32 == 0 && out_row_stride == packed_cols && aligned16(q) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0) {
+        constexpr int U = 2;
+        const int64_t items = rows * cols / 16;
+        const int64_t g = cdiv64(items, (int64_t)kBlock * U);
+        CT_REQUIRE(g < ((int64_t)1 << 31), "tensor too large for one launch");
+        hipLaunchKernelGGL((pack_flat4_kernel<U>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const u32x4*>(q), items,
+                           reinterpret_cast<u32x2*>(out));
+        CT_LAUNCH_CHECK("ct_pack_int32[flat4]");
     }
     const int vec = (cols % 16 == 0) && aligned16(q);
     dim3 grid = grid_rows(rows, cdiv64(cols, 32));

@@ -13,6 +13,8 @@
 #include "ct_quant_core.h"
 #include "ct_minmax.h"
 
+#include <cstdlib>
+
 namespace ct {
 
 // ------------------------------------------------------------------------------------------
@@ -180,6 +182,68 @@ __device__ __forceinline__ void round2(float& a, float& b) {
     }
 }
 
+// ---- fast-path predicates --------------------------------------------------------------------------------------
+// bf16: x * fl(1/s) == x / s after the rounding to bf16 for 2^-64 <= |s| <= 2^64 (ct_selftest_bf16_div).
+// fp16: reciprocal + one Newton step == the IEEE quotient after the rounding to fp16 for 2^-14 <= |s| <= 2^15 and every
+// FINITE x (ct_selftest_f16_div; quotients below 2^-13 may differ in the last subnormal place and all become code 0,
+// with or without an integer zero point) — the finiteness of a lane's 32 weights is one v_dot2c_f32_f16 per pair.
+template <int DT>
+__device__ __forceinline__ bool fast_scale_ok(float s) {
+    const float as = __builtin_fabsf(s);
+    if constexpr (DT == CT_BF16) return (as >= 0x1p-64f) && (as <= 0x1p64f);
+    else if constexpr (DT == CT_F16) return (as >= 0x1p-14f) && (as <= 0x1p15f);
+    else return false;
+}
+typedef _Float16 qh2_t __attribute__((ext_vector_type(2)));
+template <int DT, int Q>
+__device__ __forceinline__ bool fast_data_ok(const u32x4 (&r)[Q]) {
+    if constexpr (DT != CT_F16) return true;
+    else {
+        float acc = 0.0f;  // <= 32 * 65504^2 when everything is finite; inf / NaN propagate
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(qh2_t, ws[j]), __builtin_bit_cast(qh2_t, ws[j]), acc, false);
+        }
+        return acc <= 3.0e38f;
+    }
+}
+
+// fp16 weights, fast path: everything after the fp32 quotient works on fp16 PAIRS (derivation: ct_marlin24.hip) —
+// v_cvt_pk_f16_f32 is the rounding to T, the zero-point add is v_pk_add_f16 (the reference adds in fp16 too), clamp =
+// v_pk_max_f16 / v_pk_min_f16 (no NaN can reach it: fast_data_ok), round-half-even + integer cast + bias in ONE
+// v_pk_add_f16: for |t| <= 128, fl16(t + MAGIC) = MAGIC + rint(t) exactly (ulp = 1 there) and the low byte of each half is
+// the code plus MAGIC's low byte.  5.5 VALU per element instead of ~20 with the IEEE divide.
+// pairs[j] = 0x66cc66cc-style halves; returns them un-gathered
+template <bool ZP, int MAGIC>
+__device__ __forceinline__ void quant_pairs_f16(const u32x4& raw, float s, float rs, float z, float qmin, float qmax, uint32_t (&u)[4]) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 rs2 = {rs, rs}, s2 = {s, s};
+    const qh2_t lo2 = {(_Float16)qmin, (_Float16)qmin}, hi2 = {(_Float16)qmax, (_Float16)qmax};
+    const qh2_t magic = {(_Float16)(float)MAGIC, (_Float16)(float)MAGIC}, z2 = {(_Float16)z, (_Float16)z};
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f2 x = __builtin_convertvector(__builtin_bit_cast(qh2_t, ws[j]), f2);
+        f2 t = x * rs2;
+        t = __builtin_elementwise_fma(__builtin_elementwise_fma(-t, s2, x), rs2, t);
+        qh2_t t16 = __builtin_convertvector(t, qh2_t);
+        if (ZP) t16 = t16 + z2;
+        t16 = __builtin_elementwise_min(__builtin_elementwise_max(t16, lo2), hi2) + magic;
+        u[j] = __builtin_bit_cast(uint32_t, t16);
+    }
+}
+
+template <bool ZP>
+__device__ __forceinline__ uint32_t w4_quant_word_f16(const u32x4& raw, float s, float rs, float z) {
+    uint32_t u[4];
+    quant_pairs_f16<ZP, 1544>(raw, s, rs, z, -8.0f, 7.0f, u);  // 1544 = 1536 + 8: the low byte is the biased nibble
+    const uint32_t p0 = __builtin_amdgcn_perm(u[1], u[0], 0x06040200u), p1 = __builtin_amdgcn_perm(u[3], u[2], 0x06040200u);
+    const uint32_t a = p0 | __builtin_amdgcn_alignbit(p0, p0, 4), b = p1 | __builtin_amdgcn_alignbit(p1, p1, 4);
+    return __builtin_amdgcn_perm(b, a, 0x06040200u);  // bytes 0 / 2 of a and b: nibble pairs (0,1) (2,3) (4,5) (6,7)
+}
+
 // 8 weights (16 B) -> one packed word.  FAST: x * (1/s) instead of x / s — bit-identical after the
 // rounding to bf16 for every bf16 x and every bf16 s with 2^-64 <= |s| <= 2^64 (no quotient of two
 // 8-bit significands lies within 2^-17 relative of a bf16 rounding boundary, while the
@@ -188,6 +252,7 @@ __device__ __forceinline__ void round2(float& a, float& b) {
 // 0x88888888 + sum(code_k << 4k): code_k in [-8, 7], so the biased nibbles never carry.
 template <int DT, bool FAST, bool ZP>
 __device__ __forceinline__ uint32_t w4_quant_word(const u32x4& raw, float s, float rs, float z) {
+    if constexpr (DT == CT_F16 && FAST) return w4_quant_word_f16<ZP>(raw, s, rs, z);
     const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
     uint32_t word = 0x88888888u;
 #pragma unroll
@@ -221,14 +286,14 @@ __device__ __forceinline__ void w4_quant_pack_group(const W4Params& p, int64_t g
     uint32_t w[Q];
     float s = 0.0f, z = 0.0f, rs = 0.0f;
     bool fast = false, use_zp = false;
+    const bool data_ok = fast_data_ok<DT, Q>(r);
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
         if (i == 0 || !SHARED) {
             const int64_t si = w4_scale_index(p, g * Q + i);
             s = load_as_f<DT>(p.scale, si);
             z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype)
-            const float as = __builtin_fabsf(s);
-            fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+            fast = fast_scale_ok<DT>(s) && data_ok;
             rs = 1.0f / s;
             // adding an all-zero zero point is the identity (t is already rounded): skip the
             // add + second rounding when every lane of the wave has z == 0 (symmetric schemes)
@@ -267,8 +332,7 @@ __device__ __forceinline__ void w4_quant_pack_lean(const u32x4* __restrict__ in,
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = in[g * 4 + i];
     const float s = DT == CT_BF16 ? bf16_bits_to_f(sbits) : f16_bits_to_f(sbits);
-    const float as = __builtin_fabsf(s);
-    const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+    const bool fast = fast_scale_ok<DT>(s) && fast_data_ok<DT, 4>(r);
     const float rs = 1.0f / s;
     const bool use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
     uint32_t w[4];
@@ -355,8 +419,7 @@ __global__ __launch_bounds__(kBlock) void rtn_w4_kernel(const u32x4* __restrict_
         store1<DT>(scale_out, l / lpg, s);
         zp_out[l / lpg] = (int8_t)(int)z;
     }
-    const float as = __builtin_fabsf(s);
-    const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+    const bool fast = fast_scale_ok<DT>(s) && fast_data_ok<DT, 4>(r);
     const float rs = 1.0f / s;
     const bool use_zp = !symmetric && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
     uint32_t w[4];
@@ -380,8 +443,18 @@ __global__ __launch_bounds__(kBlock) void rtn_w4_kernel(const u32x4* __restrict_
     stream_store16(out + l, u32x4{w[0], w[1], w[2], w[3]});
 }
 
-// UNROLL units per lane, one block apart, starting at `base`
-template <int DT, int UNROLL, bool HAS_ZP>
+// value of lane 0 of each 16-lane row in every lane of the row (DPP row_newbcast:0)
+__device__ __forceinline__ uint32_t row_leader_value(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150, 0xf, 0xf, false);
+}
+
+// UNROLL units per lane, one block apart, starting at `base`.
+// ROWLEAD (flat scale index, >= 16 units per scale group, units % 16 == 0, int8 zero points): the 16 lanes of a DPP row
+// hold 16 consecutive units of ONE group, so only the row's first lane loads the scale (and the zero point) and a
+// v_mov_b32_dpp row_newbcast hands it to the other 15.  The kernel issues one vector-memory instruction per 4-byte
+// word, 2-byte scale and 1-byte zero point — three per 8 elements in the asymmetric case, and that instruction rate,
+// not the byte rate, is what made asymmetric decompress slower than symmetric (37 vs 29 us at 8192^2).
+template <int DT, int UNROLL, bool HAS_ZP, bool ROWLEAD = false>
 __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64_t base) {
     const uint32_t* in = static_cast<const uint32_t*>(p.x);
     uint32_t word[UNROLL];
@@ -395,15 +468,26 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
         const int64_t u = base + (int64_t)i * kBlock;
         if (u >= p.units) continue;
         const int64_t si = w4_scale_index(p, u);
-        const float s = load_as_f<DT>(p.scale, si);
-        const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
-        float v[8];
-        if (HAS_ZP && p.zdt == CT_I8) {  // wave-uniform
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float q = bits_f(0x4B000000u | ((word[i] >> (4 * k)) & 0xfu)) - 8388616.0f;
-                v[k] = dequant_core_zexact<DT>(q, z, s);
+        float s, z;
+        if constexpr (ROWLEAD) {
+            uint32_t sb = 0, zb = 0;
+            if ((threadIdx.x & 15) == 0) {
+                sb = static_cast<const uint16_t*>(p.scale)[si];
+                if (HAS_ZP) zb = (uint32_t)(int)static_cast<const int8_t*>(p.zp)[si];
             }
+            sb = row_leader_value(sb);
+            s = DT == CT_BF16 ? bf16_bits_to_f(sb) : f16_bits_to_f(sb);
+            z = HAS_ZP ? (float)(int)row_leader_value(zb) : 0.0f;
+        } else {
+            s = load_as_f<DT>(p.scale, si);
+            z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
+        }
+        float v[8];
+        if (HAS_ZP && (ROWLEAD || p.zdt == CT_I8)) {  // wave-uniform
+            // (2^23 + nibble) - (2^23 + 8 + z) is exact: the un-bias and the zero point cost ONE subtract, as in the symmetric case
+            const float off = 8388616.0f + z;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = mul_round_to<DT>(bits_f(0x4B000000u | ((word[i] >> (4 * k)) & 0xfu)) - off, s);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -416,11 +500,11 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
     }
 }
 
-template <int DT, int UNROLL, bool HAS_ZP>
+template <int DT, int UNROLL, bool HAS_ZP, bool ROWLEAD = false>
 __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_kernel(W4Params p) {
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
     for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride)
-        w4_unpack_dequant_units<DT, UNROLL, HAS_ZP>(p, base);
+        w4_unpack_dequant_units<DT, UNROLL, HAS_ZP, ROWLEAD>(p, base);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -496,6 +580,13 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const c
 // ------------------------------------------------------------------------------------------
 template <int DT, bool FAST, bool ZP>
 __device__ __forceinline__ void q8_quant_words(const u32x4& raw, float s, float rs, float z, int qmin, int qmax, uint32_t& lo, uint32_t& hi) {
+    if constexpr (DT == CT_F16 && FAST) {  // packed fp16 pipeline; 1536: the low byte of each half is the two's-complement code
+        uint32_t u[4];
+        quant_pairs_f16<ZP, 1536>(raw, s, rs, z, (float)qmin, (float)qmax, u);
+        lo = __builtin_amdgcn_perm(u[1], u[0], 0x06040200u) ^ 0x80808080u;  // the callers expect code + 128 per byte
+        hi = __builtin_amdgcn_perm(u[3], u[2], 0x06040200u) ^ 0x80808080u;
+        return;
+    }
     const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
     uint32_t acc[2] = {0x80808080u, 0x80808080u};  // sum of (128 + code) << 8k never carries between bytes
 #pragma unroll
@@ -517,80 +608,88 @@ __device__ __forceinline__ void q8_quant_words(const u32x4& raw, float s, float 
     lo = acc[0]; hi = acc[1];
 }
 
+// lane g = units 2g, 2g + 1 (32 B in, one 16 B store out)
 template <int DT, bool HAS_ZP, bool SHARED, int OFF>
-__global__ __launch_bounds__(kBlock) void q8_quant_kernel(W4Params p, int qmin, int qmax) {
+__device__ __forceinline__ void q8_quant_lane(const W4Params& p, int64_t g, int qmin, int qmax) {
     constexpr int Q = 2;
     constexpr uint32_t kFlip = OFF == 0 ? 0x80808080u : 0u;  // (code + 128) ^ 0x80 == two's-complement code
-    const int64_t groups = p.units / Q;
     const u32x4* in = static_cast<const u32x4*>(p.x);
     u32x4* out = static_cast<u32x4*>(p.out);
-    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
-        u32x4 r[Q];
+    u32x4 r[Q];
 #pragma unroll
-        for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
-        uint32_t w[2 * Q];
-        float s = 0.0f, z = 0.0f, rs = 0.0f;
-        bool fast = false, use_zp = false;
+    for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
+    uint32_t w[2 * Q];
+    float s = 0.0f, z = 0.0f, rs = 0.0f;
+    bool fast = false, use_zp = false;
+    const bool data_ok = fast_data_ok<DT, Q>(r);
 #pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            if (i == 0 || !SHARED) {
-                const int64_t si = w4_scale_index(p, g * Q + i);
-                s = load_as_f<DT>(p.scale, si);
-                z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
-                const float as = __builtin_fabsf(s);
-                fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
-                rs = 1.0f / s;
-                use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
-            }
-            if (fast) {
-                if (use_zp) q8_quant_words<DT, true, true>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
-                else q8_quant_words<DT, true, false>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
-            } else {
-                if (use_zp) q8_quant_words<DT, false, true>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
-                else q8_quant_words<DT, false, false>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
+    for (int i = 0; i < Q; ++i) {
+        if (i == 0 || !SHARED) {
+            const int64_t si = w4_scale_index(p, g * Q + i);
+            s = load_as_f<DT>(p.scale, si);
+            z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+            fast = fast_scale_ok<DT>(s) && data_ok;
+            rs = 1.0f / s;
+            use_zp = HAS_ZP && (__builtin_amdgcn_ballot_w64(z != 0.0f) != 0);
+        }
+        if (fast) {
+            if (use_zp) q8_quant_words<DT, true, true>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
+            else q8_quant_words<DT, true, false>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
+        } else {
+            if (use_zp) q8_quant_words<DT, false, true>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
+            else q8_quant_words<DT, false, false>(r[i], s, rs, z, qmin, qmax, w[2 * i], w[2 * i + 1]);
+        }
+    }
+    stream_store16(out + g, u32x4{w[0] ^ kFlip, w[1] ^ kFlip, w[2] ^ kFlip, w[3] ^ kFlip});
+}
+
+template <int DT, bool HAS_ZP, bool SHARED, int OFF>
+__global__ __launch_bounds__(kBlock) void q8_quant_kernel(W4Params p, int qmin, int qmax) {
+    const int64_t groups = p.units / 2;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock)
+        q8_quant_lane<DT, HAS_ZP, SHARED, OFF>(p, g, qmin, qmax);
+}
+
+// UNROLL units per lane, one block apart, starting at `base` (8 B in, 16 B out each)
+template <int DT, int UNROLL, bool HAS_ZP, int OFF>
+__device__ __forceinline__ void q8_dequant_units(const W4Params& p, int64_t base) {
+    constexpr uint32_t kFlip = OFF == 0 ? 0x80808080u : 0u;
+    const u32x2* in = static_cast<const u32x2*>(p.x);
+    u32x2 word[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u < p.units) word[i] = in[u];
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u >= p.units) continue;
+        const int64_t si = w4_scale_index(p, u);
+        const float s = load_as_f<DT>(p.scale, si);
+        const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+        const uint32_t ws[2] = {word[i].x ^ kFlip, word[i].y ^ kFlip};
+        float v[8];
+        if (HAS_ZP && p.zdt == CT_I8) {  // wave-uniform
+            const float off = 128.0f + z;  // exact: the un-bias and the zero point in one subtract
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = mul_round_to<DT>((float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - off, s);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float q = (float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f;  // v_cvt_f32_ubyteN
+                v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
             }
         }
-        stream_store16(out + g, u32x4{w[0] ^ kFlip, w[1] ^ kFlip, w[2] ^ kFlip, w[3] ^ kFlip});
+        store8<DT>(p.out, u * 8, v);
     }
 }
 
 template <int DT, int UNROLL, bool HAS_ZP, int OFF>
 __global__ __launch_bounds__(kBlock) void q8_dequant_kernel(W4Params p) {
-    constexpr uint32_t kFlip = OFF == 0 ? 0x80808080u : 0u;
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
-    const u32x2* in = static_cast<const u32x2*>(p.x);
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
-        u32x2 word[UNROLL];
-#pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u < p.units) word[i] = in[u];
-        }
-#pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u >= p.units) continue;
-            const int64_t si = w4_scale_index(p, u);
-            const float s = load_as_f<DT>(p.scale, si);
-            const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
-            const uint32_t ws[2] = {word[i].x ^ kFlip, word[i].y ^ kFlip};
-            float v[8];
-            if (HAS_ZP && p.zdt == CT_I8) {  // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float q = (float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f;
-                    v[k] = dequant_core_zexact<DT>(q, z, s);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float q = (float)((ws[k >> 2] >> (8 * (k & 3))) & 0xffu) - 128.0f;  // v_cvt_f32_ubyteN
-                    v[k] = dequant_core<DT>(q, HAS_ZP, z, s);
-                }
-            }
-            store8<DT>(p.out, u * 8, v);
-        }
-    }
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride)
+        q8_dequant_units<DT, UNROLL, HAS_ZP, OFF>(p, base);
 }
 
 
@@ -622,62 +721,109 @@ __device__ __forceinline__ void f8_quant_words(const u32x4& raw, float s, float 
 }
 
 template <int DT, bool HAS_ZP, bool SHARED>
-__global__ __launch_bounds__(kBlock) void f8_quant_kernel(W4Params p) {
+__device__ __forceinline__ void f8_quant_lane(const W4Params& p, int64_t g) {
     constexpr int Q = 2;
-    const int64_t groups = p.units / Q;
     const u32x4* in = static_cast<const u32x4*>(p.x);
     u32x4* out = static_cast<u32x4*>(p.out);
-    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
-        u32x4 r[Q];
+    u32x4 r[Q];
 #pragma unroll
-        for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
-        uint32_t w[2 * Q];
-        float s = 0.0f, z = 0.0f, rs = 0.0f;
-        bool fast = false;
+    for (int i = 0; i < Q; ++i) r[i] = in[g * Q + i];
+    uint32_t w[2 * Q];
+    float s = 0.0f, z = 0.0f, rs = 0.0f;
+    bool fast = false;
 #pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            if (i == 0 || !SHARED) {
-                const int64_t si = w4_scale_index(p, g * Q + i);
-                s = load_as_f<DT>(p.scale, si);
-                z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
-                const float as = __builtin_fabsf(s);
-                fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
-                rs = 1.0f / s;
-            }
-            // the zero-point add is kept even for z == 0: it turns a -0.0 quotient into +0.0, as upstream's `+=`
-            if (fast) f8_quant_words<DT, true, HAS_ZP>(r[i], s, rs, z, w[2 * i], w[2 * i + 1]);
-            else f8_quant_words<DT, false, HAS_ZP>(r[i], s, rs, z, w[2 * i], w[2 * i + 1]);
+    for (int i = 0; i < Q; ++i) {
+        if (i == 0 || !SHARED) {
+            const int64_t si = w4_scale_index(p, g * Q + i);
+            s = load_as_f<DT>(p.scale, si);
+            z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+            const float as = __builtin_fabsf(s);
+            fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+            rs = 1.0f / s;
         }
-        stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+        // the zero-point add is kept even for z == 0: it turns a -0.0 quotient into +0.0, as upstream's `+=`
+        if (fast) f8_quant_words<DT, true, HAS_ZP>(r[i], s, rs, z, w[2 * i], w[2 * i + 1]);
+        else f8_quant_words<DT, false, HAS_ZP>(r[i], s, rs, z, w[2 * i], w[2 * i + 1]);
+    }
+    stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+}
+
+template <int DT, bool HAS_ZP, bool SHARED>
+__global__ __launch_bounds__(kBlock) void f8_quant_kernel(W4Params p) {
+    const int64_t groups = p.units / 2;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) f8_quant_lane<DT, HAS_ZP, SHARED>(p, g);
+}
+
+template <int DT, int UNROLL, bool HAS_ZP>
+__device__ __forceinline__ void f8_dequant_units(const W4Params& p, int64_t base) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const u32x2* in = static_cast<const u32x2*>(p.x);
+    u32x2 word[UNROLL];
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u < p.units) word[i] = in[u];
+    }
+#pragma unroll
+    for (int i = 0; i < UNROLL; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u >= p.units) continue;
+        const int64_t si = w4_scale_index(p, u);
+        const float s = load_as_f<DT>(p.scale, si);
+        const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
+        const f2 q01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].x, false), q23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].x, true);
+        const f2 q45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].y, false), q67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].y, true);
+        const float q[8] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y};
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = dequant_core<DT>(q[k], HAS_ZP, z, s);
+        store8<DT>(p.out, u * 8, v);
     }
 }
 
 template <int DT, int UNROLL, bool HAS_ZP>
 __global__ __launch_bounds__(kBlock) void f8_dequant_kernel(W4Params p) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
-    const u32x2* in = static_cast<const u32x2*>(p.x);
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) {
-        u32x2 word[UNROLL];
-#pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u < p.units) word[i] = in[u];
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride) f8_dequant_units<DT, UNROLL, HAS_ZP>(p, base);
+}
+
+// ------------------------------------------------------------------------------------------
+// batched 8-bit codecs: ONE launch over a table of tensors (the W8A8 / FP8 counterpart of the W4 batch above; the
+// per-module loop of ModelCompressor, model_compressor.py:167-169,196-198, with Naive / Int / FloatQuantizationCompressor,
+// naive_quantized/base.py:48-126).  Same table type; `group` = number of consecutive elements of the row-major stream that
+// share one scale: cols (channel), a divisor of cols (group) or rows * cols (tensor).  Zero points: int8 or none.
+// ------------------------------------------------------------------------------------------
+template <int DT, bool FP8>
+__global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int qmin, int qmax) {
+    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+    const W4Params p = batch_params(it);
+    const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
+    if (g >= p.units / 2) return;
+    if constexpr (FP8) {
+        if (p.zp) f8_quant_lane<DT, true, true>(p, g);
+        else f8_quant_lane<DT, false, true>(p, g);
+    } else {
+        if (p.zp) q8_quant_lane<DT, true, true, 0>(p, g, qmin, qmax);
+        else q8_quant_lane<DT, false, true, 0>(p, g, qmin, qmax);
+    }
+}
+
+template <int DT, bool FP8>
+__global__ __launch_bounds__(kBlock) void q8_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride) {
+    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+    const W4Params p = batch_params(it);
+    const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kBatchIter;
+    const int64_t limit = (first + stride * kBatchIter < p.units) ? first + stride * kBatchIter : p.units;
+    // (a runtime-stride loop, like the W4 batch: hipcc schedules the body better inside one)
+    if (p.zp) {
+        for (int64_t b = first + threadIdx.x; b < limit; b += stride) {
+            if constexpr (FP8) f8_dequant_units<DT, kBatchUnroll, true>(p, b);
+            else q8_dequant_units<DT, kBatchUnroll, true, 0>(p, b);
         }
-#pragma unroll
-        for (int i = 0; i < UNROLL; ++i) {
-            const int64_t u = base + (int64_t)i * kBlock;
-            if (u >= p.units) continue;
-            const int64_t si = w4_scale_index(p, u);
-            const float s = load_as_f<DT>(p.scale, si);
-            const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
-            const f2 q01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].x, false), q23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].x, true);
-            const f2 q45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].y, false), q67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)word[i].y, true);
-            const float q[8] = {q01.x, q01.y, q23.x, q23.y, q45.x, q45.y, q67.x, q67.y};
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = dequant_core<DT>(q[k], HAS_ZP, z, s);
-            store8<DT>(p.out, u * 8, v);
+    } else {
+        for (int64_t b = first + threadIdx.x; b < limit; b += stride) {
+            if constexpr (FP8) f8_dequant_units<DT, kBatchUnroll, false>(p, b);
+            else q8_dequant_units<DT, kBatchUnroll, false, 0>(p, b);
         }
     }
 }
@@ -1163,13 +1309,15 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         dim3 grid(w4_grid(w.units, U));
         // (a scales-first lean variant of this kernel measured SLOWER: 39-42 us vs 30 us)
         // units per lane re-swept with non-temporal stores: U = 1 / 2 / 4 / 8 -> 33.4 / 29.2 / 33.0 / 30.5 us
-        if (sdt == CT_BF16) {
-            if (zp) hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U, true>), grid, dim3(kBlock), 0, as_stream(stream), w);
-            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_BF16, U, false>), grid, dim3(kBlock), 0, as_stream(stream), w);
-        } else {
-            if (zp) hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_F16, U, true>), grid, dim3(kBlock), 0, as_stream(stream), w);
-            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<CT_F16, U, false>), grid, dim3(kBlock), 0, as_stream(stream), w);
-        }
+        // one scale / zero-point load per 16-lane row when a row never straddles a scale group
+        static const int rowlead_mode = []() { const char* e = std::getenv("CT_W4D_ROWLEAD"); return e ? std::atoi(e) : 1; }();  // 0 off, 1 asymmetric, 2 both
+        const bool row_ok = w.flat_scale && w.upg_shift >= 4 && w.upg_shift < 62 && w.units % 16 == 0 && (!zp || zdt == CT_I8);
+        const bool rowlead = row_ok && (zp ? rowlead_mode >= 1 : rowlead_mode >= 2);
+#define CT_W4D(DT, ZP) do { if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, true>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, false>), grid, dim3(kBlock), 0, as_stream(stream), w); } while (0)
+        if (sdt == CT_BF16) { if (zp) CT_W4D(CT_BF16, true); else CT_W4D(CT_BF16, false); }
+        else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
+#undef CT_W4D
         CT_LAUNCH_CHECK("ct_unpack_dequant[w4]");
     }
     if (bits == 8 && words == cols / 4 && cols % 32 == 0 && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 &&
@@ -1235,6 +1383,77 @@ int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_bl
     if (dt == CT_BF16) hipLaunchKernelGGL((w4_unpack_dequant_batch_kernel<CT_BF16>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
     else hipLaunchKernelGGL((w4_unpack_dequant_batch_kernel<CT_F16>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
     CT_LAUNCH_CHECK("ct_unpack_dequant_batch");
+}
+
+int64_t ct_q8_batch_plan(ct_w4_item* items, int n, int direction) {
+    if (n < 0 || (n > 0 && items == nullptr) || (direction != 0 && direction != 1)) {
+        set_error("ct_q8_batch_plan: bad arguments");
+        return -1;
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ct_w4_item& it = items[i];
+        const int64_t numel = it.rows * it.cols;
+        const bool whole = it.rows > 0 && it.cols > 0 && it.group >= numel;  // per tensor
+        const int64_t g = whole ? numel : ((it.group <= 0 || it.group > it.cols) ? it.cols : it.group);
+        const bool ok = it.rows > 0 && it.cols > 0 && it.cols % 16 == 0 && g % 16 == 0 && (whole || it.cols % g == 0) && it.src && it.scale && it.dst &&
+                        aligned16(it.src) && aligned16(it.dst);
+        if (!ok) {
+            set_error("ct_q8_batch_plan: item %d (rows %lld, cols %lld, group %lld) is not eligible for the batched 8-bit path "
+                      "(needs cols %% 16 == 0, group %% 16 == 0, cols %% group == 0 or group == rows * cols, 16-byte aligned buffers)", i,
+                      (long long)it.rows, (long long)it.cols, (long long)it.group);
+            return -1;
+        }
+        it.units = numel / 8;
+        if (whole || g / 8 > 0x7fffffff) {  // one scale for everything: index 0 without a division (w4_scale_index: u >> 62)
+            it.upg = 0;
+            it.upg_shift = 62;
+            if (!whole) { set_error("ct_q8_batch_plan: group too large"); return -1; }
+        } else {
+            it.upg = (int32_t)(g / 8);
+            it.upg_shift = log2_exact(it.upg);
+        }
+        it.first_block = blocks;
+        blocks += direction == 0 ? cdiv64(it.units / 2, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll * kBatchIter);
+    }
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("ct_q8_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
+        return -1;
+    }
+    return blocks;
+}
+
+int ct_q8_quant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, int fp8, int bits, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_BF16 || dt == CT_F16, "batched 8-bit path: 16-bit weights only, got dtype %d", dt);
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    CT_REQUIRE(fp8 || (bits >= 1 && bits <= 8), "num_bits must be in [1, 8], got %d", bits);
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    const int qmin = fp8 ? 0 : -(1 << (bits - 1)), qmax = fp8 ? 0 : (1 << (bits - 1)) - 1;
+    const dim3 grid((unsigned)total_blocks);
+    if (dt == CT_BF16) {
+        if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
+        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
+    } else {
+        if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
+        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
+    }
+    CT_LAUNCH_CHECK("ct_q8_quant_batch");
+}
+
+int ct_q8_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, int fp8, ct_stream_t stream) {
+    CT_REQUIRE(dt == CT_BF16 || dt == CT_F16, "batched 8-bit path: 16-bit weights only, got dtype %d", dt);
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    const int64_t stride = (int64_t)kBlock * kBatchUnroll;
+    const dim3 grid((unsigned)total_blocks);
+    if (dt == CT_BF16) {
+        if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
+        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
+    } else {
+        if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
+        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
+    }
+    CT_LAUNCH_CHECK("ct_q8_dequant_batch");
 }
 
 int ct_selftest_bf16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {

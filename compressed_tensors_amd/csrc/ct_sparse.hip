@@ -16,6 +16,8 @@
 // 16-byte vectors (scalar head/tail); only LDS sees the 2-byte scattered accesses.
 #include "ct_common.h"
 
+#include <cstdlib>
+
 namespace ct {
 
 // ------------------------------------------------------------------------- element helpers
@@ -689,6 +691,7 @@ struct Flat16Plan {
     int64_t units, nblocks;
     int span;
 };
+constexpr int kMaxChunks = 64;
 static Flat16Plan flat16_plan(int64_t rows, int64_t cols) {
     Flat16Plan p;
     p.units = rows * (cols / 8);
@@ -766,10 +769,13 @@ __global__ __launch_bounds__(kBlock) void flat16_count_kernel(const u32x4* __res
     if (tid == 0) block_tot[blockIdx.x] = (int64_t)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// `x`, `units`: this launch's chunk of the flat unit stream, which starts at unit `u0` of the tensor; `base`: device word holding the
+// number of non-zeros before the chunk (NULL: 0); `total_out` receives base + the chunk's count
 __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int span, int64_t upr,
                                                                 int64_t rows, uint16_t* __restrict__ vout, int64_t capacity,
                                                                 int64_t* __restrict__ row_offsets, int64_t* __restrict__ total_out,
-                                                                const int64_t* __restrict__ block_tot, const int32_t* __restrict__ span_tot) {
+                                                                const int64_t* __restrict__ block_tot, const int32_t* __restrict__ span_tot,
+                                                                int64_t u0, const int64_t* __restrict__ base) {
     constexpr int kSlabData = kWT * 8 + 8;      // compacted run (+ phase shift)
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[kBlock / 64][kSlab];
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if (lane == 0) s_part[wave] = part;
     __syncthreads();
-    int64_t run = (int64_t)s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    int64_t run = (int64_t)s_part[0] + s_part[1] + s_part[2] + s_part[3] + (base ? *base : 0);
     for (int w = 0; w < wave; ++w) run += span_tot[(int64_t)blockIdx.x * 4 + w];
 
     uint16_t* slab = s_val[wave];
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
         }
         // row offsets of the rows that start inside this wave-tile (wave-uniform loop, usually 0-1 trips)
         {
-            const int64_t ubeg = wt * kWT, uend = ubeg + kWT;
+            const int64_t ubeg = u0 + wt * kWT, uend = ubeg + kWT;  // tensor-wide unit numbers
             for (int64_t r = (ubeg + upr - 1) / upr; r < rows && r * upr < uend; ++r) {
                 const int q = (int)(r * upr - ubeg);
                 const int i = q >> 6, l = q & 63;
@@ -1000,7 +1006,7 @@ int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const 
 int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0) return 16;
     const Flat16Plan p = flat16_plan(rows, cols);
-    const int64_t flat = p.nblocks * 8 + p.nblocks * 4 * 4;  // block totals (int64) + span totals (int32)
+    const int64_t flat = p.nblocks * 8 + p.nblocks * 4 * 4 + 8 * kMaxChunks;  // block totals (int64) + span totals (int32) + chunk totals
     const int64_t generic = (rows + 1) * 8;                  // row counts of the count / scan / scatter form
     return (flat > generic ? flat : generic) + 16;
 }
@@ -1024,11 +1030,33 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
         int64_t* block_tot = static_cast<int64_t*>(workspace);
         int32_t* span_tot = reinterpret_cast<int32_t*>(block_tot + p.nblocks);
         const int mask_dwords = (p.units % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0);
-        hipLaunchKernelGGL(flat16_count_kernel, dim3((unsigned)p.nblocks), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x),
-                           float_kind(dt), p.units, p.span, bitmask, mask_dwords, block_tot, span_tot);
-        hipLaunchKernelGGL(flat16_scatter_kernel, dim3((unsigned)p.nblocks), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x),
-                           float_kind(dt), p.units, p.span, cols / 8, rows, static_cast<uint16_t*>(values), values_capacity, row_offsets, total,
-                           block_tot, span_tot);
+        // Optionally walk the tensor in chunks (count chunk k, scatter chunk k, ...) so that the scatter's re-read of x is served
+        // by a cache instead of HBM; chunk k+1 starts from the running total chunk k left in `total`.  CT_BITMASK_CHUNK_MB
+        // (experiment knob; default: one chunk).  Every chunk is a whole number of blocks of the one-chunk plan, so the
+        // workspace layout and the per-span bookkeeping are unchanged.
+        static const int64_t chunk_mb = []() { const char* e = std::getenv("CT_BITMASK_CHUNK_MB"); return e ? (int64_t)std::atoll(e) : (int64_t)0; }();
+        const int64_t units_per_block = (int64_t)4 * p.span * kWT;
+        int64_t blocks_per_chunk = p.nblocks;
+        if (chunk_mb > 0) {
+            blocks_per_chunk = (chunk_mb << 20) / (units_per_block * 16);
+            if (blocks_per_chunk < cdiv64(p.nblocks, kMaxChunks)) blocks_per_chunk = cdiv64(p.nblocks, kMaxChunks);
+            if (blocks_per_chunk < 1) blocks_per_chunk = 1;
+        }
+        // running totals: chunk k leaves its end in chunk_tot[k] (its own word: the next chunk's waves read it while nothing writes
+        // it), the last chunk in `total`
+        int64_t* chunk_tot = reinterpret_cast<int64_t*>(span_tot + 4 * p.nblocks);
+        int chunk = 0;
+        for (int64_t b0 = 0; b0 < p.nblocks; b0 += blocks_per_chunk, ++chunk) {
+            const int64_t nb = (p.nblocks - b0) < blocks_per_chunk ? (p.nblocks - b0) : blocks_per_chunk;
+            const int64_t u0 = b0 * units_per_block;
+            const int64_t cu = (p.units - u0) < nb * units_per_block ? (p.units - u0) : nb * units_per_block;
+            const u32x4* xc = static_cast<const u32x4*>(x) + u0;
+            hipLaunchKernelGGL(flat16_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream), xc, float_kind(dt), cu, p.span, bitmask + u0,
+                               mask_dwords, block_tot + b0, span_tot + 4 * b0);
+            hipLaunchKernelGGL(flat16_scatter_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream), xc, float_kind(dt), cu, p.span, cols / 8, rows,
+                               static_cast<uint16_t*>(values), values_capacity, row_offsets, (b0 + nb >= p.nblocks) ? total : chunk_tot + chunk,
+                               block_tot + b0, span_tot + 4 * b0, u0, chunk ? chunk_tot + chunk - 1 : static_cast<const int64_t*>(nullptr));
+        }
         CT_LAUNCH_CHECK("ct_bitmask_compress[flat16]");
     }
     // other element sizes / ragged rows: count, single-block scan, scatter (all on the stream)

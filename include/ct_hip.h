@@ -183,6 +183,17 @@ int64_t ct_w4_batch_plan(ct_w4_item* items_host, int n, int direction);
 int ct_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
 int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
 
+/* Batched 8-bit codecs (Naive / Int / FloatQuantizationCompressor.compress / decompress, compressors/naive_quantized/
+ * base.py:48-126, looped per module by model_compressor.py:167-169,196-198): quantize to int8 (num_bits <= 8, clamped to the
+ * num_bits range) or float8_e4m3fn, and the inverse, for a whole table of 16-bit tensors in one launch.  Same table type and
+ * protocol as the W4 batch; `group` counts the consecutive elements that share one scale: <= 0 or cols (one per row), a
+ * divisor of cols, or >= rows * cols (one per tensor).  Needs cols % 16 == 0 and group % 16 == 0; zero points int8 or NULL.
+ * direction: 0 = quantize (src = weights, dst = codes), 1 = dequantize (src = codes, dst = weights). */
+int64_t ct_q8_batch_plan(ct_w4_item* items_host, int n, int direction);
+int ct_q8_quant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, int fp8, int bits,
+                      ct_stream_t stream);
+int ct_q8_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, int fp8, ct_stream_t stream);
+
 /* Min/max observer + calculate_qparams for weight groups (rows x ceil(cols/cdiv) groups of
  * cdiv consecutive columns).   quantization/utils/helpers.py:50-137
  * scale_out has x's dtype; zp_out is int8 (may be NULL for symmetric). */
