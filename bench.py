@@ -222,13 +222,25 @@ def cpu_baseline(dev):
         return best, res
 
     points = {}
+    by_threads = {}
     for n in (N, 4096):
         torch.manual_seed(0)
         w = torch.randn(n, n, dtype=torch.bfloat16)
         scale, zp = O.calculate_qparams_minmax(w, num_bits=BITS, group_size=GROUP, symmetric=True)
         sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
-        t_c, c = best_of(lambda: E.pack_quantized_compress(sd, symmetric=True, **kw))
-        t_d, d = best_of(lambda: E.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True))
+        # torch.set_num_threads(os.cpu_count()) is what SURVEY 8d prescribes; on a many-core host eager torch is FASTER with fewer
+        # threads (256 threads: 2.7 s, mostly fork / join), so the same sample is also timed at 64 / 32 / 16 threads and the best
+        # configuration is the one reported (with its thread count) — the baseline is never handicapped
+        t_c = t_d = None
+        for th in sorted({cores, 64, 32, 16} & set(range(1, cores + 1)), reverse=True):
+            torch.set_num_threads(th)
+            tc, c = best_of(lambda: E.pack_quantized_compress(sd, symmetric=True, **kw), 2 if th != cores else 3)
+            td, d = best_of(lambda: E.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True), 2 if th != cores else 3)
+            if n == N:
+                by_threads[str(th)] = round(tc + td, 4)
+            if t_c is None or tc + td < t_c + t_d:
+                t_c, t_d, best_th = tc, td, th
+        torch.set_num_threads(cores)
         t_pc, pc = best_of(lambda: O.pack_quantized_compress(sd, symmetric=True, **kw), 2)
         t_pd, pd = best_of(lambda: O.pack_quantized_decompress(pc, num_bits=BITS, strategy="group", symmetric=True), 2)
         g_packed = codec.quantize_and_pack(w.to(dev), scale.to(dev), zp.to(dev), **kw)
@@ -237,14 +249,16 @@ def cpu_baseline(dev):
         same = (torch.equal(c["weight_packed"], pc["weight_packed"]) and torch.equal(d["weight"].view(torch.int16), pd["weight"].view(torch.int16)))
         matches = (torch.equal(g_packed.cpu(), c["weight_packed"]) and torch.equal(g_dec.cpu().view(torch.int16), d["weight"].view(torch.int16))
                    and torch.equal(g_scale.cpu().view(torch.int16), scale.view(torch.int16)) and torch.equal(g_zp.cpu(), zp))
-        points[n] = dict(t_c=t_c, t_d=t_d, t_pc=t_pc, t_pd=t_pd, same=bool(same), matches=bool(matches))
+        points[n] = dict(t_c=t_c, t_d=t_d, t_pc=t_pc, t_pd=t_pd, same=bool(same), matches=bool(matches), threads=best_th)
     # BASELINE config 1, the reference's own CPU-runnable case: int8 per-tensor symmetric IntQuantizationCompressor round trip
     torch.manual_seed(0)
     w = torch.randn(4096, 4096, dtype=torch.bfloat16)
     s1 = (w.abs().max().float() / 127.0).to(torch.bfloat16).reshape(1)
     sd8 = {"weight": w, "weight_scale": s1, "weight_zero_point": torch.zeros(1, dtype=torch.int8)}
+    torch.set_num_threads(points[4096]["threads"])
     t_c8, c8 = best_of(lambda: E.int_quantized_compress(sd8))
     t_d8, d8 = best_of(lambda: E.int_quantized_decompress(c8))
+    torch.set_num_threads(cores)
     g_q8 = codec.quantize_tensor(w.to(dev), s1.to(dev), sd8["weight_zero_point"].to(dev), num_bits=8, strategy="tensor", dtype=torch.int8)
     g_d8 = codec.dequantize_tensor(g_q8, s1.to(dev), None)
     ok8 = bool(torch.equal(g_q8.cpu(), c8["weight"]) and torch.equal(g_d8.cpu().view(torch.int16), d8["weight"].view(torch.int16)))
@@ -256,12 +270,14 @@ def cpu_baseline(dev):
     eager = {
         "value": gbps(N, p["t_c"] + p["t_d"]),
         "unit": "GB/s",
-        "cores": cores,
+        "cores": p["threads"],
+        "host_cores": cores,
+        "seconds_by_torch_threads": by_threads,
         "kind": "port",
         "impl": "torch-eager: oracle/eager_ref.py restates the reference's op sequence (pack_quantized/base.py:62-163, helpers.py:20-180, "
-                "forward_helpers.py:118-177,523-572) on CPU tensors, torch.set_num_threads(os.cpu_count()); bit-identical to the reference "
-                "in the build container",
-        "sample": f"PackedQuantizationCompressor-shaped compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 3 "
+                "forward_helpers.py:118-177,523-572) on CPU tensors; torch.set_num_threads swept over {os.cpu_count(), 64, 32, 16}, best reported; "
+                "bit-identical to the reference in the build container",
+        "sample": f"PackedQuantizationCompressor-shaped compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 2-3 per thread count "
                   f"(compress {p['t_c']:.3f} s, decompress {p['t_d']:.3f} s)",
         "compress_s": round(p["t_c"], 4), "decompress_s": round(p["t_d"], 4),
         "at_4096": {"value": gbps(4096, points[4096]["t_c"] + points[4096]["t_d"]), "compress_s": round(points[4096]["t_c"], 4),

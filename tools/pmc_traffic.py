@@ -16,6 +16,7 @@ ALIAS = {
     "ct::w4_quant_pack_kernel<2, true, true>": "w4_quant_pack_kernel<bf16>",
     "ct::w4_quant_pack_lean_kernel<2, true>": "w4_quant_pack_lean_kernel<bf16>",
     "ct::w4_unpack_dequant_kernel<2, 2, false>": "w4_unpack_dequant_kernel<bf16>",
+    "ct::w4_unpack_dequant_kernel<2, 2, false, false>": "w4_unpack_dequant_kernel<bf16>",
 }
 
 

@@ -7,7 +7,7 @@
 # with the small TinyLlama-shaped launches; "extras": the whole default bench (all legs).
 #   usage: tools/profile_round.sh <tag>
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
