@@ -16,7 +16,10 @@
 // 16-byte vectors (scalar head/tail); only LDS sees the 2-byte scattered accesses.
 #include "ct_common.h"
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
+#include <random>
 
 namespace ct {
 
@@ -861,6 +864,257 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
     if (last_here && lane == 0 && total_out) *total_out = run;
 }
 
+// ------------------------------------------------------------------------- compress, ONE pass (16-bit), round 2 — EXPERIMENTAL
+// The two-kernel form reads x twice (349.7 MB of traffic for 209.8 MB of algorithmic bytes at 8192^2).  One pass needs every tile
+// to learn the number of non-zeros before it while it still holds its data.  Round 1 tried that four ways and lost
+// to the cross-XCD hand-off; this form (bit-exact, selected with CT_BITMASK_ONEPASS=1 / 2, NOT the default) changes what made the
+// hand-off expensive there and pins down what is left:
+//   * a wave's tile is 4 wave-tiles = 16 KB (1024 units) held in registers: 4x fewer hand-offs, ~256 KB of tile data in flight per CU;
+//   * no atomics, no memset, no separate flags: every hand-off word is 64 bits, (generation << 32) | value, written by ONE
+//     system-scope store and read by system-scope loads.  The generation is unique per call (random start per process), so the
+//     workspace needs no clearing and stale words never look valid;
+//   * three levels without a completion counter: tile t = 64 g + j publishes count[t]; the group's last tile has summed the whole
+//     group once its in-group wait ends and publishes S[g] THEN (before its own wait for the group prefix: publishing after it
+//     chained the 128 groups, 188 us); the group's first tile turns S[0..g) into the group prefix GP[g] for the other 63 (when
+//     every tile read the sums, 8192 polling waves hammered the same 16 cache lines: 78 us).
+// Dependencies only point to lower tiles = the same or an earlier workgroup, which the hardware has already dispatched: the wait
+// cannot deadlock whatever the residency.  It is bounded anyway; a wave that gives up leaves *total at the -1 the first tile
+// wrote there and the host-side wrapper falls back to count / scan / scatter.
+// Measured at 8192^2 (per-tile time stamps, CT_BITMASK_OP_NOWAIT=3): 65-71 us against 70 us for the two kernels and 47 us for
+// this kernel with the wait removed.  A tile lives ~27 us: load 5-8 (all 4096 resident tiles load at once), wait 11, scatter 7.
+// The wait is three dependent hops (count -> S -> GP -> tile) of 4-5 us each — the latency of a system-scope store becoming
+// visible to a system-scope load under a 6 TB/s stream; it does not depend on the polling rate (6 to 48 polls per tile: same
+// time) nor on pacing the first wave of workgroups (CT_BITMASK_OP_PACE: the loads then complete in tile order, the hops cost the
+// same).  With 4096 resident tiles x 16 KB and a 27 us lifetime the kernel moves 2.5 TB/s, not 6; to win, a hop has to cost
+// ~1 us, which on this part means staying inside one XCD's L2 — and the workgroup -> XCD placement that would allow it is not
+// something a kernel can rely on.
+constexpr int kOpWT = 4;                       // wave-tiles per tile
+constexpr int kOpTileUnits = kOpWT * kWT;      // 1024 units = 16 KB
+constexpr int kOpMaxGroups = 128;              // two 64-lane loads of group sums
+constexpr int kOpSpinLimit = 1 << 16;          // x ~1 us per poll: gives up long before a driver timeout
+
+// hand-off words travel at system scope: the store writes through to memory, the loads bypass the per-XCD L2s.  (Agent scope is
+// compiled to the same sc1 accesses on this multi-XCD part and measured identical.  An XCD-local variant — groups pinned to one XCD,
+// sc0-only accesses that meet in that XCD's L2 — resolved a hop in ~1.5 us instead of ~4.5 us where it worked, but workgroup b does
+// NOT reliably run on XCD b % 8 once slots are recycled, and waves that landed elsewhere polled stale lines until their bounded
+// wait gave up: dropped.)
+__device__ __forceinline__ void op_store(unsigned long long* slot, unsigned long long v) {
+    __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long op_load(const unsigned long long* slot) {
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ void op_backoff(int mode) {  // s_sleep takes an immediate: a few fixed steps (units of 64 clocks)
+    if (mode <= 0) __builtin_amdgcn_s_sleep(2);
+    else if (mode == 1) __builtin_amdgcn_s_sleep(8);
+    else if (mode == 2) __builtin_amdgcn_s_sleep(32);
+    else __builtin_amdgcn_s_sleep(127);
+}
+
+__global__ __launch_bounds__(kBlock) void flat16_onepass_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows,
+                                                                uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
+                                                                int mask_dwords, int64_t* __restrict__ row_offsets, int64_t* __restrict__ total_out,
+                                                                unsigned long long* __restrict__ tile_cnt, unsigned long long* __restrict__ group_sum,
+                                                                unsigned long long* __restrict__ group_pre, uint32_t gen, int debug_nowait, int sleep_mode, int pace_q8,
+                                                                int pace_wgs) {
+    constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile (+ phase shift)
+    constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
+    __shared__ __attribute__((aligned(16))) uint16_t s_val[kBlock / 64][kSlab];
+    __shared__ __attribute__((aligned(16))) uint8_t s_m[kBlock / 64][kWT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t b = blockIdx.x;
+    const int64_t tile = (int64_t)b * 4 + wave;  // dependencies only point to lower tiles = the same or an earlier workgroup
+    const int g = (int)(tile >> 6), jg = (int)(tile & 63);
+    const int64_t wt0 = tile * kOpWT;
+    if (wt0 * kWT >= units) return;  // wave-uniform
+    const int64_t ntiles = (units + kOpTileUnits - 1) / kOpTileUnits;
+    const int j_last = (int)((ntiles - ((int64_t)g << 6)) < 64 ? (ntiles - ((int64_t)g << 6)) - 1 : 63);  // last existing tile of the group
+    // Paced start.  The first wave of workgroups (every slot of the chip) would otherwise issue 67 MB of loads at once: they all
+    // complete together ~10-16 us later, all wait for their prefix together and all scatter together — load, hand-off and store
+    // phases in lockstep, memory idle two thirds of the time (measured: 67 us).  Delaying workgroup b by b x (its tile bytes /
+    // the HBM rate) makes the data arrive in tile order at the rate the memory delivers it; later workgroups inherit the stagger
+    // from the slots they take over.  pace_q8 = delay per workgroup in 1/256 of an s_sleep unit (64 clocks).
+    if (pace_q8 > 0 && (int)b < pace_wgs) {
+        const int n = (int)(((int64_t)b * pace_q8) >> 12);  // s_sleep(16) steps
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    unsigned long long* dbg = debug_nowait == 3 ? group_pre + kOpMaxGroups + 4 + tile * 4 : nullptr;  // per-tile time stamps (debug)
+    if (dbg && lane == 0) dbg[0] = wall_clock64();
+    // ---- phase 1: the tile into registers, bitmask out, count published
+    u32x4 data[kOpWT][4];
+#pragma unroll
+    for (int j = 0; j < kOpWT; ++j) load_wt(x, units, wt0 + j, lane, data[j]);
+    uint32_t mpack[kOpWT];  // the four mask bytes of a wave-tile (unit i*64 + lane in byte i)
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kOpWT; ++j) {
+        const int64_t wt = wt0 + j;
+        mpack[j] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t m = nz_mask16(data[j][i], is_float);
+            mpack[j] |= m << (8 * i);
+            cnt += __popc(m);
+        }
+        if (wt * kWT < units) {
+            if (mask_dwords) {
+                // same-wave LDS operations execute in order: no barrier
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s_m[wave][i * 64 + lane] = (uint8_t)(mpack[j] >> (8 * i));
+                const uint32_t d = reinterpret_cast<const uint32_t*>(s_m[wave])[lane];
+                const int64_t u = wt * kWT + 4 * lane;
+                if (u < units) *reinterpret_cast<uint32_t*>(bitmask + u) = d;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t u = wt * kWT + i * 64 + lane;
+                    if (u < units) bitmask[u] = (uint8_t)(mpack[j] >> (8 * i));
+                }
+            }
+        }
+    }
+    const int tile_total = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
+    // failure protocol: the first tile marks the total invalid (write-through, long before the last tile can finish); a kernel that
+    // gave up never overwrites it
+    if (tile == 0 && lane == 0 && total_out) __hip_atomic_store(total_out, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) op_store(tile_cnt + tile, ((unsigned long long)gen << 32) | (uint32_t)tile_total);
+    // ---- phase 2: look-back.  lanes < j watch the earlier tiles of this group, lanes < g (and < g - 64) the earlier groups' sums
+    int64_t run;
+    const unsigned long long t_wait0 = wall_clock64();
+    if (dbg && lane == 0) dbg[1] = t_wait0;
+    int dbg_spins = 0;
+    if (debug_nowait == 1) {  // timing experiment only (wrong positions): what the kernel costs without any hand-off
+        run = tile * 4096;
+    } else if (jg == 0) {
+        // the group's first tile turns the earlier groups' sums into the group's exclusive prefix, for itself and for the other 63:
+        // only 128 tiles ever read the sum array (when every tile did, 8192 polling waves hammered the same 16 cache lines — one
+        // memory channel — and the kernel took 78 us)
+        const bool need_s0 = lane < g, need_s1 = lane + 64 < g;
+        const uint32_t want = (need_s0 ? 1u : 0u) | (need_s1 ? 2u : 0u);
+        uint32_t have = 0, ps = 0;
+        const unsigned long long* ps0_addr = group_sum + (need_s0 ? lane : 0);
+        const unsigned long long* ps1_addr = group_sum + (need_s1 ? 64 + lane : 0);
+        int spins = 0;
+        bool ok = g == 0;
+        while (!ok && spins++ < kOpSpinLimit) {
+            ++dbg_spins;
+            // only the lanes that still miss a word issue a load: every poll is a system-scope request that competes with the data stream
+            unsigned long long v0 = 0, v1 = 0;
+            if (need_s0 && !(have & 1u)) v0 = op_load(ps0_addr);
+            if (need_s1 && !(have & 2u)) v1 = op_load(ps1_addr);
+            if (need_s0 && !(have & 1u) && (uint32_t)(v0 >> 32) == gen) { ps += (uint32_t)v0; have |= 1u; }
+            if (need_s1 && !(have & 2u) && (uint32_t)(v1 >> 32) == gen) { ps += (uint32_t)v1; have |= 2u; }
+            ok = __builtin_amdgcn_ballot_w64(have != want) == 0;
+            if (!ok) op_backoff(sleep_mode);
+        }
+        if (!ok) return;  // cannot happen by construction; never hang the GPU on a bug: *total_out stays -1 and the caller falls back
+        run = ps;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) run += __shfl_xor(run, d, 64);
+        // 40 bits of prefix under the 24 low bits of the generation: enough for 2^40 non-zeros before a group
+        if (lane == 0) op_store(group_pre + g, ((unsigned long long)(gen & 0xffffffu) << 40) | (unsigned long long)run);
+        if (j_last == 0 && lane == 0) op_store(group_sum + g, ((unsigned long long)gen << 32) | (uint32_t)tile_total);  // a one-tile group
+    } else {
+        // lanes < j watch the earlier counts of the group, lane 63 the group's prefix
+        const bool need_c = lane < jg, need_p = lane == 63;
+        const unsigned long long* addr = need_p ? group_pre + g : tile_cnt + ((int64_t)g << 6) + (need_c ? lane : 0);
+        uint64_t mine = 0;
+        bool got = !(need_c || need_p), sum_published = jg != j_last;
+        int spins = 0;
+        bool ok;
+        do {
+            ++dbg_spins;
+            if (!got) {
+                const unsigned long long v = op_load(addr);
+                if (need_p) { if ((uint32_t)(v >> 40) == (gen & 0xffffffu)) { mine = v & 0xffffffffffull; got = true; } }
+                else if ((uint32_t)(v >> 32) == gen) { mine = (uint32_t)v; got = true; }
+            }
+            // the last tile of a group publishes the group's sum as soon as the group's counts are in — NOT after its wait for the
+            // group's prefix, which would chain the 128 groups one hand-off after the other (measured: 188 us)
+            if (!sum_published && __builtin_amdgcn_ballot_w64(need_c && !got) == 0) {
+                int64_t gs = need_c ? (int64_t)mine : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) gs += __shfl_xor(gs, d, 64);
+                if (lane == 0) op_store(group_sum + g, ((unsigned long long)gen << 32) | (uint32_t)(gs + tile_total));  // read on other XCDs
+                sum_published = true;
+            }
+            ok = __builtin_amdgcn_ballot_w64(!got) == 0;
+            if (!ok) op_backoff(sleep_mode);
+        } while (!ok && ++spins < kOpSpinLimit);
+        if (!ok) return;
+        run = (int64_t)mine;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) run += __shfl_xor(run, d, 64);
+    }
+    if (dbg && lane == 0) dbg[2] = wall_clock64();
+    if (debug_nowait == 2 && lane == 0) {  // hand-off statistics: polls, waiting time (100 MHz ticks) summed and maximal
+        const unsigned long long dt = wall_clock64() - t_wait0;
+        atomicAdd(group_pre + kOpMaxGroups, (unsigned long long)dbg_spins);
+        atomicAdd(group_pre + kOpMaxGroups + 1, dt);
+        atomicMax(group_pre + kOpMaxGroups + 2, dt);
+    }
+    // ---- phase 3: scatter the four wave-tiles with a running prefix (the body of flat16_scatter_kernel)
+    uint16_t* slab = s_val[wave];
+    bool last_here = false;
+#pragma unroll
+    for (int j = 0; j < kOpWT; ++j) {
+        const int64_t wt = wt0 + j;
+        if (wt * kWT >= units) break;  // wave-uniform
+        last_here = (wt + 1) * kWT >= units;
+        uint32_t mm[4], rank[4];
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mm[i] = (mpack[j] >> (8 * i)) & 0xffu;
+            const int c = __popc(mm[i]);
+            const int incl = wave_incl_scan(c);
+            rank[i] = (uint32_t)(incl - c + total);
+            total += __builtin_amdgcn_readlane(incl, 63);
+        }
+        {
+            const int64_t ubeg = wt * kWT, uend = ubeg + kWT;
+            for (int64_t r = (ubeg + upr - 1) / upr; r < rows && r * upr < uend; ++r) {
+                const int q = (int)(r * upr - ubeg);
+                const int i = q >> 6, l = q & 63;
+                const uint32_t rk = i == 0 ? rank[0] : (i == 1 ? rank[1] : (i == 2 ? rank[2] : rank[3]));
+                if (lane == l) row_offsets[r] = run + rk;
+            }
+        }
+        const int shift = (int)(run & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t ws[4] = {data[j][i].x, data[j][i].y, data[j][i].z, data[j][i].w};
+            uint32_t pos = (uint32_t)shift + rank[i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool keep = (mm[i] >> k) & 1u;
+                slab[keep ? pos : (uint32_t)(kSlabData + lane)] = (uint16_t)((k & 1) ? (ws[k >> 1] >> 16) : ws[k >> 1]);
+                pos += keep ? 1u : 0u;
+            }
+        }
+        const int64_t end = run + total;
+        const int64_t e0 = run - shift;
+        const int64_t body_lo = (run + 7) & ~(int64_t)7, body_hi = end & ~(int64_t)7;
+        if (body_hi > body_lo) {
+            const int nvec = (int)((body_hi - body_lo) >> 3);
+            const int v0 = (int)((body_lo - e0) >> 3);
+            for (int v = lane; v < nvec; v += 64) {
+                const int64_t gi = body_lo + ((int64_t)v << 3);
+                if (gi + 8 <= capacity) stream_store16(vout + gi, reinterpret_cast<const u32x4*>(slab)[v0 + v]);
+                else for (int t = 0; t < 8; ++t) if (gi + t < capacity) vout[gi + t] = slab[gi + t - e0];
+            }
+            for (int64_t gi = run + lane; gi < body_lo; gi += 64) if (gi < capacity) vout[gi] = slab[gi - e0];
+            for (int64_t gi = body_hi + lane; gi < end; gi += 64) if (gi < capacity) vout[gi] = slab[gi - e0];
+        } else {
+            for (int64_t gi = run + lane; gi < end; gi += 64) if (gi < capacity) vout[gi] = slab[gi - e0];
+        }
+        run = end;
+    }
+    if (last_here && lane == 0 && total_out) __hip_atomic_store(total_out, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (dbg && lane == 0) dbg[3] = wall_clock64();
+}
+
 // ------------------------------------------------------------------------- 2:4
 // magnitude key: |x| as an orderable integer; NaN sorts largest (as torch.topk does)
 template <int ES>
@@ -1006,7 +1260,9 @@ int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const 
 int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0) return 16;
     const Flat16Plan p = flat16_plan(rows, cols);
-    const int64_t flat = p.nblocks * 8 + p.nblocks * 4 * 4 + 8 * kMaxChunks;  // block totals (int64) + span totals (int32) + chunk totals
+    int64_t flat = p.nblocks * 8 + p.nblocks * 4 * 4 + 8 * kMaxChunks;  // block totals (int64) + span totals (int32) + chunk totals
+    const int64_t onepass = (cdiv64(p.units, kOpTileUnits) * 5 + 2 * kOpMaxGroups + 4) * 8;  // tile counts + group sums + group prefixes (+ debug statistics / time stamps)
+    if (onepass > flat) flat = onepass;
     const int64_t generic = (rows + 1) * 8;                  // row counts of the count / scan / scatter form
     return (flat > generic ? flat : generic) + 16;
 }
@@ -1025,6 +1281,36 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                (long long)need);
     CT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace must be 8-byte aligned");
     CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
+    // 0: two kernels (x read twice; default — the one-pass form is bit-exact but not faster, see above), 1: one pass for tensors of at
+    // least 4 MB, 2: one pass whenever the tile count fits (tests)
+    static const int onepass_mode = []() { const char* e = std::getenv("CT_BITMASK_ONEPASS"); return e ? std::atoi(e) : 0; }();
+    if (es == 2 && cols % 8 == 0 && aligned16(x) && onepass_mode) {
+        const int64_t units = rows * (cols / 8);
+        const int64_t tiles = cdiv64(units, kOpTileUnits);
+        // up to 128 groups of 64 tiles (8192^2 elements); below ~4 MB the two-kernel form's launches are not what costs
+        if (tiles <= (int64_t)kOpMaxGroups * 64 && (onepass_mode >= 2 || tiles >= 256)) {
+            // unique per call in this process, and started at a random point so that words left in recycled device memory by another
+            // process do not carry a matching tag either
+            static const int sleep_mode = []() { const char* e = std::getenv("CT_BITMASK_OP_SLEEP"); return e ? std::atoi(e) : 1; }();
+            static const int debug_nowait = []() { const char* e = std::getenv("CT_BITMASK_OP_NOWAIT"); return e ? std::atoi(e) : 0; }();
+            static std::atomic<uint32_t> generation{[]() {
+                std::random_device rd;
+                return (uint32_t)rd() ^ (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count();
+            }()};
+            const uint32_t gen = generation.fetch_add(1u) + 1u;
+            unsigned long long* tile_cnt = static_cast<unsigned long long*>(workspace);
+            unsigned long long* group_sum = tile_cnt + tiles;
+            unsigned long long* group_pre = group_sum + kOpMaxGroups;
+            const int mask_dwords = (units % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0);
+            if (debug_nowait == 2) (void)hipMemsetAsync(group_pre + kOpMaxGroups, 0, 32, as_stream(stream));
+            static const int pace_q8 = []() { const char* e = std::getenv("CT_BITMASK_OP_PACE"); return e ? std::atoi(e) : 0; }();
+            static const int pace_wgs = []() { const char* e = std::getenv("CT_BITMASK_OP_PACE_WGS"); return e ? std::atoi(e) : 1024; }();
+            hipLaunchKernelGGL(flat16_onepass_kernel, dim3((unsigned)cdiv64(tiles, 4)), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x),
+                               float_kind(dt), units, cols / 8, rows, static_cast<uint16_t*>(values), values_capacity, bitmask, mask_dwords, row_offsets,
+                               total, tile_cnt, group_sum, group_pre, gen, debug_nowait, sleep_mode, pace_q8, pace_wgs);
+            CT_LAUNCH_CHECK("ct_bitmask_compress[onepass]");
+        }
+    }
     if (es == 2 && cols % 8 == 0 && aligned16(x)) {
         const Flat16Plan p = flat16_plan(rows, cols);
         int64_t* block_tot = static_cast<int64_t*>(workspace);

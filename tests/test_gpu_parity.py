@@ -537,6 +537,35 @@ def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt, shape):
     assert torch.equal(comp.cpu().float(), comp_ref.cpu().float()) and torch.equal(meta.cpu(), meta_ref.cpu())
 
 
+def test_bitmask_one_pass_kernel_matches_two_pass(tmp_path):
+    """the experimental one-pass sparse compress (decoupled look-back, CT_BITMASK_ONEPASS=2; the knobs are read once per process, hence
+    the subprocess): values, bitmask, row offsets and the total bit-identical to count / scan / scatter for ragged, empty, dense shapes"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from compressed_tensors_amd import codec
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(5)
+for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, torch.float16), (3000, 1000, 0.9, torch.bfloat16), (513, 8200, 0.5, torch.bfloat16),
+                         (2048, 4096, 0.0, torch.bfloat16), (1024, 4096, 1.0, torch.float16), (8192, 8192, 0.5, torch.bfloat16), (7, 8, 0.5, torch.int16)):
+    w = torch.randn(r, c, device=dev, generator=g)
+    w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
+    w = (w * 100).to(dt) if dt == torch.int16 else w.to(dt)
+    for rep in range(3):  # a fresh generation tag per call over recycled workspace memory
+        v, bm, ro = codec.bitmask_compress(w)
+        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
+        assert torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2), (r, c, dens, rep)
+print("ONEPASS_OK")
+""" % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, CT_BITMASK_ONEPASS="2"))
+    assert r.returncode == 0 and "ONEPASS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ----------------------------------------------------------------------------- modules / staging
 def test_compress_decompress_module(cta, dev):
     """reference tests/test_compressors/test_compress_decompress_module.py:24-127"""

@@ -33,3 +33,67 @@ elif what == "rtn8":
 elif what == "qp":
     r = B.qparams_leg(dev)
     print(json.dumps({"U": os.environ.get("CT_QP_U"), "us": r["us"], "fused_us": r["fused_with_compress"]["us"]}))
+elif what == "bm1":
+    # one-pass vs two-kernel sparse compress: correctness on several shapes / densities, then timing at 8192^2
+    from compressed_tensors_amd import codec
+    import time
+    res = {"mode": os.environ.get("CT_BITMASK_ONEPASS")}
+    g = torch.Generator(device=dev).manual_seed(5)
+    ok = True
+    for (r, c, dens) in ((8192, 8192, 0.5), (4096, 4096, 0.5), (1024, 2048, 0.1), (3000, 1000, 0.9), (513, 8200, 0.5), (8192, 8192, 0.0), (2048, 4096, 1.0)):
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
+        v, bm, ro = codec.bitmask_compress(w)
+        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
+        same = torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2)
+        ok = ok and same
+        if not same:
+            res.setdefault("bad", []).append([r, c, dens, int(v.numel()), int(v2.numel())])
+    res["equal_to_two_pass"] = ok
+    r = B.bitmask_leg(dev)
+    res.update(compress_us=r["compress_us"], ok=r["round_trip_bit_exact"])
+    print(json.dumps(res))
+elif what == "bm2":
+    r = B.bitmask_leg(dev)
+    print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("CT_BITMASK")}, "compress_us": r["compress_us"], "ok": r["round_trip_bit_exact"]}))
+elif what == "bm3":
+    # hand-off statistics of the one-pass kernel (CT_BITMASK_OP_NOWAIT=2)
+    from compressed_tensors_amd import _lib
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    N = B.N
+    g = torch.Generator(device=dev).manual_seed(7)
+    w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+    w = w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0)
+    ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+    vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), ws[-1:].data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        torch.cuda.synchronize()
+        tiles = N * N // 8 // 1024
+        st = ws[tiles + 256: tiles + 259].tolist()
+        print(json.dumps({"tiles": tiles, "polls_per_tile": st[0] / tiles, "avg_wait_us": st[1] / tiles / 100.0, "max_wait_us": st[2] / 100.0, "total": int(ws[-1].item())}))
+elif what == "bm4":
+    # per-tile time stamps of the one-pass kernel (CT_BITMASK_OP_NOWAIT=3)
+    from compressed_tensors_amd import _lib
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    N = B.N
+    g = torch.Generator(device=dev).manual_seed(7)
+    w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+    w = w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0)
+    ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+    vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+    tiles = N * N // 8 // 1024
+    for rep in range(3):
+        lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), ws[-1:].data_ptr(), ws.data_ptr(), ws_bytes, stream)
+        torch.cuda.synchronize()
+    st = ws[tiles + 260: tiles + 260 + 4 * tiles].reshape(tiles, 4).cpu().double()
+    t0 = st[:, 0].min()
+    st = (st - t0) / 100.0
+    import numpy as np
+    a = st.numpy()
+    print("kernel span us", a[:, 3].max())
+    for t in list(range(0, 64, 9)) + list(range(64, tiles, 509)):
+        print(t, "start %.1f loaded %.1f resolved %.1f done %.1f" % tuple(a[t]))
+    print("median load %.1f wait %.1f scatter %.1f" % (np.median(a[:, 1] - a[:, 0]), np.median(a[:, 2] - a[:, 1]), np.median(a[:, 3] - a[:, 2])))
