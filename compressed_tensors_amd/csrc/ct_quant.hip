@@ -43,9 +43,12 @@ __global__ __launch_bounds__(kBlock) void quant_units_kernel(QParams p) {
             }
             const bool uni = unit_uniform(p.L, c0, n);
             SZ sz = load_sz_q<XDT>(p, srow, c0);
-            // one reciprocal per unit instead of eight divides when x, T and the scale are all bf16
-            const bool can_rcp = XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16;
-            float rs = (can_rcp && uni) ? bf16_fast_rcp(sz.s) : 0.0f;
+            // one reciprocal per unit instead of eight divides when x, T and the scale are all bf16 — or all fp16 (+ a Newton step) when
+            // the results are INTEGER codes: below 2^-13 the fp16 shortcut can differ from the IEEE quotient in the last subnormal
+            // place, which no integer code sees but a float-typed result can (the sign of a zero after `+ zero_point`)
+            const bool f16_ok = XDT == CT_F16 && TDT == CT_F16 && p.sdt == CT_F16 && MODE == MODE_Q && p.fkind == 0 && (p.odt == CT_I8 || p.odt == CT_I32);
+            const bool can_rcp = !p.gscale && ((XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16) || f16_ok);
+            float rs = (can_rcp && uni) ? (TDT == CT_BF16 ? bf16_fast_rcp(sz.s) : f16_newton_rcp(sz.s)) : 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (k < n) {
@@ -738,7 +741,7 @@ __device__ __forceinline__ void f8_quant_lane(const W4Params& p, int64_t g) {
             s = load_as_f<DT>(p.scale, si);
             z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
             const float as = __builtin_fabsf(s);
-            fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+            fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);  // (fp16 keeps the divide: a float8 code carries the sign of a zero)
             rs = 1.0f / s;
         }
         // the zero-point add is kept even for z == 0: it turns a -0.0 quotient into +0.0, as upstream's `+=`
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, fl
             const int64_t si = w4_scale_index(p, u);
             const float s = load_as_f<DT>(p.scale, si);
             const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype) == zp.to(scale.dtype) here
-            const float rs = DT == CT_BF16 ? bf16_fast_rcp(s) : 0.0f;
+            const float rs = DT == CT_BF16 ? bf16_fast_rcp(s) : 0.0f;  // (fp16: float-typed results, see quant_units_kernel)
             const uint32_t ws[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
             float v[8];
 #pragma unroll

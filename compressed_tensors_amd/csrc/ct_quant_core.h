@@ -31,10 +31,30 @@ __device__ __forceinline__ float bf16_fast_rcp(float s) {
     return ((as >= 0x1p-64f) && (as <= 0x1p64f)) ? 1.0f / s : 0.0f;
 }
 
+// reciprocal of an fp16 scale, or 0 outside the range in which reciprocal + one Newton step is proven to give the fp16 rounding of
+// the IEEE quotient (ct_selftest_f16_div: every fp16 x, quotients below 2^-13 excepted — they all end as code / value 0)
+__device__ __forceinline__ float f16_newton_rcp(float s) {
+    const float as = __builtin_fabsf(s);
+    return ((as >= 0x1p-14f) && (as <= 0x1p15f)) ? 1.0f / s : 0.0f;
+}
+
+// the quotient x / s before its rounding to T: IEEE divide, or the proven shortcut for T (rs = 0 selects the divide)
+template <int TDT>
+__device__ __forceinline__ float fast_quotient(float x, float s, float rs) {
+    if (rs == 0.0f) return x / s;
+    if constexpr (TDT == CT_F16) {
+        const float q0 = x * rs;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
+        return __builtin_isfinite(q0) ? q1 : q0;  // x = +-inf / NaN: the correction would turn inf into NaN
+    } else {
+        return x * rs;
+    }
+}
+
 template <int TDT>
 __device__ __forceinline__ float quant_core(float x, float s, bool has_zp, float zf, float qmin,
                                             float qmax, float rs = 0.0f, int fkind = 0) {
-    float t = round_to<TDT>(rs != 0.0f ? x * rs : x / s);  // IEEE-correct fp32 divide (or the proven bf16 shortcut), RNE to T
+    float t = round_to<TDT>(fast_quotient<TDT>(x, s, rs));  // IEEE-correct fp32 divide (or the proven bf16 / fp16 shortcut), RNE to T
     if (has_zp) t = round_to<TDT>(t + zf);
     t = clamp_nan(t, qmin, qmax);
     // INT: v_rndne_f32 (round half to even).  FLOAT 8-bit: tensor.to(float8_e4m3fn) (quant_args.py:463-486); the
