@@ -74,7 +74,7 @@ _local = threading.local()
 
 def _ring(device) -> _FlagRing:
     stream = _lib.stream_of_device(device)
-    key = (device.index, int(stream), threading.get_ident())
+    key = (stream.device_index, int(stream), threading.get_ident())
     ring = _rings.get(key)
     if ring is None:
         ring = _rings[key] = _FlagRing(device, stream)
