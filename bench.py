@@ -639,6 +639,25 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
     for (w, s, z, p, o) in keep:
         p.zero_(); o.zero_()
     best = timed(batched)
+    # the same checkpoint with an ASYMMETRIC scheme (W4A16_ASYM: int8 zero points, stored packed along rows): two launches per
+    # direction — the weights and all the zero points — instead of two per module
+    asym = []
+    for (w, _, _, p, o) in keep:
+        sa, za = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=False)
+        asym.append((sa, za, torch.empty((-(-w.shape[0] * 4 // 32), za.shape[1]), dtype=torch.int32, device=dev), torch.empty_like(za)))
+    cba = codec.W4Batch([(w, sa, za, p, w.shape[0], w.shape[1], GROUP) for (w, _, _, p, _), (sa, za, _, _) in zip(keep, asym)], "compress", torch.bfloat16)
+    dba = codec.W4Batch([(p, sa, zu, o, w.shape[0], w.shape[1], GROUP) for (w, _, _, p, o), (sa, _, _, zu) in zip(keep, asym)], "decompress", torch.bfloat16)
+
+    def batched_asym():
+        cba.launch(stream)
+        codec.zp4_batch([(za, zp_) for (_, za, zp_, _) in asym], "pack")
+        codec.zp4_batch([(zp_, zu) for (_, _, zp_, zu) in asym], "unpack")
+        dba.launch(stream)
+
+    t_asym = timed(batched_asym)
+    wa0, (sa0, za0, _, zu0) = keep[0][0], asym[0]
+    asym_ok = bool(torch.equal(zu0, za0) and torch.equal(keep[0][4], codec.fake_quantize_tensor(wa0, sa0, za0, num_bits=BITS, strategy="group", group_size=GROUP)))
+    batched()  # leave the symmetric results in the buffers for the check below
     total_bytes = sum(2 * (2 * r * c + 2 * r * (c // GROUP) + r * c // 2) for _, r, c in mods)
     w0, s0, z0, p0, o0 = keep[0]
     fq = codec.fake_quantize_tensor(w0, s0, z0, num_bits=BITS, strategy="group", group_size=GROUP)
@@ -648,6 +667,7 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
             "launches": "one ct_quant_pack_batch + one ct_unpack_dequant_batch per rank",
             "ms_whole_checkpoint": round(best * 1e3, 4), "GBps": round(total_bytes / best / 1e9, 1),
             "ms_whole_checkpoint_one_launch_per_module": round(t_loop * 1e3, 4),
+            "ms_whole_checkpoint_asymmetric": round(t_asym * 1e3, 4), "asymmetric_round_trip_equals_fake_quantize": asym_ok,
             "frac_of_hbm_peak_per_gpu": round(total_bytes / best / 1e9 / world / HBM_PEAK_GBPS, 4),
             "round_trip_equals_fake_quantize": bool(torch.equal(o0, fq))}
 

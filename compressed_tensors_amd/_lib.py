@@ -60,6 +60,8 @@ _PROTOTYPES = {
     "ct_w4_batch_plan": ([_P, _I, _I], _L),
     "ct_quant_pack_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
+    "ct_zp4_batch_plan": ([_P, _I], _L),
+    "ct_zp4_pack_dim0_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_q8_batch_plan": ([_P, _I, _I], _L),
     "ct_q8_quant_batch": ([_P, _I, _L, _I, _I, _I, _S], _I),
     "ct_q8_dequant_batch": ([_P, _I, _L, _I, _I, _S], _I),

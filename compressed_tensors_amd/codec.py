@@ -34,6 +34,7 @@ __all__ = [
     "W4Batch",
     "w4_batch_eligible",
     "q8_batch_group",
+    "zp4_batch",
     "cast_to_fp4",
     "pack_fp4_to_uint8",
     "unpack_fp4_from_uint8",
@@ -665,6 +666,29 @@ class W4Batch:
             call("ct_q8_quant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), self.bits, s)
         else:
             call("ct_q8_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), s)
+
+
+def zp4_batch(pairs, direction: str) -> None:
+    """`pack_to_int32(zp, 4, packed_dim=0)` ("pack": int8 (R, G) -> int32 (ceil(R / 8), G)) or its inverse ("unpack") for a list of
+    (src, dst) tensor pairs on one GPU in ONE launch (`ct_zp4_pack_dim0_batch`); dst tensors are allocated by the caller."""
+    assert direction in ("pack", "unpack")
+    pairs = list(pairs)
+    if not pairs:
+        return
+    import ctypes
+
+    arr = (_lib.W4Item * len(pairs))()
+    for it, (src, dst) in zip(arr, pairs):
+        unpacked = src if direction == "pack" else dst
+        it.src, it.dst = src.data_ptr(), dst.data_ptr()
+        it.rows, it.cols = int(unpacked.shape[0]), int(unpacked.shape[1])
+    blocks = int(_lib.load().ct_zp4_batch_plan(ctypes.cast(arr, ctypes.c_void_p), len(pairs)))
+    if blocks < 0:
+        raise ValueError(_lib.last_error())
+    dev = pairs[0][0].device
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    call("ct_zp4_pack_dim0_batch", table.data_ptr(), len(pairs), blocks, 0 if direction == "pack" else 1, _lib.stream_on(dev))
+    table.record_stream(torch.cuda.current_stream(dev))
 
 
 def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, group_size=None, g_idx=None):

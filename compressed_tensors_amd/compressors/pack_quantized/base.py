@@ -45,7 +45,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         return names
 
     @classmethod
-    def compress(cls, state_dict: dict, scheme, _prepacked=None) -> dict:
+    def compress(cls, state_dict: dict, scheme, _prepacked=None, _prezp=None) -> dict:
         """base.py:62-114"""
         state_dict = state_dict.copy()
         weight = state_dict.pop("weight")
@@ -70,13 +70,16 @@ class PackedQuantizationCompressor(BaseCompressor):
 
         if not weights.symmetric and enum_value(weights.strategy) in PACK_ZP_STRATS:
             assert zero_point is not None, "Asymmetric quant requires zero-point values"
-            zp8 = zero_point if zero_point.dtype is torch.int8 else zero_point.to(torch.int8)
-            state_dict["weight_zero_point"] = codec.pack_to_int32(zp8, weights.num_bits, packed_dim=0)
+            if _prezp is not None:
+                state_dict["weight_zero_point"] = _prezp  # packed by the batched launch of compress_modules
+            else:
+                zp8 = zero_point if zero_point.dtype is torch.int8 else zero_point.to(torch.int8)
+                state_dict["weight_zero_point"] = codec.pack_to_int32(zp8, weights.num_bits, packed_dim=0)
 
         return cls._remove_symmetric_zp(state_dict, scheme)
 
     @classmethod
-    def decompress(cls, state_dict: dict, scheme, _preweight=None) -> dict:
+    def decompress(cls, state_dict: dict, scheme, _preweight=None, _prezp=None) -> dict:
         """base.py:116-163"""
         state_dict = state_dict.copy()
         packed = state_dict.pop("weight_packed")
@@ -94,7 +97,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         if not weights.symmetric and enum_value(weights.strategy) in PACK_ZP_STRATS:
             assert zero_point is not None, "Asymmetric quant requires zero-point values"
             zp_shape = (*shape[:-1], scale.shape[-1])
-            zero_point = codec.unpack_from_int32(zero_point, weights.num_bits, zp_shape, packed_dim=0)
+            zero_point = _prezp if _prezp is not None else codec.unpack_from_int32(zero_point, weights.num_bits, zp_shape, packed_dim=0)
             state_dict["weight_zero_point"] = zero_point
 
         # dequantize() is called without args upstream: the strategy is inferred from the scale
@@ -157,24 +160,33 @@ class PackedQuantizationCompressor(BaseCompressor):
             entries, jobs = batches.setdefault((w.device, w.dtype), ([], []))
             entries.append((w, scale, zp, packed, rows, cols, group))
             jobs.append((m, sd, scheme, packed))
-        for (_, dtype), (entries, jobs) in batches.items():
+        for (device, dtype), (entries, jobs) in batches.items():
             codec.W4Batch(entries, "compress", dtype).launch()
-            for m, sd, scheme, packed in jobs:
-                replace_direct_state_dict(m, cls.compress(sd, scheme, _prepacked=packed))
+            # the zero points of the asymmetric modules: one more launch for all of them (pack_to_int32(zp, 4, packed_dim=0))
+            zps = {}
+            for i, (m, sd, scheme, packed) in enumerate(jobs):
+                zp = sd.get("weight_zero_point")
+                if not scheme.weights.symmetric and enum_value(scheme.weights.strategy) in PACK_ZP_STRATS and zp is not None and zp.dtype is torch.int8 \
+                        and zp.dim() == 2 and zp.is_contiguous():
+                    zps[i] = (zp, torch.empty((math.ceil(zp.shape[0] * 4 / 32), zp.shape[1]), dtype=torch.int32, device=device))
+            codec.zp4_batch(zps.values(), "pack")
+            for i, (m, sd, scheme, packed) in enumerate(jobs):
+                replace_direct_state_dict(m, cls.compress(sd, scheme, _prepacked=packed, _prezp=zps[i][1] if i in zps else None))
                 m.quantization_status = QuantizationStatus.COMPRESSED
 
     @classmethod
     def _batch_decompress(cls, state_dicts, schemes):
-        """weights of every eligible state dict from ONE launch (None for the others)"""
-        outs, batches = [None] * len(state_dicts), {}
+        """(weight, unpacked zero point or None) of every eligible state dict from ONE launch (+ one for the packed zero points of the
+        asymmetric ones); (None, None) for the others"""
+        outs, batches = [(None, None)] * len(state_dicts), {}
         for i, (sd, scheme) in enumerate(zip(state_dicts, schemes)):
             packed, scale, shape_t = sd.get("weight_packed"), sd.get("weight_scale"), sd.get("weight_shape")
+            zp_packed = sd.get("weight_zero_point")
             wa = scheme.weights
             # anything unusual (a wrongly typed weight_packed, which must raise as upstream; a zero point kept next to a
             # symmetric scheme, which the per-module path applies; misaligned views) goes through `decompress`
             ok = (packed is not None and scale is not None and shape_t is not None and packed.is_cuda and packed.is_contiguous()
-                  and packed.dtype == torch.int32 and packed.data_ptr() % 16 == 0
-                  and wa.symmetric and sd.get("weight_zero_point") is None and sd.get("weight_g_idx") is None)
+                  and packed.dtype == torch.int32 and packed.data_ptr() % 16 == 0 and sd.get("weight_g_idx") is None)
             if not ok:
                 continue
             shape = tuple(int(v) for v in shape_t.tolist())
@@ -182,24 +194,37 @@ class PackedQuantizationCompressor(BaseCompressor):
                 continue
             # decompress infers the strategy from the scale shape (forward.py:99-130): (R, 1) channel, (R, G) group
             strategy, group = ("channel", shape[-1]) if scale.shape[-1] == 1 else ("group", shape[-1] // scale.shape[-1])
+            asym = not wa.symmetric and enum_value(wa.strategy) in PACK_ZP_STRATS
+            zp = None
+            if asym:
+                want = (math.ceil(shape[0] * 4 / 32), scale.shape[-1])
+                if not (zp_packed is not None and zp_packed.dtype == torch.int32 and tuple(zp_packed.shape) == want and zp_packed.is_contiguous()
+                        and zp_packed.device == packed.device and int(wa.num_bits) == 4):
+                    continue
+                zp = torch.empty((shape[0], scale.shape[-1]), dtype=torch.int8, device=packed.device)  # filled by the batched unpack below
+            elif zp_packed is not None:
+                continue
             if not (tuple(packed.shape) == (shape[0], shape[1] // 8)
-                    and codec.w4_batch_eligible(shape, scale.dtype, scale, None, num_bits=int(wa.num_bits), strategy=strategy,
+                    and codec.w4_batch_eligible(shape, scale.dtype, scale, zp, num_bits=int(wa.num_bits), strategy=strategy,
                                                 group_size=group, device=packed.device)):
                 continue
             out = torch.empty(shape, dtype=scale.dtype, device=packed.device)
-            entries, slots = batches.setdefault((packed.device, scale.dtype), ([], []))
-            entries.append((packed, scale, None, out, shape[0], shape[1], group))
-            slots.append((i, out))
-        for (_, dtype), (entries, slots) in batches.items():
+            entries, slots, zps = batches.setdefault((packed.device, scale.dtype), ([], [], []))
+            entries.append((packed, scale, zp, out, shape[0], shape[1], group))
+            slots.append((i, out, zp))
+            if asym:
+                zps.append((zp_packed, zp))
+        for (_, dtype), (entries, slots, zps) in batches.items():
+            codec.zp4_batch(zps, "unpack")
             codec.W4Batch(entries, "decompress", dtype).launch()
-            for i, out in slots:
-                outs[i] = out
+            for i, out, zp in slots:
+                outs[i] = (out, zp)
         return outs
 
     @classmethod
     def decompress_many(cls, state_dicts, scheme) -> list:
         pre = cls._batch_decompress(state_dicts, [scheme] * len(state_dicts))
-        return [cls.decompress(sd, scheme, _preweight=w) for sd, w in zip(state_dicts, pre)]
+        return [cls.decompress(sd, scheme, _preweight=w, _prezp=z) for sd, (w, z) in zip(state_dicts, pre)]
 
     @classmethod
     def decompress_modules(cls, modules) -> None:
@@ -209,8 +234,8 @@ class PackedQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         sds = [get_direct_state_dict(m) for m in modules]
         pre = cls._batch_decompress(sds, [m.quantization_scheme for m in modules])
-        for m, sd, w in zip(modules, sds, pre):
-            replace_direct_state_dict(m, cls.decompress(sd, m.quantization_scheme, _preweight=w))
+        for m, sd, (w, z) in zip(modules, sds, pre):
+            replace_direct_state_dict(m, cls.decompress(sd, m.quantization_scheme, _preweight=w, _prezp=z))
             m.quantization_status = QuantizationStatus.DECOMPRESSED
 
     @classmethod

@@ -204,6 +204,52 @@ __global__ __launch_bounds__(kBlock) void unpack_dim0_kernel(const int32_t* __re
         }
 }
 
+// batched zero-point packing (4 bits, packed along rows): ONE launch for the zero points of a whole checkpoint — the
+// `pack_to_int32(zp, bits, packed_dim=0)` / `unpack_from_int32(..., packed_dim=0)` calls of PackedQuantizationCompressor
+// (compressors/pack_quantized/base.py:107-110,147-153) that the per-module loop issues once per asymmetric module.  Table type
+// and workgroup search as in the W4 batch (ct_quant.hip); item = (src, dst, rows, cols) of the UNPACKED zero-point matrix.
+__device__ __forceinline__ const ct_w4_item& zp_batch_find(const ct_w4_item* __restrict__ items, int n, int64_t block) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    }
+    return items[lo];
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(kBlock) void zp4_dim0_batch_kernel(const ct_w4_item* __restrict__ items, int n) {
+    const ct_w4_item& it = zp_batch_find(items, n, blockIdx.x);
+    const int64_t rows = it.rows, cols = it.cols;
+    const int64_t idx = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;  // (row group, column): consecutive lanes = consecutive columns
+    if (idx >= it.units) return;
+    const int64_t g = idx / cols, c = idx - g * cols;
+    const int64_t packed_rows = (rows * 4 + 31) >> 5;
+    uint32_t words[5] = {0u, 0u, 0u, 0u, 0u};
+    if (PACK) {
+        const int8_t* q = static_cast<const int8_t*>(it.src);
+        int32_t* out = static_cast<int32_t*>(it.dst);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int64_t r = (g << 5) + i;
+            if (r < rows) pack_insert<4>(words, i, (int)q[r * cols + c]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (g * 4 + j < packed_rows) out[(g * 4 + j) * cols + c] = (int32_t)words[j];
+    } else {
+        const int32_t* p = static_cast<const int32_t*>(it.src);
+        int8_t* out = static_cast<int8_t*>(it.dst);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) words[j] = (g * 4 + j < packed_rows) ? (uint32_t)p[(g * 4 + j) * cols + c] : 0u;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int64_t r = (g << 5) + i;
+            if (r < rows) out[r * cols + c] = (int8_t)unpack_extract<4>(words, i);
+        }
+    }
+}
+
 static dim3 grid_rows(int64_t rows, int64_t items_per_row) {
     int64_t gx = cdiv64(items_per_row, kBlock);
     if (gx < 1) gx = 1;
@@ -291,6 +337,37 @@ int ct_unpack_int32(const int32_t* p, int64_t rows, int64_t words, int64_t p_row
     CT_BITS_SWITCH(bits, hipLaunchKernelGGL((unpack_rows_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), p, rows, words,
                                             p_row_stride, cols, out, vec));
     CT_LAUNCH_CHECK("ct_unpack_int32");
+}
+
+int64_t ct_zp4_batch_plan(ct_w4_item* items, int n) {
+    if (n < 0 || (n > 0 && items == nullptr)) {
+        set_error("ct_zp4_batch_plan: bad arguments");
+        return -1;
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ct_w4_item& it = items[i];
+        if (!(it.rows > 0 && it.cols > 0 && it.src && it.dst)) {
+            set_error("ct_zp4_batch_plan: item %d has an empty shape or a NULL pointer", i);
+            return -1;
+        }
+        it.units = cdiv64(it.rows, 32) * it.cols;  // one lane per (32-row group, column)
+        it.first_block = blocks;
+        blocks += cdiv64(it.units, kBlock);
+    }
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("ct_zp4_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
+        return -1;
+    }
+    return blocks;
+}
+
+int ct_zp4_pack_dim0_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int direction, ct_stream_t stream) {
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31) && (direction == 0 || direction == 1), "bad batch arguments");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    if (direction == 0) hipLaunchKernelGGL(zp4_dim0_batch_kernel<true>, dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    else hipLaunchKernelGGL(zp4_dim0_batch_kernel<false>, dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    CT_LAUNCH_CHECK("ct_zp4_pack_dim0_batch");
 }
 
 int ct_pack_int32_dim0(const int8_t* q, int64_t rows, int64_t cols, int bits, int32_t* out, ct_stream_t stream) {

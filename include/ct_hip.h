@@ -183,6 +183,13 @@ int64_t ct_w4_batch_plan(ct_w4_item* items_host, int n, int direction);
 int ct_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
 int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
 
+/* Batched 4-bit zero-point packing along rows: pack_to_int32(zp, 4, packed_dim=0) / unpack_from_int32(..., packed_dim=0) of
+ * PackedQuantizationCompressor (compressors/pack_quantized/base.py:107-110,147-153) for the zero points of many asymmetric
+ * modules in one launch.  Items: src / dst + rows, cols of the UNPACKED int8 matrix (the other fields are ignored);
+ * direction 0: int8 (rows, cols) -> int32 (ceil(rows * 4 / 32), cols); 1: the inverse.  Plan on the host copy first. */
+int64_t ct_zp4_batch_plan(ct_w4_item* items_host, int n);
+int ct_zp4_pack_dim0_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int direction, ct_stream_t stream);
+
 /* Batched 8-bit codecs (Naive / Int / FloatQuantizationCompressor.compress / decompress, compressors/naive_quantized/
  * base.py:48-126, looped per module by model_compressor.py:167-169,196-198): quantize to int8 (num_bits <= 8, clamped to the
  * num_bits range) or float8_e4m3fn, and the inverse, for a whole table of 16-bit tensors in one launch.  Same table type and
