@@ -509,6 +509,49 @@ def test_marlin24_non_square(cta, dev, out_f, in_f, bits, strategy, gs, wdt):
     assert got["meta"].shape == (in_f // 16 // 2, out_f * 2)
 
 
+@pytest.mark.parametrize("out_f,in_f,strategy,gs", [(8192, 8192, "group", 128), (512, 2048, "group", 128), (256, 1024, "channel", None)])
+def test_marlin24_decodes_through_the_reference_primitives(cta, dev, out_f, in_f, strategy, gs):
+    """encode -> decode property at BASELINE config 4's size, independent of the oracle's restatement of the (removed) compressor
+    class: the three stored tensors are taken apart with the primitives that DO survive in the reference and are golden-pinned
+    here — the inverse of `get_permutations_24`'s tile permutation (utils/permutations_24.py:20-53) and
+    `sparse_semi_structured_to_dense_cutlass` (utils/semi_structured_conversions.py:204-298) — and must give back the fp16
+    fake-quantized weight: codes x scales == fake_quantize(W.to(fp16))."""
+    g = torch.Generator().manual_seed(out_f + in_f)
+    w = torch.randn((out_f, in_f), generator=g).to(BF16)
+    w = w * O.sparse24_mask(w).to(w.dtype)
+    scale, zp = O.calculate_qparams_minmax(w.to(F16), num_bits=4, group_size=gs, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy=strategy, group_size=gs, symmetric=True))
+    got = cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
+    k2, n = in_f // 2, out_f
+    perm, sperm, sperm_single = cta.utils.get_permutations_24(4)
+    perm = perm.to(dev)
+    # weight_packed -> unsigned nibbles -> undo the tile permutation -> untile -> (n, k/2) signed kept codes
+    wp = got["weight_packed"]
+    assert wp.shape == (k2 // 16, n * 16 // 8)
+    nib = torch.stack([(wp >> (4 * i)) & 0xF for i in range(8)], dim=-1).reshape(k2 // 16, n * 16)
+    t0 = torch.empty_like(nib).reshape(-1, 1024)
+    t0[:, perm] = nib.reshape(-1, 1024)
+    codes_t = t0.reshape(k2 // 16, n // 16, 16, 16).permute(0, 2, 1, 3).reshape(k2, n)
+    comp = (codes_t.t().contiguous() - 8).to(F16)  # (n, k/2) kept codes as the fp16 values the reference's 2:4 routines take
+    # meta: undo the final view, then the reference's CUTLASS decode
+    meta = got["meta"].reshape(-1).reshape(n, in_f // 16)
+    dense_codes = cta.codec.cutlass24_to_dense(comp, meta)
+    assert dense_codes.shape == (n, in_f)
+    assert bool(((dense_codes != 0).view(-1, 4).sum(-1) <= 2).all())
+    # scale_packed -> undo the scale permutation and the transpose
+    sp = got["scale_packed"]
+    groups = in_f // gs if strategy == "group" else 1
+    assert sp.shape == (groups, n) and sp.dtype == F16
+    tbl = torch.tensor(sperm if (strategy == "group" and gs < k2) else sperm_single, device=dev)
+    st = torch.empty_like(sp).reshape(-1, 64)
+    st[:, tbl] = sp.reshape(-1, 64)
+    scale_back = st.reshape(groups, n).t().contiguous()
+    assert torch.equal(scale_back.cpu(), scale.to(F16))
+    deq = (dense_codes.reshape(n, groups, -1) * scale_back.unsqueeze(-1)).reshape(n, in_f)
+    want = O.fake_quantize(w.to(F16), scale.to(F16), zp, num_bits=4, strategy=strategy, group_size=gs)
+    assert torch.equal(deq.cpu(), want)  # value equality (an all-zero quad comes back as +0.0)
+
+
 def test_marlin24_rejects_dense_weight(cta, dev):
     """a weight that is not 2:4 must be refused (fused front end: device flag, one host read)"""
     w = torch.randn(64, 256).to(BF16)
