@@ -43,11 +43,9 @@ __global__ __launch_bounds__(kBlock) void quant_units_kernel(QParams p) {
             }
             const bool uni = unit_uniform(p.L, c0, n);
             SZ sz = load_sz_q<XDT>(p, srow, c0);
-            // one reciprocal per unit instead of eight divides when x, T and the scale are all bf16 — or all fp16 (+ a Newton step) when
-            // the results are INTEGER codes: below 2^-13 the fp16 shortcut can differ from the IEEE quotient in the last subnormal
-            // place, which no integer code sees but a float-typed result can (the sign of a zero after `+ zero_point`)
-            const bool f16_ok = XDT == CT_F16 && TDT == CT_F16 && p.sdt == CT_F16 && MODE == MODE_Q && p.fkind == 0 && (p.odt == CT_I8 || p.odt == CT_I32);
-            const bool can_rcp = !p.gscale && ((XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16) || f16_ok);
+            // one reciprocal per unit instead of eight divides when x, T and the scale are all bf16, or all fp16 (+ a Newton step and
+            // the exact fix-up of the sub-2^-13 quotients: fast_quotient)
+            const bool can_rcp = !p.gscale && ((XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16) || (XDT == CT_F16 && TDT == CT_F16 && p.sdt == CT_F16));
             float rs = (can_rcp && uni) ? (TDT == CT_BF16 ? bf16_fast_rcp(sz.s) : f16_newton_rcp(sz.s)) : 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -709,7 +707,7 @@ __device__ __forceinline__ void f8_quant_words(const u32x4& raw, float s, float 
     for (int j = 0; j < 4; ++j) {
         float x0, x1;
         unpack2<DT>(ws[j], x0, x1);
-        float t0 = FAST ? x0 * rs : x0 / s, t1 = FAST ? x1 * rs : x1 / s;
+        float t0 = fast_quotient<DT>(x0, s, FAST ? rs : 0.0f), t1 = fast_quotient<DT>(x1, s, FAST ? rs : 0.0f);
         round2<DT>(t0, t1);
         if (ZP) {
             t0 += z; t1 += z;
@@ -740,8 +738,7 @@ __device__ __forceinline__ void f8_quant_lane(const W4Params& p, int64_t g) {
             const int64_t si = w4_scale_index(p, g * Q + i);
             s = load_as_f<DT>(p.scale, si);
             z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;
-            const float as = __builtin_fabsf(s);
-            fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);  // (fp16 keeps the divide: a float8 code carries the sign of a zero)
+            fast = fast_scale_ok<DT>(s);  // fp16: reciprocal + Newton step, exact fix-up below 2^-13 (fast_quotient)
             rs = 1.0f / s;
         }
         // the zero-point add is kept even for z == 0: it turns a -0.0 quotient into +0.0, as upstream's `+=`
@@ -897,8 +894,9 @@ __global__ __launch_bounds__(kBlock) void rtn_channel8_kernel(const u32x4* __res
             store1<DT>(scale_out, row, s);
             if (zp_out) zp_out[row] = (int8_t)(int)z;
         }
-        const float as = __builtin_fabsf(s);
-        const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+        // (fp16: the float8 words use the scalar shortcut with its fix-up; the int8 words' packed-fp16 pipeline needs finite data, which
+        // a row that produced a finite non-zero scale has — a NaN or inf in the row makes the scale NaN / inf and `fast` false)
+        const bool fast = fast_scale_ok<DT>(s);
         const float rs = 1.0f / s;
         const bool use_zp = !FP8 && !symmetric && z != 0.0f;  // block-uniform
         u32x2* rout = out + row * upr;
@@ -973,8 +971,7 @@ __global__ __launch_bounds__(kBlock) void rtn_channel8_wave_kernel(const u32x4* 
         store1<DT>(scale_out, row, s);
         if (zp_out) zp_out[row] = (int8_t)(int)z;
     }
-    const float as = __builtin_fabsf(s);
-    const bool fast = (DT == CT_BF16) && (as >= 0x1p-64f) && (as <= 0x1p64f);
+    const bool fast = fast_scale_ok<DT>(s);  // fp16: see rtn_channel8_kernel
     const float rs = 1.0f / s;
     const bool use_zp = !FP8 && !symmetric && z != 0.0f;  // wave-uniform
     u32x2* rout = out + row * upr;
@@ -1015,7 +1012,7 @@ __global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, fl
             const int64_t si = w4_scale_index(p, u);
             const float s = load_as_f<DT>(p.scale, si);
             const float z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(x.dtype) == zp.to(scale.dtype) here
-            const float rs = DT == CT_BF16 ? bf16_fast_rcp(s) : 0.0f;  // (fp16: float-typed results, see quant_units_kernel)
+            const float rs = DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s);
             const uint32_t ws[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
             float v[8];
 #pragma unroll

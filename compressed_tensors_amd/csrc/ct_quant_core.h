@@ -45,7 +45,13 @@ __device__ __forceinline__ float fast_quotient(float x, float s, float rs) {
     if constexpr (TDT == CT_F16) {
         const float q0 = x * rs;
         const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, s, x), rs, q0);
-        return __builtin_isfinite(q0) ? q1 : q0;  // x = +-inf / NaN: the correction would turn inf into NaN
+        // x = +-inf / NaN: the correction would turn inf into NaN; x = -0: it would return +0 ((+0) + (-0)), and q0 is exact there
+        float r = (__builtin_isfinite(q0) && x != 0.0f) ? q1 : q0;
+        // The shortcut is proven down to 2^-13 (ct_selftest_f16_div); below it the two can differ in the last fp16-subnormal place,
+        // which an integer code never sees but a float-typed result can (an underflow to zero changes the sign `+ zero_point`
+        // leaves).  Those few elements take the divide: a divergent branch that most waves skip (x == 0 is exact either way).
+        if (__builtin_fabsf(r) < 0x1p-13f && x != 0.0f) r = x / s;
+        return r;
     } else {
         return x * rs;
     }

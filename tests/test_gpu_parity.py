@@ -282,6 +282,56 @@ def test_all_fp16_inputs_w4_and_int8(cta, dev):
         assert eq(packed.cpu(), O.pack_to_int32(O.quantize(w, s_ref, z_ref, num_bits=4, strategy="group", group_size=128, dtype=torch.int8), 4).contiguous())
 
 
+def test_all_fp16_inputs_float_typed_results(cta, dev):
+    """fp16 reciprocal + Newton shortcut with its exact fix-up below 2^-13, where a float-typed result could see the difference (an
+    underflowed zero's sign after `+ zero_point`): fake_quantize, quantize with a float result, float8 quantize — every fp16 input,
+    scales that put the quotients inside, around and far below the fix-up threshold, zero points absent / all-zero / non-zero;
+    bitwise against the oracle"""
+    allx = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(F16).reshape(64, 1024)
+    g = torch.Generator().manual_seed(8)
+    scales = torch.cat([(torch.rand(8, generator=g) * 2 + 1e-3), torch.tensor([2.0 ** -14, 2.0 ** 15, 3.0e4, 1.0e4, 4097.0, 777.0, 0.37, 2.0 ** -15])]).to(F16)
+    for i in range(0, scales.numel(), 8):
+        s = scales[i:i + 8].reshape(1, 8).repeat(64, 1).contiguous()
+        z = torch.randint(-8, 8, (64, 8), generator=g).to(torch.int8)
+        for zp in (None, torch.zeros_like(z), z):
+            kw = dict(num_bits=4, strategy="group", group_size=128)
+            assert eq(cta.codec.fake_quantize_tensor(allx.to(dev), s.to(dev), d(zp, dev), **kw).cpu(), O.fake_quantize(allx, s, zp, **kw)), (i, zp is None)
+            assert eq(cta.codec.quantize_tensor(allx.to(dev), s.to(dev), d(zp, dev), **kw).cpu(), O.quantize(allx, s, zp, **kw)), (i, zp is None)
+            kw8 = dict(num_bits=8, strategy="group", group_size=128)
+            assert eq(cta.codec.fake_quantize_tensor(allx.to(dev), s.to(dev), d(zp, dev), **kw8).cpu(), O.fake_quantize(allx, s, zp, **kw8)), (i, zp is None)
+        for zf in (None, torch.zeros((64, 8), dtype=F8)):
+            q = cta.codec.quantize_tensor(allx.to(dev), s.to(dev), d(zf, dev), num_bits=8, strategy="group", group_size=128, dtype=F8, qtype="float")
+            r = O.quantize(allx, s, zf, num_bits=8, strategy="group", group_size=128, dtype=F8, qtype="float")
+            nan = r != r
+            assert torch.equal(q.cpu().view(torch.uint8)[~nan], r.view(torch.uint8)[~nan]) and bool((q.cpu() != q.cpu())[nan].all()), (i, zf is None)
+    # channel-wise float8 round-to-nearest in one pass on fp16 (the scalar shortcut inside rtn_channel8)
+    w = (torch.randn(64, 1024, generator=g) * 0.05).to(F16)
+    w[3, :5] = torch.tensor([1e-7, -1e-7, 6e-8, -6e-8, 0.0]).to(F16)
+    for qtype in ("float", "int"):
+        qg, sg, zg = cta.codec.rtn_quantize_channel8(w.to(dev), qtype=qtype, symmetric=True)
+        if qtype == "float":
+            s_ref = O.calculate_qparams_float(w, kind="fp8")
+            r = O.quantize(w, s_ref, torch.zeros_like(s_ref, dtype=F8), num_bits=8, strategy="channel", dtype=F8, qtype="float")
+            assert eq(sg.cpu(), s_ref) and torch.equal(qg.cpu().view(torch.uint8), r.view(torch.uint8))
+        else:
+            s_ref, z_ref = O.calculate_qparams_minmax(w, num_bits=8, group_size=None, symmetric=True)
+            assert eq(sg.cpu(), s_ref) and torch.equal(qg.cpu(), O.quantize(w, s_ref, z_ref, num_bits=8, strategy="channel", dtype=torch.int8))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16, F32])
+@pytest.mark.parametrize("cols", [5632, 11008, 96, 8 * 257])
+def test_observer_on_rows_that_are_not_a_power_of_two(cta, dev, dtype, cols):
+    """channel-wise min-max qparams on Llama-style widths (5632, 11008: the vectorised one-wave-per-row kernel), symmetric and not"""
+    g = torch.Generator().manual_seed(cols)
+    w = (torch.randn(33, cols, generator=g) * 0.3).to(dtype)
+    w[1, 7] = 0.0
+    for sym in (True, False):
+        for bits in (8, 4):
+            s, z = cta.codec.minmax_qparams(w.to(dev), num_bits=bits, group_size=None, symmetric=sym)
+            s_ref, z_ref = O.calculate_qparams_minmax(w, num_bits=bits, group_size=None, symmetric=sym)
+            assert eq(s.cpu(), s_ref) and eq(z.cpu(), z_ref), (sym, bits)
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16])
 def test_asymmetric_decompress_full_range(cta, dev, dtype):
     """fused W4 decompress / int8 dequantize with an int8 zero point folded into the un-bias constant: every code x every zero
