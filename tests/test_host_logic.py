@@ -522,3 +522,42 @@ def test_float_scheme_format_inference_and_param_names(cta):
     assert fp8.pytorch_dtype() is f8
     with pytest.raises(NotImplementedError):
         nv.pytorch_dtype()
+
+
+def test_launches_run_with_the_tensors_device_current(monkeypatch):
+    """_lib.call: the trailing stream argument remembers its device, and the launch happens with THAT device current (the null
+    stream resolves against the current device).  No GPU here: torch.cuda's device bookkeeping is stubbed."""
+    from compressed_tensors_amd import _lib
+
+    state = {"current": 0, "entered": []}
+
+    class FakeDeviceCtx:
+        def __init__(self, idx):
+            self.idx = idx
+
+        def __enter__(self):
+            state["entered"].append(self.idx)
+            self.prev, state["current"] = state["current"], self.idx
+
+        def __exit__(self, *a):
+            state["current"] = self.prev
+
+    seen = []
+
+    class FakeLib:
+        @staticmethod
+        def ct_probe(a, stream):
+            seen.append((a, int(stream), state["current"]))
+            return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["current"])
+    monkeypatch.setattr(torch.cuda, "device", FakeDeviceCtx)
+    h1 = _lib.StreamHandle(0)
+    h1.device_index = 1
+    _lib.call("ct_probe", 7, h1)          # tensor on cuda:1 while cuda:0 is current -> switched for the call, restored after
+    h0 = _lib.StreamHandle(1234)
+    h0.device_index = 0
+    _lib.call("ct_probe", 8, h0)          # already current: no switch
+    _lib.call("ct_probe", 9, 5678)        # a raw handle from a C-style caller: left alone
+    assert seen == [(7, 0, 1), (8, 1234, 0), (9, 5678, 0)] and state["entered"] == [1] and state["current"] == 0
