@@ -683,6 +683,8 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     }
     const uint8_t* sc = &s_code[0][0];
     const int64_t wpr = m * 2;  // packed words per k-tile row (size_n * 16 * 4 / 32)
+    // (a thread building FOUR consecutive words of one k-tile — four table rows, one 16-byte streaming store — measured slower:
+    // 38.9 vs 36.2 us; the same word position in four k-tiles reuses one table row and its 4-byte stores are 512-byte runs)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int t = (tid >> 7) + 2 * it;  // k-tile inside the workgroup tile
