@@ -189,7 +189,70 @@ def case_marlin(g):
         assert eq(got[k].cpu().contiguous(), ref[k].contiguous()), ("marlin24", k, bits, strategy, gs, dt, rows, cols)
 
 
-CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn, case_qparams_float, case_channel8, case_sparse24, case_marlin]
+def case_batches(g):
+    """the one-launch tables: W4A16 (symmetric / asymmetric incl. the batched zero-point packing) and the 8-bit codecs, random module lists"""
+    dt = rng.choice([BF16, F16])
+    kind = rng.choice(["w4", "w4", "int8", "fp8"])
+    n = rng.randint(1, 6)
+    ents, dents, refs, zps = [], [], [], []
+    bits = 4 if kind == "w4" else 8 if kind == "fp8" else rng.choice([8, 8, 6])
+    for _ in range(n):
+        rows = rng.choice([1, 3, 32, 33, 200])
+        if kind == "w4":
+            group = rng.choice([32, 64, 128, 256])
+            cols = group * rng.choice([1, 2, 5])
+            if rng.random() < 0.25:
+                group = cols
+        else:
+            group = rng.choice([16, 64, 128])
+            cols = group * rng.choice([1, 3, 8])
+            r = rng.random()
+            group = cols if r < 0.3 else rows * cols if r < 0.5 else group
+        x = rand_x((rows, cols), dt, g, allow_nonfinite=rng.random() < 0.3)
+        strategy = "tensor" if group == rows * cols and kind != "w4" else "channel" if group == cols else "group"
+        sym = rng.random() < 0.5 or kind == "fp8"
+        fin = torch.nan_to_num(x.float(), nan=0.0, posinf=1.0, neginf=-1.0).to(dt)
+        if kind == "fp8":
+            s = O.calculate_qparams_float(fin.reshape(1, -1) if strategy == "tensor" else fin, kind="fp8", group_size=group if strategy == "group" else None)
+            z = None
+        else:
+            s, z = O.calculate_qparams_minmax(fin.reshape(1, -1) if strategy == "tensor" else fin, num_bits=bits, group_size=group if strategy == "group" else None, symmetric=sym)
+            if sym and rng.random() < 0.5:
+                z = None
+        if strategy == "tensor":
+            s = s.reshape(1)
+            z = None if z is None else z.reshape(1)
+        kw = dict(num_bits=bits, strategy=strategy, group_size=group if strategy == "group" else None)
+        xd, sd, zd = x.to(dev), s.to(dev), None if z is None else z.to(dev)
+        if kind == "w4":
+            q = O.quantize(x, s, z, dtype=torch.int8, **kw)
+            refs.append((O.pack_to_int32(q, 4).contiguous(), O.dequantize(q, s, z)))
+            packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=dev)
+            out = torch.empty((rows, cols), dtype=dt, device=dev)
+            ents.append((xd, sd, zd, packed, rows, cols, group)); dents.append((packed, sd, zd, out, rows, cols, group))
+            if z is not None:
+                zp_packed = torch.empty((-(-rows * 4 // 32), z.shape[1]), dtype=torch.int32, device=dev)
+                zps.append((zd, zp_packed, torch.empty_like(zd), O.pack_to_int32(z, 4, packed_dim=0).contiguous()))
+        else:
+            qdt = F8 if kind == "fp8" else torch.int8
+            q = O.quantize(x, s, z, dtype=qdt, qtype="float" if kind == "fp8" else "int", **kw)
+            refs.append((q, O.dequantize(q, s, z)))
+            qd = torch.empty((rows, cols), dtype=qdt, device=dev)
+            out = torch.empty((rows, cols), dtype=dt, device=dev)
+            ents.append((xd, sd, zd, qd, rows, cols, group)); dents.append((qd, sd, zd, out, rows, cols, group))
+    codec.W4Batch(ents, "compress", dt, kind=kind, bits=bits).launch()
+    codec.W4Batch(dents, "decompress", dt, kind=kind).launch()
+    for (xd, sd, zd, code, rows, cols, group), (_, _, _, out, *_), (rq, rd) in zip(ents, dents, refs):
+        ok = eq_f8(code.cpu(), rq) if kind == "fp8" else torch.equal(code.cpu(), rq)
+        assert ok and eq(out.cpu(), rd), ("batch", kind, dt, bits, rows, cols, group, zd is None)
+    if zps:
+        codec.zp4_batch([(a, b) for a, b, _, _ in zps], "pack")
+        codec.zp4_batch([(b, c) for _, b, c, _ in zps], "unpack")
+        for a, b, c, ref in zps:
+            assert torch.equal(b.cpu(), ref) and torch.equal(c, a), ("zp batch", tuple(a.shape))
+
+
+CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn, case_qparams_float, case_channel8, case_sparse24, case_marlin, case_batches, case_batches]
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
     g = torch.Generator().manual_seed(rng.randint(0, 2 ** 31))
