@@ -691,7 +691,8 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         uint32_t word = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) word |= (uint32_t)sc[src_off[e] + t * 16] << (4 * e);
-        packed[((int64_t)tile_c * 8 + t) * wpr + (int64_t)tile_r * 128 + (tid & 127)] = (int32_t)word;
+        // streaming store: a plain one leaves the line dirty in the XCD's L2 and the kernel ends with a write-back bubble
+        __builtin_nontemporal_store((int32_t)word, packed + ((int64_t)tile_c * 8 + t) * wpr + (int64_t)tile_r * 128 + (tid & 127));
     }
     // scale_packed (marlin24_pack_scales_kernel fused in): the 64 rows of this tile are one 64-entry row of the transposed
     // (groups, size_n) matrix per group, permuted inside itself — a contiguous 128-byte run.  The tile that holds a group's

@@ -43,6 +43,38 @@ def test_library_exports_every_declared_symbol(cta):
     assert _lib.load().ct_abi_version() == 1
 
 
+def test_ctypes_prototypes_match_the_header():
+    """every entry point's parameter list in include/ct_hip.h against the ctypes prototype in _lib.py: same arity, and pointers /
+    64-bit integers / ints in the same positions (an ABI drift between the two would corrupt arguments silently)"""
+    import ctypes as C
+
+    from compressed_tensors_amd import _lib
+
+    text = open(os.path.join(ROOT, "include", "ct_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    decls = dict(re.findall(r"\b(?:int64_t|int|const char\*)\s+(ct_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S))
+    assert set(decls) == set(_lib._PROTOTYPES)
+
+    def kind(param):
+        p = " ".join(param.split())
+        if "*" in p or p.startswith("ct_stream_t"):
+            return "ptr"
+        if p.startswith(("int64_t", "long long")):
+            return "i64"
+        if p.startswith(("uint32_t", "unsigned")):
+            return "u32"
+        if p.startswith("int"):
+            return "i32"
+        raise AssertionError(f"unrecognised parameter {param!r}")
+
+    ckind = {C.c_void_p: "ptr", C.c_char_p: "ptr", C.c_int64: "i64", C.c_int: "i32", C.c_uint32: "u32"}
+    for name, params in decls.items():
+        params = [q for q in (p.strip() for p in params.split(",")) if q and q != "void"]
+        argtypes, _ = _lib._PROTOTYPES[name]
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+        assert [kind(q) for q in params] == [ckind[a] for a in argtypes], name
+
+
 def test_library_targets_gfx950_only():
     out = subprocess.run(["strings", "-a", os.path.join(ROOT, "compressed_tensors_amd", "libct_hip.so")],
                          capture_output=True, text=True).stdout
