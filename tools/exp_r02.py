@@ -1,5 +1,6 @@
 """round-2 experiments (dev helper): python tools/exp_r02.py w4d|bitmask   (knobs come from the environment)"""
 import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as B
@@ -97,3 +98,26 @@ elif what == "bm4":
     for t in list(range(0, 64, 9)) + list(range(64, tiles, 509)):
         print(t, "start %.1f loaded %.1f resolved %.1f done %.1f" % tuple(a[t]))
     print("median load %.1f wait %.1f scatter %.1f" % (np.median(a[:, 1] - a[:, 0]), np.median(a[:, 2] - a[:, 1]), np.median(a[:, 3] - a[:, 2])))
+elif what == "m24host":
+    # host cost of Marlin24Compressor.compress: a tiny weight (kernel ~ few us), many calls
+    import time, cProfile, pstats, io
+    import compressed_tensors_amd as cta, oracle as O
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    w = torch.randn(64, 256, dtype=torch.bfloat16); w = w * O.sparse24_mask(w).to(w.dtype)
+    s, z = O.calculate_qparams_minmax(w.to(torch.float16), num_bits=4, group_size=128, symmetric=True)
+    sd = {"weight": w.to(dev), "weight_scale": s.to(torch.bfloat16).to(dev), "weight_zero_point": z.to(dev)}
+    M = cta.Marlin24Compressor
+    with M.deferred_structure_check():
+        for _ in range(200): M.compress(sd, scheme)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with M.deferred_structure_check():
+        for _ in range(2000): M.compress(sd, scheme)
+    torch.cuda.synchronize()
+    print("us per call (deferred):", (time.perf_counter() - t0) / 2000 * 1e6)
+    pr = cProfile.Profile(); pr.enable()
+    with M.deferred_structure_check():
+        for _ in range(2000): M.compress(sd, scheme)
+    pr.disable(); torch.cuda.synchronize()
+    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14); print(st.getvalue()[:2600])
