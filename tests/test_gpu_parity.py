@@ -1351,6 +1351,55 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rs["sparse_bitmask"]["shard_equals_slice_of_single_rank_result"] is True
 
 
+def test_rccl_process_group_on_one_gpu(tmp_path):
+    """what a one-GPU lease allows of the RCCL path: a world-size-1 `nccl` (= RCCL) process group under torch.distributed.run —
+    init_dist's backend choice and device binding, the barrier + MAX all-reduce on device tensors that bench.py uses for timing,
+    and ModelCompressor running with `is_distributed()` true (LPT shard = everything, recouple a no-op)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import compressed_tensors_amd as cta
+from compressed_tensors_amd.distributed import init_dist, is_distributed, rank_and_world
+init_dist()
+assert is_distributed() and dist.get_backend() == "nccl" and rank_and_world() == (0, 1)
+dev = torch.device("cuda", torch.cuda.current_device())
+t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+dist.barrier(); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 3.5
+buf = torch.arange(1024, dtype=torch.uint8, device=dev); dist.broadcast(buf, src=0)
+net = torch.nn.Sequential(*[torch.nn.Linear(256, 64, bias=False) for _ in range(3)]).to(dev).to(torch.bfloat16)
+args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False)
+ref = []
+for m in net:
+    m.quantization_scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    s, z = cta.quantization.calculate_qparams_from_weight(m.weight.data, args)
+    m.register_parameter("weight_scale", torch.nn.Parameter(s, requires_grad=False))
+    m.register_parameter("weight_zero_point", torch.nn.Parameter(z, requires_grad=False))
+    ref.append(cta.codec.fake_quantize_tensor(m.weight.data, s, z, num_bits=4, strategy="group", group_size=128))
+mc = cta.ModelCompressor()
+mine = mc.compress_model(net)
+assert len(mine) == 3 and all(hasattr(m, "weight_packed") for m in net) and hasattr(net, "ct_decompress_hook")
+mc.decompress_model(net, recouple=True)
+assert all(torch.equal(m.weight.data, r) for m, r in zip(net, ref))
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+""" % root
+    script = tmp_path / "rccl_one.py"
+    script.write_text(code)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
 @pytest.mark.parametrize("wdt", [BF16, F16])
 @pytest.mark.parametrize("bits", [4, 8])
 def test_marlin24_front_end_special_values(cta, dev, wdt, bits):
