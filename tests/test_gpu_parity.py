@@ -470,6 +470,22 @@ def test_bitmask_full_size(cta, dev):
     t = cta.compressors.sparse.BitmaskTensor.from_dense(w.to(dev))
     assert eq(t.compressed.cpu(), rv) and torch.equal(t.bitmask.cpu(), rb) and torch.equal(t.row_offsets.cpu(), ro)
     assert eq(t.decompress().cpu(), w)  # no -0.0 in randn*mask: exact round trip
+    # the same three tensors restated with eager torch ops on the device, independent of the oracle (the definition of the format:
+    # values = x[x != 0] in row-major order, bitmask = little-endian packbits of x != 0 — `pack_bitmasks`, utils/helpers.py:306-343 —,
+    # row_offsets = exclusive cumsum of the per-row counts)
+    wd = w.to(dev)
+    mask = wd != 0
+    assert torch.equal(t.compressed, wd[mask])
+    weights = (1 << torch.arange(8, device=dev, dtype=torch.int32))
+    assert torch.equal(t.bitmask, (mask.view(N, N // 8, 8).to(torch.int32) * weights).sum(-1).to(torch.uint8))
+    counts = mask.sum(-1)
+    assert torch.equal(t.row_offsets, torch.cumsum(counts, 0) - counts)
+    # 2:4 codec at the same size: values = the two largest magnitudes of every four, in order; bitmask as above; decompress restores them
+    m24 = cta.codec.sparse24_mask(wd.abs().to(BF16) + 0 * wd)  # top-2 of |x| (ties to the lower index, as torch.topk)
+    pruned = wd * m24.to(wd.dtype)
+    v24, b24 = cta.codec.sparse24_bitmask_compress(pruned)
+    assert torch.equal(b24, (m24.view(N, N // 8, 8).to(torch.int32) * weights).sum(-1).to(torch.uint8)) and bool((m24.view(-1, 4).sum(-1) == 2).all())
+    assert torch.equal(v24.reshape(-1), pruned[m24.bool()]) and torch.equal(cta.codec.sparse24_bitmask_decompress(v24, b24, (N, N)), pruned)
 
 
 @pytest.mark.parametrize("dtype", [BF16, F16, torch.int8])
