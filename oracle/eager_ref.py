@@ -17,6 +17,9 @@ Sequence followed (paths relative to /root/reference/src/compressed_tensors):
   unpack        compressors/pack_quantized/helpers.py:104-180
   compressors   compressors/pack_quantized/base.py:62-163, compressors/naive_quantized/base.py:48-126
 
+The functions take tensors on any device: on the GPU box they also run the same op sequence through PyTorch-ROCm's own eager kernels —
+what the reference itself would execute there (tests/test_gpu_parity.py::test_reference_op_sequence_on_the_gpu).
+
 Never imported by the product package.
 """
 import math
@@ -27,9 +30,9 @@ __all__ = ["quantize", "dequantize", "pack_to_int32", "unpack_from_int32", "pack
            "pack_quantized_decompress", "int_quantized_compress", "int_quantized_decompress"]
 
 
-def _bounds(num_bits):
+def _bounds(num_bits, device="cpu"):
     half = 2 ** num_bits // 2
-    return torch.tensor(-half, dtype=torch.float32), torch.tensor(half - 1, dtype=torch.float32)
+    return torch.tensor(-half, dtype=torch.float32, device=device), torch.tensor(half - 1, dtype=torch.float32, device=device)
 
 
 def _q(x, scale, zp, lo, hi, out_dtype):
@@ -43,7 +46,7 @@ def _q(x, scale, zp, lo, hi, out_dtype):
 
 @torch.no_grad()
 def quantize(x, scale, zero_point, *, num_bits, strategy, group_size=None, dtype=torch.int8):
-    lo, hi = _bounds(num_bits)
+    lo, hi = _bounds(num_bits, x.device)
     if strategy == "group":
         while scale.ndim < 2:
             scale = scale.unsqueeze(1)
@@ -77,8 +80,8 @@ def dequantize(x_q, scale, zero_point=None, dtype=None):
     return d.to(dtype)
 
 
-def _lanes(num_bits):
-    first_bit = torch.arange(32, dtype=torch.int32) * num_bits
+def _lanes(num_bits, device="cpu"):
+    first_bit = torch.arange(32, dtype=torch.int32, device=device) * num_bits
     return (first_bit // 32).long(), first_bit % 32
 
 
@@ -100,8 +103,8 @@ def pack_to_int32(value, num_bits, packed_dim=1):
         u = torch.nn.functional.pad(u, (0, full - cols))
     groups = full // 32
     ug = u.reshape(rows * groups, 32)
-    acc = torch.zeros(rows * groups, num_bits, dtype=torch.int32)
-    word, off = _lanes(num_bits)
+    acc = torch.zeros(rows * groups, num_bits, dtype=torch.int32, device=u.device)
+    word, off = _lanes(num_bits, u.device)
     acc.scatter_add_(1, word.unsqueeze(0).expand(rows * groups, -1), ug << off.unsqueeze(0))
     spill = off + num_bits - 32
     straddles = spill > 0
@@ -130,7 +133,7 @@ def unpack_from_int32(value, num_bits, shape, packed_dim=1):
         words += extra
     groups = words // num_bits
     vg = value.reshape(rows * groups, num_bits)
-    word, off = _lanes(num_bits)
+    word, off = _lanes(num_bits, value.device)
     low = torch.clamp(32 - off, max=num_bits)
     got = (vg[:, word] >> off.unsqueeze(0)) & ((1 << low) - 1).unsqueeze(0)
     straddles = low < num_bits

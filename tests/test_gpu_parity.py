@@ -1367,6 +1367,36 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rs["sparse_bitmask"]["shard_equals_slice_of_single_rank_result"] is True
 
 
+@pytest.mark.parametrize("n,dtype,sym", [(8192, BF16, True), (2048, BF16, False), (2048, F16, True), (2048, F16, False)])
+def test_reference_op_sequence_on_the_gpu(cta, dev, n, dtype, sym):
+    """the reference's own eager op sequence (oracle/eager_ref.py, pinned bit-for-bit against the reference in the build container)
+    executed by PyTorch-ROCm's kernels on THIS GPU — what upstream would compute here — against the fused HIP kernels: packed
+    words, packed zero points and decompressed weights bit for bit; also BASELINE config 1 (int8 per tensor)"""
+    import eager_ref as E
+
+    torch.manual_seed(n)
+    w = torch.randn(n, n, dtype=dtype, device=dev)
+    s, z = cta.codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=sym)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=sym))
+    sd = {"weight": w, "weight_scale": s, "weight_zero_point": z}
+    ref_c = E.pack_quantized_compress(sd, num_bits=4, strategy="group", group_size=128, symmetric=sym)
+    got_c = cta.PackedQuantizationCompressor.compress(sd, scheme)
+    assert sorted(ref_c) == sorted(got_c)
+    for k in ref_c:
+        assert torch.equal(ref_c[k].contiguous().cpu() if k == "weight_shape" else ref_c[k].contiguous(), got_c[k].cpu() if k == "weight_shape" else got_c[k]), k
+    ref_d = E.pack_quantized_decompress(ref_c, num_bits=4, strategy="group", symmetric=sym)
+    got_d = cta.PackedQuantizationCompressor.decompress(got_c, scheme)
+    assert eq(got_d["weight"].cpu(), ref_d["weight"].cpu())
+    if n <= 4096:
+        s1 = (w.abs().max().float() / 127.0).to(dtype).reshape(1)
+        sd8 = {"weight": w, "weight_scale": s1, "weight_zero_point": torch.zeros(1, dtype=torch.int8, device=dev)}
+        a8 = cta.QuantizationArgs(num_bits=8, strategy="tensor", symmetric=True)
+        sch8 = cta.QuantizationScheme(targets=["Linear"], weights=a8, input_activations=a8)
+        r8, g8 = E.int_quantized_compress(sd8), cta.IntQuantizationCompressor.compress(sd8, sch8)
+        assert torch.equal(r8["weight"], g8["weight"])
+        assert eq(cta.IntQuantizationCompressor.decompress(g8, sch8)["weight"].cpu(), E.int_quantized_decompress(r8)["weight"].cpu())
+
+
 def test_rccl_process_group_on_one_gpu(tmp_path):
     """what a one-GPU lease allows of the RCCL path: a world-size-1 `nccl` (= RCCL) process group under torch.distributed.run —
     init_dist's backend choice and device binding, the barrier + MAX all-reduce on device tensors that bench.py uses for timing,
