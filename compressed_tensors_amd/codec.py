@@ -764,9 +764,9 @@ def unpack_bitmasks(packed_bitmasks: torch.Tensor, original_shape) -> torch.Tens
 def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
     """sparse-bitmask compression: returns (values, bitmask uint8 (R, ceil(C/8)), row_offsets int64 (R,)).
 
-    Default: the fused form (`ct_bitmask_compress`: span / block counts, then a scatter whose
-    prefixes are sums of those counts; no scan kernel) into a worst-case sized value buffer, then one
-    host read of nnz — as unavoidable as the reference's `tensor[mask]` — to narrow it.  `two_pass=True` keeps the
+    Default: the fused form (`ct_bitmask_compress`; 16-bit elements: the register-resident kernel that reads the tensor once,
+    otherwise count + scatter whose prefixes are sums of the counts; no scan kernel) into a worst-case sized value buffer, then
+    one host read of nnz — as unavoidable as the reference's `tensor[mask]` — to narrow it.  `two_pass=True` keeps the
     count / scan / host read / scatter form that sizes `values` exactly before writing it."""
     if tensor.ndim < 1:
         raise ValueError("bitmask compression expects at least a 1-D tensor")
@@ -795,7 +795,7 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
         call("ct_bitmask_compress", ptr(x), dt, rows, cols, ptr(buf), numel, ptr(bitmask), ptr(row_offsets),
              ws[-1:].data_ptr(), ptr(ws), ws_bytes, s)
         nnz = int(ws[-1].item())
-        if nnz < 0:  # the one-pass kernel's bounded wait gave up (never observed; it cannot deadlock by construction): count / scan / scatter
+        if nnz < 0:  # a workgroup of the resident kernel gave up waiting (bounded wait; never observed outside the forced test): count / scan / scatter
             return bitmask_compress(tensor, two_pass=True)
         # keep the view when it wastes less than half of the buffer, else release the slack
         values = buf[:nnz] if 2 * nnz >= numel else buf[:nnz].clone()

@@ -706,16 +706,90 @@ static Flat16Plan flat16_plan(int64_t rows, int64_t cols) {
     return p;
 }
 
-__device__ __forceinline__ uint32_t nz_mask16(const u32x4& r, bool is_float) {
-    const uint32_t lo = is_float ? 0x7fffu : 0xffffu, hi = lo << 16;
-    const uint32_t ws[4] = {r.x, r.y, r.z, r.w};
-    uint32_t m = 0;
+// ---- the compaction primitives shared by the scatter kernels (both were VALU-bound: ~600 vector instructions per wave-tile)
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4_t;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {  // byte offset of a __shared__ object inside the workgroup's LDS
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// the 8 non-zero flags of a unit, 14 VALU: (x & keep) -> v_pk_min_u16(.., 1) gives 0/1 per half; the four dwords are merged with
+// v_lshl_or and the high halves folded down.  keep = 0x7fff7fff for floats (-0.0 is a zero), 0xffffffff for integers
+__device__ __forceinline__ uint32_t nz_mask16_fast(const u32x4& r, uint32_t keep) {
+    const uint32_t ws[4] = {r.x & keep, r.y & keep, r.z & keep, r.w & keep};
+    const uint32_t one = 0x00010001u;
+    uint32_t acc = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        m |= ((ws[j] & lo) ? 1u : 0u) << (2 * j);
-        m |= ((ws[j] & hi) ? 1u : 0u) << (2 * j + 1);
+        uint32_t f;  // (written as a vector min, hipcc turns it into two compares, two selects and a v_perm)
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(ws[j]), "v"(one));
+        acc |= f << (2 * j);
     }
-    return m;
+    return ((acc >> 15) & 0xaau) | (acc & 0x55u);
+}
+
+// ranks of a wave-tile's 4 x 64 units in unit order i * 64 + lane, from their non-zero counts (<= 8 each): two DPP wave scans over
+// packed pairs of 16-bit counts, interleaved (four separate scans were 20 DPP adds + ~50 hazard nops).  Returns the tile's total.
+__device__ __forceinline__ int tile_ranks(const uint32_t (&mm)[4], uint32_t (&rank)[4]) {
+    const int c0 = __popc(mm[0]), c1 = __popc(mm[1]), c2 = __popc(mm[2]), c3 = __popc(mm[3]);
+    int v[2] = {c0 | (c1 << 16), c2 | (c3 << 16)};
+#define CT_SCAN_STEP(ctrl, rmask)                                                                    \
+    {                                                                                                \
+        const int a0 = __builtin_amdgcn_update_dpp(0, v[0], ctrl, rmask, 0xf, false);                \
+        const int a1 = __builtin_amdgcn_update_dpp(0, v[1], ctrl, rmask, 0xf, false);                \
+        v[0] += a0;                                                                                  \
+        v[1] += a1;                                                                                  \
+    }
+    CT_SCAN_STEP(0x111, 0xf)  // row_shr:1
+    CT_SCAN_STEP(0x112, 0xf)  // row_shr:2
+    CT_SCAN_STEP(0x114, 0xf)  // row_shr:4
+    CT_SCAN_STEP(0x118, 0xf)  // row_shr:8
+    CT_SCAN_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    CT_SCAN_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+#undef CT_SCAN_STEP
+    const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane(v[0], 63), t23 = (uint32_t)__builtin_amdgcn_readlane(v[1], 63);
+    const uint32_t T0 = t01 & 0xffffu, T1 = t01 >> 16, T2 = t23 & 0xffffu, T3 = t23 >> 16;
+    rank[0] = ((uint32_t)v[0] & 0xffffu) - (uint32_t)c0;
+    rank[1] = ((uint32_t)v[0] >> 16) - (uint32_t)c1 + T0;
+    rank[2] = ((uint32_t)v[1] & 0xffffu) - (uint32_t)c2 + T0 + T1;
+    rank[3] = ((uint32_t)v[1] >> 16) - (uint32_t)c3 + T0 + T1 + T2;
+    return (int)(T0 + T1 + T2 + T3);
+}
+
+// LDS table, 256 x 8 x uint16: entry [m][k] = 2 * (number of kept elements of the unit before element k) when bit k of m is set,
+// 0x2000 otherwise — an offset that pushes the address past every slab so that min(address, dump slot) selects the dump slot:
+// an element costs one add + one min + the ds_write_b16 (was: bit test, two selects, add, shift)
+constexpr int kLutBytes = 256 * 16;
+__device__ __forceinline__ void build_compact_lut(uint16_t* lut, int tid) {
+    if (tid < 256) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k0 = 2 * j, k1 = 2 * j + 1;
+            const uint32_t e0 = ((tid >> k0) & 1) ? 2u * (uint32_t)__popc(tid & ((1 << k0) - 1)) : 0x2000u;
+            const uint32_t e1 = ((tid >> k1) & 1) ? 2u * (uint32_t)__popc(tid & ((1 << k1) - 1)) : 0x2000u;
+            w[j] = e0 | (e1 << 16);
+        }
+        reinterpret_cast<u32x4*>(lut)[tid] = u32x4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+// the kept elements of a wave-tile's four unit rows -> the wave's slab, at halfword position shift + rank[i] + (rank inside the unit)
+__device__ __forceinline__ void compact_into_slab(const u32x4 (&cur)[4], const uint32_t (&mm)[4], const uint32_t (&rank)[4], int shift,
+                                                  uint32_t slab_a, uint32_t dump_a, uint32_t lut_a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32x4 t = *(lds_cu32x4_t*)(uintptr_t)(lut_a + mm[i] * 16u);
+        const uint32_t ts[4] = {t.x, t.y, t.z, t.w};
+        const uint32_t ws[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+        const uint32_t ab = slab_a + 2u * ((uint32_t)shift + rank[i]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t off = (k & 1) ? (ts[k >> 1] >> 16) : (ts[k >> 1] & 0xffffu);
+            const uint32_t a = min(ab + off, dump_a);
+            *(lds_u16_t*)(uintptr_t)a = (uint16_t)((k & 1) ? (ws[k >> 1] >> 16) : ws[k >> 1]);
+        }
+    }
 }
 
 __device__ __forceinline__ void load_wt(const u32x4* __restrict__ x, int64_t units, int64_t wt, int lane, u32x4 (&r)[4]) {
@@ -733,6 +807,7 @@ __global__ __launch_bounds__(kBlock) void flat16_count_kernel(const u32x4* __res
     __shared__ int s_cnt[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t wt0 = ((int64_t)blockIdx.x * 4 + wave) * span;
+    const uint32_t keepbits = is_float ? 0x7fff7fffu : 0xffffffffu;
     int cnt = 0;
     // four wave-tiles (16 KB, 16 loads per lane) requested before the first is used: the kernel only reads, and with "current +
     // next" a wave had 8 KB in flight (28-29 us at 8192^2 against 24 us for the observer's read of the same bytes)
@@ -749,7 +824,7 @@ __global__ __launch_bounds__(kBlock) void flat16_count_kernel(const u32x4* __res
             uint32_t mm[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                mm[i] = nz_mask16(t[q][i], is_float);
+                mm[i] = nz_mask16_fast(t[q][i], keepbits);
                 cnt += __popc(mm[i]);
             }
             if (mask_dwords) {
@@ -788,7 +863,9 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[kBlock / 64][kSlab];
     __shared__ long long s_part[kBlock / 64];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[256 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    build_compact_lut(s_lut, tid);
     // the first wave-tile is requested BEFORE the prefix sweep (up to 16 dependent loads per thread + a barrier: 1-3 us during which the
     // block used to have nothing in flight)
     uint16_t* slab = s_val[wave];
@@ -805,6 +882,10 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
     int64_t run = (int64_t)s_part[0] + s_part[1] + s_part[2] + s_part[3] + (base ? *base : 0);
     for (int w = 0; w < wave; ++w) run += span_tot[(int64_t)blockIdx.x * 4 + w];
 
+    const uint32_t keepbits = is_float ? 0x7fff7fffu : 0xffffffffu;
+    const uint32_t slab_a = lds_addr(slab), dump_a = slab_a + 2u * (uint32_t)(kSlabData + lane), lut_a = lds_addr(s_lut);
+    // the next row that starts at or after this wave's first unit (one 64-bit division per wave, not per wave-tile)
+    int64_t next_r = (u0 + wt0 * kWT + upr - 1) / upr, next_u = next_r * upr;
     bool last_here = false;
     for (int j = 0; j < span; ++j) {
         const int64_t wt = wt0 + j;
@@ -815,38 +896,23 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
         uint32_t mm[4], rank[4];
         int total = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mm[i] = nz_mask16(cur[i], is_float);
-            const int c = __popc(mm[i]);
-            const int incl = wave_incl_scan(c);
-            rank[i] = (uint32_t)(incl - c + total);
-            total += __builtin_amdgcn_readlane(incl, 63);
-        }
+        for (int i = 0; i < 4; ++i) mm[i] = nz_mask16_fast(cur[i], keepbits);
+        total = tile_ranks(mm, rank);
         // row offsets of the rows that start inside this wave-tile (wave-uniform loop, usually 0-1 trips)
         {
             const int64_t ubeg = u0 + wt * kWT, uend = ubeg + kWT;  // tensor-wide unit numbers
-            for (int64_t r = (ubeg + upr - 1) / upr; r < rows && r * upr < uend; ++r) {
-                const int q = (int)(r * upr - ubeg);
+            for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
+                const int q = (int)(next_u - ubeg);
                 const int i = q >> 6, l = q & 63;
                 const uint32_t rk = i == 0 ? rank[0] : (i == 1 ? rank[1] : (i == 2 ? rank[2] : rank[3]));
-                if (lane == l) row_offsets[r] = run + rk;
+                if (lane == l) row_offsets[next_r] = run + rk;
             }
         }
         // compact into the wave's slab at the 16-byte phase of the destination
         // branch-free: every element is written, the zeros go to a per-lane dump slot (predicated
         // stores compile to an exec-mask save / branch / restore per element: measured slower)
         const int shift = (int)(run & 7);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t ws[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
-            uint32_t pos = (uint32_t)shift + rank[i];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool keep = (mm[i] >> k) & 1u;
-                slab[keep ? pos : (uint32_t)(kSlabData + lane)] = (uint16_t)((k & 1) ? (ws[k >> 1] >> 16) : ws[k >> 1]);
-                pos += keep ? 1u : 0u;
-            }
-        }
+        compact_into_slab(cur, mm, rank, shift, slab_a, dump_a, lut_a);
         // slab[shift, shift + total) -> vout[run, run + total): aligned 16-byte body, scalar head / tail
         const int64_t end = run + total;
         const int64_t e0 = run - shift;
@@ -871,40 +937,17 @@ __global__ __launch_bounds__(kBlock) void flat16_scatter_kernel(const u32x4* __r
     if (last_here && lane == 0 && total_out) *total_out = run;
 }
 
-// ------------------------------------------------------------------------- compress, ONE pass (16-bit), round 2 — EXPERIMENTAL
-// The two-kernel form reads x twice (349.7 MB of traffic for 209.8 MB of algorithmic bytes at 8192^2).  One pass needs every tile
-// to learn the number of non-zeros before it while it still holds its data.  Round 1 tried that four ways and lost
-// to the cross-XCD hand-off; this form (bit-exact, selected with CT_BITMASK_ONEPASS=1 / 2, NOT the default) changes what made the
-// hand-off expensive there and pins down what is left:
-//   * a wave's tile is 4 wave-tiles = 16 KB (1024 units) held in registers: 4x fewer hand-offs, ~256 KB of tile data in flight per CU;
-//   * no atomics, no memset, no separate flags: every hand-off word is 64 bits, (generation << 32) | value, written by ONE
-//     system-scope store and read by system-scope loads.  The generation is unique per call (random start per process), so the
-//     workspace needs no clearing and stale words never look valid;
-//   * three levels without a completion counter: tile t = 64 g + j publishes count[t]; the group's last tile has summed the whole
-//     group once its in-group wait ends and publishes S[g] THEN (before its own wait for the group prefix: publishing after it
-//     chained the 128 groups, 188 us); the group's first tile turns S[0..g) into the group prefix GP[g] for the other 63 (when
-//     every tile read the sums, 8192 polling waves hammered the same 16 cache lines: 78 us).
-// Dependencies only point to lower tiles = the same or an earlier workgroup, which the hardware has already dispatched: the wait
-// cannot deadlock whatever the residency.  It is bounded anyway; a wave that gives up leaves *total at the -1 the first tile
-// wrote there and the host-side wrapper falls back to count / scan / scatter.
-// Measured at 8192^2 (per-tile time stamps, CT_BITMASK_OP_NOWAIT=3): 65-71 us against 70 us for the two kernels and 47 us for
-// this kernel with the wait removed.  A tile lives ~27 us: load 5-8 (all 4096 resident tiles load at once), wait 11, scatter 7.
-// The wait is three dependent hops (count -> S -> GP -> tile) of 4-5 us each — the latency of a system-scope store becoming
-// visible to a system-scope load under a 6 TB/s stream; it does not depend on the polling rate (6 to 48 polls per tile: same
-// time) nor on pacing the first wave of workgroups (CT_BITMASK_OP_PACE: the loads then complete in tile order, the hops cost the
-// same).  With 4096 resident tiles x 16 KB and a 27 us lifetime the kernel moves 2.5 TB/s, not 6; to win, a hop has to cost
-// ~1 us, which on this part means staying inside one XCD's L2 — and the workgroup -> XCD placement that would allow it is not
-// something a kernel can rely on.
-constexpr int kOpWT = 4;                       // wave-tiles per tile
-constexpr int kOpTileUnits = kOpWT * kWT;      // 1024 units = 16 KB
-constexpr int kOpMaxGroups = 128;              // two 64-lane loads of group sums
-constexpr int kOpSpinLimit = 1 << 16;          // x ~1 us per poll: gives up long before a driver timeout
-
-// hand-off words travel at system scope: the store writes through to memory, the loads bypass the per-XCD L2s.  (Agent scope is
-// compiled to the same sc1 accesses on this multi-XCD part and measured identical.  An XCD-local variant — groups pinned to one XCD,
-// sc0-only accesses that meet in that XCD's L2 — resolved a hop in ~1.5 us instead of ~4.5 us where it worked, but workgroup b does
-// NOT reliably run on XCD b % 8 once slots are recycled, and waves that landed elsewhere polled stale lines until their bounded
-// wait gave up: dropped.)
+// ------------------------------------------------------------------------- hand-off words
+// History of the single-pass attempts (all bit-exact, all removed; DESIGN.md 5.4 has the numbers).  A tile that waits for its
+// prefix while holding its data in registers — decoupled look-back, two-level and three-level prefix words, XCD-local variants —
+// never beat the two kernels at 8192^2 (65-330 us against 70): a system-scope store becomes visible to a system-scope load on
+// another XCD after 3-5 us, independent of the polling rate, and thousands of tiles chained two or three such hops each.  The
+// resident form below needs ONE hop for the whole tensor and does all the expensive work before it.
+//
+// Hand-off words travel at system scope: the store writes through to memory, the loads bypass the per-XCD L2s (agent scope is
+// compiled to the same sc1 accesses on this multi-XCD part and measured identical).  Every word is 64 bits, (generation << 32) |
+// value, written by ONE store: the generation is unique per launch (random start per process), so the workspace needs no clearing
+// and stale words never look valid.
 __device__ __forceinline__ void op_store(unsigned long long* slot, unsigned long long v) {
     __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -912,214 +955,206 @@ __device__ __forceinline__ unsigned long long op_load(const unsigned long long* 
     return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__device__ __forceinline__ void op_backoff(int mode) {  // s_sleep takes an immediate: a few fixed steps (units of 64 clocks)
-    if (mode <= 0) __builtin_amdgcn_s_sleep(2);
-    else if (mode == 1) __builtin_amdgcn_s_sleep(8);
-    else if (mode == 2) __builtin_amdgcn_s_sleep(32);
-    else __builtin_amdgcn_s_sleep(127);
-}
+// ------------------------------------------------------------------------- compress, RESIDENT (16-bit), round 2
+// The one-pass forms above lose to the hand-off because a tile can only live in registers for a few microseconds while thousands
+// of tiles depend on one another.  This form turns the problem around: a workgroup's whole share of the tensor lives in its
+// registers across ONE hand-off, and everything expensive happens BEFORE the hand-off, while the loads are still landing.
+// Workgroup = 8 waves; a wave owns KEEP = 8 consecutive wave-tiles (32 KB, 128 VGPRs), a workgroup 256 KB:
+//   phase A  all 32 loads of a wave are issued up front (256 KB in flight per workgroup: the memory-level parallelism comes from
+//            the loads, not from occupancy).  As a tile lands: masks (-> an LDS plane, for the bitmask), ranks, compaction through the
+//            wave's LDS slab at the tile's own origin, and the compacted tile is read back INTO THE SAME registers; its count stays
+//            in a scalar.  The row offsets of rows that start in the tile are left in row_offsets[] relative to the tile.
+//   hand-off the workgroup's count goes out as ONE generation-tagged 64-bit system-scope word; workgroup b waits for the words of
+//            the b workgroups before it (lane t polls word t, t + 512, ...: every hop is direct, nothing is chained).  The bitmask
+//            leaves while the counts travel.
+//   phase B  stores only: each compacted tile goes to vout + (its offset) as 16-byte stores at 2-byte alignment (global memory
+//            takes them), its last partial vector element-wise; the stashed row offsets get the tile's offset added.
+// x is read once.  Workgroups beyond the chip's residency start as earlier ones retire (their reads overlap the others' stores);
+// dependencies point to lower workgroups only.  The wait is bounded by wall-clock time; a workgroup that gives up raises the
+// (generation-tagged) fail word, and a one-thread kernel after it writes *total — the count, or -1 when any workgroup failed, in
+// which case the caller falls back to the two kernels.
+typedef u32x4 u32x4_a2_t __attribute__((aligned(2)));
+constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB, 64 VGPRs)
+constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
+constexpr int kResMaxWGs = 8192;  // count words in the workspace: 1 GiB of 16-bit elements per launch, more goes in chunks
 
-__global__ __launch_bounds__(kBlock) void flat16_onepass_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows,
-                                                                uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
-                                                                int mask_dwords, int64_t* __restrict__ row_offsets, int64_t* __restrict__ total_out,
-                                                                unsigned long long* __restrict__ tile_cnt, unsigned long long* __restrict__ group_sum,
-                                                                unsigned long long* __restrict__ group_pre, uint32_t gen, int debug_nowait, int sleep_mode, int pace_q8,
-                                                                int pace_wgs) {
-    constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile (+ phase shift)
+template <int KEEP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows, int tpw,
+                                                                    uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
+                                                                    int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
+                                                                    const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
+                                                                    unsigned long long* __restrict__ run_out, unsigned long long* __restrict__ fail_word,
+                                                                    uint32_t gen, uint32_t gen_call, unsigned long long wait_ticks,
+                                                                    unsigned long long* __restrict__ stamps) {
+    constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
-    __shared__ __attribute__((aligned(16))) uint16_t s_val[kBlock / 64][kSlab];
-    __shared__ __attribute__((aligned(16))) uint8_t s_m[kBlock / 64][kWT];
+    __shared__ __attribute__((aligned(16))) uint16_t s_val[WAVES][kSlab];
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[256 * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mask[WAVES][KEEP][64];  // packed masks (unit i * 64 + lane in byte i)
+    __shared__ int s_cnt[WAVES];
+    __shared__ long long s_part[WAVES];
+    __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t b = blockIdx.x;
-    const int64_t tile = (int64_t)b * 4 + wave;  // dependencies only point to lower tiles = the same or an earlier workgroup
-    const int g = (int)(tile >> 6), jg = (int)(tile & 63);
-    const int64_t wt0 = tile * kOpWT;
-    if (wt0 * kWT >= units) return;  // wave-uniform
-    const int64_t ntiles = (units + kOpTileUnits - 1) / kOpTileUnits;
-    const int j_last = (int)((ntiles - ((int64_t)g << 6)) < 64 ? (ntiles - ((int64_t)g << 6)) - 1 : 63);  // last existing tile of the group
-    // Paced start.  The first wave of workgroups (every slot of the chip) would otherwise issue 67 MB of loads at once: they all
-    // complete together ~10-16 us later, all wait for their prefix together and all scatter together — load, hand-off and store
-    // phases in lockstep, memory idle two thirds of the time (measured: 67 us).  Delaying workgroup b by b x (its tile bytes /
-    // the HBM rate) makes the data arrive in tile order at the rate the memory delivers it; later workgroups inherit the stagger
-    // from the slots they take over.  pace_q8 = delay per workgroup in 1/256 of an s_sleep unit (64 clocks).
-    if (pace_q8 > 0 && (int)b < pace_wgs) {
-        const int n = (int)(((int64_t)b * pace_q8) >> 12);  // s_sleep(16) steps
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    unsigned long long* dbg = debug_nowait == 3 ? group_pre + kOpMaxGroups + 4 + tile * 4 : nullptr;  // per-tile time stamps (debug)
-    if (dbg && lane == 0) dbg[0] = wall_clock64();
-    // ---- phase 1: the tile into registers, bitmask out, count published
-    u32x4 data[kOpWT][4];
+    const int b = (int)blockIdx.x;
+    const int64_t wt0 = ((int64_t)b * WAVES + wave) * tpw;  // tpw <= KEEP wave-tiles per wave
+    const uint32_t keepbits = is_float ? 0x7fff7fffu : 0xffffffffu;
+    if (tid == 0) s_fail = 0;
+    if (stamps && tid == 0 && b < 512) stamps[b * 4 + 0] = wall_clock64();
+    // ---- phase A
+    u32x4 keep[KEEP][4];
 #pragma unroll
-    for (int j = 0; j < kOpWT; ++j) load_wt(x, units, wt0 + j, lane, data[j]);
-    uint32_t mpack[kOpWT];  // the four mask bytes of a wave-tile (unit i*64 + lane in byte i)
+    for (int i = 0; i < KEEP; ++i) {
+        if (i < tpw) load_wt(x, units, wt0 + i, lane, keep[i]);  // zeros beyond the chunk
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) keep[i][q] = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    build_compact_lut(s_lut, tid);
+    __syncthreads();
+    const uint32_t slab_a = lds_addr(s_val[wave]), dump_a = slab_a + 2u * (uint32_t)(kSlabData + lane), lut_a = lds_addr(s_lut);
+    const u32x4* slab_v = reinterpret_cast<const u32x4*>(s_val[wave]);
+    int tot[KEEP];  // wave-uniform
+    int64_t next_r = (u0 + wt0 * kWT + upr - 1) / upr, next_u = next_r * upr;  // the next row that starts at or after the wave's first unit
+    const int64_t first_r = next_r;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        tot[i] = 0;
+        if (i >= tpw) continue;  // wave-uniform
+        uint32_t mm[4], rank[4], pk = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mm[q] = nz_mask16_fast(keep[i][q], keepbits);
+            pk |= mm[q] << (8 * q);
+        }
+        s_mask[wave][i][lane] = pk;
+        tot[i] = tile_ranks(mm, rank);
+        {   // rows that start inside this wave-tile: their offset relative to the tile, completed in phase B
+            const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
+            for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
+                const int q = (int)(next_u - ubeg);
+                const int qi = q >> 6, l = q & 63;
+                const uint32_t rk = qi == 0 ? rank[0] : (qi == 1 ? rank[1] : (qi == 2 ? rank[2] : rank[3]));
+                if (lane == l) row_offsets[next_r] = (int64_t)rk;
+            }
+        }
+        compact_into_slab(keep[i], mm, rank, 0, slab_a, dump_a, lut_a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[i][q] = slab_v[q * 64 + lane];  // vector q * 64 + lane of the compacted tile (garbage past tot)
+    }
     int cnt = 0;
 #pragma unroll
-    for (int j = 0; j < kOpWT; ++j) {
-        const int64_t wt = wt0 + j;
-        mpack[j] = 0;
+    for (int i = 0; i < KEEP; ++i) cnt += tot[i];
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int wg = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t m = nz_mask16(data[j][i], is_float);
-            mpack[j] |= m << (8 * i);
-            cnt += __popc(m);
-        }
-        if (wt * kWT < units) {
+        for (int w = 0; w < WAVES; ++w) wg += s_cnt[w];
+        op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
+        if (stamps && b < 512) stamps[b * 4 + 1] = wall_clock64();
+    }
+    // ---- the bitmask leaves while the counts travel: output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the
+    // packed masks of lanes 4 (L & 15) .. + 3
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        const int64_t wt = wt0 + i;
+        if (i < tpw && wt * kWT < units) {  // wave-uniform
             if (mask_dwords) {
-                // same-wave LDS operations execute in order: no barrier
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s_m[wave][i * 64 + lane] = (uint8_t)(mpack[j] >> (8 * i));
-                const uint32_t d = reinterpret_cast<const uint32_t*>(s_m[wave])[lane];
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(s_mask[wave][i]) + 16 * (lane & 15) + (lane >> 4);
+                const uint32_t d = (uint32_t)src[0] | ((uint32_t)src[4] << 8) | ((uint32_t)src[8] << 16) | ((uint32_t)src[12] << 24);
                 const int64_t u = wt * kWT + 4 * lane;
                 if (u < units) *reinterpret_cast<uint32_t*>(bitmask + u) = d;
             } else {
+                const uint32_t pk = s_mask[wave][i][lane];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t u = wt * kWT + i * 64 + lane;
-                    if (u < units) bitmask[u] = (uint8_t)(mpack[j] >> (8 * i));
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t u = wt * kWT + q * 64 + lane;
+                    if (u < units) bitmask[u] = (uint8_t)(pk >> (8 * q));
                 }
             }
         }
     }
-    const int tile_total = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
-    // failure protocol: the first tile marks the total invalid (write-through, long before the last tile can finish); a kernel that
-    // gave up never overwrites it
-    if (tile == 0 && lane == 0 && total_out) __hip_atomic_store(total_out, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 0) op_store(tile_cnt + tile, ((unsigned long long)gen << 32) | (uint32_t)tile_total);
-    // ---- phase 2: look-back.  lanes < j watch the earlier tiles of this group, lanes < g (and < g - 64) the earlier groups' sums
-    int64_t run;
-    const unsigned long long t_wait0 = wall_clock64();
-    if (dbg && lane == 0) dbg[1] = t_wait0;
-    int dbg_spins = 0;
-    if (debug_nowait == 1) {  // timing experiment only (wrong positions): what the kernel costs without any hand-off
-        run = tile * 4096;
-    } else if (jg == 0) {
-        // the group's first tile turns the earlier groups' sums into the group's exclusive prefix, for itself and for the other 63:
-        // only 128 tiles ever read the sum array (when every tile did, 8192 polling waves hammered the same 16 cache lines — one
-        // memory channel — and the kernel took 78 us)
-        const bool need_s0 = lane < g, need_s1 = lane + 64 < g;
-        const uint32_t want = (need_s0 ? 1u : 0u) | (need_s1 ? 2u : 0u);
-        uint32_t have = 0, ps = 0;
-        const unsigned long long* ps0_addr = group_sum + (need_s0 ? lane : 0);
-        const unsigned long long* ps1_addr = group_sum + (need_s1 ? 64 + lane : 0);
-        int spins = 0;
-        bool ok = g == 0;
-        while (!ok && spins++ < kOpSpinLimit) {
-            ++dbg_spins;
-            // only the lanes that still miss a word issue a load: every poll is a system-scope request that competes with the data stream
-            unsigned long long v0 = 0, v1 = 0;
-            if (need_s0 && !(have & 1u)) v0 = op_load(ps0_addr);
-            if (need_s1 && !(have & 2u)) v1 = op_load(ps1_addr);
-            if (need_s0 && !(have & 1u) && (uint32_t)(v0 >> 32) == gen) { ps += (uint32_t)v0; have |= 1u; }
-            if (need_s1 && !(have & 2u) && (uint32_t)(v1 >> 32) == gen) { ps += (uint32_t)v1; have |= 2u; }
-            ok = __builtin_amdgcn_ballot_w64(have != want) == 0;
-            if (!ok) op_backoff(sleep_mode);
+    // ---- hand-off: lane t watches the words of workgroups t, t + 512, ...
+    {
+        long long part = 0;
+        bool ok = true;
+        const unsigned long long t0 = wall_clock64();
+        for (int w0 = 0; w0 < b; w0 += (WAVES * 64)) {  // workgroup-uniform trip count
+            const int w = w0 + tid;
+            const bool need = w < b;
+            bool got = !need;
+            uint32_t mine = 0;
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
+                for (;;) {
+                    if (!got) {
+                        const unsigned long long v = op_load(slots + w);
+                        if ((uint32_t)(v >> 32) == gen) { mine = (uint32_t)v; got = true; }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
+                    if (wall_clock64() - t0 > wait_ticks) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            ok = ok && got;
+            part += mine;
         }
-        if (!ok) return;  // cannot happen by construction; never hang the GPU on a bug: *total_out stays -1 and the caller falls back
-        run = ps;
+        if (__builtin_amdgcn_ballot_w64(!ok) != 0 && lane == 0) s_fail = 1;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) run += __shfl_xor(run, d, 64);
-        // 40 bits of prefix under the 24 low bits of the generation: enough for 2^40 non-zeros before a group
-        if (lane == 0) op_store(group_pre + g, ((unsigned long long)(gen & 0xffffffu) << 40) | (unsigned long long)run);
-        if (j_last == 0 && lane == 0) op_store(group_sum + g, ((unsigned long long)gen << 32) | (uint32_t)tile_total);  // a one-tile group
-    } else {
-        // lanes < j watch the earlier counts of the group, lane 63 the group's prefix
-        const bool need_c = lane < jg, need_p = lane == 63;
-        const unsigned long long* addr = need_p ? group_pre + g : tile_cnt + ((int64_t)g << 6) + (need_c ? lane : 0);
-        uint64_t mine = 0;
-        bool got = !(need_c || need_p), sum_published = jg != j_last;
-        int spins = 0;
-        bool ok;
-        do {
-            ++dbg_spins;
-            if (!got) {
-                const unsigned long long v = op_load(addr);
-                if (need_p) { if ((uint32_t)(v >> 40) == (gen & 0xffffffu)) { mine = v & 0xffffffffffull; got = true; } }
-                else if ((uint32_t)(v >> 32) == gen) { mine = (uint32_t)v; got = true; }
-            }
-            // the last tile of a group publishes the group's sum as soon as the group's counts are in — NOT after its wait for the
-            // group's prefix, which would chain the 128 groups one hand-off after the other (measured: 188 us)
-            if (!sum_published && __builtin_amdgcn_ballot_w64(need_c && !got) == 0) {
-                int64_t gs = need_c ? (int64_t)mine : 0;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) gs += __shfl_xor(gs, d, 64);
-                if (lane == 0) op_store(group_sum + g, ((unsigned long long)gen << 32) | (uint32_t)(gs + tile_total));  // read on other XCDs
-                sum_published = true;
-            }
-            ok = __builtin_amdgcn_ballot_w64(!got) == 0;
-            if (!ok) op_backoff(sleep_mode);
-        } while (!ok && ++spins < kOpSpinLimit);
-        if (!ok) return;
-        run = (int64_t)mine;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) run += __shfl_xor(run, d, 64);
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_part[wave] = part;
     }
-    if (dbg && lane == 0) dbg[2] = wall_clock64();
-    if (debug_nowait == 2 && lane == 0) {  // hand-off statistics: polls, waiting time (100 MHz ticks) summed and maximal
-        const unsigned long long dt = wall_clock64() - t_wait0;
-        atomicAdd(group_pre + kOpMaxGroups, (unsigned long long)dbg_spins);
-        atomicAdd(group_pre + kOpMaxGroups + 1, dt);
-        atomicMax(group_pre + kOpMaxGroups + 2, dt);
+    __syncthreads();
+    const bool failed = s_fail != 0;  // workgroup-uniform
+    if (stamps && tid == 0 && b < 512) stamps[b * 4 + 2] = wall_clock64();
+    if (!failed) {
+        int64_t run = base ? (int64_t)*base : 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) run += s_part[w];
+        for (int w = 0; w < wave; ++w) run += s_cnt[w];
+        // ---- phase B: stores only
+        next_r = first_r;
+        next_u = first_r * upr;
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int64_t wt = wt0 + i;
+            const int total = tot[i];
+            if (i >= tpw) continue;  // wave-uniform
+            {   // complete the row offsets stashed in phase A (same lane wrote them)
+                const int64_t uend = u0 + (wt + 1) * kWT;
+                for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
+                    const int l = (int)(next_u - (u0 + wt * kWT)) & 63;
+                    if (lane == l) row_offsets[next_r] += run;
+                }
+            }
+            const int64_t lim = run + total < capacity ? run + total : capacity;  // one past the last element this tile may write
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t gi = run + ((int64_t)(q * 64 + lane) << 3);
+                if (gi + 8 <= lim) {
+                    __builtin_nontemporal_store(keep[i][q], reinterpret_cast<u32x4_a2_t*>(vout + gi));  // 2-byte aligned
+                } else if (gi < lim) {
+                    const uint32_t ws[4] = {keep[i][q].x, keep[i][q].y, keep[i][q].z, keep[i][q].w};
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (gi + t < lim) vout[gi + t] = (uint16_t)((t & 1) ? (ws[t >> 1] >> 16) : ws[t >> 1]);
+                }
+            }
+            run += total;
+            if ((wt + 1) * kWT >= units && wt * kWT < units && lane == 0) op_store(run_out, (unsigned long long)run);  // the chunk's last wave-tile
+        }
     }
-    // ---- phase 3: scatter the four wave-tiles with a running prefix (the body of flat16_scatter_kernel)
-    uint16_t* slab = s_val[wave];
-    bool last_here = false;
-#pragma unroll
-    for (int j = 0; j < kOpWT; ++j) {
-        const int64_t wt = wt0 + j;
-        if (wt * kWT >= units) break;  // wave-uniform
-        last_here = (wt + 1) * kWT >= units;
-        uint32_t mm[4], rank[4];
-        int total = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mm[i] = (mpack[j] >> (8 * i)) & 0xffu;
-            const int c = __popc(mm[i]);
-            const int incl = wave_incl_scan(c);
-            rank[i] = (uint32_t)(incl - c + total);
-            total += __builtin_amdgcn_readlane(incl, 63);
-        }
-        {
-            const int64_t ubeg = wt * kWT, uend = ubeg + kWT;
-            for (int64_t r = (ubeg + upr - 1) / upr; r < rows && r * upr < uend; ++r) {
-                const int q = (int)(r * upr - ubeg);
-                const int i = q >> 6, l = q & 63;
-                const uint32_t rk = i == 0 ? rank[0] : (i == 1 ? rank[1] : (i == 2 ? rank[2] : rank[3]));
-                if (lane == l) row_offsets[r] = run + rk;
-            }
-        }
-        const int shift = (int)(run & 7);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t ws[4] = {data[j][i].x, data[j][i].y, data[j][i].z, data[j][i].w};
-            uint32_t pos = (uint32_t)shift + rank[i];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool keep = (mm[i] >> k) & 1u;
-                slab[keep ? pos : (uint32_t)(kSlabData + lane)] = (uint16_t)((k & 1) ? (ws[k >> 1] >> 16) : ws[k >> 1]);
-                pos += keep ? 1u : 0u;
-            }
-        }
-        const int64_t end = run + total;
-        const int64_t e0 = run - shift;
-        const int64_t body_lo = (run + 7) & ~(int64_t)7, body_hi = end & ~(int64_t)7;
-        if (body_hi > body_lo) {
-            const int nvec = (int)((body_hi - body_lo) >> 3);
-            const int v0 = (int)((body_lo - e0) >> 3);
-            for (int v = lane; v < nvec; v += 64) {
-                const int64_t gi = body_lo + ((int64_t)v << 3);
-                if (gi + 8 <= capacity) stream_store16(vout + gi, reinterpret_cast<const u32x4*>(slab)[v0 + v]);
-                else for (int t = 0; t < 8; ++t) if (gi + t < capacity) vout[gi + t] = slab[gi + t - e0];
-            }
-            for (int64_t gi = run + lane; gi < body_lo; gi += 64) if (gi < capacity) vout[gi] = slab[gi - e0];
-            for (int64_t gi = body_hi + lane; gi < end; gi += 64) if (gi < capacity) vout[gi] = slab[gi - e0];
-        } else {
-            for (int64_t gi = run + lane; gi < end; gi += 64) if (gi < capacity) vout[gi] = slab[gi - e0];
-        }
-        run = end;
-    }
-    if (last_here && lane == 0 && total_out) __hip_atomic_store(total_out, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (dbg && lane == 0) dbg[3] = wall_clock64();
+    if (failed && tid == 0) op_store(fail_word, ((unsigned long long)gen_call << 32) | 1ull);
+    if (stamps && tid == 0 && b < 512) stamps[b * 4 + 3] = wall_clock64();
+}
+
+// *total = the count the last wave left, or -1 when any workgroup of the call raised the fail word.  A separate one-thread launch:
+// the kernel boundary is the only "every workgroup has finished" signal that costs no atomics (a generation-tagged CAS counter
+// — 256 workgroups finishing together on one system-scope word — serialised at ~2 us per workgroup: 580 us).
+__global__ void flat16_resident_finish_kernel(const unsigned long long* __restrict__ fail_word, const unsigned long long* __restrict__ run_word,
+                                              uint32_t gen_call, int64_t* __restrict__ total_out) {
+    const unsigned long long f = op_load(fail_word);
+    *total_out = ((uint32_t)(f >> 32) == gen_call) ? (int64_t)-1 : (int64_t)op_load(run_word);
 }
 
 // ------------------------------------------------------------------------- 2:4
@@ -1268,8 +1303,8 @@ int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0) return 16;
     const Flat16Plan p = flat16_plan(rows, cols);
     int64_t flat = p.nblocks * 8 + p.nblocks * 4 * 4 + 8 * kMaxChunks;  // block totals (int64) + span totals (int32) + chunk totals
-    const int64_t onepass = (cdiv64(p.units, kOpTileUnits) * 5 + 2 * kOpMaxGroups + 4) * 8;  // tile counts + group sums + group prefixes (+ debug statistics / time stamps)
-    if (onepass > flat) flat = onepass;
+    const int64_t resident = (int64_t)(kResMaxWGs + 4 + 4 * 512) * 8;  // count words + control words (+ time stamps of the first 512 workgroups)
+    if (resident > flat) flat = resident;
     const int64_t generic = (rows + 1) * 8;                  // row counts of the count / scan / scatter form
     return (flat > generic ? flat : generic) + 16;
 }
@@ -1288,34 +1323,65 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                (long long)need);
     CT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace must be 8-byte aligned");
     CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
-    // 0: two kernels (x read twice; default — the one-pass form is bit-exact but not faster, see above), 1: one pass for tensors of at
-    // least 4 MB, 2: one pass whenever the tile count fits (tests)
-    static const int onepass_mode = []() { const char* e = std::getenv("CT_BITMASK_ONEPASS"); return e ? std::atoi(e) : 0; }();
-    if (es == 2 && cols % 8 == 0 && aligned16(x) && onepass_mode) {
+    // 16-bit elements: the resident form (x read once).  CT_BITMASK_RESIDENT=0 selects the two kernels below (x read twice), which
+    // are also what the caller falls back to when the resident form reports -1; 3 = time stamps of the first 512 workgroups in the
+    // workspace (tools/exp_r02.py bmres)
+    static const int resident_mode = []() { const char* e = std::getenv("CT_BITMASK_RESIDENT"); return e ? std::atoi(e) : 1; }();
+    if (es == 2 && cols % 8 == 0 && aligned16(x) && resident_mode) {
         const int64_t units = rows * (cols / 8);
-        const int64_t tiles = cdiv64(units, kOpTileUnits);
-        // up to 128 groups of 64 tiles (8192^2 elements); below ~4 MB the two-kernel form's launches are not what costs
-        if (tiles <= (int64_t)kOpMaxGroups * 64 && (onepass_mode >= 2 || tiles >= 256)) {
-            // unique per call in this process, and started at a random point so that words left in recycled device memory by another
-            // process do not carry a matching tag either
-            static const int sleep_mode = []() { const char* e = std::getenv("CT_BITMASK_OP_SLEEP"); return e ? std::atoi(e) : 1; }();
-            static const int debug_nowait = []() { const char* e = std::getenv("CT_BITMASK_OP_NOWAIT"); return e ? std::atoi(e) : 0; }();
+        const int64_t wts = cdiv64(units, kWT);
+        int dev = 0, cus = kCUs;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            static std::atomic<int> cu_cache[64];
+            int c = dev >= 0 && dev < 64 ? cu_cache[dev].load() : 0;
+            if (c <= 0) {
+                if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = kCUs;
+                if (dev >= 0 && dev < 64) cu_cache[dev].store(c);
+            }
+            cus = c;
+        }
+        // wave-tiles per wave: as many as the registers hold, fewer when the tensor would otherwise leave CUs without a workgroup
+        // (two workgroups fit a CU)
+        int64_t tpw = cdiv64(wts, (int64_t)cus * 2 * kResWaves);
+        if (tpw > kResKeep) tpw = kResKeep;
+        if (tpw < 1) tpw = 1;
+        const int64_t wg_wts = (int64_t)kResWaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
+        static const int64_t max_wgs = []() {  // per launch: the count words of the workspace (the knob exists for the chunking tests)
+            const char* e = std::getenv("CT_BITMASK_RESIDENT_MAX_WGS");
+            const int64_t v = e ? (int64_t)std::atoll(e) : (int64_t)kResMaxWGs;
+            return v < 1 ? (int64_t)1 : (v > kResMaxWGs ? (int64_t)kResMaxWGs : v);
+        }();
+        const int64_t chunk_wts = max_wgs * wg_wts;
+        const int64_t nchunks = cdiv64(wts, chunk_wts);
+        if (nchunks <= 4096) {
             static std::atomic<uint32_t> generation{[]() {
                 std::random_device rd;
                 return (uint32_t)rd() ^ (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count();
             }()};
-            const uint32_t gen = generation.fetch_add(1u) + 1u;
-            unsigned long long* tile_cnt = static_cast<unsigned long long*>(workspace);
-            unsigned long long* group_sum = tile_cnt + tiles;
-            unsigned long long* group_pre = group_sum + kOpMaxGroups;
-            const int mask_dwords = (units % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0);
-            if (debug_nowait == 2) (void)hipMemsetAsync(group_pre + kOpMaxGroups, 0, 32, as_stream(stream));
-            static const int pace_q8 = []() { const char* e = std::getenv("CT_BITMASK_OP_PACE"); return e ? std::atoi(e) : 0; }();
-            static const int pace_wgs = []() { const char* e = std::getenv("CT_BITMASK_OP_PACE_WGS"); return e ? std::atoi(e) : 1024; }();
-            hipLaunchKernelGGL(flat16_onepass_kernel, dim3((unsigned)cdiv64(tiles, 4)), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x),
-                               float_kind(dt), units, cols / 8, rows, static_cast<uint16_t*>(values), values_capacity, bitmask, mask_dwords, row_offsets,
-                               total, tile_cnt, group_sum, group_pre, gen, debug_nowait, sleep_mode, pace_q8, pace_wgs);
-            CT_LAUNCH_CHECK("ct_bitmask_compress[onepass]");
+            // unique per launch in this process (random start: words left in recycled device memory by another process carry no
+            // matching tag either); the call's first tag also marks its fail word
+            const uint32_t gen0 = generation.fetch_add((uint32_t)nchunks) + 1u;
+            unsigned long long* slots = static_cast<unsigned long long*>(workspace);
+            unsigned long long* ctl = slots + kResMaxWGs;  // [1] fail word, [2] / [3] running totals (alternating between chunks)
+            unsigned long long* stamps = resident_mode == 3 ? ctl + 4 : nullptr;
+            static const unsigned long long wait_ticks = []() {  // 100 MHz ticks; default 200 ms
+                const char* e = std::getenv("CT_BITMASK_RESIDENT_WAIT_US");
+                return (unsigned long long)(e ? std::atoll(e) : 200000ll) * 100ull;
+            }();
+            for (int64_t k = 0; k < nchunks; ++k) {
+                const int64_t w0 = k * chunk_wts;
+                const int64_t cw = (wts - w0) < chunk_wts ? (wts - w0) : chunk_wts;
+                const int64_t u0 = w0 * kWT;
+                const int64_t cu = (units - u0) < cw * kWT ? (units - u0) : cw * kWT;
+                const int64_t nwg = cdiv64(cw, wg_wts);
+                const int mask_dwords = (cu % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask + u0) & 3u) == 0);
+                hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),
+                                   static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, cols / 8, rows, (int)tpw, static_cast<uint16_t*>(values),
+                                   values_capacity, bitmask + u0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots,
+                                   ctl + 2 + (k & 1), ctl + 1, gen0 + (uint32_t)k, gen0, wait_ticks, k == 0 ? stamps : nullptr);
+            }
+            hipLaunchKernelGGL(flat16_resident_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), ctl + 1, ctl + 2 + ((nchunks - 1) & 1), gen0, total);
+            CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
         }
     }
     if (es == 2 && cols % 8 == 0 && aligned16(x)) {
@@ -1347,8 +1413,8 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
             hipLaunchKernelGGL(flat16_count_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream), xc, float_kind(dt), cu, p.span, bitmask + u0,
                                mask_dwords, block_tot + b0, span_tot + 4 * b0);
             hipLaunchKernelGGL(flat16_scatter_kernel, dim3((unsigned)nb), dim3(kBlock), 0, as_stream(stream), xc, float_kind(dt), cu, p.span, cols / 8, rows,
-                               static_cast<uint16_t*>(values), values_capacity, row_offsets, (b0 + nb >= p.nblocks) ? total : chunk_tot + chunk,
-                               block_tot + b0, span_tot + 4 * b0, u0, chunk ? chunk_tot + chunk - 1 : static_cast<const int64_t*>(nullptr));
+                           static_cast<uint16_t*>(values), values_capacity, row_offsets, (b0 + nb >= p.nblocks) ? total : chunk_tot + chunk,
+                           block_tot + b0, span_tot + 4 * b0, u0, chunk ? chunk_tot + chunk - 1 : static_cast<const int64_t*>(nullptr));
         }
         CT_LAUNCH_CHECK("ct_bitmask_compress[flat16]");
     }

@@ -646,9 +646,48 @@ def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt, shape):
     assert torch.equal(comp.cpu().float(), comp_ref.cpu().float()) and torch.equal(meta.cpu(), meta_ref.cpu())
 
 
-def test_bitmask_one_pass_kernel_matches_two_pass(tmp_path):
-    """the experimental one-pass sparse compress (decoupled look-back, CT_BITMASK_ONEPASS=2; the knobs are read once per process, hence
-    the subprocess): values, bitmask, row offsets and the total bit-identical to count / scan / scatter for ragged, empty, dense shapes"""
+_BITMASK_FORMS_CODE = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from compressed_tensors_amd import codec
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(5)
+for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, torch.float16), (3000, 1000, 0.9, torch.bfloat16), (513, 8200, 0.5, torch.bfloat16),
+                         (2048, 4096, 0.0, torch.bfloat16), (1024, 4096, 1.0, torch.float16), (8192, 8192, 0.5, torch.bfloat16), (7, 8, 0.5, torch.int16),
+                         (1, 8, 1.0, torch.bfloat16), (4099, 24, 0.5, torch.float16)):
+    w = torch.randn(r, c, device=dev, generator=g)
+    w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
+    w = (w * 100).to(dt) if dt == torch.int16 else w.to(dt)
+    if dt != torch.int16 and dens > 0:
+        w.view(-1)[::7] = -0.0  # a negative zero is a zero
+    for rep in range(3):  # a fresh generation tag per call over recycled workspace memory
+        v, bm, ro = codec.bitmask_compress(w)
+        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
+        assert v.numel() == v2.numel() and torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2), (r, c, dens, rep)
+print("FORMS_OK")
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {},                                          # the resident form (default)
+    {"CT_BITMASK_RESIDENT": "0"},                # the two kernels (count + scatter)
+    {"CT_BITMASK_RESIDENT_MAX_WGS": "3"},        # resident, the tensor in chunks of three workgroups with a running total between them
+    {"CT_BITMASK_RESIDENT_WAIT_US": "0"},        # every workgroup that has to wait gives up: *total = -1 and the codec falls back
+], ids=["resident", "two_kernels", "resident_chunked", "resident_gives_up"])
+def test_bitmask_compress_forms_agree(env):
+    """every form of the 16-bit sparse compress (the knobs are read once per process, hence the subprocess): values, bitmask, row
+    offsets and the total bit-identical to count / scan / scatter for ragged, empty, dense, tiny shapes"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _BITMASK_FORMS_CODE % root], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "FORMS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_bitmask_resident_reports_failure(dev):
+    """the raw ABI: with a zero wait budget the resident form must say -1 in *total (never a wrong count)"""
     import os
     import subprocess
     import sys
@@ -657,22 +696,20 @@ def test_bitmask_one_pass_kernel_matches_two_pass(tmp_path):
     code = r"""
 import sys, torch
 sys.path.insert(0, %r)
-from compressed_tensors_amd import codec
-dev = torch.device("cuda:0")
-g = torch.Generator(device=dev).manual_seed(5)
-for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, torch.float16), (3000, 1000, 0.9, torch.bfloat16), (513, 8200, 0.5, torch.bfloat16),
-                         (2048, 4096, 0.0, torch.bfloat16), (1024, 4096, 1.0, torch.float16), (8192, 8192, 0.5, torch.bfloat16), (7, 8, 0.5, torch.int16)):
-    w = torch.randn(r, c, device=dev, generator=g)
-    w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
-    w = (w * 100).to(dt) if dt == torch.int16 else w.to(dt)
-    for rep in range(3):  # a fresh generation tag per call over recycled workspace memory
-        v, bm, ro = codec.bitmask_compress(w)
-        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
-        assert torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2), (r, c, dens, rep)
-print("ONEPASS_OK")
+from compressed_tensors_amd import _lib
+lib = _lib.load(); dev = torch.device("cuda:0")
+N = 4096
+w = torch.randn(N, N, dtype=torch.bfloat16, device=dev)
+ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+rc = lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes,
+                             torch.cuda.current_stream(dev).cuda_stream)
+torch.cuda.synchronize()
+print("TOTAL", rc, int(wk[-1].item()))
 """ % root
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, CT_BITMASK_ONEPASS="2"))
-    assert r.returncode == 0 and "ONEPASS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, CT_BITMASK_RESIDENT_WAIT_US="0"))
+    assert r.returncode == 0 and "TOTAL 0 -1" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 # ----------------------------------------------------------------------------- modules / staging

@@ -34,70 +34,73 @@ elif what == "rtn8":
 elif what == "qp":
     r = B.qparams_leg(dev)
     print(json.dumps({"U": os.environ.get("CT_QP_U"), "us": r["us"], "fused_us": r["fused_with_compress"]["us"]}))
-elif what == "bm1":
-    # one-pass vs two-kernel sparse compress: correctness on several shapes / densities, then timing at 8192^2
-    from compressed_tensors_amd import codec
-    import time
-    res = {"mode": os.environ.get("CT_BITMASK_ONEPASS")}
-    g = torch.Generator(device=dev).manual_seed(5)
-    ok = True
-    for (r, c, dens) in ((8192, 8192, 0.5), (4096, 4096, 0.5), (1024, 2048, 0.1), (3000, 1000, 0.9), (513, 8200, 0.5), (8192, 8192, 0.0), (2048, 4096, 1.0)):
-        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
-        w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
-        v, bm, ro = codec.bitmask_compress(w)
-        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
-        same = torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2)
-        ok = ok and same
-        if not same:
-            res.setdefault("bad", []).append([r, c, dens, int(v.numel()), int(v2.numel())])
-    res["equal_to_two_pass"] = ok
-    r = B.bitmask_leg(dev)
-    res.update(compress_us=r["compress_us"], ok=r["round_trip_bit_exact"])
-    print(json.dumps(res))
 elif what == "bm2":
     r = B.bitmask_leg(dev)
     print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("CT_BITMASK")}, "compress_us": r["compress_us"], "ok": r["round_trip_bit_exact"]}))
-elif what == "bm3":
-    # hand-off statistics of the one-pass kernel (CT_BITMASK_OP_NOWAIT=2)
+elif what == "bmres":
+    # resident bitmask compress: run with CT_BITMASK_RESIDENT=1|2|3; parity against a CT_BITMASK_RESIDENT=0 subprocess dump is done by
+    # comparing with the count / scan / scatter form (two_pass=True) in-process
+    from compressed_tensors_amd import _lib, codec
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator(device=dev).manual_seed(11)
+    res = {"mode": os.environ.get("CT_BITMASK_RESIDENT")}
+    ok = True
+    for (r, c, dens) in ((8192, 8192, 0.5), (4096, 4096, 0.5), (8192, 8192, 0.05), (8192, 8192, 1.0), (1000, 4104, 0.3), (3, 8, 0.5), (257, 2048, 0.0), (12288, 8192, 0.5), (16384, 16384, 0.5)):
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        if dens < 1.0:
+            w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
+        v, bm, ro = codec.bitmask_compress(w)
+        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
+        same = v.numel() == v2.numel() and torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2)
+        ok = ok and same
+        res[f"{r}x{c}@{dens}"] = bool(same)
+        del w, v, v2, bm, bm2, ro, ro2
+        torch.cuda.empty_cache()
+    res["all_equal"] = ok
+    for N in (8192, 4096, 2048, 1024, 256):
+        nsets = 6
+        ws_ = []
+        for i in range(nsets):
+            w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+            ws_.append(w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0))
+        ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+        wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+        vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+        f = lambda i: lib.ct_bitmask_compress(ws_[i % nsets].data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes, stream)
+        res[f"us_{N}"] = round(B.time_kernel(f, 40), 2)
+        res[f"total_{N}"] = int(wk[-1].item())
+        if os.environ.get("CT_BITMASK_RESIDENT") == "3":
+            torch.cuda.synchronize()
+            st = wk[8196: 8196 + 4 * 512].reshape(512, 4).cpu().double()
+            st = st[st[:, 3] > 0]
+            if st.shape[0] > 256:
+                aa = ((st - st[:, 0].min()) / 100.0).numpy()
+                import numpy as np
+                res[f"rounds_{N}"] = [[round(float(np.median(aa[sl, k])), 1) for k in range(4)] + [round(float(aa[sl, 3].max()), 1)] for sl in (slice(0, 256), slice(256, None))]
+            st = (st - st[:, 0].min()) / 100.0
+            import numpy as np
+            a = st.numpy()
+            wk[8196: 8196 + 4 * 512] = 0
+            res[f"stamps_{N}"] = {"wgs": int(a.shape[0]), "start_max": float(a[:, 0].max()), "published_med": float(np.median(a[:, 1])), "published_max": float(a[:, 1].max()),
+                                  "resolved_med": float(np.median(a[:, 2])), "resolved_max": float(a[:, 2].max()), "done_med": float(np.median(a[:, 3])), "done_max": float(a[:, 3].max())}
+        del ws_, vals, bm, ro
+        torch.cuda.empty_cache()
+    print(json.dumps(res))
+elif what == "bmres1":
+    # a few launches of the bitmask compress at 8192^2 (for rocprofv3 counter passes)
     from compressed_tensors_amd import _lib
     lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
-    N = B.N
-    g = torch.Generator(device=dev).manual_seed(7)
+    g = torch.Generator(device=dev).manual_seed(11)
+    N = 8192
     w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
     w = w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0)
     ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
-    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+    wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
     vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
-    for _ in range(3):
-        lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), ws[-1:].data_ptr(), ws.data_ptr(), ws_bytes, stream)
-        torch.cuda.synchronize()
-        tiles = N * N // 8 // 1024
-        st = ws[tiles + 256: tiles + 259].tolist()
-        print(json.dumps({"tiles": tiles, "polls_per_tile": st[0] / tiles, "avg_wait_us": st[1] / tiles / 100.0, "max_wait_us": st[2] / 100.0, "total": int(ws[-1].item())}))
-elif what == "bm4":
-    # per-tile time stamps of the one-pass kernel (CT_BITMASK_OP_NOWAIT=3)
-    from compressed_tensors_amd import _lib
-    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
-    N = B.N
-    g = torch.Generator(device=dev).manual_seed(7)
-    w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
-    w = w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0)
-    ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
-    ws = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
-    vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
-    tiles = N * N // 8 // 1024
-    for rep in range(3):
-        lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), ws[-1:].data_ptr(), ws.data_ptr(), ws_bytes, stream)
-        torch.cuda.synchronize()
-    st = ws[tiles + 260: tiles + 260 + 4 * tiles].reshape(tiles, 4).cpu().double()
-    t0 = st[:, 0].min()
-    st = (st - t0) / 100.0
-    import numpy as np
-    a = st.numpy()
-    print("kernel span us", a[:, 3].max())
-    for t in list(range(0, 64, 9)) + list(range(64, tiles, 509)):
-        print(t, "start %.1f loaded %.1f resolved %.1f done %.1f" % tuple(a[t]))
-    print("median load %.1f wait %.1f scatter %.1f" % (np.median(a[:, 1] - a[:, 0]), np.median(a[:, 2] - a[:, 1]), np.median(a[:, 3] - a[:, 2])))
+    for _ in range(10):
+        lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes, stream)
+    torch.cuda.synchronize()
+    print(int(wk[-1].item()))
 elif what == "m24host":
     # host cost of Marlin24Compressor.compress: a tiny weight (kernel ~ few us), many calls
     import time, cProfile, pstats, io
