@@ -686,6 +686,45 @@ def test_bitmask_compress_forms_agree(env):
     assert r.returncode == 0 and "FORMS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_bitmask_compress_concurrent_streams(cta, dev):
+    """resident compress kernels in flight at once on two streams (raw ABI, no host synchronisation between launches) next to a GEMM that
+    occupies CUs: workgroups of one kernel wait for workgroups that are not resident yet.  Dependencies only point to earlier workgroups,
+    so every launch must finish with the right total — results bit-identical to count / scan / scatter"""
+    from compressed_tensors_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(23)
+    ws, ref, bufs = [], [], []
+    for n in (4096, 3072):
+        w = torch.randn(n, n, dtype=BF16, device=dev, generator=g)
+        w = w.masked_fill(torch.rand(n, n, device=dev, generator=g) < 0.5, 0)
+        ws.append(w)
+        ref.append(cta.codec.bitmask_compress(w, two_pass=True))
+        nb = int(lib.ct_bitmask_compress_workspace_bytes(n, n))
+        reps = []
+        for rep in range(5):
+            reps.append(dict(wk=torch.empty(nb // 8 + 1, dtype=torch.int64, device=dev), vals=torch.empty(n * n, dtype=BF16, device=dev),
+                             bm=torch.empty(n, n // 8, dtype=torch.uint8, device=dev), ro=torch.empty(n, dtype=torch.int64, device=dev), nb=nb))
+        bufs.append(reps)
+    a = torch.randn(4096, 4096, dtype=BF16, device=dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(5):
+        with torch.cuda.stream(streams[2]):
+            a @ a
+        for k in (0, 1):
+            b, w, n = bufs[k][rep], ws[k], ws[k].shape[0]
+            rc = lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, n, n, b["vals"].data_ptr(), b["vals"].numel(), b["bm"].data_ptr(), b["ro"].data_ptr(),
+                                         b["wk"][-1:].data_ptr(), b["wk"].data_ptr(), b["nb"], streams[k].cuda_stream)
+            assert rc == 0
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        v_ref, bm_ref, ro_ref = ref[k]
+        for b in bufs[k]:
+            nnz = int(b["wk"][-1].item())
+            assert nnz == v_ref.numel()
+            assert torch.equal(b["vals"][:nnz].view(torch.int16), v_ref.view(torch.int16)) and torch.equal(b["bm"], bm_ref) and torch.equal(b["ro"], ro_ref)
+
+
 def test_bitmask_resident_reports_failure(dev):
     """the raw ABI: with a zero wait budget the resident form must say -1 in *total (never a wrong count)"""
     import os
