@@ -45,8 +45,9 @@ __global__ __launch_bounds__(kBlock) void quant_units_kernel(QParams p) {
             SZ sz = load_sz_q<XDT>(p, srow, c0);
             // one reciprocal per unit instead of eight divides when x, T and the scale are all bf16, or all fp16 (+ a Newton step and
             // the exact fix-up of the sub-2^-13 quotients: fast_quotient)
-            const bool can_rcp = !p.gscale && ((XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16) || (XDT == CT_F16 && TDT == CT_F16 && p.sdt == CT_F16));
-            float rs = (can_rcp && uni) ? (TDT == CT_BF16 ? bf16_fast_rcp(sz.s) : f16_newton_rcp(sz.s)) : 0.0f;
+            const bool can_rcp = !p.gscale && ((XDT == CT_BF16 && TDT == CT_BF16 && p.sdt == CT_BF16) || (XDT == CT_F16 && TDT == CT_F16 && p.sdt == CT_F16) ||
+                                               TDT == CT_F32);
+            float rs = (can_rcp && uni) ? (TDT == CT_BF16 ? bf16_fast_rcp(sz.s) : (TDT == CT_F16 ? f16_newton_rcp(sz.s) : f32_fast_rcp(sz.s))) : 0.0f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 if (k < n) {
@@ -318,6 +319,79 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
         w4_quant_pack_group<DT, HAS_ZP, SHARED>(p, g);
 }
 
+
+// ---- fp32 weights (the reference's own unit tests feed them; fp32 checkpoints exist): a lane takes one unit = 8 floats = two 16-byte
+// loads and produces one packed word; two units per lane, a block apart, all four loads issued first.  The any-width kernels
+// (ct_quant_g32.inc) give a lane 32 elements = 128 bytes at a 128-byte lane stride, which is fine for 16-bit weights going through
+// the flat kernels above anyway but left fp32 at 140 us (compress) and 688 us (decompress: 32 scalar stores per lane) for
+// 304 MB at 8192^2.  The quotient: quant_core's reciprocal + half-integer test (fp32 has no proven shortcut; the test is exact).
+template <bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void w4_quant_pack_f32_kernel(W4Params p, int sdt) {
+    constexpr int U = 2;
+    const u32x4* in = static_cast<const u32x4*>(p.x);
+    uint32_t* out = static_cast<uint32_t*>(p.out);
+    const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
+    u32x4 a[U][2];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u < p.units) {
+            a[i][0] = in[2 * u];
+            a[i][1] = in[2 * u + 1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u >= p.units) continue;
+        const int64_t si = w4_scale_index(p, u);
+        const float s = load_rt(p.scale, sdt, si);
+        const float z = HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f;  // zp.to(float32): exact
+        const float rs = f32_fast_rcp(s);
+        const uint32_t ws[8] = {a[i][0].x, a[i][0].y, a[i][0].z, a[i][0].w, a[i][1].x, a[i][1].y, a[i][1].z, a[i][1].w};
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float t = quant_core<CT_F32>(bits_f(ws[k]), s, HAS_ZP, z, -8.0f, 7.0f, rs);
+            word |= (uint32_t)((cvt_i32_hw(t) + 8) & 15) << (4 * k);  // NaN -> code 0
+        }
+        __builtin_nontemporal_store(word, out + u);
+    }
+}
+
+// decompress to fp32 (scales and output fp32).  A lane takes HALF a word (4 codes -> one 16-byte store), so that a store instruction
+// covers 1 KB without gaps: with a whole word per lane the two stores of a lane interleaved at 32 bytes and every 32-byte sector
+// was written twice, half each time (110-135 us at 8192^2 instead of ~55).
+template <bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void w4_unpack_dequant_f32_kernel(W4Params p) {
+    constexpr int U = 4;
+    const uint32_t* in = static_cast<const uint32_t*>(p.x);
+    u32x4* out = static_cast<u32x4*>(p.out);
+    const int64_t halves = 2 * p.units;
+    const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
+    uint32_t w[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t h = base + (int64_t)i * kBlock;
+        w[i] = h < halves ? in[h >> 1] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t h = base + (int64_t)i * kBlock;
+        if (h >= halves) continue;
+        const int64_t si = w4_scale_index(p, h >> 1);
+        const float s = static_cast<const float*>(p.scale)[si];
+        const float z = HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f;
+        const uint32_t c4 = (w[i] >> (16 * (int)(h & 1))) & 0xffffu;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float q = (float)((int)((c4 >> (4 * k)) & 15u) - 8);
+            v[k] = dequant_core<CT_F32>(q, HAS_ZP, z, s);
+        }
+        stream_store16(out + h, u32x4{f_bits(v[0]), f_bits(v[1]), f_bits(v[2]), f_bits(v[3])});
+    }
+}
 
 // lean compress body for the common layout (flat scale index = lane >> gshift, one scale per lane, int8
 // zero point): no grid-stride loop, no generic index arithmetic, and the scale / zero point are loaded
@@ -1029,6 +1103,114 @@ __global__ __launch_bounds__(kBlock) void fq16_kernel(W4Params p, float qmin, fl
     }
 }
 
+// fake_quantize, INT codes, flat scale layout (scale index = unit >> ushift), int8 or no zero point: the lean form — exact grid, the
+// scale / zero-point loads ahead of the 16-byte loads, a finite-data test per unit (sum of squares, one dot2 per pair: the float
+// result has to carry a NaN through, which the packed path below does not), arithmetic on float PAIRS (v_pk_mul_f32 / v_pk_add_f32,
+// one v_cvt_pk per rounding).  6 (symmetric) / 8.5 VALU per element against ~18 in fq16_kernel: 54.3 -> see DESIGN 5.2.
+template <int DT>
+__device__ __forceinline__ float fq_sumsq(uint32_t d, float acc) {
+    if constexpr (DT == CT_BF16) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b2, d), __builtin_bit_cast(b2, d), acc, false);
+    } else {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(qh2_t, d), __builtin_bit_cast(qh2_t, d), acc, false);
+    }
+}
+
+template <int DT, bool HAS_ZP>
+__device__ __forceinline__ uint32_t fq16_pair(uint32_t d, float s, float rs, float z, float qmin, float qmax) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float x0, x1;
+    unpack2<DT>(d, x0, x1);
+    float t0, t1;
+    if constexpr (DT == CT_BF16) {
+        const f2 t = f2{x0, x1} * f2{rs, rs};
+        t0 = t.x; t1 = t.y;
+    } else {
+        t0 = fast_quotient<CT_F16>(x0, s, rs);
+        t1 = fast_quotient<CT_F16>(x1, s, rs);
+    }
+    round2<DT>(t0, t1);
+    if (HAS_ZP) {
+        const f2 t = f2{t0, t1} + f2{z, z};
+        t0 = t.x; t1 = t.y;
+        round2<DT>(t0, t1);
+    }
+    // finite by construction: v_med3_f32 is the clamp
+    t0 = __builtin_rintf(__builtin_amdgcn_fmed3f(t0, qmin, qmax));
+    t1 = __builtin_rintf(__builtin_amdgcn_fmed3f(t1, qmin, qmax));
+    f2 q = {t0, t1};
+    if (HAS_ZP) q = q - f2{z, z};  // |q - z| <= 255: exact in bf16 / fp16, the reference's rounding of the difference is the identity
+    q = q * f2{s, s};
+    if constexpr (DT == CT_BF16) {
+        typedef bf16_t b2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(q, b2));
+    } else {
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(q, qh2_t));
+    }
+}
+
+template <int DT, bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void fq16_lean_kernel(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale, const int8_t* __restrict__ zp,
+                                                           u32x4* __restrict__ out, int64_t units, int ushift, float qmin, float qmax) {
+    constexpr int U = 2;
+    const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
+    uint32_t sbits[U];
+    float z[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        const int64_t si = (u < units ? u : 0) >> ushift;
+        sbits[i] = __builtin_nontemporal_load(scale + si);
+        z[i] = HAS_ZP ? (float)__builtin_nontemporal_load(zp + si) : 0.0f;  // int8: exact in bf16 / fp16
+    }
+    asm volatile("" ::: "memory");  // keep the small loads ahead of the big ones
+    u32x4 raw[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u < units) raw[i] = in[u];
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u >= units) continue;
+        const float s = DT == CT_BF16 ? bf16_bits_to_f(sbits[i]) : f16_bits_to_f(sbits[i]);
+        const uint32_t ws[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fq_sumsq<DT>(ws[j], acc);
+        const bool fast = fast_scale_ok<DT>(s) && acc <= 3.0e38f;  // every element finite (a huge finite one also takes the exact path)
+        uint32_t o[4];
+        if (fast) {
+            const float rs = DT == CT_BF16 ? 1.0f / s : f16_newton_rcp(s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fq16_pair<DT, HAS_ZP>(ws[j], s, rs, z[i], qmin, qmax);
+        } else {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0, x1;
+                unpack2<DT>(ws[j], x0, x1);
+                const float t0 = quant_core<DT>(x0, s, HAS_ZP, z[i], qmin, qmax), t1 = quant_core<DT>(x1, s, HAS_ZP, z[i], qmin, qmax);
+                v[2 * j] = dequant_core<DT>(t0, HAS_ZP, z[i], s);
+                v[2 * j + 1] = dequant_core<DT>(t1, HAS_ZP, z[i], s);
+            }
+            typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (DT == CT_BF16) {
+                    typedef bf16_t b2 __attribute__((ext_vector_type(2)));
+                    o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v[2 * j], v[2 * j + 1]}, b2));
+                } else {
+                    o[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{v[2 * j], v[2 * j + 1]}, qh2_t));
+                }
+            }
+        }
+        stream_store16(out + u, u32x4{o[0], o[1], o[2], o[3]});
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // diagnostics: exhaustive check of the reciprocal fast path
 // ------------------------------------------------------------------------------------------
@@ -1170,6 +1352,15 @@ static int fake_quantize_impl(const void* x, int xdt, const void* scale, int sdt
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(x) && aligned16(out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         constexpr int U = 2;
+        if (p.fkind == 0 && w.flat_scale && w.upg_shift >= 0 && (!zp || zdt == CT_I8) && w.units < ((int64_t)1 << 38)) {
+            dim3 gl((unsigned)cdiv64(w.units, (int64_t)kBlock * 2));
+#define CT_FQL(DT, ZP) hipLaunchKernelGGL((fq16_lean_kernel<DT, ZP>), gl, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), \
+                                           static_cast<const uint16_t*>(scale), static_cast<const int8_t*>(zp), static_cast<u32x4*>(out), w.units, w.upg_shift, p.qmin, p.qmax)
+            if (xdt == CT_BF16) { if (zp) CT_FQL(CT_BF16, true); else CT_FQL(CT_BF16, false); }
+            else { if (zp) CT_FQL(CT_F16, true); else CT_FQL(CT_F16, false); }
+#undef CT_FQL
+            CT_LAUNCH_CHECK("ct_fake_quantize[fq16 lean]");
+        }
         dim3 gf(w4_grid(w.units, U));
 #define CT_FQ(DT, ZP) hipLaunchKernelGGL((fq16_kernel<DT, U, ZP>), gf, dim3(kBlock), 0, as_stream(stream), w, p.qmin, p.qmax, p.fkind)
         if (xdt == CT_BF16) { if (zp) CT_FQ(CT_BF16, true); else CT_FQ(CT_BF16, false); }
@@ -1302,6 +1493,14 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
 #undef CT_W4Q
         CT_LAUNCH_CHECK("ct_quant_pack[w4]");
     }
+    if (bits == 4 && xdt == CT_F32 && tdt == CT_F32 && !col_group && is_float_dt(sdt) && cols % 8 == 0 && cdiv % 8 == 0 && aligned16(x) &&
+        (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && rows * (cols / 8) < ((int64_t)1 << 38)) {
+        W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
+        dim3 gf(w4_grid(w.units, 2));
+        if (zp) hipLaunchKernelGGL((w4_quant_pack_f32_kernel<true>), gf, dim3(kBlock), 0, as_stream(stream), w, sdt);
+        else hipLaunchKernelGGL((w4_quant_pack_f32_kernel<false>), gf, dim3(kBlock), 0, as_stream(stream), w, sdt);
+        CT_LAUNCH_CHECK("ct_quant_pack[w4 f32]");
+    }
     if (bits == 8 && cols % 32 == 0 && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, packed)) {
         // 8-bit words are four (code + 128) bytes: the int8 stream kernel with OFF = 128
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
@@ -1408,6 +1607,14 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D
         CT_LAUNCH_CHECK("ct_unpack_dequant[w4]");
+    }
+    if (bits == 4 && words == cols / 8 && sdt == CT_F32 && odt == CT_F32 && !col_group && cols % 8 == 0 && cdiv % 8 == 0 && aligned16(out) &&
+        (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && rows * (cols / 8) < ((int64_t)1 << 38)) {
+        W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        dim3 gf(w4_grid(2 * w.units, 4));
+        if (zp) hipLaunchKernelGGL((w4_unpack_dequant_f32_kernel<true>), gf, dim3(kBlock), 0, as_stream(stream), w);
+        else hipLaunchKernelGGL((w4_unpack_dequant_f32_kernel<false>), gf, dim3(kBlock), 0, as_stream(stream), w);
+        CT_LAUNCH_CHECK("ct_unpack_dequant[w4 f32]");
     }
     if (bits == 8 && words == cols / 4 && cols % 32 == 0 && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(packed) & 7u) == 0) {

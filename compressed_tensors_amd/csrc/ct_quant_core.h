@@ -31,6 +31,14 @@ __device__ __forceinline__ float bf16_fast_rcp(float s) {
     return ((as >= 0x1p-64f) && (as <= 0x1p64f)) ? 1.0f / s : 0.0f;
 }
 
+// reciprocal of a scale for fp32 arithmetic, or 0 when the caller has to divide.  x * fl(1/s) is NOT the IEEE quotient in fp32, but
+// an integer code only depends on which side of a half-integer the (shifted, clamped) quotient falls: quant_core tests that with
+// an error bound and divides only for the elements that are too close to call (about 1e-5 of them for int4).
+__device__ __forceinline__ float f32_fast_rcp(float s) {
+    const float as = __builtin_fabsf(s);
+    return ((as >= 0x1p-100f) && (as <= 0x1p100f)) ? 1.0f / s : 0.0f;
+}
+
 // reciprocal of an fp16 scale, or 0 outside the range in which reciprocal + one Newton step is proven to give the fp16 rounding of
 // the IEEE quotient (ct_selftest_f16_div: every fp16 x, quotients below 2^-13 excepted — they all end as code / value 0)
 __device__ __forceinline__ float f16_newton_rcp(float s) {
@@ -52,6 +60,8 @@ __device__ __forceinline__ float fast_quotient(float x, float s, float rs) {
         // leaves).  Those few elements take the divide: a divergent branch that most waves skip (x == 0 is exact either way).
         if (__builtin_fabsf(r) < 0x1p-13f && x != 0.0f) r = x / s;
         return r;
+    } else if constexpr (TDT == CT_F32) {
+        return x / s;  // rs only feeds quant_core's half-integer test
     } else {
         return x * rs;
     }
@@ -60,6 +70,20 @@ __device__ __forceinline__ float fast_quotient(float x, float s, float rs) {
 template <int TDT>
 __device__ __forceinline__ float quant_core(float x, float s, bool has_zp, float zf, float qmin,
                                             float qmax, float rs = 0.0f, int fkind = 0) {
+    if constexpr (TDT == CT_F32) {
+        // fp32, INT codes: q0 = x * fl(1/s) is within 2^-22 |q0| of fl(x / s), and the zero-point add rounds once more, so the
+        // value that gets clamped and rounded is within E = 2^-21 (|q0| + |z| + 1) of the reference's.  Clamping is 1-Lipschitz:
+        // if the clamped value is farther than E from every half-integer, both round to the same integer (NaN compares false and
+        // comes back as NaN, as the divide would give; an overflowing q0 makes E infinite and takes the divide).
+        if (rs != 0.0f && fkind == 0) {
+            const float q0 = x * rs;
+            const float a = has_zp ? q0 + zf : q0;
+            const float c = clamp_nan(a, qmin, qmax);
+            const float r = __builtin_rintf(c);
+            const float tol = (__builtin_fabsf(q0) + __builtin_fabsf(zf) + 1.0f) * 0x1p-21f;
+            if (!(__builtin_fabsf(__builtin_fabsf(c - r) - 0.5f) < tol)) return r;
+        }
+    }
     float t = round_to<TDT>(fast_quotient<TDT>(x, s, rs));  // IEEE-correct fp32 divide (or the proven bf16 / fp16 shortcut), RNE to T
     if (has_zp) t = round_to<TDT>(t + zf);
     t = clamp_nan(t, qmin, qmax);

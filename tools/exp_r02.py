@@ -101,6 +101,61 @@ elif what == "bmres1":
         lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes, stream)
     torch.cuda.synchronize()
     print(int(wk[-1].item()))
+elif what == "f32":
+    # fp32 weights and scales: W4 g128 compress / decompress, int8 channel-wise quantize / dequantize (ct_quant_pack, ct_unpack_dequant, ct_quantize, ct_dequantize)
+    from compressed_tensors_amd import _lib, codec
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    N = 8192; nsets = 4
+    g = torch.Generator(device=dev).manual_seed(5)
+    res = {}
+    for sym in (True, False):
+        sets = []
+        for _ in range(nsets):
+            w = torch.randn(N, N, dtype=torch.float32, device=dev, generator=g)
+            sc, zp = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=sym)
+            sets.append((w, sc, zp, torch.empty(N, N // 8, dtype=torch.int32, device=dev), torch.empty(N, N, dtype=torch.float32, device=dev)))
+        F = _lib.DT[torch.float32]
+        ca = [(w.data_ptr(), F, sc.data_ptr(), F, zp.data_ptr(), _lib.I8, N, N, 1, 128, N // 128, None, 4, F, pk.data_ptr(), stream) for (w, sc, zp, pk, out) in sets]
+        da = [(pk.data_ptr(), N, N // 8, N, 4, sc.data_ptr(), F, None if sym else zp.data_ptr(), -1 if sym else _lib.I8, 1, 128, N // 128, None, out.data_ptr(), F, stream) for (w, sc, zp, pk, out) in sets]
+        def c(i): _lib.check(lib.ct_quant_pack(*ca[i % nsets]))
+        def d(i): _lib.check(lib.ct_unpack_dequant(*da[i % nsets]))
+        for i in range(nsets): c(i)
+        us_c, us_d = B.time_kernel(c, 16), B.time_kernel(d, 16)
+        w, sc, zp, pk, out = sets[0]
+        ok = torch.equal(out, codec.fake_quantize_tensor(w, sc, zp, num_bits=4, strategy="group", group_size=128))
+        alg = N * N * 4 + N * N // 2 + N * (N // 128) * 4
+        res["w4_sym" if sym else "w4_asym"] = {"compress_us": round(us_c, 1), "decompress_us": round(us_d, 1), "alg_MB": round(alg / 1e6, 1), "compress_frac": round(alg / us_c / 8e6, 3),
+                                               "decompress_frac": round(alg / us_d / 8e6, 3), "round_trip_equals_fake_quantize": bool(ok)}
+        del sets, ca, da
+        torch.cuda.empty_cache()
+    print(json.dumps(res))
+elif what == "f32q":
+    # int8 channel-wise quantize / dequantize / fake-quantize kernels through the C ABI (symmetric and asymmetric), fp32 and bf16 weights
+    from compressed_tensors_amd import _lib
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    N = 8192
+    g = torch.Generator(device=dev).manual_seed(5)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        D = _lib.DT[dt]
+        ws = [torch.randn(N, N, dtype=torch.float32, device=dev, generator=g).to(dt) for _ in range(4)]
+        sc = (ws[0].float().abs().amax(dim=1, keepdim=True) / 127.0).to(dt).contiguous()
+        zp = torch.randint(-3, 4, (N, 1), dtype=torch.int8, device=dev)
+        qs = [torch.empty(N, N, dtype=torch.int8, device=dev) for _ in range(4)]
+        outs = [torch.empty(N, N, dtype=dt, device=dev) for _ in range(2)]
+        es = ws[0].element_size()
+        for name, z in (("sym", None), ("asym", zp)):
+            zptr = None if z is None else z.data_ptr()
+            zdt = -1 if z is None else _lib.I8
+            fq = lambda i: _lib.check(lib.ct_quantize(ws[i % 4].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, N, N, 1, N, 1, None, 8, D, qs[i % 4].data_ptr(), _lib.I8, stream))
+            fd = lambda i: _lib.check(lib.ct_dequantize(qs[i % 4].data_ptr(), _lib.I8, sc.data_ptr(), D, zptr, zdt, N, N, 1, N, 1, None, outs[i % 2].data_ptr(), D, stream))
+            ff = lambda i: _lib.check(lib.ct_fake_quantize(ws[i % 4].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, N, N, 1, N, 1, None, 8, D, outs[i % 2].data_ptr(), D, stream))
+            for i in range(4): fq(i)
+            res[f"{str(dt).split('.')[-1]}_{name}"] = {"quantize_us": round(B.time_kernel(fq, 16), 1), "dequantize_us": round(B.time_kernel(fd, 16), 1), "fake_quantize_us": round(B.time_kernel(ff, 16), 1),
+                                                      "qd_alg_MB": round(N * N * (es + 1) / 1e6, 1), "fq_alg_MB": round(N * N * 2 * es / 1e6, 1)}
+        del ws, qs, outs
+        torch.cuda.empty_cache()
+    print(json.dumps(res))
 elif what == "m24host":
     # host cost of Marlin24Compressor.compress: a tiny weight (kernel ~ few us), many calls
     import time, cProfile, pstats, io
