@@ -393,6 +393,57 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_f32_kernel(W4Params 
     }
 }
 
+// fp32 quantize (-> int8 codes) / dequantize (int8 -> fp32) / fake_quantize, INT kinds: a lane takes FOUR consecutive elements — 16 bytes
+// of floats and 4 bytes of codes — so that every load and store instruction of a wave is contiguous (the unit kernels give a lane 8
+// floats = two 16-byte accesses interleaved with its neighbour's: 88 / 68 / 123 us at 8192^2 for 335 / 335 / 537 MB).  Four such
+// quads per lane, a block apart, all loads first.
+enum { F32_Q = 0, F32_DQ = 1, F32_FQ = 2 };
+template <int MODE, bool HAS_ZP>
+__global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, float qmin, float qmax) {
+    constexpr int U = 4;
+    const int64_t quads = 2 * p.units;
+    const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
+    u32x4 a[U];
+    uint32_t c[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t h = base + (int64_t)i * kBlock;
+        if (h < quads) {
+            if constexpr (MODE == F32_DQ) c[i] = static_cast<const uint32_t*>(p.x)[h];
+            else a[i] = static_cast<const u32x4*>(p.x)[h];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t h = base + (int64_t)i * kBlock;
+        if (h >= quads) continue;
+        const int64_t si = w4_scale_index(p, h >> 1);
+        const float s = load_rt(p.scale, sdt, si);
+        const float z = HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f;  // zp.to(float32): exact
+        float v[4];
+        if constexpr (MODE == F32_DQ) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>((float)(int)(int8_t)(c[i] >> (8 * k)), HAS_ZP, z, s);
+            stream_store16(static_cast<u32x4*>(p.out) + h, u32x4{f_bits(v[0]), f_bits(v[1]), f_bits(v[2]), f_bits(v[3])});
+        } else {
+            const float rs = f32_fast_rcp(s);
+            const uint32_t ws[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = quant_core<CT_F32>(bits_f(ws[k]), s, HAS_ZP, z, qmin, qmax, rs);
+            if constexpr (MODE == F32_Q) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) word |= (uint32_t)(cvt_i32_hw(v[k]) & 255) << (8 * k);  // NaN -> 0
+                __builtin_nontemporal_store(word, static_cast<uint32_t*>(p.out) + h);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>(v[k], HAS_ZP, z, s);
+                stream_store16(static_cast<u32x4*>(p.out) + h, u32x4{f_bits(v[0]), f_bits(v[1]), f_bits(v[2]), f_bits(v[3])});
+            }
+        }
+    }
+}
+
 // lean compress body for the common layout (flat scale index = lane >> gshift, one scale per lane, int8
 // zero point): no grid-stride loop, no generic index arithmetic, and the scale / zero point are loaded
 // BEFORE the 64 bytes of weights so that the reciprocal is ready when they land.  30.3 -> 29.4 us at 8192^2.
@@ -1287,6 +1338,20 @@ static unsigned w4_grid(int64_t items, int unroll) {
     return (unsigned)g;
 }
 
+// fp32 flat kernels (f32_quads_kernel): groups of a multiple of 8 columns (or the whole row), no g_idx, 16-byte aligned float side,
+// 4-byte aligned code side
+static bool f32_quads_ok(int64_t rows, int64_t cols, int64_t cdiv, const int32_t* col_group, const void* floats, const void* codes) {
+    return !col_group && rows > 0 && cols > 0 && cols % 8 == 0 && (cdiv % 8 == 0 || cdiv >= cols) && aligned16(floats) &&
+           (codes == nullptr || (reinterpret_cast<uintptr_t>(codes) & 3u) == 0) && rows * (cols / 8) < ((int64_t)1 << 38);
+}
+template <int MODE>
+static int launch_f32_quads(const W4Params& w, const void* zp, int sdt, float qmin, float qmax, ct_stream_t stream, const char* what) {
+    dim3 g(w4_grid(2 * w.units, 4));
+    if (zp) hipLaunchKernelGGL((f32_quads_kernel<MODE, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax);
+    else hipLaunchKernelGGL((f32_quads_kernel<MODE, false>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax);
+    return hip_check(hipGetLastError(), what);
+}
+
 }  // namespace ct
 
 using namespace ct;
@@ -1314,6 +1379,10 @@ static int quantize_impl(const void* x, int xdt, const void* scale, int sdt, con
     if (rc) return rc;
     set_float_kind(p, fkind, gscale);
     if (rows == 0 || cols == 0) return CT_OK;
+    if (!gscale && fkind == 0 && xdt == CT_F32 && tdt == CT_F32 && odt == CT_I8 && is_float_dt(sdt) && f32_quads_ok(rows, cols, cdiv, col_group, x, out)) {
+        W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        return launch_f32_quads<F32_Q>(w, zp, sdt, p.qmin, p.qmax, stream, "ct_quantize[f32]");
+    }
     if (!gscale && fkind != 2 && (fkind ? odt == CT_F8E4M3 : odt == CT_I8) && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         const bool shared = (cdiv % 16 == 0) || cdiv >= cols;
@@ -1348,6 +1417,10 @@ static int fake_quantize_impl(const void* x, int xdt, const void* scale, int sdt
     if (rc) return rc;
     set_float_kind(p, fkind, gscale);
     if (rows == 0 || cols == 0) return CT_OK;
+    if (!gscale && p.fkind == 0 && xdt == CT_F32 && tdt == CT_F32 && odt == CT_F32 && sdt == CT_F32 && f32_quads_ok(rows, cols, cdiv, col_group, x, nullptr) && aligned16(out)) {
+        W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        return launch_f32_quads<F32_FQ>(w, zp, sdt, p.qmin, p.qmax, stream, "ct_fake_quantize[f32]");
+    }
     if (!gscale && odt == xdt && !col_group && (xdt == CT_BF16 || xdt == CT_F16) && sdt == xdt && tdt == xdt && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(x) && aligned16(out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
@@ -1438,6 +1511,10 @@ static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, 
     if (rows == 0 || cols == 0) return CT_OK;
     p.vec = (cols % 8 == 0) && aligned16(out) && ((reinterpret_cast<uintptr_t>(xq) & 7u) == 0);
     set_float_kind(p, 0, gscale);
+    if (!gscale && qdt == CT_I8 && sdt == CT_F32 && odt == CT_F32 && f32_quads_ok(rows, cols, cdiv, col_group, out, xq)) {
+        W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        return launch_f32_quads<F32_DQ>(w, zp, sdt, 0.0f, 0.0f, stream, "ct_dequantize[f32]");
+    }
     if (!gscale && (qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);

@@ -36,7 +36,7 @@ __device__ __forceinline__ float bf16_fast_rcp(float s) {
 // an error bound and divides only for the elements that are too close to call (about 1e-5 of them for int4).
 __device__ __forceinline__ float f32_fast_rcp(float s) {
     const float as = __builtin_fabsf(s);
-    return ((as >= 0x1p-100f) && (as <= 0x1p100f)) ? 1.0f / s : 0.0f;
+    return ((as >= 0x1p-100f) && (as <= 0x1p100f)) ? __builtin_amdgcn_rcpf(s) : 0.0f;  // v_rcp_f32: 1 ulp
 }
 
 // reciprocal of an fp16 scale, or 0 outside the range in which reciprocal + one Newton step is proven to give the fp16 rounding of
@@ -71,17 +71,18 @@ template <int TDT>
 __device__ __forceinline__ float quant_core(float x, float s, bool has_zp, float zf, float qmin,
                                             float qmax, float rs = 0.0f, int fkind = 0) {
     if constexpr (TDT == CT_F32) {
-        // fp32, INT codes: q0 = x * fl(1/s) is within 2^-22 |q0| of fl(x / s), and the zero-point add rounds once more, so the
-        // value that gets clamped and rounded is within E = 2^-21 (|q0| + |z| + 1) of the reference's.  Clamping is 1-Lipschitz:
-        // if the clamped value is farther than E from every half-integer, both round to the same integer (NaN compares false and
-        // comes back as NaN, as the divide would give; an overflowing q0 makes E infinite and takes the divide).
+        // fp32, INT codes: with rs = 1/s to 1 ulp (v_rcp_f32), q0 = x * rs is within 2^-22 |q0| of fl(x / s), and the zero-point add
+        // rounds once more, so the value that gets clamped and rounded is within E = 2^-21 (|q0| + |z| + 1) of the reference's.
+        // Clamping is 1-Lipschitz: if the clamped value is at least E away from every half-integer, both round to the same integer.
+        // The test is written so that a NaN anywhere (x, or an E that overflowed) fails it and takes the divide below; the clamp can
+        // then be a plain v_med3_f32.
         if (rs != 0.0f && fkind == 0) {
             const float q0 = x * rs;
             const float a = has_zp ? q0 + zf : q0;
-            const float c = clamp_nan(a, qmin, qmax);
+            const float c = __builtin_amdgcn_fmed3f(a, qmin, qmax);
             const float r = __builtin_rintf(c);
-            const float tol = (__builtin_fabsf(q0) + __builtin_fabsf(zf) + 1.0f) * 0x1p-21f;
-            if (!(__builtin_fabsf(__builtin_fabsf(c - r) - 0.5f) < tol)) return r;
+            const float tol = __builtin_fmaf(__builtin_fabsf(q0), 0x1p-21f, (__builtin_fabsf(zf) + 1.0f) * 0x1p-21f);
+            if (__builtin_fabsf(__builtin_fabsf(c - r) - 0.5f) >= tol) return r;  // (a NaN or infinite x makes tol NaN / inf: false)
         }
     }
     float t = round_to<TDT>(fast_quotient<TDT>(x, s, rs));  // IEEE-correct fp32 divide (or the proven bf16 / fp16 shortcut), RNE to T

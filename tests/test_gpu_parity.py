@@ -158,6 +158,12 @@ QCASES = [
     (F16, F16, 8, "tensor", None, (64, 512), True),
     (F32, F32, 4, "group", 64, (64, 512), False),
     (F32, F32, 3, "channel", None, (33, 70), False),
+    (F32, F32, 4, "group", 128, (96, 1024), True),      # the flat fp32 kernels (W4 words, quads)
+    (F32, F32, 4, "group", 128, (96, 1024), False),
+    (F32, BF16, 4, "group", 32, (64, 512), False),
+    (F32, F32, 8, "channel", None, (64, 2048), False),
+    (F32, F32, 8, "tensor", None, (64, 520), True),
+    (F32, F32, 6, "block", None, (64, 256), True),
     (BF16, BF16, 5, "group", 32, (36, 96), False),
     (BF16, BF16, 2, "group", 16, (17, 48), True),
     (BF16, BF16, 1, "channel", None, (8, 100), True),
@@ -230,6 +236,40 @@ def test_bf16_reciprocal_fast_path_is_exact(cta, dev):
 def test_f16_newton_quotient_is_exact(cta, dev):
     """exhaustive: every fp16 x against every fp16 scale of the fast-path range (marlin-24 front end)"""
     assert cta.codec.selftest_f16_div(0, 65536) == 0
+
+
+def test_fp32_quotient_ties(cta, dev):
+    """the fp32 quantize paths multiply by a reciprocal and divide only when the clamped value is too close to a half-integer to call:
+    feed them exact ties (x = (k + 0.5) s for scales with a short significand), the neighbours one and two ulps either side, huge,
+    tiny, infinite, NaN and signed-zero inputs, scales from 2^-100 to 2^100 and outside; every code, fake-quantized value and
+    packed word must equal the oracle's (IEEE divide)"""
+    g = torch.Generator().manual_seed(77)
+    rows, cols = 64, 1024
+    ks = torch.arange(-140, 141, dtype=F32)
+    scales = torch.tensor([0.125, 0.0390625, 3.0, 1.0 / 3.0, 0.1, 7.3e-5, 2.0 ** -90, 2.0 ** 90, 2.0 ** -110, 2.0 ** 110, 1e-3, 0.75, 5.0, 1.7, 2.0 ** -20, 9.5e4], dtype=F32)
+    for bits, sym in ((4, True), (4, False), (8, True), (8, False), (6, False)):
+        s = scales[torch.arange(rows) % scales.numel()].reshape(rows, 1).clone()
+        x = torch.empty(rows, cols, dtype=F32)
+        base = ((ks[torch.randint(0, ks.numel(), (rows, cols), generator=g)] + 0.5) * s)
+        x.copy_(base)
+        bits_view = x.view(torch.int32)
+        bump = torch.randint(-2, 3, (rows, cols), generator=g, dtype=torch.int32)
+        bits_view += bump  # exact ties and their 1-2 ulp neighbours
+        x[:, -16:] = torch.randn(rows, 16, generator=g) * s * 3
+        sp = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 3e38, -3e38, 1e-45, -1e-45, 1.17549435e-38], dtype=F32)
+        x[:, : sp.numel()] = sp
+        zp = torch.zeros(rows, 1, dtype=torch.int8) if sym else torch.randint(-(2 ** (bits - 1)), 2 ** (bits - 1), (rows, 1), generator=g, dtype=torch.int8)
+        kw = dict(num_bits=bits, strategy="channel", group_size=None)
+        q_ref = O.quantize(x, s, zp, dtype=torch.int8, **kw)
+        q = cta.codec.quantize_tensor(x.to(dev), s.to(dev), zp.to(dev), dtype=torch.int8, **kw)
+        assert eq(q.cpu(), q_ref), (bits, sym)
+        assert eq(cta.codec.fake_quantize_tensor(x.to(dev), s.to(dev), zp.to(dev), **kw).cpu(), O.fake_quantize(x, s, zp, **kw)), (bits, sym)
+        assert eq(cta.codec.quantize_and_pack(x.to(dev), s.to(dev), zp.to(dev), **kw).cpu(), O.pack_to_int32(q_ref, bits).contiguous()), (bits, sym)
+        # group-wise with the same data: the W4 word kernel and the quads kernel index scales per group
+        sg = s.expand(rows, cols // 128).contiguous()
+        zg = zp.expand(rows, cols // 128).contiguous()
+        kwg = dict(num_bits=bits, strategy="group", group_size=128)
+        assert eq(cta.codec.quantize_and_pack(x.to(dev), sg.to(dev), zg.to(dev), **kwg).cpu(), O.pack_to_int32(O.quantize(x, sg, zg, dtype=torch.int8, **kwg), bits).contiguous()), (bits, sym)
 
 
 def test_all_bf16_inputs_w4(cta, dev):
