@@ -417,6 +417,67 @@ def int8_leg(dev):
             "dequantize_matches_torch": bool(ok)}
 
 
+def quantize_leg(dev):
+    """SURVEY 8(a) R5 / R6 / R7 as kernels: quantize -> int8 codes, dequantize, fake_quantize (int8 channel-wise, symmetric and with
+    zero points) at 8192x8192 through the C ABI, bf16 and fp32 weights, HBM-cold rotation; the results of one set are compared with
+    the oracle on a 256-row slice."""
+    from compressed_tensors_amd import _lib
+
+    O = _oracle()
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    n = N
+    out = {"workload": f"int8 channel-wise quantize / dequantize / fake_quantize kernels, {n}x{n}, through the C ABI"}
+    g = torch.Generator(device=dev).manual_seed(17)
+    for dt in (torch.bfloat16, torch.float32):
+        D = _lib.DT[dt]
+        es = torch.empty(0, dtype=dt).element_size()
+        nsets = 6 if es == 2 else 4
+        ws = [torch.randn(n, n, dtype=torch.float32, device=dev, generator=g).to(dt) for _ in range(nsets)]
+        sc = (ws[0].float().abs().amax(dim=1, keepdim=True) / 127.0).to(dt).contiguous()
+        zp = torch.randint(-3, 4, (n, 1), dtype=torch.int8, device=dev, generator=g)
+        qs = [torch.empty(n, n, dtype=torch.int8, device=dev) for _ in range(nsets)]
+        outs = [torch.empty(n, n, dtype=dt, device=dev) for _ in range(2)]
+        for name, z in (("symmetric", None), ("asymmetric", zp)):
+            zptr, zdt = (None, -1) if z is None else (z.data_ptr(), _lib.I8)
+
+            def fq(i):
+                _lib.check(lib.ct_quantize(ws[i % nsets].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, 8, D, qs[i % nsets].data_ptr(), _lib.I8, stream))
+
+            def fd(i):
+                _lib.check(lib.ct_dequantize(qs[i % nsets].data_ptr(), _lib.I8, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, outs[i % 2].data_ptr(), D, stream))
+
+            def ff(i):
+                _lib.check(lib.ct_fake_quantize(ws[i % nsets].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, 8, D, outs[i % 2].data_ptr(), D, stream))
+
+            for i in range(nsets):
+                fq(i)
+            us_q, us_d, us_f = time_kernel(fq, 24), time_kernel(fd, 24), time_kernel(ff, 24)
+            # oracle gate on a slice of set 0
+            rows = slice(0, 256)
+            zc = torch.zeros(256, 1, dtype=torch.int8) if z is None else z[rows].cpu()
+            kw = dict(num_bits=8, strategy="channel", group_size=None)
+            fq(0); ff(0)
+            torch.cuda.synchronize()
+            q_ref = O.quantize(ws[0][rows].cpu(), sc[rows].cpu(), zc, dtype=torch.int8, **kw)
+            ok = torch.equal(qs[0][rows].cpu(), q_ref)
+            f_ref = O.fake_quantize(ws[0][rows].cpu(), sc[rows].cpu(), zc, **kw)
+            ok = ok and torch.equal(outs[0][rows].cpu().view(torch.int16 if es == 2 else torch.int32), f_ref.view(torch.int16 if es == 2 else torch.int32))
+            fd(0)
+            torch.cuda.synchronize()
+            d_ref = O.dequantize(q_ref, sc[rows].cpu(), zc, strategy="channel")
+            ok = ok and torch.equal(outs[0][rows].cpu().view(torch.int16 if es == 2 else torch.int32), d_ref.view(torch.int16 if es == 2 else torch.int32))
+            qd, fqb = n * n * (es + 1), n * n * 2 * es
+            out[f"{str(dt).split('.')[-1]}_{name}"] = {
+                "quantize_us": round(us_q, 2), "quantize_frac_hbm": round(qd / us_q / 1e3 / HBM_PEAK_GBPS, 4),
+                "dequantize_us": round(us_d, 2), "dequantize_frac_hbm": round(qd / us_d / 1e3 / HBM_PEAK_GBPS, 4),
+                "fake_quantize_us": round(us_f, 2), "fake_quantize_frac_hbm": round(fqb / us_f / 1e3 / HBM_PEAK_GBPS, 4),
+                "alg_bytes_quantize_or_dequantize": qd, "alg_bytes_fake_quantize": fqb, "bit_exact_vs_oracle_256_rows": bool(ok)}
+        del ws, qs, outs
+        torch.cuda.empty_cache()
+    return out
+
+
 def marlin24_leg(dev):
     """BASELINE config 4: 2:4 semi-structured + int4 group-128 in the Marlin-24 layout, 8192x8192 bf16,
     through the Marlin24Compressor plug-in class (quantize -> 2:4 compress + metadata -> tile-permuted
@@ -994,7 +1055,7 @@ def main():
         if world == 1 and not a.no_extra:
             del sets
             torch.cuda.empty_cache()
-            for key, leg in (("kernels_other", w4_variants_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
+            for key, leg in (("kernels_other", w4_variants_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("quantize_dequantize_fake_quantize", quantize_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
                              ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg), ("tinyllama_w8a8", tinyllama_w8_leg)):
                 try:
                     result[key] = leg(dev)
