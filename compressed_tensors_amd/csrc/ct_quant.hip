@@ -320,6 +320,72 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
 }
 
 
+// ---- activation ordering (weight_g_idx): column c of a row uses scale group col_group[c], any of the row's groups.  The any-layout
+// kernels look the group up per element in global memory and give a lane 128 strided bytes (198 / 238 us at 8192^2 for the 29 / 25 us
+// job).  Here a workgroup stays inside one row: the row's scales, reciprocals and zero points go to LDS once (<= 1024 groups), a
+// lane takes whole units (16-byte weight access, two 16-byte loads of the 8 group numbers — the same 32 KB for every row, so they
+// come from the L2) and gathers its 8 (scale, reciprocal, zero point) triples from LDS.
+constexpr int kGidxMaxGroups = 1024;
+template <int DT, bool HAS_ZP, bool COMPRESS>
+__global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32_t* __restrict__ col_group, int chunks_per_row) {
+    constexpr int U = 2;
+    __shared__ float s_s[kGidxMaxGroups], s_rs[kGidxMaxGroups], s_z[HAS_ZP ? kGidxMaxGroups : 1];
+    const int64_t row = blockIdx.x / (unsigned)chunks_per_row;
+    const int chunk = (int)(blockIdx.x - (unsigned)row * (unsigned)chunks_per_row);
+    for (int g = threadIdx.x; g < (int)p.scale_cols; g += kBlock) {
+        const int64_t si = row * p.scale_cols + g;
+        const float s = load_as_f<DT>(p.scale, si);
+        s_s[g] = s;
+        if (COMPRESS) s_rs[g] = DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s);
+        if (HAS_ZP) s_z[g] = round_to<DT>(load_rt(p.zp, p.zdt, si));
+    }
+    __syncthreads();
+    const int64_t cu0 = (int64_t)chunk * (U * kBlock) + threadIdx.x;
+    u32x4 wv[U], g0[U], g1[U];
+    uint32_t pw[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t cu = cu0 + (int64_t)i * kBlock;
+        if (cu < p.upr) {
+            const int64_t u = row * p.upr + cu;
+            if (COMPRESS) wv[i] = static_cast<const u32x4*>(p.x)[u];
+            else pw[i] = static_cast<const uint32_t*>(p.x)[u];
+            g0[i] = reinterpret_cast<const u32x4*>(col_group)[2 * cu];
+            g1[i] = reinterpret_cast<const u32x4*>(col_group)[2 * cu + 1];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t cu = cu0 + (int64_t)i * kBlock;
+        if (cu >= p.upr) continue;
+        const int64_t u = row * p.upr + cu;
+        const uint32_t gs[8] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w, g1[i].x, g1[i].y, g1[i].z, g1[i].w};
+        if constexpr (COMPRESS) {
+            const uint32_t ws[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0, x1;
+                unpack2<DT>(ws[j], x0, x1);
+                const uint32_t ga = gs[2 * j], gb = gs[2 * j + 1];
+                const float t0 = quant_core<DT>(x0, s_s[ga], HAS_ZP, HAS_ZP ? s_z[ga] : 0.0f, -8.0f, 7.0f, s_rs[ga]);
+                const float t1 = quant_core<DT>(x1, s_s[gb], HAS_ZP, HAS_ZP ? s_z[gb] : 0.0f, -8.0f, 7.0f, s_rs[gb]);
+                word |= (uint32_t)((cvt_i32_hw(t0) + 8) & 15) << (8 * j);  // NaN -> code 0
+                word |= (uint32_t)((cvt_i32_hw(t1) + 8) & 15) << (8 * j + 4);
+            }
+            __builtin_nontemporal_store(word, static_cast<uint32_t*>(p.out) + u);
+        } else {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float q = (float)((int)((pw[i] >> (4 * k)) & 15u) - 8);
+                v[k] = dequant_core<DT>(q, HAS_ZP, HAS_ZP ? s_z[gs[k]] : 0.0f, s_s[gs[k]]);
+            }
+            store8<DT>(p.out, u * 8, v);
+        }
+    }
+}
+
 // ---- fp32 weights (the reference's own unit tests feed them; fp32 checkpoints exist): a lane takes one unit = 8 floats = two 16-byte
 // loads and produces one packed word; two units per lane, a block apart, all four loads issued first.  The any-width kernels
 // (ct_quant_g32.inc) give a lane 32 elements = 128 bytes at a 128-byte lane stride, which is fine for 16-bit weights going through
@@ -1374,6 +1440,24 @@ static unsigned w4_grid(int64_t items, int unroll) {
     return (unsigned)g;
 }
 
+// activation-ordered W4 (w4_gidx_kernel): one dtype for weight / scale / result, row-wise scales, group table aligned
+static bool w4_gidx_ok(int dt, int sdt, int tdt_or_odt, int bits, int64_t rows, int64_t cols, int64_t rdiv, int64_t scale_cols,
+                       const int32_t* col_group, const void* a, const void* b) {
+    return bits == 4 && col_group && (dt == CT_BF16 || dt == CT_F16) && sdt == dt && tdt_or_odt == dt && rows > 0 && cols > 0 && cols % 8 == 0 && rdiv == 1 &&
+           scale_cols >= 1 && scale_cols <= kGidxMaxGroups && aligned16(col_group) && aligned16(a) && aligned16(b) &&
+           rows * cdiv64(cols / 8, 2 * kBlock) < ((int64_t)1 << 31);
+}
+template <bool COMPRESS>
+static int launch_w4_gidx(const W4Params& w, int dt, const void* zp, const int32_t* col_group, int64_t rows, ct_stream_t stream, const char* what) {
+    const int chunks = (int)cdiv64(w.upr, 2 * kBlock);
+    dim3 g((unsigned)(rows * chunks));
+#define CT_GIDX(DT, ZP) hipLaunchKernelGGL((w4_gidx_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks)
+    if (dt == CT_BF16) { if (zp) CT_GIDX(CT_BF16, true); else CT_GIDX(CT_BF16, false); }
+    else { if (zp) CT_GIDX(CT_F16, true); else CT_GIDX(CT_F16, false); }
+#undef CT_GIDX
+    return hip_check(hipGetLastError(), what);
+}
+
 // fp32 flat kernels (f32_quads_kernel): groups of a multiple of 8 columns (or the whole row), no g_idx, 16-byte aligned float side,
 // 4-byte aligned code side
 static bool f32_quads_ok(int64_t rows, int64_t cols, int64_t cdiv, const int32_t* col_group, const void* floats, const void* codes) {
@@ -1612,6 +1696,10 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
 #undef CT_W4Q
         CT_LAUNCH_CHECK("ct_quant_pack[w4]");
     }
+    if (w4_gidx_ok(xdt, sdt, tdt, bits, rows, cols, rdiv, scale_cols, col_group, x, packed)) {
+        W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cols, scale_cols);
+        return launch_w4_gidx<true>(w, xdt, zp, col_group, rows, stream, "ct_quant_pack[w4 g_idx]");
+    }
     if (bits == 4 && xdt == CT_F32 && tdt == CT_F32 && !col_group && is_float_dt(sdt) && cols % 8 == 0 && cdiv % 8 == 0 && aligned16(x) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && rows * (cols / 8) < ((int64_t)1 << 38)) {
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
@@ -1726,6 +1814,10 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D
         CT_LAUNCH_CHECK("ct_unpack_dequant[w4]");
+    }
+    if (words == cols / 8 && w4_gidx_ok(sdt, sdt, odt, bits, rows, cols, rdiv, scale_cols, col_group, packed, out)) {
+        W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cols, scale_cols);
+        return launch_w4_gidx<false>(w, sdt, zp, col_group, rows, stream, "ct_unpack_dequant[w4 g_idx]");
     }
     if (bits == 4 && words == cols / 8 && sdt == CT_F32 && odt == CT_F32 && !col_group && cols % 8 == 0 && cdiv % 8 == 0 && aligned16(out) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && rows * (cols / 8) < ((int64_t)1 << 38)) {

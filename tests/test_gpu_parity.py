@@ -211,21 +211,30 @@ def test_quant_paths_vs_oracle(cta, dev, xdt, sdt, bits, strategy, gs, shape, sy
     assert eq(q0.cpu(), O.pack_to_int32(O.quantize(x, scale, None, dtype=torch.int8, **kw), bits).contiguous())
 
 
-def test_gidx_vs_oracle(cta, dev):
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn((32, 512), generator=g).to(BF16)
-    perm = torch.randperm(512, generator=g)
-    g_idx = (torch.arange(512, dtype=torch.int32) // 128)[perm].contiguous()
-    scale = (torch.rand((32, 4), generator=g) * 0.3 + 0.05).to(BF16)
-    zp = torch.randint(-8, 8, (32, 4), generator=g).to(torch.int8)
-    kw = dict(num_bits=4, strategy="group", group_size=128)
+@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("sym", [True, False], ids=["sym", "asym"])
+@pytest.mark.parametrize("shape,gs", [((32, 512), 128), ((96, 4096), 128), ((7, 1032), 8), ((16, 8192 * 2), 16)], ids=["small", "wide", "ragged_chunk", "1024_groups"])
+def test_gidx_vs_oracle(cta, dev, dt, sym, shape, gs):
+    """activation ordering (weight_g_idx): quantize, the packed words and the decompressed weight against the oracle — the flat W4
+    g_idx kernels (a workgroup inside one row, the row's scales in LDS) for 16-bit weights, special values included"""
+    g = torch.Generator().manual_seed(11 + shape[1])
+    rows, cols = shape
+    x = torch.randn(shape, generator=g).to(dt)
+    sp = special_values(dt)
+    x.view(-1)[: sp.numel()] = sp
+    perm = torch.randperm(cols, generator=g)
+    g_idx = (torch.arange(cols, dtype=torch.int32) // gs)[perm].contiguous()
+    scale = (torch.rand((rows, cols // gs), generator=g) * 0.3 + 0.05).to(dt)
+    scale[0, 0] = 2.0 ** -30 if dt == BF16 else 2.0 ** -15  # one scale outside the reciprocal range of fp16
+    zp = torch.zeros(rows, cols // gs, dtype=torch.int8) if sym else torch.randint(-8, 8, (rows, cols // gs), generator=g).to(torch.int8)
+    kw = dict(num_bits=4, strategy="group", group_size=gs)
     ref = O.quantize(x, scale, zp, dtype=torch.int8, g_idx=g_idx, **kw)
     got = cta.codec.quantize_tensor(x.to(dev), scale.to(dev), zp.to(dev), dtype=torch.int8, g_idx=g_idx.to(dev), **kw)
     assert eq(got.cpu(), ref)
-    packed = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), zp.to(dev), g_idx=g_idx.to(dev), **kw)
+    packed = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), None if sym else zp.to(dev), g_idx=g_idx.to(dev), **kw)
     assert eq(packed.cpu(), O.pack_to_int32(ref, 4).contiguous())
-    out = cta.codec.unpack_and_dequantize(packed, x.shape, scale.to(dev), zp.to(dev), g_idx=g_idx.to(dev), **kw)
-    assert eq(out.cpu(), O.dequantize(ref, scale, zp, strategy="group", group_size=128, g_idx=g_idx))
+    out = cta.codec.unpack_and_dequantize(packed, x.shape, scale.to(dev), None if sym else zp.to(dev), g_idx=g_idx.to(dev), **kw)
+    assert eq(out.cpu(), O.dequantize(ref, scale, zp, strategy="group", group_size=gs, g_idx=g_idx))
 
 
 def test_bf16_reciprocal_fast_path_is_exact(cta, dev):

@@ -156,6 +156,35 @@ elif what == "f32q":
         del ws, qs, outs
         torch.cuda.empty_cache()
     print(json.dumps(res))
+elif what == "gidx":
+    # W4A16 g128 with activation ordering (weight_g_idx): compress / decompress through the C ABI at 8192^2 bf16
+    from compressed_tensors_amd import _lib, codec
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    N = 8192; nsets = 6
+    g = torch.Generator(device=dev).manual_seed(5)
+    D = _lib.BF16
+    perm = torch.randperm(N, device=dev, generator=g)
+    g_idx = torch.empty(N, dtype=torch.int32, device=dev); g_idx[perm] = (torch.arange(N, device=dev) // 128).to(torch.int32)
+    sets = []
+    for _ in range(nsets):
+        w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+        sc = (torch.rand(N, N // 128, device=dev, generator=g) * 0.05 + 0.2).to(torch.bfloat16)
+        zp = torch.zeros(N, N // 128, dtype=torch.int8, device=dev)
+        sets.append((w, sc, zp, torch.empty(N, N // 8, dtype=torch.int32, device=dev), torch.empty(N, N, dtype=torch.bfloat16, device=dev)))
+    res = {}
+    for name, cg in (("plain", None), ("g_idx", g_idx)):
+        cgp = None if cg is None else cg.data_ptr()
+        ca = [(w.data_ptr(), D, sc.data_ptr(), D, None, -1, N, N, 1, 128, N // 128, cgp, 4, D, pk.data_ptr(), stream) for (w, sc, zp, pk, out) in sets]
+        da = [(pk.data_ptr(), N, N // 8, N, 4, sc.data_ptr(), D, None, -1, 1, 128, N // 128, cgp, out.data_ptr(), D, stream) for (w, sc, zp, pk, out) in sets]
+        def c(i): _lib.check(lib.ct_quant_pack(*ca[i % nsets]))
+        def d(i): _lib.check(lib.ct_unpack_dequant(*da[i % nsets]))
+        for i in range(nsets): c(i)
+        res[name] = {"compress_us": round(B.time_kernel(c, 18), 1), "decompress_us": round(B.time_kernel(d, 18), 1)}
+        w, sc, zp, pk, out = sets[0]
+        ref = codec.fake_quantize_tensor(w, sc, None, num_bits=4, strategy="group", group_size=128, g_idx=None) if cg is None else None
+        if cg is None:
+            res[name]["round_trip_equals_fake_quantize"] = bool(torch.equal(out, ref))
+    print(json.dumps(res))
 elif what == "m24host":
     # host cost of Marlin24Compressor.compress: a tiny weight (kernel ~ few us), many calls
     import time, cProfile, pstats, io
