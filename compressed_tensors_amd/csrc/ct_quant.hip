@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_f32_kernel(W4Params 
 // quads per lane, a block apart, all loads first.
 enum { F32_Q = 0, F32_DQ = 1, F32_FQ = 2 };
 template <int MODE, bool HAS_ZP>
-__global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, float qmin, float qmax) {
+__global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, float qmin, float qmax, uint32_t xoff /* 0x80808080: codes stored + 128 (8-bit packed words) */) {
     constexpr int U = 4;
     const int64_t quads = 2 * p.units;
     const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, 
         float v[4];
         if constexpr (MODE == F32_DQ) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>((float)(int)(int8_t)(c[i] >> (8 * k)), HAS_ZP, z, s);
+            for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>((float)(int)(int8_t)((c[i] ^ xoff) >> (8 * k)), HAS_ZP, z, s);
             stream_store16(static_cast<u32x4*>(p.out) + h, u32x4{f_bits(v[0]), f_bits(v[1]), f_bits(v[2]), f_bits(v[3])});
         } else {
             const float rs = f32_fast_rcp(s);
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, 
                 uint32_t word = 0;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) word |= (uint32_t)(cvt_i32_hw(v[k]) & 255) << (8 * k);  // NaN -> 0
-                __builtin_nontemporal_store(word, static_cast<uint32_t*>(p.out) + h);
+                __builtin_nontemporal_store(word ^ xoff, static_cast<uint32_t*>(p.out) + h);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>(v[k], HAS_ZP, z, s);
@@ -1465,10 +1465,10 @@ static bool f32_quads_ok(int64_t rows, int64_t cols, int64_t cdiv, const int32_t
            (codes == nullptr || (reinterpret_cast<uintptr_t>(codes) & 3u) == 0) && rows * (cols / 8) < ((int64_t)1 << 38);
 }
 template <int MODE>
-static int launch_f32_quads(const W4Params& w, const void* zp, int sdt, float qmin, float qmax, ct_stream_t stream, const char* what) {
+static int launch_f32_quads(const W4Params& w, const void* zp, int sdt, float qmin, float qmax, ct_stream_t stream, const char* what, uint32_t xoff = 0u) {
     dim3 g(w4_grid(2 * w.units, 4));
-    if (zp) hipLaunchKernelGGL((f32_quads_kernel<MODE, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax);
-    else hipLaunchKernelGGL((f32_quads_kernel<MODE, false>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax);
+    if (zp) hipLaunchKernelGGL((f32_quads_kernel<MODE, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax, xoff);
+    else hipLaunchKernelGGL((f32_quads_kernel<MODE, false>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax, xoff);
     return hip_check(hipGetLastError(), what);
 }
 
@@ -1696,6 +1696,10 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
 #undef CT_W4Q
         CT_LAUNCH_CHECK("ct_quant_pack[w4]");
     }
+    if (bits == 8 && xdt == CT_F32 && tdt == CT_F32 && is_float_dt(sdt) && f32_quads_ok(rows, cols, cdiv, col_group, x, packed)) {
+        W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);  // a word = four (code + 128) bytes = one quad
+        return launch_f32_quads<F32_Q>(w, zp, sdt, -128.0f, 127.0f, stream, "ct_quant_pack[w8 f32]", 0x80808080u);
+    }
     if (w4_gidx_ok(xdt, sdt, tdt, bits, rows, cols, rdiv, scale_cols, col_group, x, packed)) {
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cols, scale_cols);
         return launch_w4_gidx<true>(w, xdt, zp, col_group, rows, stream, "ct_quant_pack[w4 g_idx]");
@@ -1814,6 +1818,10 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D
         CT_LAUNCH_CHECK("ct_unpack_dequant[w4]");
+    }
+    if (bits == 8 && words == cols / 4 && sdt == CT_F32 && odt == CT_F32 && f32_quads_ok(rows, cols, cdiv, col_group, out, packed)) {
+        W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        return launch_f32_quads<F32_DQ>(w, zp, sdt, 0.0f, 0.0f, stream, "ct_unpack_dequant[w8 f32]", 0x80808080u);
     }
     if (words == cols / 8 && w4_gidx_ok(sdt, sdt, odt, bits, rows, cols, rdiv, scale_cols, col_group, packed, out)) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cols, scale_cols);
