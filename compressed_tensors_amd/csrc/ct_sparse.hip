@@ -1218,6 +1218,56 @@ __global__ __launch_bounds__(kBlock) void sparse24_compress_kernel(const void* _
     }
 }
 
+// two adjacent units per lane (8- and 16-bit elements): 16 / 32 contiguous bytes in, ONE 8- / 16-byte streaming store of values and a
+// 2-byte store of the two mask bytes, exact grid — the unit kernel above stores 4 / 8 bytes of values and single mask bytes per lane
+// through a grid-stride loop (bf16 at 8192^2: see DESIGN 5.3)
+template <int ES>
+__global__ __launch_bounds__(kBlock) void sparse24_pair_kernel(const void* __restrict__ x, bool is_float, int64_t pairs, void* __restrict__ values,
+                                                               uint8_t* __restrict__ bitmask) {
+    typedef typename ElemT<ES>::type T;
+    const int64_t pr = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (pr >= pairs) return;
+    T e[2][8];
+    if constexpr (ES == 2) {
+        const u32x4 a = static_cast<const u32x4*>(x)[2 * pr], b = static_cast<const u32x4*>(x)[2 * pr + 1];
+        const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { e[j >> 2][2 * (j & 3)] = (T)(ws[j] & 0xffffu); e[j >> 2][2 * (j & 3) + 1] = (T)(ws[j] >> 16); }
+    } else {
+        const u32x4 a = static_cast<const u32x4*>(x)[pr];
+        const uint32_t ws[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[j >> 1][4 * (j & 1) + k] = (T)(ws[j] >> (8 * k));
+    }
+    uint32_t mm = 0;
+    T o[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t k4[4] = {abs_key<ES>(e[u][4 * h], is_float), abs_key<ES>(e[u][4 * h + 1], is_float),
+                                    abs_key<ES>(e[u][4 * h + 2], is_float), abs_key<ES>(e[u][4 * h + 3], is_float)};
+            m |= top2_mask(k4) << (4 * h);
+        }
+        int pos = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if ((m >> k) & 1u) o[u][pos++] = e[u][k];
+        mm |= m << (8 * u);
+    }
+    __builtin_nontemporal_store((uint16_t)mm, reinterpret_cast<uint16_t*>(bitmask) + pr);
+    if constexpr (ES == 2) {
+        stream_store16(static_cast<u32x4*>(values) + pr, u32x4{(uint32_t)o[0][0] | ((uint32_t)o[0][1] << 16), (uint32_t)o[0][2] | ((uint32_t)o[0][3] << 16),
+                                                                (uint32_t)o[1][0] | ((uint32_t)o[1][1] << 16), (uint32_t)o[1][2] | ((uint32_t)o[1][3] << 16)});
+    } else {
+        stream_store8(static_cast<u32x2*>(values) + pr, u32x2{(uint32_t)o[0][0] | ((uint32_t)o[0][1] << 8) | ((uint32_t)o[0][2] << 16) | ((uint32_t)o[0][3] << 24),
+                                                              (uint32_t)o[1][0] | ((uint32_t)o[1][1] << 8) | ((uint32_t)o[1][2] << 16) | ((uint32_t)o[1][3] << 24)});
+    }
+}
+
 static bool float_kind(int dt) { return is_float_dt(dt); }
 
 static unsigned grid_1d(int64_t items) {
@@ -1467,6 +1517,14 @@ int ct_sparse24_compress(const void* x, int dt, int64_t rows, int64_t cols, void
     const int64_t units = rows * (cols / 8);
     CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
     const int vec = aligned16(x);
+    static const int pair_mode = []() { const char* e = std::getenv("CT_SPARSE24_PAIRS"); return e ? std::atoi(e) : 1; }();
+    if (pair_mode && vec && (es == 1 || es == 2) && units % 2 == 0 && (reinterpret_cast<uintptr_t>(bitmask) & 1u) == 0 && units / 2 < ((int64_t)1 << 38)) {
+        const int64_t pairs = units / 2;
+        dim3 g((unsigned)cdiv64(pairs, kBlock));
+        if (es == 2) hipLaunchKernelGGL((sparse24_pair_kernel<2>), g, dim3(kBlock), 0, as_stream(stream), x, float_kind(dt), pairs, values, bitmask);
+        else hipLaunchKernelGGL((sparse24_pair_kernel<1>), g, dim3(kBlock), 0, as_stream(stream), x, float_kind(dt), pairs, values, bitmask);
+        CT_LAUNCH_CHECK("ct_sparse24_compress[pairs]");
+    }
     CT_ES_SWITCH(es, hipLaunchKernelGGL((sparse24_compress_kernel<ES>), dim3(grid_1d(units)), dim3(kBlock), 0, as_stream(stream), x,
                                         float_kind(dt), units, values, bitmask, (uint8_t*)nullptr, vec));
     CT_LAUNCH_CHECK("ct_sparse24_compress");
