@@ -53,6 +53,8 @@ def case_quant(g):
         z = torch.zeros(sshape, dtype=torch.int8) if sym else torch.randint(-2 ** (bits - 1), 2 ** (bits - 1), sshape, generator=g, dtype=torch.int8)
     kw = dict(num_bits=bits, strategy=strategy, group_size=gs, block_structure=block, qtype=qtype)
     d = lambda t: None if t is None else t.to(dev)
+    if strategy == "group" and qtype == "int" and rng.random() < 0.4:
+        return case_quant_gidx(x, s, z, kw, dt, sdt, g)
     odt = F8 if qtype == "float" else torch.int8
     q = codec.quantize_tensor(d(x), d(s), d(z), dtype=odt, **kw)
     qr = O.quantize(x, s, z, dtype=odt, **kw)
@@ -67,6 +69,22 @@ def case_quant(g):
         assert torch.equal(packed.cpu(), O.pack_to_int32(O.quantize(x, s, z, dtype=torch.int8, **kw), bits).contiguous()), ("quant_pack", kw, dt, sdt, x.shape)
         back = codec.unpack_and_dequantize(packed, x.shape, d(s), d(z), num_bits=bits, strategy=strategy, group_size=gs)
         assert eq(back.cpu(), O.dequantize(O.quantize(x, s, z, dtype=torch.int8, **kw), s, z, **dkw)), ("unpack_dequant", kw, dt, sdt, x.shape)
+
+
+def case_quant_gidx(x, s, z, kw, dt, sdt, g):
+    """activation ordering: the same checks with a random column -> group table"""
+    cols, gs, bits = x.shape[1], kw["group_size"], kw["num_bits"]
+    g_idx = (torch.arange(cols, dtype=torch.int32) // gs)[torch.randperm(cols, generator=g)].contiguous()
+    kw = {k: v for k, v in kw.items() if k not in ("qtype", "block_structure")}
+    d = lambda t: None if t is None else t.to(dev)
+    qr = O.quantize(x, s, z, dtype=torch.int8, g_idx=g_idx, **kw)
+    q = codec.quantize_tensor(d(x), d(s), d(z), dtype=torch.int8, g_idx=d(g_idx), **kw)
+    assert torch.equal(q.cpu(), qr), ("quantize g_idx", kw, dt, sdt, x.shape)
+    assert eq(codec.fake_quantize_tensor(d(x), d(s), d(z), g_idx=d(g_idx), **kw).cpu(), O.fake_quantize(x, s, z, g_idx=g_idx, **kw)), ("fake_quantize g_idx", kw, dt, sdt, x.shape)
+    packed = codec.quantize_and_pack(d(x), d(s), d(z), g_idx=d(g_idx), **kw)
+    assert torch.equal(packed.cpu(), O.pack_to_int32(qr, bits).contiguous()), ("quant_pack g_idx", kw, dt, sdt, x.shape)
+    back = codec.unpack_and_dequantize(packed, x.shape, d(s), d(z), g_idx=d(g_idx), **kw)
+    assert eq(back.cpu(), O.dequantize(qr, s, z, strategy="group", group_size=gs, g_idx=g_idx)), ("unpack_dequant g_idx", kw, dt, sdt, x.shape)
 
 
 def case_pack(g):
