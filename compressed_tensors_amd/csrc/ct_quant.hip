@@ -368,10 +368,26 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32
                 float x0, x1;
                 unpack2<DT>(ws[j], x0, x1);
                 const uint32_t ga = gs[2 * j], gb = gs[2 * j + 1];
-                const float t0 = quant_core<DT>(x0, s_s[ga], HAS_ZP, HAS_ZP ? s_z[ga] : 0.0f, -8.0f, 7.0f, s_rs[ga]);
-                const float t1 = quant_core<DT>(x1, s_s[gb], HAS_ZP, HAS_ZP ? s_z[gb] : 0.0f, -8.0f, 7.0f, s_rs[gb]);
-                word |= (uint32_t)((cvt_i32_hw(t0) + 8) & 15) << (8 * j);  // NaN -> code 0
-                word |= (uint32_t)((cvt_i32_hw(t1) + 8) & 15) << (8 * j + 4);
+                const float ra = s_rs[ga], rb = s_rs[gb];
+                int c0, c1;
+                if (DT == CT_BF16 && ra != 0.0f && rb != 0.0f) {
+                    // both scales inside the proven range: the arithmetic of w4_quant_word with one reciprocal per element
+                    // (v_cvt_i32_f32 turns a NaN into code 0 and saturates, v_med3_i32 clamps: the same codes as quant_core)
+                    float t0 = x0 * ra, t1 = x1 * rb;
+                    round2<DT>(t0, t1);
+                    if (HAS_ZP) {
+                        t0 += s_z[ga]; t1 += s_z[gb];
+                        round2<DT>(t0, t1);
+                    }
+                    c0 = cvt_i32_hw(__builtin_rintf(t0)); c1 = cvt_i32_hw(__builtin_rintf(t1));
+                    c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
+                    c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
+                } else {
+                    c0 = cvt_i32_hw(quant_core<DT>(x0, s_s[ga], HAS_ZP, HAS_ZP ? s_z[ga] : 0.0f, -8.0f, 7.0f, ra));  // NaN -> code 0
+                    c1 = cvt_i32_hw(quant_core<DT>(x1, s_s[gb], HAS_ZP, HAS_ZP ? s_z[gb] : 0.0f, -8.0f, 7.0f, rb));
+                }
+                word |= (uint32_t)((c0 + 8) & 15) << (8 * j);
+                word |= (uint32_t)((c1 + 8) & 15) << (8 * j + 4);
             }
             __builtin_nontemporal_store(word, static_cast<uint32_t*>(p.out) + u);
         } else {
