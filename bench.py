@@ -375,7 +375,7 @@ def bitmask_leg(dev):
         "alg_bytes": alg,
         "decompress_us": round(us_d, 2), "decompress_GBps": round(alg / us_d / 1e3, 1), "decompress_frac_hbm": round(alg / us_d / 1e3 / HBM_PEAK_GBPS, 4),
         "compress_us": round(us_c1, 2), "compress_GBps": round(alg / us_c1 / 1e3, 1), "compress_frac_hbm": round(alg / us_c1 / 1e3 / HBM_PEAK_GBPS, 4),
-        "compress_kernel": "flat16_resident_kernel + one-thread finish (x read once, no scan kernel, no host round trip)",
+        "compress_kernel": "flat16_resident_kernel (x read once, one launch, no scan kernel, no host round trip)",
         "compress_two_pass_us": round(us_c, 2),
         "round_trip_bit_exact": bool(ok and ok1),
     }

@@ -795,8 +795,6 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
         call("ct_bitmask_compress", ptr(x), dt, rows, cols, ptr(buf), numel, ptr(bitmask), ptr(row_offsets),
              ws[-1:].data_ptr(), ptr(ws), ws_bytes, s)
         nnz = int(ws[-1].item())
-        if nnz < 0:  # a workgroup of the resident kernel gave up waiting (bounded wait; never observed outside the forced test): count / scan / scatter
-            return bitmask_compress(tensor, two_pass=True)
         # keep the view when it wastes less than half of the buffer, else release the slack
         values = buf[:nnz] if 2 * nnz >= numel else buf[:nnz].clone()
     return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor), _home(row_offsets, tensor)

@@ -285,11 +285,10 @@ int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const 
 /* sparse-bitmask compress, fused form: bitmask, row_offsets, values and total[0] = nnz with no host
  * round trip.  16-bit payloads with cols % 8 == 0: ONE pass over x — every workgroup keeps its share
  * of the tensor in registers, compacts it while the loads land, publishes its count as one 64-bit
- * word and stores once it has the counts of the workgroups before it (a one-thread kernel then
- * writes total[0]).  The wait is bounded: if a workgroup gives up (never observed), total[0] = -1 and
- * the outputs are unspecified — call again with CT_BITMASK_RESIDENT=0 semantics (count + scatter,
- * x read twice, no inter-workgroup waiting) or use count / scan / scatter; the Python codec does the
- * latter.  Other payloads: count, scan, scatter.  `values` must hold `values_capacity` elements
+ * word and stores once it has the counts of the workgroups before it; a count that does not arrive
+ * within 2 ms is recomputed by the waiting workgroup, so the call cannot fail or deadlock.
+ * CT_BITMASK_RESIDENT=0 selects count + scatter (x read twice, no inter-workgroup waiting).
+ * Other payloads: count, scan, scatter.  `values` must hold `values_capacity` elements
  * (numel is always enough; the 16-bit paths never write beyond the capacity and still report the
  * needed size in total).  `workspace` = ct_bitmask_compress_workspace_bytes(rows, cols) bytes, 8-byte
  * aligned, need not be initialised. */

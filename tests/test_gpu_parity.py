@@ -721,8 +721,9 @@ print("FORMS_OK")
     {},                                          # the resident form (default)
     {"CT_BITMASK_RESIDENT": "0"},                # the two kernels (count + scatter)
     {"CT_BITMASK_RESIDENT_MAX_WGS": "3"},        # resident, the tensor in chunks of three workgroups with a running total between them
-    {"CT_BITMASK_RESIDENT_WAIT_US": "0"},        # every workgroup that has to wait gives up: *total = -1 and the codec falls back
-], ids=["resident", "two_kernels", "resident_chunked", "resident_gives_up"])
+    {"CT_BITMASK_RESIDENT_WAIT_US": "0"},        # no waiting at all: every workgroup recounts the shares whose counts have not arrived (self-help)
+    {"CT_BITMASK_RESIDENT_WAIT_US": "0", "CT_BITMASK_RESIDENT_MAX_WGS": "5"},
+], ids=["resident", "two_kernels", "resident_chunked", "resident_self_help", "resident_self_help_chunked"])
 def test_bitmask_compress_forms_agree(env):
     """every form of the 16-bit sparse compress (the knobs are read once per process, hence the subprocess): values, bitmask, row
     offsets and the total bit-identical to count / scan / scatter for ragged, empty, dense, tiny shapes"""
@@ -774,8 +775,8 @@ def test_bitmask_compress_concurrent_streams(cta, dev):
             assert torch.equal(b["vals"][:nnz].view(torch.int16), v_ref.view(torch.int16)) and torch.equal(b["bm"], bm_ref) and torch.equal(b["ro"], ro_ref)
 
 
-def test_bitmask_resident_reports_failure(dev):
-    """the raw ABI: with a zero wait budget the resident form must say -1 in *total (never a wrong count)"""
+def test_bitmask_resident_self_help_total(dev):
+    """the raw ABI with a zero wait budget: workgroups recount what they would have waited for; *total is the right count"""
     import os
     import subprocess
     import sys
@@ -788,16 +789,18 @@ from compressed_tensors_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 N = 4096
 w = torch.randn(N, N, dtype=torch.bfloat16, device=dev)
+w = w.masked_fill(torch.rand(N, N, device=dev) < 0.37, 0)
 ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
 wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
 vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
 rc = lib.ct_bitmask_compress(w.data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes,
                              torch.cuda.current_stream(dev).cuda_stream)
 torch.cuda.synchronize()
-print("TOTAL", rc, int(wk[-1].item()))
+nnz = int((w != 0).sum().item())
+print("TOTAL", rc, int(wk[-1].item()) == nnz, bool(torch.equal(vals[:nnz], w[w != 0])))
 """ % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, CT_BITMASK_RESIDENT_WAIT_US="0"))
-    assert r.returncode == 0 and "TOTAL 0 -1" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "TOTAL 0 True True" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 # ----------------------------------------------------------------------------- modules / staging
