@@ -429,6 +429,36 @@ def test_w4a16_full_size(cta, dev, N):
     assert torch.equal(c2["weight_packed"], c["weight_packed"])
 
 
+@pytest.mark.parametrize("variant", ["fp32", "g_idx"])
+def test_w4a16_full_size_other_layouts(cta, dev, variant):
+    """the round-2 flat kernels at size, through the compressor class: fp32 weights and scales (4096x4096), and bf16 with activation
+    ordering (weight_g_idx, 2048x8192) — packed words and the decompressed weight against the oracle, round trip == fake_quantize"""
+    torch.manual_seed(3)
+    if variant == "fp32":
+        rows, cols, dt = 4096, 4096, F32
+    else:
+        rows, cols, dt = 2048, 8192, BF16
+    w = torch.randn(rows, cols, dtype=torch.float32).to(dt)
+    scale, zp = O.calculate_qparams_minmax(w, num_bits=4, group_size=128, symmetric=False)
+    scale = scale.to(dt)
+    g_idx = None
+    if variant == "g_idx":
+        g_idx = (torch.arange(cols, dtype=torch.int32) // 128)[torch.randperm(cols)].contiguous()
+    kw = dict(num_bits=4, strategy="group", group_size=128)
+    q_ref = O.quantize(w, scale, zp, dtype=torch.int8, g_idx=g_idx, **kw)
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, actorder="group" if g_idx is not None else None)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    sd = {"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}
+    if g_idx is not None:
+        sd["weight_g_idx"] = g_idx.to(dev)
+    c = cta.PackedQuantizationCompressor.compress(sd, scheme)
+    assert torch.equal(c["weight_packed"].cpu(), O.pack_to_int32(q_ref, 4))
+    dd = cta.PackedQuantizationCompressor.decompress(c, scheme)
+    ref = O.dequantize(q_ref, scale, zp, strategy="group", group_size=128, g_idx=g_idx)
+    assert dd["weight"].dtype == dt and eq(dd["weight"].cpu(), ref)
+    assert torch.equal(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, g_idx=g_idx, **kw))
+
+
 def test_int8_per_tensor_full_size(cta, dev):
     """BASELINE config 1 on the GPU path: int8 per-tensor symmetric, 4096x4096 bf16"""
     torch.manual_seed(0)
