@@ -407,19 +407,21 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32
 // (ct_quant_g32.inc) give a lane 32 elements = 128 bytes at a 128-byte lane stride, which is fine for 16-bit weights going through
 // the flat kernels above anyway but left fp32 at 140 us (compress) and 688 us (decompress: 32 scalar stores per lane) for
 // 304 MB at 8192^2.  The quotient: quant_core's reciprocal + half-integer test (fp32 has no proven shortcut; the test is exact).
-template <bool HAS_ZP>
+template <int XDT, bool HAS_ZP>
 __global__ __launch_bounds__(kBlock) void w4_quant_pack_f32_kernel(W4Params p, int sdt) {
+    // XDT = CT_F32, or a 16-bit weight divided by a float32 scale (torch promotes the quotient to float32: T = float32)
     constexpr int U = 2;
+    constexpr int V = XDT == CT_F32 ? 2 : 1;  // 16-byte vectors per unit
     const u32x4* in = static_cast<const u32x4*>(p.x);
     uint32_t* out = static_cast<uint32_t*>(p.out);
     const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
-    u32x4 a[U][2];
+    u32x4 a[U][V];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int64_t u = base + (int64_t)i * kBlock;
         if (u < p.units) {
-            a[i][0] = in[2 * u];
-            a[i][1] = in[2 * u + 1];
+#pragma unroll
+            for (int v = 0; v < V; ++v) a[i][v] = in[V * u + v];
         }
     }
 #pragma unroll
@@ -430,11 +432,20 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_f32_kernel(W4Params p, i
         const float s = load_rt(p.scale, sdt, si);
         const float z = HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f;  // zp.to(float32): exact
         const float rs = f32_fast_rcp(s);
-        const uint32_t ws[8] = {a[i][0].x, a[i][0].y, a[i][0].z, a[i][0].w, a[i][1].x, a[i][1].y, a[i][1].z, a[i][1].w};
+        float xs[8];
+        if constexpr (XDT == CT_F32) {
+            const uint32_t ws[8] = {a[i][0].x, a[i][0].y, a[i][0].z, a[i][0].w, a[i][1].x, a[i][1].y, a[i][1].z, a[i][1].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xs[k] = bits_f(ws[k]);
+        } else {
+            const uint32_t ws[4] = {a[i][0].x, a[i][0].y, a[i][0].z, a[i][0].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) unpack2<XDT>(ws[k], xs[2 * k], xs[2 * k + 1]);
+        }
         uint32_t word = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float t = quant_core<CT_F32>(bits_f(ws[k]), s, HAS_ZP, z, -8.0f, 7.0f, rs);
+            const float t = quant_core<CT_F32>(xs[k], s, HAS_ZP, z, -8.0f, 7.0f, rs);
             word |= (uint32_t)((cvt_i32_hw(t) + 8) & 15) << (4 * k);  // NaN -> code 0
         }
         __builtin_nontemporal_store(word, out + u);
@@ -1720,12 +1731,14 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cols, scale_cols);
         return launch_w4_gidx<true>(w, xdt, zp, col_group, rows, stream, "ct_quant_pack[w4 g_idx]");
     }
-    if (bits == 4 && xdt == CT_F32 && tdt == CT_F32 && !col_group && is_float_dt(sdt) && cols % 8 == 0 && cdiv % 8 == 0 && aligned16(x) &&
+    if (bits == 4 && tdt == CT_F32 && is_float_dt(xdt) && !col_group && is_float_dt(sdt) && cols % 8 == 0 && cdiv % 8 == 0 && aligned16(x) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && rows * (cols / 8) < ((int64_t)1 << 38)) {
         W4Params w = make_w4(x, scale, zp, zdt, packed, rows, cols, rdiv, cdiv, scale_cols);
         dim3 gf(w4_grid(w.units, 2));
-        if (zp) hipLaunchKernelGGL((w4_quant_pack_f32_kernel<true>), gf, dim3(kBlock), 0, as_stream(stream), w, sdt);
-        else hipLaunchKernelGGL((w4_quant_pack_f32_kernel<false>), gf, dim3(kBlock), 0, as_stream(stream), w, sdt);
+#define CT_W4F(X) do { if (zp) hipLaunchKernelGGL((w4_quant_pack_f32_kernel<X, true>), gf, dim3(kBlock), 0, as_stream(stream), w, sdt); \
+                       else hipLaunchKernelGGL((w4_quant_pack_f32_kernel<X, false>), gf, dim3(kBlock), 0, as_stream(stream), w, sdt); } while (0)
+        if (xdt == CT_F32) CT_W4F(CT_F32); else if (xdt == CT_BF16) CT_W4F(CT_BF16); else CT_W4F(CT_F16);
+#undef CT_W4F
         CT_LAUNCH_CHECK("ct_quant_pack[w4 f32]");
     }
     if (bits == 8 && cols % 32 == 0 && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, packed)) {
