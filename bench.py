@@ -167,6 +167,35 @@ def parity_gate(sets):
     return bool(ok_c and ok_d)
 
 
+def valu_busy_from_profile(path=None):
+    """{kernel: {"valu_busy_frac": f, ...}} from profiles/r02_headline_sq.txt: SQ_INSTS_VALU counts wave64 VALU instructions (4 cycles each
+    on a SIMD), the chip has 1024 SIMDs; busy = instructions * 4 / (kernel time * clock * 1024) at the 2.4 GHz peak clock (a lower bound
+    on the utilisation if the clock was lower)."""
+    import re
+
+    path = path or os.path.join(ROOT, "profiles", "r02_headline_sq.txt")
+    alias = {"ct::w4_quant_pack_lean_kernel<2, true>": "w4_quant_pack_lean_kernel<bf16>",
+             "ct::w4_unpack_dequant_kernel<2, 2, false, false>": "w4_unpack_dequant_kernel<bf16>"}
+    out = {}
+    try:
+        txt = open(path).read().splitlines()
+    except OSError:
+        return out
+    us, valu = {}, {}
+    for line in txt:
+        m = re.match(r"^(ct::.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+\d+\s+\d+", line)
+        if m and m.group(1).strip() in alias:
+            us[m.group(1).strip()] = float(m.group(3))
+        m = re.match(r"^(ct::.*?)\s+SQ_INSTS_VALU\s+\d+\s+([\d.]+)", line)
+        if m and m.group(1).strip() in alias:
+            valu[m.group(1).strip()] = float(m.group(2))
+    for k in alias:
+        if k in us and k in valu:
+            out[alias[k]] = {"valu_busy_frac": round(valu[k] * 4 / (us[k] * 1e-6 * 2.4e9 * 1024), 3), "valu_insts_per_launch": int(valu[k]),
+                             "valu_source": "profiles/r02_headline_sq.txt (SQ_INSTS_VALU x 4 cycles / (avg kernel time x 2.4 GHz x 1024 SIMDs)); committed profile, not live"}
+    return out
+
+
 def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -1008,6 +1037,11 @@ def main():
             "w4_unpack_dequant_kernel<bf16>": {"avg_us": round(us_d, 2), "GBps": round(one / us_d / 1e3, 1), "frac": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4),
                                                "avg_us_cache_warm": round(warm_d, 2)},
         }
+        # VALU utilisation next to the GB/s (a VALU-bound result must not be misread as a memory problem): from the committed
+        # SQ counter pass of the same two kernels (tools/profile_round.sh headline_sq), not measured live
+        for kname, busy in valu_busy_from_profile().items():
+            if kname in kernels:
+                kernels[kname].update(busy)
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
