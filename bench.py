@@ -465,21 +465,22 @@ def quantize_leg(dev):
         ws = [torch.randn(n, n, dtype=torch.float32, device=dev, generator=g).to(dt) for _ in range(nsets)]
         sc = (ws[0].float().abs().amax(dim=1, keepdim=True) / 127.0).to(dt).contiguous()
         zp = torch.randint(-3, 4, (n, 1), dtype=torch.int8, device=dev, generator=g)
-        qs = [torch.empty(n, n, dtype=torch.int8, device=dev) for _ in range(nsets)]
+        nq = 8  # 8 x 67 MB of codes: the dequantize's reads cannot be served by the 256 MiB Infinity Cache
+        qs = [torch.empty(n, n, dtype=torch.int8, device=dev) for _ in range(nq)]
         outs = [torch.empty(n, n, dtype=dt, device=dev) for _ in range(2)]
         for name, z in (("symmetric", None), ("asymmetric", zp)):
             zptr, zdt = (None, -1) if z is None else (z.data_ptr(), _lib.I8)
 
             def fq(i):
-                _lib.check(lib.ct_quantize(ws[i % nsets].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, 8, D, qs[i % nsets].data_ptr(), _lib.I8, stream))
+                _lib.check(lib.ct_quantize(ws[i % nsets].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, 8, D, qs[i % nq].data_ptr(), _lib.I8, stream))
 
             def fd(i):
-                _lib.check(lib.ct_dequantize(qs[i % nsets].data_ptr(), _lib.I8, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, outs[i % 2].data_ptr(), D, stream))
+                _lib.check(lib.ct_dequantize(qs[i % nq].data_ptr(), _lib.I8, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, outs[i % 2].data_ptr(), D, stream))
 
             def ff(i):
                 _lib.check(lib.ct_fake_quantize(ws[i % nsets].data_ptr(), D, sc.data_ptr(), D, zptr, zdt, n, n, 1, n, 1, None, 8, D, outs[i % 2].data_ptr(), D, stream))
 
-            for i in range(nsets):
+            for i in range(nq):
                 fq(i)
             us_q, us_d, us_f = time_kernel(fq, 24), time_kernel(fd, 24), time_kernel(ff, 24)
             # oracle gate on a slice of set 0

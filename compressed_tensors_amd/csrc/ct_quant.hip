@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_f32_kernel(W4Params 
 enum { F32_Q = 0, F32_DQ = 1, F32_FQ = 2 };
 template <int MODE, bool HAS_ZP>
 __global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, float qmin, float qmax, uint32_t xoff /* 0x80808080: codes stored + 128 (8-bit packed words) */) {
-    constexpr int U = 4;
+    constexpr int U = MODE == F32_DQ ? 8 : 4;  // dequantize loads only 4 bytes per quad: more of them in flight
     const int64_t quads = 2 * p.units;
     const int64_t base = (int64_t)blockIdx.x * (U * kBlock) + threadIdx.x;
     u32x4 a[U];
@@ -1493,7 +1493,7 @@ static bool f32_quads_ok(int64_t rows, int64_t cols, int64_t cdiv, const int32_t
 }
 template <int MODE>
 static int launch_f32_quads(const W4Params& w, const void* zp, int sdt, float qmin, float qmax, ct_stream_t stream, const char* what, uint32_t xoff = 0u) {
-    dim3 g(w4_grid(2 * w.units, 4));
+    dim3 g(w4_grid(2 * w.units, MODE == F32_DQ ? 8 : 4));
     if (zp) hipLaunchKernelGGL((f32_quads_kernel<MODE, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax, xoff);
     else hipLaunchKernelGGL((f32_quads_kernel<MODE, false>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, qmin, qmax, xoff);
     return hip_check(hipGetLastError(), what);
