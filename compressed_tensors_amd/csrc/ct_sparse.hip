@@ -383,11 +383,80 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress_kernel(const void* 
     __shared__ __attribute__((aligned(16))) ExpandLut s_lut;
     __shared__ int s_tot[kUPL][kBlock / 64];
     build_expand_lut(s_lut);  // visible after the first __syncthreads below
+    // 2:4-regular rows (every nibble of the row's bitmask has exactly two bits: what a 2:4 codec writes): the values of quad q are
+    // the row's values 2q and 2q + 1, no prefix is needed, and a lane turns 8 bytes of values + its mask bits into one 16-byte store
+    // with byte permutes.  Checked per row (one pass over <= cols / 8 mask bytes + a barrier); any other row takes the general
+    // path below.  Selector tables: [j][nibble] for byte payloads (the pair sits in bytes 2j, 2j+1 of its dword), [nibble][2]
+    // for 16-bit payloads (v0 = bytes 0-1, v1 = bytes 2-3); 0x0c selects a zero byte.
+    __shared__ uint32_t s_sel[64];
+    if (threadIdx.x < 32) {
+        const uint32_t nb = threadIdx.x & 15u, j = threadIdx.x >> 4;
+        uint32_t sel8 = 0, sel16a = 0, sel16b = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool bit = (nb >> k) & 1u;
+            const uint32_t rk = __popc(nb & ((1u << k) - 1u)) ? 1u : 0u;
+            sel8 |= (bit ? (2u * j + rk) : 0x0cu) << (8 * k);
+            const uint32_t h = bit ? ((2u * rk) | ((2u * rk + 1u) << 8)) : 0x0c0cu;  // the two bytes of element k
+            if (k < 2) sel16a |= h << (16 * k);
+            else sel16b |= h << (16 * (k - 2));
+        }
+        s_sel[threadIdx.x] = sel8;                 // [j * 16 + nibble]
+        if (j == 0) {
+            s_sel[32 + 2 * nb] = sel16a;           // [32 + 2 * nibble + {0, 1}]
+            s_sel[32 + 2 * nb + 1] = sel16b;
+        }
+    }
     const T* vin = static_cast<const T*>(values);
     const int64_t bcols = (cols + 7) >> 3;
     const bool single = cols <= kSuper;
+    const bool try_regular = vec_out && cols % 16 == 0 && (reinterpret_cast<uintptr_t>(bitmask) & 1u) == 0 && (reinterpret_cast<uintptr_t>(vin) & 7u) == 0;
     for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
+        if (try_regular) {  // workgroup-uniform
+            const uint16_t* mrow = reinterpret_cast<const uint16_t*>(bitmask + row * bcols);
+            bool reg = ((run * ES) & 7) == 0 && run >= 0 && run + (cols >> 1) <= values_len;
+            for (int64_t i = threadIdx.x; i < (bcols >> 1); i += kBlock) {
+                const uint32_t b = mrow[i];
+                uint32_t t = b - ((b >> 1) & 0x5555u);
+                t = (t & 0x3333u) + ((t >> 2) & 0x3333u);  // popcount of each nibble
+                reg = reg && (t == 0x2222u);
+            }
+            if (__syncthreads_and(reg)) {
+                const u32x2* vrow = reinterpret_cast<const u32x2*>(vin + run);
+                u32x4* orow = reinterpret_cast<u32x4*>(static_cast<T*>(out) + row * cols);
+                const int64_t nvec = cols * ES / 16;
+                for (int64_t v = threadIdx.x; v < nvec; v += kBlock) {
+                    const u32x2 val = vrow[v];
+                    u32x4 o;
+                    if constexpr (ES == 1) {
+                        const uint32_t mm = mrow[v];
+                        o.x = __builtin_amdgcn_perm(0u, val.x, s_sel[mm & 15u]);
+                        o.y = __builtin_amdgcn_perm(0u, val.x, s_sel[16 + ((mm >> 4) & 15u)]);
+                        o.z = __builtin_amdgcn_perm(0u, val.y, s_sel[(mm >> 8) & 15u]);
+                        o.w = __builtin_amdgcn_perm(0u, val.y, s_sel[16 + (mm >> 12)]);
+                    } else if constexpr (ES == 2) {
+                        const uint32_t mm = reinterpret_cast<const uint8_t*>(mrow)[v];
+                        const uint32_t n0 = mm & 15u, n1 = mm >> 4;
+                        o.x = __builtin_amdgcn_perm(0u, val.x, s_sel[32 + 2 * n0]);
+                        o.y = __builtin_amdgcn_perm(0u, val.x, s_sel[32 + 2 * n0 + 1]);
+                        o.z = __builtin_amdgcn_perm(0u, val.y, s_sel[32 + 2 * n1]);
+                        o.w = __builtin_amdgcn_perm(0u, val.y, s_sel[32 + 2 * n1 + 1]);
+                    } else {
+                        const uint32_t nb = (reinterpret_cast<const uint8_t*>(mrow)[v >> 1] >> (4 * (int)(v & 1))) & 15u;
+                        uint32_t e[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t src = (nb & ((1u << k) - 1u)) ? val.y : val.x;  // a second kept element of the quad takes v1
+                            e[k] = ((nb >> k) & 1u) ? src : 0u;
+                        }
+                        o = u32x4{e[0], e[1], e[2], e[3]};
+                    }
+                    stream_store16(orow + v, o);
+                }
+                continue;
+            }
+        }
         int64_t row_end = values_len;
         if (single) {
             if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
@@ -1492,6 +1561,7 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
     // aligned 16-byte loads of the value runs need a 16-byte aligned base; vectors that would
     // cross values_len are read element-wise in the kernel
     const int vec_in = aligned16(values);
+    // (2:4-regular rows of 16-bit payloads measure the same on this kernel as on the general kernel's local-expand path: 33.9 / 34.8 us)
     if (es == 2 && cols % 32 == 0 && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0) {
         const int64_t tiles = rows * cdiv64(cols, kTile16);
         const unsigned grid = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));  // exact grid measured best
