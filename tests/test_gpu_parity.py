@@ -584,6 +584,42 @@ def test_sparse24_vs_oracle(cta, dev, dtype):
     assert eq(out.cpu(), O.sparse24_bitmask_decompress(rv, rb, pruned.shape))
 
 
+@pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn, BF16, F32], ids=["int8", "fp8", "bf16", "fp32"])
+@pytest.mark.parametrize("cols", [64, 1040, 8192])
+def test_sparse24_decompress_regular_and_irregular_rows(cta, dev, dtype, cols):
+    """the general bitmask decompress expands 2:4-regular rows locally (no prefix) and every other row through the prefix path; a
+    tensor whose rows all keep cols / 2 elements but only some of which are 2:4-regular must come back exactly (oracle: the dense
+    scatter), for 8-, 16- and 32-bit payloads"""
+    g = torch.Generator().manual_seed(cols)
+    rows = 37
+    base = torch.randn(rows, cols, generator=g)
+    mask = torch.zeros(rows, cols, dtype=torch.bool)
+    quads = mask.view(rows, cols // 4, 4)
+    for r in range(rows):
+        if r % 3 == 1:  # irregular row: the same number of kept elements, placed anywhere
+            idx = torch.randperm(cols, generator=g)[: cols // 2]
+            mask[r, idx] = True
+        else:          # regular: two of every four
+            sel = torch.rand(cols // 4, 4, generator=g).argsort(dim=-1)[:, :2]
+            quads[r].scatter_(1, sel, True)
+    if dtype in (torch.int8,):
+        dense = (base * 40).to(torch.int8)
+        dense[dense == 0] = 1
+    elif dtype is torch.float8_e4m3fn:
+        dense = (base.to(BF16).to(dtype).view(torch.int8) | 1).view(dtype)  # no zero payloads
+    else:
+        dense = (base + base.sign() * 0.5).to(dtype)
+    dense_bits = dense.view(torch.int8) if dense.element_size() == 1 else dense
+    pruned = torch.where(mask, dense_bits, torch.zeros_like(dense_bits))
+    values = pruned[mask].reshape(rows, cols // 2)
+    weights = (1 << torch.arange(8, dtype=torch.int32))
+    bitmask = (mask.view(rows, cols // 8, 8).to(torch.int32) * weights).sum(-1).to(torch.uint8)
+    out = cta.codec.sparse24_bitmask_decompress(values.to(dev), bitmask.to(dev), (rows, cols))
+    assert torch.equal(out.cpu(), pruned)
+    ref = O.sparse24_bitmask_decompress(values, bitmask, (rows, cols))
+    assert torch.equal(out.cpu().view(torch.uint8), ref.view(torch.uint8))
+
+
 @pytest.mark.parametrize("case", [c for c in cases("sparse") if c["kind"] == "cutlass24"], ids=lambda c: c["key"])
 def test_cutlass24_golden(golden, cta, dev, case):
     t = golden.case("sparse", case["key"])
