@@ -176,8 +176,8 @@ def case_channel8(g):
 
 
 def case_sparse24(g):
-    dt = rng.choice([BF16, F16, torch.int8])
-    rows, cols = rng.choice([1, 4, 33, 64]), 8 * rng.choice([1, 2, 9, 64, 512])
+    dt = rng.choice([BF16, F16, torch.int8, F32])
+    rows, cols = rng.choice([1, 4, 33, 64]), 8 * rng.choice([1, 2, 9, 64, 130, 512, 1024])
     x = torch.randn((rows, cols), generator=g)
     x = (x * 40).to(dt) if dt == torch.int8 else x.to(dt)
     mask = codec.sparse24_mask(x.to(dev))
