@@ -1313,6 +1313,24 @@ __device__ __forceinline__ void top2_bytes(uint32_t x, uint32_t& nibble, uint32_
     kept16 = __builtin_amdgcn_perm(0u, x, lo | (hi << 8) | 0x0c0c0000u);
 }
 
+// a quad of 16-bit FLOAT payloads (two dwords): keys (|bits| << 2 | 3 - index) as 32-bit integers, the same selection network on
+// v_max_u32 / v_min_u32 / v_max3_u32, the two kept halfwords through one v_perm over the dword pair
+__device__ __forceinline__ void top2_halves(uint32_t d0, uint32_t d1, uint32_t& nibble, uint32_t& kept32) {
+    const uint32_t k0 = ((d0 & 0x7fffu) << 2) | 3u, k1 = (((d0 >> 16) & 0x7fffu) << 2) | 2u;
+    const uint32_t k2 = ((d1 & 0x7fffu) << 2) | 1u, k3 = (((d1 >> 16) & 0x7fffu) << 2);
+    const uint32_t m0 = k0 > k2 ? k0 : k2, n0 = k0 > k2 ? k2 : k0;   // pairs (0,2) and (1,3)
+    const uint32_t m1 = k1 > k3 ? k1 : k3, n1 = k1 > k3 ? k3 : k1;
+    const uint32_t t = m0 > m1 ? m0 : m1, u = m0 > m1 ? m1 : m0;
+    uint32_t sec = n0 > n1 ? n0 : n1;
+    sec = sec > u ? sec : u;
+    const uint32_t i1 = 3u - (t & 3u), i2 = 3u - (sec & 3u);
+    nibble = (1u << i1) | (1u << i2);
+    const uint32_t lo = i1 < i2 ? i1 : i2, hi = i1 < i2 ? i2 : i1;
+    // bytes of the pair (d1:d0): element e sits in bytes 2e, 2e + 1
+    const uint32_t sel = (2u * lo) | ((2u * lo + 1u) << 8) | ((2u * hi) << 16) | ((2u * hi + 1u) << 24);
+    kept32 = __builtin_amdgcn_perm(d1, d0, sel);
+}
+
 template <int ES>
 __global__ __launch_bounds__(kBlock) void sparse24_pair_kernel(const void* __restrict__ x, bool is_float, int64_t pairs, void* __restrict__ values,
                                                                uint8_t* __restrict__ bitmask) {
@@ -1346,6 +1364,22 @@ __global__ __launch_bounds__(kBlock) void sparse24_pair_kernel(const void* __res
         __builtin_nontemporal_store((uint16_t)m16, reinterpret_cast<uint16_t*>(bitmask) + pr);
         stream_store8(static_cast<u32x2*>(values) + pr, u32x2{k[0] | (k[1] << 16), k[2] | (k[3] << 16)});
         return;
+    }
+    if constexpr (ES == 2) {
+        if (is_float) {  // kernel-uniform
+            const u32x4 a = static_cast<const u32x4*>(x)[2 * pr], b = static_cast<const u32x4*>(x)[2 * pr + 1];
+            const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t m16 = 0, k[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t nb;
+                top2_halves(ws[2 * q], ws[2 * q + 1], nb, k[q]);
+                m16 |= nb << (4 * q);
+            }
+            __builtin_nontemporal_store((uint16_t)m16, reinterpret_cast<uint16_t*>(bitmask) + pr);
+            stream_store16(static_cast<u32x4*>(values) + pr, u32x4{k[0], k[1], k[2], k[3]});
+            return;
+        }
     }
     uint32_t mm = 0;
     T o[2][4];
