@@ -593,3 +593,20 @@ def test_launches_run_with_the_tensors_device_current(monkeypatch):
     _lib.call("ct_probe", 8, h0)          # already current: no switch
     _lib.call("ct_probe", 9, 5678)        # a raw handle from a C-style caller: left alone
     assert seen == [(7, 0, 1), (8, 1234, 0), (9, 5678, 0)] and state["entered"] == [1] and state["current"] == 0
+
+
+def test_bench_reads_valu_utilisation_from_the_committed_profile():
+    """bench.py reports VALU utilisation next to the GB/s of the two headline kernels from profiles/r02_headline_sq.txt:
+    the parser must find both kernels and give a fraction in (0, 1); the algorithmic byte count it divides by elsewhere is the survey's"""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    busy = bench.valu_busy_from_profile()
+    assert set(busy) == {"w4_quant_pack_lean_kernel<bf16>", "w4_unpack_dequant_kernel<bf16>"}
+    for v in busy.values():
+        assert 0.0 < v["valu_busy_frac"] < 1.0 and v["valu_insts_per_launch"] > 0
+    assert bench.alg_bytes_one_direction() == 168820736  # SURVEY 8(d), config 2
