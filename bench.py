@@ -83,24 +83,70 @@ def make_launchers(sets, stream, stream_d=None):
     return compress, decompress
 
 
-def time_kernel(fn, iters, offset=0):
-    """average launch duration (us) with HIP events on the launch stream"""
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for i in range(4):
-        fn(offset + i)
-    torch.cuda.synchronize()
-    start.record()
-    for i in range(iters):
-        fn(offset + i)
-    stop.record()
-    torch.cuda.synchronize()
-    return start.elapsed_time(stop) * 1000.0 / iters
+WARM_MS = 250.0   # fixed-DURATION device warm-up before the first timed region (independent of --warmup)
+KERNEL_WARM_MS = 40.0  # ... and before every per-kernel event timing
+BLOCKS = 5        # timed regions are repeated BLOCKS times; the MEDIAN block is the one reported
 
 
-def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60):
-    """HBM-cold per-kernel timing of the fused W4A16 g128 compress / decompress at another size, weight dtype or with
-    an asymmetric scheme (int8 zero points): enough rotating sets that the smallest read stream (the packed words) is
-    >= 2x the 256 MiB Infinity Cache.  Parity: decompress(compress(W)) == fake_quantize(W) on one set."""
+def device_warmup(fns, min_ms):
+    """run the REAL launches until `min_ms` of wall time has passed (clocks / power state / TLBs settle on a fresh lease:
+    round 2's driver run, 5 warm-up steps = 0.3 ms of GPU activity before the timed region, measured 5-8 % below steady state)"""
+    t0, i = time.perf_counter(), 0
+    while True:
+        for _ in range(32):
+            for f in fns:
+                f(i)
+            i += 1
+        torch.cuda.synchronize()
+        if (time.perf_counter() - t0) * 1e3 >= min_ms:
+            return i
+
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def time_kernel(fn, iters, offset=0, spread=None):
+    """average launch duration (us) with HIP events on the launch stream: >= KERNEL_WARM_MS of the same launches first, then
+    BLOCKS blocks of `iters` back-to-back launches; the median block is returned (min / max go to `spread` if given)"""
+    device_warmup([lambda i: fn(offset + i)], KERNEL_WARM_MS)
+    per = []
+    for _ in range(BLOCKS):
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for i in range(iters):
+            fn(offset + i)
+        stop.record()
+        torch.cuda.synchronize()
+        per.append(start.elapsed_time(stop) * 1000.0 / iters)
+    if spread is not None:
+        spread["min_us"], spread["max_us"], spread["blocks"], spread["launches_per_block"] = round(min(per), 2), round(max(per), 2), BLOCKS, iters
+    return median(per)
+
+
+def read_clocks():
+    """current shader / memory / fabric clock levels from sysfs (the '*' line of pp_dpm_*), if the box exposes them"""
+    import glob
+
+    out = {}
+    for name in ("sclk", "mclk", "fclk"):
+        for path in sorted(glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{name}")):
+            try:
+                cur = [l.strip() for l in open(path).read().splitlines() if l.strip().endswith("*")]
+            except OSError:
+                continue
+            if cur:
+                out[name] = cur[0].rstrip("*").strip()
+                break
+    return out or None
+
+
+def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, actorder=False):
+    """HBM-cold per-kernel timing of the fused W4A16 g128 compress / decompress at another size, weight dtype, with an
+    asymmetric scheme (int8 zero points) or with activation ordering (`weight_g_idx`: a random assignment of the columns to
+    the groups): enough rotating sets that the smallest read stream (the packed words) is >= 2x the 256 MiB Infinity Cache.
+    Parity: decompress(compress(W)) == fake_quantize(W) on one set (for actorder: fake_quantize with the same g_idx)."""
     from compressed_tensors_amd import _lib, codec
 
     lib = _lib.load()
@@ -108,15 +154,21 @@ def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60):
     dt = _lib.DT[dtype]
     nsets = max(4, -(-(2 * 256 * 2 ** 20) // (n * n // 2)))
     g = torch.Generator(device=dev).manual_seed(31 + n)
+    g_idx = cg = None
+    if actorder:
+        g_idx = (torch.randperm(n, device=dev, generator=g) // GROUP).to(torch.int32)
+        cg = codec.QuantLayout((n, n), torch.empty(n, n // GROUP, dtype=dtype, device=dev), "group", GROUP, None, g_idx).col_group
+        order = torch.argsort(g_idx)
     sets = []
     for _ in range(nsets):
         w = torch.randn(n, n, dtype=torch.float32, device=dev, generator=g).to(dtype)
-        scale, zp = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=symmetric)
+        scale, zp = codec.minmax_qparams(w[:, order].contiguous() if actorder else w, num_bits=BITS, group_size=GROUP, symmetric=symmetric)
         sets.append((w, scale, zp, torch.empty(n, n // 8, dtype=torch.int32, device=dev), torch.empty(n, n, dtype=dtype, device=dev)))
-    ca = [(w.data_ptr(), dt, sc.data_ptr(), dt, zp.data_ptr(), _lib.I8, n, n, 1, GROUP, n // GROUP, None, BITS, dt, pk.data_ptr(), stream)
+    cgp = None if cg is None else cg.data_ptr()
+    ca = [(w.data_ptr(), dt, sc.data_ptr(), dt, zp.data_ptr(), _lib.I8, n, n, 1, GROUP, n // GROUP, cgp, BITS, dt, pk.data_ptr(), stream)
           for (w, sc, zp, pk, out) in sets]
     da = [(pk.data_ptr(), n, n // 8, n, BITS, sc.data_ptr(), dt, None if symmetric else zp.data_ptr(), -1 if symmetric else _lib.I8,
-           1, GROUP, n // GROUP, None, out.data_ptr(), dt, stream) for (w, sc, zp, pk, out) in sets]
+           1, GROUP, n // GROUP, cgp, out.data_ptr(), dt, stream) for (w, sc, zp, pk, out) in sets]
 
     def compress(i):
         rc = lib.ct_quant_pack(*ca[i % nsets])
@@ -130,13 +182,23 @@ def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60):
 
     for i in range(nsets):
         compress(i)
-    one = alg_bytes_one_direction(n) + (0 if symmetric else n * (n // GROUP))  # + the int8 zero points
+    one = alg_bytes_one_direction(n) + (0 if symmetric else n * (n // GROUP)) + (4 * n if actorder else 0)  # + int8 zero points, + the group table
     us_c, us_d = time_kernel(compress, iters), time_kernel(decompress, iters, offset=nsets // 2)
+    # the same launches on ONE buffer set (Infinity-Cache-warm; reported beside the cold figure, never instead of it)
+    warm_c, warm_d = time_kernel(lambda i: compress(0), iters), time_kernel(lambda i: decompress(0), iters)
     w, sc, zp, pk, out = sets[0]
-    ok = torch.equal(out, codec.fake_quantize_tensor(w, sc, zp, num_bits=BITS, strategy="group", group_size=GROUP))
+    ok = torch.equal(out, codec.fake_quantize_tensor(w, sc, zp, num_bits=BITS, strategy="group", group_size=GROUP, g_idx=g_idx))
+    if actorder:  # the CPU oracle on a 64-row slice of set 0: packed words and decompressed rows, bit for bit
+        O = _oracle()
+        sl = slice(0, 64)
+        sd = {"weight": w[sl].cpu(), "weight_scale": sc[sl].cpu(), "weight_zero_point": zp[sl].cpu(), "weight_g_idx": g_idx.cpu()}
+        oc = O.pack_quantized_compress(sd, num_bits=BITS, strategy="group", group_size=GROUP, symmetric=symmetric)
+        od = O.pack_quantized_decompress(oc, num_bits=BITS, strategy="group", symmetric=symmetric)
+        ok = ok and torch.equal(pk[sl].cpu(), oc["weight_packed"]) and torch.equal(out[sl].cpu().view(torch.int16), od["weight"].view(torch.int16))
     return {"alg_bytes_per_direction": one, "sets": nsets,
             "compress_us": round(us_c, 2), "compress_GBps": round(one / us_c / 1e3, 1), "compress_frac_hbm": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4),
             "decompress_us": round(us_d, 2), "decompress_GBps": round(one / us_d / 1e3, 1), "decompress_frac_hbm": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4),
+            "compress_us_cache_warm": round(warm_c, 2), "decompress_us_cache_warm": round(warm_d, 2),
             "round_trip_equals_fake_quantize": bool(ok)}
 
 
@@ -144,7 +206,8 @@ def w4_variants_leg(dev):
     """north_star's second size (4096x4096) and the other weight dtypes / schemes of the same two kernels at 8192x8192"""
     out = {"workload": "W4A16 g128 fused compress / decompress kernels through the C ABI, HBM-cold rotation"}
     for key, kw in (("bf16_4096", dict(n=4096)), ("fp16_8192", dict(n=N, dtype=torch.float16)),
-                    ("bf16_8192_asymmetric", dict(n=N, symmetric=False)), ("fp16_8192_asymmetric", dict(n=N, dtype=torch.float16, symmetric=False))):
+                    ("bf16_8192_asymmetric", dict(n=N, symmetric=False)), ("fp16_8192_asymmetric", dict(n=N, dtype=torch.float16, symmetric=False)),
+                    ("bf16_8192_actorder", dict(n=N, actorder=True))):
         out[key] = w4_kernel_point(dev, **kw)
         torch.cuda.empty_cache()
     return out
@@ -167,13 +230,39 @@ def parity_gate(sets):
     return bool(ok_c and ok_d)
 
 
+def lib_srchash():
+    try:
+        return open(os.path.join(ROOT, "compressed_tensors_amd", "libct_hip.so.srchash")).read().strip()
+    except OSError:
+        return None
+
+
+def committed_traffic(kernel):
+    """roofline.traffic comes from a committed PMC pass (profiles/pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE runs under rocprofv3,
+    which cannot run inside the timed region).  The file records the source hash of the library it was collected on; if the library
+    has changed since, the figure is reported as STALE instead of silently."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None, "profiles/pmc_traffic.json missing"
+    rec, cur = d.get("_srchash"), lib_srchash()
+    state = "current library" if rec and rec == cur else ("STALE: kernels changed since the PMC pass" if rec else "no library hash recorded with the pass")
+    return d.get(kernel), f"profiles/pmc_traffic.json ({d.get('_tag', 'committed PMC pass')}; {state})"
+
+
 def valu_busy_from_profile(path=None):
-    """{kernel: {"valu_busy_frac": f, ...}} from profiles/r02_headline_sq.txt: SQ_INSTS_VALU counts wave64 VALU instructions (4 cycles each
-    on a SIMD), the chip has 1024 SIMDs; busy = instructions * 4 / (kernel time * clock * 1024) at the 2.4 GHz peak clock (a lower bound
-    on the utilisation if the clock was lower)."""
+    """{kernel: {"valu_busy_frac": f, ...}} from the committed SQ counter pass (profiles/<tag>_headline_sq.txt, newest tag): SQ_INSTS_VALU counts
+    wave64 VALU instructions (4 cycles each on a SIMD), the chip has 1024 SIMDs; busy = instructions * 4 / (kernel time * clock * 1024) at the
+    2.4 GHz peak clock (a lower bound on the utilisation if the clock was lower).  Marked stale when the library changed since the pass."""
+    import glob
     import re
 
-    path = path or os.path.join(ROOT, "profiles", "r02_headline_sq.txt")
+    if path is None:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_headline_sq.txt")))
+        if not cands:
+            return {}
+        path = cands[-1]
     alias = {"ct::w4_quant_pack_lean_kernel<2, true>": "w4_quant_pack_lean_kernel<bf16>",
              "ct::w4_unpack_dequant_kernel<2, 2, false, false>": "w4_unpack_dequant_kernel<bf16>"}
     out = {}
@@ -181,6 +270,8 @@ def valu_busy_from_profile(path=None):
         txt = open(path).read().splitlines()
     except OSError:
         return out
+    rec = next((l.split()[-1] for l in txt if l.startswith("# srchash")), None)
+    state = "current library" if rec and rec == lib_srchash() else ("STALE: kernels changed since the pass" if rec else "no library hash recorded with the pass")
     us, valu = {}, {}
     for line in txt:
         m = re.match(r"^(ct::.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+\d+\s+\d+", line)
@@ -189,10 +280,11 @@ def valu_busy_from_profile(path=None):
         m = re.match(r"^(ct::.*?)\s+SQ_INSTS_VALU\s+\d+\s+([\d.]+)", line)
         if m and m.group(1).strip() in alias:
             valu[m.group(1).strip()] = float(m.group(2))
+    rel = os.path.relpath(path, ROOT)
     for k in alias:
         if k in us and k in valu:
             out[alias[k]] = {"valu_busy_frac": round(valu[k] * 4 / (us[k] * 1e-6 * 2.4e9 * 1024), 3), "valu_insts_per_launch": int(valu[k]),
-                             "valu_source": "profiles/r02_headline_sq.txt (SQ_INSTS_VALU x 4 cycles / (avg kernel time x 2.4 GHz x 1024 SIMDs)); committed profile, not live"}
+                             "valu_source": f"{rel} (SQ_INSTS_VALU x 4 cycles / (avg kernel time x 2.4 GHz x 1024 SIMDs)); committed profile, not live; {state}"}
     return out
 
 
@@ -399,7 +491,37 @@ def bitmask_leg(dev):
     us_c1 = time_kernel(compress1, 24)
     ok1 = all(torch.equal(it["v2"].view(torch.int16), it["values"].view(torch.int16)) and torch.equal(it["bm2"], it["bitmask"])
               and torch.equal(it["ro2"], it["ro"]) and int(it["ws"][-1].item()) == it["values"].numel() for it in items)
+    # sparse-24-bitmask (S2) on the same tensors pruned 2:4: compress = top-2 of every quad + bitmask, decompress = the 2:4-regular row path
+    s24 = {}
+    try:
+        O = _oracle()
+        for it in items:
+            it["w"].mul_(codec.sparse24_mask(it["w"]).to(torch.bfloat16))  # 2:4-pruned in place (zeros stay zeros)
+            it["v24"] = torch.empty(N, N // 2, dtype=torch.bfloat16, device=dev)
+
+        def c24(i):
+            it = items[i % NB]
+            lib.ct_sparse24_compress(it["w"].data_ptr(), BF16, N, N, it["v24"].data_ptr(), it["bm2"].data_ptr(), stream)
+
+        def d24(i):
+            it = items[i % NB]
+            lib.ct_bitmask_decompress(it["v24"].data_ptr(), it["v24"].numel(), it["bm2"].data_ptr(), None, N // 2, BF16, N, N, it["out"].data_ptr(), stream)
+
+        for i in range(NB):
+            c24(i)
+        alg24 = 2 * N * N + N * N + N * N // 8
+        us_c24, us_d24 = time_kernel(c24, 24), time_kernel(d24, 24, offset=NB // 2)
+        it = items[0]
+        rv, rb = O.sparse24_bitmask_compress(items[0]["w"][:256].cpu())
+        ok24 = (torch.equal(it["out"].view(torch.int16), it["w"].view(torch.int16)) and torch.equal(items[0]["v24"][:256].cpu().view(torch.int16), rv.view(torch.int16))
+                and torch.equal(items[0]["bm2"][:256].cpu(), rb))
+        s24 = {"s24_alg_bytes": alg24, "s24_compress_us": round(us_c24, 2), "s24_compress_frac_hbm": round(alg24 / us_c24 / 1e3 / HBM_PEAK_GBPS, 4),
+               "s24_decompress_us": round(us_d24, 2), "s24_decompress_frac_hbm": round(alg24 / us_d24 / 1e3 / HBM_PEAK_GBPS, 4), "s24_bit_exact": bool(ok24),
+               "s24_workload": f"sparse-24-bitmask compress / decompress, {N}x{N} bf16 pruned 2:4, C ABI, {NB} rotating sets; 256 rows against the CPU oracle"}
+    except Exception as e:
+        s24 = {"s24_error": repr(e)}
     return {
+        **s24,
         "workload": f"sparse-bitmask 50% unstructured {N}x{N} bf16 (nnz={nnz})",
         "alg_bytes": alg,
         "decompress_us": round(us_d, 2), "decompress_GBps": round(alg / us_d / 1e3, 1), "decompress_frac_hbm": round(alg / us_d / 1e3 / HBM_PEAK_GBPS, 4),
@@ -691,6 +813,54 @@ def float_formats_leg(dev):
     out["nvfp4_rtn_one_pass_given_global_scale"] = dict(alg_bytes=alg_n, **rate(alg_n, time_kernel(nq, 36)))
     out["workload"] = f"float-quantized (float8_e4m3fn, channel), nvfp4- and mxfp4-pack-quantized weight paths, {N}x{N} bf16, C ABI"
     return out
+
+
+def roofline_rows(result):
+    """one {kernel, config, alg_bytes, us, GBps, frac} row per extra leg, appended to roofline.kernels (the driver keeps `roofline` whole)"""
+    rows = []
+
+    def row(kernel, config, alg, us, **kw):
+        if us:
+            rows.append(dict(kernel=kernel, config=config, alg_bytes=int(alg), us=us, GBps=round(alg / us / 1e3, 1), frac=round(alg / us / 1e3 / HBM_PEAK_GBPS, 4), **kw))
+
+    def leg(key):
+        v = result.get(key)
+        return v if isinstance(v, dict) and "error" not in v else None
+
+    b = leg("bitmask")
+    if b:
+        row("bitmask_decompress16_kernel", "sparse-bitmask 50 % 8192x8192 bf16 (config 3), decompress", b["alg_bytes"], b["decompress_us"], bit_exact=b["round_trip_bit_exact"])
+        row("flat16_resident_kernel", "sparse-bitmask 50 % 8192x8192 bf16 (config 3), compress", b["alg_bytes"], b["compress_us"], bit_exact=b["round_trip_bit_exact"])
+        if "s24_compress_us" in b:
+            row("sparse24_pair_kernel", "sparse-24-bitmask 8192x8192 bf16, compress", b["s24_alg_bytes"], b["s24_compress_us"], bit_exact=b["s24_bit_exact"])
+            row("bitmask_decompress16_kernel<2:4 rows>", "sparse-24-bitmask 8192x8192 bf16, decompress", b["s24_alg_bytes"], b["s24_decompress_us"], bit_exact=b["s24_bit_exact"])
+    k4 = leg("kernels_4096")
+    if k4:
+        row("w4_quant_pack_lean_kernel<bf16>", "W4A16 g128 4096x4096 bf16, compress", k4["alg_bytes_per_direction"], k4["compress_us"])
+        row("w4_unpack_dequant_kernel<bf16>", "W4A16 g128 4096x4096 bf16, decompress", k4["alg_bytes_per_direction"], k4["decompress_us"])
+    ko = leg("kernels_other") or {}
+    for key in ("fp16_8192", "bf16_8192_asymmetric", "bf16_8192_actorder"):
+        v = ko.get(key)
+        if isinstance(v, dict):
+            row("w4 compress", f"W4A16 g128 8192x8192 {key}", v["alg_bytes_per_direction"], v["compress_us"])
+            row("w4 decompress", f"W4A16 g128 8192x8192 {key}", v["alg_bytes_per_direction"], v["decompress_us"])
+    i8 = leg("int8_per_tensor")
+    if i8:
+        row("q8_quant_kernel", "int8 per-tensor 4096x4096 bf16 (config 1), quantize", i8["alg_bytes_per_direction"], i8["quantize_us"])
+        row("q8_dequant_kernel", "int8 per-tensor 4096x4096 bf16 (config 1), dequantize", i8["alg_bytes_per_direction"], i8["dequantize_us"])
+    m = leg("marlin24")
+    if m:
+        row("marlin24_fused_w4_lean_kernel", "marlin-24 2:4 + int4 g128 8192x8192 bf16 (config 4), kernel", m["alg_bytes"], m["kernels_us"], bit_exact=m["bit_exact_vs_oracle"])
+        row("Marlin24Compressor.compress", "config 4 through the plug-in class", m["alg_bytes"], m["compress_us"], bit_exact=m["bit_exact_vs_oracle"])
+    q = leg("minmax_qparams")
+    if q:
+        row("qparams_absmax_kernel", "min-max observer int4 g128 8192x8192 bf16", q["alg_bytes"], q["us"])
+        row("rtn_w4_kernel", "observer + quantize + pack in one pass", q["fused_with_compress"]["alg_bytes"], q["fused_with_compress"]["us"])
+    pu = leg("pack_unpack")
+    if pu:
+        row("pack_flat4_kernel", "pack_to_int32 b=4 8192x8192 int8", pu["alg_bytes_per_direction"], pu["pack_us"])
+        row("unpack_flat4_kernel", "unpack_from_int32 b=4 8192x8192", pu["alg_bytes_per_direction"], pu["unpack_us"])
+    return rows
 
 
 TINYLLAMA_LAYER = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048),
@@ -996,30 +1166,47 @@ def main():
         if distributed:
             dist.barrier()
 
-    def timed_steps(c, d):
+    def timed_steps(c, d, cold_probe=None):
+        """BLOCKS timed regions of EXACTLY --steps steps each, every one bracketed by barrier + synchronize on both sides and
+        max-reduced over the ranks; returns the per-block wall times.  Before them: every packed buffer is populated, a
+        fixed-duration warm-up of the same launches (WARM_MS, independent of --warmup), then the --warmup untimed steps."""
         for i in range(NSETS):  # populate every packed buffer once
             c(i)
         torch.cuda.synchronize()
+
+        def block():
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                c(i)
+                d(i + NSETS // 2)  # a packed buffer written 8 steps (1.3 GB of traffic) ago: evicted from the Infinity Cache
+            torch.cuda.synchronize()
+            barrier()
+            el = time.perf_counter() - t0
+            if distributed:
+                t = torch.tensor([el], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only; the data path has no collective
+                el = float(t.item())
+            return el
+
+        if cold_probe is not None:  # what round 2's protocol measured: --warmup steps only, on a device that has done nothing yet
+            for i in range(a.warmup):
+                c(i)
+                d(i + NSETS // 2)
+            cold_probe.append(block())
+        device_warmup([c, lambda i: d(i + NSETS // 2)], WARM_MS)
         for i in range(a.warmup):
             c(i)
             d(i + NSETS // 2)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            c(i)
-            d(i + NSETS // 2)  # a packed buffer written 8 steps (1.3 GB of traffic) ago: evicted from the Infinity Cache
-        torch.cuda.synchronize()
-        barrier()
-        el = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([el], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only; the data path has no collective
-            el = float(t.item())
-        return el
+        return [block() for _ in range(BLOCKS)]
 
-    elapsed_one = timed_steps(compress, decompress)
-    elapsed = elapsed_one if a.one_stream else timed_steps(compress2, decompress2)
+    clocks_before = read_clocks()
+    cold = []
+    blocks_one = timed_steps(compress, decompress, cold_probe=cold)
+    blocks = blocks_one if a.one_stream else timed_steps(compress2, decompress2)
+    clocks_after = read_clocks()
+    elapsed_one, elapsed = median(blocks_one), median(blocks)
 
     step_bytes = 2 * alg_bytes_one_direction()
     value = world * step_bytes * a.steps / elapsed / 1e9
@@ -1027,16 +1214,17 @@ def main():
     result = None
     if rank == 0:
         one = alg_bytes_one_direction()
-        us_c = time_kernel(compress, 60)
-        us_d = time_kernel(decompress, 60, offset=NSETS // 2)
+        sp_c, sp_d = {}, {}
+        us_c = time_kernel(compress, 60, spread=sp_c)
+        us_d = time_kernel(decompress, 60, offset=NSETS // 2, spread=sp_d)
         # the same launches on ONE buffer set: its 168 MB stay in the 256 MiB Infinity Cache (reported, never `value`)
         warm_c = time_kernel(lambda i: compress(0), 60)
         warm_d = time_kernel(lambda i: decompress(0), 60)
         kernels = {
             "w4_quant_pack_lean_kernel<bf16>": {"avg_us": round(us_c, 2), "GBps": round(one / us_c / 1e3, 1), "frac": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4),
-                                                "avg_us_cache_warm": round(warm_c, 2)},
+                                                "avg_us_cache_warm": round(warm_c, 2), **sp_c},
             "w4_unpack_dequant_kernel<bf16>": {"avg_us": round(us_d, 2), "GBps": round(one / us_d / 1e3, 1), "frac": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4),
-                                               "avg_us_cache_warm": round(warm_d, 2)},
+                                               "avg_us_cache_warm": round(warm_d, 2), **sp_d},
         }
         # VALU utilisation next to the GB/s (a VALU-bound result must not be misread as a memory problem): from the committed
         # SQ counter pass of the same two kernels (tools/profile_round.sh headline_sq), not measured live
@@ -1044,13 +1232,7 @@ def main():
             if kname in kernels:
                 kernels[kname].update(busy)
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
+        traffic, traffic_src = committed_traffic(dom)
         result = {
             "metric": "GB/s pack+unpack (int4 g128, bitmask) vs HBM peak; bit-exact round-trip",
             "value": round(value, 1),
@@ -1083,6 +1265,20 @@ def main():
                 "frac": kernels[dom]["frac"],
                 "traffic": traffic,
                 "alg_bytes_per_launch": one,
+                "traffic_source": traffic_src,
+                # everything below is measured live in this run; it sits INSIDE `roofline` so that it survives the driver's parse
+                "step": {"value_two_streams": round(world * step_bytes * a.steps / elapsed / 1e9, 1),
+                         "value_one_stream": round(world * step_bytes * a.steps / elapsed_one / 1e9, 1),
+                         "frac_two_streams": round(value / world / HBM_PEAK_GBPS, 4),
+                         "frac_one_stream": round(step_bytes * a.steps / elapsed_one / 1e9 / HBM_PEAK_GBPS, 4),
+                         "protocol": f"{WARM_MS:.0f} ms device warm-up of the same launches, then --warmup steps, then {BLOCKS} blocks of --steps steps "
+                                     "(barrier + synchronize on both sides of every block, wall clock, max over ranks); the MEDIAN block is ms_per_step",
+                         "ms_per_step_blocks": [round(x / a.steps * 1e3, 5) for x in blocks],
+                         "ms_per_step_blocks_one_stream": [round(x / a.steps * 1e3, 5) for x in blocks_one],
+                         "ms_per_step_without_device_warmup": round(cold[0] / a.steps * 1e3, 5) if cold else None,
+                         "clocks_before": clocks_before, "clocks_after": clocks_after},
+                "kernels": [dict(kernel=k, config=f"W4A16 g128 {N}x{N} bf16", alg_bytes=one, us=v["avg_us"], min_us=v.get("min_us"), max_us=v.get("max_us"),
+                                 GBps=v["GBps"], frac=v["frac"], valu_busy_frac=v.get("valu_busy_frac")) for k, v in kernels.items()],
             },
             "kernels": kernels,
             "parity_gate": parity_gate(sets),
@@ -1099,6 +1295,7 @@ def main():
                 torch.cuda.empty_cache()
             if isinstance(result.get("kernels_other"), dict) and "bf16_4096" in result["kernels_other"]:
                 result["kernels_4096"] = result["kernels_other"]["bf16_4096"]  # north_star names both sizes
+            result["roofline"]["kernels"] += roofline_rows(result)
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["cpu_baseline_port"] = cpu_baseline(dev)
         result["oracle_slice_check"] = oracle_slice_check(dev)  # never skipped: no configuration runs without the real checker

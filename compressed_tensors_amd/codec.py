@@ -150,6 +150,26 @@ def unpack_from_int32(value: torch.Tensor, num_bits: int, shape: Sequence[int], 
 
 
 # --------------------------------------------------------------------------- quantization layout
+def _col_group_of(g_idx: torch.Tensor, group_size: int) -> torch.Tensor:
+    """activation ordering (forward_helpers.py:147-175): column c uses the group of its position in the g_idx-sorted order; a g_idx
+    that still holds a -1 (not initialised) means plain column order.  The reference decides that with `-1 in g_idx`, a host read
+    per call; here the choice is a device-side select — no synchronisation — and the table is cached on the g_idx tensor itself
+    (keyed by its version counter), so a module's repeated compress / decompress calls pay the two sorts once."""
+    key = (g_idx._version, int(group_size), g_idx.device)
+    hit = getattr(g_idx, "_ct_col_group", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    flat = g_idx.detach().reshape(-1)
+    inv = torch.argsort(torch.argsort(flat))
+    plain = torch.arange(flat.numel(), device=flat.device)
+    col_group = (torch.where((flat == -1).any(), plain, inv) // int(group_size)).to(torch.int32)
+    try:
+        g_idx._ct_col_group = (key, col_group)
+    except Exception:  # a tensor subclass that refuses attributes: just recompute next time
+        pass
+    return col_group
+
+
 class QuantLayout:
     """How scale / zero-point entries map onto the elements of x:
     idx(r, c) = (r // rdiv) * scale_cols + (col_group[c] if col_group is not None else c // cdiv)
@@ -185,12 +205,8 @@ class QuantLayout:
             self.scale_cols = scols
             if scols * group_size < cols and scols != math.ceil(cols / group_size):
                 raise ValueError(f"scale of shape {tuple(scale.shape)} does not cover {cols} columns with groups of {group_size}")
-            if g_idx is not None and g_idx.device.type != "meta" and not bool((g_idx == -1).any()):
-                # activation ordering (forward_helpers.py:147-175): column c uses the group of
-                # its position in the g_idx-sorted order
-                perm = torch.argsort(g_idx)
-                inv = torch.argsort(perm)
-                self.col_group = (inv // group_size).to(torch.int32)
+            if g_idx is not None and g_idx.device.type != "meta":
+                self.col_group = _col_group_of(g_idx, group_size)
         elif st == "block":
             if len(x_shape) != 2:
                 raise NotImplementedError("block quantization expects a 2-D weight")

@@ -39,6 +39,11 @@ def main():
     write.update(parse(f"{src}/headline_write.txt", "WRITE_SIZE"))
     res = {"_source": f"{src}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py",
            "_formula": "bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950 read under-count) + WRITE_SIZE * 1024"}
+    try:
+        res["_srchash"] = open(f"{src}/srchash").read().strip()  # the library the counters were collected on (bench.py flags a mismatch as stale)
+    except OSError:
+        pass
+    res["_tag"] = src.rstrip("/").split("/")[-1]
     for k in sorted(set(fetch) & set(write)):
         b = int(2 * fetch[k] * 1024 + write[k] * 1024)
         res[ALIAS.get(k, k.replace("ct::", ""))] = b

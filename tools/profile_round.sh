@@ -17,8 +17,10 @@ FULL="python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 run() {  # name, rocprof args..., -- cmd
     local name=$1; shift
     rocprofv3 --kernel-trace "$@" > "$OUT/$name.stdout" 2> /dev/null
-    python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/$name/run_results.db > "$OUT/$name.txt"
+    { echo "# srchash $(cat "$ROOT/compressed_tensors_amd/libct_hip.so.srchash" 2>/dev/null)"; echo "# cmd rocprofv3 --kernel-trace $*";
+      python "$ROOT/tools/prof_summary.py" /tmp/prof_$TAG/$name/run_results.db; } > "$OUT/$name.txt"
 }
+cp "$ROOT/compressed_tensors_amd/libct_hip.so.srchash" "$OUT/srchash" 2>/dev/null
 run headline_trace --stats -d /tmp/prof_$TAG/headline_trace -o run -- $HEAD
 run headline_fetch --pmc FETCH_SIZE -d /tmp/prof_$TAG/headline_fetch -o run -- $HEAD
 run headline_write --pmc WRITE_SIZE -d /tmp/prof_$TAG/headline_write -o run -- $HEAD
