@@ -532,7 +532,7 @@ def bitmask_leg(dev):
     try:
         O = _oracle()
         for it in items:
-            it["w"].mul_(codec.sparse24_mask(it["w"]).to(torch.bfloat16))  # 2:4-pruned in place (zeros stay zeros)
+            it["w"].masked_fill_(~codec.sparse24_mask(it["w"]), 0)  # 2:4-pruned in place (+0.0 for the dropped elements)
             it["v24"] = torch.empty(N, N // 2, dtype=torch.bfloat16, device=dev)
 
         def c24(i):

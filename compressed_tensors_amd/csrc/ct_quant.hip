@@ -402,6 +402,155 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32
     }
 }
 
+// ---- activation ordering, round 3: R rows per workgroup.  What round 2's kernel above actually paid for (bench leg `bf16_8192_actorder`,
+// HBM-cold: 43 / 45 us for a 29 us job) was not the gathers: (1) every workgroup first fetched its row's scales, waited, filled the LDS
+// table, hit a barrier and only THEN issued its data loads — two dependent HBM latencies per 512 units of work; (2) the group table is
+// int32: 32 bytes of table per 4-byte packed word / 16-byte weight unit, re-fetched from the L2 for every row (268 MB of L2 reads for
+// a 168 MB job); (3) the compress side stored 4 bytes per lane.  Here a lane keeps the group numbers of ITS columns in registers (as
+// 16-bit LDS byte offsets, two per register) and reuses them for R rows; all R rows' data loads are issued before anything is
+// waited for; the R rows' scale entries go to LDS in one pass (one barrier per workgroup); the compress side gives a lane 4
+// consecutive units = one 16-byte `nt` store.  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
+// beside it in one 8-byte entry when the scheme has one — ONE ds_read per element.
+constexpr int kGidxRows = 4;
+template <int DT, bool HAS_ZP, bool COMPRESS>
+__global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const int32_t* __restrict__ col_group, int chunks_per_row, int64_t rows) {
+    constexpr int R = kGidxRows;
+    constexpr int UL = COMPRESS ? 4 : 2;                  // units per lane
+    constexpr int ESZ = HAS_ZP ? 8 : 4;                   // bytes per LDS entry
+    constexpr int kRowBytes = kGidxMaxGroups * ESZ;       // compile-time row stride: the row index is an instruction offset
+    __shared__ __attribute__((aligned(16))) unsigned char s_tab[R * kRowBytes];
+    __shared__ float s_slow[COMPRESS ? R * kGidxMaxGroups : 1];  // the scales themselves, read only by lanes that must divide
+    const int64_t rb = blockIdx.x / (unsigned)chunks_per_row;
+    const int chunk = (int)(blockIdx.x - (unsigned)rb * (unsigned)chunks_per_row);
+    const int64_t row0 = rb * R;
+    // this lane's units: compress 4 consecutive ones, decompress 2 one block apart (16-byte stores, 1 KiB per wave instruction)
+    int64_t cu[UL];
+    bool live[UL];
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+        cu[i] = COMPRESS ? ((int64_t)chunk * kBlock + threadIdx.x) * 4 + i : (int64_t)chunk * (2 * kBlock) + (int64_t)i * kBlock + threadIdx.x;
+        live[i] = cu[i] < p.upr;
+    }
+    // 1. group numbers of this lane's columns (the same for every row)
+    u32x4 gv[UL][2];
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+        if (live[i]) {
+            gv[i][0] = reinterpret_cast<const u32x4*>(col_group)[2 * cu[i]];
+            gv[i][1] = reinterpret_cast<const u32x4*>(col_group)[2 * cu[i] + 1];
+        } else {
+            gv[i][0] = gv[i][1] = u32x4{0, 0, 0, 0};
+        }
+    }
+    // 2. every row's data loads, before anything is waited for
+    u32x4 wv[COMPRESS ? R : 1][COMPRESS ? UL : 1];
+    uint32_t pw[COMPRESS ? 1 : R][COMPRESS ? 1 : UL];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+#pragma unroll
+        for (int i = 0; i < UL; ++i) {
+            if (row < rows && live[i]) {
+                if constexpr (COMPRESS) wv[r][i] = static_cast<const u32x4*>(p.x)[row * p.upr + cu[i]];
+                else pw[r][i] = static_cast<const uint32_t*>(p.x)[row * p.upr + cu[i]];
+            }
+        }
+    }
+    // 3. the R rows' entries -> LDS
+    for (int e = threadIdx.x; e < R * (int)p.scale_cols; e += kBlock) {
+        const int r = e / (int)p.scale_cols, g = e - r * (int)p.scale_cols;
+        if (row0 + r < rows) {
+            const int64_t si = (row0 + r) * p.scale_cols + g;
+            const float s = load_as_f<DT>(p.scale, si);
+            const float v = COMPRESS ? (DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s)) : s;
+            if constexpr (HAS_ZP) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, round_to<DT>(load_rt(p.zp, p.zdt, si))};
+            } else {
+                *reinterpret_cast<float*>(s_tab + r * kRowBytes + g * 4) = v;
+            }
+            if constexpr (COMPRESS) s_slow[r * kGidxMaxGroups + g] = s;
+        }
+    }
+    // LDS byte offsets of the groups, two per register
+    uint32_t go[UL][4];
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+        const uint32_t gs[8] = {gv[i][0].x, gv[i][0].y, gv[i][0].z, gv[i][0].w, gv[i][1].x, gv[i][1].y, gv[i][1].z, gv[i][1].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) go[i][j] = (gs[2 * j] * ESZ) | ((gs[2 * j + 1] * ESZ) << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= rows) break;
+        const unsigned char* tab = s_tab + r * kRowBytes;
+        if constexpr (COMPRESS) {
+            uint32_t words[UL];
+#pragma unroll
+            for (int i = 0; i < UL; ++i) {
+                const uint32_t ws[4] = {wv[r][i].x, wv[r][i].y, wv[r][i].z, wv[r][i].w};
+                uint32_t word = 0x88888888u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x0, x1;
+                    unpack2<DT>(ws[j], x0, x1);
+                    const uint32_t oa = go[i][j] & 0xffffu, ob = go[i][j] >> 16;
+                    float ra, rb2, za = 0.0f, zb = 0.0f;
+                    if constexpr (HAS_ZP) {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const f2 ea = *reinterpret_cast<const f2*>(tab + oa), eb = *reinterpret_cast<const f2*>(tab + ob);
+                        ra = ea.x; za = ea.y; rb2 = eb.x; zb = eb.y;
+                    } else {
+                        ra = *reinterpret_cast<const float*>(tab + oa); rb2 = *reinterpret_cast<const float*>(tab + ob);
+                    }
+                    int c0, c1;
+                    if (DT == CT_BF16 && ra != 0.0f && rb2 != 0.0f) {
+                        // both scales inside the proven range: w4_quant_word's arithmetic with one reciprocal per element
+                        float t0 = x0 * ra, t1 = x1 * rb2;
+                        round2<DT>(t0, t1);
+                        if (HAS_ZP) {
+                            t0 += za; t1 += zb;
+                            round2<DT>(t0, t1);
+                        }
+                        c0 = cvt_i32_hw(__builtin_rintf(t0)); c1 = cvt_i32_hw(__builtin_rintf(t1));
+                        c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
+                        c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
+                    } else {
+                        const float sa = s_slow[r * kGidxMaxGroups + oa / ESZ], sb = s_slow[r * kGidxMaxGroups + ob / ESZ];
+                        c0 = cvt_i32_hw(quant_core<DT>(x0, sa, HAS_ZP, za, -8.0f, 7.0f, ra));  // NaN -> code 0
+                        c1 = cvt_i32_hw(quant_core<DT>(x1, sb, HAS_ZP, zb, -8.0f, 7.0f, rb2));
+                    }
+                    word += (uint32_t)c0 << (8 * j);       // codes in [-8, 7] on top of the 0x88888888 bias: no carries
+                    word += (uint32_t)c1 << (8 * j + 4);
+                }
+                words[i] = word;
+            }
+            if (live[0]) stream_store16(static_cast<uint32_t*>(p.out) + row * p.upr + cu[0], u32x4{words[0], words[1], words[2], words[3]});
+        } else {
+#pragma unroll
+            for (int i = 0; i < UL; ++i) {
+                if (!live[i]) continue;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t o = (k & 1) ? (go[i][k >> 1] >> 16) : (go[i][k >> 1] & 0xffffu);
+                    const float q = (float)((int)((pw[r][i] >> (4 * k)) & 15u) - 8);
+                    if constexpr (HAS_ZP) {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const f2 e = *reinterpret_cast<const f2*>(tab + o);
+                        v[k] = dequant_core<DT>(q, true, e.y, e.x);
+                    } else {
+                        v[k] = dequant_core<DT>(q, false, 0.0f, *reinterpret_cast<const float*>(tab + o));
+                    }
+                }
+                store8<DT>(p.out, (row * p.upr + cu[i]) * 8, v);
+            }
+        }
+    }
+}
+
 // ---- fp32 weights (the reference's own unit tests feed them; fp32 checkpoints exist): a lane takes one unit = 8 floats = two 16-byte
 // loads and produces one packed word; two units per lane, a block apart, all four loads issued first.  The any-width kernels
 // (ct_quant_g32.inc) give a lane 32 elements = 128 bytes at a 128-byte lane stride, which is fine for 16-bit weights going through
@@ -1476,6 +1625,15 @@ static bool w4_gidx_ok(int dt, int sdt, int tdt_or_odt, int bits, int64_t rows, 
 }
 template <bool COMPRESS>
 static int launch_w4_gidx(const W4Params& w, int dt, const void* zp, const int32_t* col_group, int64_t rows, ct_stream_t stream, const char* what) {
+    if (!COMPRESS || w.upr % 4 == 0) {  // R rows per workgroup (w4_gidx_rows_kernel); a row of cols % 32 != 0 cannot give a lane 4 whole units
+        const int chunks = (int)cdiv64(w.upr, (COMPRESS ? 4 : 2) * kBlock);
+        dim3 g((unsigned)(cdiv64(rows, kGidxRows) * chunks));
+#define CT_GIDXR(DT, ZP) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows)
+        if (dt == CT_BF16) { if (zp) CT_GIDXR(CT_BF16, true); else CT_GIDXR(CT_BF16, false); }
+        else { if (zp) CT_GIDXR(CT_F16, true); else CT_GIDXR(CT_F16, false); }
+#undef CT_GIDXR
+        return hip_check(hipGetLastError(), what);
+    }
     const int chunks = (int)cdiv64(w.upr, 2 * kBlock);
     dim3 g((unsigned)(rows * chunks));
 #define CT_GIDX(DT, ZP) hipLaunchKernelGGL((w4_gidx_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks)

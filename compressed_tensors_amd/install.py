@@ -170,13 +170,38 @@ def uninstall_from(table: dict, saved: dict) -> None:
     saved.clear()
 
 
-def install():
+_REBOUND = []  # (module, attribute name, original class)
+
+
+def _rebind_names(table: dict, saved: dict) -> None:
+    """callers that reach a codec by NAME instead of through the registry — `from compressed_tensors.compressors import
+    PackedQuantizationCompressor`, as upstream's own tests do (tests/test_compressors/test_pack_quant.py:17-20) — get the HIP
+    subclass too: every attribute of an already-imported `compressed_tensors.*` module that IS an upstream codec class is pointed at
+    its subclass.  (A name imported into some other module before install() keeps the upstream class: that binding is not ours.)"""
+    import sys
+
+    swap = {id(orig): (orig, table[fmt]) for fmt, orig in saved.items()}
+    for mod_name, mod in list(sys.modules.items()):
+        if mod is None or not (mod_name == "compressed_tensors" or mod_name.startswith("compressed_tensors.")):
+            continue
+        for attr, val in list(vars(mod).items()):
+            hit = swap.get(id(val))
+            if hit is not None and isinstance(val, type):
+                setattr(mod, attr, hit[1])
+                _REBOUND.append((mod, attr, hit[0]))
+
+
+def install(rebind_names: bool = True):
+    """registry swap + ImplBackend registration (+ the by-name bindings inside upstream's own modules unless rebind_names=False)"""
     import compressed_tensors  # the upstream package; ImportError if it is not installed
     from compressed_tensors.compressors import BaseCompressor
     from compressed_tensors.registry import registry as up_registry
     from compressed_tensors.utils.impl_backend import ImplBackend
 
-    install_into(up_registry._REGISTRY[BaseCompressor], ImplBackend, _SAVED)
+    table = up_registry._REGISTRY[BaseCompressor]
+    install_into(table, ImplBackend, _SAVED)
+    if rebind_names and not _REBOUND:
+        _rebind_names(table, _SAVED)
     return compressed_tensors
 
 
@@ -199,4 +224,7 @@ def uninstall():
     from compressed_tensors.compressors import BaseCompressor
     from compressed_tensors.registry import registry as up_registry
 
+    for mod, attr, orig in _REBOUND:
+        setattr(mod, attr, orig)
+    _REBOUND.clear()
     uninstall_from(up_registry._REGISTRY[BaseCompressor], _SAVED)

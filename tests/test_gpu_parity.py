@@ -213,7 +213,8 @@ def test_quant_paths_vs_oracle(cta, dev, xdt, sdt, bits, strategy, gs, shape, sy
 
 @pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("sym", [True, False], ids=["sym", "asym"])
-@pytest.mark.parametrize("shape,gs", [((32, 512), 128), ((96, 4096), 128), ((7, 1032), 8), ((16, 8192 * 2), 16)], ids=["small", "wide", "ragged_chunk", "1024_groups"])
+@pytest.mark.parametrize("shape,gs", [((32, 512), 128), ((96, 4096), 128), ((7, 1032), 8), ((16, 8192 * 2), 16), ((5, 8288), 32), ((9, 4128), 16)],
+                         ids=["small", "wide", "ragged_chunk", "1024_groups", "second_chunk_tail", "half_chunk_tail"])
 def test_gidx_vs_oracle(cta, dev, dt, sym, shape, gs):
     """activation ordering (weight_g_idx): quantize, the packed words and the decompressed weight against the oracle — the flat W4
     g_idx kernels (a workgroup inside one row, the row's scales in LDS) for 16-bit weights, special values included"""

@@ -96,7 +96,7 @@ def test_reference_forward_tests_accelerator_vs_cpu(tmp_path):
     files = ["tests/test_quantization/lifecycle/test_forward.py"]
     hip = run_reference_tests(files, install=True, report=str(tmp_path / "hip.json"))
     up = run_reference_tests(files, install=False, report=str(tmp_path / "up.json"))
-    _check(hip, up, "forward", ("ct_quantize",), min_passed=100)
+    _check(hip, up, "forward", ("ct_quantize", "ct_quantize_fp8", "ct_quantize_fp4"), min_passed=80)
 
 
 # ----------------------------------------------------------------------------- install()ed GPU outputs == the reference's CPU outputs

@@ -129,3 +129,25 @@ def test_install_covers_the_fp4_codecs(upstream):
     ct_amd.uninstall()
     for f in fmts:
         assert BaseCompressor.get_value_from_registry(f) is before[f]
+
+
+def test_install_rebinds_the_by_name_bindings_and_uninstall_restores_them(upstream):
+    """upstream's own tests import the codec classes by name (test_pack_quant.py:17-20); install() points those names inside
+    upstream's modules at the HIP subclasses, uninstall() puts the originals back"""
+    ct, ct_amd = upstream
+    import compressed_tensors.compressors as pkg
+    import compressed_tensors.compressors.pack_quantized.base as base_mod
+
+    orig = pkg.PackedQuantizationCompressor
+    assert base_mod.PackedQuantizationCompressor is orig
+    ct_amd.install()
+    assert pkg.PackedQuantizationCompressor is not orig and issubclass(pkg.PackedQuantizationCompressor, orig)
+    assert base_mod.PackedQuantizationCompressor is pkg.PackedQuantizationCompressor
+    assert pkg.IntQuantizationCompressor.__name__.endswith("MI355X")
+    ct_amd.uninstall()
+    assert pkg.PackedQuantizationCompressor is orig and base_mod.PackedQuantizationCompressor is orig
+    ct_amd.install(rebind_names=False)
+    assert pkg.PackedQuantizationCompressor is orig
+    from compressed_tensors.compressors import BaseCompressor
+
+    assert BaseCompressor.get_value_from_registry("pack-quantized") is not orig
