@@ -888,7 +888,7 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
     if (m == 0 || k == 0) return CT_OK;
     const int64_t c = cdiv > k ? k : cdiv;
     const unsigned tg = (unsigned)((m / 64) * (k / 256));
-    const bool lean = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8) && std::getenv("CT_MARLIN24_LEGACY") == nullptr;
+    const bool lean = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8);
     if (lean) {
 #define CT_M24_LEAN(X, S)                                                                                                                      \
     hipLaunchKernelGGL((marlin24_fused_w4_lean_kernel<X, S>), dim3(tg), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(w), \

@@ -179,11 +179,11 @@ static int minmax_qparams_impl(const void* x, int xdt, int64_t rows, int64_t col
     const bool subwave = (cdiv % 8 == 0) && (cols % cdiv == 0) && upg >= 1 && upg <= 256 && log2_exact(upg) >= 0 && aligned16(x);
     if (subwave && symmetric && xdt != CT_F32 && upg <= 64) {
         const int64_t units = rows * (cols / 8);
-        static const int umode = []() { const char* e = std::getenv("CT_QP_U"); return e ? std::atoi(e) : 4; }();  // units per lane (experiment knob)
+        // units per lane: 2 / 4 / 8 measured 25.0 / 24.4 / 27.0 us at 8192^2 (round 2): 4
 #define CT_QPA(DT, U) do { const int64_t g = cdiv64(units, (int64_t)kBlock * U); CT_REQUIRE(g < ((int64_t)1 << 31), "tensor too large for one launch"); \
         hipLaunchKernelGGL((qparams_absmax_kernel<DT, U>), dim3((unsigned)g), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), units, (int)upg, bits, scale_out, \
                            zp_out, kind, gscale); } while (0)
-        if (xdt == CT_BF16) { if (umode == 8) CT_QPA(CT_BF16, 8); else if (umode == 2) CT_QPA(CT_BF16, 2); else CT_QPA(CT_BF16, 4); }
+        if (xdt == CT_BF16) CT_QPA(CT_BF16, 4);
         else CT_QPA(CT_F16, 4);
 #undef CT_QPA
         CT_LAUNCH_CHECK("ct_minmax_qparams[absmax]");

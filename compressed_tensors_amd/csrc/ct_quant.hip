@@ -1953,16 +1953,15 @@ int ct_rtn_quant_channel8(const void* x, int xdt, int64_t rows, int64_t cols, in
     if (rows == 0 || cols == 0) return CT_OK;
     const int upr = (int)(cols / 8);
     // measured at 8192^2 (10 rotating sets): workgroup per row 37.6 (fp8) / 40.5 (int8) / 53.4 us (int8 asymmetric: three reductions
-    // through LDS); wave per row 46.2 / 46.2 / 49.9 us.  So: wave per row for asymmetric schemes only (0 never, 2 always).
-    static const int wave_mode = []() { const char* e = std::getenv("CT_RTN8_WAVE"); return e ? std::atoi(e) : 1; }();
-    if ((wave_mode == 2 || (wave_mode == 1 && !symmetric)) && upr <= 64 * 16 && cdiv64(rows, kBlock / 64) < ((int64_t)1 << 31)) {  // rows of up to 8192 elements: one wave per row
+    // through LDS); wave per row 46.2 / 46.2 / 49.9 us.  So: wave per row for asymmetric schemes only.
+    if (!symmetric && upr <= 64 * 16 && cdiv64(rows, kBlock / 64) < ((int64_t)1 << 31)) {  // rows of up to 8192 elements: one wave per row
         const int needw = (upr + 63) / 64;
         const unsigned gw = (unsigned)cdiv64(rows, kBlock / 64);
 #define CT_RW8(DT, MU, F8) hipLaunchKernelGGL((rtn_channel8_wave_kernel<DT, MU, F8>), dim3(gw), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), rows, upr, \
                                               symmetric, static_cast<u32x2*>(out), scale_out, zp_out)
 #define CT_RW8_U(DT, F8) do { if (needw <= 2) CT_RW8(DT, 2, F8); else if (needw <= 4) CT_RW8(DT, 4, F8); else if (needw <= 8) CT_RW8(DT, 8, F8); else CT_RW8(DT, 16, F8); } while (0)
-        if (xdt == CT_BF16) { if (fp8) CT_RW8_U(CT_BF16, true); else CT_RW8_U(CT_BF16, false); }
-        else { if (fp8) CT_RW8_U(CT_F16, true); else CT_RW8_U(CT_F16, false); }
+        if (xdt == CT_BF16) CT_RW8_U(CT_BF16, false);  // asymmetric is INT only (checked above)
+        else CT_RW8_U(CT_F16, false);
 #undef CT_RW8_U
 #undef CT_RW8
         CT_LAUNCH_CHECK("ct_rtn_quant_channel8[wave]");
@@ -1996,9 +1995,8 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         // (a scales-first lean variant of this kernel measured SLOWER: 39-42 us vs 30 us)
         // units per lane re-swept with non-temporal stores: U = 1 / 2 / 4 / 8 -> 33.4 / 29.2 / 33.0 / 30.5 us
         // one scale / zero-point load per 16-lane row when a row never straddles a scale group
-        static const int rowlead_mode = []() { const char* e = std::getenv("CT_W4D_ROWLEAD"); return e ? std::atoi(e) : 1; }();  // 0 off, 1 asymmetric, 2 both
-        const bool row_ok = w.flat_scale && w.upg_shift >= 4 && w.upg_shift < 62 && w.units % 16 == 0 && (!zp || zdt == CT_I8);
-        const bool rowlead = row_ok && (zp ? rowlead_mode >= 1 : rowlead_mode >= 2);
+        // (asymmetric only: on the symmetric kernel the same trick measured 29.5 -> 31.1 us)
+        const bool rowlead = zp && w.flat_scale && w.upg_shift >= 4 && w.upg_shift < 62 && w.units % 16 == 0 && zdt == CT_I8;
 #define CT_W4D(DT, ZP) do { if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, true>), grid, dim3(kBlock), 0, as_stream(stream), w); \
                             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, false>), grid, dim3(kBlock), 0, as_stream(stream), w); } while (0)
         if (sdt == CT_BF16) { if (zp) CT_W4D(CT_BF16, true); else CT_W4D(CT_BF16, false); }

@@ -1087,17 +1087,40 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     int tot[KEEP];  // wave-uniform
     int64_t next_r = (u0 + wt0 * kWT + upr - 1) / upr, next_u = next_r * upr;  // the next row that starts at or after the wave's first unit
     const int64_t first_r = next_r;
+    // ---- pass 1: only what the hand-off needs — the non-zero flags and their count.  The workgroup's count word leaves BEFORE the
+    // ranks / compaction of pass 2 (round 2 published after them: the 3 us publish -> visible hop was serial with ~300 vector
+    // instructions and ~40 LDS operations per wave-tile instead of hidden behind them)
+    uint32_t pks[KEEP];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) {
+        uint32_t pk = 0;
+        if (i < tpw) {  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pk |= nz_mask16_fast(keep[i][q], keepbits) << (8 * q);
+            s_mask[wave][i][lane] = pk;
+        }
+        pks[i] = pk;
+        cnt += __popc(pk);
+    }
+    cnt = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
+    if (lane == 0) s_cnt[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int wg = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) wg += s_cnt[w];
+        op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
+        if (stamps && b < 512) stamps[b * 4 + 1] = wall_clock64();
+    }
+    // ---- pass 2, while the word travels: ranks, row offsets, compaction through the wave's slab, read back in place
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         tot[i] = 0;
         if (i >= tpw) continue;  // wave-uniform
-        uint32_t mm[4], rank[4], pk = 0;
+        uint32_t mm[4], rank[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            mm[q] = nz_mask16_fast(keep[i][q], keepbits);
-            pk |= mm[q] << (8 * q);
-        }
-        s_mask[wave][i][lane] = pk;
+        for (int q = 0; q < 4; ++q) mm[q] = (pks[i] >> (8 * q)) & 0xffu;
         tot[i] = tile_ranks(mm, rank);
         {   // rows that start inside this wave-tile: their offset relative to the tile, completed in phase B
             const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
@@ -1111,18 +1134,6 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
         compact_into_slab(keep[i], mm, rank, 0, slab_a, dump_a, lut_a);
 #pragma unroll
         for (int q = 0; q < 4; ++q) keep[i][q] = slab_v[q * 64 + lane];  // vector q * 64 + lane of the compacted tile (garbage past tot)
-    }
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < KEEP; ++i) cnt += tot[i];
-    if (lane == 0) s_cnt[wave] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        int wg = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) wg += s_cnt[w];
-        op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
-        if (stamps && b < 512) stamps[b * 4 + 1] = wall_clock64();
     }
     // ---- the bitmask leaves while the counts travel: output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the
     // packed masks of lanes 4 (L & 15) .. + 3
@@ -1551,6 +1562,10 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
             // unique per launch in this process (random start: words left in recycled device memory by another process carry no
             // matching tag either)
             const uint32_t gen0 = generation.fetch_add((uint32_t)nchunks) + 1u;
+            // the tag of chunk k: top bit always set and never all ones, so that neither zero-filled nor 0xff-filled fresh memory can
+            // look like a published word; a recycled word that happens to carry the current tag (2^-31 per word) is the
+            // residual risk of not clearing the 64 KB of slots before every launch
+            auto tag_of = [](uint32_t c) { return 0x80000000u | (c % 0x7ffffffeu); };
             unsigned long long* slots = static_cast<unsigned long long*>(workspace);
             unsigned long long* ctl = slots + kResMaxWGs;  // [2] / [3] running totals (alternating between chunks)
             unsigned long long* stamps = resident_mode == 3 ? ctl + 4 : nullptr;
@@ -1570,7 +1585,7 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),
                                    static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, cols / 8, rows, (int)tpw, static_cast<uint16_t*>(values),
                                    values_capacity, bitmask + u0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots,
-                                   run_out, gen0 + (uint32_t)k, wait_ticks, k == 0 ? stamps : nullptr);
+                                   run_out, tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr);
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
         }
@@ -1580,18 +1595,11 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
         int64_t* block_tot = static_cast<int64_t*>(workspace);
         int32_t* span_tot = reinterpret_cast<int32_t*>(block_tot + p.nblocks);
         const int mask_dwords = (p.units % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0);
-        // Optionally walk the tensor in chunks (count chunk k, scatter chunk k, ...) so that the scatter's re-read of x is served
-        // by a cache instead of HBM; chunk k+1 starts from the running total chunk k left in `total`.  CT_BITMASK_CHUNK_MB
-        // (experiment knob; default: one chunk).  Every chunk is a whole number of blocks of the one-chunk plan, so the
-        // workspace layout and the per-span bookkeeping are unchanged.
-        static const int64_t chunk_mb = []() { const char* e = std::getenv("CT_BITMASK_CHUNK_MB"); return e ? (int64_t)std::atoll(e) : (int64_t)0; }();
+        // One chunk.  (Walking the tensor in cache-sized chunks — count chunk k, scatter chunk k, ... — so that the scatter's re-read
+        // of x hits a cache was measured in round 2: 64 / 32 / 16 / 8 MB chunks -> 80 / 102 / 155 / 280 us against 66; the loop below
+        // still carries a running total from chunk to chunk, and is exercised with one chunk.)
         const int64_t units_per_block = (int64_t)4 * p.span * kWT;
-        int64_t blocks_per_chunk = p.nblocks;
-        if (chunk_mb > 0) {
-            blocks_per_chunk = (chunk_mb << 20) / (units_per_block * 16);
-            if (blocks_per_chunk < cdiv64(p.nblocks, kMaxChunks)) blocks_per_chunk = cdiv64(p.nblocks, kMaxChunks);
-            if (blocks_per_chunk < 1) blocks_per_chunk = 1;
-        }
+        const int64_t blocks_per_chunk = p.nblocks;
         // running totals: chunk k leaves its end in chunk_tot[k] (its own word: the next chunk's waves read it while nothing writes
         // it), the last chunk in `total`
         int64_t* chunk_tot = reinterpret_cast<int64_t*>(span_tot + 4 * p.nblocks);
@@ -1659,8 +1667,7 @@ int ct_sparse24_compress(const void* x, int dt, int64_t rows, int64_t cols, void
     const int64_t units = rows * (cols / 8);
     CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
     const int vec = aligned16(x);
-    static const int pair_mode = []() { const char* e = std::getenv("CT_SPARSE24_PAIRS"); return e ? std::atoi(e) : 1; }();
-    if (pair_mode && vec && (es == 1 || es == 2) && units % 2 == 0 && (reinterpret_cast<uintptr_t>(bitmask) & 1u) == 0 && units / 2 < ((int64_t)1 << 38)) {
+    if (vec && (es == 1 || es == 2) && units % 2 == 0 && (reinterpret_cast<uintptr_t>(bitmask) & 1u) == 0 && units / 2 < ((int64_t)1 << 38)) {
         const int64_t pairs = units / 2;
         dim3 g((unsigned)cdiv64(pairs, kBlock));
         if (es == 2) hipLaunchKernelGGL((sparse24_pair_kernel<2>), g, dim3(kBlock), 0, as_stream(stream), x, float_kind(dt), pairs, values, bitmask);

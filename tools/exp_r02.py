@@ -14,10 +14,10 @@ if what == "w4d":
         r = B.w4_kernel_point(dev, **kw)
         out[key] = (r["compress_us"], r["decompress_us"], r["round_trip_equals_fake_quantize"])
         torch.cuda.empty_cache()
-    print(json.dumps({"rowlead": os.environ.get("CT_W4D_ROWLEAD"), **out}))
+    print(json.dumps({**out}))
 elif what == "bitmask":
     r = B.bitmask_leg(dev)
-    print(json.dumps({"chunk_mb": os.environ.get("CT_BITMASK_CHUNK_MB"), "compress_us": r["compress_us"], "decompress_us": r["decompress_us"], "ok": r["round_trip_bit_exact"]}))
+    print(json.dumps({"chunk_mb": os.environ.get(""), "compress_us": r["compress_us"], "decompress_us": r["decompress_us"], "ok": r["round_trip_bit_exact"]}))
 elif what == "rtn8":
     from compressed_tensors_amd import _lib
     lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
@@ -30,10 +30,10 @@ elif what == "rtn8":
     for name, fp8, sym in (("fp8", 1, 1), ("int8_sym", 0, 1), ("int8_asym", 0, 0)):
         f = lambda i: lib.ct_rtn_quant_channel8(ws[i % nsets].data_ptr(), _lib.BF16, N, N, fp8, sym, q8[i % nsets].data_ptr(), sc.data_ptr(), zp.data_ptr(), stream)
         out[name] = round(B.time_kernel(f, 40), 2)
-    print(json.dumps({"wave": os.environ.get("CT_RTN8_WAVE"), **out}))
+    print(json.dumps({**out}))
 elif what == "qp":
     r = B.qparams_leg(dev)
-    print(json.dumps({"U": os.environ.get("CT_QP_U"), "us": r["us"], "fused_us": r["fused_with_compress"]["us"]}))
+    print(json.dumps({"us": r["us"], "fused_us": r["fused_with_compress"]["us"]}))
 elif what == "bm2":
     r = B.bitmask_leg(dev)
     print(json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("CT_BITMASK")}, "compress_us": r["compress_us"], "ok": r["round_trip_bit_exact"]}))
