@@ -412,10 +412,10 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32
 // consecutive units = one 16-byte `nt` store.  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
 // beside it in one 8-byte entry when the scheme has one — ONE ds_read per element.
 constexpr int kGidxRows = 4;
-template <int DT, bool HAS_ZP, bool COMPRESS>
+constexpr int kGidxCompressUnits = 4;  // consecutive units per lane on the compress side (one 16-byte store)
+template <int DT, bool HAS_ZP, bool COMPRESS, int R = kGidxRows, int UL = (COMPRESS ? kGidxCompressUnits : 2)>
 __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const int32_t* __restrict__ col_group, int chunks_per_row, int64_t rows) {
-    constexpr int R = kGidxRows;
-    constexpr int UL = COMPRESS ? 4 : 2;                  // units per lane
+    static_assert(!COMPRESS || UL == 1 || UL == 2 || UL == 4, "the compress side stores UL consecutive words per lane");
     constexpr int ESZ = HAS_ZP ? 8 : 4;                   // bytes per LDS entry
     constexpr int kRowBytes = kGidxMaxGroups * ESZ;       // compile-time row stride: the row index is an instruction offset
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[R * kRowBytes];
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
     bool live[UL];
 #pragma unroll
     for (int i = 0; i < UL; ++i) {
-        cu[i] = COMPRESS ? ((int64_t)chunk * kBlock + threadIdx.x) * 4 + i : (int64_t)chunk * (2 * kBlock) + (int64_t)i * kBlock + threadIdx.x;
+        cu[i] = COMPRESS ? ((int64_t)chunk * kBlock + threadIdx.x) * UL + i : (int64_t)chunk * (UL * kBlock) + (int64_t)i * kBlock + threadIdx.x;
         live[i] = cu[i] < p.upr;
     }
     // 1. group numbers of this lane's columns (the same for every row)
@@ -527,7 +527,12 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
                 }
                 words[i] = word;
             }
-            if (live[0]) stream_store16(static_cast<uint32_t*>(p.out) + row * p.upr + cu[0], u32x4{words[0], words[1], words[2], words[3]});
+            if (live[0]) {
+                uint32_t* dst = static_cast<uint32_t*>(p.out) + row * p.upr + cu[0];
+                if constexpr (UL == 4) stream_store16(dst, u32x4{words[0], words[1], words[2], words[3]});
+                else if constexpr (UL == 2) stream_store8(dst, u32x2{words[0], words[1]});
+                else __builtin_nontemporal_store(words[0], dst);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < UL; ++i) {
@@ -1625,8 +1630,8 @@ static bool w4_gidx_ok(int dt, int sdt, int tdt_or_odt, int bits, int64_t rows, 
 }
 template <bool COMPRESS>
 static int launch_w4_gidx(const W4Params& w, int dt, const void* zp, const int32_t* col_group, int64_t rows, ct_stream_t stream, const char* what) {
-    if (!COMPRESS || w.upr % 4 == 0) {  // R rows per workgroup (w4_gidx_rows_kernel); a row of cols % 32 != 0 cannot give a lane 4 whole units
-        const int chunks = (int)cdiv64(w.upr, (COMPRESS ? 4 : 2) * kBlock);
+    if (!COMPRESS || w.upr % kGidxCompressUnits == 0) {  // R rows per workgroup (w4_gidx_rows_kernel); a lane needs whole units
+        const int chunks = (int)cdiv64(w.upr, (COMPRESS ? kGidxCompressUnits : 2) * kBlock);
         dim3 g((unsigned)(cdiv64(rows, kGidxRows) * chunks));
 #define CT_GIDXR(DT, ZP) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows)
         if (dt == CT_BF16) { if (zp) CT_GIDXR(CT_BF16, true); else CT_GIDXR(CT_BF16, false); }
