@@ -408,12 +408,16 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32
 // int32: 32 bytes of table per 4-byte packed word / 16-byte weight unit, re-fetched from the L2 for every row (268 MB of L2 reads for
 // a 168 MB job); (3) the compress side stored 4 bytes per lane.  Here a lane keeps the group numbers of ITS columns in registers (as
 // 16-bit LDS byte offsets, two per register) and reuses them for R rows; all R rows' data loads are issued before anything is
-// waited for; the R rows' scale entries go to LDS in one pass (one barrier per workgroup); the compress side gives a lane 4
-// consecutive units = one 16-byte `nt` store.  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
+// waited for; the R rows' scale entries go to LDS in one pass (one barrier per workgroup); the compress side gives a lane 2
+// consecutive units = one 8-byte `nt` store (4 units / 16 bytes needs 140 VGPRs and measured 41.5 us against 32.9).  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
 // beside it in one 8-byte entry when the scheme has one — ONE ds_read per element.
 constexpr int kGidxRows = 4;
-constexpr int kGidxCompressUnits = 4;  // consecutive units per lane on the compress side (one 16-byte store)
-template <int DT, bool HAS_ZP, bool COMPRESS, int R = kGidxRows, int UL = (COMPRESS ? kGidxCompressUnits : 2)>
+// rows per workgroup R and units per lane UL, measured at 8192^2 bf16 on the product's own template (tools/kbench/kbench_prod.hip `gidx`,
+// profiles/r03_kbench_prod.txt).  compress (R, UL): (4, 4) 41.5 us — 140 VGPRs, 3 waves per SIMD — (4, 2) 32.9, (4, 1) 34.4, (2, 2) 35.2,
+// (8, 2) 48.4, (1, 4) 63.2; decompress: (4, 1) 31.0, (8, 1) 31.3, (8, 2) 31.8, (4, 2) 32.9, (2, 2) 34.4, (4, 4) 34.3.
+constexpr int kGidxCompressUnits = 2;    // consecutive units per lane on the compress side (one 8-byte store)
+constexpr int kGidxDecompressUnits = 1;  // units per lane, one block apart, on the decompress side (16-byte stores)
+template <int DT, bool HAS_ZP, bool COMPRESS, int R = kGidxRows, int UL = (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits)>
 __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const int32_t* __restrict__ col_group, int chunks_per_row, int64_t rows) {
     static_assert(!COMPRESS || UL == 1 || UL == 2 || UL == 4, "the compress side stores UL consecutive words per lane");
     constexpr int ESZ = HAS_ZP ? 8 : 4;                   // bytes per LDS entry
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
     const int64_t rb = blockIdx.x / (unsigned)chunks_per_row;
     const int chunk = (int)(blockIdx.x - (unsigned)rb * (unsigned)chunks_per_row);
     const int64_t row0 = rb * R;
-    // this lane's units: compress 4 consecutive ones, decompress 2 one block apart (16-byte stores, 1 KiB per wave instruction)
+    // this lane's units: compress UL consecutive ones, decompress UL one block apart (16-byte stores, 1 KiB per wave instruction)
     int64_t cu[UL];
     bool live[UL];
 #pragma unroll
@@ -1621,6 +1625,25 @@ static unsigned w4_grid(int64_t items, int unroll) {
     return (unsigned)g;
 }
 
+// units per lane on the decompress side (4- or 8-byte loads, 16-byte stores, one block apart).  2 is the optimum for tensors of many
+// residency rounds (8192^2: U = 1 / 2 / 4 / 8 -> 33.3 / 28.9 / 33.9 / 31.0 us), but a tensor that FITS one residency round of the chip —
+// 256 CUs x 8 workgroups of 256 lanes — should be launched as one: at 4096^2 U = 2 / 4 / 8 -> 9.4 / 8.6 / 8.6 us for W4 and
+// 10.7 / 9.6 / 9.7 us for int8, at 2048 x 5632 7.0 / 6.7 / 6.7 us, at 8192 x 4096 16.1 / 17.3 / 16.0 us (a second, partial round is what
+// costs: U = 4 there is 4096 workgroups).  tools/kbench/kbench_prod.hip `small`, profiles/r03_kbench_prod.txt.
+static int decomp_unroll(int64_t units) {
+    const int64_t round_lanes = (int64_t)kCUs * 8 * kBlock;
+    if (units <= 2 * round_lanes) return 2;
+    if (units <= 4 * round_lanes) return 4;
+    if (units <= 8 * round_lanes) return 8;
+    return 2;
+}
+#define CT_FOR_UNROLL(u, ...)                                   \
+    do {                                                        \
+        if ((u) == 8) { constexpr int U = 8; __VA_ARGS__; }      \
+        else if ((u) == 4) { constexpr int U = 4; __VA_ARGS__; } \
+        else { constexpr int U = 2; __VA_ARGS__; }               \
+    } while (0)
+
 // activation-ordered W4 (w4_gidx_kernel): one dtype for weight / scale / result, row-wise scales, group table aligned
 static bool w4_gidx_ok(int dt, int sdt, int tdt_or_odt, int bits, int64_t rows, int64_t cols, int64_t rdiv, int64_t scale_cols,
                        const int32_t* col_group, const void* a, const void* b) {
@@ -1631,7 +1654,7 @@ static bool w4_gidx_ok(int dt, int sdt, int tdt_or_odt, int bits, int64_t rows, 
 template <bool COMPRESS>
 static int launch_w4_gidx(const W4Params& w, int dt, const void* zp, const int32_t* col_group, int64_t rows, ct_stream_t stream, const char* what) {
     if (!COMPRESS || w.upr % kGidxCompressUnits == 0) {  // R rows per workgroup (w4_gidx_rows_kernel); a lane needs whole units
-        const int chunks = (int)cdiv64(w.upr, (COMPRESS ? kGidxCompressUnits : 2) * kBlock);
+        const int chunks = (int)cdiv64(w.upr, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits) * kBlock);
         dim3 g((unsigned)(cdiv64(rows, kGidxRows) * chunks));
 #define CT_GIDXR(DT, ZP) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows)
         if (dt == CT_BF16) { if (zp) CT_GIDXR(CT_BF16, true); else CT_GIDXR(CT_BF16, false); }
@@ -1834,10 +1857,10 @@ static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, 
     if (!gscale && (qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        constexpr int U = 2;
-        dim3 g8(w4_grid(w.units, U));
-#define CT_Q8D(DT, ZP) do { if (qdt == CT_F8E4M3) hipLaunchKernelGGL((f8_dequant_kernel<DT, U, ZP>), g8, dim3(kBlock), 0, as_stream(stream), w); \
-                            else hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 0>), g8, dim3(kBlock), 0, as_stream(stream), w); } while (0)
+        const int unroll = decomp_unroll(w.units);
+        dim3 g8(w4_grid(w.units, unroll));
+#define CT_Q8D(DT, ZP) CT_FOR_UNROLL(unroll, if (qdt == CT_F8E4M3) hipLaunchKernelGGL((f8_dequant_kernel<DT, U, ZP>), g8, dim3(kBlock), 0, as_stream(stream), w); \
+                                             else hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 0>), g8, dim3(kBlock), 0, as_stream(stream), w))
         if (sdt == CT_BF16) { if (zp) CT_Q8D(CT_BF16, true); else CT_Q8D(CT_BF16, false); }
         else { if (zp) CT_Q8D(CT_F16, true); else CT_Q8D(CT_F16, false); }
 #undef CT_Q8D
@@ -1995,15 +2018,15 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
     if (words == cols / 8 && w4_eligible(sdt, sdt, odt, bits, rows, cols, rdiv, cdiv, col_group, packed, out) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        constexpr int U = 2;
-        dim3 grid(w4_grid(w.units, U));
+        const int unroll = decomp_unroll(w.units);
+        dim3 grid(w4_grid(w.units, unroll));
         // (a scales-first lean variant of this kernel measured SLOWER: 39-42 us vs 30 us)
-        // units per lane re-swept with non-temporal stores: U = 1 / 2 / 4 / 8 -> 33.4 / 29.2 / 33.0 / 30.5 us
+        // units per lane: decomp_unroll()
         // one scale / zero-point load per 16-lane row when a row never straddles a scale group
         // (asymmetric only: on the symmetric kernel the same trick measured 29.5 -> 31.1 us)
         const bool rowlead = zp && w.flat_scale && w.upg_shift >= 4 && w.upg_shift < 62 && w.units % 16 == 0 && zdt == CT_I8;
-#define CT_W4D(DT, ZP) do { if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, true>), grid, dim3(kBlock), 0, as_stream(stream), w); \
-                            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, false>), grid, dim3(kBlock), 0, as_stream(stream), w); } while (0)
+#define CT_W4D(DT, ZP) CT_FOR_UNROLL(unroll, if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, true>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                                             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, false>), grid, dim3(kBlock), 0, as_stream(stream), w))
         if (sdt == CT_BF16) { if (zp) CT_W4D(CT_BF16, true); else CT_W4D(CT_BF16, false); }
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D
@@ -2028,9 +2051,9 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
     if (bits == 8 && words == cols / 4 && cols % 32 == 0 && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(packed) & 7u) == 0) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        constexpr int U = 2;
-        dim3 g8(w4_grid(w.units, U));
-#define CT_Q8U(DT, ZP) hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 128>), g8, dim3(kBlock), 0, as_stream(stream), w)
+        const int unroll = decomp_unroll(w.units);
+        dim3 g8(w4_grid(w.units, unroll));
+#define CT_Q8U(DT, ZP) CT_FOR_UNROLL(unroll, hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 128>), g8, dim3(kBlock), 0, as_stream(stream), w))
         if (sdt == CT_BF16) { if (zp) CT_Q8U(CT_BF16, true); else CT_Q8U(CT_BF16, false); }
         else { if (zp) CT_Q8U(CT_F16, true); else CT_Q8U(CT_F16, false); }
 #undef CT_Q8U

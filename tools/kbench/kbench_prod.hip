@@ -13,7 +13,7 @@
 #include <vector>
 
 using namespace ct;
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+#define CK(x) do { hipError_t ck_err_ = (x); if (ck_err_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(ck_err_), __FILE__, __LINE__); exit(1);} } while (0)
 
 __global__ void fill_bf16(uint16_t* p, int64_t n, uint32_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -30,6 +30,9 @@ __global__ void fill_u32(uint32_t* p, int64_t n, uint32_t seed) {
 
 static double timed(const std::function<void(int)>& fn, int iters) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    fn(0);
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
     for (int i = 0; i < 600; ++i) fn(i);
     CK(hipDeviceSynchronize());
     std::vector<double> per;
@@ -67,6 +70,7 @@ struct Sets {
             if (with_q8) { int8_t* q; CK(hipMalloc(&q, e)); hipLaunchKernelGGL(fill_u32, dim3(4096), dim3(256), 0, 0, (uint32_t*)q, e / 4, 31u * i); q8.push_back(q); }
         }
         CK(hipDeviceSynchronize());
+        printf("# sets ready: %lldx%lld x %d\n", (long long)r, (long long)c, n); fflush(stdout);
     }
     ~Sets() { for (auto p : w) hipFree(p); for (auto p : pk) hipFree(p); for (auto p : out) hipFree(p); for (auto p : q8) hipFree(p); hipFree(scale); hipFree(zp); }
 };
@@ -78,6 +82,7 @@ static void gidx_compress(Sets& S, const int32_t* cg, bool zp) {
     if (upr % UL) return;
     const int chunks = (int)cdiv64(upr, (int64_t)UL * kBlock);
     dim3 g((unsigned)(cdiv64(S.rows, R) * chunks));
+    printf("# g_idx compress R=%d UL=%d grid %u\n", R, UL, g.x); fflush(stdout);
     const double bytes = (2.0 + 0.5 + 2.0 / 128 + (zp ? 1.0 / 128 : 0)) * S.rows * S.cols;
     double us = timed([&](int i) {
         W4Params w = make_w4(S.w[i % S.n], S.scale, zp ? S.zp : nullptr, CT_I8, S.pk[i % S.n], S.rows, S.cols, 1, S.cols, S.cols / 128);
@@ -163,7 +168,8 @@ int main(int argc, char** argv) {
         gidx_compress<2, 4>(S, d_cg, true); gidx_compress<4, 2>(S, d_cg, true);
         gidx_decompress<4, 2>(S, d_cg, false); gidx_decompress<2, 2>(S, d_cg, false); gidx_decompress<8, 2>(S, d_cg, false);
         gidx_decompress<4, 4>(S, d_cg, false); gidx_decompress<8, 1>(S, d_cg, false); gidx_decompress<4, 1>(S, d_cg, false);
-        gidx_decompress<4, 2>(S, d_cg, true); gidx_decompress<8, 2>(S, d_cg, true);
+        gidx_decompress<4, 2>(S, d_cg, true); gidx_decompress<8, 2>(S, d_cg, true); gidx_decompress<4, 1>(S, d_cg, true);
+        gidx_compress<4, 1>(S, d_cg, true); gidx_compress<3, 2>(S, d_cg, false); gidx_compress<6, 2>(S, d_cg, false);
     }
     if (all || !strcmp(what, "small")) {
         for (auto sh : {std::pair<int64_t, int64_t>{4096, 4096}, {2048, 5632}, {8192, 4096}, {8192, 8192}}) {
