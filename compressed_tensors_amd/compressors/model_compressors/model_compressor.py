@@ -24,7 +24,7 @@ from typing import Optional
 import torch
 
 from ...config import CompressionFormat
-from ...distributed import is_distributed, module_size, rank_and_world, replace_module_parallel
+from ...distributed import dense_numel, is_distributed, module_size, rank_and_world, replace_module_parallel
 from ...quantization.quant_args import QuantizationStatus
 from ...quantization.utils import is_module_quantized
 from ..base import compress_modules, decompress_modules
@@ -74,11 +74,24 @@ class ModelCompressor:
 
     # ------------------------------------------------------------------ compress / decompress
     def _quantized_modules(self, model, skip_compressed=False):
-        return [
-            m for _, m in model.named_modules(remove_duplicate=True)
-            if is_module_quantized(m)
-            and (not skip_compressed or getattr(m, "quantization_status", None) != QuantizationStatus.COMPRESSED)
-        ]
+        return [m for _, m in self._named_quantized_modules(model) if not (skip_compressed and self._is_compressed(m))]
+
+    @staticmethod
+    def _is_compressed(m) -> bool:
+        return getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED
+
+    @staticmethod
+    def _named_quantized_modules(model):
+        """(name, module) of every quantized module, in `named_modules` order: the SAME list on every rank of a replicated model —
+        what replace_module_parallel needs to agree on module identity (the ranks' skip_compressed filters may differ)"""
+        return [(n, m) for n, m in model.named_modules(remove_duplicate=True) if is_module_quantized(m)]
+
+    def _parallel(self, model, apply_many, recouple: bool, skip_compressed: bool):
+        named = self._named_quantized_modules(model)
+        done_fn = self._is_compressed if skip_compressed else None
+        # collective-free mode with a skip filter: the LPT weights must not depend on what a rank has already compressed
+        weight_fn = dense_numel if (skip_compressed and not recouple) else module_size
+        return replace_module_parallel([m for _, m in named], apply_many, weight_fn, recouple=recouple, names=[n for n, _ in named], done_fn=done_fn)
 
     def _finish_compress(self, model, recouple: bool) -> None:
         if not recouple and is_distributed() and rank_and_world()[1] > 1:
@@ -92,10 +105,9 @@ class ModelCompressor:
         `recouple=True` (default, as upstream's replace_module_parallel) the results are then replicated on every
         rank at the price of one RCCL broadcast per owner rank; `recouple=False` is the collective-free
         shard-per-rank mode (see the module docstring).  Returns the modules this rank compressed."""
-        modules = self._quantized_modules(model, skip_compressed)
         fmt = self.force_compression_format
         # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
-        mine = replace_module_parallel(modules, lambda ms: compress_modules(ms, fmt), module_size, recouple=recouple)
+        mine = self._parallel(model, lambda ms: compress_modules(ms, fmt), recouple, skip_compressed)
         self._finish_compress(model, recouple)
         return mine
 
@@ -128,7 +140,7 @@ class ModelCompressor:
                     scheme.format = fmt.value
                 module.quantization_status = QuantizationStatus.COMPRESSED
 
-        mine = replace_module_parallel(self._quantized_modules(model, skip_compressed=True), apply, module_size, recouple=recouple)
+        mine = self._parallel(model, apply, recouple, skip_compressed=True)
         self._finish_compress(model, recouple)
         return mine
 
@@ -143,7 +155,8 @@ class ModelCompressor:
             def apply(ms):
                 decompress_modules([m for m in ms if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
 
-            replace_module_parallel(modules, apply, module_size, recouple=True)
+            named = self._named_quantized_modules(model)
+            replace_module_parallel([m for _, m in named], apply, module_size, recouple=True, names=[n for n, _ in named])
         elif is_distributed():
             decompress_modules([m for m in modules if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
         else:

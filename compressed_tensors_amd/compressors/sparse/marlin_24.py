@@ -41,7 +41,9 @@ _STRUCTURE_ERROR = ("Marlin24 Compressor is only compatible with weights that ha
 
 class _FlagRing:
     """int32 violation flags of the launches issued on one (device, stream): zeroed once, one slot per compress call, read back
-    by `check` (one device reduction + one host read for all slots in use).  Slots are handed out as raw device addresses."""
+    by `check` (ONE device-to-host copy of the slots in use).  Slots are handed out as raw device addresses.  The kernels OR into
+    the slots on `stream`, so the read-back and the re-zeroing run on that same stream whatever the caller's current stream is
+    by then (a nested `torch.cuda.stream(...)` must not let the read race the kernels: ADVICE r02)."""
 
     SLOTS = 1024
 
@@ -50,34 +52,45 @@ class _FlagRing:
         self.base = self.flags.data_ptr()
         self.stream = stream  # _lib.StreamHandle: the raw hipStream_t + its device
         self.used = 0
+        self.labels = []
 
-    def take(self) -> int:
+    def _torch_stream(self):
+        dev = torch.device("cuda", self.stream.device_index)
+        return torch.cuda.default_stream(dev) if int(self.stream) == 0 else torch.cuda.ExternalStream(int(self.stream), device=dev)
+
+    def take(self, label=None) -> int:
         if self.used == self.SLOTS:
             self.check()
         self.used += 1
+        self.labels.append(label)
         return self.base + 4 * (self.used - 1)
 
     def check(self) -> None:
         if not self.used:
             return
-        live = self.flags[:self.used]
-        bad = bool((live if self.used == 1 else live.any()).item())  # one slot: a plain 4-byte read, no reduction kernel
-        live.zero_()
-        self.used = 0
+        with torch.cuda.stream(self._torch_stream()):
+            live = self.flags[:self.used]
+            host = live.cpu()  # stream-ordered after the launches that OR into the slots; blocks until it has landed
+            live.zero_()
+        labels, self.labels, self.used = self.labels, [], 0
+        bad = [i for i, v in enumerate(host.tolist()) if v]
         if bad:
-            raise ValueError(_STRUCTURE_ERROR)
+            named = [str(labels[i]) for i in bad if labels[i] is not None]
+            raise ValueError(_STRUCTURE_ERROR + (f" (offending: {', '.join(named[:8])}{', ...' if len(named) > 8 else ''})" if named else ""))
 
 
-_rings = {}
-_local = threading.local()
+_local = threading.local()  # the rings live in thread-local storage: a thread's rings go away with the thread
 
 
 def _ring(device) -> _FlagRing:
     stream = _lib.stream_of_device(device)
-    key = (stream.device_index, int(stream), threading.get_ident())
-    ring = _rings.get(key)
+    table = getattr(_local, "ring_table", None)
+    if table is None:
+        table = _local.ring_table = {}
+    key = (stream.device_index, int(stream))
+    ring = table.get(key)
     if ring is None:
-        ring = _rings[key] = _FlagRing(device, stream)
+        ring = table[key] = _FlagRing(device, stream)
     return ring
 
 
@@ -119,9 +132,16 @@ class Marlin24Compressor(BaseCompressor):
 
     @classmethod
     def compress_modules(cls, modules) -> None:
+        """one host read for the whole batch.  (Upstream validates before it replaces a module; here every module of the batch
+        is already replaced when the single ValueError is raised — it names the offending modules.)"""
         with cls.deferred_structure_check():
-            for m in modules:
-                cls.compress_module(m)
+            for i, m in enumerate(modules):
+                w = getattr(m, "weight", None)
+                _local.label = f"module #{i} ({type(m).__name__}{'' if w is None else ' ' + 'x'.join(str(d) for d in w.shape)})"
+                try:
+                    cls.compress_module(m)
+                finally:
+                    _local.label = None
 
     @staticmethod
     def validate_quant_compatability(weights) -> bool:
@@ -172,7 +192,7 @@ class Marlin24Compressor(BaseCompressor):
                 # everything in one host call: no int8 intermediate, no separate packing / scale launches
                 ring, deferred = cls._flag(weight.device)
                 packed, meta, scale_packed, _ = codec.marlin24_compress_w4_full(weight, scale2d, zero_point, group_size=g, group_perm=is_group,
-                                                                                flag_ptr=ring.take(), stream=ring.stream)
+                                                                                flag_ptr=ring.take(getattr(_local, "label", None)), stream=ring.stream)
                 state_dict["weight_packed"] = packed
                 state_dict["scale_packed"] = scale_packed
                 state_dict["meta"] = meta

@@ -28,13 +28,20 @@ def _pad(n: int) -> int:
     return (n + _ALIGN - 1) // _ALIGN * _ALIGN
 
 
-def recouple_modules(modules: Sequence[torch.nn.Module], owner: Dict[torch.nn.Module, int], device: Optional[torch.device] = None) -> None:
-    """make every rank hold the direct state dict (and quantization_status) that the OWNER of each module has"""
+def recouple_modules(modules: Sequence[torch.nn.Module], owner: Dict[torch.nn.Module, int], device: Optional[torch.device] = None,
+                     names: Optional[Dict[torch.nn.Module, str]] = None) -> None:
+    """make every rank hold the direct state dict (and quantization_status) that the OWNER of each module has.  The state
+    travels keyed by module NAME (`names`; default: the position in `modules`), never by a list index that the sender and
+    the receiver could disagree on: a name the receiver does not know raises."""
     rank, world = rank_and_world()
     if world == 1:
         return
     modules = list(modules)
-    index = {m: i for i, m in enumerate(modules)}
+    if names is None:
+        names = {m: str(i) for i, m in enumerate(modules)}
+    by_name = {names[m]: m for m in modules}
+    if len(by_name) != len(modules):
+        raise ValueError("recouple_modules: module names must be unique")
     mine = [m for m in modules if owner[m] == rank]
     if device is None:
         device = next((t.device for m in mine for t in get_direct_state_dict(m).values() if t is not None and t.device.type != "cpu"), None)
@@ -55,7 +62,7 @@ def recouple_modules(modules: Sequence[torch.nn.Module], owner: Dict[torch.nn.Mo
                 entries.append((key, tuple(t.shape), t.dtype, t.device.type, offset))
                 chunks.append((offset, t))
                 offset += _pad(nbytes)
-        desc[index[m]] = (entries, getattr(m, "quantization_status", None))
+        desc[names[m]] = (entries, getattr(m, "quantization_status", None))
     gathered = [None] * world
     dist.all_gather_object(gathered, (desc, offset))
 
@@ -73,7 +80,9 @@ def recouple_modules(modules: Sequence[torch.nn.Module], owner: Dict[torch.nn.Mo
             dist.broadcast(flat, src=src)
         if src == rank:
             continue
-        for mi, (entries, status) in src_desc.items():
+        for name, (entries, status) in src_desc.items():
+            if name not in by_name:
+                raise RuntimeError(f"recouple: rank {src} sent the state of module {name!r}, which rank {rank} does not have in its list")
             state = {}
             for key, shape, dtype, where, payload in entries:
                 if shape is None:
@@ -82,38 +91,71 @@ def recouple_modules(modules: Sequence[torch.nn.Module], owner: Dict[torch.nn.Mo
                     state[key] = payload
                 else:
                     n = 1
-                    for s in shape:
-                        n *= s
+                    for s_ in shape:
+                        n *= s_
                     n *= torch.empty(0, dtype=dtype).element_size()
                     view = flat[payload:payload + n].view(dtype).view(shape)  # a view into the received buffer
                     state[key] = view if where != "cpu" or device.type == "cpu" else view.cpu()
-            m = modules[mi]
+            m = by_name[name]
             replace_direct_state_dict(m, {k: v for k, v in state.items() if v is not None})
             if status is not None:
                 m.quantization_status = status
 
 
 def replace_module_parallel(modules: List[torch.nn.Module], apply_many_fn: Callable[[List[torch.nn.Module]], None],
-                            weight_fn: Callable = module_size, recouple: bool = True) -> List[torch.nn.Module]:
+                            weight_fn: Callable = module_size, recouple: bool = True, names: Optional[Sequence[str]] = None,
+                            done_fn: Optional[Callable[[torch.nn.Module], bool]] = None) -> List[torch.nn.Module]:
     """Split `modules` over the ranks (LPT by `weight_fn`), apply `apply_many_fn` to this rank's share (a list, so
     that a codec can batch its launches) and, if `recouple`, replicate the results on every rank.  Returns this
-    rank's share.  Without torch.distributed it simply applies the function to everything."""
+    rank's share.  Without torch.distributed it simply applies the function to everything that is not done.
+
+    `modules` must be the SAME list on every rank (the same model, e.g. every quantized module in `named_modules` order),
+    `names` its module names.  `done_fn(m)` says that THIS rank already holds the result for `m` (`skip_compressed`); the
+    ranks may disagree about it — after a shard-per-rank compress every rank has compressed a different subset.
+
+    recouple=True: the ranks first agree on identity (one `all_gather_object` of names / done flags / sizes — a few KB; a
+    differing name list raises instead of silently pairing one rank's module 3 with another rank's module 5): a module
+    that some rank already holds done is OWNED by the lowest such rank and is not processed again; the rest is LPT-packed
+    with rank 0's sizes; modules every rank holds are not sent at all.
+    recouple=False (collective-free): the bins come from the unfiltered list, so every rank computes the same assignment
+    without talking, and `done_fn` only removes work from a rank's own bin.  When `done_fn` is given the weights must not
+    depend on what a rank has already compressed: pass a `weight_fn` that is invariant under compression (ModelCompressor
+    passes `dense_numel`)."""
     modules = list(modules)
+    done = [bool(done_fn(m)) for m in modules] if done_fn is not None else [False] * len(modules)
     if not is_distributed():
-        apply_many_fn(modules)
-        return modules
+        todo = [m for m, d in zip(modules, done) if not d]
+        apply_many_fn(todo)
+        return todo
     rank, world = rank_and_world()
-    order = list(modules)
-    if recouple and world > 1:
-        # ownership must be identical on every rank even if the replicas have drifted apart (e.g. after a
-        # shard-per-rank compress the byte sizes differ per rank): rank 0's sizes decide.  A few hundred ints.
-        box = [[int(weight_fn(m)) for m in order]]
-        dist.broadcast_object_list(box, src=0)
-        size_of = dict(zip(order, box[0]))
-        weight_fn = size_of.__getitem__
-    _, bins, owner = greedy_bin_packing(order, world, weight_fn)
+    if not recouple or world == 1:
+        skip = {id(m) for m, d in zip(modules, done) if d}
+        _, bins, _ = greedy_bin_packing(list(modules), world, weight_fn)  # (sorts its argument in place)
+        mine = [m for m in bins[rank] if id(m) not in skip]
+        apply_many_fn(mine)
+        return mine
+    names = [str(i) for i in range(len(modules))] if names is None else list(names)
+    if len(names) != len(modules) or len(set(names)) != len(names):
+        raise ValueError("replace_module_parallel: `names` must be unique and match `modules`")
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (names, done, [int(weight_fn(m)) for m in modules]))
+    for r, (other, _, _) in enumerate(gathered):
+        if other != names:
+            raise RuntimeError(f"replace_module_parallel: rank {r} lists different modules than rank {rank} "
+                               f"({len(other)} vs {len(names)} entries); pass the same module list on every rank")
+    size_of = dict(zip(modules, gathered[0][2]))  # rank 0's sizes decide: replicas may have drifted apart
+    owner, todo = {}, []
+    for i, m in enumerate(modules):
+        holders = [r for r in range(world) if gathered[r][1][i]]
+        if holders:
+            owner[m] = holders[0]  # a rank that already holds the result owns it; nobody recomputes it
+        else:
+            todo.append(m)
+    _, bins, packed = greedy_bin_packing(list(todo), world, size_of.__getitem__)
+    owner.update(packed)
     mine = bins[rank]
     apply_many_fn(mine)
-    if recouple:
-        recouple_modules(modules, owner)
+    need = [m for i, m in enumerate(modules) if not all(gathered[r][1][i] for r in range(world))]
+    if need:
+        recouple_modules(need, owner, names={m: names[i] for i, m in enumerate(modules)})
     return mine

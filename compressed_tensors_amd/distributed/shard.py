@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 from .assign import greedy_bin_packing
 
-__all__ = ["init_dist", "is_distributed", "rank_and_world", "module_size", "shard_modules", "shard_rows", "shard_items", "merge_bitmask_row_shards"]
+__all__ = ["init_dist", "is_distributed", "rank_and_world", "module_size", "dense_numel", "shard_modules", "shard_rows", "shard_items", "merge_bitmask_row_shards"]
 
 
 def is_distributed() -> bool:
@@ -52,6 +52,22 @@ def module_size(module: torch.nn.Module) -> int:
         if t is not None:
             total += t.numel() * t.element_size()
     return total
+
+
+def dense_numel(module: torch.nn.Module) -> int:
+    """number of elements of the module's DENSE weight, whether or not it is currently compressed (`weight_shape` of the packed
+    codecs, else the weight / packed tensor's own element count): an LPT weight that every rank computes identically even after
+    the ranks have compressed different subsets of the model"""
+    shape = getattr(module, "weight_shape", None)
+    if shape is not None and shape.numel() >= 1:
+        n = 1
+        for s in shape.tolist():
+            n *= int(s)
+        return n
+    w = getattr(module, "weight", None)
+    if w is not None:
+        return int(w.numel())
+    return module_size(module)
 
 
 def shard_items(items: Sequence, weight_fn: Callable = lambda x: 1, rank: Optional[int] = None,

@@ -239,6 +239,109 @@ def gen_compressors():
     save("compressors", tensors, {"cases": cases})
 
 
+def _sha(t):
+    import hashlib
+
+    return hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+def gen_compressors2():
+    """round 3: the cases the first family lacked — activation ordering GROUP / WEIGHT through the class
+    (tests/test_compressors/test_pack_quant.py:238-277), a 3-D (experts, rows, cols) weight through compress
+    (pack_quantized/helpers.py:45-51), channel-symmetric int4, `block` for naive int8 with padding (naive_quantized/base.py:72-77)."""
+    g = torch.Generator().manual_seed(4242)
+    tensors, cases = {}, []
+    configs = [
+        ("pq_g128_b4_sym_actgroup_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True, actorder="group"), (64, 512), torch.bfloat16, True),
+        ("pq_g128_b4_asym_actgroup_f16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=False, actorder="group"), (32, 512), torch.float16, True),
+        ("pq_g32_b4_sym_actgroup_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=32, symmetric=True, actorder="group"), (40, 256), torch.bfloat16, True),
+        ("pq_g128_b4_sym_actweight_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True, actorder="weight"), (64, 512), torch.bfloat16, True),
+        ("pq_ch_b4_sym_bf16", "pack-quantized", dict(num_bits=4, strategy="channel", symmetric=True), (64, 256), torch.bfloat16, True),
+        ("pq_g128_b4_sym_experts3d_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True), (4, 32, 256), torch.bfloat16, False),
+        ("pq_g64_b8_asym_experts3d_f16", "pack-quantized", dict(num_bits=8, strategy="group", group_size=64, symmetric=False), (3, 16, 128), torch.float16, False),
+        ("nq_block_b8_sym_bf16", "naive-quantized", dict(num_bits=8, strategy="block", block_structure=[128, 128], symmetric=True), (200, 300), torch.bfloat16, True),
+        ("nq_block_b8_asym_f16", "naive-quantized", dict(num_bits=8, strategy="block", block_structure=[64, 32], symmetric=False), (128, 96), torch.float16, True),
+    ]
+    for key, fmt, kw, shape, dt, round_trip in configs:
+        args = QuantizationArgs(**kw)
+        scheme = QuantizationScheme(targets=["Linear"], weights=args)
+        w = torch.randn(shape, generator=g).to(dt)
+        if kw["strategy"] == "block":
+            from compressed_tensors.quantization.utils import maybe_pad_tensor_for_block_quant
+
+            scale, zp = make_qparams(maybe_pad_tensor_for_block_quant(w, tuple(kw["block_structure"])), args)
+        else:
+            scale, zp = make_qparams(w, args)
+        sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+        if kw.get("actorder") == "group":
+            cols = shape[-1]
+            sd["weight_g_idx"] = (torch.randperm(cols, generator=g) // kw["group_size"]).to(torch.int32)
+        comp = BaseCompressor.get_value_from_registry(fmt)
+        c = comp.compress(dict(sd), scheme)
+        d = {}
+        if round_trip:
+            d = comp.decompress(dict(c), scheme)
+            if kw["strategy"] != "block":  # (the padded block grid has no unpadded fake_quantize counterpart)
+                fq = fake_quantize(w, scale, zp, args, g_idx=sd.get("weight_g_idx"))
+                assert torch.equal(fq, d["weight"].to(fq.dtype)), key
+            assert d["weight"].shape == w.shape, key
+        for k, v in sd.items():
+            tensors[f"{key}.in.{k}"] = v
+        for k, v in c.items():
+            tensors[f"{key}.c.{k}"] = v
+        for k, v in d.items():
+            tensors[f"{key}.d.{k}"] = v
+        cases.append({"key": key, "format": fmt, "args": kw, "shape": list(shape), "round_trip": round_trip,
+                      "compressed_keys": sorted(c.keys()), "decompressed_keys": sorted(d.keys())})
+    save("compressors2", tensors, {"cases": cases})
+
+
+def gen_compressors_big():
+    """one 1024 x 4096 case per format / scheme so that the reference-generated vectors reach the flat / lean / rows-per-workgroup
+    kernels the small shapes do not all select.  To keep the fixtures small the weight is regenerated from its seed by the test
+    (and checked against the sha256 recorded here) and the outputs are stored as sha256 digests of their bytes; only the scales /
+    zero points / g_idx — what the reference's calculate_qparams produced — are stored as tensors."""
+    tensors, cases = {}, []
+    configs = [
+        ("big_pq_g128_b4_sym_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True), torch.bfloat16),
+        ("big_pq_g128_b4_asym_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=False), torch.bfloat16),
+        ("big_pq_g128_b4_sym_f16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True), torch.float16),
+        ("big_pq_g128_b4_sym_actgroup_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True, actorder="group"), torch.bfloat16),
+        ("big_pq_g128_b4_asym_actgroup_bf16", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=False, actorder="group"), torch.bfloat16),
+        ("big_pq_ch_b4_sym_bf16", "pack-quantized", dict(num_bits=4, strategy="channel", symmetric=True), torch.bfloat16),
+        ("big_pq_g128_b8_sym_bf16", "pack-quantized", dict(num_bits=8, strategy="group", group_size=128, symmetric=True), torch.bfloat16),
+        ("big_pq_g128_b3_asym_bf16", "pack-quantized", dict(num_bits=3, strategy="group", group_size=128, symmetric=False), torch.bfloat16),
+        ("big_iq_t_b8_sym_bf16", "int-quantized", dict(num_bits=8, strategy="tensor", symmetric=True), torch.bfloat16),
+        ("big_iq_ch_b8_asym_bf16", "int-quantized", dict(num_bits=8, strategy="channel", symmetric=False), torch.bfloat16),
+        ("big_nq_g128_b8_sym_f16", "naive-quantized", dict(num_bits=8, strategy="group", group_size=128, symmetric=True), torch.float16),
+        ("big_pq_g128_b4_sym_f32", "pack-quantized", dict(num_bits=4, strategy="group", group_size=128, symmetric=True), torch.float32),
+    ]
+    shape = (1024, 4096)
+    for i, (key, fmt, kw, dt) in enumerate(configs):
+        seed = 9000 + i
+        args = QuantizationArgs(**kw)
+        act = QuantizationArgs(num_bits=8, strategy="tensor", symmetric=True) if fmt == "int-quantized" else None
+        scheme = QuantizationScheme(targets=["Linear"], weights=args, input_activations=act)
+        w = torch.randn(shape, generator=torch.Generator().manual_seed(seed)).mul_(0.05).to(dt)
+        scale, zp = make_qparams(w, args)
+        sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+        if kw.get("actorder") == "group":
+            sd["weight_g_idx"] = (torch.randperm(shape[1], generator=torch.Generator().manual_seed(seed + 500)) // kw["group_size"]).to(torch.int32)
+        comp = BaseCompressor.get_value_from_registry(fmt)
+        c = comp.compress(dict(sd), scheme)
+        d = comp.decompress(dict(c), scheme)
+        fq = fake_quantize(w, scale, zp, args, g_idx=sd.get("weight_g_idx"))
+        assert torch.equal(fq, d["weight"].to(fq.dtype)), key
+        for k, v in sd.items():
+            if k != "weight":
+                tensors[f"{key}.in.{k}"] = v
+        cases.append({"key": key, "format": fmt, "args": kw, "shape": list(shape), "dtype": str(dt).split(".")[-1], "seed": seed,
+                      "weight_sha256": _sha(w),
+                      "compressed": {k: {"sha256": _sha(v), "shape": list(v.shape), "dtype": str(v.dtype).split(".")[-1]} for k, v in c.items()},
+                      "decompressed": {k: {"sha256": _sha(v), "shape": list(v.shape), "dtype": str(v.dtype).split(".")[-1]} for k, v in d.items()}})
+    save("compressors_big", tensors, {"cases": cases})
+
+
 # ----------------------------------------------------------------------------- sparse primitives
 def gen_sparse():
     g = torch.Generator().manual_seed(2024)
@@ -560,7 +663,8 @@ def gen_qparams_float():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    families = {"pack": gen_pack, "quant": gen_quant, "qparams": gen_qparams, "compressors": gen_compressors, "sparse": gen_sparse,
+    families = {"pack": gen_pack, "quant": gen_quant, "qparams": gen_qparams, "compressors": gen_compressors, "compressors2": gen_compressors2, "compressors_big": gen_compressors_big,
+                "sparse": gen_sparse,
                 "fp4": gen_fp4, "fp8": gen_fp8, "fp4q": gen_fp4q, "qparams_float": gen_qparams_float}
     wanted = sys.argv[1:] or list(families)  # `python oracle/gen_golden.py fp4` regenerates one family only
     mpath = os.path.join(OUT, "manifest.json")

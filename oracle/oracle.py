@@ -131,7 +131,10 @@ def _resolve(x, scale, strategy, group_size, block_structure):
         s2 = scale
         while s2.ndim < 2:
             s2 = s2.unsqueeze(1)
-        rdiv = 1 if s2.shape[0] == rows else max(rows, 1)
+        srows = 1
+        for d in s2.shape[:-1]:  # an N-D weight (experts, rows, cols) carries an N-D scale (experts, rows, groups): rows are flattened
+            srows *= int(d)
+        rdiv = 1 if srows == rows else max(rows, 1)
         return rows, cols, rdiv, group_size, s2.shape[-1], False
     if strategy == "block":
         bh, bw = block_structure

@@ -1,6 +1,8 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle and the reference's golden
 vectors.  Every test here needs an MI355X:  python -m pytest tests -m gpu"""
 import math
+import os
+import re
 
 import pytest
 import torch
@@ -143,6 +145,59 @@ def test_compressor_golden(golden, cta, dev, case):
     for k, v in exp_d.items():
         assert eq(dd[k].cpu().contiguous(), v), k
     assert sorted(comp.compression_param_names(scheme)) == sorted(k for k in case["compressed_keys"])
+
+
+@pytest.mark.parametrize("case", cases("compressors2"), ids=lambda c: c["key"])
+def test_compressor_golden_round3(golden, cta, dev, case):
+    """reference-generated class-level vectors the first family lacked: activation ordering GROUP / WEIGHT
+    (reference test_pack_quant.py:238-277), 3-D expert weights through compress (helpers.py:45-51), channel-symmetric int4,
+    naive int8 `block` with padding (naive_quantized/base.py:72-77)"""
+    t = golden.case("compressors2", case["key"])
+    sd = {k[3:]: d(v, dev) for k, v in t.items() if k.startswith("in.")}
+    exp_c = {k[2:]: v for k, v in t.items() if k.startswith("c.")}
+    exp_d = {k[2:]: v for k, v in t.items() if k.startswith("d.")}
+    scheme = _scheme(cta, case)
+    comp = cta.BaseCompressor.get_value_from_registry(case["format"])
+    c = comp.compress(dict(sd), scheme)
+    assert sorted(c.keys()) == case["compressed_keys"]
+    for k, v in exp_c.items():
+        assert eq(c[k].cpu().contiguous(), v), k
+    if case["round_trip"]:
+        dd = comp.decompress({k: d(v, dev) if k != "weight_shape" else v for k, v in exp_c.items()}, scheme)
+        assert sorted(dd.keys()) == case["decompressed_keys"]
+        for k, v in exp_d.items():
+            assert eq(dd[k].cpu().contiguous(), v), k
+
+
+@pytest.mark.parametrize("case", cases("compressors_big"), ids=lambda c: c["key"])
+def test_compressor_golden_big(golden, cta, dev, case):
+    """1024 x 4096 per format / scheme — the sizes at which the flat / lean / rows-per-workgroup kernels are selected — against
+    sha256 digests of the reference's own outputs (weight regenerated from its seed and checked against the recorded digest)"""
+    from test_oracle_golden import big_case_inputs, digest_matches
+
+    sd = {k: d(v, dev) for k, v in big_case_inputs(golden, case).items()}
+    scheme = _scheme(cta, case)
+    comp = cta.BaseCompressor.get_value_from_registry(case["format"])
+    c = comp.compress(dict(sd), scheme)
+    assert sorted(c.keys()) == sorted(case["compressed"])
+    for k, rec in case["compressed"].items():
+        assert digest_matches(c[k], rec), f"compressed[{k}] differs from the reference"
+    dd = comp.decompress(dict(c), scheme)
+    for k, rec in case["decompressed"].items():
+        assert digest_matches(dd[k], rec), f"decompressed[{k}] differs from the reference"
+
+
+def test_fuzz_parity_bounded():
+    """tools/fuzz_parity.py (every public codec entry point against the oracle on random shapes / dtypes / strategies / special
+    values) with a fixed seed and a bounded number of cases, so that the driver's -m gpu run re-runs it (VERDICT r02 #5)"""
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "90", "20260926", "1500"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    m = re.search(r"fuzz: (\d+) random cases, no mismatch", r.stdout)
+    assert m and int(m.group(1)) >= 400, r.stdout[-500:]
 
 
 # ----------------------------------------------------------------------------- random vs oracle

@@ -491,8 +491,29 @@ net = model(); comp.compress_model(net)
 comp.decompress_model(net, recouple=True)
 assert all(torch.equal(m.weight.data, w) and m.quantization_status == St.DECOMPRESSED for m, w in zip(net, ref))
 # ... and ownership is agreed even when the replicas' byte sizes have drifted apart
-net = model(); comp.compress_model(net, recouple=False); comp.compress_model(net, skip_compressed=True)
-assert all(hasattr(m, "weight_packed") for m in net)
+# (ADVICE r02: each rank skips only what IT compressed, so the ranks' filtered lists differ — identity is agreed by module
+# name, a module some rank already holds is owned by that rank, and every module must end with ITS OWN data and shape)
+net = model(); first = comp.compress_model(net, recouple=False)
+second = comp.compress_model(net, skip_compressed=True)
+assert second == []   # every module was already held compressed by one of the two ranks: nothing is recomputed
+for m, w in zip(net, ref):
+    assert m.quantization_status == St.COMPRESSED and not hasattr(m, "weight")
+    assert m.weight_packed.shape == w.shape and torch.equal(m.weight_packed.data, w * 4), "a module received another module's state"
+    assert m.weight_shape.tolist() == list(w.shape)
+comp.decompress_model(net)
+assert all(torch.equal(m.weight.data, w) for m, w in zip(net, ref))
+# the collective-free mode with a skip filter: bins from the unfiltered list with a compression-invariant weight -> still a partition
+net = model(); a = comp.compress_model(net, recouple=False)
+b = comp.compress_model(net, recouple=False, skip_compressed=True)
+assert b == [] and sum(hasattr(m, "weight_packed") for m in net) == len(a)
+# ranks that disagree about the module list get an error, not a silent mix-up
+from compressed_tensors_amd.distributed import replace_module_parallel
+mods = [torch.nn.Linear(4, 4) for _ in range(3)]
+try:
+    replace_module_parallel(mods, lambda ms: None, recouple=True, names=[f"m{{i}}" for i in range(3)] if rank == 0 else ["m0", "mX", "m2"])
+    raise SystemExit("differing module lists were accepted")
+except RuntimeError as e:
+    assert "different modules" in str(e)
 dist.barrier()
 open(os.path.join(os.environ["CT_TEST_OUT"], f"rank{{rank}}.ok"), "w").write("ok")
 """

@@ -162,6 +162,80 @@ def test_compressor_golden(golden, case):
         assert eq(d, exp_d["weight"])
 
 
+def _oracle_codec(case, sd, exp_c):
+    """the oracle's restatement of one codec call: (compressed dict, decompress function)"""
+    a = case["args"]
+    if case["format"] == "pack-quantized":
+        c = O.pack_quantized_compress(sd, num_bits=a["num_bits"], strategy=a["strategy"], group_size=a.get("group_size"), symmetric=a["symmetric"])
+        return c, lambda cc: O.pack_quantized_decompress(cc, num_bits=a["num_bits"], strategy=a["strategy"], symmetric=a["symmetric"])
+    w = sd["weight"]
+    if a["strategy"] == "block":  # naive_quantized/base.py:72-77: pad to whole blocks, quantize, truncate
+        bh, bw = a["block_structure"]
+        pr, pc = (-w.shape[0]) % bh, (-w.shape[1]) % bw
+        w = torch.nn.functional.pad(w, (0, pc, 0, pr))
+    q = O.quantize(w, sd["weight_scale"], sd["weight_zero_point"], num_bits=a["num_bits"], strategy=a["strategy"], group_size=a.get("group_size"),
+                   block_structure=a.get("block_structure"), dtype=torch.int8, g_idx=sd.get("weight_g_idx"))
+    q = q[: sd["weight"].shape[0], : sd["weight"].shape[1]]
+    c = {"weight": q, "weight_scale": sd["weight_scale"]}
+    if not a["symmetric"]:
+        c["weight_zero_point"] = sd["weight_zero_point"]
+    return c, lambda cc: {**{k: v for k, v in cc.items() if k != "weight"},
+                          "weight": O.dequantize(cc["weight"], cc["weight_scale"], cc.get("weight_zero_point"), g_idx=cc.get("weight_g_idx"))}
+
+
+@pytest.mark.parametrize("case", cases("compressors2"), ids=lambda c: c["key"])
+def test_compressor_golden_round3(golden, case):
+    """activation ordering GROUP / WEIGHT through the class (reference test_pack_quant.py:238-277), 3-D expert weights through
+    compress (helpers.py:45-51), channel-symmetric int4, naive int8 `block` with padding (naive_quantized/base.py:72-77)"""
+    t = golden.case("compressors2", case["key"])
+    sd = {k[3:]: v for k, v in t.items() if k.startswith("in.")}
+    exp_c = {k[2:]: v for k, v in t.items() if k.startswith("c.")}
+    exp_d = {k[2:]: v for k, v in t.items() if k.startswith("d.")}
+    c, dec = _oracle_codec(case, sd, exp_c)
+    assert sorted(c.keys()) == case["compressed_keys"]
+    for k in exp_c:
+        assert eq(c[k].contiguous(), exp_c[k]), k
+    if case["round_trip"]:
+        d = dec(dict(exp_c))
+        assert sorted(d.keys()) == case["decompressed_keys"]
+        for k in exp_d:
+            assert eq(d[k].contiguous(), exp_d[k]), k
+
+
+def big_case_inputs(golden, case):
+    """the 1024 x 4096 weight of a `compressors_big` case, regenerated from its seed and checked against the recorded digest"""
+    import hashlib
+
+    dt = getattr(torch, case["dtype"])
+    w = torch.randn(tuple(case["shape"]), generator=torch.Generator().manual_seed(case["seed"])).mul_(0.05).to(dt)
+    got = hashlib.sha256(w.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+    assert got == case["weight_sha256"], "torch.randn no longer reproduces the weight the goldens were generated from: regenerate them (oracle/gen_golden.py compressors_big)"
+    sd = {"weight": w}
+    sd.update({k[3:]: v for k, v in golden.case("compressors_big", case["key"]).items() if k.startswith("in.")})
+    return sd
+
+
+def digest_matches(t, rec):
+    import hashlib
+
+    t = t.detach().cpu().contiguous()
+    return (list(t.shape) == rec["shape"] and str(t.dtype).split(".")[-1] == rec["dtype"]
+            and hashlib.sha256(t.view(torch.uint8).numpy().tobytes()).hexdigest() == rec["sha256"])
+
+
+@pytest.mark.parametrize("case", cases("compressors_big"), ids=lambda c: c["key"])
+def test_compressor_golden_big(golden, case):
+    """1024 x 4096 per format: the oracle against sha256 digests of the reference's outputs"""
+    sd = big_case_inputs(golden, case)
+    c, dec = _oracle_codec(case, sd, None)
+    assert sorted(c.keys()) == sorted(case["compressed"])
+    for k, rec in case["compressed"].items():
+        assert digest_matches(c[k], rec), k
+    d = dec(dict(c))
+    for k, rec in case["decompressed"].items():
+        assert digest_matches(d[k], rec), k
+
+
 # ----------------------------------------------------------------------------- sparse primitives
 @pytest.mark.parametrize("case", [c for c in cases("sparse") if c["kind"] == "bitmask"], ids=lambda c: c["key"])
 def test_bitmask_primitives_golden(golden, case):

@@ -1,5 +1,5 @@
 """Randomised differential test of the HIP path against the CPU oracle (developer tool; the fixed cases live in tests/).
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [max_cases]
 Random shapes / dtypes / strategies / special values through the public codec entry points; stops at the first mismatch."""
 import os, sys, time, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,7 @@ from test_oracle_golden import eq, eq_f8
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_cases = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 62  # the -m gpu test runs a bounded, seeded number of cases
 rng = random.Random(seed)
 dev = torch.device("cuda:0")
 BF16, F16, F32, F8 = torch.bfloat16, torch.float16, torch.float32, torch.float8_e4m3fn
@@ -272,8 +273,8 @@ def case_batches(g):
 
 CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn, case_qparams_float, case_channel8, case_sparse24, case_marlin, case_batches, case_batches]
 t0, n = time.time(), 0
-while time.time() - t0 < budget:
+while time.time() - t0 < budget and n < max_cases:
     g = torch.Generator().manual_seed(rng.randint(0, 2 ** 31))
     rng.choice(CASES)(g)
     n += 1
-print(f"fuzz: {n} random cases, no mismatch (seed {seed}, {budget:.0f} s)")
+print(f"fuzz: {n} random cases, no mismatch (seed {seed}, {time.time() - t0:.0f} s of {budget:.0f} s)")
