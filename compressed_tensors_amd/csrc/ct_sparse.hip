@@ -1043,6 +1043,16 @@ __device__ __forceinline__ unsigned long long op_load(const unsigned long long* 
 // share of x itself, so the kernel cannot fail or deadlock whatever the dispatch order or residency, and the wave that owns the
 // last wave-tile writes *total directly (an earlier form reported failures through a fail word and needed a one-thread kernel
 // after it to publish *total: 2.5-4 us per call; a generation-tagged CAS completion counter cost 580 us).
+// Round 3 (per-workgroup time stamps, CT_BITMASK_RESIDENT=3, 8192^2): round 1's workgroups publish at 8 us (blocks 0-255) / 12 us
+// (256-511) — the load phase, memory-bound —, have their prefix at 14.7 / 18.6 us (every workgroup waits for the SLOWEST earlier loader
+// plus a 3-5 us hop: its polls queue behind the co-resident workgroup's streaming loads) and are done at 17 / 26 us; round 2 repeats that
+// from 17-29 us to 49 us.  Tried against it: (1) publishing the count before the compaction (kept: the compaction now overlaps the wait;
+// no change in time — the wait is set by the slowest loader, not by this workgroup's own compute); (2) a persistent STREAMING form —
+// 64 / 32 KB batches handed out by an atomic ticket counter, two batches in registers, p1 (count + publish) / store previous / load
+// next / p2 (compact) — bit-exact, but 69-87 us: every batch's prefix depends on every earlier batch, so each batch step is a chip-wide
+// synchronisation (ticket + load + hop, three dependent memory round trips of 2-3 us under load for 64 KB of work); (3) delaying the
+// start of blocks [CUs, 2 CUs) by one load phase so that a CU's two workgroups alternate load / store phases: 48.2 -> 44.6 us, kept for
+// launches of at least two residency rounds.
 typedef u32x4 u32x4_a2_t __attribute__((aligned(2)));
 constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB, 64 VGPRs)
 constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
@@ -1054,7 +1064,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
                                                                     int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
                                                                     const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
                                                                     unsigned long long* __restrict__ run_out, uint32_t gen, unsigned long long wait_ticks,
-                                                                    unsigned long long* __restrict__ stamps) {
+                                                                    unsigned long long* __restrict__ stamps, int stagger_lo, int stagger_hi, unsigned stagger_ticks) {
     constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[WAVES][kSlab];
@@ -1069,6 +1079,13 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     const int64_t wt0 = ((int64_t)b * WAVES + wave) * tpw;  // tpw <= KEEP wave-tiles per wave
     const uint32_t keepbits = is_float ? 0x7fff7fffu : 0xffffffffu;
     if (tid == 0) s_nmiss = 0;
+    // ---- stagger: the second workgroup of every CU starts its loads one load-phase later than the first, so that from then on
+    // one of a CU's two workgroups reads while the other computes / waits for its prefix / stores (without it the whole chip moves
+    // in lockstep: everybody loads, then everybody stores — 2 x 25 us at 8192^2 for 36 us of traffic)
+    if (b >= stagger_lo && b < stagger_hi) {
+        const unsigned long long s0 = wall_clock64();
+        while (wall_clock64() - s0 < stagger_ticks) __builtin_amdgcn_s_sleep(16);
+    }
     if (stamps && tid == 0 && b < 512) stamps[b * 4 + 0] = wall_clock64();
     // ---- phase A
     u32x4 keep[KEEP][4];
@@ -1236,283 +1253,6 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
         }
     }
     if (stamps && tid == 0 && b < 512) stamps[b * 4 + 3] = wall_clock64();
-}
-
-// ------------------------------------------------------------------------- compress, STREAMING (16-bit), round 3
-// The resident form above reads x once, but its workgroups move in lockstep: at 8192^2 the 1024 workgroups are two residency
-// rounds of 512, and within a round every workgroup loads (11.6 us for the round's 134 MB at HBM rate), then computes (~4 us),
-// then waits for its prefix (~3 us), then stores (6.5 us) at the same time as all the others — 2 x 25 us = the measured 49-50 us,
-// against 36 us if reads and writes overlapped.  This form makes them overlap: a workgroup is persistent and works through a
-// sequence of 64 KB BATCHES with TWO batches in registers — while batch k is counted, compacted, handed off and stored, the
-// loads of batch k + 1 are already in flight, and batch k + 2 is requested as soon as k's registers are free.
-//   * Batches are numbered in tensor order and handed out by a TICKET counter (one returning atomic per batch, claimed two
-//     batches ahead of its use, so its latency is never waited for).  Only running workgroups hold tickets, and a workgroup works
-//     through its tickets in increasing order, so the holder of the lowest unfinished ticket never waits for anything: no
-//     assumption about residency or dispatch order (the first ticket is the block index — the counter starts at gridDim.x).
-//   * prefix(t) = end of this workgroup's previous batch p + the counts of the batches p + 1 .. t - 1 (other workgroups' — about one
-//     per workgroup): lane i polls word p + 1 + i, every hop is direct.  Counts are published in pass 1, before the compaction.
-//   * a count that does not arrive within the time budget is recounted by the waiting workgroup (self-help), as before.
-// Count words and the ticket counter are generation-tagged 64-bit words: the workspace needs no clearing.
-constexpr int kStrWaves = 8;
-constexpr int kStrTiles = 2;  // wave-tiles per wave and batch: 2 x 4 KB per lane-row; two batches in registers = 64 VGPRs
-
-__device__ __forceinline__ long long claim_ticket(unsigned long long* ctr, uint32_t gen, uint32_t first) {
-    unsigned long long v = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        if ((uint32_t)(v >> 32) == gen) return (long long)(uint32_t)v;
-        // a stale word (another launch's, or uninitialised memory): the first claimer installs (gen, first + 1) and owns ticket `first`
-        v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(v >> 32) == gen) { v = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
-        const unsigned long long want = ((unsigned long long)gen << 32) | (unsigned long long)(first + 1u);
-        if (__hip_atomic_compare_exchange_strong(ctr, &v, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return (long long)first;
-        v = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-__device__ __forceinline__ long long uniform64(long long v) {  // a workgroup-uniform value read from LDS / memory -> scalar registers
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-
-// The order of work inside a workgroup (two register buffers; F = the buffer that is "fronted": counted, published, compacted;
-// L = the buffer whose loads are landing; tN = the next ticket, already claimed):
-//     p1(L): flags + count -> the count word leaves          (needs L's data: issued one step ago)
-//     back(F): poll the counts between this workgroup's previous batch and F's (published >= one step ago), store F
-//     issue(F <- tN): F's registers are free again
-//     p2(L): ranks, compaction in place, bitmask             (while F's loads fly and L's count word travels)
-// so a buffer's load latency hides behind the other buffer's p2 + p1, and a count word's ~3 us publish -> visible hop hides behind
-// p2 of its own batch and p1 of the next.
-template <int TPB, int WAVES, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void flat16_stream_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows, int tpb,
-                                                                     long long nbatches, uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
-                                                                     int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
-                                                                     const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
-                                                                     unsigned long long* __restrict__ ticket, unsigned long long* __restrict__ run_out, uint32_t gen,
-                                                                     unsigned long long wait_ticks) {
-    constexpr int kSlabData = kWT * 8 + 8;
-    constexpr int kSlab = kSlabData + 64;
-    __shared__ __attribute__((aligned(16))) uint16_t s_val[WAVES][kSlab];
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[256 * 8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_mask[WAVES][TPB][64];
-    __shared__ int s_cnt[2][WAVES];        // [buffer]
-    __shared__ long long s_part[WAVES];
-    __shared__ long long s_tk;
-    __shared__ int s_miss[WAVES * 64];
-    __shared__ int s_nmiss;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: everything indexed by the wave stays in SGPRs
-    const uint32_t keepbits = is_float ? 0x7fff7fffu : 0xffffffffu;
-    const int64_t batch_units = (int64_t)WAVES * tpb * kWT;
-    const uint32_t slab_a = lds_addr(s_val[wave]), dump_a = slab_a + 2u * (uint32_t)(kSlabData + lane), lut_a = lds_addr(s_lut);
-    const u32x4* slab_v = reinterpret_cast<const u32x4*>(s_val[wave]);
-
-    auto issue = [&](u32x4 (&buf)[TPB][4], long long t) __attribute__((always_inline)) {
-        const int64_t wt0 = (t * WAVES + wave) * tpb;
-#pragma unroll
-        for (int i = 0; i < TPB; ++i) {
-            if (i < tpb) load_wt(x, units, wt0 + i, lane, buf[i]);  // zeros beyond the chunk
-            else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) buf[i][q] = u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-    };
-
-    // p1: flags + count of batch t (in `buf`, buffer number `bi`); thread 0 also posts `mail` (the ticket it claimed); returns the ticket
-    auto p1 = [&](u32x4 (&buf)[TPB][4], int bi, long long t, uint32_t (&pks)[TPB], long long mail) __attribute__((always_inline)) -> long long {
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < TPB; ++i) {
-            uint32_t pk = 0;
-            if (i < tpb) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pk |= nz_mask16_fast(buf[i][q], keepbits) << (8 * q);
-                s_mask[wave][i][lane] = pk;
-            }
-            pks[i] = pk;
-            cnt += __popc(pk);
-        }
-        cnt = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
-        if (lane == 0) s_cnt[bi][wave] = cnt;
-        if (tid == 0) s_tk = mail;
-        __syncthreads();
-        if (tid == 0) {
-            int wg = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) wg += s_cnt[bi][w];
-            op_store(slots + t, ((unsigned long long)gen << 32) | (uint32_t)wg);
-        }
-        return uniform64(s_tk);
-    };
-
-    // p2: ranks, row offsets relative to the tile, compaction through the wave's slab (read back in place), the bitmask
-    auto p2 = [&](u32x4 (&buf)[TPB][4], long long t, const uint32_t (&pks)[TPB], int (&tot)[TPB]) __attribute__((always_inline)) {
-        const int64_t wt0 = (t * WAVES + wave) * tpb;
-        int64_t next_r = (u0 + wt0 * kWT + upr - 1) / upr, next_u = next_r * upr;
-#pragma unroll
-        for (int i = 0; i < TPB; ++i) {
-            tot[i] = 0;
-            if (i >= tpb) continue;
-            uint32_t mm[4], rank[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mm[q] = (pks[i] >> (8 * q)) & 0xffu;
-            tot[i] = tile_ranks(mm, rank);
-            {
-                const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
-                for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
-                    const int q = (int)(next_u - ubeg);
-                    const int qi = q >> 6, l = q & 63;
-                    const uint32_t rk = qi == 0 ? rank[0] : (qi == 1 ? rank[1] : (qi == 2 ? rank[2] : rank[3]));
-                    if (lane == l) row_offsets[next_r] = (int64_t)rk;
-                }
-            }
-            compact_into_slab(buf[i], mm, rank, 0, slab_a, dump_a, lut_a);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) buf[i][q] = slab_v[q * 64 + lane];
-            const int64_t wt = wt0 + i;
-            if (wt * kWT < units) {
-                if (mask_dwords) {
-                    const uint8_t* src = reinterpret_cast<const uint8_t*>(s_mask[wave][i]) + 16 * (lane & 15) + (lane >> 4);
-                    const uint32_t d = (uint32_t)src[0] | ((uint32_t)src[4] << 8) | ((uint32_t)src[8] << 16) | ((uint32_t)src[12] << 24);
-                    const int64_t u = wt * kWT + 4 * lane;
-                    if (u < units) *reinterpret_cast<uint32_t*>(bitmask + u) = d;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int64_t u = wt * kWT + q * 64 + lane;
-                        if (u < units) bitmask[u] = (uint8_t)(pks[i] >> (8 * q));
-                    }
-                }
-            }
-        }
-    };
-
-    long long prev_t = -1;                              // this workgroup's previous batch
-    long long prev_end = base ? (long long)*base : 0;   // non-zeros up to and including batch prev_t
-    prev_end = uniform64(prev_end);
-
-    // back: the counts of the batches between this workgroup's previous one and t, then the stores
-    auto back = [&](u32x4 (&buf)[TPB][4], int bi, long long t, const int (&tot)[TPB]) __attribute__((always_inline)) {
-        long long part = 0;
-        {
-            const unsigned long long c0 = wall_clock64();
-            for (long long w0 = prev_t + 1; w0 < t; w0 += (WAVES * 64)) {  // workgroup-uniform trip count
-                const long long w = w0 + tid;
-                const bool need = w < t;
-                bool got = !need;
-                uint32_t mine = 0;
-                if (__builtin_amdgcn_ballot_w64(need) != 0) {
-                    for (;;) {
-                        if (!got) {
-                            const unsigned long long v = op_load(slots + w);
-                            if ((uint32_t)(v >> 32) == gen) { mine = (uint32_t)v; got = true; }
-                        }
-                        if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
-                        if (wall_clock64() - c0 >= wait_ticks) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                part += mine;
-                if (!got) s_miss[atomicAdd(&s_nmiss, 1)] = (int)w;
-                __syncthreads();
-                const int nmiss = __builtin_amdgcn_readfirstlane(s_nmiss);  // workgroup-uniform; almost always 0
-                if (nmiss) {  // self-help: count the missing batches' shares of x here
-                    for (int m = 0; m < nmiss; ++m) {
-                        const int64_t u_lo = (int64_t)s_miss[m] * batch_units;
-                        int64_t u_hi = u_lo + batch_units;
-                        if (u_hi > units) u_hi = units;
-                        for (int64_t u = u_lo + tid; u < u_hi; u += WAVES * 64) part += __popc(nz_mask16_fast(x[u], keepbits));
-                    }
-                    __syncthreads();
-                    if (tid == 0) s_nmiss = 0;
-                    __syncthreads();
-                }
-            }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-            if (lane == 0) s_part[wave] = part;
-        }
-        __syncthreads();
-        long long before = prev_end;
-        int wg = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) { before += s_part[w]; wg += s_cnt[bi][w]; }
-        before = uniform64(before);
-        int64_t run = before;
-        for (int w = 0; w < wave; ++w) run += s_cnt[bi][w];
-        run = uniform64(run);
-        const int64_t wt0 = (t * WAVES + wave) * tpb;
-        int64_t next_r = (u0 + wt0 * kWT + upr - 1) / upr, next_u = next_r * upr;
-#pragma unroll
-        for (int i = 0; i < TPB; ++i) {
-            const int64_t wt = wt0 + i;
-            const int total = tot[i];
-            if (i >= tpb) continue;
-            {
-                const int64_t uend = u0 + (wt + 1) * kWT;
-                for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
-                    const int l = (int)(next_u - (u0 + wt * kWT)) & 63;
-                    if (lane == l) row_offsets[next_r] += run;
-                }
-            }
-            const int64_t lim = run + total < capacity ? run + total : capacity;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t gi = run + ((int64_t)(q * 64 + lane) << 3);
-                if (gi + 8 <= lim) {
-                    __builtin_nontemporal_store(buf[i][q], reinterpret_cast<u32x4_a2_t*>(vout + gi));  // 2-byte aligned
-                } else if (gi < lim) {
-                    const uint32_t ws[4] = {buf[i][q].x, buf[i][q].y, buf[i][q].z, buf[i][q].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (gi + e < lim) vout[gi + e] = (uint16_t)((e & 1) ? (ws[e >> 1] >> 16) : ws[e >> 1]);
-                }
-            }
-            run += total;
-            if ((wt + 1) * kWT >= units && wt * kWT < units && lane == 0) op_store(run_out, (unsigned long long)run);  // the chunk's last wave-tile
-        }
-        prev_end = before + uniform64((long long)wg);
-        prev_t = t;
-        __syncthreads();  // s_part / s_cnt[bi] are free again
-    };
-
-    // ---- start: ticket 0 is the block index (dispatch order makes the lower blocks run); the counter hands out the rest
-    u32x4 bufA[TPB][4], bufB[TPB][4];
-    uint32_t pksA[TPB], pksB[TPB];
-    int totA[TPB], totB[TPB];
-    long long tF = (long long)blockIdx.x, tL = 0, tN = 0, mail = 0;
-    if (tid == 0) {
-        s_nmiss = 0;
-        mail = claim_ticket(ticket, gen, gridDim.x);  // issued before the loads: it returns first
-    }
-    issue(bufA, tF);
-    build_compact_lut(s_lut, tid);
-    if (tid == 0) s_tk = mail;
-    __syncthreads();
-    tL = uniform64(s_tk);
-    __syncthreads();
-    if (tL < nbatches) issue(bufB, tL);
-    if (tid == 0) mail = claim_ticket(ticket, gen, gridDim.x);
-    tN = p1(bufA, 0, tF, pksA, mail);
-    p2(bufA, tF, pksA, totA);
-    // invariant: A fronted with tF, B landing with tL (if < nbatches), tN claimed
-    for (;;) {
-        if (tL >= nbatches) { back(bufA, 0, tF, totA); break; }
-        if (tid == 0) mail = claim_ticket(ticket, gen, gridDim.x);
-        long long tNN = p1(bufB, 1, tL, pksB, mail);
-        back(bufA, 0, tF, totA);
-        if (tN < nbatches) issue(bufA, tN);
-        p2(bufB, tL, pksB, totB);
-        tF = tL; tL = tN; tN = tNN;
-        // now: B fronted with tF, A landing with tL
-        if (tL >= nbatches) { back(bufB, 1, tF, totB); break; }
-        if (tid == 0) mail = claim_ticket(ticket, gen, gridDim.x);
-        tNN = p1(bufA, 0, tL, pksA, mail);
-        back(bufB, 1, tF, totB);
-        if (tN < nbatches) issue(bufB, tN);
-        p2(bufA, tL, pksA, totA);
-        tF = tL; tL = tN; tN = tNN;
-    }
 }
 
 // ------------------------------------------------------------------------- 2:4
@@ -1829,48 +1569,6 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
             const int64_t v = e ? (int64_t)std::atoll(e) : (int64_t)kResMaxWGs;
             return v < 1 ? (int64_t)1 : (v > kResMaxWGs ? (int64_t)kResMaxWGs : v);
         }();
-        if (resident_mode != 1 && resident_mode != 3) {
-            // streaming form: batches of kStrWaves * tpb wave-tiles handed out by tickets to a persistent grid of two workgroups per CU
-            int64_t stb = cdiv64(wts, (int64_t)cus * 2 * kStrWaves);  // wave-tiles per wave and batch: fewer when the tensor is small
-            const int tiles_cap = (resident_mode == 2 || resident_mode == 5) ? 2 : 1;
-            if (stb > tiles_cap) stb = tiles_cap;
-            if (stb < 1) stb = 1;
-            const int64_t batch_wts = (int64_t)kStrWaves * stb;
-            const int64_t chunk_wts_s = max_wgs * batch_wts;  // one count word per batch
-            const int64_t nchunks_s = cdiv64(wts, chunk_wts_s);
-            if (nchunks_s <= 4096) {
-                static std::atomic<uint32_t> generation_s{[]() {
-                    std::random_device rd;
-                    return (uint32_t)rd() ^ (uint32_t)std::chrono::steady_clock::now().time_since_epoch().count();
-                }()};
-                const uint32_t gen0 = generation_s.fetch_add((uint32_t)nchunks_s) + 1u;
-                auto tag_of = [](uint32_t c) { return 0x80000000u | (c % 0x7ffffffeu); };
-                unsigned long long* slots = static_cast<unsigned long long*>(workspace);
-                unsigned long long* ctl = slots + kResMaxWGs;  // [0] ticket counter, [2] / [3] running totals (alternating between chunks)
-                static const unsigned long long wait_ticks_s = []() {
-                    const char* e = std::getenv("CT_BITMASK_RESIDENT_WAIT_US");
-                    return (unsigned long long)(e ? std::atoll(e) : 2000ll) * 100ull;
-                }();
-                for (int64_t k = 0; k < nchunks_s; ++k) {
-                    const int64_t w0 = k * chunk_wts_s;
-                    const int64_t cw = (wts - w0) < chunk_wts_s ? (wts - w0) : chunk_wts_s;
-                    const int64_t u0 = w0 * kWT;
-                    const int64_t cu = (units - u0) < cw * kWT ? (units - u0) : cw * kWT;
-                    const int64_t nb = cdiv64(cw, batch_wts);
-                    int64_t grid = (int64_t)cus * ((resident_mode == 2 || resident_mode == 6) ? 1 : 2);
-                    if (grid > nb) grid = nb;
-                    const int mask_dwords = (cu % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask + u0) & 3u) == 0);
-                    unsigned long long* run_out = k + 1 == nchunks_s ? reinterpret_cast<unsigned long long*>(total) : ctl + 2 + (k & 1);
-#define CT_STREAM(TPB, MINW) hipLaunchKernelGGL((flat16_stream_kernel<TPB, kStrWaves, MINW>), dim3((unsigned)grid), dim3(kStrWaves * 64), 0, as_stream(stream), \
-                                       static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, cols / 8, rows, (int)stb, (long long)nb, static_cast<uint16_t*>(values), \
-                                       values_capacity, bitmask + u0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, ctl, \
-                                       run_out, tag_of(gen0 + (uint32_t)k), wait_ticks_s)
-                    if (resident_mode == 2) CT_STREAM(2, 2); else if (resident_mode == 4) CT_STREAM(1, 4); else if (resident_mode == 5) CT_STREAM(2, 4); else CT_STREAM(1, 2);
-#undef CT_STREAM
-                }
-                CT_LAUNCH_CHECK("ct_bitmask_compress[stream]");
-            }
-        }
         const int64_t chunk_wts = max_wgs * wg_wts;
         const int64_t nchunks = cdiv64(wts, chunk_wts);
         if (nchunks <= 4096) {
@@ -1901,10 +1599,16 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 const int mask_dwords = (cu % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask + u0) & 3u) == 0);
                 // the chunk's running total: straight into *total for the last chunk, else into one of two alternating workspace words
                 unsigned long long* run_out = k + 1 == nchunks ? reinterpret_cast<unsigned long long*>(total) : ctl + 2 + (k & 1);
+                // stagger (see the kernel): only when the launch is at least two full residency rounds (two workgroups per CU each) — with a
+                // single round a delayed start is pure loss (4096^2: 15.0 -> 17.4 us), with two it buys 48.2 -> 44.6 us at 8192^2.  The delay is
+                // one load phase of a workgroup at the CU's share of the HBM rate (~19 GB/s per CU): 128 KB -> 7 us.
+                const bool stagger = nwg >= 4 * (int64_t)cus;
+                const int stagger_lo = cus, stagger_hi = stagger ? 2 * cus : 0;
+                const unsigned stagger_ticks = (unsigned)((wg_wts * kWT * 16) / 188);  // 100 MHz ticks
                 hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),
                                    static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, cols / 8, rows, (int)tpw, static_cast<uint16_t*>(values),
                                    values_capacity, bitmask + u0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots,
-                                   run_out, tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr);
+                                   run_out, tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks);
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
         }

@@ -1,0 +1,52 @@
+"""round-3 experiments (dev helper): python tools/exp_r03.py bm   (CT_BITMASK_RESIDENT selects the compress form)"""
+import json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+what = sys.argv[1]
+if what == "bm":
+    from compressed_tensors_amd import _lib, codec
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator(device=dev).manual_seed(11)
+    res = {"mode": os.environ.get("CT_BITMASK_RESIDENT")}
+    ok = True
+    shapes = ((8192, 8192, 0.5), (4096, 4096, 0.5), (8192, 8192, 0.05), (8192, 8192, 1.0), (1000, 4104, 0.3), (3, 8, 0.5), (257, 2048, 0.0), (12288, 8192, 0.5))
+    if len(sys.argv) > 2 and sys.argv[2] == "big":
+        shapes = shapes + ((16384, 16384, 0.5), (20000, 16384, 0.7))
+    for (r, c, dens) in shapes:
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        if dens < 1.0:
+            w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
+        v, bm, ro = codec.bitmask_compress(w)
+        v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
+        same = v.numel() == v2.numel() and torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2)
+        ok = ok and same
+        res[f"{r}x{c}@{dens}"] = bool(same)
+        del w, v, v2, bm, bm2, ro, ro2
+        torch.cuda.empty_cache()
+    res["all_equal"] = ok
+    for N in (8192, 4096, 2048, 256):
+        nsets = 8 if N == 8192 else 6
+        ws_ = []
+        for i in range(nsets):
+            w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+            ws_.append(w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0))
+        ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+        wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+        vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+        f = lambda i: lib.ct_bitmask_compress(ws_[i % nsets].data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes, stream)
+        f(0); torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter(); f(1); torch.cuda.synchronize(); one = (time.perf_counter() - t0) * 1e6
+        if one > 1500:  # time-outs inside the kernel: do not spend GPU minutes timing it
+            res[f"us_{N}"] = f"single launch {one:.0f} us: skipped"
+        else:
+            res[f"us_{N}"] = round(B.time_kernel(f, 40), 2)
+        res[f"total_{N}"] = int(wk[-1].item())
+        del ws_, vals, bm, ro
+        torch.cuda.empty_cache()
+    print(json.dumps(res))
