@@ -615,8 +615,6 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     const int tiles_c = (int)(k / 256);
     const int tile_r = (int)(blockIdx.x / (unsigned)tiles_c), tile_c = (int)(blockIdx.x - (unsigned)tile_r * (unsigned)tiles_c);
     const int tid = threadIdx.x;
-    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
-    const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
     const uint32_t per = (uint32_t)(cdiv >> 4);
     const bool per_pow2 = (per & (per - 1)) == 0;
     const int per_shift = __builtin_ctz(per);
@@ -682,9 +680,16 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         stream_store8(meta + pair_base + chunk * 4, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
     }
     const uint8_t* sc = &s_code[0][0];
+    // (the permutation row is fetched here, not at the top: eight registers less through the front end, 100 -> 95 VGPRs = 5 waves per SIMD)
+    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
+    const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
     const int64_t wpr = m * 2;  // packed words per k-tile row (size_n * 16 * 4 / 32)
     // (a thread building FOUR consecutive words of one k-tile — four table rows, one 16-byte streaming store — measured slower:
-    // 38.9 vs 36.2 us; the same word position in four k-tiles reuses one table row and its 4-byte stores are 512-byte runs)
+    // 38.9 vs 36.2 us; the same word position in four k-tiles reuses one table row and its 4-byte stores are 512-byte runs.
+    // Round 3: staging the words through 4 KB of LDS so that they leave as one 16-byte store per thread: 35.3 us, no change;
+    // 5 instead of 4 waves per SIMD: 35.6 us, no change; the 32-byte-per-lane read shape against lane-contiguous 16-byte reads
+    // (tools/kbench/kbench_readshape.hip): 21.6 against 21.9 us for the 134 MB, no difference.  What is left is instruction
+    // issue: 12.3 M vector instructions per launch, ~7 per element of packed-float / dot work that issues at half rate.)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int t = (tid >> 7) + 2 * it;  // k-tile inside the workgroup tile

@@ -50,3 +50,6 @@ if what == "bm":
         del ws_, vals, bm, ro
         torch.cuda.empty_cache()
     print(json.dumps(res))
+elif what == "m24":
+    r = B.marlin24_leg(dev)
+    print(json.dumps({k: v for k, v in r.items() if "us" in k or "exact" in k}))
