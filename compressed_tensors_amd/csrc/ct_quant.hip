@@ -734,6 +734,9 @@ __global__ __launch_bounds__(kBlock) void f32_quant_units_kernel(W4Params p, int
 // lean compress body for the common layout (flat scale index = lane >> gshift, one scale per lane, int8
 // zero point): no grid-stride loop, no generic index arithmetic, and the scale / zero point are loaded
 // BEFORE the 64 bytes of weights so that the reciprocal is ready when they land.  30.3 -> 29.4 us at 8192^2.
+// (Round 3, for the 4096^2 launches: F = 2 / 3 / 4 consecutive chunks per workgroup with every chunk's loads requested up
+// front measured 9.9 / 11.7 / 12.1 us against 8.8 us for this one-chunk form, and 31.0 / 32.7 / 34.2 against 29.4 us at 8192^2;
+// block sizes 128 ... 1024 and the traffic-only stand-in all sit at 8.4-8.5 us: the exact grid of small workgroups stays.)
 template <int DT, bool HAS_ZP>
 __device__ __forceinline__ void w4_quant_pack_lean(const u32x4* __restrict__ in, const uint16_t* __restrict__ scale,
                                                    const int8_t* __restrict__ zp, u32x4* __restrict__ out, int64_t g, int gshift) {
