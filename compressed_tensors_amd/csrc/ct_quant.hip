@@ -320,110 +320,32 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_kernel(W4Params p) {
 }
 
 
-// ---- activation ordering (weight_g_idx): column c of a row uses scale group col_group[c], any of the row's groups.  The any-layout
-// kernels look the group up per element in global memory and give a lane 128 strided bytes (198 / 238 us at 8192^2 for the 29 / 25 us
-// job).  Here a workgroup stays inside one row: the row's scales, reciprocals and zero points go to LDS once (<= 1024 groups), a
-// lane takes whole units (16-byte weight access, two 16-byte loads of the 8 group numbers — the same 32 KB for every row, so they
-// come from the L2) and gathers its 8 (scale, reciprocal, zero point) triples from LDS.
 constexpr int kGidxMaxGroups = 1024;
-template <int DT, bool HAS_ZP, bool COMPRESS>
-__global__ __launch_bounds__(kBlock) void w4_gidx_kernel(W4Params p, const int32_t* __restrict__ col_group, int chunks_per_row) {
-    constexpr int U = 2;
-    __shared__ float s_s[kGidxMaxGroups], s_rs[kGidxMaxGroups], s_z[HAS_ZP ? kGidxMaxGroups : 1];
-    const int64_t row = blockIdx.x / (unsigned)chunks_per_row;
-    const int chunk = (int)(blockIdx.x - (unsigned)row * (unsigned)chunks_per_row);
-    for (int g = threadIdx.x; g < (int)p.scale_cols; g += kBlock) {
-        const int64_t si = row * p.scale_cols + g;
-        const float s = load_as_f<DT>(p.scale, si);
-        s_s[g] = s;
-        if (COMPRESS) s_rs[g] = DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s);
-        if (HAS_ZP) s_z[g] = round_to<DT>(load_rt(p.zp, p.zdt, si));
-    }
-    __syncthreads();
-    const int64_t cu0 = (int64_t)chunk * (U * kBlock) + threadIdx.x;
-    u32x4 wv[U], g0[U], g1[U];
-    uint32_t pw[U];
-#pragma unroll
-    for (int i = 0; i < U; ++i) {
-        const int64_t cu = cu0 + (int64_t)i * kBlock;
-        if (cu < p.upr) {
-            const int64_t u = row * p.upr + cu;
-            if (COMPRESS) wv[i] = static_cast<const u32x4*>(p.x)[u];
-            else pw[i] = static_cast<const uint32_t*>(p.x)[u];
-            g0[i] = reinterpret_cast<const u32x4*>(col_group)[2 * cu];
-            g1[i] = reinterpret_cast<const u32x4*>(col_group)[2 * cu + 1];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < U; ++i) {
-        const int64_t cu = cu0 + (int64_t)i * kBlock;
-        if (cu >= p.upr) continue;
-        const int64_t u = row * p.upr + cu;
-        const uint32_t gs[8] = {g0[i].x, g0[i].y, g0[i].z, g0[i].w, g1[i].x, g1[i].y, g1[i].z, g1[i].w};
-        if constexpr (COMPRESS) {
-            const uint32_t ws[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
-            uint32_t word = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x0, x1;
-                unpack2<DT>(ws[j], x0, x1);
-                const uint32_t ga = gs[2 * j], gb = gs[2 * j + 1];
-                const float ra = s_rs[ga], rb = s_rs[gb];
-                int c0, c1;
-                if (DT == CT_BF16 && ra != 0.0f && rb != 0.0f) {
-                    // both scales inside the proven range: the arithmetic of w4_quant_word with one reciprocal per element
-                    // (v_cvt_i32_f32 turns a NaN into code 0 and saturates, v_med3_i32 clamps: the same codes as quant_core)
-                    float t0 = x0 * ra, t1 = x1 * rb;
-                    round2<DT>(t0, t1);
-                    if (HAS_ZP) {
-                        t0 += s_z[ga]; t1 += s_z[gb];
-                        round2<DT>(t0, t1);
-                    }
-                    c0 = cvt_i32_hw(__builtin_rintf(t0)); c1 = cvt_i32_hw(__builtin_rintf(t1));
-                    c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
-                    c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
-                } else {
-                    c0 = cvt_i32_hw(quant_core<DT>(x0, s_s[ga], HAS_ZP, HAS_ZP ? s_z[ga] : 0.0f, -8.0f, 7.0f, ra));  // NaN -> code 0
-                    c1 = cvt_i32_hw(quant_core<DT>(x1, s_s[gb], HAS_ZP, HAS_ZP ? s_z[gb] : 0.0f, -8.0f, 7.0f, rb));
-                }
-                word |= (uint32_t)((c0 + 8) & 15) << (8 * j);
-                word |= (uint32_t)((c1 + 8) & 15) << (8 * j + 4);
-            }
-            __builtin_nontemporal_store(word, static_cast<uint32_t*>(p.out) + u);
-        } else {
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float q = (float)((int)((pw[i] >> (4 * k)) & 15u) - 8);
-                v[k] = dequant_core<DT>(q, HAS_ZP, HAS_ZP ? s_z[gs[k]] : 0.0f, s_s[gs[k]]);
-            }
-            store8<DT>(p.out, u * 8, v);
-        }
-    }
-}
-
 // ---- activation ordering, round 3: R rows per workgroup.  What round 2's kernel above actually paid for (bench leg `bf16_8192_actorder`,
 // HBM-cold: 43 / 45 us for a 29 us job) was not the gathers: (1) every workgroup first fetched its row's scales, waited, filled the LDS
 // table, hit a barrier and only THEN issued its data loads — two dependent HBM latencies per 512 units of work; (2) the group table is
 // int32: 32 bytes of table per 4-byte packed word / 16-byte weight unit, re-fetched from the L2 for every row (268 MB of L2 reads for
 // a 168 MB job); (3) the compress side stored 4 bytes per lane.  Here a lane keeps the group numbers of ITS columns in registers (as
 // 16-bit LDS byte offsets, two per register) and reuses them for R rows; all R rows' data loads are issued before anything is
-// waited for; the R rows' scale entries go to LDS in one pass (one barrier per workgroup); the compress side gives a lane 2
-// consecutive units = one 8-byte `nt` store (4 units / 16 bytes needs 140 VGPRs and measured 41.5 us against 32.9).  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
+// waited for; the R rows' scale entries go to LDS in one pass (one barrier per workgroup); (3) turned out NOT to be the lever: a lane
+// with 4 units / one 16-byte store needs 140 VGPRs and measured 41.5 us, one unit per lane 30.6 (see the constants below).  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
 // beside it in one 8-byte entry when the scheme has one — ONE ds_read per element.
 constexpr int kGidxRows = 4;
 // rows per workgroup R and units per lane UL, measured at 8192^2 bf16 on the product's own template (tools/kbench/kbench_prod.hip `gidx`,
-// profiles/r03_kbench_prod.txt).  compress (R, UL): (4, 4) 41.5 us — 140 VGPRs, 3 waves per SIMD — (4, 2) 32.9, (4, 1) 34.4, (2, 2) 35.2,
-// (8, 2) 48.4, (1, 4) 63.2; decompress: (4, 1) 31.0, (8, 1) 31.3, (8, 2) 31.8, (4, 2) 32.9, (2, 2) 34.4, (4, 4) 34.3.
-constexpr int kGidxCompressUnits = 2;    // consecutive units per lane on the compress side (one 8-byte store)
-constexpr int kGidxDecompressUnits = 1;  // units per lane, one block apart, on the decompress side (16-byte stores)
-template <int DT, bool HAS_ZP, bool COMPRESS, int R = kGidxRows, int UL = (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits)>
+// profiles/r03_kbench_prod.txt, r03_kbench_gidx_small_tables.txt).  With the tables sized for 1024 groups per row LDS capped the
+// kernel at 3-5 workgroups per CU: compress (R, UL) = (4, 4) 41.5 us — 140 VGPRs —, (4, 2) 32.9, (4, 1) 34.4, (2, 2) 35.2, (8, 2) 48.4.
+// With tables for <= 128 groups (6-8 waves per SIMD): compress (4, 1) 30.6, (8, 1) 33.8, (4, 2) 34.5, (2, 2) 35.2, (4, 4) 41.3;
+// decompress (8, 1) 30.3, (4, 1) 30.5, (8, 2) 31.9, (4, 2) 32.2.  One unit per lane on both sides: occupancy beats store width here.
+constexpr int kGidxCompressUnits = 1;    // units per lane on the compress side (one 4-byte word per lane and row)
+constexpr int kGidxDecompressUnits = 1;  // units per lane on the decompress side (one 16-byte store per lane and row)
+constexpr int kGidxSmallGroups = 128;  // tables sized for rows of up to 128 groups (8192 columns of group 64) keep LDS out of the occupancy limit
+template <int DT, bool HAS_ZP, bool COMPRESS, int R = kGidxRows, int UL = (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits), int MAXG = kGidxMaxGroups>
 __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const int32_t* __restrict__ col_group, int chunks_per_row, int64_t rows) {
     static_assert(!COMPRESS || UL == 1 || UL == 2 || UL == 4, "the compress side stores UL consecutive words per lane");
     constexpr int ESZ = HAS_ZP ? 8 : 4;                   // bytes per LDS entry
-    constexpr int kRowBytes = kGidxMaxGroups * ESZ;       // compile-time row stride: the row index is an instruction offset
+    constexpr int kRowBytes = MAXG * ESZ;                 // compile-time row stride: the row index is an instruction offset
     __shared__ __attribute__((aligned(16))) unsigned char s_tab[R * kRowBytes];
-    __shared__ float s_slow[COMPRESS ? R * kGidxMaxGroups : 1];  // the scales themselves, read only by lanes that must divide
+    __shared__ float s_slow[COMPRESS ? R * MAXG : 1];     // the scales themselves, read only by lanes that must divide
     const int64_t rb = blockIdx.x / (unsigned)chunks_per_row;
     const int chunk = (int)(blockIdx.x - (unsigned)rb * (unsigned)chunks_per_row);
     const int64_t row0 = rb * R;
@@ -461,6 +383,7 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
         }
     }
     // 3. the R rows' entries -> LDS
+    bool nz = false;  // some zero point of these rows is not zero
     for (int e = threadIdx.x; e < R * (int)p.scale_cols; e += kBlock) {
         const int r = e / (int)p.scale_cols, g = e - r * (int)p.scale_cols;
         if (row0 + r < rows) {
@@ -469,11 +392,13 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
             const float v = COMPRESS ? (DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s)) : s;
             if constexpr (HAS_ZP) {
                 typedef float f2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, round_to<DT>(load_rt(p.zp, p.zdt, si))};
+                const float z = round_to<DT>(load_rt(p.zp, p.zdt, si));
+                nz |= z != 0.0f;
+                *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, z};
             } else {
                 *reinterpret_cast<float*>(s_tab + r * kRowBytes + g * 4) = v;
             }
-            if constexpr (COMPRESS) s_slow[r * kGidxMaxGroups + g] = s;
+            if constexpr (COMPRESS) s_slow[r * MAXG + g] = s;
         }
     }
     // LDS byte offsets of the groups, two per register
@@ -484,7 +409,10 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
 #pragma unroll
         for (int j = 0; j < 4; ++j) go[i][j] = (gs[2 * j] * ESZ) | ((gs[2 * j + 1] * ESZ) << 16);
     }
-    __syncthreads();
+    // symmetric schemes hand over an all-zero zero point: adding it is the identity (t is already rounded), so the add and the second
+    // rounding are skipped when no zero point of the workgroup's rows is set — the wave-uniform skip of the flat kernels, per workgroup
+    const bool use_zp = HAS_ZP && (COMPRESS ? __syncthreads_or(nz) != 0 : true);
+    if (!(HAS_ZP && COMPRESS)) __syncthreads();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t row = row0 + r;
@@ -514,7 +442,7 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
                         // both scales inside the proven range: w4_quant_word's arithmetic with one reciprocal per element
                         float t0 = x0 * ra, t1 = x1 * rb2;
                         round2<DT>(t0, t1);
-                        if (HAS_ZP) {
+                        if (use_zp) {
                             t0 += za; t1 += zb;
                             round2<DT>(t0, t1);
                         }
@@ -522,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
                         c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);
                         c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
                     } else {
-                        const float sa = s_slow[r * kGidxMaxGroups + oa / ESZ], sb = s_slow[r * kGidxMaxGroups + ob / ESZ];
+                        const float sa = s_slow[r * MAXG + oa / ESZ], sb = s_slow[r * MAXG + ob / ESZ];
                         c0 = cvt_i32_hw(quant_core<DT>(x0, sa, HAS_ZP, za, -8.0f, 7.0f, ra));  // NaN -> code 0
                         c1 = cvt_i32_hw(quant_core<DT>(x1, sb, HAS_ZP, zb, -8.0f, 7.0f, rb2));
                     }
@@ -1647,30 +1575,23 @@ static int decomp_unroll(int64_t units) {
         else { constexpr int U = 2; __VA_ARGS__; }               \
     } while (0)
 
-// activation-ordered W4 (w4_gidx_kernel): one dtype for weight / scale / result, row-wise scales, group table aligned
+// activation-ordered W4 (w4_gidx_rows_kernel): one dtype for weight / scale / result, row-wise scales, group table aligned
 static bool w4_gidx_ok(int dt, int sdt, int tdt_or_odt, int bits, int64_t rows, int64_t cols, int64_t rdiv, int64_t scale_cols,
                        const int32_t* col_group, const void* a, const void* b) {
     return bits == 4 && col_group && (dt == CT_BF16 || dt == CT_F16) && sdt == dt && tdt_or_odt == dt && rows > 0 && cols > 0 && cols % 8 == 0 && rdiv == 1 &&
            scale_cols >= 1 && scale_cols <= kGidxMaxGroups && aligned16(col_group) && aligned16(a) && aligned16(b) &&
-           rows * cdiv64(cols / 8, 2 * kBlock) < ((int64_t)1 << 31);
+           cdiv64(rows, kGidxRows) * cdiv64(cols / 8, kBlock) < ((int64_t)1 << 31);
 }
 template <bool COMPRESS>
 static int launch_w4_gidx(const W4Params& w, int dt, const void* zp, const int32_t* col_group, int64_t rows, ct_stream_t stream, const char* what) {
-    if (!COMPRESS || w.upr % kGidxCompressUnits == 0) {  // R rows per workgroup (w4_gidx_rows_kernel); a lane needs whole units
-        const int chunks = (int)cdiv64(w.upr, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits) * kBlock);
-        dim3 g((unsigned)(cdiv64(rows, kGidxRows) * chunks));
-#define CT_GIDXR(DT, ZP) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows)
-        if (dt == CT_BF16) { if (zp) CT_GIDXR(CT_BF16, true); else CT_GIDXR(CT_BF16, false); }
-        else { if (zp) CT_GIDXR(CT_F16, true); else CT_GIDXR(CT_F16, false); }
+    const int chunks = (int)cdiv64(w.upr, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits) * kBlock);
+    dim3 g((unsigned)(cdiv64(rows, kGidxRows) * chunks));
+#define CT_GIDXR(DT, ZP) do { if (w.scale_cols <= kGidxSmallGroups) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS, kGidxRows, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits), kGidxSmallGroups>), \
+                                                                                       g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows); \
+                              else hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows); } while (0)
+    if (dt == CT_BF16) { if (zp) CT_GIDXR(CT_BF16, true); else CT_GIDXR(CT_BF16, false); }
+    else { if (zp) CT_GIDXR(CT_F16, true); else CT_GIDXR(CT_F16, false); }
 #undef CT_GIDXR
-        return hip_check(hipGetLastError(), what);
-    }
-    const int chunks = (int)cdiv64(w.upr, 2 * kBlock);
-    dim3 g((unsigned)(rows * chunks));
-#define CT_GIDX(DT, ZP) hipLaunchKernelGGL((w4_gidx_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks)
-    if (dt == CT_BF16) { if (zp) CT_GIDX(CT_BF16, true); else CT_GIDX(CT_BF16, false); }
-    else { if (zp) CT_GIDX(CT_F16, true); else CT_GIDX(CT_F16, false); }
-#undef CT_GIDX
     return hip_check(hipGetLastError(), what);
 }
 

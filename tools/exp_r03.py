@@ -53,3 +53,10 @@ if what == "bm":
 elif what == "m24":
     r = B.marlin24_leg(dev)
     print(json.dumps({k: v for k, v in r.items() if "us" in k or "exact" in k}))
+elif what == "w4pts":
+    out = {}
+    for key, kw in (("actorder", dict(n=B.N, actorder=True)), ("actorder_asym", dict(n=B.N, actorder=True, symmetric=False)), ("bf16_4096", dict(n=4096))):
+        r = B.w4_kernel_point(dev, **kw)
+        out[key] = (r["compress_us"], r["decompress_us"], r["round_trip_equals_fake_quantize"])
+        torch.cuda.empty_cache()
+    print(json.dumps(out))

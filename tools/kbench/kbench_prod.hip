@@ -86,8 +86,8 @@ static void gidx_compress(Sets& S, const int32_t* cg, bool zp) {
     const double bytes = (2.0 + 0.5 + 2.0 / 128 + (zp ? 1.0 / 128 : 0)) * S.rows * S.cols;
     double us = timed([&](int i) {
         W4Params w = make_w4(S.w[i % S.n], S.scale, zp ? S.zp : nullptr, CT_I8, S.pk[i % S.n], S.rows, S.cols, 1, S.cols, S.cols / 128);
-        if (zp) hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, true, true, R, UL>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
-        else hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, false, true, R, UL>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
+        if (zp) hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, true, true, R, UL, kGidxSmallGroups>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
+        else hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, false, true, R, UL, kGidxSmallGroups>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
     }, 40);
     snprintf(name, sizeof name, "g_idx compress  %lldx%lld %s R=%d UL=%d", (long long)S.rows, (long long)S.cols, zp ? "asym" : "sym ", R, UL);
     rep(name, us, bytes);
@@ -101,8 +101,8 @@ static void gidx_decompress(Sets& S, const int32_t* cg, bool zp) {
     const double bytes = (2.0 + 0.5 + 2.0 / 128 + (zp ? 1.0 / 128 : 0)) * S.rows * S.cols;
     double us = timed([&](int i) {
         W4Params w = make_w4(S.pk[(i + S.n / 2) % S.n], S.scale, zp ? S.zp : nullptr, CT_I8, S.out[i % S.n], S.rows, S.cols, 1, S.cols, S.cols / 128);
-        if (zp) hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, true, false, R, UL>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
-        else hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, false, false, R, UL>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
+        if (zp) hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, true, false, R, UL, kGidxSmallGroups>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
+        else hipLaunchKernelGGL((w4_gidx_rows_kernel<CT_BF16, false, false, R, UL, kGidxSmallGroups>), g, dim3(kBlock), 0, 0, w, cg, chunks, S.rows);
     }, 40);
     snprintf(name, sizeof name, "g_idx decompress %lldx%lld %s R=%d UL=%d", (long long)S.rows, (long long)S.cols, zp ? "asym" : "sym ", R, UL);
     rep(name, us, bytes);
@@ -162,14 +162,11 @@ int main(int argc, char** argv) {
         std::shuffle(cg.begin(), cg.end(), std::mt19937(7));
         for (auto& v : cg) v /= 128;
         int32_t* d_cg; CK(hipMalloc(&d_cg, 8192 * 4)); CK(hipMemcpy(d_cg, cg.data(), 8192 * 4, hipMemcpyHostToDevice));
-        gidx_compress<4, 4>(S, d_cg, false); gidx_compress<2, 4>(S, d_cg, false); gidx_compress<1, 4>(S, d_cg, false);
-        gidx_compress<4, 2>(S, d_cg, false); gidx_compress<2, 2>(S, d_cg, false); gidx_compress<8, 2>(S, d_cg, false);
-        gidx_compress<4, 1>(S, d_cg, false); gidx_compress<8, 1>(S, d_cg, false);
-        gidx_compress<2, 4>(S, d_cg, true); gidx_compress<4, 2>(S, d_cg, true);
-        gidx_decompress<4, 2>(S, d_cg, false); gidx_decompress<2, 2>(S, d_cg, false); gidx_decompress<8, 2>(S, d_cg, false);
-        gidx_decompress<4, 4>(S, d_cg, false); gidx_decompress<8, 1>(S, d_cg, false); gidx_decompress<4, 1>(S, d_cg, false);
-        gidx_decompress<4, 2>(S, d_cg, true); gidx_decompress<8, 2>(S, d_cg, true); gidx_decompress<4, 1>(S, d_cg, true);
-        gidx_compress<4, 1>(S, d_cg, true); gidx_compress<3, 2>(S, d_cg, false); gidx_compress<6, 2>(S, d_cg, false);
+        gidx_compress<4, 2>(S, d_cg, false); gidx_compress<8, 2>(S, d_cg, false); gidx_compress<2, 2>(S, d_cg, false); gidx_compress<4, 4>(S, d_cg, false);
+        gidx_compress<8, 1>(S, d_cg, false); gidx_compress<4, 1>(S, d_cg, false);
+        gidx_compress<4, 2>(S, d_cg, true); gidx_compress<8, 2>(S, d_cg, true); gidx_compress<4, 4>(S, d_cg, true);
+        gidx_decompress<4, 1>(S, d_cg, false); gidx_decompress<8, 1>(S, d_cg, false); gidx_decompress<8, 2>(S, d_cg, false); gidx_decompress<4, 2>(S, d_cg, false);
+        gidx_decompress<4, 1>(S, d_cg, true); gidx_decompress<8, 1>(S, d_cg, true); gidx_decompress<4, 2>(S, d_cg, true);
     }
     if (all || !strcmp(what, "small")) {
         for (auto sh : {std::pair<int64_t, int64_t>{4096, 4096}, {2048, 5632}, {8192, 4096}, {8192, 8192}}) {
