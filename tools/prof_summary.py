@@ -26,9 +26,13 @@ def main():
         f"select name, count(*), avg(duration), min(duration), max(duration), sum(duration), "
         f"max(grid_x), max(workgroup_x), max(vgpr_count), max(sgpr_count), max(lds_size) from kernels {flt} group by name order by sum(duration) desc"))
     print(f"# rocprofv3 kernel-trace summary of {path}")
-    print(f"{'kernel':<92} {'calls':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'grid':>9} {'wg':>5} {'vgpr':>5} {'sgpr':>5} {'lds':>6}")
+    print("# full_n / full_avg_us / full_med_us: the dispatches at the kernel's LARGEST grid only (the benchmark's workload, without the small parity-gate launches)")
+    print(f"{'kernel':<92} {'calls':>6} {'avg_us':>9} {'min_us':>9} {'max_us':>9} {'grid':>9} {'wg':>5} {'vgpr':>5} {'sgpr':>5} {'lds':>6} {'full_n':>7} {'full_avg_us':>11} {'full_med_us':>11}")
     for name, n, avg, mn, mx, tot, gx, wx, vg, sg, lds in rows:
-        print(f"{short(name):<92} {n:>6} {avg/1e3:>9.2f} {mn/1e3:>9.2f} {mx/1e3:>9.2f} {gx:>9} {wx:>5} {vg:>5} {sg:>5} {lds:>6}")
+        full = sorted(d for (d,) in cur.execute("select duration from kernels where name = ? and grid_x = ?", (name, gx)))
+        favg = sum(full) / len(full) / 1e3 if full else 0.0
+        fmed = full[len(full) // 2] / 1e3 if full else 0.0
+        print(f"{short(name):<92} {n:>6} {avg/1e3:>9.2f} {mn/1e3:>9.2f} {mx/1e3:>9.2f} {gx:>9} {wx:>5} {vg:>5} {sg:>5} {lds:>6} {len(full):>7} {favg:>11.2f} {fmed:>11.2f}")
     try:
         flt2 = "" if show_all else "where kernel_name like '%ct::%'"
         crow = list(cur.execute(

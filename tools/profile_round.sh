@@ -7,7 +7,7 @@
 # with the small TinyLlama-shaped launches; "extras": the whole default bench (all legs).
 #   usage: tools/profile_round.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p "$OUT"
@@ -22,10 +22,11 @@ run() {  # name, rocprof args..., -- cmd
 }
 cp "$ROOT/compressed_tensors_amd/libct_hip.so.srchash" "$OUT/srchash" 2>/dev/null
 run headline_trace --stats -d /tmp/prof_$TAG/headline_trace -o run -- $HEAD
+export CT_BENCH_WARM_SCALE=0.1  # counter passes: per-kernel counters do not depend on clocks
 run headline_fetch --pmc FETCH_SIZE -d /tmp/prof_$TAG/headline_fetch -o run -- $HEAD
 run headline_write --pmc WRITE_SIZE -d /tmp/prof_$TAG/headline_write -o run -- $HEAD
 run headline_sq --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d /tmp/prof_$TAG/headline_sq -o run -- $HEAD
-run extras_trace --stats -d /tmp/prof_$TAG/extras_trace -o run -- $FULL
+CT_BENCH_WARM_SCALE=1 run extras_trace --stats -d /tmp/prof_$TAG/extras_trace -o run -- $FULL
 run extras_fetch --pmc FETCH_SIZE -d /tmp/prof_$TAG/extras_fetch -o run -- $FULL
 run extras_write --pmc WRITE_SIZE -d /tmp/prof_$TAG/extras_write -o run -- $FULL
 rm -f "$OUT"/*_fetch.stdout "$OUT"/*_write.stdout "$OUT"/*_sq.stdout
