@@ -1052,7 +1052,8 @@ __device__ __forceinline__ unsigned long long op_load(const unsigned long long* 
 // next / p2 (compact) — bit-exact, but 69-87 us: every batch's prefix depends on every earlier batch, so each batch step is a chip-wide
 // synchronisation (ticket + load + hop, three dependent memory round trips of 2-3 us under load for 64 KB of work); (3) delaying the
 // start of blocks [CUs, 2 CUs) by one load phase so that a CU's two workgroups alternate load / store phases: 48.2 -> 44.6 us, kept for
-// launches of at least two residency rounds.
+// launches of at least two residency rounds; (4) other workgroup shapes without the stagger — 4 waves x 4 tiles (four per CU) 47.9 us,
+// 8 x 2 (three per CU) 46.8, 8 x 3 50.5, 4 x 2 (six per CU) 47.9 against 48.2 for 8 x 4: the shape is not the lever either.
 typedef u32x4 u32x4_a2_t __attribute__((aligned(2)));
 constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB, 64 VGPRs)
 constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
