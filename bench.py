@@ -100,9 +100,14 @@ def device_warmup(fns, min_ms):
             for f in fns:
                 f(i)
             i += 1
+        if (time.perf_counter() - t0) * 1e3 >= 0.6 * min_ms and "busy" not in CLOCKS:
+            CLOCKS["busy"] = read_clocks()  # sampled while the queue is full: the clocks the timed region runs at
         torch.cuda.synchronize()
         if (time.perf_counter() - t0) * 1e3 >= min_ms:
             return i
+
+
+CLOCKS = {}
 
 
 def median(xs):
@@ -1318,7 +1323,7 @@ def main():
                          "ms_per_step_blocks": [round(x / a.steps * 1e3, 5) for x in blocks],
                          "ms_per_step_blocks_one_stream": [round(x / a.steps * 1e3, 5) for x in blocks_one],
                          "ms_per_step_without_device_warmup": round(cold[0] / a.steps * 1e3, 5) if cold else None,
-                         "clocks_before": clocks_before, "clocks_after": clocks_after},
+                         "clocks_idle_before": clocks_before, "clocks_under_load": CLOCKS.get("busy"), "clocks_idle_after": clocks_after},
                 "kernels": [dict(kernel=k, config=f"W4A16 g128 {N}x{N} bf16", alg_bytes=one, us=v["avg_us"], min_us=v.get("min_us"), max_us=v.get("max_us"),
                                  GBps=v["GBps"], frac=v["frac"], valu_busy_frac=v.get("valu_busy_frac")) for k, v in kernels.items()],
             },
