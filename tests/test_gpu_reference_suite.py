@@ -99,6 +99,22 @@ def test_reference_forward_tests_accelerator_vs_cpu(tmp_path):
     _check(hip, up, "forward", ("ct_quantize", "ct_quantize_fp8", "ct_quantize_fp4"), min_passed=80)
 
 
+def test_reference_model_compressor_and_float_format_tests(tmp_path):
+    """tests/test_compressors/model_compressors/test_model_compressor.py (ModelCompressor.compress_model / decompress_model over whole
+    models, format inference, the 2-GPU cases skip themselves) and the FP8 / FP4 / MX codec tests, on GPU tensors (default device
+    "cuda") through the swapped registry and the rebound class names"""
+    files = ["tests/test_compressors/model_compressors/test_model_compressor.py", "tests/test_compressors/test_fp8_quant.py",
+             "tests/test_compressors/test_fp4_quant.py", "tests/test_compressors/test_mxfp4_quant.py", "tests/test_compressors/test_mxfp8_quant.py",
+             "tests/test_compressors/test_fp4_optimizations.py"]
+    hip = run_reference_tests(files, install=True, default_cuda=True, report=str(tmp_path / "hip.json"))
+    up = run_reference_tests(files, install=False, default_cuda=True, report=str(tmp_path / "up.json"))
+    _check(hip, up, "model_and_float_cuda", (), min_passed=30)
+    assert sum(hip["launches"].values()) > 0, "no launch reached libct_hip.so"
+    plain = run_reference_tests(files, install=True, report=str(tmp_path / "plain.json"))
+    plain_up = run_reference_tests(files, install=False, report=str(tmp_path / "plain_up.json"))
+    _check(plain, plain_up, "model_and_float", (), min_passed=30)
+
+
 # ----------------------------------------------------------------------------- install()ed GPU outputs == the reference's CPU outputs
 @pytest.fixture(scope="module")
 def upstream():
