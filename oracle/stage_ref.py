@@ -15,6 +15,7 @@ snapshot, like the built .so files).  `oracle/ref_import.py` unpacks it into a t
     tests/test_compressors/*.py                  incl. test_compress_decompress_module.py (@requires_gpu), test_pack_quant.py,
                                                  test_int_quant.py, test_packed_asym_decompression.py
     tests/test_quantization/lifecycle/*.py       test_forward.py's accelerator-vs-CPU comparisons (:765-1150)
+    tests/test_offload/conftest.py               the `torchrun` decorator test_model_compressor.py imports
 
 `__graft_entry__.build()` runs this whenever /root/reference is present.  Nothing here is read by compressed_tensors_amd.
 """
@@ -31,7 +32,8 @@ ARCHIVE = os.path.join(OUT_DIR, "reference_stage.tar.gz")
 
 WANT_DIRS = ("src/compressed_tensors", "tests/test_compressors", "tests/test_quantization/lifecycle")
 WANT_FILES = ("tests/__init__.py", "tests/conftest.py", "tests/mock_observer.py", "tests/testing_utils.py",
-              "tests/test_quantization/__init__.py")
+              "tests/test_quantization/__init__.py",
+              "tests/test_offload/__init__.py", "tests/test_offload/conftest.py")  # test_model_compressor.py imports its `torchrun` helper
 
 
 def _members():

@@ -51,3 +51,12 @@ def test_staged_archive_imports_and_runs_the_references_codec_tests(tmp_path):
     rep = json.load(open(report))
     assert r.returncode == 0 and not rep["failed"] and len(rep["passed"]) >= 100, r.stdout[-2000:]
     assert not rep["launches"]  # CPU tensors: the HIP subclass defers to upstream
+    # every staged test module the GPU suite runs must at least IMPORT from the archive alone (a helper module missing from the
+    # archive only shows on the GPU box otherwise: tests.test_offload.conftest did)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-p", "ct_ref_plugin", "-p", "no:cacheprovider", "-q", "--collect-only",
+                        "tests/test_compressors/test_compress_decompress_module.py", "tests/test_compressors/test_packed_asym_decompression.py",
+                        "tests/test_compressors/model_compressors/test_model_compressor.py", "tests/test_compressors/test_fp8_quant.py",
+                        "tests/test_compressors/test_fp4_quant.py", "tests/test_compressors/test_mxfp4_quant.py", "tests/test_compressors/test_mxfp8_quant.py",
+                        "tests/test_compressors/test_fp4_optimizations.py", "tests/test_quantization/lifecycle/test_forward.py"],
+                       cwd=root, env=dict(env, CT_REF_INSTALL="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "error" not in r.stdout.lower().split("warnings")[0][-300:], r.stdout[-3000:]
