@@ -50,6 +50,17 @@ def _fp4_compressible(state_dict, group) -> bool:
             and w.shape[1] % group == 0)
 
 
+def _fp4_decompressible(state_dict, group) -> bool:
+    """the stored layout the FP4 decompress kernel reads: (rows, cols / 2) bytes with one scale per `group` columns.  Anything else —
+    upstream infers the group from the scale's shape and accepts e.g. a (1, 4) weight with a (1, 2) scale under group_size 32,
+    tests/test_compressors/test_mxfp4_quant.py:60-84 — is upstream's"""
+    p, sc = state_dict.get("weight_packed"), state_dict.get("weight_scale")
+    if p is None or sc is None or not p.is_cuda or p.dim() != 2 or sc.dim() != 2:
+        return False
+    cols = p.shape[1] * 2
+    return cols % group == 0 and tuple(sc.shape) == (p.shape[0], cols // group)
+
+
 def make_hip_subclass(up_cls, amd_cls):
     """A subclass of the upstream codec `up_cls` (so `can_compress`, `compression_param_names`, `compress_module`,
     `decompress_module` and any upstream helper are inherited) whose `compress` / `decompress` run `amd_cls`'s HIP
@@ -73,8 +84,10 @@ def make_hip_subclass(up_cls, amd_cls):
         def decompress(cls, state_dict, scheme):
             probe = state_dict.get("weight_packed", state_dict.get("weight"))
             ours = _fp4_weights(scheme) if fp4_group is not None else _int_weights(scheme)
-            if ours and _on_gpu(probe) and fp4_group is not None:
+            if ours and fp4_group is not None and _fp4_decompressible(state_dict, fp4_group):
                 return amd_cls.decompress(state_dict, scheme)
+            if fp4_group is not None:
+                return up_cls.decompress.__func__(cls, state_dict, scheme)
             if ours and _on_gpu(probe):
                 return amd_cls.decompress.__func__(cls, state_dict, scheme)
             return up_cls.decompress.__func__(cls, state_dict, scheme)
