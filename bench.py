@@ -12,6 +12,12 @@ numbers are HBM-cold.  The timed loop issues the step's two independent launches
 (`value`); the same loop on one stream is reported as `value_one_stream`, and the per-kernel
 roofline figures are single-stream HIP-event timings of back-to-back launches.
 
+Protocol (round 3): 250 ms of the real launches before any timed region (independent of
+--warmup: a fresh lease measures ~5 % low for its first milliseconds), then --warmup steps, then 5 blocks of
+EXACTLY --steps steps, each bracketed by barrier + torch.cuda.synchronize() and max-reduced over the ranks;
+`ms_per_step` is the MEDIAN block (all blocks, and one block timed without the device warm-up, are in
+roofline.step).  Every extra leg's kernel row is also appended to roofline.kernels[].
+
 value = algorithmic bytes of all ranks / max-over-ranks wall time, in GB/s; algorithmic bytes
 per step = 2 x (2 N^2 + 2 N^2/128 + N^2/2) = 337,641,472 B at N = 8192.
 Multi-GPU (--gpus N, launched by torch.distributed.run): every rank processes its own weight
@@ -346,10 +352,11 @@ def staged_reference():
 def cpu_baseline(dev):
     """The reference's CPU path on this box's host cores, next to the GPU number (baseline, not the target).
 
-    /root/reference does not exist on the GPU box, so what is timed is oracle/eager_ref.py: the reference's own eager torch
-    op sequence (quantize: divide / add / clamp / round / cast passes in bf16; pack: int32 upcast, shifts, scatter_add_;
-    unpack: gather of a (rows x groups, 32) int32 matrix; dequantize), pinned bit-for-bit against the reference itself in the
-    build container (tests/test_oracle_golden.py) and measured there within 10 % of the reference's own time.
+    When the reference is importable — /root/reference in the build container, the archive oracle/stage_ref.py staged under
+    oracle/_ref on the GPU box — the reference's OWN PackedQuantizationCompressor.compress / .decompress is timed on CPU tensors and
+    reported (`kind: "reference"`).  Beside it (and alone, `kind: "port"`, when no reference is present): oracle/eager_ref.py, the
+    reference's eager torch op sequence restated (quantize: divide / add / clamp / round / cast passes in bf16; pack: int32 upcast,
+    shifts, scatter_add_; unpack: gather of a (rows x groups, 32) int32 matrix; dequantize), pinned bit-for-bit against the reference.
     torch.set_num_threads(os.cpu_count()); 1 warm-up + min of 3.  Its outputs check the GPU path on the same tensor.
     The C/OpenMP oracle (a stronger baseline than the reference) is reported as `cpu_baseline_port`."""
     O = _oracle()
