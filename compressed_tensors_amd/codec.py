@@ -155,7 +155,7 @@ def _col_group_of(g_idx: torch.Tensor, group_size: int) -> torch.Tensor:
     that still holds a -1 (not initialised) means plain column order.  The reference decides that with `-1 in g_idx`, a host read
     per call; here the choice is a device-side select — no synchronisation — and the table is cached on the g_idx tensor itself
     (keyed by its version counter), so a module's repeated compress / decompress calls pay the two sorts once."""
-    key = (g_idx._version, int(group_size), g_idx.device)
+    key = (g_idx.data_ptr(), g_idx._version, g_idx.numel(), int(group_size), g_idx.device)  # (a `.data` swap keeps the version counter)
     hit = getattr(g_idx, "_ct_col_group", None)
     if hit is not None and hit[0] == key:
         return hit[1]
