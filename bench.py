@@ -709,26 +709,11 @@ def marlin24_leg(dev):
     exact = all(out[k].shape == ref[k].shape and torch.equal(out[k].cpu().contiguous().view(torch.int16 if out[k].dtype == torch.float16 else out[k].dtype),
                                                              ref[k].contiguous().view(torch.int16 if ref[k].dtype == torch.float16 else ref[k].dtype))
                 for k in ("weight_packed", "scale_packed", "meta"))
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 18
     M = cta.Marlin24Compressor
-    with M.deferred_structure_check():  # warm-up
-        for i in range(4):
-            M.compress(sds[i % len(sds)], scheme)
-    torch.cuda.synchronize()
-    start.record()
-    with M.deferred_structure_check():  # the batch form ModelCompressor uses: the 2:4 violation flags are read once, at the exit
-        for i in range(iters):
-            M.compress(sds[i % len(sds)], scheme)
-    stop.record()
-    torch.cuda.synchronize()
-    us = start.elapsed_time(stop) * 1000.0 / iters
-    start.record()
-    for i in range(iters):  # upstream's semantics: the ValueError is raised by the call itself (one host read per tensor)
-        M.compress(sds[i % len(sds)], scheme)
-    stop.record()
-    torch.cuda.synchronize()
-    us_strict = start.elapsed_time(stop) * 1000.0 / iters
+    with M.deferred_structure_check():  # the batch form ModelCompressor uses: the 2:4 violation flags are read once (per 1024 calls / at the exit)
+        us = time_kernel(lambda i: M.compress(sds[i % len(sds)], scheme), 18)
+    # upstream's semantics: the ValueError is raised by the call itself (one host read per tensor)
+    us_strict = time_kernel(lambda i: M.compress(sds[i % len(sds)], scheme), 18)
     # the kernels alone, through the C ABI
     from compressed_tensors_amd import _lib
 

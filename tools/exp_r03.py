@@ -60,3 +60,32 @@ elif what == "w4pts":
         out[key] = (r["compress_us"], r["decompress_us"], r["round_trip_equals_fake_quantize"])
         torch.cuda.empty_cache()
     print(json.dumps(out))
+elif what == "m24prof":
+    import cProfile, pstats, io
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd import codec
+    N = 8192
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    g = torch.Generator(device=dev).manual_seed(13)
+    w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+    w = w * codec.sparse24_mask(w).to(w.dtype)
+    scale, zp = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+    sd = {"weight": w, "weight_scale": scale, "weight_zero_point": zp}
+    M = cta.Marlin24Compressor
+    with M.deferred_structure_check():
+        for _ in range(50):
+            M.compress(sd, scheme)
+    torch.cuda.synchronize()
+    import time
+    pr = cProfile.Profile()
+    with M.deferred_structure_check():
+        t0 = time.perf_counter()
+        pr.enable()
+        for _ in range(400):
+            M.compress(sd, scheme)
+        pr.disable()
+        host = (time.perf_counter() - t0) / 400 * 1e6
+    torch.cuda.synchronize()
+    st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14)
+    print("host us per call (profiled)", round(host, 1)); print(st.getvalue()[:3500])
