@@ -89,3 +89,23 @@ elif what == "m24prof":
     torch.cuda.synchronize()
     st = io.StringIO(); pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14)
     print("host us per call (profiled)", round(host, 1)); print(st.getvalue()[:3500])
+elif what == "bmstamps":
+    from compressed_tensors_amd import _lib
+    import numpy as np
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator(device=dev).manual_seed(11)
+    N = 8192; nsets = 8
+    ws_ = [torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g).masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0) for _ in range(nsets)]
+    ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+    wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+    vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev); bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+    f = lambda i: lib.ct_bitmask_compress(ws_[i % nsets].data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes, stream)
+    us = B.time_kernel(f, 40)
+    torch.cuda.synchronize()
+    st = wk[8196: 8196 + 4 * 512].reshape(512, 4).cpu().double().numpy()
+    t0 = st[:, 1].min()
+    a = (st - t0) / 100.0
+    out = {"us": round(us, 2)}
+    for name, sl in (("blocks_0_255", slice(0, 256)), ("blocks_256_511", slice(256, 512))):
+        out[name] = {"published": round(float(np.median(a[sl, 1])), 1), "pass2_done": round(float(np.median(a[sl, 0])), 1), "resolved": round(float(np.median(a[sl, 2])), 1), "done": round(float(np.median(a[sl, 3])), 1)}
+    print(json.dumps(out))
