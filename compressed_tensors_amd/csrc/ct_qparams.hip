@@ -92,13 +92,31 @@ __global__ __launch_bounds__(kBlock) void qparams_absmax_kernel(const u32x4* __r
         const int64_t u = base + (int64_t)i * kBlock;
         r[i] = u < units ? x[u] : u32x4{0u, 0u, 0u, 0u};
     }
+    uint32_t acc[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
-        const int64_t u = base + (int64_t)i * kBlock;
-        uint32_t acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(0u, r[i].x), r[i].y), r[i].z), r[i].w);
-        acc = absmax_group_reduce(acc, upg);
-        if (u < units && (threadIdx.x & (upg - 1)) == 0) {
-            const MinMax m = absmax_finish<XDT>(acc);
+        acc[i] = absmax_acc(absmax_acc(absmax_acc(absmax_acc(0u, r[i].x), r[i].y), r[i].z), r[i].w);
+        acc[i] = absmax_group_reduce(acc[i], upg);
+    }
+    // Round 3: the scale arithmetic (IEEE divides, the zero-point rounding: ~80 vector instructions) used to run once per load, with
+    // one lane in `upg` active — for group 128 four passes per wave with 4 live lanes each, ~320 of the wave's ~400 instructions: the
+    // kernel was issue-bound next to a 21.3 us read.  The wave's U * 64 / upg group maxima are first gathered into consecutive lanes
+    // (lane L takes load L / gpl, group L % gpl; one ds_bpermute per load) and evaluated in ONE pass.
+    const int lane = threadIdx.x & 63;
+    const int gpl = 64 / upg;            // groups per load instruction and wave (upg is a power of two <= 64)
+    const int ngr = U * gpl;             // groups of this wave: <= 4 * 64
+    for (int g0 = 0; g0 < ngr; g0 += 64) {  // one trip unless upg == 1 with U > 1
+        const int gi = g0 + lane;           // this lane's group within the wave
+        const int li = gi / gpl, lk = gi - li * gpl;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t v = (uint32_t)__shfl((int)acc[i], lk * upg, 64);
+            mine = li == i ? v : mine;
+        }
+        const int64_t u = (int64_t)blockIdx.x * kBlock * U + (int64_t)li * kBlock + (threadIdx.x & ~63) + lk * upg;  // first unit of the group
+        if (gi < ngr && u < units) {
+            const MinMax m = absmax_finish<XDT>(mine);
             if (kind == QP_INT) emit_qparams<XDT>(m, bits, 1, scale_out, zp_out, u / upg);
             else emit_qparams_float<XDT>(m, kind, gscale, scale_out, u / upg);
         }
