@@ -612,6 +612,8 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     constexpr bool NEWTON = !(XDT == CT_BF16 && SDT == CT_BF16);
     __shared__ __attribute__((aligned(16))) uint16_t s_meta[8][128];
     __shared__ __attribute__((aligned(16))) uint8_t s_code[64][128 + 8];  // +8: rows start on different banks
+    __shared__ float s_rs[64][16];                 // reciprocal of the (row, group) scale, 0 = the words of that group take the exact path
+    __shared__ float s_s16[NEWTON ? 64 : 1][16];   // the fp16 scale itself (Newton step of the fp16 forms)
     const int tiles_c = (int)(k / 256);
     const int tile_r = (int)(blockIdx.x / (unsigned)tiles_c), tile_c = (int)(blockIdx.x - (unsigned)tile_r * (unsigned)tiles_c);
     const int tid = threadIdx.x;
@@ -630,31 +632,45 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     bool violation = false;
     // all 128 bytes of this lane's four words are requested before the first one is used
     u32x4 wa[4], wb[4];
-    uint32_t sbits[4];
-    int zs[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int64_t r = (int64_t)tile_r * 64 + it * 16 + rl0;
-        const int64_t si = r * scale_cols + grp;
-        sbits[it] = scale[si];
-        zs[it] = zp != nullptr ? (int)zp[si] : 0;
         const u32x4* in = reinterpret_cast<const u32x4*>(w + r * k + (int64_t)mc * 16);
         wa[it] = in[0];
         wb[it] = in[1];
     }
+    // Round 3: the tile's scales — 64 rows x (at most 16, for group 128 two) groups — are converted ONCE, cooperatively, while the
+    // weights are in flight: scale.to(fp16), the lean-range test and the IEEE reciprocal used to be recomputed by every thread for
+    // each of its four words (1024 divisions per tile for 128 distinct scales, plus eight small loads per thread).  A group whose
+    // zero point is not zero gets reciprocal 0, which sends its words to the exact path like an out-of-range scale does.
+    const uint32_t g_first = per_pow2 ? (((uint32_t)tile_c * 16u) >> per_shift) : (((uint32_t)tile_c * 16u) / per);
+    const uint32_t g_last = per_pow2 ? (((uint32_t)tile_c * 16u + 15u) >> per_shift) : (((uint32_t)tile_c * 16u + 15u) / per);
+    const int ng = (int)(g_last - g_first) + 1;  // <= 16
+    for (int e = tid; e < 64 * ng; e += kBlock) {
+        const int rl = e / ng, gi = e - rl * ng;
+        const int64_t si = ((int64_t)tile_r * 64 + rl) * scale_cols + g_first + gi;
+        const uint32_t sb = scale[si];
+        const float s16 = SDT == CT_F16 ? f16_bits_to_f(sb) : round_to<CT_F16>(bf16_bits_to_f(sb));  // scale.to(fp16)
+        float rs = m24_lean_rcp(s16);
+        if (zp != nullptr && zp[si] != 0) rs = 0.0f;
+        s_rs[rl][gi] = rs;
+        if (NEWTON) s_s16[rl][gi] = s16;
+    }
+    __syncthreads();
+    const int gl = (int)(grp - g_first);
     uint32_t redo = 0;  // words the range test rejected
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int rl = it * 16 + rl0;  // (rl >> 3) advances by 2 per iteration -> the metadata row by 8
         const uint32_t ws[8] = {wa[it].x, wa[it].y, wa[it].z, wa[it].w, wb[it].x, wb[it].y, wb[it].z, wb[it].w};
-        const float s16 = SDT == CT_F16 ? f16_bits_to_f(sbits[it]) : round_to<CT_F16>(bf16_bits_to_f(sbits[it]));  // scale.to(fp16)
-        const float rs = m24_lean_rcp(s16);
+        const float rs = s_rs[rl][gl];
+        const float s16 = NEWTON ? s_s16[rl][gl] : 0.0f;  // only the Newton step reads the scale itself
         u32x2 codes;
         uint32_t word;
         float sumsq = 0.0f;
         uint32_t vm = 0;
         marlin24_word_lean<XDT, NEWTON>(ws, s16, rs, codes, word, vm, sumsq);
-        const bool special = !(sumsq <= m24_limit<XDT>::v) || rs == 0.0f || zs[it] != 0;
+        const bool special = !(sumsq <= m24_limit<XDT>::v) || rs == 0.0f;
         redo |= special ? (1u << it) : 0u;
         vmax = (!special && vm > vmax) ? vm : vmax;
         *reinterpret_cast<u32x2*>(&s_code[rl][cl * 8]) = codes;
