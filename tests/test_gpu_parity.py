@@ -515,6 +515,30 @@ def test_w4a16_full_size_other_layouts(cta, dev, variant):
     assert torch.equal(dd["weight"].cpu(), O.fake_quantize(w, scale, zp, g_idx=g_idx, **kw))
 
 
+@pytest.mark.parametrize("shape", [(2048, 5632), (8192, 4096), (4096, 8192 + 128)], ids=["u4", "u8_exact_round", "u8"])
+@pytest.mark.parametrize("kind", ["w4_sym", "w4_asym", "int8", "w8_packed"])
+def test_decompress_side_one_residency_round(cta, dev, shape, kind):
+    """tensors that fit one residency round are decompressed with 4 or 8 units per lane (`decomp_unroll`, round 3): every kernel
+    that takes the unroll — W4 symmetric, W4 asymmetric (the row-leader form), int8 dequantize, 8-bit packed — against the oracle"""
+    rows, cols = shape
+    g = torch.Generator().manual_seed(rows + cols)
+    w = torch.randn(rows, cols, generator=g).to(BF16)
+    if kind.startswith("w4") or kind == "w8_packed":
+        bits = 4 if kind.startswith("w4") else 8
+        sym = kind != "w4_asym"
+        scale, zp = O.calculate_qparams_minmax(w, num_bits=bits, group_size=128, symmetric=sym)
+        kw = dict(num_bits=bits, strategy="group", group_size=128)
+        q = O.quantize(w, scale, zp, dtype=torch.int8, **kw)
+        packed = O.pack_to_int32(q, bits).contiguous()
+        got = cta.codec.unpack_and_dequantize(packed.to(dev), (rows, cols), scale.to(dev), None if sym else zp.to(dev), **kw)
+        assert eq(got.cpu(), O.dequantize(q, scale, None if sym else zp, strategy="group", group_size=128))
+    else:
+        scale, zp = O.calculate_qparams_minmax(w, num_bits=8, group_size=None, symmetric=True)
+        q = O.quantize(w, scale, zp, num_bits=8, strategy="channel", dtype=torch.int8)
+        got = cta.codec.dequantize_tensor(q.to(dev), scale.to(dev), None)
+        assert eq(got.cpu(), O.dequantize(q, scale, None))
+
+
 def test_int8_per_tensor_full_size(cta, dev):
     """BASELINE config 1 on the GPU path: int8 per-tensor symmetric, 4096x4096 bf16"""
     torch.manual_seed(0)
