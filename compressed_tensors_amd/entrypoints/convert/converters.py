@@ -103,6 +103,38 @@ def _args_from_dict(d: Optional[dict]) -> Optional[QuantizationArgs]:
     return QuantizationArgs(**known)
 
 
+_H2D_ALIGN = 256
+
+
+def _stage_to_device(state_dicts, dev, host_only=()):
+    """Move a shard's compressed tensors to the device through ONE pinned buffer and ONE copy.  The tensors safetensors
+    hands out are lazily mapped file pages: `t.to(device)` per tensor is a pageable copy that faults the file in 4 KB at a
+    time on the calling thread (23.0 ms for the 125 MB of a TinyLlama-shaped shard, half of `process`).  Here the I/O
+    threads copy the mapped pages into the pinned buffer in parallel, one asynchronous H2D moves it (6.7 ms together), and
+    the device tensors are views into the device buffer (256-byte aligned).  Replaces the entries of `state_dicts` in place; returns what must stay alive until
+    the stream is synchronised."""
+    from .safetensors_io import host_bytes, parallel_copy
+
+    plan, off = [], 0
+    for sd in state_dicts:
+        for key, t in sd.items():
+            if key in host_only or t is None or t.device.type != "cpu":
+                continue
+            t = t.contiguous()
+            n = t.numel() * t.element_size()
+            plan.append((sd, key, t, off, n))
+            off += (n + _H2D_ALIGN - 1) // _H2D_ALIGN * _H2D_ALIGN
+    if not plan:
+        return None
+    stage = torch.empty(off, dtype=torch.uint8, pin_memory=True)
+    flat = stage.numpy()
+    parallel_copy([(flat[o:o + n], host_bytes(t)) for _, _, t, o, n in plan if n])
+    dbuf = stage.to(dev, non_blocking=True)
+    for sd, key, t, o, n in plan:
+        sd[key] = dbuf[o:o + n].view(t.dtype).view(t.shape)
+    return stage, dbuf
+
+
 class CompressedTensorsDequantizer(Converter):
     """ct_dequantizer.py:21-171: dequantize a checkpoint in the compressed-tensors format to `dtype`"""
 
@@ -136,20 +168,18 @@ class CompressedTensorsDequantizer(Converter):
 
         dev = self.device or _lib.require_device()
         out: Dict[str, torch.Tensor] = {}
+        keep = []  # the pinned H2D staging buffers, alive until the stream has been synchronised below
         for scheme in self.schemes:
             comp = self._compressor(scheme)
             names = comp.compression_param_names(scheme)
             modules, state_dicts = [], []
             for module_name, _ in match_quantizable_tensors(tensors, self.ignore, scheme.targets, param_targets=[names[0]]):
-                sd = {}
-                for p in names:
-                    t = tensors.pop(f"{module_name}.{p}")
-                    # weight_shape stays on the host (upstream keeps it a CPU int64 tensor)
-                    sd[p] = t if p == "weight_shape" else t.to(dev, non_blocking=True)
+                # weight_shape stays on the host (upstream keeps it a CPU int64 tensor)
                 modules.append(module_name)
-                state_dicts.append(sd)
+                state_dicts.append({p: tensors.pop(f"{module_name}.{p}") for p in names})
             if not modules:
                 continue
+            keep.append(_stage_to_device(state_dicts, dev, host_only=("weight_shape",)))
             results = comp.decompress_many(state_dicts, scheme)  # one launch for the eligible modules
             weights = [res["weight"].to(self.dtype) for res in results]
             # ONE pinned staging buffer per scheme and shard (a pinned allocation per tensor costs more than its copy)
@@ -162,6 +192,7 @@ class CompressedTensorsDequantizer(Converter):
                 out[f"{module_name}.weight"] = host
                 off += n
         torch.cuda.current_stream(dev).synchronize()
+        del keep
         # remaining (ignored / untargeted) tensors pass through, KV-cache qparams are dropped
         for name, t in tensors.items():
             if name.endswith(KV_CACHE_PARAM_NAMES):

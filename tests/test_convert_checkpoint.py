@@ -278,3 +278,33 @@ def test_convert_checkpoint_shards_files_over_ranks(tmp_path):
     index = json.load(open(dst / "model.safetensors.index.json"))
     assert set(index["weight_map"]) == set(out) and index["metadata"]["total_size"] == total
     assert json.load(open(dst / "config.json")) == {"a": 2} and not list(dst.glob(".index_fragment*"))
+
+
+def test_write_safetensors_reads_back_with_the_safetensors_library(tmp_path):
+    """the zero-copy writer produces a file the safetensors library reads back bit for bit (mixed dtypes, an empty tensor,
+    a non-contiguous view); `parallel_copy` (the H2D staging of the dequantizer) moves a tensor larger than one piece"""
+    from compressed_tensors_amd.entrypoints.convert.safetensors_io import parallel_copy, write_safetensors
+
+    g = torch.Generator().manual_seed(3)
+    tensors = {"b.big": torch.randn(1200, 2048, generator=g).to(torch.bfloat16),  # 4.9 MB: two pieces
+               "a.i32": torch.randint(-2**31, 2**31 - 1, (33, 7), generator=g, dtype=torch.int32),
+               "c.empty": torch.empty(0, 5), "d.scalarish": torch.tensor([7], dtype=torch.int64),
+               "e.t": torch.randn(17, 9, generator=g).t(), "f.u8": torch.randint(0, 255, (1001,), generator=g, dtype=torch.uint8)}
+    if hasattr(torch, "float8_e4m3fn"):
+        tensors["g.f8"] = torch.randn(64, 32, generator=g).to(torch.float8_e4m3fn)
+    path = tmp_path / "out.safetensors"
+    write_safetensors(tensors, str(path))
+    back = load_file(str(path))
+    assert set(back) == set(tensors)
+    for k, t in tensors.items():
+        assert back[k].dtype == t.dtype and back[k].shape == t.shape, k
+        if t.numel():
+            assert torch.equal(back[k].contiguous().view(torch.uint8), t.contiguous().view(torch.uint8)), k
+    import numpy as np
+    from compressed_tensors_amd.entrypoints.convert.safetensors_io import host_bytes
+    src = host_bytes(tensors["b.big"])
+    dst = [np.zeros(src.size, dtype=np.uint8), np.zeros(1001, dtype=np.uint8)]
+    parallel_copy([(dst[0], src), (dst[1], host_bytes(tensors["f.u8"]))])
+    assert np.array_equal(dst[0], src) and np.array_equal(dst[1], tensors["f.u8"].numpy())
+    with pytest.raises(ValueError):
+        parallel_copy([(np.zeros(3, dtype=np.uint8), np.zeros(4, dtype=np.uint8))])
