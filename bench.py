@@ -574,8 +574,50 @@ def bitmask_leg(dev):
                "s24_workload": f"sparse-24-bitmask compress / decompress, {N}x{N} bf16 pruned 2:4, C ABI, {NB} rotating sets; 256 rows against the CPU oracle"}
     except Exception as e:
         s24 = {"s24_error": repr(e)}
+    # float32 payloads (older sparse checkpoints keep fp32 weights): the resident kernel moves them as pairs of halves
+    f32 = {}
+    try:
+        del items
+        torch.cuda.empty_cache()
+        F32, NF = _lib.F32, 4  # 4 x 268 MB of reads
+        sets32 = []
+        for _ in range(NF):
+            w = torch.randn(N, N, dtype=torch.float32, device=dev, generator=g)
+            w = w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0)
+            sets32.append(w)
+        v32 = torch.empty(N * N, dtype=torch.float32, device=dev)
+        bm32, ro32 = torch.empty(N, N // 8, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.int64, device=dev)
+        wk32 = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+        o32 = [torch.empty(N, N, dtype=torch.float32, device=dev) for _ in range(2)]
+
+        def c32(i):
+            lib.ct_bitmask_compress(sets32[i % NF].data_ptr(), F32, N, N, v32.data_ptr(), v32.numel(), bm32.data_ptr(), ro32.data_ptr(), wk32[-1:].data_ptr(),
+                                    wk32.data_ptr(), ws_bytes, stream)
+
+        us_c32 = time_kernel(c32, 12)
+        c32(0)
+        torch.cuda.synchronize()
+        nnz32 = int(wk32[-1].item())
+        w0 = sets32[0]
+        m0 = w0 != 0
+        cnt0 = m0.sum(-1)
+        ok32 = (nnz32 == int(cnt0.sum().item()) and torch.equal(v32[:nnz32], w0[m0]) and torch.equal(ro32, torch.cumsum(cnt0, 0) - cnt0)
+                and torch.equal(bm32, (m0.view(N, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8)))
+
+        def d32(i):
+            lib.ct_bitmask_decompress(v32.data_ptr(), nnz32, bm32.data_ptr(), ro32.data_ptr(), -1, F32, N, N, o32[i % 2].data_ptr(), stream)
+
+        us_d32 = time_kernel(d32, 12)
+        ok32 = ok32 and torch.equal(o32[0], w0)
+        alg32 = 4 * N * N + 4 * nnz32 + N * N // 8 + 8 * N
+        f32 = {"f32_alg_bytes": alg32, "f32_compress_us": round(us_c32, 2), "f32_compress_frac_hbm": round(alg32 / us_c32 / 1e3 / HBM_PEAK_GBPS, 4),
+               "f32_decompress_us": round(us_d32, 2), "f32_decompress_frac_hbm": round(alg32 / us_d32 / 1e3 / HBM_PEAK_GBPS, 4), "f32_bit_exact": bool(ok32),
+               "f32_workload": f"sparse-bitmask 50 % unstructured {N}x{N} float32, C ABI, {NF} rotating inputs; outputs against eager torch ops on the device"}
+        del sets32, v32, o32
+    except Exception as e:
+        f32 = {"f32_error": repr(e)}
     return {
-        **s24,
+        **s24, **f32,
         "workload": f"sparse-bitmask 50% unstructured {N}x{N} bf16 (nnz={nnz})",
         "alg_bytes": alg,
         "decompress_us": round(us_d, 2), "decompress_GBps": round(alg / us_d / 1e3, 1), "decompress_frac_hbm": round(alg / us_d / 1e3 / HBM_PEAK_GBPS, 4),
@@ -882,6 +924,9 @@ def roofline_rows(result):
         if "s24_compress_us" in b:
             row("sparse24_pair_kernel", "sparse-24-bitmask 8192x8192 bf16, compress", b["s24_alg_bytes"], b["s24_compress_us"], bit_exact=b["s24_bit_exact"])
             row("bitmask_decompress16_kernel<2:4 rows>", "sparse-24-bitmask 8192x8192 bf16, decompress", b["s24_alg_bytes"], b["s24_decompress_us"], bit_exact=b["s24_bit_exact"])
+        if "f32_compress_us" in b:
+            row("flat16_resident_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, compress", b["f32_alg_bytes"], b["f32_compress_us"], bit_exact=b["f32_bit_exact"])
+            row("bitmask_decompress_kernel<4>", "sparse-bitmask 50 % 8192x8192 float32, decompress", b["f32_alg_bytes"], b["f32_decompress_us"], bit_exact=b["f32_bit_exact"])
     k4 = leg("kernels_4096")
     if k4:
         row("w4_quant_pack_lean_kernel<bf16>", "W4A16 g128 4096x4096 bf16, compress", k4["alg_bytes_per_direction"], k4["compress_us"])

@@ -797,6 +797,21 @@ __device__ __forceinline__ uint32_t nz_mask16_fast(const u32x4& r, uint32_t keep
     return ((acc >> 15) & 0xaau) | (acc & 0x55u);
 }
 
+// 32-bit payloads seen as pairs of 16-bit halves: the unit's four non-zero flags, each doubled (bits 2j and 2j + 1 = element j), so that
+// ranks, compaction and stores below move both halves of a kept element.  keep = 0x7fffffff for floats, 0xffffffff for integers
+__device__ __forceinline__ uint32_t nz_mask32_pairs(const u32x4& r, uint32_t keep) {
+    return ((r.x & keep) ? 0x03u : 0u) | ((r.y & keep) ? 0x0cu : 0u) | ((r.z & keep) ? 0x30u : 0u) | ((r.w & keep) ? 0xc0u : 0u);
+}
+template <int ES>
+__device__ __forceinline__ uint32_t nz_mask_unit(const u32x4& r, uint32_t keep) {
+    if constexpr (ES == 4) return nz_mask32_pairs(r, keep);
+    else return nz_mask16_fast(r, keep);
+}
+// a doubled mask byte -> the element nibble (bits 0, 2, 4, 6)
+__device__ __forceinline__ uint32_t pair_mask_nibble(uint32_t b) {
+    return (b & 1u) | ((b >> 1) & 2u) | ((b >> 2) & 4u) | ((b >> 3) & 8u);
+}
+
 // ranks of a wave-tile's 4 x 64 units in unit order i * 64 + lane, from their non-zero counts (<= 8 each): two DPP wave scans over
 // packed pairs of 16-bit counts, interleaved (four separate scans were 20 DPP adds + ~50 hazard nops).  Returns the tile's total.
 __device__ __forceinline__ int tile_ranks(const uint32_t (&mm)[4], uint32_t (&rank)[4]) {
@@ -1059,7 +1074,11 @@ constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB
 constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
 constexpr int kResMaxWGs = 8192;  // count words in the workspace: 1 GiB of 16-bit elements per launch, more goes in chunks
 
-template <int KEEP, int WAVES>
+// ES = 4 (round 3): 32-bit payloads ride the same kernel as pairs of halves — `units`, `upr`, `capacity`, the count words and every
+// offset inside the kernel are in 16-byte units / 16-bit halves exactly as for ES = 2; only the non-zero test (per 32-bit element, flag
+// doubled), the bitmask that leaves (one bit per ELEMENT: the nibbles of two adjacent units make a byte), the row offsets and the totals
+// (halved on the way out) differ.
+template <int KEEP, int WAVES, int ES>
 __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows, int tpw,
                                                                     uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
                                                                     int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
@@ -1078,7 +1097,8 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = (int)blockIdx.x;
     const int64_t wt0 = ((int64_t)b * WAVES + wave) * tpw;  // tpw <= KEEP wave-tiles per wave
-    const uint32_t keepbits = is_float ? 0x7fff7fffu : 0xffffffffu;
+    const uint32_t keepbits = is_float ? (ES == 4 ? 0x7fffffffu : 0x7fff7fffu) : 0xffffffffu;
+    constexpr int SH = ES == 4 ? 1 : 0;  // halves per element, as a shift
     if (tid == 0) s_nmiss = 0;
     // ---- stagger: the second workgroup of every CU starts its loads one load-phase later than the first, so that from then on
     // one of a CU's two workgroups reads while the other computes / waits for its prefix / stores (without it the whole chip moves
@@ -1115,7 +1135,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
         uint32_t pk = 0;
         if (i < tpw) {  // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pk |= nz_mask16_fast(keep[i][q], keepbits) << (8 * q);
+            for (int q = 0; q < 4; ++q) pk |= nz_mask_unit<ES>(keep[i][q], keepbits) << (8 * q);
             s_mask[wave][i][lane] = pk;
         }
         pks[i] = pk;
@@ -1158,7 +1178,20 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         const int64_t wt = wt0 + i;
-        if (i < tpw && wt * kWT < units) {  // wave-uniform
+        if (ES == 4 && i < tpw && wt * kWT < units) {  // wave-uniform; one bit per 32-bit element: lane L < 32 = units 8L .. 8L + 7 of the tile
+            if (lane < 32) {
+                const uint8_t* src = reinterpret_cast<const uint8_t*>(s_mask[wave][i]) + 4 * (8 * (lane & 7)) + (lane >> 3);
+                uint32_t d = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) d |= pair_mask_nibble(src[4 * t]) << (4 * t);
+                const int64_t u = wt * kWT + 8 * lane;  // first unit of this dword; units and u are even
+                uint8_t* dst = bitmask + (u >> 1);
+                if (mask_dwords && u + 8 <= units) *reinterpret_cast<uint32_t*>(dst) = d;
+                else
+                    for (int t = 0; t < 4; ++t)
+                        if (u + 2 * t < units) dst[t] = (uint8_t)(d >> (8 * t));
+            }
+        } else if (i < tpw && wt * kWT < units) {  // wave-uniform
             if (mask_dwords) {
                 const uint8_t* src = reinterpret_cast<const uint8_t*>(s_mask[wave][i]) + 16 * (lane & 15) + (lane >> 4);
                 const uint32_t d = (uint32_t)src[0] | ((uint32_t)src[4] << 8) | ((uint32_t)src[8] << 16) | ((uint32_t)src[12] << 24);
@@ -1204,7 +1237,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
                 const int64_t u_lo = (int64_t)s_miss[m] * WAVES * tpw * kWT;
                 int64_t u_hi = u_lo + (int64_t)WAVES * tpw * kWT;
                 if (u_hi > units) u_hi = units;
-                for (int64_t u = u_lo + tid; u < u_hi; u += WAVES * 64) part += __popc(nz_mask16_fast(x[u], keepbits));
+                for (int64_t u = u_lo + tid; u < u_hi; u += WAVES * 64) part += __popc(nz_mask_unit<ES>(x[u], keepbits));
             }
             __syncthreads();
             if (tid == 0) s_nmiss = 0;
@@ -1217,7 +1250,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     __syncthreads();
     if (stamps && tid == 0 && b < 512) stamps[b * 4 + 2] = wall_clock64();
     {
-        int64_t run = base ? (int64_t)*base : 0;
+        int64_t run = base ? (int64_t)*base << SH : 0;  // the running totals between chunks are in elements
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) run += s_part[w];
         for (int w = 0; w < wave; ++w) run += s_cnt[w];
@@ -1233,7 +1266,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
                 const int64_t uend = u0 + (wt + 1) * kWT;
                 for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
                     const int l = (int)(next_u - (u0 + wt * kWT)) & 63;
-                    if (lane == l) row_offsets[next_r] += run;
+                    if (lane == l) row_offsets[next_r] = (row_offsets[next_r] + run) >> SH;
                 }
             }
             const int64_t lim = run + total < capacity ? run + total : capacity;  // one past the last element this tile may write
@@ -1250,7 +1283,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
                 }
             }
             run += total;
-            if ((wt + 1) * kWT >= units && wt * kWT < units && lane == 0) op_store(run_out, (unsigned long long)run);  // the chunk's last wave-tile
+            if ((wt + 1) * kWT >= units && wt * kWT < units && lane == 0) op_store(run_out, (unsigned long long)(run >> SH));  // the chunk's last wave-tile
         }
     }
     if (stamps && tid == 0 && b < 512) stamps[b * 4 + 3] = wall_clock64();
@@ -1546,8 +1579,9 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
     // are also what the caller falls back to when the resident form reports -1; 3 = time stamps of the first 512 workgroups in the
     // workspace (tools/exp_r02.py bmres)
     static const int resident_mode = []() { const char* e = std::getenv("CT_BITMASK_RESIDENT"); return e ? std::atoi(e) : 1; }();
-    if (es == 2 && cols % 8 == 0 && aligned16(x) && resident_mode) {
-        const int64_t units = rows * (cols / 8);
+    if ((es == 2 || es == 4) && cols % 8 == 0 && aligned16(x) && resident_mode) {
+        const int64_t upr = cols * es / 16;  // 16-byte units per row
+        const int64_t units = rows * upr;
         const int64_t wts = cdiv64(units, kWT);
         int dev = 0, cus = kCUs;
         if (hipGetDevice(&dev) == hipSuccess) {
@@ -1597,7 +1631,8 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 const int64_t u0 = w0 * kWT;
                 const int64_t cu = (units - u0) < cw * kWT ? (units - u0) : cw * kWT;
                 const int64_t nwg = cdiv64(cw, wg_wts);
-                const int mask_dwords = (cu % 4 == 0) && ((reinterpret_cast<uintptr_t>(bitmask + u0) & 3u) == 0);
+                uint8_t* bm0 = bitmask + (es == 4 ? u0 / 2 : u0);  // a mask byte covers one 16-bit unit or two 32-bit units
+                const int mask_dwords = (es == 4 || cu % 4 == 0) && ((reinterpret_cast<uintptr_t>(bm0) & 3u) == 0);
                 // the chunk's running total: straight into *total for the last chunk, else into one of two alternating workspace words
                 unsigned long long* run_out = k + 1 == nchunks ? reinterpret_cast<unsigned long long*>(total) : ctl + 2 + (k & 1);
                 // stagger (see the kernel): only when the launch is at least two full residency rounds (two workgroups per CU each) — with a
@@ -1606,10 +1641,14 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 const bool stagger = nwg >= 4 * (int64_t)cus;
                 const int stagger_lo = cus, stagger_hi = stagger ? 2 * cus : 0;
                 const unsigned stagger_ticks = (unsigned)((wg_wts * kWT * 16) / 188);  // 100 MHz ticks
-                hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),
-                                   static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, cols / 8, rows, (int)tpw, static_cast<uint16_t*>(values),
-                                   values_capacity, bitmask + u0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots,
-                                   run_out, tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks);
+#define CT_RESIDENT(ES_)                                                                                                                          \
+    hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves, ES_>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),         \
+                       static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
+                       values_capacity * (ES_ / 2), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out,        \
+                       tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks)
+                if (es == 4) CT_RESIDENT(4);
+                else CT_RESIDENT(2);
+#undef CT_RESIDENT
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
         }

@@ -849,16 +849,23 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(5)
 for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, torch.float16), (3000, 1000, 0.9, torch.bfloat16), (513, 8200, 0.5, torch.bfloat16),
                          (2048, 4096, 0.0, torch.bfloat16), (1024, 4096, 1.0, torch.float16), (8192, 8192, 0.5, torch.bfloat16), (7, 8, 0.5, torch.int16),
-                         (1, 8, 1.0, torch.bfloat16), (4099, 24, 0.5, torch.float16)):
+                         (1, 8, 1.0, torch.bfloat16), (4099, 24, 0.5, torch.float16),
+                         # 32-bit payloads ride the resident kernel as pairs of halves (one mask bit per element, offsets and totals halved)
+                         (4096, 4096, 0.5, torch.float32), (513, 8200, 0.5, torch.float32), (3000, 1000, 0.9, torch.float32), (2048, 4104, 0.3, torch.float32),
+                         (1024, 4096, 0.0, torch.float32), (512, 4096, 1.0, torch.float32), (7, 8, 0.5, torch.int32), (1, 8, 1.0, torch.float32),
+                         (4099, 24, 0.5, torch.float32), (4096, 8192, 0.5, torch.float32)):
     w = torch.randn(r, c, device=dev, generator=g)
     w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
-    w = (w * 100).to(dt) if dt == torch.int16 else w.to(dt)
-    if dt != torch.int16 and dens > 0:
+    w = (w * 100).to(dt) if dt in (torch.int16, torch.int32) else w.to(dt)
+    if dt not in (torch.int16, torch.int32) and dens > 0:
         w.view(-1)[::7] = -0.0  # a negative zero is a zero
+    if dt == torch.float32 and dens > 0:
+        w.view(torch.int32).view(-1)[3::11] = 0x00010000  # a denormal whose low half is zero: non-zero as an element, zero as a half
+        w.view(torch.int32).view(-1)[5::13] = 0x00000001  # ... and one whose high half is zero
     for rep in range(3):  # a fresh generation tag per call over recycled workspace memory
         v, bm, ro = codec.bitmask_compress(w)
         v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
-        assert v.numel() == v2.numel() and torch.equal(v.view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2), (r, c, dens, rep)
+        assert v.numel() == v2.numel() and torch.equal(v.view(torch.uint8), v2.view(torch.uint8)) and torch.equal(bm, bm2) and torch.equal(ro, ro2), (r, c, dens, dt, rep)
 print("FORMS_OK")
 """
 
@@ -871,7 +878,7 @@ print("FORMS_OK")
     {"CT_BITMASK_RESIDENT_WAIT_US": "0", "CT_BITMASK_RESIDENT_MAX_WGS": "5"},
 ], ids=["resident", "two_kernels", "resident_chunked", "resident_self_help", "resident_self_help_chunked"])
 def test_bitmask_compress_forms_agree(env):
-    """every form of the 16-bit sparse compress (the knobs are read once per process, hence the subprocess): values, bitmask, row
+    """every form of the 16- / 32-bit sparse compress (the knobs are read once per process, hence the subprocess): values, bitmask, row
     offsets and the total bit-identical to count / scan / scatter for ragged, empty, dense, tiny shapes"""
     import os
     import subprocess

@@ -50,6 +50,33 @@ if what == "bm":
         del ws_, vals, bm, ro
         torch.cuda.empty_cache()
     print(json.dumps(res))
+elif what == "bm32":
+    # 32-bit payloads through the sparse-bitmask compress (CT_BITMASK_RESIDENT=0: count / scan / scatter, the round-2 path for them)
+    from compressed_tensors_amd import _lib
+    lib = _lib.load(); stream = torch.cuda.current_stream(dev).cuda_stream
+    g = torch.Generator(device=dev).manual_seed(11)
+    out = {}
+    for N, C in ((8192, 8192), (4096, 4096)):
+        nsets = 4 if N == 8192 else 12
+        ws_ = [torch.randn(N, C, dtype=torch.float32, device=dev, generator=g).masked_fill(torch.rand(N, C, device=dev, generator=g) < 0.5, 0) for _ in range(nsets)]
+        ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, C))
+        wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+        vals = torch.empty(N * C, dtype=torch.float32, device=dev); bm = torch.empty(N, C // 8, dtype=torch.uint8, device=dev); ro = torch.empty(N, dtype=torch.int64, device=dev)
+        f = lambda i: lib.ct_bitmask_compress(ws_[i % nsets].data_ptr(), _lib.F32, N, C, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(), wk.data_ptr(), ws_bytes, stream)
+        us = B.time_kernel(f, 12)
+        f(0); torch.cuda.synchronize()
+        w0 = ws_[0]; nnz = int(wk[-1].item())
+        ok = nnz == int((w0 != 0).sum().item()) and bool(torch.equal(vals[:nnz], w0[w0 != 0]))
+        alg = 4 * N * C + 4 * nnz + N * C // 8 + 8 * N
+        out[f"{N}x{C}"] = {"us": round(us, 1), "GBps": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / B.HBM_PEAK_GBPS, 4), "exact": ok}
+        # decompress of the same payload
+        outs = [torch.empty(N, C, dtype=torch.float32, device=dev) for _ in range(nsets)]
+        fd = lambda i: lib.ct_bitmask_decompress(vals.data_ptr(), nnz, bm.data_ptr(), ro.data_ptr(), -1, _lib.F32, N, C, outs[i % nsets].data_ptr(), stream)
+        usd = B.time_kernel(fd, 12)
+        fd(0); torch.cuda.synchronize()
+        out[f"{N}x{C}"].update({"decompress_us": round(usd, 1), "decompress_frac": round(alg / usd / 1e3 / B.HBM_PEAK_GBPS, 4), "decompress_exact": bool(torch.equal(outs[0], w0))})
+        del ws_, vals, bm, outs; torch.cuda.empty_cache()
+    print(json.dumps(out))
 elif what == "m24":
     r = B.marlin24_leg(dev)
     print(json.dumps({k: v for k, v in r.items() if "us" in k or "exact" in k}))
