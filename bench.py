@@ -926,7 +926,7 @@ def roofline_rows(result):
             row("bitmask_decompress16_kernel<2:4 rows>", "sparse-24-bitmask 8192x8192 bf16, decompress", b["s24_alg_bytes"], b["s24_decompress_us"], bit_exact=b["s24_bit_exact"])
         if "f32_compress_us" in b:
             row("flat16_resident_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, compress", b["f32_alg_bytes"], b["f32_compress_us"], bit_exact=b["f32_bit_exact"])
-            row("bitmask_decompress_kernel<4>", "sparse-bitmask 50 % 8192x8192 float32, decompress", b["f32_alg_bytes"], b["f32_decompress_us"], bit_exact=b["f32_bit_exact"])
+            row("bitmask_decompress16_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, decompress", b["f32_alg_bytes"], b["f32_decompress_us"], bit_exact=b["f32_bit_exact"])
     k4 = leg("kernels_4096")
     if k4:
         row("w4_quant_pack_lean_kernel<bf16>", "W4A16 g128 4096x4096 bf16, compress", k4["alg_bytes_per_direction"], k4["compress_us"])

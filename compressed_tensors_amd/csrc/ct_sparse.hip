@@ -592,11 +592,25 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
-template <bool SINGLE>
-__global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len,
+// every bit of a 16-bit value doubled (bit k -> bits 2k, 2k + 1): the element mask of 32-bit payloads as a mask of their halves
+__device__ __forceinline__ uint32_t double_bits16(uint32_t x) {
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x | (x << 1);
+}
+
+// ES = 4 (round 3): 32-bit payloads as pairs of 16-bit halves — the value run, the ranks, the windows and the stores are those of a
+// 16-bit tensor with twice the columns whose mask has every bit doubled; only the mask loads (half as many real bytes) and the
+// offsets (doubled on the way in) differ.
+template <bool SINGLE, int ES>
+__global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len_e,
                                                                       const uint8_t* __restrict__ bitmask,
-                                                                      const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz,
-                                                                      int64_t rows, int64_t cols, uint16_t* __restrict__ out) {
+                                                                      const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz_e,
+                                                                      int64_t rows, int64_t cols_e, uint16_t* __restrict__ out) {
+    constexpr int SH = ES == 4 ? 1 : 0;
+    const int64_t values_len = values_len_e << SH, cols = cols_e << SH, fixed_row_nnz = fixed_row_nnz_e << SH;  // in 16-bit items from here on
     __shared__ __attribute__((aligned(16))) uint16_t s_val[kTile16 + 32];
     __shared__ uint32_t s_sel8[8];  // v_perm_b32 selectors indexed by (window misaligned) << 2 | (b1 << 1) | b0
     __shared__ __attribute__((aligned(16))) uint16_t s_rank[kTile16 / 8];  // wave-local rank of every unit
@@ -616,13 +630,24 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         const int64_t u0 = SINGLE ? 0 : (tile - row * tiles_per_row) * (kTile16 / 8);  // first unit of the tile in its row
         const int64_t left = bcols - u0;
         const int nu = left < kTile16 / 8 ? (int)left : kTile16 / 8;                    // units in this tile (multiple of 4)
-        const uint8_t* mrow = bitmask + row * bcols;
-        const uint32_t md = (4 * tid < nu) ? *reinterpret_cast<const uint32_t*>(mrow + u0 + 4 * tid) : 0u;
+        const uint8_t* mrow = bitmask + row * (bcols >> SH);  // the real mask row: one byte per unit (ES = 2) / per two units (ES = 4)
+        uint32_t md = 0;
+        if (4 * tid < nu) {
+            if constexpr (ES == 4) md = double_bits16(*reinterpret_cast<const uint16_t*>(mrow + ((u0 + 4 * tid) >> 1)));
+            else md = *reinterpret_cast<const uint32_t*>(mrow + u0 + 4 * tid);
+        }
         // the consumer lane's own mask bytes (unit i*256 + tid): same cache lines as the dword above
         uint32_t mb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) mb[i] = (i * kBlock + tid < nu) ? (uint32_t)mrow[u0 + i * kBlock + tid] : 0u;
-        int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
+        for (int i = 0; i < 4; ++i) {
+            const int64_t v = u0 + i * kBlock + tid;
+            mb[i] = 0u;
+            if (i * kBlock + tid < nu) {
+                if constexpr (ES == 4) mb[i] = double_bits16(((uint32_t)mrow[v >> 1] >> (4 * (int)(v & 1))) & 0xfu);
+                else mb[i] = (uint32_t)mrow[v];
+            }
+        }
+        int64_t run = row_offsets ? (row_offsets[row] << SH) : row * fixed_row_nnz;
         run = run < 0 ? 0 : (run > values_len ? values_len : run);
 
         // stage vin[run, run + total) at s_val[shift ...]; shift = offset of `run` inside its 16-byte
@@ -667,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         if constexpr (!SINGLE) {
             // popcount of the row's mask bytes before this tile
             int c = 0;
-            for (int64_t d = tid; d < (u0 >> 2); d += kBlock) c += __popc(reinterpret_cast<const uint32_t*>(mrow)[d]);
+            for (int64_t d = tid; d < (u0 >> (2 + SH)); d += kBlock) c += __popc(reinterpret_cast<const uint32_t*>(mrow)[d]) << SH;
             c = wave_incl_scan(c);
             if (lane == 63) s_pre[wave] = c;
         }
@@ -686,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         for (int i = 0; i < 4; ++i) offs4[i] = (2u * __popc(mb[i] & 3u)) | ((2u * __popc(mb[i] & 15u)) << 8) | ((2u * __popc(mb[i] & 63u)) << 16) | (mb[i] << 24);
         if constexpr (SINGLE) {
             int64_t row_end = values_len;
-            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
+            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1] << SH; }
             else row_end = run + fixed_row_nnz;
             int64_t len = row_end - run;
             len = len < 0 ? 0 : (len > kTile16 ? kTile16 : len);
@@ -1703,15 +1728,17 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
     // cross values_len are read element-wise in the kernel
     const int vec_in = aligned16(values);
     // (2:4-regular rows of 16-bit payloads measure the same on this kernel as on the general kernel's local-expand path: 33.9 / 34.8 us)
-    if (es == 2 && cols % 32 == 0 && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0) {
-        const int64_t tiles = rows * cdiv64(cols, kTile16);
+    if ((es == 2 || es == 4) && (cols * es / 2) % 32 == 0 && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0 &&
+        values_len < ((int64_t)1 << 61)) {
+        const int64_t hcols = cols * es / 2;  // the row in 16-bit items
+        const int64_t tiles = rows * cdiv64(hcols, kTile16);
         const unsigned grid = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));  // exact grid measured best
-        if (cols <= kTile16)
-            hipLaunchKernelGGL((bitmask_decompress16_kernel<true>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values),
-                               values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out));
-        else
-            hipLaunchKernelGGL((bitmask_decompress16_kernel<false>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values),
-                               values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out));
+#define CT_DEC16(SINGLE_, ES_)                                                                                                                      \
+    hipLaunchKernelGGL((bitmask_decompress16_kernel<SINGLE_, ES_>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values), \
+                       values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out))
+        if (es == 4) { if (hcols <= kTile16) CT_DEC16(true, 4); else CT_DEC16(false, 4); }
+        else { if (hcols <= kTile16) CT_DEC16(true, 2); else CT_DEC16(false, 2); }
+#undef CT_DEC16
         CT_LAUNCH_CHECK("ct_bitmask_decompress[16]");
     }
     // 4096 resident-ish workgroups, grid-strided over rows: measured best on MI355X (tools/kbench)

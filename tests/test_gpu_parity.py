@@ -853,7 +853,7 @@ for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, to
                          # 32-bit payloads ride the resident kernel as pairs of halves (one mask bit per element, offsets and totals halved)
                          (4096, 4096, 0.5, torch.float32), (513, 8200, 0.5, torch.float32), (3000, 1000, 0.9, torch.float32), (2048, 4104, 0.3, torch.float32),
                          (1024, 4096, 0.0, torch.float32), (512, 4096, 1.0, torch.float32), (7, 8, 0.5, torch.int32), (1, 8, 1.0, torch.float32),
-                         (4099, 24, 0.5, torch.float32), (4096, 8192, 0.5, torch.float32)):
+                         (4099, 24, 0.5, torch.float32), (4096, 8192, 0.5, torch.float32), (1024, 2048, 0.5, torch.int32)):
     w = torch.randn(r, c, device=dev, generator=g)
     w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
     w = (w * 100).to(dt) if dt in (torch.int16, torch.int32) else w.to(dt)
@@ -866,6 +866,9 @@ for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, to
         v, bm, ro = codec.bitmask_compress(w)
         v2, bm2, ro2 = codec.bitmask_compress(w, two_pass=True)
         assert v.numel() == v2.numel() and torch.equal(v.view(torch.uint8), v2.view(torch.uint8)) and torch.equal(bm, bm2) and torch.equal(ro, ro2), (r, c, dens, dt, rep)
+    back = codec.bitmask_decompress(v, bm, (r, c), ro)
+    expect = torch.where(w != 0, w, torch.zeros_like(w))  # -0.0 comes back as +0.0
+    assert torch.equal(back.view(torch.uint8), expect.view(torch.uint8)) and torch.equal(codec.bitmask_decompress(v, bm, (r, c)).view(torch.uint8), expect.view(torch.uint8)), (r, c, dens, dt)
 print("FORMS_OK")
 """
 
