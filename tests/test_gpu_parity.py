@@ -853,7 +853,8 @@ for (r, c, dens, dt) in ((4096, 4096, 0.5, torch.bfloat16), (1024, 2048, 0.1, to
                          # 32-bit payloads ride the resident kernel as pairs of halves (one mask bit per element, offsets and totals halved)
                          (4096, 4096, 0.5, torch.float32), (513, 8200, 0.5, torch.float32), (3000, 1000, 0.9, torch.float32), (2048, 4104, 0.3, torch.float32),
                          (1024, 4096, 0.0, torch.float32), (512, 4096, 1.0, torch.float32), (7, 8, 0.5, torch.int32), (1, 8, 1.0, torch.float32),
-                         (4099, 24, 0.5, torch.float32), (4096, 8192, 0.5, torch.float32), (1024, 2048, 0.5, torch.int32)):
+                         (4099, 24, 0.5, torch.float32), (4096, 8192, 0.5, torch.float32), (1024, 2048, 0.5, torch.int32),
+                         (37, 8208, 0.5, torch.float32), (5, 4112, 0.7, torch.float32), (64, 48, 0.5, torch.float32)):  # mask rows of 2 (mod 4) bytes
     w = torch.randn(r, c, device=dev, generator=g)
     w = w.masked_fill(torch.rand(r, c, device=dev, generator=g) >= dens, 0)
     w = (w * 100).to(dt) if dt in (torch.int16, torch.int32) else w.to(dt)
