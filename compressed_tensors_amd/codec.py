@@ -780,7 +780,7 @@ def unpack_bitmasks(packed_bitmasks: torch.Tensor, original_shape) -> torch.Tens
 def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
     """sparse-bitmask compression: returns (values, bitmask uint8 (R, ceil(C/8)), row_offsets int64 (R,)).
 
-    Default: the fused form (`ct_bitmask_compress`; 16-bit elements: the register-resident kernel that reads the tensor once,
+    Default: the fused form (`ct_bitmask_compress`; 16- and 32-bit elements: the register-resident kernel that reads the tensor once,
     otherwise count + scatter whose prefixes are sums of the counts; no scan kernel) into a worst-case sized value buffer, then
     one host read of nnz — as unavoidable as the reference's `tensor[mask]` — to narrow it.  `two_pass=True` keeps the
     count / scan / host read / scatter form that sizes `values` exactly before writing it."""

@@ -1600,7 +1600,8 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                (long long)need);
     CT_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace must be 8-byte aligned");
     CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
-    // 16-bit elements: the resident form (x read once).  CT_BITMASK_RESIDENT=0 selects the two kernels below (x read twice), which
+    // 16- and 32-bit elements (the latter as pairs of halves): the resident form (x read once).  CT_BITMASK_RESIDENT=0 selects the two kernels
+    // below for 16-bit elements (x read twice; 32-bit ones then take the generic path), which
     // are also what the caller falls back to when the resident form reports -1; 3 = time stamps of the first 512 workgroups in the
     // workspace (tools/exp_r02.py bmres)
     static const int resident_mode = []() { const char* e = std::getenv("CT_BITMASK_RESIDENT"); return e ? std::atoi(e) : 1; }();

@@ -283,13 +283,14 @@ int ct_exclusive_scan_i64(const int64_t* counts, int64_t n, int64_t* offsets, in
 int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const int64_t* row_offsets,
                        void* values, ct_stream_t stream);
 /* sparse-bitmask compress, fused form: bitmask, row_offsets, values and total[0] = nnz with no host
- * round trip.  16-bit payloads with cols % 8 == 0: ONE pass over x — every workgroup keeps its share
+ * round trip.  16- and 32-bit payloads with cols % 8 == 0 (a 32-bit element travels as its two
+ * 16-bit halves; the bitmask, the row offsets and the total are per ELEMENT): ONE pass over x — every workgroup keeps its share
  * of the tensor in registers, compacts it while the loads land, publishes its count as one 64-bit
  * word and stores once it has the counts of the workgroups before it; a count that does not arrive
  * within 2 ms is recomputed by the waiting workgroup, so the call cannot fail or deadlock.
  * CT_BITMASK_RESIDENT=0 selects count + scatter (x read twice, no inter-workgroup waiting).
- * Other payloads: count, scan, scatter.  `values` must hold `values_capacity` elements
- * (numel is always enough; the 16-bit paths never write beyond the capacity and still report the
+ * 8-bit payloads / other column counts: count, scan, scatter.  `values` must hold `values_capacity` elements
+ * (numel is always enough; the one-pass paths never write beyond the capacity and still report the
  * needed size in total).  `workspace` = ct_bitmask_compress_workspace_bytes(rows, cols) bytes, 8-byte
  * aligned, need not be initialised. */
 int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols);
@@ -297,7 +298,9 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                         int64_t values_capacity, uint8_t* bitmask, int64_t* row_offsets, int64_t* total,
                         void* workspace, int64_t workspace_bytes, ct_stream_t stream);
 /* sparse-bitmask decompress: out = zeros; out[mask] = values.  row_offsets may be NULL only if
- * fixed_row_nnz >= 0 (every row holds exactly that many values: the 2:4 codec) */
+ * fixed_row_nnz >= 0 (every row holds exactly that many values: the 2:4 codec).  16-bit payloads with
+ * cols % 32 == 0 and 32-bit payloads with cols % 16 == 0 (as pairs of halves) take the LDS-window
+ * kernel; everything else the general one. */
 int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t* bitmask,
                           const int64_t* row_offsets, int64_t fixed_row_nnz, int dt, int64_t rows,
                           int64_t cols, void* out, ct_stream_t stream);
