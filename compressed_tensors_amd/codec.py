@@ -153,21 +153,13 @@ def unpack_from_int32(value: torch.Tensor, num_bits: int, shape: Sequence[int], 
 def _col_group_of(g_idx: torch.Tensor, group_size: int) -> torch.Tensor:
     """activation ordering (forward_helpers.py:147-175): column c uses the group of its position in the g_idx-sorted order; a g_idx
     that still holds a -1 (not initialised) means plain column order.  The reference decides that with `-1 in g_idx`, a host read
-    per call; here the choice is a device-side select — no synchronisation — and the table is cached on the g_idx tensor itself
-    (keyed by its version counter), so a module's repeated compress / decompress calls pay the two sorts once."""
-    key = (g_idx.data_ptr(), g_idx._version, g_idx.numel(), int(group_size), g_idx.device)  # (a `.data` swap keeps the version counter)
-    hit = getattr(g_idx, "_ct_col_group", None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    per call; here the choice is a device-side select — no synchronisation.  Nothing is cached: `param.data.copy_(...)` rewrites a
+    g_idx in place without moving its pointer or bumping its version counter, so no key derived from the tensor is safe
+    (ADVICE r03), and the two argsorts of a (cols,) vector are noise next to the weight pass."""
     flat = g_idx.detach().reshape(-1)
     inv = torch.argsort(torch.argsort(flat))
     plain = torch.arange(flat.numel(), device=flat.device)
-    col_group = (torch.where((flat == -1).any(), plain, inv) // int(group_size)).to(torch.int32)
-    try:
-        g_idx._ct_col_group = (key, col_group)
-    except Exception:  # a tensor subclass that refuses attributes: just recompute next time
-        pass
-    return col_group
+    return (torch.where((flat == -1).any(), plain, inv) // int(group_size)).to(torch.int32)
 
 
 class QuantLayout:
@@ -634,6 +626,22 @@ def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, str
     return True
 
 
+def _upload_table(words, dev) -> torch.Tensor:
+    """a host table of int64 words -> device bytes.  The staging buffer is pinned (PyTorch's caching host allocator hands the
+    block out again only after the copy's stream event has completed), so the copy is asynchronous: no blocking pageable H2D
+    (25-30 us per table before) on the path of a launch"""
+    import ctypes
+
+    nbytes = 8 * len(words)
+    host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) if dev.type == "cuda" else torch.empty(nbytes, dtype=torch.uint8)
+    src, _ = words.buffer_info()
+    ctypes.memmove(host.data_ptr(), src, nbytes)
+    return host.to(dev, non_blocking=True)
+
+
+_ITEM_WORDS = 11  # struct ct_w4_item of include/ct_hip.h: 4 pointers, rows, cols, group, first_block, units, {upg_shift, upg}
+
+
 class W4Batch:
     """A table of tensors processed by ONE kernel launch per direction — the per-module loop of ModelCompressor without a
     launch (and a ~5 us host call) per module.
@@ -641,35 +649,35 @@ class W4Batch:
     entries: (src, scale, zero_point or None, dst, rows, cols, group) with src / dst in the order the direction needs
     ("compress": weight -> codes).  kind "w4": W4A16 pack-quantized (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`,
     dst / src = packed int32 words); kind "int8" / "fp8": the 8-bit codecs (`ct_q8_quant_batch` / `ct_q8_dequant_batch`, one
-    byte per element, `bits` = the INT scheme's num_bits; group may be rows * cols for a per-tensor scale)."""
+    byte per element, `bits` = the INT scheme's num_bits; group may be rows * cols for a per-tensor scale).
+
+    The host table is one flat array of 64-bit words (11 per item, the layout of `struct ct_w4_item`) planned in place by the
+    library and uploaded asynchronously from pinned memory."""
 
     def __init__(self, entries, direction: str, dtype: torch.dtype, kind: str = "w4", bits: int = 8):
         assert direction in ("compress", "decompress") and kind in ("w4", "int8", "fp8")
+        import array
+
         self.direction = 0 if direction == "compress" else 1
         self.kind, self.bits = kind, int(bits)
         self.dt = DT[dtype]
-        self.keep = list(entries)  # the table holds raw pointers: keep the tensors alive
-        n = len(self.keep)
-        self.n = n
-        arr = (_lib.W4Item * max(n, 1))()
+        self.keep = entries if isinstance(entries, list) else list(entries)  # the table holds raw pointers: keep the tensors alive
+        n = self.n = len(self.keep)
+        flat = []
         dev = None
-        for i, (src, scale, zp, dst, rows, cols, group) in enumerate(self.keep):
-            dev = src.device
-            it = arr[i]
-            it.src, it.scale, it.zp, it.dst = src.data_ptr(), scale.data_ptr(), (zp.data_ptr() if zp is not None else None), dst.data_ptr()
-            it.rows, it.cols, it.group = int(rows), int(cols), int(group)
-        import ctypes
-
-        plan = _lib.load().ct_w4_batch_plan if kind == "w4" else _lib.load().ct_q8_batch_plan
-        self.blocks = int(plan(ctypes.cast(arr, ctypes.c_void_p), n, self.direction)) if n else 0
-        if self.blocks < 0:
-            raise ValueError(_lib.last_error())
-        self.device = dev
+        for src, scale, zp, dst, rows, cols, group in self.keep:
+            flat += (src.data_ptr(), scale.data_ptr(), 0 if zp is None else zp.data_ptr(), dst.data_ptr(), rows, cols, group, 0, 0, 0, 0)
+        self.blocks, self.table, self.device = 0, None, None
         if n:
-            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.table = host.to(dev)
-        else:
-            self.table = None
+            dev = self.keep[0][0].device
+            words = array.array("q", flat)
+            lib = _lib.load()
+            plan = lib.ct_w4_batch_plan if kind == "w4" else lib.ct_q8_batch_plan
+            self.blocks = int(plan(words.buffer_info()[0], n, self.direction))
+            if self.blocks < 0:
+                raise ValueError(_lib.last_error())
+            self.device = dev
+            self.table = _upload_table(words, dev)
 
     def launch(self, stream=None):
         """`stream`: a raw hipStream_t of self.device (default: the caller's current stream there)"""
@@ -691,18 +699,18 @@ def zp4_batch(pairs, direction: str) -> None:
     pairs = list(pairs)
     if not pairs:
         return
-    import ctypes
+    import array
 
-    arr = (_lib.W4Item * len(pairs))()
-    for it, (src, dst) in zip(arr, pairs):
+    flat = []
+    for src, dst in pairs:
         unpacked = src if direction == "pack" else dst
-        it.src, it.dst = src.data_ptr(), dst.data_ptr()
-        it.rows, it.cols = int(unpacked.shape[0]), int(unpacked.shape[1])
-    blocks = int(_lib.load().ct_zp4_batch_plan(ctypes.cast(arr, ctypes.c_void_p), len(pairs)))
+        flat += (src.data_ptr(), 0, 0, dst.data_ptr(), int(unpacked.shape[0]), int(unpacked.shape[1]), 0, 0, 0, 0, 0)
+    words = array.array("q", flat)
+    blocks = int(_lib.load().ct_zp4_batch_plan(words.buffer_info()[0], len(pairs)))
     if blocks < 0:
         raise ValueError(_lib.last_error())
     dev = pairs[0][0].device
-    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    table = _upload_table(words, dev)
     call("ct_zp4_pack_dim0_batch", table.data_ptr(), len(pairs), blocks, 0 if direction == "pack" else 1, _lib.stream_on(dev))
     table.record_stream(torch.cuda.current_stream(dev))
 
@@ -777,12 +785,23 @@ def unpack_bitmasks(packed_bitmasks: torch.Tensor, original_shape) -> torch.Tens
     return _home(out.view(torch.bool), packed_bitmasks)
 
 
+_WS_BYTES = {}
+
+
+def _bitmask_workspace_bytes(rows: int, cols: int) -> int:
+    n = _WS_BYTES.get((rows, cols))
+    if n is None:
+        n = _WS_BYTES[(rows, cols)] = int(_lib.load().ct_bitmask_compress_workspace_bytes(rows, cols))
+    return n
+
+
 def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
     """sparse-bitmask compression: returns (values, bitmask uint8 (R, ceil(C/8)), row_offsets int64 (R,)).
 
     Default: the fused form (`ct_bitmask_compress`; 16- and 32-bit elements: the register-resident kernel that reads the tensor once,
     otherwise count + scatter whose prefixes are sums of the counts; no scan kernel) into a worst-case sized value buffer, then
-    one host read of nnz — as unavoidable as the reference's `tensor[mask]` — to narrow it.  `two_pass=True` keeps the
+    one host wait for nnz — as unavoidable as the reference's `tensor[mask]` — to narrow it: the kernel stores nnz into a pinned
+    host word (`_lib.Mailbox`) and the host spins on that word instead of copying it back.  `two_pass=True` keeps the
     count / scan / host read / scatter form that sizes `values` exactly before writing it."""
     if tensor.ndim < 1:
         raise ValueError("bitmask compression expects at least a 1-D tensor")
@@ -805,12 +824,15 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
             call("ct_bitmask_scatter", ptr(x), dt, rows, cols, ptr(row_offsets), ptr(values), s)
     else:
         numel = rows * cols
-        ws_bytes = int(_lib.load().ct_bitmask_compress_workspace_bytes(rows, cols))
-        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)  # [-1] receives nnz
+        ws_bytes = _bitmask_workspace_bytes(rows, cols)
+        ws = torch.empty(ws_bytes // 8, dtype=torch.int64, device=dev)
         buf = torch.empty(numel, dtype=x.dtype, device=dev)
-        call("ct_bitmask_compress", ptr(x), dt, rows, cols, ptr(buf), numel, ptr(bitmask), ptr(row_offsets),
-             ws[-1:].data_ptr(), ptr(ws), ws_bytes, s)
-        nnz = int(ws[-1].item())
+        # nnz comes back through the thread's pinned mailbox word: the kernel's last wave stores it there (system scope) as soon
+        # as the prefix is known — before the last values have left — and the host spins on the word; no D2H copy, no `.item()`
+        mb = _lib.mailbox(s.device_index)
+        mb.words[0] = -1
+        call("ct_bitmask_compress", ptr(x), dt, rows, cols, ptr(buf), numel, ptr(bitmask), ptr(row_offsets), mb.dev, ptr(ws), ws_bytes, s)
+        nnz = mb.wait_word(0, -1, s)
         # keep the view when it wastes less than half of the buffer, else release the slack
         values = buf[:nnz] if 2 * nnz >= numel else buf[:nnz].clone()
     return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor), _home(row_offsets, tensor)

@@ -74,17 +74,23 @@ class BaseCompressor(RegistryMixin, ABC):
         shard, converters/ct_dequantizer.py:63-99); codecs may override to batch their launches"""
         return [cls.decompress(sd, scheme) for sd in state_dicts]
 
+    _ZP_OF_ARGS = (("input_activations", "input_zero_point"), ("weights", "weight_zero_point"), ("output_activations", "output_zero_point"))
+
+    @classmethod
+    def _symmetric_zp_keys(cls, scheme) -> list:
+        """the zero-point names that a symmetric scheme does not store (compressors/base.py:147-167)"""
+        keys = []
+        for args_name, key in cls._ZP_OF_ARGS:
+            args = getattr(scheme, args_name, None)
+            if args is not None and getattr(args, "symmetric", False):
+                keys.append(key)
+        return keys
+
     @classmethod
     def _remove_symmetric_zp(cls, state_dict: dict, scheme) -> dict:
         """compressors/base.py:147-167: vLLM cannot load zero points of symmetric schemes"""
-        for args_name, key in (
-            ("input_activations", "input_zero_point"),
-            ("weights", "weight_zero_point"),
-            ("output_activations", "output_zero_point"),
-        ):
-            args = getattr(scheme, args_name, None)
-            if args is not None and getattr(args, "symmetric", False):
-                state_dict.pop(key, None)
+        for key in cls._symmetric_zp_keys(scheme):
+            state_dict.pop(key, None)
         return state_dict
 
 
@@ -110,12 +116,21 @@ def compress_module(module: torch.nn.Module, format: Optional[CompressionFormat]
 
 
 def _by_format(modules, format):
-    groups = {}
+    """modules grouped by the wire format their scheme resolves to; the resolution (and the `scheme.format` write-back of
+    compress_module, compressors/base.py:186-190) happens once per (scheme object, module type), not once per module"""
+    groups, seen = {}, {}
     for m in modules:
         scheme = getattr(m, "quantization_scheme", None)
-        if not is_scheme(scheme):
-            continue
-        groups.setdefault(_resolve_format(m, scheme, format).value, []).append(m)
+        key = (id(scheme), type(m))
+        fmt = seen.get(key)
+        if fmt is None:
+            if not is_scheme(scheme):
+                continue
+            fmt = seen[key] = _resolve_format(m, scheme, format).value
+        group = groups.get(fmt)
+        if group is None:
+            group = groups[fmt] = []
+        group.append(m)
     return groups
 
 

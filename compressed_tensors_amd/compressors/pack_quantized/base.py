@@ -136,43 +136,86 @@ class PackedQuantizationCompressor(BaseCompressor):
     # ------------------------------------------------------------------ batched module paths
     @classmethod
     def compress_modules(cls, modules) -> None:
-        """One launch for every eligible module (int4, 16-bit, group / channel scales), the rest
-        one by one.  State-dict results are identical to compress_module's."""
+        """One launch for every eligible module (int4, 16-bit, group / channel scales), the rest one by one.  The modules end in
+        exactly the state `compress_module` leaves them in.
+
+        Host side (bench.py `tinyllama_checkpoint.api`): the table is built from the modules' own entries (no state-dict copies), the
+        launch is issued BEFORE any module is touched, and the per-module bookkeeping — drop `weight` (and the zero point of a
+        symmetric scheme), add `weight_packed` / `weight_shape` — then runs under the kernel as a delta (`swap_direct_entries`)."""
         from ...quantization.quant_args import QuantizationStatus
-        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+        from ...utils.module import swap_direct_entries
 
         batches = {}  # (device, dtype) -> (entries, jobs): one table and one launch per GPU and weight dtype
+        rest = []
+        schemes = {}  # id(scheme) -> (group or 0 for channel, asymmetric with packed zero points) | None: what only depends on the scheme
+        f16 = (torch.bfloat16, torch.float16)
         for m in modules:
             scheme = m.quantization_scheme
-            sd = get_direct_state_dict(m)
-            w, scale, zp = sd.get("weight"), sd.get("weight_scale"), sd.get("weight_zero_point")
-            wa = scheme.weights
-            ok = (w is not None and w.is_cuda and w.is_contiguous() and w.data_ptr() % 16 == 0
-                  and enum_value(getattr(wa, "type", "int")) == "int"
-                  and codec.w4_batch_eligible(w.shape, w.dtype, scale, zp, num_bits=int(wa.num_bits), strategy=wa.strategy,
-                                              group_size=getattr(wa, "group_size", None), g_idx=sd.get("weight_g_idx"), device=w.device))
+            info = schemes.get(id(scheme), 0)
+            if info == 0:
+                wa = scheme.weights
+                st = enum_value(wa.strategy)
+                info = None
+                if int(wa.num_bits) == 4 and enum_value(getattr(wa, "type", "int")) == "int" and st in ("group", "channel"):
+                    g = 0 if st == "channel" else int(getattr(wa, "group_size", 0) or -1)
+                    if g >= 0 and g % 32 == 0:
+                        info = (g, not wa.symmetric)
+                schemes[id(scheme)] = info
+            params, buffers = m._parameters, m._buffers
+            w = params.get("weight")
+            if w is None:
+                w = buffers.get("weight")
+            scale = params.get("weight_scale")
+            if scale is None:
+                scale = buffers.get("weight_scale")
+            zp = params.get("weight_zero_point")
+            if zp is None:
+                zp = buffers.get("weight_zero_point")
+            # the conditions of codec.w4_batch_eligible, on the module's own entries
+            ok = (info is not None and w is not None and scale is not None and w.dim() == 2 and w.dtype in f16 and scale.dtype is w.dtype
+                  and w.is_cuda and w.is_contiguous() and w.data_ptr() % 16 == 0
+                  and scale.is_contiguous() and scale.data_ptr() % 16 == 0 and scale.device == w.device
+                  and "weight_g_idx" not in params and "weight_g_idx" not in buffers)
+            if ok:
+                rows, cols = w.shape
+                group = info[0] or cols
+                ok = rows > 0 and cols % 32 == 0 and cols % group == 0 and scale.shape == (rows, cols // group)
+                if ok and zp is not None:
+                    ok = (zp.dtype is torch.int8 and zp.shape == scale.shape and zp.is_contiguous() and zp.data_ptr() % 16 == 0
+                          and zp.device == w.device)
             if not ok:
-                cls.compress_module(m)
+                rest.append(m)
                 continue
-            rows, cols = w.shape
-            group = cols if enum_value(wa.strategy) == "channel" else int(wa.group_size)
             packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=w.device)
             entries, jobs = batches.setdefault((w.device, w.dtype), ([], []))
             entries.append((w, scale, zp, packed, rows, cols, group))
-            jobs.append((m, sd, scheme, packed))
+            jobs.append((m, scheme, packed, zp, (rows, cols)))
         for (device, dtype), (entries, jobs) in batches.items():
             codec.W4Batch(entries, "compress", dtype).launch()
             # the zero points of the asymmetric modules: one more launch for all of them (pack_to_int32(zp, 4, packed_dim=0))
             zps = {}
-            for i, (m, sd, scheme, packed) in enumerate(jobs):
-                zp = sd.get("weight_zero_point")
-                if not scheme.weights.symmetric and enum_value(scheme.weights.strategy) in PACK_ZP_STRATS and zp is not None and zp.dtype is torch.int8 \
-                        and zp.dim() == 2 and zp.is_contiguous():
-                    zps[i] = (zp, torch.empty((math.ceil(zp.shape[0] * 4 / 32), zp.shape[1]), dtype=torch.int32, device=device))
+            for i, (m, scheme, packed, zp, shape) in enumerate(jobs):
+                wa = scheme.weights
+                if not wa.symmetric and enum_value(wa.strategy) in PACK_ZP_STRATS:
+                    assert zp is not None, "Asymmetric quant requires zero-point values"
+                    if zp.dtype is torch.int8 and zp.dim() == 2 and zp.is_contiguous():
+                        zps[i] = (zp, torch.empty((math.ceil(zp.shape[0] * 4 / 32), zp.shape[1]), dtype=torch.int32, device=device))
             codec.zp4_batch(zps.values(), "pack")
-            for i, (m, sd, scheme, packed) in enumerate(jobs):
-                replace_direct_state_dict(m, cls.compress(sd, scheme, _prepacked=packed, _prezp=zps[i][1] if i in zps else None))
-                m.quantization_status = QuantizationStatus.COMPRESSED
+            # from here on the host works under the kernels
+            shape_of = {}
+            for i, (m, scheme, packed, zp, shape) in enumerate(jobs):
+                base = shape_of.get(shape)
+                if base is None:
+                    base = shape_of[shape] = torch.tensor(shape)  # int64, CPU: as upstream (:105)
+                add = {"weight_packed": packed, "weight_shape": base.clone()}
+                remove = ["weight"]
+                wa = scheme.weights
+                if not wa.symmetric and enum_value(wa.strategy) in PACK_ZP_STRATS:
+                    add["weight_zero_point"] = zps[i][1] if i in zps else codec.pack_to_int32(zp.data.to(torch.int8), wa.num_bits, packed_dim=0)
+                remove += cls._symmetric_zp_keys(scheme)
+                swap_direct_entries(m, remove, add, QuantizationStatus.COMPRESSED)
+        for m in rest:
+            cls.compress_module(m)
 
     @classmethod
     def _batch_decompress(cls, state_dicts, schemes):
@@ -189,7 +232,7 @@ class PackedQuantizationCompressor(BaseCompressor):
                   and packed.dtype == torch.int32 and packed.data_ptr() % 16 == 0 and sd.get("weight_g_idx") is None)
             if not ok:
                 continue
-            shape = tuple(int(v) for v in shape_t.tolist())
+            shape = tuple(shape_t.tolist())
             if len(shape) != 2 or scale.ndim != 2:
                 continue
             # decompress infers the strategy from the scale shape (forward.py:99-130): (R, 1) channel, (R, G) group
@@ -228,15 +271,24 @@ class PackedQuantizationCompressor(BaseCompressor):
 
     @classmethod
     def decompress_modules(cls, modules) -> None:
+        """one launch (+ one for the packed zero points) for every eligible module; the modules end in exactly the state
+        `decompress_module` leaves them in: `weight_packed` replaced by `weight`, an asymmetric scheme's zero point unpacked to
+        int8, `weight_shape` kept (base.py:116-163)"""
         from ...quantization.quant_args import QuantizationStatus
-        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+        from ...utils.module import direct_entry, swap_direct_entries
 
         modules = list(modules)
-        sds = [get_direct_state_dict(m) for m in modules]
+        names = ("weight_packed", "weight_scale", "weight_shape", "weight_zero_point", "weight_g_idx")
+        sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]
         pre = cls._batch_decompress(sds, [m.quantization_scheme for m in modules])
-        for m, sd, (w, z) in zip(modules, sds, pre):
-            replace_direct_state_dict(m, cls.decompress(sd, m.quantization_scheme, _preweight=w, _prezp=z))
-            m.quantization_status = QuantizationStatus.DECOMPRESSED
+        for m, (w, z) in zip(modules, pre):
+            if w is None:
+                cls.decompress_module(m)
+                continue
+            add = {"weight": w}
+            if z is not None:
+                add["weight_zero_point"] = z
+            swap_direct_entries(m, ("weight_packed",), add, QuantizationStatus.DECOMPRESSED)
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

@@ -16,10 +16,12 @@ other shapes / int8 use the fused front end (`ct_marlin24_quant_compress`, no fu
 that reads the un-transposed int8 codes (the transpose is index arithmetic) and the scale kernel.
 
 The 2:4 structure check.  Upstream validates the quantized weight on the host before compressing (a blocking device read on
-a GPU).  Here the kernels OR a violation into one int32 slot of a per-stream flag ring and the class reads it back:
-immediately in `compress` (default: the ValueError is raised by the call, as upstream), or — inside
-`with Marlin24Compressor.deferred_structure_check():`, which `compress_modules` uses for a whole batch — once when the
-context exits, so that a checkpoint's worth of launches is queued without a host round trip per tensor.
+a GPU).  Here a violating lane stores 1 into an int32 slot.  Default (the ValueError is raised by the call, as upstream): the
+slot is a word of the thread's pinned, device-mapped mailbox (`_lib.Mailbox`) and the call spins on the stream until the launch
+has completed — no D2H copy, no torch synchronisation (65 -> see bench.py `marlin24.compress_us_default`).  Inside
+`with Marlin24Compressor.deferred_structure_check():` — which `compress_modules` uses for a whole batch — the slots are a
+per-stream device ring read back once when the context exits, so that a checkpoint's worth of launches is queued without a
+host round trip per tensor.
 """
 import contextlib
 import threading
@@ -190,14 +192,23 @@ class Marlin24Compressor(BaseCompressor):
                     and scale2d.is_cuda and scale2d.is_contiguous() and (zero_point is None or (zero_point.is_cuda and zero_point.is_contiguous()))
                     and (size_n * scale2d.shape[1]) % 64 == 0):
                 # everything in one host call: no int8 intermediate, no separate packing / scale launches
-                ring, deferred = cls._flag(weight.device)
+                if getattr(_local, "depth", 0) > 0:  # deferred: a slot of the stream's device-side ring, read when the context exits
+                    ring, _ = cls._flag(weight.device)
+                    flag_ptr, stream, mb = ring.take(getattr(_local, "label", None)), ring.stream, None
+                else:  # the call itself raises (upstream's behaviour): the verdict lands in the thread's pinned mailbox word
+                    stream = _lib.stream_of_device(weight.device)
+                    mb = _lib.mailbox(stream.device_index)
+                    mb.words[1] = 0
+                    flag_ptr = mb.dev + 8
                 packed, meta, scale_packed, _ = codec.marlin24_compress_w4_full(weight, scale2d, zero_point, group_size=g, group_perm=is_group,
-                                                                                flag_ptr=ring.take(getattr(_local, "label", None)), stream=ring.stream)
+                                                                                flag_ptr=flag_ptr, stream=stream)
                 state_dict["weight_packed"] = packed
                 state_dict["scale_packed"] = scale_packed
                 state_dict["meta"] = meta
-                if not deferred:
-                    ring.check()  # one host read, as the reference pipeline's structure check
+                if mb is not None:
+                    _lib.stream_wait(stream)  # the one host wait of the reference pipeline's structure check: a spin on the stream, no copy
+                    if mb.words[1]:
+                        raise ValueError(_STRUCTURE_ERROR)
                 return state_dict
             comp, meta, bad = codec.marlin24_quant_compress(weight, scale, zero_point, num_bits=int(weights.num_bits), group_size=g)
             packed = codec.marlin24_pack_weights(comp, int(weights.num_bits), transposed=True, add_offset=True)

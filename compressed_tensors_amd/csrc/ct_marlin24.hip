@@ -24,6 +24,11 @@ __host__ __device__ __forceinline__ int64_t meta_reorder_offset(int64_t r, int64
     return (dc / 2) * m * 2 + dr * 2 + dc % 2;
 }
 
+// the 2:4 structure verdict: every violating lane stores the same 1 (idempotent, no read-modify-write), at system scope — the slot may
+// live in pinned host memory (ct_mailbox_alloc: the default, check-per-call mode of Marlin24Compressor) where a device atomic
+// would need PCIe atomics
+__device__ __forceinline__ void raise_flag(int* bad) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // 4-bit code of a quad from its non-zero flags (:111-153)
 __device__ __forceinline__ uint32_t quad_code(bool m0, bool m1, bool m3) {
     const bool e0 = m0 && m1, e1 = !m0 && m1, e2 = !m0 && !m1;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_quant_compress_kernel(const v
         const bool violation = marlin24_item<XDT>(w, scale, sdt, zp, zdt, r, mc, k, cdiv, scale_cols, qmin, qmax, codes, word);
         stream_store8(comp + r * (k / 2) + mc * 8, codes);
         meta[meta_reorder_offset(r, mc, m, 2)] = (uint16_t)word;
-        if (violation) atomicOr(bad, 1);
+        if (violation) raise_flag(bad);
     }
 }
 
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_quant_compress_tiled_kernel(c
         dr += adj;
         s_meta[cl >> 1][dr * 2 + ((cl - adj) & 1)] = (uint16_t)word;
     }
-    if (violation) atomicOr(bad, 1);
+    if (violation) raise_flag(bad);
     __syncthreads();
     {
         const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_kernel(const void* _
         const int64_t pair_base = (tile_c * 8 + pair) * m * 2 + tile_r * 128;
         s_meta[pair][(int)(off - pair_base)] = (uint16_t)word;
     }
-    if (violation) atomicOr(bad, 1);
+    if (violation) raise_flag(bad);
     __syncthreads();
     {
         const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
             s_meta[cl >> 1][mpos0 + it * 16] = (uint16_t)word;
         }
     }
-    if (violation || vmax >= 16u * 24u) atomicOr(bad, 1);  // a quad with three or more non-zero codes
+    if (violation || vmax >= 16u * 24u) raise_flag(bad);  // a quad with three or more non-zero codes
     __syncthreads();
     {
         const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16

@@ -49,6 +49,26 @@ const char* ct_last_error(void);
 int ct_abi_version(void);
 
 /* ------------------------------------------------------------------------------------
+ * Host mailbox — the only entries that wait.  Two points of the reference's interface hand a
+ * DEVICE result to the HOST before the call may return: the number of kept values of the
+ * sparse-bitmask codec (`tensor[mask]` sizes its result on the host; restated S1 over
+ * utils/helpers.py:306-343) and the 2:4 structure verdict of the marlin-24 codec
+ * (`tensor_follows_mask_structure(...)` raises from the call, utils/helpers.py:87-109).
+ * With torch that is a D2H copy + a synchronisation per call (`.item()`, `.cpu()`: 20-30 us).
+ * Here the kernels write the word straight into pinned, device-mapped host memory (one
+ * system-scope store) and the host spins on it.
+ *   ct_mailbox_alloc     `bytes` of zeroed pinned host memory; *dev_ptr is what the kernels get
+ *   ct_mailbox_wait_i64  returns in *value the 64-bit word at host_word as soon as it differs
+ *                        from `pending` (the host writes `pending` before the launch); if the
+ *                        stream drains first, whatever the word holds then
+ *   ct_stream_wait       returns when every launch queued on `stream` has completed (spins on
+ *                        hipStreamQuery: ~1 us after completion, no interrupt, no copy) */
+int ct_mailbox_alloc(int64_t bytes, void** host_ptr, void** dev_ptr);
+int ct_mailbox_free(void* host_ptr);
+int ct_mailbox_wait_i64(const int64_t* host_word, int64_t pending, ct_stream_t stream, int64_t* value);
+int ct_stream_wait(ct_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Scale / zero-point addressing used by every quantization entry point:
  *     idx(r, c) = (r / rdiv) * scale_cols + (col_group ? col_group[c] : c / cdiv)
  * tensor:  rdiv = rows, cdiv = cols, scale_cols = 1

@@ -293,6 +293,26 @@ def test_gidx_vs_oracle(cta, dev, dt, sym, shape, gs):
     assert eq(out.cpu(), O.dequantize(ref, scale, zp, strategy="group", group_size=gs, g_idx=g_idx))
 
 
+def test_gidx_rewritten_in_place_is_seen(cta, dev):
+    """a weight_g_idx first seen as all -1 (plain column order) and then filled through `param.data.copy_` — which
+    neither moves the pointer nor bumps the version counter — must use the new ordering on the next call"""
+    g = torch.Generator().manual_seed(5)
+    rows, cols, gs = 16, 1024, 128
+    x = torch.randn(rows, cols, generator=g).to(BF16)
+    scale = (torch.rand((rows, cols // gs), generator=g) * 0.3 + 0.05).to(BF16)
+    kw = dict(num_bits=4, strategy="group", group_size=gs)
+    param = torch.nn.Parameter(torch.full((cols,), -1, dtype=torch.int32, device=dev), requires_grad=False)
+    plain = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), None, g_idx=param.data, **kw)
+    assert eq(plain.cpu(), O.pack_to_int32(O.quantize(x, scale, None, dtype=torch.int8, **kw), 4).contiguous())
+    g_idx = (torch.arange(cols, dtype=torch.int32) // gs)[torch.randperm(cols, generator=g)].contiguous()
+    param.data.copy_(g_idx.to(dev))
+    ordered = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), None, g_idx=param.data, **kw)
+    ref = O.quantize(x, scale, None, dtype=torch.int8, g_idx=g_idx, **kw)
+    assert eq(ordered.cpu(), O.pack_to_int32(ref, 4).contiguous())
+    out = cta.codec.unpack_and_dequantize(ordered, x.shape, scale.to(dev), None, g_idx=param.data, **kw)
+    assert eq(out.cpu(), O.dequantize(ref, scale, None, strategy="group", group_size=gs, g_idx=g_idx))
+
+
 def test_bf16_reciprocal_fast_path_is_exact(cta, dev):
     """exhaustive over all 65536 x 65536 bf16 (x, scale) pairs inside the fast-path range"""
     assert cta.codec.selftest_bf16_div(0, 65536) == 0
