@@ -20,8 +20,10 @@ roofline.step).  Every extra leg's kernel row is also appended to roofline.kerne
 
 value = algorithmic bytes of all ranks / max-over-ranks wall time, in GB/s; algorithmic bytes
 per step = 2 x (2 N^2 + 2 N^2/128 + N^2/2) = 337,641,472 B at N = 8192.
-Multi-GPU (--gpus N, launched by torch.distributed.run): every rank processes its own weight
-shard, no collective on the data path (weak scaling); only the timing uses a barrier and a MAX.
+Multi-GPU (--gpus N): under torch.distributed.run one process per GPU, as the driver launches it; without a launcher
+(`python bench.py --gpus N`) the script starts its N ranks itself.  Every rank processes its own weight shard, no collective
+on the data path (weak scaling); only the timing uses a barrier and a MAX.  `config.ranks_seen` is the process group's size
+and `config.per_rank_GBps` what each rank did on its own.
 """
 import argparse
 import json
@@ -95,6 +97,7 @@ _WARM_SCALE = float(os.environ.get("CT_BENCH_WARM_SCALE", "1"))
 WARM_MS = 250.0 * _WARM_SCALE   # fixed-DURATION device warm-up before the first timed region (independent of --warmup)
 KERNEL_WARM_MS = 40.0 * _WARM_SCALE  # ... and before every per-kernel event timing
 BLOCKS = 5        # timed regions are repeated BLOCKS times; the MEDIAN block is the one reported
+MIN_LAUNCHES_PER_BLOCK = 60  # every per-kernel / per-call timing block holds at least this many back-to-back launches (VERDICT r03 hygiene)
 
 
 def device_warmup(fns, min_ms):
@@ -106,14 +109,9 @@ def device_warmup(fns, min_ms):
             for f in fns:
                 f(i)
             i += 1
-        if (time.perf_counter() - t0) * 1e3 >= 0.6 * min_ms and "busy" not in CLOCKS:
-            CLOCKS["busy"] = read_clocks()  # sampled while the queue is full: the clocks the timed region runs at
         torch.cuda.synchronize()
         if (time.perf_counter() - t0) * 1e3 >= min_ms:
             return i
-
-
-CLOCKS = {}
 
 
 def median(xs):
@@ -124,6 +122,7 @@ def median(xs):
 def time_kernel(fn, iters, offset=0, spread=None):
     """average launch duration (us) with HIP events on the launch stream: >= KERNEL_WARM_MS of the same launches first, then
     BLOCKS blocks of `iters` back-to-back launches; the median block is returned (min / max go to `spread` if given)"""
+    iters = max(int(iters), MIN_LAUNCHES_PER_BLOCK)
     device_warmup([lambda i: fn(offset + i)], KERNEL_WARM_MS)
     per = []
     for _ in range(BLOCKS):
@@ -139,21 +138,21 @@ def time_kernel(fn, iters, offset=0, spread=None):
     return median(per)
 
 
-def read_clocks():
-    """current shader / memory / fabric clock levels from sysfs (the '*' line of pp_dpm_*), if the box exposes them"""
-    import glob
-
-    out = {}
-    for name in ("sclk", "mclk", "fclk"):
-        for path in sorted(glob.glob(f"/sys/class/drm/card*/device/pp_dpm_{name}")):
-            try:
-                cur = [l.strip() for l in open(path).read().splitlines() if l.strip().endswith("*")]
-            except OSError:
-                continue
-            if cur:
-                out[name] = cur[0].rstrip("*").strip()
-                break
-    return out or None
+def time_calls(fn, iters=MIN_LAUNCHES_PER_BLOCK, offset=0):
+    """per-call WALL time (us) of a plug-in call that may wait on the device itself (e.g. BitmaskTensor.from_dense needs nnz on the
+    host before it can return): KERNEL_WARM_MS of the same calls, then BLOCKS blocks of `iters` back-to-back calls between two
+    synchronisations; the median block and the (min, max) are returned.  HIP events cannot time these: the host is part of the path."""
+    iters = max(int(iters), MIN_LAUNCHES_PER_BLOCK)
+    device_warmup([lambda i: fn(offset + i)], KERNEL_WARM_MS)
+    per = []
+    for _ in range(BLOCKS):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            fn(offset + i)
+        torch.cuda.synchronize()
+        per.append((time.perf_counter() - t0) / iters * 1e6)
+    return median(per), min(per), max(per)
 
 
 def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, actorder=False):
@@ -357,7 +356,7 @@ def cpu_baseline(dev):
     reported (`kind: "reference"`).  Beside it (and alone, `kind: "port"`, when no reference is present): oracle/eager_ref.py, the
     reference's eager torch op sequence restated (quantize: divide / add / clamp / round / cast passes in bf16; pack: int32 upcast,
     shifts, scatter_add_; unpack: gather of a (rows x groups, 32) int32 matrix; dequantize), pinned bit-for-bit against the reference.
-    torch.set_num_threads(os.cpu_count()); 1 warm-up + min of 3.  Its outputs check the GPU path on the same tensor.
+    torch.set_num_threads(os.cpu_count()); 1 warm-up + min AND median of 3.  Its outputs check the GPU path on the same tensor.
     The C/OpenMP oracle (a stronger baseline than the reference) is reported as `cpu_baseline_port`."""
     O = _oracle()
     import eager_ref as E
@@ -368,15 +367,19 @@ def cpu_baseline(dev):
     torch.set_num_threads(cores)
     kw = dict(num_bits=BITS, strategy="group", group_size=GROUP)
 
-    def best_of(fn, n=3):
+    medians = {}
+
+    def best_of(fn, n=3, label=None):
+        """1 warm-up, then min (returned) and median (kept under `label`) of n >= 3 runs: SURVEY 8d / BASELINE.md 4"""
         fn()
-        best, res = None, None
-        for _ in range(n):
+        ts, res = [], None
+        for _ in range(max(n, 3)):
             t0 = time.perf_counter()
             res = fn()
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        return best, res
+            ts.append(time.perf_counter() - t0)
+        if label:
+            medians[label] = round(median(ts), 4)
+        return min(ts), res
 
     points = {}
     by_threads = {}
@@ -392,8 +395,8 @@ def cpu_baseline(dev):
         t_c = t_d = None
         for th in sorted({cores, 64, 32, 16} & set(range(1, cores + 1)), reverse=True):
             torch.set_num_threads(th)
-            tc, c = best_of(lambda: E.pack_quantized_compress(sd, symmetric=True, **kw), 2 if th != cores else 3)
-            td, d = best_of(lambda: E.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True), 2 if th != cores else 3)
+            tc, c = best_of(lambda: E.pack_quantized_compress(sd, symmetric=True, **kw), 3, f"restatement_compress_s_{n}_{th}thr")
+            td, d = best_of(lambda: E.pack_quantized_decompress(c, num_bits=BITS, strategy="group", symmetric=True), 3, f"restatement_decompress_s_{n}_{th}thr")
             if n == N:
                 by_threads[str(th)] = round(tc + td, 4)
             if t_c is None or tc + td < t_c + t_d:
@@ -401,13 +404,13 @@ def cpu_baseline(dev):
         ref_pt = None
         if ref is not None and n == N:  # the reference's OWN classes on the same tensor, at the thread count that was best for the op sequence
             torch.set_num_threads(best_th)
-            rc_t, rc = best_of(lambda: ref["cls"].compress(dict(sd), ref["scheme"]), 2)
-            rd_t, rd = best_of(lambda: ref["cls"].decompress(dict(rc), ref["scheme"]), 2)
+            rc_t, rc = best_of(lambda: ref["cls"].compress(dict(sd), ref["scheme"]), 3, "reference_compress_s")
+            rd_t, rd = best_of(lambda: ref["cls"].decompress(dict(rc), ref["scheme"]), 3, "reference_decompress_s")
             ref_pt = dict(t_c=rc_t, t_d=rd_t, threads=best_th,
                           same_as_restatement=bool(torch.equal(rc["weight_packed"], c["weight_packed"]) and torch.equal(rd["weight"].view(torch.int16), d["weight"].view(torch.int16))))
         torch.set_num_threads(cores)
-        t_pc, pc = best_of(lambda: O.pack_quantized_compress(sd, symmetric=True, **kw), 2)
-        t_pd, pd = best_of(lambda: O.pack_quantized_decompress(pc, num_bits=BITS, strategy="group", symmetric=True), 2)
+        t_pc, pc = best_of(lambda: O.pack_quantized_compress(sd, symmetric=True, **kw), 3)
+        t_pd, pd = best_of(lambda: O.pack_quantized_decompress(pc, num_bits=BITS, strategy="group", symmetric=True), 3)
         g_packed = codec.quantize_and_pack(w.to(dev), scale.to(dev), zp.to(dev), **kw)
         g_dec = codec.unpack_and_dequantize(g_packed, (n, n), scale.to(dev), None, **kw)
         g_scale, g_zp = codec.minmax_qparams(w.to(dev), num_bits=BITS, group_size=GROUP, symmetric=True)
@@ -464,8 +467,9 @@ def cpu_baseline(dev):
         "impl": "torch-eager: oracle/eager_ref.py restates the reference's op sequence (pack_quantized/base.py:62-163, helpers.py:20-180, "
                 "forward_helpers.py:118-177,523-572) on CPU tensors; torch.set_num_threads swept over {os.cpu_count(), 64, 32, 16}, best reported; "
                 "bit-identical to the reference in the build container",
-        "sample": f"PackedQuantizationCompressor-shaped compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 2-3 per thread count "
-                  f"(compress {p['t_c']:.3f} s, decompress {p['t_d']:.3f} s)",
+        "sample": f"PackedQuantizationCompressor-shaped compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 3 per thread count "
+                  f"(compress {p['t_c']:.3f} s, decompress {p['t_d']:.3f} s); medians in `median_s`",
+        "median_s": medians,
         "compress_s": round(p["t_c"], 4), "decompress_s": round(p["t_d"], 4),
         "at_4096": {"value": gbps(4096, points[4096]["t_c"] + points[4096]["t_d"]), "compress_s": round(points[4096]["t_c"], 4),
                     "decompress_s": round(points[4096]["t_d"], 4)},
@@ -483,13 +487,15 @@ def cpu_baseline(dev):
         eager.update({"value": gbps(N, rp["t_c"] + rp["t_d"]), "cores": rp["threads"], "kind": "reference",
                       "impl": "the reference's own PackedQuantizationCompressor.compress / .decompress (compressors/pack_quantized/base.py:62-163) on CPU tensors, imported from the "
                               "archive oracle/stage_ref.py staged (oracle/_ref); torch threads = the best of the sweep in seconds_by_torch_threads",
-                      "sample": f"compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 2 (compress {rp['t_c']:.3f} s, decompress {rp['t_d']:.3f} s)",
+                      "sample": f"compress + decompress of ONE W4A16 g128 {N}x{N} bf16 weight, 1 warm-up + min of 3 (compress {rp['t_c']:.3f} s, decompress {rp['t_d']:.3f} s; "
+                                f"medians {medians.get('reference_compress_s')} / {medians.get('reference_decompress_s')} s)",
+                      "value_from_medians": gbps(N, medians.get("reference_compress_s", rp["t_c"]) + medians.get("reference_decompress_s", rp["t_d"])),
                       "compress_s": round(rp["t_c"], 4), "decompress_s": round(rp["t_d"], 4), "bit_identical_to_restatement_and_gpu": bool(rp["same_as_restatement"] and p["matches"])})
         eager["gpu_bit_exact_vs_oracle"] = bool(eager["gpu_bit_exact_vs_oracle"] and rp["same_as_restatement"])
     port = {
         "value": gbps(N, p["t_pc"] + p["t_pd"]), "unit": "GB/s", "cores": O.num_threads(), "kind": "port",
         "impl": "C restatement with OpenMP over rows (oracle/ct_oracle.c), unfused quantize->pack / unpack->dequantize",
-        "sample": f"the same {N}x{N} weight, best of 2 ({p['t_pc'] + p['t_pd']:.3f} s)",
+        "sample": f"the same {N}x{N} weight, best of 3 ({p['t_pc'] + p['t_pd']:.3f} s)",
         "at_4096": {"value": gbps(4096, points[4096]["t_pc"] + points[4096]["t_pd"])},
     }
     return eager, port
@@ -545,6 +551,37 @@ def bitmask_leg(dev):
     us_c1 = time_kernel(compress1, 24)
     ok1 = all(torch.equal(it["v2"].view(torch.int16), it["values"].view(torch.int16)) and torch.equal(it["bm2"], it["bitmask"])
               and torch.equal(it["ro2"], it["ro"]) and int(it["ws"][-1].item()) == it["values"].numel() for it in items)
+    # the drop-in class (VERDICT r03 weak #2c): BitmaskTensor.from_dense allocates its own worst-case value buffer, bitmask, row
+    # offsets and workspace and must have nnz on the host before it returns; .decompress() allocates the dense output
+    api = {}
+    try:
+        from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
+
+        bts = [BitmaskTensor(shape=(N, N), compressed=it["values"], bitmask=it["bitmask"], row_offsets=it["ro"]) for it in items]
+        last = {}
+
+        def api_compress(i):
+            last["bt"] = BitmaskTensor.from_dense(items[i % NB]["w"])
+
+        def api_decompress(i):
+            last["dense"] = bts[i % NB].decompress()
+
+        c_us, c_min, c_max = time_calls(api_compress)
+        bt = last["bt"]
+        j = (MIN_LAUNCHES_PER_BLOCK - 1) % NB
+        api_ok = (torch.equal(bt.compressed.view(torch.int16), items[j]["values"].view(torch.int16)) and torch.equal(bt.bitmask, items[j]["bitmask"])
+                  and torch.equal(bt.row_offsets, items[j]["ro"]))
+        d_us, d_min, d_max = time_calls(api_decompress)
+        api_ok = api_ok and torch.equal(last["dense"].view(torch.int16), items[j]["w"].view(torch.int16))
+        last.clear()
+        api = {"api_compress_us": round(c_us, 2), "api_compress_us_min_max": [round(c_min, 2), round(c_max, 2)],
+               "api_compress_frac_hbm": round(alg / c_us / 1e3 / HBM_PEAK_GBPS, 4),
+               "api_decompress_us": round(d_us, 2), "api_decompress_us_min_max": [round(d_min, 2), round(d_max, 2)],
+               "api_decompress_frac_hbm": round(alg / d_us / 1e3 / HBM_PEAK_GBPS, 4), "api_bit_exact": bool(api_ok),
+               "api": "BitmaskTensor.from_dense(w) / .decompress(): per-call wall time incl. the class's own allocations and the host wait for nnz "
+                      "(pinned mailbox word, no D2H copy)"}
+    except Exception as e:
+        api = {"api_error": repr(e)}
     # sparse-24-bitmask (S2) on the same tensors pruned 2:4: compress = top-2 of every quad + bitmask, decompress = the 2:4-regular row path
     s24 = {}
     try:
@@ -617,7 +654,7 @@ def bitmask_leg(dev):
     except Exception as e:
         f32 = {"f32_error": repr(e)}
     return {
-        **s24, **f32,
+        **s24, **f32, **api,
         "workload": f"sparse-bitmask 50% unstructured {N}x{N} bf16 (nnz={nnz})",
         "alg_bytes": alg,
         "decompress_us": round(us_d, 2), "decompress_GBps": round(alg / us_d / 1e3, 1), "decompress_frac_hbm": round(alg / us_d / 1e3 / HBM_PEAK_GBPS, 4),
@@ -763,8 +800,9 @@ def marlin24_leg(dev):
                 M.compress(sds[i % len(sds)], scheme)
             host_us.append((time.perf_counter() - t0) / 18 * 1e6)
         torch.cuda.synchronize()
-    # upstream's semantics: the ValueError is raised by the call itself (one host read per tensor)
-    us_strict = time_kernel(lambda i: M.compress(sds[i % len(sds)], scheme), 18)
+    # upstream's semantics — the DEFAULT of the class: the ValueError is raised by the call itself, i.e. the host waits for the launch
+    # (a spin on the stream; the verdict is a pinned mailbox word).  Wall time per call: the host is part of this path.
+    us_strict, strict_min, strict_max = time_calls(lambda i: M.compress(sds[i % len(sds)], scheme))
     # the kernels alone, through the C ABI
     from compressed_tensors_amd import _lib
 
@@ -782,8 +820,14 @@ def marlin24_leg(dev):
     exact = exact and torch.equal(bufs[0], M.compress(sds[23 % len(sds)], scheme)["weight_packed"]) and int(flag.item()) == 0
     alg = 2 * N * N + 2 * N * (N // GROUP) + N * N // 4 + N * N // 8 + 2 * N * (N // GROUP)
     return {"workload": f"marlin-24 compress (2:4 + int4 g128), {N}x{N} bf16, plug-in class API",
-            "alg_bytes": alg, "compress_us": round(us, 1), "compress_GBps": round(alg / us / 1e3, 1),
-            "compress_frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "alg_bytes": alg,
+            # the class as a caller gets it by default: Marlin24Compressor.compress raises the 2:4 ValueError itself
+            "compress_us_default": round(us_strict, 1), "compress_us_default_min_max": [round(strict_min, 1), round(strict_max, 1)],
+            "compress_default_frac_hbm": round(alg / us_strict / 1e3 / HBM_PEAK_GBPS, 4),
+            # inside `with Marlin24Compressor.deferred_structure_check()` (what compress_modules / ModelCompressor use for a batch)
+            "compress_us_deferred_check": round(us, 1), "compress_deferred_check_frac_hbm": round(alg / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "compress_us": round(us_strict, 1), "compress_GBps": round(alg / us_strict / 1e3, 1),
+            "compress_frac_hbm": round(alg / us_strict / 1e3 / HBM_PEAK_GBPS, 4),
             "compress_us_structure_check_per_call": round(us_strict, 1), "host_issue_us_per_call": round(median(host_us), 1),
             "kernels_us": round(us_k, 2), "kernels_frac_hbm": round(alg / us_k / 1e3 / HBM_PEAK_GBPS, 4),
             "kernels": "marlin24_fused_w4_lean_kernel + marlin24_pack_scales_kernel (ct_marlin24_compress_w4_full)",
@@ -921,6 +965,10 @@ def roofline_rows(result):
     if b:
         row("bitmask_decompress16_kernel", "sparse-bitmask 50 % 8192x8192 bf16 (config 3), decompress", b["alg_bytes"], b["decompress_us"], bit_exact=b["round_trip_bit_exact"])
         row("flat16_resident_kernel", "sparse-bitmask 50 % 8192x8192 bf16 (config 3), compress", b["alg_bytes"], b["compress_us"], bit_exact=b["round_trip_bit_exact"])
+        if "api_compress_us" in b:
+            row("BitmaskTensor.from_dense", "config 3 through the plug-in class, wall time per call (allocations + host wait for nnz)", b["alg_bytes"], b["api_compress_us"],
+                bit_exact=b["api_bit_exact"])
+            row("BitmaskTensor.decompress", "config 3 through the plug-in class, wall time per call", b["alg_bytes"], b["api_decompress_us"], bit_exact=b["api_bit_exact"])
         if "s24_compress_us" in b:
             row("sparse24_pair_kernel", "sparse-24-bitmask 8192x8192 bf16, compress", b["s24_alg_bytes"], b["s24_compress_us"], bit_exact=b["s24_bit_exact"])
             row("bitmask_decompress16_kernel<2:4 rows>", "sparse-24-bitmask 8192x8192 bf16, decompress", b["s24_alg_bytes"], b["s24_decompress_us"], bit_exact=b["s24_bit_exact"])
@@ -944,7 +992,17 @@ def roofline_rows(result):
     m = leg("marlin24")
     if m:
         row("marlin24_fused_w4_lean_kernel", "marlin-24 2:4 + int4 g128 8192x8192 bf16 (config 4), kernel", m["alg_bytes"], m["kernels_us"], bit_exact=m["bit_exact_vs_oracle"])
-        row("Marlin24Compressor.compress", "config 4 through the plug-in class", m["alg_bytes"], m["compress_us"], bit_exact=m["bit_exact_vs_oracle"])
+        row("Marlin24Compressor.compress (default: the call raises the 2:4 ValueError)", "config 4 through the plug-in class, wall time per call",
+            m["alg_bytes"], m["compress_us_default"], bit_exact=m["bit_exact_vs_oracle"])
+        row("Marlin24Compressor.compress (deferred_structure_check)", "config 4 through the plug-in class inside the batch context", m["alg_bytes"],
+            m["compress_us_deferred_check"], bit_exact=m["bit_exact_vs_oracle"])
+    t = leg("tinyllama_checkpoint")
+    if t:
+        row("w4_*_batch_kernel x 2", "TinyLlama-1.1B-shaped W4A16 checkpoint (config 5), C ABI", t["alg_bytes_all_ranks"], t["ms_whole_checkpoint"] * 1e3)
+        a = t.get("api") or {}
+        if a.get("ms_both"):
+            row("ModelCompressor.compress_model + decompress_model", "config 5 through the drop-in API (154-module tree), wall time", t["alg_bytes_all_ranks"], a["ms_both"] * 1e3,
+                api_over_kernels=a["api_over_kernels"])
     q = leg("minmax_qparams")
     if q:
         row("qparams_absmax_kernel", "min-max observer int4 g128 8192x8192 bf16", q["alg_bytes"], q["us"])
@@ -1040,7 +1098,13 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
     total_bytes = sum(2 * (2 * r * c + 2 * r * (c // GROUP) + r * c // 2) for _, r, c in mods)
     w0, s0, z0, p0, o0 = keep[0]
     fq = codec.fake_quantize_tensor(w0, s0, z0, num_bits=BITS, strategy="group", group_size=GROUP)
-    return {"workload": "TinyLlama-1.1B-shaped checkpoint (154 Linear modules, 1.94 GB bf16), W4A16 g128 compress + decompress, "
+    api = {}
+    if world == 1:  # the drop-in API on the same checkpoint (VERDICT r03 missing #3): a module TREE through ModelCompressor
+        try:
+            api = tinyllama_api_leg(dev, mine, keep, best, fq)
+        except Exception as e:
+            api = {"error": repr(e)}
+    return {"api": api, "workload": "TinyLlama-1.1B-shaped checkpoint (154 Linear modules, 1.94 GB bf16), W4A16 g128 compress + decompress, "
                         f"LPT module shards over {world} rank(s), no collectives",
             "modules_this_rank": len(mine), "alg_bytes_all_ranks": total_bytes, "rank0_share_of_bytes": round(my_bytes / total_bytes, 4),
             "launches": "one ct_quant_pack_batch + one ct_unpack_dequant_batch per rank",
@@ -1049,6 +1113,79 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
             "ms_whole_checkpoint_asymmetric": round(t_asym * 1e3, 4), "asymmetric_round_trip_equals_fake_quantize": asym_ok,
             "frac_of_hbm_peak_per_gpu": round(total_bytes / best / 1e9 / world / HBM_PEAK_GBPS, 4),
             "round_trip_equals_fake_quantize": bool(torch.equal(o0, fq))}
+
+
+def tinyllama_module_tree(mine, keep, scheme):
+    """a TinyLlama-shaped nn.Module tree (model.layers[L].{q,k,v,o,gate,up,down}_proj: 154 Linear modules) over the tensors of the
+    C-ABI leg, with the scheme attached the way upstream's apply_quantization_config does it: ONE scheme object per config group
+    (quantization/lifecycle/apply.py:156-165) and weight_scale / weight_zero_point as non-trainable parameters"""
+    root = torch.nn.Module()
+    root.layers = torch.nn.ModuleList()
+    blocks = {}
+    for (name, r, c), (w, s_, z, _, _) in zip(mine, keep):
+        parts = name.split(".")
+        layer, proj = int(parts[2]), parts[3]
+        blk = blocks.get(layer)
+        if blk is None:
+            blk = blocks[layer] = torch.nn.Module()
+            root.layers.append(blk)
+        lin = torch.nn.Linear(c, r, bias=False, device="meta")
+        lin.weight = torch.nn.Parameter(w, requires_grad=False)
+        lin.weight_scale = torch.nn.Parameter(s_, requires_grad=False)
+        lin.weight_zero_point = torch.nn.Parameter(z, requires_grad=False)
+        lin.quantization_scheme = scheme
+        setattr(blk, proj, lin)
+    return root
+
+
+def tinyllama_api_leg(dev, mine, keep, kernels_s, fq0):
+    """ModelCompressor().compress_model(model) + .decompress_model(model) on the 154-module tree: WALL time, weights resident in HBM,
+    median of 7 cycles after 2 warm-up cycles (reference model_compressors/model_compressor.py:138-207, utils/module.py:33-65).
+    Everything the drop-in does is inside the timed region: the module walk, the format resolution, the table build and its upload,
+    the output allocations, the two launches and the per-module parameter replacement."""
+    import compressed_tensors_amd as cta
+
+    args = cta.QuantizationArgs(num_bits=BITS, group_size=GROUP, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    model = tinyllama_module_tree(mine, keep, scheme)
+    mc = cta.ModelCompressor()
+
+    def cycle():
+        mc.compress_model(model)
+        mc.decompress_model(model)
+
+    cycle()
+    first_lin = model.layers[0].q_proj
+    ok = bool(torch.equal(first_lin.weight.data, fq0))  # module 0 of the tree is keep[0]: round trip == fake_quantize
+    cycle()
+    both, comp, dec, host_c, host_d = [], [], [], [], []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cycle()
+        torch.cuda.synchronize()
+        both.append(time.perf_counter() - t0)
+    for _ in range(7):  # each direction on its own (a synchronisation in between), and the host's share of it (time until the call returns)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mc.compress_model(model)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        mc.decompress_model(model)
+        t3 = time.perf_counter()
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        comp.append(t2 - t0); host_c.append(t1 - t0); dec.append(t4 - t2); host_d.append(t3 - t2)
+    n = len(keep)
+    out = {"entry": "compressed_tensors_amd.ModelCompressor().compress_model(model) + .decompress_model(model), 154-module TinyLlama-shaped nn.Module tree",
+           "modules": n, "ms_both": round(median(both) * 1e3, 4), "ms_both_min_max": [round(min(both) * 1e3, 4), round(max(both) * 1e3, 4)],
+           "ms_compress_model": round(median(comp) * 1e3, 4), "ms_decompress_model": round(median(dec) * 1e3, 4),
+           "ms_host_until_compress_model_returns": round(median(host_c) * 1e3, 4), "ms_host_until_decompress_model_returns": round(median(host_d) * 1e3, 4),
+           "host_us_per_module_compress": round(median(host_c) / n * 1e6, 2), "host_us_per_module_decompress": round(median(host_d) / n * 1e6, 2),
+           "ms_kernels_only": round(kernels_s * 1e3, 4), "api_over_kernels": round(median(both) / kernels_s, 3),
+           "round_trip_equals_fake_quantize": ok, "timing": "wall clock, synchronize on both sides, median of 7 cycles after 2 warm-up cycles"}
+    return out
 
 
 def tinyllama_w8_leg(dev):
@@ -1198,6 +1335,22 @@ def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters
     return out
 
 
+def self_launch(n: int) -> int:
+    """re-exec this command under torch.distributed.run: one process per GPU, rendezvous on 127.0.0.1 and a free port"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL / cross-process device memory)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1217,8 +1370,10 @@ def main():
     distributed = world > 1
     if a.gpus != world and distributed:
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
-    if a.gpus > 1 and not distributed:
-        raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the command the driver would have used) and hand
+        # its exit code back; rank 0 of that run prints the one JSON line on the stdout this process shares with it
+        raise SystemExit(self_launch(a.gpus))
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # CT_BENCH_SHARE_GPU=1 (test knob): every rank uses cuda:0 and the timing collectives go over gloo, so
@@ -1275,12 +1430,14 @@ def main():
                 c(i)
                 d(i + NSETS // 2)  # a packed buffer written 8 steps (1.3 GB of traffic) ago: evicted from the Infinity Cache
             torch.cuda.synchronize()
+            local = time.perf_counter() - t0  # this rank's own work, before it waits for the others
             barrier()
             el = time.perf_counter() - t0
             if distributed:
                 t = torch.tensor([el], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)  # timing only; the data path has no collective
                 el = float(t.item())
+            local_times.append(local)
             return el
 
         if cold_probe is not None:  # what round 2's protocol measured: --warmup steps only, on a device that has done nothing yet
@@ -1294,14 +1451,23 @@ def main():
             d(i + NSETS // 2)
         return [block() for _ in range(BLOCKS)]
 
-    clocks_before = read_clocks()
     cold = []
+    local_times = []
     blocks_one = timed_steps(compress, decompress, cold_probe=cold)
+    if not a.one_stream:
+        local_times.clear()
     blocks = blocks_one if a.one_stream else timed_steps(compress2, decompress2)
-    clocks_after = read_clocks()
-    elapsed_one, elapsed = median(blocks_one), median(blocks)
-
+    # what every rank did on its own (median of its blocks of the reported configuration), gathered for the line: a rank that lags shows
     step_bytes = 2 * alg_bytes_one_direction()
+    mine = step_bytes * a.steps / median(local_times[-BLOCKS:]) / 1e9
+    ranks_seen, per_rank = 1, [round(mine, 1)]
+    if distributed:
+        ranks_seen = dist.get_world_size()
+        t = torch.zeros(ranks_seen, dtype=torch.float64, device=red_dev)
+        t[rank] = mine
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)  # reporting only
+        per_rank = [round(float(v), 1) for v in t.tolist()]
+    elapsed_one, elapsed = median(blocks_one), median(blocks)
     value = world * step_bytes * a.steps / elapsed / 1e9
 
     result = None
@@ -1346,6 +1512,9 @@ def main():
                 "boundary": "C ABI (ct_quant_pack + ct_unpack_dequant), inputs resident in HBM",
                 "streams": 1 if a.one_stream else 2,
                 "parallelism": f"{world} independent weight shards, no collectives",
+                "value_one_stream": round(world * step_bytes * a.steps / elapsed_one / 1e9, 1),
+                "ranks_seen": ranks_seen,
+                "per_rank_GBps": per_rank,
             },
             "frac_of_hbm_peak": round(value / world / HBM_PEAK_GBPS, 4),
             "value_one_stream": round(world * step_bytes * a.steps / elapsed_one / 1e9, 1),
@@ -1368,8 +1537,7 @@ def main():
                                      "(barrier + synchronize on both sides of every block, wall clock, max over ranks); the MEDIAN block is ms_per_step",
                          "ms_per_step_blocks": [round(x / a.steps * 1e3, 5) for x in blocks],
                          "ms_per_step_blocks_one_stream": [round(x / a.steps * 1e3, 5) for x in blocks_one],
-                         "ms_per_step_without_device_warmup": round(cold[0] / a.steps * 1e3, 5) if cold else None,
-                         "clocks_idle_before": clocks_before, "clocks_under_load": CLOCKS.get("busy"), "clocks_idle_after": clocks_after},
+                         "ms_per_step_without_device_warmup": round(cold[0] / a.steps * 1e3, 5) if cold else None},
                 "kernels": [dict(kernel=k, config=f"W4A16 g128 {N}x{N} bf16", alg_bytes=one, us=v["avg_us"], min_us=v.get("min_us"), max_us=v.get("max_us"),
                                  GBps=v["GBps"], frac=v["frac"], valu_busy_frac=v.get("valu_busy_frac")) for k, v in kernels.items()],
             },
@@ -1388,7 +1556,6 @@ def main():
                 torch.cuda.empty_cache()
             if isinstance(result.get("kernels_other"), dict) and "bf16_4096" in result["kernels_other"]:
                 result["kernels_4096"] = result["kernels_other"]["bf16_4096"]  # north_star names both sizes
-            result["roofline"]["kernels"] += roofline_rows(result)
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["cpu_baseline_port"] = cpu_baseline(dev)
         result["oracle_slice_check"] = oracle_slice_check(dev)  # never skipped: no configuration runs without the real checker
@@ -1412,6 +1579,8 @@ def main():
             leg = {"error": repr(e)}
         if rank == 0:
             result["tinyllama_checkpoint"] = leg
+            if world == 1:
+                result["roofline"]["kernels"] += roofline_rows(result)  # every extra leg's row, inside `roofline` so that the driver's parse keeps it
         if distributed or a.shard == "rows":
             torch.cuda.empty_cache()
             try:

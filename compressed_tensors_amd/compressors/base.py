@@ -15,10 +15,23 @@ from ..quantization.quant_args import QuantizationStatus, is_scheme
 from ..registry import RegistryMixin
 from ..utils.module import get_direct_state_dict, replace_direct_state_dict
 
-__all__ = ["BaseCompressor", "compress_module", "decompress_module", "compress_modules", "decompress_modules", "COMPRESSIBLE_MODULE_TYPES"]
+__all__ = ["BaseCompressor", "symmetric_zp_keys", "compress_module", "decompress_module", "compress_modules", "decompress_modules", "COMPRESSIBLE_MODULE_TYPES"]
 
 # reference compressors/base.py:31
 COMPRESSIBLE_MODULE_TYPES = (torch.nn.Linear, torch.nn.Embedding)
+
+
+_ZP_OF_ARGS = (("input_activations", "input_zero_point"), ("weights", "weight_zero_point"), ("output_activations", "output_zero_point"))
+
+
+def symmetric_zp_keys(scheme) -> list:
+    """the zero-point names that a symmetric scheme does not store (compressors/base.py:147-167)"""
+    keys = []
+    for args_name, key in _ZP_OF_ARGS:
+        args = getattr(scheme, args_name, None)
+        if args is not None and getattr(args, "symmetric", False):
+            keys.append(key)
+    return keys
 
 
 class BaseCompressor(RegistryMixin, ABC):
@@ -74,22 +87,10 @@ class BaseCompressor(RegistryMixin, ABC):
         shard, converters/ct_dequantizer.py:63-99); codecs may override to batch their launches"""
         return [cls.decompress(sd, scheme) for sd in state_dicts]
 
-    _ZP_OF_ARGS = (("input_activations", "input_zero_point"), ("weights", "weight_zero_point"), ("output_activations", "output_zero_point"))
-
-    @classmethod
-    def _symmetric_zp_keys(cls, scheme) -> list:
-        """the zero-point names that a symmetric scheme does not store (compressors/base.py:147-167)"""
-        keys = []
-        for args_name, key in cls._ZP_OF_ARGS:
-            args = getattr(scheme, args_name, None)
-            if args is not None and getattr(args, "symmetric", False):
-                keys.append(key)
-        return keys
-
     @classmethod
     def _remove_symmetric_zp(cls, state_dict: dict, scheme) -> dict:
         """compressors/base.py:147-167: vLLM cannot load zero points of symmetric schemes"""
-        for key in cls._symmetric_zp_keys(scheme):
+        for key in symmetric_zp_keys(scheme):
             state_dict.pop(key, None)
         return state_dict
 

@@ -14,7 +14,7 @@ from ... import codec
 from ...config import CompressionFormat
 from ...quantization.quant_args import enum_value
 from ...utils import getattr_chain
-from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor
+from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor, symmetric_zp_keys
 
 __all__ = ["PackedQuantizationCompressor"]
 
@@ -212,7 +212,7 @@ class PackedQuantizationCompressor(BaseCompressor):
                 wa = scheme.weights
                 if not wa.symmetric and enum_value(wa.strategy) in PACK_ZP_STRATS:
                     add["weight_zero_point"] = zps[i][1] if i in zps else codec.pack_to_int32(zp.data.to(torch.int8), wa.num_bits, packed_dim=0)
-                remove += cls._symmetric_zp_keys(scheme)
+                remove += symmetric_zp_keys(scheme)
                 swap_direct_entries(m, remove, add, QuantizationStatus.COMPRESSED)
         for m in rest:
             cls.compress_module(m)
@@ -280,7 +280,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         names = ("weight_packed", "weight_scale", "weight_shape", "weight_zero_point", "weight_g_idx")
         sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]
-        pre = cls._batch_decompress(sds, [m.quantization_scheme for m in modules])
+        pre = PackedQuantizationCompressor._batch_decompress(sds, [m.quantization_scheme for m in modules])  # (`cls` may be install()'s subclass of the UPSTREAM codec)
         for m, (w, z) in zip(modules, pre):
             if w is None:
                 cls.decompress_module(m)

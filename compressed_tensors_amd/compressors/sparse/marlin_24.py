@@ -133,17 +133,29 @@ class Marlin24Compressor(BaseCompressor):
         return ring, deferred
 
     @classmethod
-    def compress_modules(cls, modules) -> None:
-        """one host read for the whole batch.  (Upstream validates before it replaces a module; here every module of the batch
-        is already replaced when the single ValueError is raised — it names the offending modules.)"""
+    def compress_modules(cls, modules, names=None) -> None:
+        """One host read for the whole batch, and — as upstream, which validates before it replaces anything — no module is touched
+        unless EVERY module of the batch has the 2:4 structure: all launches are queued inside the deferred-check context (their
+        results held aside), the single ValueError raised at its exit names the offending modules (`names`: their dotted names, when
+        the caller has them), and only then are the modules' parameters replaced (a failing model used to be left
+        half-converted)."""
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+
+        modules = list(modules)
+        names = list(names) if names is not None else [None] * len(modules)
+        results = []
         with cls.deferred_structure_check():
-            for i, m in enumerate(modules):
+            for i, (m, name) in enumerate(zip(modules, names)):
                 w = getattr(m, "weight", None)
-                _local.label = f"module #{i} ({type(m).__name__}{'' if w is None else ' ' + 'x'.join(str(d) for d in w.shape)})"
+                _local.label = name or f"module #{i} ({type(m).__name__}{'' if w is None else ' ' + 'x'.join(str(d) for d in w.shape)})"
                 try:
-                    cls.compress_module(m)
+                    results.append(cls.compress(get_direct_state_dict(m), m.quantization_scheme))
                 finally:
                     _local.label = None
+        for m, new in zip(modules, results):
+            replace_direct_state_dict(m, new)
+            m.quantization_status = QuantizationStatus.COMPRESSED
 
     @staticmethod
     def validate_quant_compatability(weights) -> bool:

@@ -459,11 +459,15 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
                 }
                 words[i] = word;
             }
-            if (live[0]) {
+            if (live[UL - 1]) {  // every unit of the lane is inside the row: one wide store
                 uint32_t* dst = static_cast<uint32_t*>(p.out) + row * p.upr + cu[0];
                 if constexpr (UL == 4) stream_store16(dst, u32x4{words[0], words[1], words[2], words[3]});
                 else if constexpr (UL == 2) stream_store8(dst, u32x2{words[0], words[1]});
                 else __builtin_nontemporal_store(words[0], dst);
+            } else if constexpr (UL > 1) {  // the row ends inside this lane's units (upr % UL != 0): word by word, live units only
+#pragma unroll
+                for (int i = 0; i < UL; ++i)
+                    if (live[i]) __builtin_nontemporal_store(words[i], static_cast<uint32_t*>(p.out) + row * p.upr + cu[i]);
             }
         } else {
 #pragma unroll

@@ -1098,6 +1098,8 @@ typedef u32x4 u32x4_a2_t __attribute__((aligned(2)));
 constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB, 64 VGPRs)
 constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
 constexpr int kResMaxWGs = 8192;  // count words in the workspace: 1 GiB of 16-bit elements per launch, more goes in chunks
+constexpr int kResStampWGs = 1024; // CT_BITMASK_RESIDENT=3: time stamps of the first workgroups (two residency rounds at 8192^2)
+constexpr int kResRoundWords = 64; // "inclusive count through residency round r" words (kResMaxWGs / (2 x CUs) rounds at most)
 
 // ES = 4 (round 3): 32-bit payloads ride the same kernel as pairs of halves — `units`, `upr`, `capacity`, the count words and every
 // offset inside the kernel are in 16-byte units / 16-bit halves exactly as for ES = 2; only the non-zero test (per 32-bit element, flag
@@ -1109,7 +1111,8 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
                                                                     int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
                                                                     const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
                                                                     unsigned long long* __restrict__ run_out, uint32_t gen, unsigned long long wait_ticks,
-                                                                    unsigned long long* __restrict__ stamps, int stagger_lo, int stagger_hi, unsigned stagger_ticks) {
+                                                                    unsigned long long* __restrict__ stamps, int stagger_lo, int stagger_hi, unsigned stagger_ticks,
+                                                                    unsigned stagger_slope_q8, int round_wgs, unsigned long long* __restrict__ round_words) {
     constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[WAVES][kSlab];
@@ -1130,9 +1133,10 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     // in lockstep: everybody loads, then everybody stores — 2 x 25 us at 8192^2 for 36 us of traffic)
     if (b >= stagger_lo && b < stagger_hi) {
         const unsigned long long s0 = wall_clock64();
-        while (wall_clock64() - s0 < stagger_ticks) __builtin_amdgcn_s_sleep(16);
+        const unsigned long long wait = stagger_ticks + (((unsigned long long)(b - stagger_lo) * stagger_slope_q8) >> 8);
+        while (wall_clock64() - s0 < wait) __builtin_amdgcn_s_sleep(16);
     }
-    if (stamps && tid == 0 && b < 512) stamps[b * 4 + 0] = wall_clock64();
+    if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 0] = wall_clock64();
     // ---- phase A
     u32x4 keep[KEEP][4];
 #pragma unroll
@@ -1174,7 +1178,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) wg += s_cnt[w];
         op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
-        if (stamps && b < 512) stamps[b * 4 + 1] = wall_clock64();
+        if (stamps && b < kResStampWGs) stamps[b * 4 + 1] = wall_clock64();
     }
     // ---- pass 2, while the word travels: ranks, row offsets, compaction through the wave's slab, read back in place
 #pragma unroll
@@ -1238,7 +1242,30 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     {
         long long part = 0;
         const unsigned long long t0 = wall_clock64();
-        for (int w0 = 0; w0 < b; w0 += (WAVES * 64)) {  // workgroup-uniform trip count
+        // a workgroup of residency round r >= 1 (b / round_wgs) starts when a round r - 1 workgroup retires: by then the LAST workgroup of
+        // round r - 1 has long published the inclusive count through itself (one word, below), so b polls that word plus the b - r * R
+        // words of its own round instead of all b.  If the word does not arrive within the budget: all b raw words, as before.
+        int w_lo = 0;
+        if (round_wgs > 0 && b >= round_wgs) {
+            const int r = b / round_wgs;
+            if (tid == 0) {
+                s_part[0] = -1;
+                for (;;) {
+                    const unsigned long long v = op_load(round_words + (r - 1));
+                    if ((uint32_t)(v >> 32) == gen) { s_part[0] = (long long)(uint32_t)v; break; }
+                    if (wall_clock64() - t0 >= wait_ticks) break;
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            __syncthreads();
+            const long long head = s_part[0];
+            __syncthreads();
+            if (head >= 0) {
+                w_lo = r * round_wgs;
+                if (tid == 0) part = head;
+            }
+        }
+        for (int w0 = w_lo; w0 < b; w0 += (WAVES * 64)) {  // workgroup-uniform trip count
             const int w = w0 + tid;
             const bool need = w < b;
             bool got = !need;
@@ -1273,7 +1300,13 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
         if (lane == 0) s_part[wave] = part;
     }
     __syncthreads();
-    if (stamps && tid == 0 && b < 512) stamps[b * 4 + 2] = wall_clock64();
+    if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 2] = wall_clock64();
+    if (round_wgs > 0 && tid == 0 && (b + 1) % round_wgs == 0 && b + 1 < (int)gridDim.x) {  // the last workgroup of a residency round
+        long long incl = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) incl += s_part[w] + s_cnt[w];
+        op_store(round_words + b / round_wgs, ((unsigned long long)gen << 32) | (uint32_t)incl);
+    }
     {
         int64_t run = base ? (int64_t)*base << SH : 0;  // the running totals between chunks are in elements
 #pragma unroll
@@ -1311,7 +1344,7 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
             if ((wt + 1) * kWT >= units && wt * kWT < units && lane == 0) op_store(run_out, (unsigned long long)(run >> SH));  // the chunk's last wave-tile
         }
     }
-    if (stamps && tid == 0 && b < 512) stamps[b * 4 + 3] = wall_clock64();
+    if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 3] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------- 2:4
@@ -1580,7 +1613,7 @@ int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols) {
     if (rows <= 0 || cols <= 0) return 16;
     const Flat16Plan p = flat16_plan(rows, cols);
     int64_t flat = p.nblocks * 8 + p.nblocks * 4 * 4 + 8 * kMaxChunks;  // block totals (int64) + span totals (int32) + chunk totals
-    const int64_t resident = (int64_t)(kResMaxWGs + 4 + 4 * 512) * 8;  // count words + control words (+ time stamps of the first 512 workgroups)
+    const int64_t resident = (int64_t)(kResMaxWGs + 4 + 4 * kResStampWGs + kResRoundWords) * 8;  // count words + control words (+ time stamps of the first workgroups) + round words
     if (resident > flat) flat = resident;
     const int64_t generic = (rows + 1) * 8;                  // row counts of the count / scan / scatter form
     return (flat > generic ? flat : generic) + 16;
@@ -1665,13 +1698,31 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 // single round a delayed start is pure loss (4096^2: 15.0 -> 17.4 us), with two it buys 48.2 -> 44.6 us at 8192^2.  The delay is
                 // one load phase of a workgroup at the CU's share of the HBM rate (~19 GB/s per CU): 128 KB -> 7 us.
                 const bool stagger = nwg >= 4 * (int64_t)cus;
-                const int stagger_lo = cus, stagger_hi = stagger ? 2 * cus : 0;
-                const unsigned stagger_ticks = (unsigned)((wg_wts * kWT * 16) / 188);  // 100 MHz ticks
+                int stagger_lo = cus, stagger_hi = stagger ? 2 * cus : 0;
+                unsigned stagger_ticks = (unsigned)((wg_wts * kWT * 16) / 188);  // 100 MHz ticks
+                unsigned stagger_slope_q8 = 0;
+                // EXPERIMENT knobs (round 4, removed once measured): CT_BM_X = "<stagger mode>:<spread us>:<round words 0/1>"
+                //   stagger mode 0 off, 1 second workgroup of a CU one load phase late (shipped), 2 gradient over the first residency round
+                static const char* xenv = std::getenv("CT_BM_X");
+                int use_rounds = 1;
+                if (xenv) {
+                    int mode = 1, spread = 12, rw = 1;
+                    sscanf(xenv, "%d:%d:%d", &mode, &spread, &rw);
+                    use_rounds = rw;
+                    if (mode == 0) stagger_hi = 0;
+                    else if (mode == 2 && stagger) {
+                        stagger_lo = 0; stagger_hi = 2 * cus; stagger_ticks = 0;
+                        stagger_slope_q8 = (unsigned)(((unsigned long long)spread * 100ull * 256ull) / (unsigned long long)(2 * cus));
+                    }
+                }
+                const int round_wgs = (use_rounds && 2 * cus <= kResMaxWGs && cdiv64(nwg, 2 * (int64_t)cus) <= kResRoundWords) ? 2 * cus : 0;
+                unsigned long long* round_words = ctl + 4 + 4 * kResStampWGs;
 #define CT_RESIDENT(ES_)                                                                                                                          \
     hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves, ES_>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),         \
                        static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
                        values_capacity * (ES_ / 2), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out,        \
-                       tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks)
+                       tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
+                       round_wgs, round_words)
                 if (es == 4) CT_RESIDENT(4);
                 else CT_RESIDENT(2);
 #undef CT_RESIDENT

@@ -92,6 +92,47 @@ def make_hip_subclass(up_cls, amd_cls):
                 return amd_cls.decompress.__func__(cls, state_dict, scheme)
             return up_cls.decompress.__func__(cls, state_dict, scheme)
 
+        # ---- a LIST of modules (what the wrapped ModelCompressor loops hand over, see `_wrap_model_compressor`): the GPU modules of a
+        # type the kernels implement go through amd_cls's batched launches — one table and one launch per device instead of one
+        # launch per module —, the rest one by one through this class (i.e. upstream's code for CPU / meta tensors)
+        @classmethod
+        def _ct_split(cls, modules, probe_names):
+            ours, rest = [], []
+            for m in modules:
+                scheme = getattr(m, "quantization_scheme", None)
+                probe = None
+                for n in probe_names:
+                    probe = m._parameters.get(n)
+                    if probe is None:
+                        probe = m._buffers.get(n)
+                    if probe is not None:
+                        break
+                (ours if (fp4_group is None and scheme is not None and _int_weights(scheme) and _on_gpu(probe)) else rest).append(m)
+            return ours, rest
+
+        @classmethod
+        def compress_modules(cls, modules, status=None):
+            ours, rest = cls._ct_split(modules, ("weight",))
+            if ours:
+                amd_cls.compress_modules(ours)
+                if status is not None:
+                    for m in ours:
+                        m.__dict__["quantization_status"] = status  # the host library's own enum member, not ours
+            for m in rest:
+                cls.compress_module(m)
+
+        @classmethod
+        def decompress_modules(cls, modules, status=None):
+            ours, rest = cls._ct_split(modules, ("weight_packed", "weight"))
+            if ours:
+                amd_cls.decompress_modules(ours)
+                if status is not None:
+                    for m in ours:
+                        m.__dict__["quantization_status"] = status
+            for m in rest:
+                cls.decompress_module(m)
+
+    _Hip._ct_batched = True
     _Hip.__name__ = up_cls.__name__ + "MI355X"
     _Hip.__qualname__ = _Hip.__name__
     return _Hip
@@ -204,8 +245,162 @@ def _rebind_names(table: dict, saved: dict) -> None:
                 _REBOUND.append((mod, attr, hit[0]))
 
 
-def install(rebind_names: bool = True):
-    """registry swap + ImplBackend registration (+ the by-name bindings inside upstream's own modules unless rebind_names=False)"""
+_MC_SAVED = {}  # upstream ModelCompressor's own compress_model / decompress_model while the wrappers are in place
+
+
+def _wrap_model_compressor() -> None:
+    """Upstream's `ModelCompressor.compress_model` / `decompress_model` loop `compress_module` / `decompress_module` over the
+    quantized modules (model_compressors/model_compressor.py:167-169,196-198): one codec call, one launch and a full state-dict
+    replacement per module.  The wrappers keep everything else of those methods — the module filter (:152-164,191-195), the
+    distributed branch (:171-173: untouched, handed to the original), the config status (:175-177,200-204) and the decompress
+    hook (:179-182,206-207) — and hand each format's module list to the registry class's `compress_modules` /
+    `decompress_modules` when it has them (the HIP subclasses: one launch per device), module by module otherwise."""
+    import compressed_tensors.compressors.model_compressors.model_compressor as up_mc
+    from compressed_tensors.compressors import BaseCompressor
+    from compressed_tensors.compressors.format import infer_module_format
+    from compressed_tensors.config import CompressionFormat
+    from compressed_tensors.quantization import QuantizationScheme, QuantizationStatus
+    from compressed_tensors.quantization.utils import is_module_quantized
+
+    MC = up_mc.ModelCompressor
+    if _MC_SAVED:
+        return
+    _MC_SAVED["compress_model"], _MC_SAVED["decompress_model"] = MC.compress_model, MC.decompress_model
+    is_distributed = getattr(up_mc, "is_distributed", lambda: False)
+
+    def by_codec(modules, format):
+        """[(registry class, [modules])] in first-seen order; the format resolution and `scheme.format` write-back of upstream's
+        compress_module / decompress_module (compressors/base.py:185-192,211-218); modules without a scheme are skipped as there"""
+        groups, seen = {}, {}
+        for m in modules:
+            scheme = getattr(m, "quantization_scheme", None)
+            if not isinstance(scheme, QuantizationScheme):
+                continue
+            key = (id(scheme), type(m))
+            cls = seen.get(key)
+            if cls is None:
+                fmt = format or scheme.format or infer_module_format(type(m), scheme)
+                scheme.format = CompressionFormat(fmt)
+                cls = seen[key] = BaseCompressor.get_value_from_registry(scheme.format.value)
+            groups.setdefault(cls, []).append(m)
+        return groups.items()
+
+    def compress_model(self, model, skip_compressed: bool = False) -> None:
+        if is_distributed():
+            return _MC_SAVED["compress_model"](self, model, skip_compressed)
+        modules = [m for _, m in model.named_modules(remove_duplicate=True)
+                   if is_module_quantized(m) and (not skip_compressed or getattr(m, "quantization_status", None) != QuantizationStatus.COMPRESSED)]
+        for cls, ms in by_codec(modules, self.force_compression_format):
+            if getattr(cls, "_ct_batched", False):
+                cls.compress_modules(ms, status=QuantizationStatus.COMPRESSED)
+            else:
+                for m in ms:
+                    cls.compress_module(m)
+        if self.quantization_config is not None:
+            self.quantization_config.quantization_status = QuantizationStatus.COMPRESSED
+        self.add_decompress_hook(model)
+
+    def decompress_model(self, model) -> None:
+        modules = [m for _, m in model.named_modules(remove_duplicate=True) if is_module_quantized(m)]
+        for cls, ms in by_codec(modules, self.force_compression_format):
+            if getattr(cls, "_ct_batched", False):
+                cls.decompress_modules(ms, status=QuantizationStatus.DECOMPRESSED)
+            else:
+                for m in ms:
+                    cls.decompress_module(m)
+        if self.quantization_config is not None:
+            self.quantization_config.quantization_status = QuantizationStatus.DECOMPRESSED
+        self.remove_decompression_hook(model)
+
+    compress_model.__doc__, decompress_model.__doc__ = MC.compress_model.__doc__, MC.decompress_model.__doc__
+    MC.compress_model, MC.decompress_model = compress_model, decompress_model
+
+
+def _unwrap_model_compressor() -> None:
+    if not _MC_SAVED:
+        return
+    import compressed_tensors.compressors.model_compressors.model_compressor as up_mc
+
+    up_mc.ModelCompressor.compress_model = _MC_SAVED.pop("compress_model")
+    up_mc.ModelCompressor.decompress_model = _MC_SAVED.pop("decompress_model")
+
+
+_FN_REBOUND = []  # (module, attribute name, original function)
+
+
+def _patch_functions() -> None:
+    """`install(patch_functions=True)`: the four plain functions of the hot path that have no plug-in point upstream —
+    `pack_to_int32` / `unpack_from_int32` (compressors/pack_quantized/helpers.py:20-24,104-109, bound by name at
+    pack_quantized/base.py:11-14) and `dequantize` / `fake_quantize` (quantization/lifecycle/forward.py:76-181) — are rebound, in
+    every already-imported `compressed_tensors.*` module that holds them, to wrappers that send GPU tensors of a layout the
+    kernels implement through `codec` and everything else (CPU / meta tensors, exotic strategies; also a NotImplementedError from
+    the HIP path) to the original — the dispatch rule of upstream's ImplBackend (utils/impl_backend.py:113-119)."""
+    import functools
+    import sys
+
+    import compressed_tensors.compressors.pack_quantized.helpers as up_helpers
+    import compressed_tensors.quantization.lifecycle.forward as up_forward
+
+    from .quantization import forward as amd_forward
+
+    floats = (torch.float32, torch.float16, torch.bfloat16)
+    plain = ("tensor", "channel", "group", "block")
+
+    def simple_args(args) -> bool:
+        if args is None:
+            return True
+        qt, bits = enum_value(getattr(args, "type", "int")), int(args.num_bits)
+        return (enum_value(args.strategy) in plain and ((qt == "int" and 1 <= bits <= 8) or (qt == "float" and bits == 8))
+                and not getattr(args, "dynamic", False))
+
+    def dispatching(orig, ours, take):
+        @functools.wraps(orig)
+        def fn(*args, **kwargs):
+            try:
+                if take(*args, **kwargs):
+                    return ours(*args, **kwargs)
+            except NotImplementedError:
+                pass
+            return orig(*args, **kwargs)
+
+        fn._ct_original = orig
+        return fn
+
+    def take_pack(value, num_bits, packed_dim=1):
+        return value.is_cuda and value.dtype is torch.int8 and value.dim() >= 2
+
+    def take_unpack(value, num_bits, shape, packed_dim=1):
+        return value.is_cuda and value.dtype is torch.int32 and value.dim() >= 2
+
+    def take_dequantize(x_q, scale, zero_point=None, args=None, dtype=None, g_idx=None, global_scale=None):
+        return (x_q.is_cuda and x_q.dim() == 2 and global_scale is None and simple_args(args) and scale.dtype in floats
+                and x_q.dtype in (torch.int8, torch.float8_e4m3fn))
+
+    def take_fake_quantize(x, scale, zero_point, args, g_idx=None, global_scale=None):
+        return x.is_cuda and x.dim() == 2 and global_scale is None and simple_args(args) and x.dtype in floats and scale.dtype in floats
+
+    new = [
+        (up_helpers.pack_to_int32, dispatching(up_helpers.pack_to_int32, codec.pack_to_int32, take_pack)),
+        (up_helpers.unpack_from_int32, dispatching(up_helpers.unpack_from_int32, codec.unpack_from_int32, take_unpack)),
+        (up_forward.dequantize, dispatching(up_forward.dequantize, amd_forward.dequantize, take_dequantize)),
+        (up_forward.fake_quantize, dispatching(up_forward.fake_quantize, amd_forward.fake_quantize, take_fake_quantize)),
+    ]
+    swap = {id(o): (o, n) for o, n in new}
+    for mod_name, mod in list(sys.modules.items()):
+        if mod is None or not (mod_name == "compressed_tensors" or mod_name.startswith("compressed_tensors.")):
+            continue
+        for attr, val in list(vars(mod).items()):
+            hit = swap.get(id(val))
+            if hit is not None and callable(val):
+                setattr(mod, attr, hit[1])
+                _FN_REBOUND.append((mod, attr, hit[0]))
+
+
+def install(rebind_names: bool = True, wrap_model_compressor: bool = True, patch_functions: bool = False):
+    """registry swap + ImplBackend registration
+    (+ the by-name bindings of the codec classes inside upstream's own modules unless rebind_names=False;
+     + batched launches behind upstream's ModelCompressor.compress_model / decompress_model unless wrap_model_compressor=False;
+     + with patch_functions=True the plain functions pack_to_int32 / unpack_from_int32 / dequantize / fake_quantize)."""
     import compressed_tensors  # the upstream package; ImportError if it is not installed
     from compressed_tensors.compressors import BaseCompressor
     from compressed_tensors.registry import registry as up_registry
@@ -213,8 +408,14 @@ def install(rebind_names: bool = True):
 
     table = up_registry._REGISTRY[BaseCompressor]
     install_into(table, ImplBackend, _SAVED)
-    if rebind_names and not _REBOUND:
+    if rebind_names:
+        # every call re-scans sys.modules, so upstream modules imported since the last install() are covered too; an attribute that
+        # already holds the subclass is not in the swap table (ids of the ORIGINAL classes), so nothing is recorded twice
         _rebind_names(table, _SAVED)
+    if wrap_model_compressor:
+        _wrap_model_compressor()
+    if patch_functions and not _FN_REBOUND:
+        _patch_functions()
     return compressed_tensors
 
 
@@ -237,7 +438,9 @@ def uninstall():
     from compressed_tensors.compressors import BaseCompressor
     from compressed_tensors.registry import registry as up_registry
 
-    for mod, attr, orig in _REBOUND:
+    for mod, attr, orig in _REBOUND + _FN_REBOUND:
         setattr(mod, attr, orig)
     _REBOUND.clear()
+    _FN_REBOUND.clear()
+    _unwrap_model_compressor()
     uninstall_from(up_registry._REGISTRY[BaseCompressor], _SAVED)

@@ -7,8 +7,8 @@ not installed in this image, and (b) expects a setuptools_scm-generated
 imported *in the build container* to (1) pin the oracle and (2) generate the golden
 vectors under tests/golden/.  /root/reference does not exist on the GPU box; there the
 archive that `oracle/stage_ref.py` packed in the build container (oracle/_ref/, git-ignored,
-travels with the gpurun snapshot) is unpacked into a temp directory and imported instead, so
-that the HIP path can meet the reference itself on the MI355X.  `available()` tells callers
+travels with the gpurun snapshot) is unpacked and imported instead, so
+that the HIP path can meet the reference itself on the MI355X (unpacked inside oracle/_ref/, owner-only).  `available()` tells callers
 whether either source exists; `root()` is the directory that holds `src/` and `tests/`.
 
 Never imported by the product package (compressed_tensors_amd).
@@ -52,20 +52,42 @@ def root() -> str:
 
     with open(ARCHIVE, "rb") as f:
         tag = hashlib.sha256(f.read()).hexdigest()[:16]
-    dst = os.path.join(tempfile.gettempdir(), f"ct_reference_stage_{tag}")
-    if not os.path.exists(os.path.join(dst, "STAGED_FROM")):
-        tmp = tempfile.mkdtemp(prefix="ct_reference_stage_", dir=tempfile.gettempdir())
+    # unpacked next to the archive, inside the repo's own git-ignored oracle/_ref/ (mode 0700), never under a shared, predictable
+    # /tmp path that another local user could pre-create and have imported; a read-only checkout falls back to a
+    # private mkdtemp directory for this process
+    base = os.path.dirname(ARCHIVE)
+    dst = os.path.join(base, f"unpacked_{tag}")
+
+    def _trusted(path):
+        try:
+            st = os.stat(path)
+        except OSError:
+            return False
+        return st.st_uid == os.getuid() and not (st.st_mode & 0o022) and os.path.exists(os.path.join(path, "STAGED_FROM"))
+
+    if not _trusted(dst):
+        try:
+            tmp = tempfile.mkdtemp(prefix="unpacking_", dir=base)
+        except OSError:
+            tmp, dst = tempfile.mkdtemp(prefix="ct_reference_stage_"), None  # 0700, unpredictable, ours
         with tarfile.open(ARCHIVE, "r:gz") as tar:
             for m in tar.getmembers():  # plain relative file names only (the archive is ours, but check anyway)
                 if m.name.startswith(("/", "..")) or ".." in m.name.split("/") or not (m.isfile() or m.isdir()):
                     raise RuntimeError(f"unexpected archive member {m.name!r}")
             tar.extractall(tmp)
-        try:
-            os.rename(tmp, dst)
-        except OSError:  # another process won the race
-            import shutil
+        os.chmod(tmp, 0o700)
+        if dst is None:
+            dst = tmp
+        else:
+            try:
+                os.rename(tmp, dst)
+            except OSError:  # the name is taken: by another process of ours that won the race — or by something we do not trust
+                if _trusted(dst):
+                    import shutil
 
-            shutil.rmtree(tmp, ignore_errors=True)
+                    shutil.rmtree(tmp, ignore_errors=True)
+                else:
+                    dst = tmp  # keep our own private copy for this process
     _ROOT = dst
     return _ROOT
 

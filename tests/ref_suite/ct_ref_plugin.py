@@ -8,6 +8,8 @@ upstream.  What it does, before any reference module is imported:
     reference's src/ on sys.path;
   * CT_REF_INSTALL=1: `compressed_tensors_amd.install.install()` — the registry swap + ImplBackend registration of
     INTEGRATION.md §A — so that `/root/reference/src/compressed_tensors/compressors/base.py:192,218` resolves to the HIP subclasses;
+  * CT_REF_PATCH_FUNCTIONS=1 (with CT_REF_INSTALL=1): `install(patch_functions=True)` — pack_to_int32 / unpack_from_int32 /
+    dequantize / fake_quantize rebound to the device-dispatching wrappers too;
   * CT_REF_DEFAULT_CUDA=1: `torch.set_default_device("cuda")`, which turns the reference's CPU-tensor tests
     (test_pack_quant.py, test_int_quant.py, ...) into GPU-tensor tests without editing them;
   * counts every launch that goes through the C ABI of libct_hip.so and, at session end, writes
@@ -58,7 +60,7 @@ def pytest_configure(config):
     if os.environ.get("CT_REF_INSTALL") == "1":
         import compressed_tensors_amd.install as ct_amd
 
-        ct_amd.install()
+        ct_amd.install(patch_functions=os.environ.get("CT_REF_PATCH_FUNCTIONS") == "1")
         if torch.cuda.is_available():
             _count_launches()
     if os.environ.get("CT_REF_DEFAULT_CUDA") == "1":

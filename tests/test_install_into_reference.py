@@ -151,3 +151,84 @@ def test_install_rebinds_the_by_name_bindings_and_uninstall_restores_them(upstre
     from compressed_tensors.compressors import BaseCompressor
 
     assert BaseCompressor.get_value_from_registry("pack-quantized") is not orig
+
+
+def _w4_model(ct, n=3, rows=32, cols=256):
+    from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme
+
+    torch.manual_seed(0)
+    args = QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = QuantizationScheme(targets=["Linear"], weights=args)  # one scheme object for the group, as apply_quantization_config attaches it
+    model = torch.nn.Sequential(*[torch.nn.Linear(cols, rows, bias=False).to(torch.bfloat16) for _ in range(n)])
+    for lin in model:
+        w = lin.weight.data
+        lin.quantization_scheme = scheme
+        lin.register_parameter("weight_scale", torch.nn.Parameter((w.reshape(rows, -1, 128).abs().amax(-1).float() / 7.5).to(torch.bfloat16), requires_grad=False))
+        lin.register_parameter("weight_zero_point", torch.nn.Parameter(torch.zeros(rows, cols // 128, dtype=torch.int8), requires_grad=False))
+    return model
+
+
+def test_install_wraps_the_model_compressor_loops_and_uninstall_restores_them(upstream):
+    """install() puts batched `compress_modules` / `decompress_modules` behind upstream's ModelCompressor.compress_model /
+    decompress_model (model_compressor.py:167-169,196-198); with CPU tensors every module still goes through upstream's own
+    code, module by module, and the model ends exactly as upstream leaves it; uninstall() restores the original methods"""
+    import copy
+
+    ct, ct_amd = upstream
+    from compressed_tensors import ModelCompressor
+    from compressed_tensors.quantization import QuantizationStatus
+
+    orig_c, orig_d = ModelCompressor.compress_model, ModelCompressor.decompress_model
+    ref_model = _w4_model(ct)
+    got_model = copy.deepcopy(ref_model)
+    ModelCompressor().compress_model(ref_model)
+    ct_amd.install()
+    assert ModelCompressor.compress_model is not orig_c and ModelCompressor.decompress_model is not orig_d
+    mc = ModelCompressor()
+    mc.compress_model(got_model)
+    assert hasattr(got_model, "ct_decompress_hook")
+    for a, b in zip(ref_model, got_model):
+        assert list(a._parameters) == list(b._parameters)
+        for k in a._parameters:
+            assert (a._parameters[k] is None and b._parameters[k] is None) or torch.equal(a._parameters[k], b._parameters[k]), k
+        assert b.quantization_status == QuantizationStatus.COMPRESSED and type(b.quantization_status) is QuantizationStatus
+    mc.compress_model(got_model, skip_compressed=True)  # nothing left to do; must not raise
+    mc.decompress_model(got_model)
+    orig_d(ModelCompressor(), ref_model)  # upstream's own loop on the model upstream compressed
+    for a, b in zip(ref_model, got_model):
+        assert set(a._parameters) == set(b._parameters) and torch.equal(a.weight, b.weight)
+        assert b.quantization_status == QuantizationStatus.DECOMPRESSED
+    assert not hasattr(got_model, "ct_decompress_hook")
+    ct_amd.uninstall()
+    assert ModelCompressor.compress_model is orig_c and ModelCompressor.decompress_model is orig_d
+
+
+def test_install_patch_functions_rebinds_and_falls_through_on_cpu(upstream):
+    """install(patch_functions=True) rebinds pack_to_int32 / unpack_from_int32 in BOTH helpers and pack_quantized.base
+    (base.py:11-14 binds them by name) and dequantize / fake_quantize in lifecycle.forward; CPU tensors reach the originals;
+    uninstall() restores every binding"""
+    ct, ct_amd = upstream
+    import compressed_tensors.compressors.pack_quantized.base as base_mod
+    import compressed_tensors.compressors.pack_quantized.helpers as helpers_mod
+    import compressed_tensors.quantization.lifecycle.forward as forward_mod
+    from compressed_tensors.quantization import QuantizationArgs
+
+    originals = (helpers_mod.pack_to_int32, helpers_mod.unpack_from_int32, forward_mod.dequantize, forward_mod.fake_quantize)
+    ct_amd.install(patch_functions=True)
+    assert helpers_mod.pack_to_int32 is base_mod.pack_to_int32 is not originals[0]
+    assert helpers_mod.unpack_from_int32 is base_mod.unpack_from_int32 is not originals[1]
+    assert forward_mod.dequantize is not originals[2] and forward_mod.fake_quantize is not originals[3]
+    assert helpers_mod.pack_to_int32._ct_original is originals[0]
+    q = torch.randint(-8, 8, (4, 64), dtype=torch.int8)
+    packed = helpers_mod.pack_to_int32(q, 4)
+    assert torch.equal(packed, originals[0](q, 4)) and torch.equal(helpers_mod.unpack_from_int32(packed, 4, q.shape), q)
+    with pytest.raises(ValueError):
+        helpers_mod.pack_to_int32(q.to(torch.int32), 4)  # upstream's own argument error (helpers.py:36-37)
+    args = QuantizationArgs(num_bits=8, strategy="channel", symmetric=True)
+    x = torch.randn(4, 64, dtype=torch.bfloat16)
+    s = (x.abs().amax(-1, keepdim=True).float() / 127).to(torch.bfloat16)
+    z = torch.zeros(4, 1, dtype=torch.int8)
+    assert torch.equal(forward_mod.fake_quantize(x, s, z, args), originals[3](x, s, z, args))
+    ct_amd.uninstall()
+    assert (helpers_mod.pack_to_int32, helpers_mod.unpack_from_int32, forward_mod.dequantize, forward_mod.fake_quantize) == originals
+    assert base_mod.pack_to_int32 is originals[0] and base_mod.unpack_from_int32 is originals[1]

@@ -44,7 +44,7 @@ def test_staged_archive_imports_and_runs_the_references_codec_tests(tmp_path):
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests", "ref_suite"), ROOT]))
     root = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, 'oracle'); import ref_import; print(ref_import.root())"],
                           cwd=ROOT, env=env, capture_output=True, text=True, check=True).stdout.strip()
-    assert "ct_reference_stage_" in root and os.path.exists(os.path.join(root, "tests", "testing_utils.py"))
+    assert ("oracle/_ref/unpacked_" in root or "ct_reference_stage_" in root) and (os.stat(root).st_mode & 0o022) == 0 and os.path.exists(os.path.join(root, "tests", "testing_utils.py"))
     r = subprocess.run([sys.executable, "-m", "pytest", "-p", "ct_ref_plugin", "-p", "no:cacheprovider", "-q",
                         "tests/test_compressors/test_pack_quant.py", "tests/test_compressors/test_int_quant.py"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)

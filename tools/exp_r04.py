@@ -1,0 +1,100 @@
+"""round-4 experiments (dev helper, run on the GPU box): python tools/exp_r04.py bmx|bmstamps|marlin|host   (knobs from the environment)
+
+bmx       sparse-bitmask compress at 8192^2 bf16 50 %: HBM-cold time of ct_bitmask_compress (6 rotating inputs, 5 x 60 launches) and a
+          parity check against the count / scan / scatter form, under whatever CT_BM_X / CT_BITMASK_RESIDENT says
+bmstamps  CT_BITMASK_RESIDENT=3: per-workgroup time stamps (start / published / resolved / done) of the first 1024 workgroups,
+          summarised per residency round and per decile of the block index
+marlin    marlin-24 fused kernel at 8192^2 (C ABI), parity against the codec's own unfused chain
+host      host cost of the plug-in calls that wait on the device (mailbox vs the torch forms they replaced)
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench as B
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+what = sys.argv[1]
+from compressed_tensors_amd import _lib, codec
+
+lib = _lib.load()
+stream = torch.cuda.current_stream(dev).cuda_stream
+N = 8192
+
+
+def sparse_inputs(n, nsets, seed=11):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = []
+    for _ in range(nsets):
+        w = torch.randn(n, n, dtype=torch.bfloat16, device=dev, generator=g)
+        out.append(w.masked_fill(torch.rand(n, n, device=dev, generator=g) < 0.5, 0))
+    return out
+
+
+if what in ("bmx", "bmstamps"):
+    res = {"CT_BM_X": os.environ.get("CT_BM_X"), "CT_BITMASK_RESIDENT": os.environ.get("CT_BITMASK_RESIDENT")}
+    ws_ = sparse_inputs(N, 6)
+    ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(N, N))
+    wk = torch.zeros(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+    vals = torch.empty(N * N, dtype=torch.bfloat16, device=dev)
+    bm = torch.empty(N, N // 8, dtype=torch.uint8, device=dev)
+    ro = torch.empty(N, dtype=torch.int64, device=dev)
+    f = lambda i: lib.ct_bitmask_compress(ws_[i % 6].data_ptr(), _lib.BF16, N, N, vals.data_ptr(), vals.numel(), bm.data_ptr(), ro.data_ptr(), wk[-1:].data_ptr(),
+                                          wk.data_ptr(), ws_bytes, stream)
+    sp = {}
+    res["us"] = round(B.time_kernel(f, 60, spread=sp), 2)
+    res.update(sp)
+    # parity of the last launch (input (60 - 1) % 6 = 5) against the two-pass form
+    torch.cuda.synchronize()
+    v2, bm2, ro2 = codec.bitmask_compress(ws_[5], two_pass=True)
+    nnz = int(wk[-1].item())
+    res["ok"] = bool(nnz == v2.numel() and torch.equal(vals[:nnz].view(torch.int16), v2.view(torch.int16)) and torch.equal(bm, bm2) and torch.equal(ro, ro2))
+    if what == "bmstamps":
+        import numpy as np
+
+        base = 8192 + 4  # kResMaxWGs + control words
+        wk[base: base + 4 * 1024] = 0
+        f(0)
+        torch.cuda.synchronize()
+        st = wk[base: base + 4 * 1024].reshape(1024, 4).cpu().double().numpy()
+        st = (st - st[:, 0].min()) / 100.0  # us
+        names = ("start", "published", "resolved", "done")
+        res["stamps_us"] = {}
+        for lo in range(0, 1024, 128):
+            sl = st[lo: lo + 128]
+            res["stamps_us"][f"wg{lo}-{lo + 127}"] = {n: [round(float(np.median(sl[:, k])), 1), round(float(sl[:, k].max()), 1)] for k, n in enumerate(names)}
+        res["stamps_us"]["all"] = {"done_max": round(float(st[:, 3].max()), 1), "wait_med_round1": round(float(np.median(st[:512, 2] - st[:512, 1])), 1),
+                                   "wait_med_round2": round(float(np.median(st[512:, 2] - st[512:, 1])), 1),
+                                   "store_med_round1": round(float(np.median(st[:512, 3] - st[:512, 2])), 1), "store_med_round2": round(float(np.median(st[512:, 3] - st[512:, 2])), 1),
+                                   "load_med_round1": round(float(np.median(st[:512, 1] - st[:512, 0])), 1), "load_med_round2": round(float(np.median(st[512:, 1] - st[512:, 0])), 1)}
+    print(json.dumps(res))
+elif what == "marlin":
+    r = B.marlin24_leg(dev)
+    print(json.dumps({k: r[k] for k in ("kernels_us", "kernels_frac_hbm", "compress_us_default", "compress_us_deferred_check", "host_issue_us_per_call", "bit_exact_vs_oracle")}))
+elif what == "host":
+    import compressed_tensors_amd as cta
+
+    out = {}
+
+    def per_call(fn, n=2000):
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / n * 1e6, 2)
+
+    s = _lib.stream_of_device(dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    small = torch.zeros(64, dtype=torch.float32, device=dev)
+    mb = _lib.mailbox(0)
+    out["tiny kernel + .item() (torch D2H + sync)"] = per_call(lambda: (small.add_(1), int(flag.item())))
+    out["tiny kernel + ct_stream_wait (spin on hipStreamQuery)"] = per_call(lambda: (small.add_(1), _lib.stream_wait(s)))
+    out["tiny kernel + torch.cuda.synchronize()"] = per_call(lambda: (small.add_(1), torch.cuda.synchronize()))
+    w = sparse_inputs(256, 1)[0]
+    out["codec.bitmask_compress 256x256 (mailbox nnz)"] = per_call(lambda: codec.bitmask_compress(w))
+    out["codec.bitmask_compress 256x256 two_pass (.item())"] = per_call(lambda: codec.bitmask_compress(w, two_pass=True))
+    print(json.dumps(out, indent=1))
