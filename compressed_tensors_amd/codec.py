@@ -639,7 +639,7 @@ def _upload_table(words, dev) -> torch.Tensor:
     return host.to(dev, non_blocking=True)
 
 
-_ITEM_WORDS = 11  # struct ct_w4_item of include/ct_hip.h: 4 pointers, rows, cols, group, first_block, units, {upg_shift, upg}
+_ITEM_WORDS = 10  # struct ct_w4_item of include/ct_hip.h in 64-bit words: 4 pointers, rows, cols, group, first_block, units, {upg_shift, upg}
 
 
 class W4Batch:
@@ -651,7 +651,7 @@ class W4Batch:
     dst / src = packed int32 words); kind "int8" / "fp8": the 8-bit codecs (`ct_q8_quant_batch` / `ct_q8_dequant_batch`, one
     byte per element, `bits` = the INT scheme's num_bits; group may be rows * cols for a per-tensor scale).
 
-    The host table is one flat array of 64-bit words (11 per item, the layout of `struct ct_w4_item`) planned in place by the
+    The host table is one flat array of 64-bit words (10 per item, the layout of `struct ct_w4_item`) planned in place by the
     library and uploaded asynchronously from pinned memory."""
 
     def __init__(self, entries, direction: str, dtype: torch.dtype, kind: str = "w4", bits: int = 8):
@@ -666,7 +666,7 @@ class W4Batch:
         flat = []
         dev = None
         for src, scale, zp, dst, rows, cols, group in self.keep:
-            flat += (src.data_ptr(), scale.data_ptr(), 0 if zp is None else zp.data_ptr(), dst.data_ptr(), rows, cols, group, 0, 0, 0, 0)
+            flat += (src.data_ptr(), scale.data_ptr(), 0 if zp is None else zp.data_ptr(), dst.data_ptr(), rows, cols, group, 0, 0, 0)
         self.blocks, self.table, self.device = 0, None, None
         if n:
             dev = self.keep[0][0].device
@@ -704,7 +704,7 @@ def zp4_batch(pairs, direction: str) -> None:
     flat = []
     for src, dst in pairs:
         unpacked = src if direction == "pack" else dst
-        flat += (src.data_ptr(), 0, 0, dst.data_ptr(), int(unpacked.shape[0]), int(unpacked.shape[1]), 0, 0, 0, 0, 0)
+        flat += (src.data_ptr(), 0, 0, dst.data_ptr(), int(unpacked.shape[0]), int(unpacked.shape[1]), 0, 0, 0, 0)
     words = array.array("q", flat)
     blocks = int(_lib.load().ct_zp4_batch_plan(words.buffer_info()[0], len(pairs)))
     if blocks < 0:

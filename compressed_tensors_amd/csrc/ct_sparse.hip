@@ -1137,14 +1137,22 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
         while (wall_clock64() - s0 < wait) __builtin_amdgcn_s_sleep(16);
     }
     if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 0] = wall_clock64();
-    // ---- phase A
+    // ---- phase A.  Round 4: every load is UNCONDITIONAL straight-line code (unit index clamped to the chunk's last unit; a unit
+    // beyond the chunk, or a tile beyond this wave's `tpw`, contributes no flags), so that hipcc's wait-count pass can count the
+    // loads: a tile is consumed behind `s_waitcnt vmcnt(12 / 8 / 4 / 0)` as it lands.  With a load behind a branch the pass gives up
+    // and waits for ALL sixteen before the first flag is computed (every s_waitcnt in the round-3 build was vmcnt(0)): the whole
+    // load phase stalled the wave, and all four tiles' ranks + compaction (4.2 us, VALU-bound) then sat between the last load and
+    // the first poll.  No vector-memory store may sit between the loads and the last tile's use for the same reason: the row
+    // offsets of rows that start inside a tile are written after the hand-off word has left (ranks recomputed from the flags).
     u32x4 keep[KEEP][4];
+    const uint32_t units32 = (uint32_t)units;  // a chunk holds at most kResMaxWGs workgroups x 8 waves x KEEP tiles x 256 units < 2^31
+    const uint32_t ubase = (uint32_t)(wt0 * kWT) + (uint32_t)lane;
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
-        if (i < tpw) load_wt(x, units, wt0 + i, lane, keep[i]);  // zeros beyond the chunk
-        else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) keep[i][q] = u32x4{0u, 0u, 0u, 0u};
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t u = ubase + (uint32_t)(i * kWT + q * 64);
+            keep[i][q] = x[u < units32 ? u : units32 - 1u];
         }
     }
     build_compact_lut(s_lut, tid);
@@ -1154,21 +1162,34 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
     int tot[KEEP];  // wave-uniform
     int64_t next_r = (u0 + wt0 * kWT + upr - 1) / upr, next_u = next_r * upr;  // the next row that starts at or after the wave's first unit
     const int64_t first_r = next_r;
-    // ---- pass 1: only what the hand-off needs — the non-zero flags and their count.  The workgroup's count word leaves BEFORE the
-    // ranks / compaction of pass 2 (round 2 published after them: the 3 us publish -> visible hop was serial with ~300 vector
-    // instructions and ~40 LDS operations per wave-tile instead of hidden behind them)
     uint32_t pks[KEEP];
     int cnt = 0;
+    // ranks, compaction through the wave's slab, read back in place — of ONE wave-tile (LDS and VALU only)
+    auto pass2 = [&](int i) {
+        uint32_t mm[4], rank[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mm[q] = (pks[i] >> (8 * q)) & 0xffu;
+        tot[i] = tile_ranks(mm, rank);
+        compact_into_slab(keep[i], mm, rank, 0, slab_a, dump_a, lut_a);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[i][q] = slab_v[q * 64 + lane];  // vector q * 64 + lane of the compacted tile (garbage past tot)
+    };
+    // (per-workgroup stamps, gpurun_out/r04a: the 6.8 us between a workgroup's publish and its resolved prefix were its OWN pass 2 over
+    // all four tiles plus one poll round trip, not the other workgroups' loads.)  The tiles before the last one are ranked and
+    // compacted AS THEY LAND, in the shadow of the loads still in flight; only the LAST tile's flags gate the publish and only its
+    // pass 2 sits behind it.
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         uint32_t pk = 0;
-        if (i < tpw) {  // wave-uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pk |= nz_mask_unit<ES>(keep[i][q], keepbits) << (8 * q);
-            s_mask[wave][i][lane] = pk;
+        for (int q = 0; q < 4; ++q) {
+            const bool live = i < tpw && ubase + (uint32_t)(i * kWT + q * 64) < units32;
+            pk |= (live ? nz_mask_unit<ES>(keep[i][q], keepbits) : 0u) << (8 * q);
         }
+        s_mask[wave][i][lane] = pk;
         pks[i] = pk;
         cnt += __popc(pk);
+        if (i < KEEP - 1) pass2(i);
     }
     cnt = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
     if (lane == 0) s_cnt[wave] = cnt;
@@ -1180,17 +1201,17 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
         op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
         if (stamps && b < kResStampWGs) stamps[b * 4 + 1] = wall_clock64();
     }
-    // ---- pass 2, while the word travels: ranks, row offsets, compaction through the wave's slab, read back in place
+    // ---- the last tile's pass 2, while the word travels
+    pass2(KEEP - 1);
+    // ---- rows that start inside one of this wave's tiles: their offset relative to the tile, completed in phase B
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
-        tot[i] = 0;
-        if (i >= tpw) continue;  // wave-uniform
-        uint32_t mm[4], rank[4];
+        const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
+        if (i < tpw && next_r < rows && next_u < uend) {  // wave-uniform; one row in four tiles at 8192 columns
+            uint32_t mm[4], rank[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mm[q] = (pks[i] >> (8 * q)) & 0xffu;
-        tot[i] = tile_ranks(mm, rank);
-        {   // rows that start inside this wave-tile: their offset relative to the tile, completed in phase B
-            const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
+            for (int q = 0; q < 4; ++q) mm[q] = (pks[i] >> (8 * q)) & 0xffu;
+            (void)tile_ranks(mm, rank);
             for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
                 const int q = (int)(next_u - ubeg);
                 const int qi = q >> 6, l = q & 63;
@@ -1198,9 +1219,6 @@ __global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4
                 if (lane == l) row_offsets[next_r] = (int64_t)rk;
             }
         }
-        compact_into_slab(keep[i], mm, rank, 0, slab_a, dump_a, lut_a);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) keep[i][q] = slab_v[q * 64 + lane];  // vector q * 64 + lane of the compacted tile (garbage past tot)
     }
     // ---- the bitmask leaves while the counts travel: output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the
     // packed masks of lanes 4 (L & 15) .. + 3

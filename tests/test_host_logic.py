@@ -682,3 +682,35 @@ def test_bench_reads_valu_utilisation_from_the_committed_profile():
     for v in busy.values():
         assert 0.0 < v["valu_busy_frac"] < 1.0 and v["valu_insts_per_launch"] > 0
     assert bench.alg_bytes_one_direction() == 168820736
+
+
+def test_batch_table_words_match_the_struct(cta):
+    """the batched entries take a table of `struct ct_w4_item` (include/ct_hip.h); codec.W4Batch fills it as a flat array of 64-bit
+    words — the word layout must be the struct's (a miscount shifts every field of every item but the first), and the library's
+    host-side planner must accept it and fill the derived fields where the struct has them"""
+    import array
+    import ctypes
+
+    from compressed_tensors_amd import _lib, codec
+
+    assert ctypes.sizeof(_lib.W4Item) == 8 * codec._ITEM_WORDS
+    shapes = [(2048, 2048, 128), (256, 2048, 128), (5632, 2048, 128), (2048, 5632, 5632)]
+    flat, structs = [], (_lib.W4Item * len(shapes))()
+    for i, (r, c, g) in enumerate(shapes):
+        ptrs = [0x10000 * (4 * i + k + 1) for k in range(4)]
+        flat += (*ptrs, r, c, g, 0, 0, 0)
+        it = structs[i]
+        it.src, it.scale, it.zp, it.dst = ptrs
+        it.rows, it.cols, it.group = r, c, g
+    assert len(flat) == codec._ITEM_WORDS * len(shapes)
+    words = array.array("q", flat)
+    lib = _lib.load()
+    for direction in (0, 1):
+        w = array.array("q", words)
+        s = (_lib.W4Item * len(shapes)).from_buffer_copy(bytes(structs))
+        blocks_w = lib.ct_w4_batch_plan(w.buffer_info()[0], len(shapes), direction)
+        blocks_s = lib.ct_w4_batch_plan(ctypes.cast(s, ctypes.c_void_p), len(shapes), direction)
+        assert blocks_w == blocks_s > 0
+        assert bytes(w) == bytes(s)
+        for i, (r, c, g) in enumerate(shapes):
+            assert (s[i].rows, s[i].cols, s[i].group) == (r, c, g) and s[i].units == r * c // 8
