@@ -1121,6 +1121,7 @@ def tinyllama_module_tree(mine, keep, scheme):
     (quantization/lifecycle/apply.py:156-165) and weight_scale / weight_zero_point as non-trainable parameters"""
     root = torch.nn.Module()
     root.layers = torch.nn.ModuleList()
+    root.first_linear = []  # (a plain list: not a child module) the Linear built over keep[0], for the round-trip check
     blocks = {}
     for (name, r, c), (w, s_, z, _, _) in zip(mine, keep):
         parts = name.split(".")
@@ -1135,6 +1136,8 @@ def tinyllama_module_tree(mine, keep, scheme):
         lin.weight_zero_point = torch.nn.Parameter(z, requires_grad=False)
         lin.quantization_scheme = scheme
         setattr(blk, proj, lin)
+        if not root.first_linear:
+            root.first_linear.append(lin)
     return root
 
 
@@ -1155,8 +1158,8 @@ def tinyllama_api_leg(dev, mine, keep, kernels_s, fq0):
         mc.decompress_model(model)
 
     cycle()
-    first_lin = model.layers[0].q_proj
-    ok = bool(torch.equal(first_lin.weight.data, fq0))  # module 0 of the tree is keep[0]: round trip == fake_quantize
+    first_lin = model.first_linear[0]
+    ok = bool(torch.equal(first_lin.weight.data, fq0))  # the module over keep[0] (the shard list is in LPT order): round trip == fake_quantize
     cycle()
     both, comp, dec, host_c, host_d = [], [], [], [], []
     for _ in range(7):

@@ -32,6 +32,7 @@ __all__ = [
     "pack_bitmasks",
     "unpack_bitmasks",
     "W4Batch",
+    "launch_w4_words",
     "w4_batch_eligible",
     "q8_batch_group",
     "zp4_batch",
@@ -627,16 +628,31 @@ def w4_batch_eligible(weight_shape, w_dtype, scale, zero_point, *, num_bits, str
 
 
 def _upload_table(words, dev) -> torch.Tensor:
-    """a host table of int64 words -> device bytes.  The staging buffer is pinned (PyTorch's caching host allocator hands the
-    block out again only after the copy's stream event has completed), so the copy is asynchronous: no blocking pageable H2D
-    (25-30 us per table before) on the path of a launch"""
+    """a host table of int64 words (an `array.array("q")` or a CPU int64 tensor) -> device bytes.  The staging buffer is pinned
+    (PyTorch's caching host allocator hands the block out again only after the copy's stream event has completed), so the copy is
+    asynchronous: no blocking pageable H2D (25-30 us per table before) on the path of a launch"""
     import ctypes
 
-    nbytes = 8 * len(words)
+    if isinstance(words, torch.Tensor):
+        src, nbytes = words.data_ptr(), 8 * words.numel()
+    else:
+        src, nbytes = words.buffer_info()[0], 8 * len(words)
     host = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True) if dev.type == "cuda" else torch.empty(nbytes, dtype=torch.uint8)
-    src, _ = words.buffer_info()
     ctypes.memmove(host.data_ptr(), src, nbytes)
     return host.to(dev, non_blocking=True)
+
+
+def launch_w4_words(words: torch.Tensor, n: int, direction: str, dtype: torch.dtype, device: torch.device) -> None:
+    """plan, upload and launch a W4 table that already exists as a flat CPU int64 tensor of `struct ct_w4_item` words (built by the
+    C++ host loop, csrc/host/ct_hostpath.cpp) on `device`'s current stream.  The caller keeps the tensors the table points at alive."""
+    if not n:
+        return
+    d = 0 if direction == "compress" else 1
+    blocks = int(_lib.load().ct_w4_batch_plan(words.data_ptr(), n, d))
+    if blocks < 0:
+        raise ValueError(_lib.last_error())
+    table = _upload_table(words, device)
+    call("ct_quant_pack_batch" if d == 0 else "ct_unpack_dequant_batch", table.data_ptr(), n, blocks, DT[dtype], _lib.stream_on(device))
 
 
 _ITEM_WORDS = 10  # struct ct_w4_item of include/ct_hip.h in 64-bit words: 4 pointers, rows, cols, group, first_block, units, {upg_shift, upg}

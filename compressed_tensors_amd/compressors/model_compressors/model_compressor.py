@@ -74,7 +74,14 @@ class ModelCompressor:
 
     # ------------------------------------------------------------------ compress / decompress
     def _quantized_modules(self, model, skip_compressed=False):
-        return [m for _, m in self._named_quantized_modules(model) if not (skip_compressed and self._is_compressed(m))]
+        """every quantized module, in `named_modules(remove_duplicate=True)` order (model_compressor.py:152-164,191-195); the walk runs in
+        the C++ host extension when it is built (300 modules: 0.3 ms of interpreter time per call, comparable to the kernels of a
+        1B-parameter checkpoint)"""
+        from ..pack_quantized.base import _hostpath
+
+        hp = _hostpath()
+        mods = hp.quantized_modules(model) if hp is not None else [m for _, m in self._named_quantized_modules(model)]
+        return [m for m in mods if not self._is_compressed(m)] if skip_compressed else mods
 
     @staticmethod
     def _is_compressed(m) -> bool:
@@ -107,7 +114,11 @@ class ModelCompressor:
         shard-per-rank mode (see the module docstring).  Returns the modules this rank compressed."""
         fmt = self.force_compression_format
         # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
-        mine = self._parallel(model, lambda ms: compress_modules(ms, fmt), recouple, skip_compressed)
+        if not is_distributed():  # one rank: every module is this rank's (what replace_module_parallel does without a process group)
+            mine = self._quantized_modules(model, skip_compressed)
+            compress_modules(mine, fmt)
+        else:
+            mine = self._parallel(model, lambda ms: compress_modules(ms, fmt), recouple, skip_compressed)
         self._finish_compress(model, recouple)
         return mine
 

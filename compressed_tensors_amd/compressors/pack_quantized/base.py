@@ -20,6 +20,39 @@ __all__ = ["PackedQuantizationCompressor"]
 
 PACK_ZP_STRATS = ("group", "channel")
 
+_HOSTPATH = []  # [module or None], resolved on first use
+
+
+def _hostpath():
+    """the C++ host loop of the batched module paths (csrc/host/ct_hostpath.cpp, built by __graft_entry__.build()), or None when it
+    has not been built: the Python loop below does the same work, four times slower per module"""
+    if not _HOSTPATH:
+        try:
+            from ... import _hostpath as hp
+        except ImportError:
+            hp = None
+        _HOSTPATH.append(hp)
+    return _HOSTPATH[0]
+
+
+_DTYPE_OF_CODE = {1: torch.float16, 2: torch.bfloat16}
+
+
+def _plain_w4_scheme(scheme):
+    """(is a symmetric int4 group / channel scheme without activation arguments, group size or 0 for channel-wise): the schemes whose
+    modules the C++ host loop takes (an asymmetric scheme's packed zero points, an activation scheme's extra zero-point names and
+    everything else stay with the Python loop)"""
+    wa = scheme.weights
+    if (wa is None or getattr(scheme, "input_activations", None) is not None or getattr(scheme, "output_activations", None) is not None
+            or not wa.symmetric or int(wa.num_bits) != 4 or enum_value(getattr(wa, "type", "int")) != "int"):
+        return False, -1
+    st = enum_value(wa.strategy)
+    if st == "channel":
+        return True, 0
+    if st == "group" and getattr(wa, "group_size", None):
+        return True, int(wa.group_size)
+    return False, -1
+
 
 def _layout_kwargs(weights):
     return dict(
@@ -144,6 +177,24 @@ class PackedQuantizationCompressor(BaseCompressor):
         symmetric scheme), add `weight_packed` / `weight_shape` — then runs under the kernel as a delta (`swap_direct_entries`)."""
         from ...quantization.quant_args import QuantizationStatus
         from ...utils.module import swap_direct_entries
+
+        hp = _hostpath()
+        if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
+            # the plain case — symmetric int4, parameters only, nn.Module's own attribute hooks — in C++: table rows, output allocations
+            # and, after the launch, the parameter dictionaries; whatever it does not take comes back in `modules`
+            modules = list(modules)
+            seen = {}
+            infos = []
+            for m in modules:
+                scheme = m.quantization_scheme
+                g = seen.get(id(scheme))
+                if g is None:
+                    g = seen[id(scheme)] = _plain_w4_scheme(scheme)[1]
+                infos.append(g)
+            planned, modules = hp.w4_plan_compress(modules, infos)
+            for (dev_index, code), (words, n, jobs) in planned.items():
+                codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+                hp.w4_finish_compress(jobs, QuantizationStatus.COMPRESSED)
 
         batches = {}  # (device, dtype) -> (entries, jobs): one table and one launch per GPU and weight dtype
         rest = []
@@ -278,6 +329,20 @@ class PackedQuantizationCompressor(BaseCompressor):
         from ...utils.module import direct_entry, swap_direct_entries
 
         modules = list(modules)
+        hp = _hostpath()
+        if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
+            seen = {}
+            infos = []
+            for m in modules:
+                scheme = m.quantization_scheme
+                ok = seen.get(id(scheme))
+                if ok is None:
+                    ok = seen[id(scheme)] = int(_plain_w4_scheme(scheme)[0])
+                infos.append(ok)
+            planned, modules = hp.w4_plan_decompress(modules, infos)
+            for (dev_index, code), (words, n, jobs) in planned.items():
+                codec.launch_w4_words(words, n, "decompress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+                hp.w4_finish_decompress(jobs, QuantizationStatus.DECOMPRESSED)
         names = ("weight_packed", "weight_scale", "weight_shape", "weight_zero_point", "weight_g_idx")
         sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]
         pre = PackedQuantizationCompressor._batch_decompress(sds, [m.quantization_scheme for m in modules])  # (`cls` may be install()'s subclass of the UPSTREAM codec)

@@ -1106,7 +1106,7 @@ constexpr int kResRoundWords = 64; // "inclusive count through residency round r
 // doubled), the bitmask that leaves (one bit per ELEMENT: the nibbles of two adjacent units make a byte), the row offsets and the totals
 // (halved on the way out) differ.
 template <int KEEP, int WAVES, int ES>
-__global__ __launch_bounds__(WAVES * 64) void flat16_resident_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows, int tpw,
+__global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows, int tpw,
                                                                     uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
                                                                     int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
                                                                     const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
@@ -1672,10 +1672,13 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
         }
         // wave-tiles per wave: as many as the registers hold, fewer when the tensor would otherwise leave CUs without a workgroup
         // (two workgroups fit a CU)
-        int64_t tpw = cdiv64(wts, (int64_t)cus * 2 * kResWaves);
+        // EXPERIMENT (round 4): CT_BM_X's fourth field picks 4-wave workgroups (64 KB, four per CU) instead of 8-wave ones (128 KB, two per CU)
+        static const int xwaves = []() { const char* e = std::getenv("CT_BM_X"); int a = 1, b = 0, c = 1, w = kResWaves; if (e) sscanf(e, "%d:%d:%d:%d", &a, &b, &c, &w); return w == 4 ? 4 : kResWaves; }();
+        const int wgs_per_cu = xwaves == 4 ? 4 : 2;
+        int64_t tpw = cdiv64(wts, (int64_t)cus * wgs_per_cu * xwaves);
         if (tpw > kResKeep) tpw = kResKeep;
         if (tpw < 1) tpw = 1;
-        const int64_t wg_wts = (int64_t)kResWaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
+        const int64_t wg_wts = (int64_t)xwaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
         static const int64_t max_wgs = []() {  // per launch: the count words of the workspace (the knob exists for the chunking tests)
             const char* e = std::getenv("CT_BITMASK_RESIDENT_MAX_WGS");
             const int64_t v = e ? (int64_t)std::atoll(e) : (int64_t)kResMaxWGs;
@@ -1715,7 +1718,7 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 // stagger (see the kernel): only when the launch is at least two full residency rounds (two workgroups per CU each) — with a
                 // single round a delayed start is pure loss (4096^2: 15.0 -> 17.4 us), with two it buys 48.2 -> 44.6 us at 8192^2.  The delay is
                 // one load phase of a workgroup at the CU's share of the HBM rate (~19 GB/s per CU): 128 KB -> 7 us.
-                const bool stagger = nwg >= 4 * (int64_t)cus;
+                const bool stagger = nwg >= 2 * wgs_per_cu * (int64_t)cus;
                 int stagger_lo = cus, stagger_hi = stagger ? 2 * cus : 0;
                 unsigned stagger_ticks = (unsigned)((wg_wts * kWT * 16) / 188);  // 100 MHz ticks
                 unsigned stagger_slope_q8 = 0;
@@ -1729,21 +1732,22 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                     use_rounds = rw;
                     if (mode == 0) stagger_hi = 0;
                     else if (mode == 2 && stagger) {
-                        stagger_lo = 0; stagger_hi = 2 * cus; stagger_ticks = 0;
-                        stagger_slope_q8 = (unsigned)(((unsigned long long)spread * 100ull * 256ull) / (unsigned long long)(2 * cus));
+                        stagger_lo = 0; stagger_hi = wgs_per_cu * cus; stagger_ticks = 0;
+                        stagger_slope_q8 = (unsigned)(((unsigned long long)spread * 100ull * 256ull) / (unsigned long long)(wgs_per_cu * cus));
                     }
                 }
-                const int round_wgs = (use_rounds && 2 * cus <= kResMaxWGs && cdiv64(nwg, 2 * (int64_t)cus) <= kResRoundWords) ? 2 * cus : 0;
+                const int round_wgs = (use_rounds && wgs_per_cu * cus <= kResMaxWGs && cdiv64(nwg, wgs_per_cu * (int64_t)cus) <= kResRoundWords) ? wgs_per_cu * cus : 0;
                 unsigned long long* round_words = ctl + 4 + 4 * kResStampWGs;
-#define CT_RESIDENT(ES_)                                                                                                                          \
-    hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, kResWaves, ES_>), dim3((unsigned)nwg), dim3(kResWaves * 64), 0, as_stream(stream),         \
+#define CT_RESIDENT_W(ES_, W_)                                                                                                                    \
+    hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, W_, ES_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                       \
                        static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
                        values_capacity * (ES_ / 2), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out,        \
                        tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
                        round_wgs, round_words)
-                if (es == 4) CT_RESIDENT(4);
-                else CT_RESIDENT(2);
-#undef CT_RESIDENT
+                if (es == 4) CT_RESIDENT_W(4, kResWaves);
+                else if (xwaves == 4) CT_RESIDENT_W(2, 4);
+                else CT_RESIDENT_W(2, kResWaves);
+#undef CT_RESIDENT_W
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
         }

@@ -1,0 +1,339 @@
+// ct_hostpath.cpp — the per-module host loop of the batched W4A16 module paths, in C++ (CPython extension `_hostpath`).
+//
+// Why: compress_model / decompress_model of a 154-module checkpoint spend 20 us of interpreter time per module and direction in
+// PackedQuantizationCompressor.compress_modules / decompress_modules (dictionary look-ups, ~25 tensor attribute calls, torch.empty,
+// nn.Parameter, dictionary surgery) next to two kernels of 0.42 ms each (bench.py `tinyllama_checkpoint.api`).  The same steps here
+// cost ~5 us.  Nothing in this file computes on tensor data: it reads the modules' own `_parameters`, validates layouts, allocates
+// outputs with ATen, fills the `struct ct_w4_item` table (include/ct_hip.h) that ct_quant_pack_batch / ct_unpack_dequant_batch
+// consume, and — after the Python side has planned, uploaded and LAUNCHED the table — rewrites the modules' parameter
+// dictionaries under the running kernel, exactly as compressed_tensors_amd/utils/module.py:swap_direct_entries does
+// (reference: compressors/base.py:95-131, utils/module.py:33-65, compressors/pack_quantized/base.py:62-163).
+//
+// A module that is anything but the plain case (a buffer among its entries, a trainable parameter that stays, a class with its own
+// __setattr__, an asymmetric scheme, activation ordering, an unusual layout) is handed back untouched in `rest`; the Python path,
+// which covers every case, takes it.  The Python path is also what runs when this extension has not been built.
+#include <torch/csrc/autograd/python_variable.h>
+#include <torch/extension.h>
+
+#include <cstdint>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace py = pybind11;
+
+namespace {
+
+py::object g_make_subclass;   // torch.Tensor._make_subclass
+py::object g_parameter_cls;   // torch.nn.Parameter
+py::object g_module_setattr;  // torch.nn.Module.__setattr__
+py::object g_module_delattr;  // torch.nn.Module.__delattr__
+std::unordered_map<PyTypeObject*, bool> g_plain_type;
+bool g_allow_cpu = false;  // tests only (tests/test_host_logic.py): run the host logic on CPU tensors, with the launch stubbed out
+
+struct Names {
+    PyObject *parameters, *buffers, *weight, *weight_scale, *weight_zero_point, *weight_g_idx, *weight_packed, *weight_shape, *quantization_status,
+        *setattr, *delattr;
+    void init() {
+        parameters = PyUnicode_InternFromString("_parameters");
+        buffers = PyUnicode_InternFromString("_buffers");
+        weight = PyUnicode_InternFromString("weight");
+        weight_scale = PyUnicode_InternFromString("weight_scale");
+        weight_zero_point = PyUnicode_InternFromString("weight_zero_point");
+        weight_g_idx = PyUnicode_InternFromString("weight_g_idx");
+        weight_packed = PyUnicode_InternFromString("weight_packed");
+        weight_shape = PyUnicode_InternFromString("weight_shape");
+        quantization_status = PyUnicode_InternFromString("quantization_status");
+        setattr = PyUnicode_InternFromString("__setattr__");
+        delattr = PyUnicode_InternFromString("__delattr__");
+    }
+} N;
+
+// does the module's class keep nn.Module's own attribute hooks?  (then writing `_parameters` directly cannot be told from setattr)
+bool plain_type(PyObject* module) {
+    PyTypeObject* tp = Py_TYPE(module);
+    auto it = g_plain_type.find(tp);
+    if (it != g_plain_type.end()) return it->second;
+    PyObject* s = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.setattr);
+    PyObject* d = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.delattr);
+    const bool plain = s && d && s == g_module_setattr.ptr() && d == g_module_delattr.ptr();
+    Py_XDECREF(s);
+    Py_XDECREF(d);
+    PyErr_Clear();
+    g_plain_type.emplace(tp, plain);
+    return plain;
+}
+
+struct Entries {
+    PyObject* params = nullptr;   // new references
+    PyObject* buffers = nullptr;
+    ~Entries() {
+        Py_XDECREF(params);
+        Py_XDECREF(buffers);
+    }
+    bool open(PyObject* module) {
+        params = PyObject_GetAttr(module, N.parameters);
+        buffers = PyObject_GetAttr(module, N.buffers);
+        if (!params || !buffers || !PyDict_Check(params) || !PyDict_Check(buffers)) {
+            PyErr_Clear();
+            return false;
+        }
+        return true;
+    }
+    // a parameter entry as a tensor, nullptr when absent / None / not a tensor
+    const at::Tensor* tensor(PyObject* name) const {
+        PyObject* o = PyDict_GetItem(params, name);  // borrowed
+        if (!o || o == Py_None || !THPVariable_Check(o)) return nullptr;
+        return &THPVariable_Unpack(o);
+    }
+    bool has(PyObject* name) const { return PyDict_GetItem(params, name) != nullptr; }
+};
+
+inline bool aligned16(const at::Tensor& t) { return (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15u) == 0; }
+inline bool half_type(at::ScalarType t) { return t == at::kBFloat16 || t == at::kHalf; }
+
+// every parameter that stays must already be a non-trainable Parameter (else the generic path re-wraps it); no buffers at all
+bool staying_entries_are_final(const Entries& e, std::initializer_list<PyObject*> leaving) {
+    if (PyDict_Size(e.buffers) != 0) return false;
+    PyObject *key, *value;
+    Py_ssize_t pos = 0;
+    while (PyDict_Next(e.params, &pos, &key, &value)) {
+        bool leaves = false;
+        for (PyObject* l : leaving) leaves = leaves || key == l || PyObject_RichCompareBool(key, l, Py_EQ) == 1;
+        if (leaves || value == Py_None) continue;
+        if (!THPVariable_Check(value) || THPVariable_Unpack(value).requires_grad()) return false;
+    }
+    return true;
+}
+
+py::object make_parameter(const at::Tensor& t) {
+    return g_make_subclass(g_parameter_cls, py::reinterpret_steal<py::object>(THPVariable_Wrap(t)), false);
+}
+
+void set_status(PyObject* module, PyObject* status) {
+    PyObject** dictptr = _PyObject_GetDictPtr(module);
+    if (dictptr && *dictptr) PyDict_SetItem(*dictptr, N.quantization_status, status);  // a plain attribute: what nn.Module.__setattr__ ends up doing
+    else PyObject_SetAttr(module, N.quantization_status, status);
+}
+
+bool dict_has(PyObject* module, PyObject* name) {
+    PyObject** dictptr = _PyObject_GetDictPtr(module);
+    return dictptr && *dictptr && PyDict_GetItem(*dictptr, name) != nullptr;
+}
+
+struct Batch {
+    std::vector<int64_t> words;  // 10 per item: struct ct_w4_item
+    py::list jobs;
+    int n = 0;
+};
+
+py::dict batches_to_python(std::map<std::pair<int, int>, Batch>& batches) {
+    py::dict out;
+    for (auto& kv : batches) {
+        at::Tensor words = at::empty({(int64_t)kv.second.words.size()}, at::TensorOptions().dtype(at::kLong));
+        std::memcpy(words.data_ptr(), kv.second.words.data(), kv.second.words.size() * sizeof(int64_t));
+        out[py::make_tuple(kv.first.first, kv.first.second)] = py::make_tuple(words, kv.second.n, kv.second.jobs);
+    }
+    return out;
+}
+
+// infos[i]: group size of module i's scheme (0 = channel-wise), or < 0 when the scheme is not a symmetric int4 group / channel scheme
+py::tuple w4_plan_compress(py::list modules, py::list infos) {
+    std::map<std::pair<int, int>, Batch> batches;  // (device index, dtype code 1 = fp16 / 2 = bf16) -> table
+    py::list rest;
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t ginfo = PyLong_AsLongLong(PyList_GET_ITEM(infos.ptr(), i));
+        Entries e;
+        bool ok = ginfo >= 0 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
+        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
+        int64_t rows = 0, cols = 0, group = 0;
+        if (ok) {
+            w = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            zp = e.tensor(N.weight_zero_point);
+            ok = w && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && w->dim() == 2 && half_type(w->scalar_type()) &&
+                 scale->scalar_type() == w->scalar_type() && (w->is_cuda() || g_allow_cpu) && w->is_contiguous() && aligned16(*w) && scale->is_contiguous() &&
+                 aligned16(*scale) && scale->device() == w->device();
+        }
+        if (ok) {
+            rows = w->size(0);
+            cols = w->size(1);
+            group = ginfo == 0 ? cols : ginfo;
+            ok = rows > 0 && cols % 32 == 0 && group % 32 == 0 && cols % group == 0 && scale->dim() == 2 && scale->size(0) == rows &&
+                 scale->size(1) == cols / group;
+            if (ok && zp)
+                ok = zp->scalar_type() == at::kChar && zp->sizes() == scale->sizes() && zp->is_contiguous() && aligned16(*zp) && zp->device() == w->device();
+            ok = ok && staying_entries_are_final(e, {N.weight, N.weight_zero_point});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        at::Tensor packed = at::empty({rows, cols / 8}, w->options().dtype(at::kInt));
+        Batch& b = batches[{w->is_cuda() ? (int)w->device().index() : -1, w->scalar_type() == at::kHalf ? 1 : 2}];
+        const int64_t item[10] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
+                                  (int64_t)(uintptr_t)packed.data_ptr(), rows, cols, group, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + 10);
+        b.n += 1;
+        // the job keeps the inputs alive until the launch has been issued (the table holds raw pointers)
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(packed)), rows, cols,
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight))));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+// after the launch: `weight` (and the zero point a symmetric scheme does not store) leave, `weight_packed` and `weight_shape` arrive
+void w4_finish_compress(py::list jobs, py::object status) {
+    const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
+        PyObject* m = PyTuple_GET_ITEM(job, 0);
+        const at::Tensor& packed = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));
+        const int64_t rows = PyLong_AsLongLong(PyTuple_GET_ITEM(job, 2)), cols = PyLong_AsLongLong(PyTuple_GET_ITEM(job, 3));
+        Entries e;
+        if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        PyDict_DelItem(e.params, N.weight);
+        if (PyDict_GetItem(e.params, N.weight_zero_point)) PyDict_DelItem(e.params, N.weight_zero_point);
+        at::Tensor shape = at::empty({2}, at::TensorOptions().dtype(at::kLong));  // int64, CPU: as upstream (pack_quantized/base.py:105)
+        shape.data_ptr<int64_t>()[0] = rows;
+        shape.data_ptr<int64_t>()[1] = cols;
+        PyDict_SetItem(e.params, N.weight_packed, make_parameter(packed).ptr());
+        PyDict_SetItem(e.params, N.weight_shape, make_parameter(shape).ptr());
+        set_status(m, status.ptr());
+    }
+}
+
+// infos[i]: 1 when module i's scheme is a symmetric int4 scheme (the strategy is inferred from the scale's shape, as `dequantize` does), else 0
+py::tuple w4_plan_decompress(py::list modules, py::list infos) {
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const bool scheme_ok = PyLong_AsLongLong(PyList_GET_ITEM(infos.ptr(), i)) == 1;
+        Entries e;
+        bool ok = scheme_ok && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
+        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr;
+        int64_t rows = 0, cols = 0, group = 0;
+        if (ok) {
+            packed = e.tensor(N.weight_packed);
+            scale = e.tensor(N.weight_scale);
+            shape_t = e.tensor(N.weight_shape);
+            ok = packed && scale && shape_t && !e.has(N.weight_g_idx) && !e.has(N.weight_zero_point) && !e.has(N.weight) && (packed->is_cuda() || g_allow_cpu) &&
+                 packed->is_contiguous() && packed->scalar_type() == at::kInt && aligned16(*packed) && packed->dim() == 2 && scale->dim() == 2 &&
+                 half_type(scale->scalar_type()) && scale->is_contiguous() && aligned16(*scale) && scale->device() == packed->device() &&
+                 shape_t->device().is_cpu() && shape_t->scalar_type() == at::kLong && shape_t->numel() == 2 && shape_t->is_contiguous();
+        }
+        if (ok) {
+            rows = shape_t->data_ptr<int64_t>()[0];
+            cols = shape_t->data_ptr<int64_t>()[1];
+            ok = rows > 0 && cols > 0 && scale->size(1) > 0 && cols % scale->size(1) == 0;
+        }
+        if (ok) {
+            group = scale->size(1) == 1 ? cols : cols / scale->size(1);  // (R, 1): channel; (R, G): group (forward.py:99-130)
+            ok = cols % 32 == 0 && group % 32 == 0 && cols % group == 0 && scale->size(0) == rows && scale->size(1) == cols / group && packed->size(0) == rows &&
+                 packed->size(1) == cols / 8 && staying_entries_are_final(e, {N.weight_packed});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        at::Tensor out = at::empty({rows, cols}, scale->options());
+        Batch& b = batches[{packed->is_cuda() ? (int)packed->device().index() : -1, scale->scalar_type() == at::kHalf ? 1 : 2}];
+        const int64_t item[10] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), 0, (int64_t)(uintptr_t)out.data_ptr(), rows, cols,
+                                  group, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + 10);
+        b.n += 1;
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_packed))));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+void w4_finish_decompress(py::list jobs, py::object status) {
+    const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
+        PyObject* m = PyTuple_GET_ITEM(job, 0);
+        const at::Tensor& out = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));
+        Entries e;
+        if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        PyDict_DelItem(e.params, N.weight_packed);
+        PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
+        set_status(m, status.ptr());
+    }
+}
+
+// the quantized modules of a model in `named_modules(remove_duplicate=True)` order (pre-order over `_modules`, every module once):
+// model_compressor.py:152-164,191-195 with is_module_quantized (quantization/utils/helpers.py:229-250: a scheme with at least one of
+// weights / input_activations / output_activations).  300 modules cost the interpreter 0.3 ms per walk; here ~30 us.
+struct Walker {
+    PyObject* modules_name = PyUnicode_InternFromString("_modules");
+    PyObject* scheme_name = PyUnicode_InternFromString("quantization_scheme");
+    PyObject* arg_names[3] = {PyUnicode_InternFromString("weights"), PyUnicode_InternFromString("input_activations"),
+                              PyUnicode_InternFromString("output_activations")};
+    std::unordered_set<PyObject*> seen;
+    py::list out;
+
+    void visit(PyObject* module) {
+        if (!seen.insert(module).second) return;
+        PyObject* scheme = PyObject_GetAttr(module, scheme_name);
+        if (!scheme) {
+            PyErr_Clear();
+        } else {
+            bool quantized = false;
+            if (scheme != Py_None) {
+                for (PyObject* a : arg_names) {
+                    PyObject* v = PyObject_GetAttr(scheme, a);
+                    if (!v) {
+                        PyErr_Clear();
+                        continue;
+                    }
+                    quantized = quantized || v != Py_None;
+                    Py_DECREF(v);
+                }
+            }
+            Py_DECREF(scheme);
+            if (quantized) out.append(py::reinterpret_borrow<py::object>(module));
+        }
+        PyObject* children = PyObject_GetAttr(module, modules_name);
+        if (!children) {
+            PyErr_Clear();
+            return;
+        }
+        if (PyDict_Check(children)) {
+            PyObject *key, *value;
+            Py_ssize_t pos = 0;
+            while (PyDict_Next(children, &pos, &key, &value))
+                if (value != Py_None) visit(value);
+        }
+        Py_DECREF(children);
+    }
+};
+
+py::list quantized_modules(py::object model) {
+    Walker w;
+    w.visit(model.ptr());
+    return w.out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_hostpath, mod) {
+    N.init();
+    py::module_ torch_mod = py::module_::import("torch");
+    g_make_subclass = torch_mod.attr("Tensor").attr("_make_subclass");
+    g_parameter_cls = torch_mod.attr("nn").attr("Parameter");
+    g_module_setattr = torch_mod.attr("nn").attr("Module").attr("__setattr__");
+    g_module_delattr = torch_mod.attr("nn").attr("Module").attr("__delattr__");
+    mod.def("w4_plan_compress", &w4_plan_compress);
+    mod.def("w4_finish_compress", &w4_finish_compress);
+    mod.def("w4_plan_decompress", &w4_plan_decompress);
+    mod.def("w4_finish_decompress", &w4_finish_decompress);
+    mod.def("quantized_modules", &quantized_modules);
+    mod.def("set_allow_cpu", [](bool v) { g_allow_cpu = v; });
+    mod.attr("ITEM_WORDS") = 10;
+}

@@ -266,7 +266,7 @@ def test_upstream_model_compressor_takes_the_batched_launches(upstream):
         for a, b in zip(cpu_model, gpu_model):
             assert set(a._parameters) == set(b._parameters)
             for k, v in a._parameters.items():
-                assert torch.equal(b._parameters[k].cpu(), v), k
+                assert (v is None and b._parameters[k] is None) or torch.equal(b._parameters[k].cpu(), v), k
             assert b.quantization_status == QuantizationStatus.COMPRESSED and type(b.quantization_status) is QuantizationStatus
             assert b.weight_packed.is_cuda and not b.weight_shape.is_cuda
         mc.decompress_model(gpu_model)

@@ -714,3 +714,111 @@ def test_batch_table_words_match_the_struct(cta):
         assert bytes(w) == bytes(s)
         for i, (r, c, g) in enumerate(shapes):
             assert (s[i].rows, s[i].cols, s[i].group) == (r, c, g) and s[i].units == r * c // 8
+
+
+def _tree(cta, scheme, shapes, *, trainable_scale=False, buffer_zp=False, odd_class=False, g_idx=False):
+    class Odd(torch.nn.Linear):
+        def __setattr__(self, name, value):
+            super().__setattr__(name, value)
+
+    root = torch.nn.Module()
+    root.blocks = torch.nn.ModuleList()
+    for k, (r, c) in enumerate(shapes):
+        lin = (Odd if odd_class and k == 1 else torch.nn.Linear)(c, r, bias=False, device="meta")
+        lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=torch.bfloat16), requires_grad=True)  # a fresh Linear's weight is trainable
+        lin.weight_scale = torch.nn.Parameter(torch.ones(r, c // 128, dtype=torch.bfloat16), requires_grad=trainable_scale and k == 2)
+        zp = torch.zeros(r, c // 128, dtype=torch.int8)
+        if buffer_zp and k == 0:
+            lin.register_buffer("weight_zero_point", zp)
+        else:
+            lin.weight_zero_point = torch.nn.Parameter(zp, requires_grad=False)
+        if g_idx and k == 3:
+            lin.weight_g_idx = torch.nn.Parameter(torch.arange(c, dtype=torch.int32) // 128, requires_grad=False)
+        lin.quantization_scheme = scheme
+        blk = torch.nn.Module()
+        blk.proj = lin
+        root.blocks.append(blk)
+    root.shared = root.blocks[0]  # the same module twice in the tree: walked once
+    return root
+
+
+@pytest.mark.parametrize("variant", ["plain", "trainable_scale", "buffer_zp", "odd_class", "g_idx"])
+def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
+    """csrc/host/ct_hostpath.cpp (the per-module loop of PackedQuantizationCompressor.compress_modules / decompress_modules in C++) against
+    the Python loop it replaces, on CPU tensors with the two launches stubbed out: the same table (pointers, shapes, groups), the
+    same modules handed back for the generic path, and every module left in the same state — names, order, kinds, trainability,
+    shapes, dtypes, status; also the module walk against named_modules(remove_duplicate=True) + is_module_quantized"""
+    import copy
+
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.compressors.pack_quantized import base as pq
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+    from compressed_tensors_amd.quantization.utils import is_module_quantized
+
+    hp = pq._hostpath()
+    assert hp is not None, "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    shapes = [(64, 256), (32, 512), (96, 128), (64, 384), (16, 256)]
+    a = _tree(cta, scheme, shapes, **({} if variant == "plain" else {variant: True}))
+    b = copy.deepcopy(a)
+    for x, y in zip(a.modules(), b.modules()):
+        if hasattr(x, "quantization_scheme"):
+            y.quantization_scheme = x.quantization_scheme  # one scheme object per group, as apply_quantization_config attaches it
+    assert [id(m) for m in hp.quantized_modules(a)] == [id(m) for _, m in a.named_modules(remove_duplicate=True) if is_module_quantized(m)]
+
+    tables = {"cpp": [], "py": []}
+    which = {"now": "cpp"}
+
+    def fake_words(words, n, direction, dtype, device):
+        rows = words.reshape(n, 10)[:, 4:7].tolist()
+        tables[which["now"]].append((direction, dtype, rows))
+
+    class FakeBatch:
+        def __init__(self, entries, direction, dtype, kind="w4", bits=8):
+            self.rec = (direction, dtype, [[int(e[4]), int(e[5]), int(e[6])] for e in entries])
+
+        def launch(self, stream=None):
+            if self.rec[2]:
+                tables[which["now"]].append(self.rec)
+
+    monkeypatch.setattr(codec, "launch_w4_words", fake_words)
+    monkeypatch.setattr(codec, "W4Batch", FakeBatch)
+    monkeypatch.setattr(codec, "quantize_and_pack", lambda w, *a_, **k: torch.zeros(w.shape[0], w.shape[1] // 8, dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_and_dequantize", lambda p, shape, scale, *a_, **k: torch.zeros(shape, dtype=scale.dtype))
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)  # the Python loop's own device test
+    hp.set_allow_cpu(True)
+    try:
+        mods_a = [m for m in a.modules() if isinstance(m, torch.nn.Linear)]
+        mods_b = [m for m in b.modules() if isinstance(m, torch.nn.Linear)]
+        pq.PackedQuantizationCompressor.compress_modules(mods_a)  # C++ loop first, Python loop for what it hands back
+        which["now"] = "py"
+        monkeypatch.setattr(pq, "_HOSTPATH", [None])  # the Python loop alone
+        pq.PackedQuantizationCompressor.compress_modules(mods_b)
+        monkeypatch.setattr(pq, "_HOSTPATH", [hp])
+        n_plain = {"plain": 5, "trainable_scale": 4, "buffer_zp": 4, "odd_class": 4, "g_idx": 4}[variant]
+        assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "compress") >= n_plain - 0
+        for x, y in zip(mods_a, mods_b):
+            assert _module_state_no_ptr(x) == _module_state_no_ptr(y), variant
+            assert x.quantization_status == QuantizationStatus.COMPRESSED == y.quantization_status
+            assert x.weight_shape.tolist() == list(x.weight_packed.shape[:1]) + [x.weight_packed.shape[1] * 8]
+        which["now"] = "cpp"
+        pq.PackedQuantizationCompressor.decompress_modules(mods_a)
+        which["now"] = "py"
+        monkeypatch.setattr(pq, "_HOSTPATH", [None])
+        pq.PackedQuantizationCompressor.decompress_modules(mods_b)
+        for x, y in zip(mods_a, mods_b):
+            assert _module_state_no_ptr(x) == _module_state_no_ptr(y), variant
+            assert x.quantization_status == QuantizationStatus.DECOMPRESSED == y.quantization_status
+            assert x.weight.shape == (x.out_features, x.in_features) and x.weight.dtype == torch.bfloat16
+        # the same work reached the launches, whichever loop built the table
+        flat = lambda ts, d: sorted(tuple(r) for t in ts if t[0] == d for r in t[2])
+        for d in ("compress", "decompress"):
+            assert flat(tables["cpp"], d) == flat(tables["py"], d), (variant, d)
+    finally:
+        hp.set_allow_cpu(False)
+
+
+def _module_state_no_ptr(m):
+    return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
+            [(k, None if v is None else (type(v).__name__, tuple(v.shape))) for k, v in m._buffers.items()])
