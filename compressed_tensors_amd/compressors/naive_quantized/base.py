@@ -141,21 +141,21 @@ class NaiveQuantizationCompressor(BaseCompressor):
     @classmethod
     def compress_modules(cls, modules) -> None:
         from ...quantization.quant_args import QuantizationStatus
-        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+        from ...utils.module import direct_entry, swap_direct_entries
+        from ..base import symmetric_zp_keys
 
         modules = list(modules)
         if not cls._owns_codec():
             return super().compress_modules(modules)
-        sds = [get_direct_state_dict(m) for m in modules]
+        names = ("weight", "weight_scale", "weight_zero_point", "weight_g_idx")
+        sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]  # the modules' own entries: no state-dict copies
         pre = cls._batch_compress(sds, [m.quantization_scheme for m in modules])
-        for m, sd, q in zip(modules, sds, pre):
+        for m, q in zip(modules, pre):
             if q is None:
                 cls.compress_module(m)
                 continue
-            new = dict(sd)
-            new["weight"] = q
-            replace_direct_state_dict(m, cls._remove_symmetric_zp(new, m.quantization_scheme))
-            m.quantization_status = QuantizationStatus.COMPRESSED
+            # what replace_direct_state_dict(module, compress(state_dict)) leaves: the codes in `weight`, no zero point for a symmetric scheme
+            swap_direct_entries(m, symmetric_zp_keys(m.quantization_scheme), {"weight": q}, QuantizationStatus.COMPRESSED)
 
     @classmethod
     def decompress_many(cls, state_dicts, scheme) -> list:
@@ -175,21 +175,19 @@ class NaiveQuantizationCompressor(BaseCompressor):
     @classmethod
     def decompress_modules(cls, modules) -> None:
         from ...quantization.quant_args import QuantizationStatus
-        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+        from ...utils.module import direct_entry, swap_direct_entries
 
         modules = list(modules)
         if not cls._owns_codec():
             return super().decompress_modules(modules)
-        sds = [get_direct_state_dict(m) for m in modules]
+        names = ("weight", "weight_scale", "weight_zero_point", "weight_g_idx")
+        sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]
         pre = cls._batch_decompress(sds)
-        for m, sd, w in zip(modules, sds, pre):
+        for m, w in zip(modules, pre):
             if w is None:
                 cls.decompress_module(m)
                 continue
-            new = dict(sd)
-            new["weight"] = w
-            replace_direct_state_dict(m, new)
-            m.quantization_status = QuantizationStatus.DECOMPRESSED
+            swap_direct_entries(m, (), {"weight": w}, QuantizationStatus.DECOMPRESSED)
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

@@ -638,6 +638,33 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     const int mpos0 = (dr0 + adj) * 2 + ((cl - adj) & 1);
     uint32_t vmax = 0;
     bool violation = false;
+    // Round 3: the tile's scales — 64 rows x (at most 16, for group 128 two) groups — are converted ONCE, cooperatively: scale.to(fp16),
+    // the lean-range test and the IEEE reciprocal used to be recomputed by every thread for each of its four words (1024 divisions per
+    // tile for 128 distinct scales, plus eight small loads per thread).  A group whose zero point is not zero gets reciprocal 0, which
+    // sends its words to the exact path like an out-of-range scale does.
+    // Round 4: the scale (and zero point) load is issued BEFORE the weight loads and is unconditional straight-line code (entry index
+    // clamped; a missing zero-point tensor reads a byte of the scale instead and ignores it).  Vector-memory results return in order:
+    // issued after the 128 bytes of weights — as in round 3 — the scale could only be used behind `s_waitcnt vmcnt(0)`, i.e. the
+    // "conversion while the weights are in flight" waited for every weight first and the whole load latency of a workgroup was exposed
+    // (the ISA showed it).  Now the conversion (a divide) and the LDS hand-over run under the weight loads, and the four words are
+    // consumed behind vmcnt(6 / 4 / 2 / 0) as they land.
+    const uint32_t g_first = per_pow2 ? (((uint32_t)tile_c * 16u) >> per_shift) : (((uint32_t)tile_c * 16u) / per);
+    const uint32_t g_last = per_pow2 ? (((uint32_t)tile_c * 16u + 15u) >> per_shift) : (((uint32_t)tile_c * 16u + 15u) / per);
+    const int ng = (int)(g_last - g_first) + 1;  // <= 16
+    const int n_entries = 64 * ng;
+    const int e0 = tid < n_entries ? tid : n_entries - 1;
+    const int rl_e = e0 / ng, gi_e = e0 - rl_e * ng;
+    const int64_t si_e = ((int64_t)tile_r * 64 + rl_e) * scale_cols + g_first + gi_e;
+    // (inline asm: hipcc sinks an ordinary small load to its first use, below the eight wide ones, and a volatile one is waited for
+    // on the spot; these two are issued here and waited for by hand — `vmcnt(8)`: everything but the eight weight loads issued after them)
+    uint32_t sb_e;
+    int32_t zb_e;
+    {
+        const uint16_t* sp = scale + si_e;
+        const int8_t* zq = zp != nullptr ? zp + si_e : reinterpret_cast<const int8_t*>(sp);
+        asm volatile("global_load_ushort %0, %1, off" : "=v"(sb_e) : "v"(sp) : "memory");
+        asm volatile("global_load_sbyte %0, %1, off" : "=v"(zb_e) : "v"(zq) : "memory");
+    }
     // all 128 bytes of this lane's four words are requested before the first one is used
     u32x4 wa[4], wb[4];
 #pragma unroll
@@ -647,18 +674,21 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         wa[it] = in[0];
         wb[it] = in[1];
     }
-    // Round 3: the tile's scales — 64 rows x (at most 16, for group 128 two) groups — are converted ONCE, cooperatively, while the
-    // weights are in flight: scale.to(fp16), the lean-range test and the IEEE reciprocal used to be recomputed by every thread for
-    // each of its four words (1024 divisions per tile for 128 distinct scales, plus eight small loads per thread).  A group whose
-    // zero point is not zero gets reciprocal 0, which sends its words to the exact path like an out-of-range scale does.
-    const uint32_t g_first = per_pow2 ? (((uint32_t)tile_c * 16u) >> per_shift) : (((uint32_t)tile_c * 16u) / per);
-    const uint32_t g_last = per_pow2 ? (((uint32_t)tile_c * 16u + 15u) >> per_shift) : (((uint32_t)tile_c * 16u + 15u) / per);
-    const int ng = (int)(g_last - g_first) + 1;  // <= 16
-    for (int e = tid; e < 64 * ng; e += kBlock) {
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(sb_e), "+v"(zb_e) : : "memory");
+    {
+        const float s16 = SDT == CT_F16 ? f16_bits_to_f(sb_e) : round_to<CT_F16>(bf16_bits_to_f(sb_e));  // scale.to(fp16)
+        float rs = m24_lean_rcp(s16);
+        if (zp != nullptr && zb_e != 0) rs = 0.0f;
+        if (tid < n_entries) {
+            s_rs[rl_e][gi_e] = rs;
+            if (NEWTON) s_s16[rl_e][gi_e] = s16;
+        }
+    }
+    for (int e = tid + kBlock; e < n_entries; e += kBlock) {  // more than 256 (row, group) entries: groups narrower than 64 columns
         const int rl = e / ng, gi = e - rl * ng;
         const int64_t si = ((int64_t)tile_r * 64 + rl) * scale_cols + g_first + gi;
         const uint32_t sb = scale[si];
-        const float s16 = SDT == CT_F16 ? f16_bits_to_f(sb) : round_to<CT_F16>(bf16_bits_to_f(sb));  // scale.to(fp16)
+        const float s16 = SDT == CT_F16 ? f16_bits_to_f(sb) : round_to<CT_F16>(bf16_bits_to_f(sb));
         float rs = m24_lean_rcp(s16);
         if (zp != nullptr && zp[si] != 0) rs = 0.0f;
         s_rs[rl][gi] = rs;

@@ -1128,9 +1128,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
     const uint32_t keepbits = is_float ? (ES == 4 ? 0x7fffffffu : 0x7fff7fffu) : 0xffffffffu;
     constexpr int SH = ES == 4 ? 1 : 0;  // halves per element, as a shift
     if (tid == 0) s_nmiss = 0;
-    // ---- stagger: the second workgroup of every CU starts its loads one load-phase later than the first, so that from then on
-    // one of a CU's two workgroups reads while the other computes / waits for its prefix / stores (without it the whole chip moves
-    // in lockstep: everybody loads, then everybody stores — 2 x 25 us at 8192^2 for 36 us of traffic)
+    // ---- stagger: the workgroups of the first residency round start their loads spread over one load phase (workgroup b waits
+    // stagger_ticks + (b - stagger_lo) x slope), so that from then on a CU's two workgroups — and the chip as a whole — read, compute /
+    // wait for a prefix and store at different times (without it the whole chip moves in lockstep: everybody loads, then everybody
+    // stores — 2 x 25 us at 8192^2 for 36 us of traffic).  Later rounds inherit the spread: a workgroup starts when an earlier one retires.
     if (b >= stagger_lo && b < stagger_hi) {
         const unsigned long long s0 = wall_clock64();
         const unsigned long long wait = stagger_ticks + (((unsigned long long)(b - stagger_lo) * stagger_slope_q8) >> 8);
@@ -1653,8 +1654,8 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
     CT_REQUIRE(aligned16(values), "values buffer must be 16-byte aligned");
     // 16- and 32-bit elements (the latter as pairs of halves): the resident form (x read once).  CT_BITMASK_RESIDENT=0 selects the two kernels
     // below for 16-bit elements (x read twice; 32-bit ones then take the generic path), which
-    // are also what the caller falls back to when the resident form reports -1; 3 = time stamps of the first 512 workgroups in the
-    // workspace (tools/exp_r02.py bmres)
+    // are also what the caller falls back to when the resident form reports -1; 3 = time stamps of the first 1024 workgroups in the
+    // workspace (tools/exp_r04.py bmstamps)
     static const int resident_mode = []() { const char* e = std::getenv("CT_BITMASK_RESIDENT"); return e ? std::atoi(e) : 1; }();
     if ((es == 2 || es == 4) && cols % 8 == 0 && aligned16(x) && resident_mode) {
         const int64_t upr = cols * es / 16;  // 16-byte units per row
@@ -1671,14 +1672,12 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
             cus = c;
         }
         // wave-tiles per wave: as many as the registers hold, fewer when the tensor would otherwise leave CUs without a workgroup
-        // (two workgroups fit a CU)
-        // EXPERIMENT (round 4): CT_BM_X's fourth field picks 4-wave workgroups (64 KB, four per CU) instead of 8-wave ones (128 KB, two per CU)
-        static const int xwaves = []() { const char* e = std::getenv("CT_BM_X"); int a = 1, b = 0, c = 1, w = kResWaves; if (e) sscanf(e, "%d:%d:%d:%d", &a, &b, &c, &w); return w == 4 ? 4 : kResWaves; }();
-        const int wgs_per_cu = xwaves == 4 ? 4 : 2;
-        int64_t tpw = cdiv64(wts, (int64_t)cus * wgs_per_cu * xwaves);
+        // (two 8-wave workgroups fit a CU; 4-wave workgroups, four per CU, measured the same: 41.8-43.3 us against 42.0-42.3)
+        constexpr int wgs_per_cu = 2;
+        int64_t tpw = cdiv64(wts, (int64_t)cus * wgs_per_cu * kResWaves);
         if (tpw > kResKeep) tpw = kResKeep;
         if (tpw < 1) tpw = 1;
-        const int64_t wg_wts = (int64_t)xwaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
+        const int64_t wg_wts = (int64_t)kResWaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
         static const int64_t max_wgs = []() {  // per launch: the count words of the workspace (the knob exists for the chunking tests)
             const char* e = std::getenv("CT_BITMASK_RESIDENT_MAX_WGS");
             const int64_t v = e ? (int64_t)std::atoll(e) : (int64_t)kResMaxWGs;
@@ -1716,27 +1715,19 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 // the chunk's running total: straight into *total for the last chunk, else into one of two alternating workspace words
                 unsigned long long* run_out = k + 1 == nchunks ? reinterpret_cast<unsigned long long*>(total) : ctl + 2 + (k & 1);
                 // stagger (see the kernel): only when the launch is at least two full residency rounds (two workgroups per CU each) — with a
-                // single round a delayed start is pure loss (4096^2: 15.0 -> 17.4 us), with two it buys 48.2 -> 44.6 us at 8192^2.  The delay is
-                // one load phase of a workgroup at the CU's share of the HBM rate (~19 GB/s per CU): 128 KB -> 7 us.
+                // single round a delayed start is pure loss (4096^2: 15.0 -> 17.4 us).  Round 4: a GRADIENT over the first residency round —
+                // workgroup b of the first 2 x CUs starts b / (2 x CUs) of one load phase late, so that counts resolve, values leave and
+                // slots free up progressively instead of in two lockstep halves (round 3: the second workgroup of every CU one whole load
+                // phase late).  Spread swept at 8192^2 with the tile-by-tile kernel: none 43.7, 4 us 43.0, 7 us 42.3, 8 us 42.1, 9 us 42.0,
+                // 10 us 42.7 (the round-3 form: 44.9).  9 us per 128 KB workgroup = the load phase of a workgroup at the CU's share of the HBM rate.
                 const bool stagger = nwg >= 2 * wgs_per_cu * (int64_t)cus;
-                int stagger_lo = cus, stagger_hi = stagger ? 2 * cus : 0;
-                unsigned stagger_ticks = (unsigned)((wg_wts * kWT * 16) / 188);  // 100 MHz ticks
-                unsigned stagger_slope_q8 = 0;
-                // EXPERIMENT knobs (round 4, removed once measured): CT_BM_X = "<stagger mode>:<spread us>:<round words 0/1>"
-                //   stagger mode 0 off, 1 second workgroup of a CU one load phase late (shipped), 2 gradient over the first residency round
-                static const char* xenv = std::getenv("CT_BM_X");
-                int use_rounds = 1;
-                if (xenv) {
-                    int mode = 1, spread = 12, rw = 1;
-                    sscanf(xenv, "%d:%d:%d", &mode, &spread, &rw);
-                    use_rounds = rw;
-                    if (mode == 0) stagger_hi = 0;
-                    else if (mode == 2 && stagger) {
-                        stagger_lo = 0; stagger_hi = wgs_per_cu * cus; stagger_ticks = 0;
-                        stagger_slope_q8 = (unsigned)(((unsigned long long)spread * 100ull * 256ull) / (unsigned long long)(wgs_per_cu * cus));
-                    }
-                }
-                const int round_wgs = (use_rounds && wgs_per_cu * cus <= kResMaxWGs && cdiv64(nwg, wgs_per_cu * (int64_t)cus) <= kResRoundWords) ? wgs_per_cu * cus : 0;
+                const int stagger_lo = 0, stagger_hi = stagger ? wgs_per_cu * cus : 0;
+                const unsigned stagger_ticks = 0;
+                const unsigned long long spread_ticks = (unsigned long long)(wg_wts * kWT * 16) * 900ull / (128ull * 1024ull);  // 100 MHz ticks: 9 us per 128 KB
+                const unsigned stagger_slope_q8 = (unsigned)((spread_ticks * 256ull) / (unsigned long long)(wgs_per_cu * cus));
+                // one "inclusive count through residency round r" word per round: a round r >= 1 workgroup polls it instead of the r x 2 x CUs
+                // raw count words of the earlier rounds (44.9 -> 44.6 us by itself; kept: it halves the polling of the later rounds)
+                const int round_wgs = (wgs_per_cu * cus <= kResMaxWGs && cdiv64(nwg, wgs_per_cu * (int64_t)cus) <= kResRoundWords) ? wgs_per_cu * cus : 0;
                 unsigned long long* round_words = ctl + 4 + 4 * kResStampWGs;
 #define CT_RESIDENT_W(ES_, W_)                                                                                                                    \
     hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, W_, ES_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                       \
@@ -1745,7 +1736,6 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                        tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
                        round_wgs, round_words)
                 if (es == 4) CT_RESIDENT_W(4, kResWaves);
-                else if (xwaves == 4) CT_RESIDENT_W(2, 4);
                 else CT_RESIDENT_W(2, kResWaves);
 #undef CT_RESIDENT_W
             }

@@ -156,6 +156,77 @@ def test_convert_checkpoint_dequantizes_on_the_gpu(tmp_path, max_workers):
 
 
 @pytest.mark.gpu
+def test_convert_checkpoint_end_to_end_rate_on_tmpfs():
+    """the model-free path end to end — 8 safetensors shards of a TinyLlama-shaped W4A16 checkpoint in /dev/shm
+    -> GPU decompress -> bf16 safetensors in /dev/shm, `max_workers` = 4 and 8 — as a driver-visible record
+    (gpurun_out/convert_rate.json, printed).  The path is bound by host copies and the tmpfs write, not by the
+    kernels; the floor asserted here is what a regression of the pipeline (serialised shards, pageable copies) would break, every
+    converted tensor is checked against fake_quantize on the device."""
+    import shutil
+    import time
+
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd import codec
+
+    dev = torch.device("cuda:0")
+    root = "/dev/shm/ct_convert_rate_test"
+    shutil.rmtree(root, ignore_errors=True)
+    src, dst = os.path.join(root, "src"), os.path.join(root, "dst")
+    os.makedirs(src)
+    try:
+        layer = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048), ("gate_proj", 5632, 2048),
+                 ("up_proj", 5632, 2048), ("down_proj", 2048, 5632))
+        args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+        scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+        qcfg = dict(QCFG, ignore=[])
+        json.dump({"quantization_config": qcfg}, open(os.path.join(src, "config.json"), "w"))
+        g = torch.Generator(device=dev).manual_seed(3)
+        wm, in_bytes, out_bytes, probe = {}, 0, 0, None
+        nshards, per = 8, 3  # 8 shards x 3 layers (the last one holds 1): 22 layers
+        for sh in range(nshards):
+            tensors = {}
+            for l in range(sh * per, min((sh + 1) * per, 22)):
+                for name, r, c in layer:
+                    w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+                    sc, zp = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+                    comp = cta.PackedQuantizationCompressor.compress({"weight": w, "weight_scale": sc, "weight_zero_point": zp}, scheme)
+                    for k, v in comp.items():
+                        tensors[f"model.layers.{l}.{name}.{k}"] = v.cpu().contiguous()
+                    out_bytes += r * c * 2
+                    if probe is None:
+                        probe = (f"model.layers.{l}.{name}.weight", codec.fake_quantize_tensor(w, sc, zp, num_bits=4, strategy="group", group_size=128).cpu())
+            if not tensors:
+                continue
+            fn = f"model-{sh + 1:05d}-of-{nshards:05d}.safetensors"
+            save_file(tensors, os.path.join(src, fn))
+            in_bytes += sum(t.numel() * t.element_size() for t in tensors.values())
+            wm.update({k: fn for k in tensors})
+        json.dump({"metadata": {"total_size": in_bytes}, "weight_map": wm}, open(os.path.join(src, "model.safetensors.index.json"), "w"))
+        conv = CompressedTensorsDequantizer(src, dtype=torch.bfloat16, device=dev)
+        rates = {}
+        for workers in (4, 8):
+            best = None
+            for _ in range(3):
+                shutil.rmtree(dst, ignore_errors=True)
+                t0 = time.perf_counter()
+                convert_checkpoint(src, dst, conv, max_workers=workers)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            rates[f"max_workers_{workers}"] = {"ms": round(best * 1e3, 1), "GBps_file_bytes": round((in_bytes + out_bytes) / best / 1e9, 2)}
+        fn0 = wm[probe[0].replace(".weight", ".weight_packed")]
+        got = load_file(os.path.join(dst, fn0))[probe[0]]
+        assert torch.equal(got, probe[1])
+        rec = {"what": "convert_checkpoint + CompressedTensorsDequantizer, TinyLlama-1.1B-shaped W4A16 checkpoint, 8 shards, files in /dev/shm (tmpfs)",
+               "in_MB": round(in_bytes / 1e6, 1), "out_MB": round(out_bytes / 1e6, 1), "host_cores": os.cpu_count(), **rates}
+        print(rec)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "convert_rate.json"), "w"), indent=1)
+        assert max(r["GBps_file_bytes"] for r in rates.values()) >= 6.0, rec
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_convert_checkpoint_float_formats(tmp_path):
     """the same converter over float-quantized (fp8), mxfp8-, nvfp4- and mxfp4-pack-quantized modules: the format of
     every config group is inferred from its scheme, the weights come back as the oracle's decompress"""

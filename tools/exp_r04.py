@@ -98,3 +98,51 @@ elif what == "host":
     out["codec.bitmask_compress 256x256 (mailbox nnz)"] = per_call(lambda: codec.bitmask_compress(w))
     out["codec.bitmask_compress 256x256 two_pass (.item())"] = per_call(lambda: codec.bitmask_compress(w, two_pass=True))
     print(json.dumps(out, indent=1))
+if what == "hostmodel":
+    # where the host time of ModelCompressor.compress_model / decompress_model goes on a 154-module TinyLlama-shaped tree (C++ host loop)
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd.compressors import base as cbase
+    from compressed_tensors_amd.compressors.pack_quantized import base as pq
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+
+    hp = pq._hostpath()
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    g = torch.Generator(device=dev).manual_seed(1)
+    mods, keep = [(f"model.layers.{l}.{n}", r, c) for l in range(22) for (n, r, c) in B.TINYLLAMA_LAYER], []
+    for _, r, c in mods:
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        s_, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+        keep.append((w, s_, z, None, None))
+    model = B.tinyllama_module_tree(mods, keep, scheme)
+    mc = cta.ModelCompressor()
+    for _ in range(3):
+        mc.compress_model(model); mc.decompress_model(model)
+    torch.cuda.synchronize()
+
+    def med(fn, n=9):
+        ts = []
+        for _ in range(n):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); ts.append((time.perf_counter() - t0) * 1e6)
+        return round(sorted(ts)[n // 2], 1), r
+
+    out = {}
+    out["walk (C++)"], ms = med(lambda: hp.quantized_modules(model))
+    out["walk (named_modules + is_module_quantized)"], _ = med(lambda: mc._named_quantized_modules(model))
+    out["_by_format"], groups = med(lambda: cbase._by_format(ms, None))
+    infos = [128] * len(ms)
+    t_plan, (planned, rest) = med(lambda: hp.w4_plan_compress(ms, infos), n=1)
+    out["w4_plan_compress (one call: allocates 154 outputs)"] = t_plan
+    (key, (words, n, jobs)), = planned.items()
+    out["launch_w4_words compress (plan + pinned upload + launch)"], _ = med(lambda: codec.launch_w4_words(words, n, "compress", torch.bfloat16, dev), n=5)
+    t0 = time.perf_counter(); hp.w4_finish_compress(jobs, QuantizationStatus.COMPRESSED); out["w4_finish_compress"] = round((time.perf_counter() - t0) * 1e6, 1)
+    torch.cuda.synchronize()
+    t_plan, (planned, rest) = med(lambda: hp.w4_plan_decompress(ms, [1] * len(ms)), n=1)
+    out["w4_plan_decompress"] = t_plan
+    (key, (words, n, jobs)), = planned.items()
+    out["launch_w4_words decompress"], _ = med(lambda: codec.launch_w4_words(words, n, "decompress", torch.bfloat16, dev), n=5)
+    t0 = time.perf_counter(); hp.w4_finish_decompress(jobs, QuantizationStatus.DECOMPRESSED); out["w4_finish_decompress"] = round((time.perf_counter() - t0) * 1e6, 1)
+    torch.cuda.synchronize()
+    out["compress_model (host, until it returns)"], _ = med(lambda: mc.compress_model(model), n=1)
+    out["decompress_model (host, until it returns)"], _ = med(lambda: mc.decompress_model(model), n=1)
+    print(json.dumps(out, indent=1))
