@@ -38,6 +38,17 @@ def _hostpath():
 _DTYPE_OF_CODE = {1: torch.float16, 2: torch.bfloat16}
 
 
+def _launch_chunks(n: int):
+    """[lo, hi) slices of a module list for the batched launches: planning a 154-module table takes the host ~0.17 ms during which the
+    GPU would idle, so a large list goes out as a short first table (the GPU starts after ~40 us) and two longer ones; a small list
+    as one (every extra launch costs the host ~15 us and the device a ramp / tail of ~3 us)"""
+    if n <= 64:
+        return [(0, n)]
+    a = 32
+    b = a + (n - a) // 2
+    return [(0, a), (a, b), (b, n)]
+
+
 def _plain_w4_scheme(scheme):
     """(is a symmetric int4 group / channel scheme without activation arguments, group size or 0 for channel-wise): the schemes whose
     modules the C++ host loop takes (an asymmetric scheme's packed zero points, an activation scheme's extra zero-point names and
@@ -191,10 +202,16 @@ class PackedQuantizationCompressor(BaseCompressor):
                 if g is None:
                     g = seen[id(scheme)] = _plain_w4_scheme(scheme)[1]
                 infos.append(g)
-            planned, modules = hp.w4_plan_compress(modules, infos)
-            for (dev_index, code), (words, n, jobs) in planned.items():
-                codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+            rest, pending = [], []
+            for lo, hi in _launch_chunks(len(modules)):  # the first launch leaves after a fifth of the planning, not after all of it
+                planned, back = hp.w4_plan_compress(modules[lo:hi], infos[lo:hi])
+                rest += back
+                for (dev_index, code), (words, n, jobs) in planned.items():
+                    codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+                    pending.append(jobs)
+            for jobs in pending:  # the parameter dictionaries, under the kernels
                 hp.w4_finish_compress(jobs, QuantizationStatus.COMPRESSED)
+            modules = rest
 
         batches = {}  # (device, dtype) -> (entries, jobs): one table and one launch per GPU and weight dtype
         rest = []
@@ -339,10 +356,16 @@ class PackedQuantizationCompressor(BaseCompressor):
                 if ok is None:
                     ok = seen[id(scheme)] = int(_plain_w4_scheme(scheme)[0])
                 infos.append(ok)
-            planned, modules = hp.w4_plan_decompress(modules, infos)
-            for (dev_index, code), (words, n, jobs) in planned.items():
-                codec.launch_w4_words(words, n, "decompress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+            rest, pending = [], []
+            for lo, hi in _launch_chunks(len(modules)):
+                planned, back = hp.w4_plan_decompress(modules[lo:hi], infos[lo:hi])
+                rest += back
+                for (dev_index, code), (words, n, jobs) in planned.items():
+                    codec.launch_w4_words(words, n, "decompress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+                    pending.append(jobs)
+            for jobs in pending:
                 hp.w4_finish_decompress(jobs, QuantizationStatus.DECOMPRESSED)
+            modules = rest
         names = ("weight_packed", "weight_scale", "weight_shape", "weight_zero_point", "weight_g_idx")
         sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]
         pre = PackedQuantizationCompressor._batch_decompress(sds, [m.quantization_scheme for m in modules])  # (`cls` may be install()'s subclass of the UPSTREAM codec)

@@ -619,6 +619,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     __shared__ __attribute__((aligned(16))) uint8_t s_code[64][128 + 8];  // +8: rows start on different banks
     __shared__ float s_rs[64][16];                 // reciprocal of the (row, group) scale, 0 = the words of that group take the exact path
     __shared__ float s_s16[NEWTON ? 64 : 1][16];   // the fp16 scale itself (Newton step of the fp16 forms)
+    __shared__ uint16_t s_sbits[64][16];           // its fp16 bit pattern: what scale_packed stores (round 4: no second read of the scale matrix)
     const int tiles_c = (int)(k / 256);
     // (Round 4: remapping blockIdx so that each XCD walks a contiguous eighth of the tiles — the 32 tiles of a row block, which share the
     // row block's scale lines, then meet in one L2 instead of eight — measured 36.5 us against 33.6: like the W4 kernels,
@@ -682,6 +683,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         if (tid < n_entries) {
             s_rs[rl_e][gi_e] = rs;
             if (NEWTON) s_s16[rl_e][gi_e] = s16;
+            s_sbits[rl_e][gi_e] = SDT == CT_BF16 ? (uint16_t)f_to_f16_bits(s16) : (uint16_t)sb_e;
         }
     }
     for (int e = tid + kBlock; e < n_entries; e += kBlock) {  // more than 256 (row, group) entries: groups narrower than 64 columns
@@ -693,9 +695,11 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         if (zp != nullptr && zp[si] != 0) rs = 0.0f;
         s_rs[rl][gi] = rs;
         if (NEWTON) s_s16[rl][gi] = s16;
+        s_sbits[rl][gi] = SDT == CT_BF16 ? (uint16_t)f_to_f16_bits(s16) : (uint16_t)sb;
     }
     __syncthreads();
     const int gl = (int)(grp - g_first);
+    const uint32_t g_first_tile = g_first;
     uint32_t redo = 0;  // words the range test rejected
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -727,6 +731,10 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         }
     }
     if (violation || vmax >= 16u * 24u) raise_flag(bad);  // a quad with three or more non-zero codes
+    // the permutation row of the packing phase is requested here — the weight registers are dead (and so is the rare exact path, which
+    // needs the registers itself: requested above it, the row cost the fifth wave per SIMD) — so that its ~1 us (an L2 hit) passes
+    // under the barrier and the metadata store instead of in front of the packing loop, where round 3 fetched it
+    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
     __syncthreads();
     {
         const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
@@ -734,8 +742,6 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         stream_store8(meta + pair_base + chunk * 4, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
     }
     const uint8_t* sc = &s_code[0][0];
-    // (the permutation row is fetched here, not at the top: eight registers less through the front end, 100 -> 95 VGPRs = 5 waves per SIMD)
-    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
     const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
     const int64_t wpr = m * 2;  // packed words per k-tile row (size_n * 16 * 4 / 32)
     // (a thread building FOUR consecutive words of one k-tile — four table rows, one 16-byte streaming store — measured slower:
@@ -764,8 +770,8 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
             const int gi = e >> 6, j = e & 63;
             const int pj = scale_single ? j : ((j & ~7) + (((j & 7) >> 1) | ((j & 1) << 2)));  // scale_perm: [0, 4, 1, 5, 2, 6, 3, 7] per 8
             const int64_t g = g_first + gi;
-            const uint16_t v = scale[((int64_t)tile_r * 64 + pj) * scale_cols + g];
-            scale_packed[g * m + (int64_t)tile_r * 64 + j] = SDT == CT_BF16 ? (uint16_t)f_to_f16_bits(bf16_bits_to_f(v)) : v;
+            // the tile's own LDS copy (a group that starts in this tile is one of the tile's groups): fp16(scale), converted once above
+            scale_packed[g * m + (int64_t)tile_r * 64 + j] = s_sbits[pj][(int)(g - (int64_t)g_first_tile)];
         }
     }
 }
