@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
                                                                     const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
                                                                     unsigned long long* __restrict__ run_out, uint32_t gen, unsigned long long wait_ticks,
                                                                     unsigned long long* __restrict__ stamps, int stagger_lo, int stagger_hi, unsigned stagger_ticks,
-                                                                    unsigned stagger_slope_q8, int round_wgs, unsigned long long* __restrict__ round_words, int late_mask) {
+                                                                    unsigned stagger_slope_q8, int round_wgs, unsigned long long* __restrict__ round_words) {
     constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[WAVES][kSlab];
@@ -1184,11 +1184,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
         uint32_t pk = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // (arithmetic mask, not a select: hipcc turns `live ? flags : 0` into a branch around the flag computation, the wait for the
-            // unit's load lands inside that branch, and every later use of the registers then waits AGAIN — which would make the last
-            // tile's pass 2 wait for the early hand-off loads issued just before it)
-            const uint32_t live = 0u - (uint32_t)(i < tpw && ubase + (uint32_t)(i * kWT + q * 64) < units32);
-            pk |= (nz_mask_unit<ES>(keep[i][q], keepbits) & live) << (8 * q);
+            const bool live = i < tpw && ubase + (uint32_t)(i * kWT + q * 64) < units32;
+            pk |= (live ? nz_mask_unit<ES>(keep[i][q], keepbits) : 0u) << (8 * q);
         }
         s_mask[wave][i][lane] = pk;
         pks[i] = pk;
@@ -1205,15 +1202,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
         op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
         if (stamps && b < kResStampWGs) stamps[b * 4 + 1] = wall_clock64();
     }
-    // ---- a FIRST attempt at the hand-off words is requested here and looked at after the last tile's pass 2: with the staggered start
-    // most of a workgroup's predecessors have published long before, so the ~2.5 us round trip of the poll (gpurun_out/r04b stamps:
-    // published -> resolved 3.3-3.7 us, of which pass 2 of one tile is ~1 us) runs under that pass instead of behind it
-    const int r_idx = (round_wgs > 0 && b >= round_wgs) ? b / round_wgs : 0;
-    const int w_guess = r_idx * round_wgs + tid;  // this lane's word of the first sweep, if the round word is there
-    unsigned long long pre_round = 0, pre_raw = 0;
-    if (r_idx > 0 && tid == 0) pre_round = op_load(round_words + (r_idx - 1));
-    if (w_guess < b) pre_raw = op_load(slots + w_guess);
-    // ---- the last tile's pass 2, while the words travel
+    // ---- the last tile's pass 2, while the word travels.  (Round 4, measured and dropped: requesting the round word and the first sweep
+    // of count words HERE, ahead of this pass, so that the ~2.5 us poll round trip runs under it — with the flags masked branch-free so
+    // that the pass does not wait for those loads — 46.3-47.0 us against 42.2: the early attempt fails more often than the late one, a
+    // failed attempt costs a full extra round trip, and published -> resolved grew from 3.3 to 4.6 us; moving the bitmask stores
+    // behind the hand-off changed nothing, 46.3.)
     pass2(KEEP - 1);
     // ---- rows that start inside one of this wave's tiles: their offset relative to the tile, completed in phase B
 #pragma unroll
@@ -1232,8 +1225,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
             }
         }
     }
-    // ---- the bitmask: output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the packed masks of lanes 4 (L & 15) .. + 3
-    auto store_bitmask = [&]() {
+    // ---- the bitmask leaves while the counts travel: output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the
+    // packed masks of lanes 4 (L & 15) .. + 3
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         const int64_t wt = wt0 + i;
@@ -1266,8 +1259,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
             }
         }
     }
-    };
-    if (!late_mask) store_bitmask();  // EXPERIMENT (round 4): before the hand-off (round 2: "leaves while the counts travel") or after it
     // ---- hand-off: lane t watches the words of workgroups t, t + 512, ...  A word that does not arrive within the time budget is
     // not an error: the workgroup COUNTS that workgroup's share of x itself (self-help; never observed outside the forced test).
     // So nothing here can fail or deadlock, whatever the dispatch order or residency, and no status has to be reported.
@@ -1279,15 +1270,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
         // words of its own round instead of all b.  If the word does not arrive within the budget: all b raw words, as before.
         int w_lo = 0;
         if (round_wgs > 0 && b >= round_wgs) {
-            const int r = r_idx;
+            const int r = b / round_wgs;
             if (tid == 0) {
                 s_part[0] = -1;
-                unsigned long long v = pre_round;  // the early attempt first
                 for (;;) {
+                    const unsigned long long v = op_load(round_words + (r - 1));
                     if ((uint32_t)(v >> 32) == gen) { s_part[0] = (long long)(uint32_t)v; break; }
                     if (wall_clock64() - t0 >= wait_ticks) break;
                     __builtin_amdgcn_s_sleep(4);
-                    v = op_load(round_words + (r - 1));
                 }
             }
             __syncthreads();
@@ -1303,10 +1293,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
             const bool need = w < b;
             bool got = !need;
             uint32_t mine = 0;
-            if (need && w == w_guess && (uint32_t)(pre_raw >> 32) == gen) {  // the early attempt of the first sweep
-                mine = (uint32_t)pre_raw;
-                got = true;
-            }
             if (__builtin_amdgcn_ballot_w64(need) != 0) {  // wave-uniform
                 for (;;) {
                     if (!got) {
@@ -1338,7 +1324,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
     }
     __syncthreads();
     if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 2] = wall_clock64();
-    if (late_mask) store_bitmask();
     if (round_wgs > 0 && tid == 0 && (b + 1) % round_wgs == 0 && b + 1 < (int)gridDim.x) {  // the last workgroup of a residency round
         long long incl = 0;
 #pragma unroll
@@ -1753,8 +1738,7 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                        static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
                        values_capacity * (ES_ / 2), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out,        \
                        tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
-                       round_wgs, round_words, late_mask)
-                static const int late_mask = []() { const char* e = std::getenv("CT_BM_LATE"); return e ? std::atoi(e) : 0; }();  // experiment knob, round 4
+                       round_wgs, round_words)
                 if (es == 4) CT_RESIDENT_W(4, kResWaves);
                 else CT_RESIDENT_W(2, kResWaves);
 #undef CT_RESIDENT_W
