@@ -330,6 +330,10 @@ constexpr int kGidxMaxGroups = 1024;
 // waited for; the R rows' scale entries go to LDS in one pass (one barrier per workgroup); (3) turned out NOT to be the lever: a lane
 // with 4 units / one 16-byte store needs 140 VGPRs and measured 41.5 us, one unit per lane 30.6 (see the constants below).  LDS entry: the reciprocal (compress) or the scale (decompress), with the zero point
 // beside it in one 8-byte entry when the scheme has one — ONE ds_read per element.
+// Round 4, measured and dropped: requesting this thread's scale entry FIRST (inline asm, converted behind vmcnt(<loads issued after it>))
+// and making the group-number / data loads unconditional so that the rows are consumed behind vmcnt(3 .. 0) — what bought marlin-24
+// 10 % — measured 32.8 / 32.5 us here against 31.2 / 31.8: at 8 waves per SIMD the exposed latency was already
+// covered by other waves, and the clamped indices plus the early conversions only added instructions.
 constexpr int kGidxRows = 4;
 // rows per workgroup R and units per lane UL, measured at 8192^2 bf16 on the product's own template (tools/kbench/kbench_prod.hip `gidx`,
 // profiles/r03_kbench_prod.txt, r03_kbench_gidx_small_tables.txt).  With the tables sized for 1024 groups per row LDS capped the
@@ -357,80 +361,48 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
         cu[i] = COMPRESS ? ((int64_t)chunk * kBlock + threadIdx.x) * UL + i : (int64_t)chunk * (UL * kBlock) + (int64_t)i * kBlock + threadIdx.x;
         live[i] = cu[i] < p.upr;
     }
-    // Round 4: load ORDER and unconditional loads.  Vector-memory results return in order and hipcc's wait-count pass only counts loads it can
-    // see in straight-line code.  Round 3 issued the group numbers and the R rows' data first and fetched the scale entries last, behind a
-    // loop: the entries could only be converted behind `s_waitcnt vmcnt(0)` — after EVERY data load had landed — and, the data loads sitting
-    // behind `if (live)` branches, the rows were consumed behind vmcnt(0) as well: the whole latency of a workgroup's loads was exposed, then
-    // the conversions (a reciprocal each), the LDS hand-over and the barrier followed serially (same finding as marlin-24).
-    // Now: 0. this thread's scale (and int8 zero point) entry is requested FIRST (inline asm, so that hipcc cannot sink it to its first
-    // use), 1./2. the group numbers and the data loads follow unconditionally (indices clamped; a dead lane or row loads a valid
-    // address and stores nothing), 3. the entry is converted and handed over behind `vmcnt(<everything issued after it>)`, i.e. under the
-    // data loads, and the rows are consumed behind vmcnt(R-1 .. 0) as they land.
-    const int n_ent = R * (int)p.scale_cols;
-    const int e0 = (int)threadIdx.x < n_ent ? (int)threadIdx.x : n_ent - 1;
-    const int r_e0 = e0 / (int)p.scale_cols, g_e0 = e0 - r_e0 * (int)p.scale_cols;
-    const int64_t row_e0 = row0 + r_e0 < rows ? row0 + r_e0 : rows - 1;
-    const int64_t si_e0 = row_e0 * p.scale_cols + g_e0;
-    uint32_t sb_e0;
-    int32_t zb_e0 = 0;
-    {
-        const uint16_t* sp = static_cast<const uint16_t*>(p.scale) + si_e0;
-        asm volatile("global_load_ushort %0, %1, off" : "=v"(sb_e0) : "v"(sp) : "memory");
-        if constexpr (HAS_ZP) {  // (any other zero-point type: a harmless byte of the scale here, the typed load below)
-            const int8_t* zq = p.zdt == CT_I8 ? static_cast<const int8_t*>(p.zp) + si_e0 : reinterpret_cast<const int8_t*>(sp);
-            asm volatile("global_load_sbyte %0, %1, off" : "=v"(zb_e0) : "v"(zq) : "memory");
-        }
-    }
     // 1. group numbers of this lane's columns (the same for every row)
     u32x4 gv[UL][2];
-    int64_t cuc[UL];  // clamped unit index: dead lanes re-read the row's last unit
 #pragma unroll
     for (int i = 0; i < UL; ++i) {
-        cuc[i] = live[i] ? cu[i] : p.upr - 1;
-        gv[i][0] = reinterpret_cast<const u32x4*>(col_group)[2 * cuc[i]];
-        gv[i][1] = reinterpret_cast<const u32x4*>(col_group)[2 * cuc[i] + 1];
+        if (live[i]) {
+            gv[i][0] = reinterpret_cast<const u32x4*>(col_group)[2 * cu[i]];
+            gv[i][1] = reinterpret_cast<const u32x4*>(col_group)[2 * cu[i] + 1];
+        } else {
+            gv[i][0] = gv[i][1] = u32x4{0, 0, 0, 0};
+        }
     }
     // 2. every row's data loads, before anything is waited for
     u32x4 wv[COMPRESS ? R : 1][COMPRESS ? UL : 1];
     uint32_t pw[COMPRESS ? 1 : R][COMPRESS ? 1 : UL];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;
+        const int64_t row = row0 + r;
 #pragma unroll
         for (int i = 0; i < UL; ++i) {
-            if constexpr (COMPRESS) wv[r][i] = static_cast<const u32x4*>(p.x)[row * p.upr + cuc[i]];
-            else pw[r][i] = static_cast<const uint32_t*>(p.x)[row * p.upr + cuc[i]];
+            if (row < rows && live[i]) {
+                if constexpr (COMPRESS) wv[r][i] = static_cast<const u32x4*>(p.x)[row * p.upr + cu[i]];
+                else pw[r][i] = static_cast<const uint32_t*>(p.x)[row * p.upr + cu[i]];
+            }
         }
     }
-    // 3. the R rows' entries -> LDS: this thread's early entry first, under the data loads
+    // 3. the R rows' entries -> LDS
     bool nz = false;  // some zero point of these rows is not zero
-    auto put_entry = [&](int r, int g, float s, float z) {
-        const float v = COMPRESS ? (DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s)) : s;
-        if constexpr (HAS_ZP) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            nz |= z != 0.0f;
-            *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, z};
-        } else {
-            *reinterpret_cast<float*>(s_tab + r * kRowBytes + g * 4) = v;
-        }
-        if constexpr (COMPRESS) s_slow[r * MAXG + g] = s;
-    };
-    {
-        constexpr int kYounger = 2 * UL + R * UL;  // the loads issued after the early entry: all of them may still be in flight
-        if constexpr (HAS_ZP) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(sb_e0), "+v"(zb_e0) : "n"(kYounger) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sb_e0) : "n"(kYounger) : "memory");
-        const float s = DT == CT_BF16 ? bf16_bits_to_f(sb_e0) : f16_bits_to_f(sb_e0);
-        float z = 0.0f;
-        if constexpr (HAS_ZP) z = p.zdt == CT_I8 ? round_to<DT>((float)zb_e0) : round_to<DT>(load_rt(p.zp, p.zdt, si_e0));
-        if ((int)threadIdx.x < n_ent && row0 + r_e0 < rows) put_entry(r_e0, g_e0, s, z);
-    }
-    for (int e = threadIdx.x + kBlock; e < n_ent; e += kBlock) {  // more than 256 (row, group) entries per workgroup: rows of more than 64 groups
+    for (int e = threadIdx.x; e < R * (int)p.scale_cols; e += kBlock) {
         const int r = e / (int)p.scale_cols, g = e - r * (int)p.scale_cols;
         if (row0 + r < rows) {
             const int64_t si = (row0 + r) * p.scale_cols + g;
-            float z = 0.0f;
-            if constexpr (HAS_ZP) z = round_to<DT>(load_rt(p.zp, p.zdt, si));
-            put_entry(r, g, load_as_f<DT>(p.scale, si), z);
+            const float s = load_as_f<DT>(p.scale, si);
+            const float v = COMPRESS ? (DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s)) : s;
+            if constexpr (HAS_ZP) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const float z = round_to<DT>(load_rt(p.zp, p.zdt, si));
+                nz |= z != 0.0f;
+                *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, z};
+            } else {
+                *reinterpret_cast<float*>(s_tab + r * kRowBytes + g * 4) = v;
+            }
+            if constexpr (COMPRESS) s_slow[r * MAXG + g] = s;
         }
     }
     // LDS byte offsets of the groups, two per register
