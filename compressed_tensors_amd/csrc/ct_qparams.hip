@@ -86,16 +86,19 @@ template <int XDT, int U>
 __global__ __launch_bounds__(kBlock) void qparams_absmax_kernel(const u32x4* __restrict__ x, int64_t units, int upg, int bits, void* __restrict__ scale_out,
                                                                 int8_t* __restrict__ zp_out, int kind, const float* __restrict__ gscale) {
     const int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x;
+    // (round 4: unconditional loads — the index clamped, a unit beyond the tensor masked out of the maximum — so that hipcc's wait-count pass
+    // can count them: behind `u < units ? x[u] : 0` every load sat in a branch and the first reduction waited for all U of them, vmcnt(0))
     u32x4 r[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int64_t u = base + (int64_t)i * kBlock;
-        r[i] = u < units ? x[u] : u32x4{0u, 0u, 0u, 0u};
+        r[i] = x[u < units ? u : units - 1];
     }
     uint32_t acc[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
-        acc[i] = absmax_acc(absmax_acc(absmax_acc(absmax_acc(0u, r[i].x), r[i].y), r[i].z), r[i].w);
+        const uint32_t live = 0u - (uint32_t)(base + (int64_t)i * kBlock < units);
+        acc[i] = absmax_acc(absmax_acc(absmax_acc(absmax_acc(0u, r[i].x), r[i].y), r[i].z), r[i].w) & live;
         acc[i] = absmax_group_reduce(acc[i], upg);
     }
     // Round 3: the scale arithmetic (IEEE divides, the zero-point rounding: ~80 vector instructions) used to run once per load, with
