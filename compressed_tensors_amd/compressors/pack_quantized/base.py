@@ -194,17 +194,10 @@ class PackedQuantizationCompressor(BaseCompressor):
             # the plain case — symmetric int4, parameters only, nn.Module's own attribute hooks — in C++: table rows, output allocations
             # and, after the launch, the parameter dictionaries; whatever it does not take comes back in `modules`
             modules = list(modules)
-            seen = {}
-            infos = []
-            for m in modules:
-                scheme = m.quantization_scheme
-                g = seen.get(id(scheme))
-                if g is None:
-                    g = seen[id(scheme)] = _plain_w4_scheme(scheme)[1]
-                infos.append(g)
+            info = lambda scheme: _plain_w4_scheme(scheme)[1]  # asked once per distinct scheme object and chunk
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):  # the first launch leaves after a fifth of the planning, not after all of it
-                planned, back = hp.w4_plan_compress(modules[lo:hi], infos[lo:hi])
+                planned, back = hp.w4_plan_compress(modules[lo:hi], info)
                 rest += back
                 for (dev_index, code), (words, n, jobs) in planned.items():
                     codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
@@ -348,17 +341,10 @@ class PackedQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         hp = _hostpath()
         if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
-            seen = {}
-            infos = []
-            for m in modules:
-                scheme = m.quantization_scheme
-                ok = seen.get(id(scheme))
-                if ok is None:
-                    ok = seen[id(scheme)] = int(_plain_w4_scheme(scheme)[0])
-                infos.append(ok)
+            info = lambda scheme: int(_plain_w4_scheme(scheme)[0])
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):
-                planned, back = hp.w4_plan_decompress(modules[lo:hi], infos[lo:hi])
+                planned, back = hp.w4_plan_decompress(modules[lo:hi], info)
                 rest += back
                 for (dev_index, code), (words, n, jobs) in planned.items():
                     codec.launch_w4_words(words, n, "decompress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))

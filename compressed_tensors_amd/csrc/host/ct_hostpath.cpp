@@ -65,6 +65,56 @@ bool plain_type(PyObject* module) {
     return plain;
 }
 
+// an attribute the way `getattr(obj, name, None)` finds it for names that live in the instance dictionary or on the class, WITHOUT falling into
+// nn.Module.__getattr__ on a miss (a Python-level search of _parameters / _buffers / _modules that then raises: ~2 us for every container
+// module of a model walk).  New reference or nullptr.
+PyObject* lookup_plain(PyObject* obj, PyObject* name) {
+    PyObject** dictptr = _PyObject_GetDictPtr(obj);
+    if (dictptr && *dictptr) {
+        PyObject* v = PyDict_GetItem(*dictptr, name);  // borrowed
+        if (v) {
+            Py_INCREF(v);
+            return v;
+        }
+    }
+    PyObject* t = _PyType_Lookup(Py_TYPE(obj), name);  // borrowed; a plain class attribute or a descriptor
+    if (!t) return nullptr;
+    descrgetfunc get = Py_TYPE(t)->tp_descr_get;
+    if (get) {
+        PyObject* v = get(t, obj, reinterpret_cast<PyObject*>(Py_TYPE(obj)));
+        if (!v) PyErr_Clear();
+        return v;
+    }
+    Py_INCREF(t);
+    return t;
+}
+
+// infos: a list with one integer per module, or a callable scheme -> integer that is asked once per distinct scheme object
+struct Infos {
+    PyObject* src;
+    bool callable;
+    PyObject* scheme_name = PyUnicode_InternFromString("quantization_scheme");
+    std::unordered_map<PyObject*, int64_t> cache;
+    explicit Infos(PyObject* s) : src(s), callable(!PyList_Check(s)) {}
+    int64_t of(PyObject* module, Py_ssize_t i) {
+        if (!callable) return PyLong_AsLongLong(PyList_GET_ITEM(src, i));
+        PyObject* scheme = lookup_plain(module, scheme_name);
+        if (!scheme) return -1;
+        auto it = cache.find(scheme);
+        int64_t v;
+        if (it != cache.end()) v = it->second;
+        else {
+            PyObject* r = PyObject_CallFunctionObjArgs(src, scheme, nullptr);
+            if (!r) throw py::error_already_set();
+            v = PyLong_AsLongLong(r);
+            Py_DECREF(r);
+            cache.emplace(scheme, v);  // (the module keeps the scheme alive for the duration of the call)
+        }
+        Py_DECREF(scheme);
+        return v;
+    }
+};
+
 struct Entries {
     PyObject* params = nullptr;   // new references
     PyObject* buffers = nullptr;
@@ -139,13 +189,14 @@ py::dict batches_to_python(std::map<std::pair<int, int>, Batch>& batches) {
 }
 
 // infos[i]: group size of module i's scheme (0 = channel-wise), or < 0 when the scheme is not a symmetric int4 group / channel scheme
-py::tuple w4_plan_compress(py::list modules, py::list infos) {
+py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
     std::map<std::pair<int, int>, Batch> batches;  // (device index, dtype code 1 = fp16 / 2 = bf16) -> table
     py::list rest;
+    Infos infos(infos_arg.ptr());
     const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
-        const int64_t ginfo = PyLong_AsLongLong(PyList_GET_ITEM(infos.ptr(), i));
+        const int64_t ginfo = infos.of(m, i);
         Entries e;
         bool ok = ginfo >= 0 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
         const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
@@ -207,13 +258,14 @@ void w4_finish_compress(py::list jobs, py::object status) {
 }
 
 // infos[i]: 1 when module i's scheme is a symmetric int4 scheme (the strategy is inferred from the scale's shape, as `dequantize` does), else 0
-py::tuple w4_plan_decompress(py::list modules, py::list infos) {
+py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
     std::map<std::pair<int, int>, Batch> batches;
     py::list rest;
+    Infos infos(infos_arg.ptr());
     const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
-        const bool scheme_ok = PyLong_AsLongLong(PyList_GET_ITEM(infos.ptr(), i)) == 1;
+        const bool scheme_ok = infos.of(m, i) == 1;
         Entries e;
         bool ok = scheme_ok && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
         const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr;
@@ -280,10 +332,8 @@ struct Walker {
 
     void visit(PyObject* module) {
         if (!seen.insert(module).second) return;
-        PyObject* scheme = PyObject_GetAttr(module, scheme_name);
-        if (!scheme) {
-            PyErr_Clear();
-        } else {
+        PyObject* scheme = lookup_plain(module, scheme_name);
+        if (scheme) {
             bool quantized = false;
             if (scheme != Py_None) {
                 for (PyObject* a : arg_names) {
@@ -299,11 +349,8 @@ struct Walker {
             Py_DECREF(scheme);
             if (quantized) out.append(py::reinterpret_borrow<py::object>(module));
         }
-        PyObject* children = PyObject_GetAttr(module, modules_name);
-        if (!children) {
-            PyErr_Clear();
-            return;
-        }
+        PyObject* children = lookup_plain(module, modules_name);
+        if (!children) return;
         if (PyDict_Check(children)) {
             PyObject *key, *value;
             Py_ssize_t pos = 0;
