@@ -25,10 +25,11 @@ namespace py = pybind11;
 
 namespace {
 
-py::object g_make_subclass;   // torch.Tensor._make_subclass
-py::object g_parameter_cls;   // torch.nn.Parameter
-py::object g_module_setattr;  // torch.nn.Module.__setattr__
-py::object g_module_delattr;  // torch.nn.Module.__delattr__
+// (raw pointers, referenced once at import and never released: a py::object at namespace scope would be destroyed after the interpreter)
+PyObject* g_make_subclass = nullptr;   // torch.Tensor._make_subclass
+PyObject* g_parameter_cls = nullptr;   // torch.nn.Parameter
+PyObject* g_module_setattr = nullptr;  // torch.nn.Module.__setattr__
+PyObject* g_module_delattr = nullptr;  // torch.nn.Module.__delattr__
 std::unordered_map<PyTypeObject*, bool> g_plain_type;
 bool g_allow_cpu = false;  // tests only (tests/test_host_logic.py): run the host logic on CPU tensors, with the launch stubbed out
 
@@ -57,7 +58,7 @@ bool plain_type(PyObject* module) {
     if (it != g_plain_type.end()) return it->second;
     PyObject* s = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.setattr);
     PyObject* d = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.delattr);
-    const bool plain = s && d && s == g_module_setattr.ptr() && d == g_module_delattr.ptr();
+    const bool plain = s && d && s == g_module_setattr && d == g_module_delattr;
     Py_XDECREF(s);
     Py_XDECREF(d);
     PyErr_Clear();
@@ -157,8 +158,15 @@ bool staying_entries_are_final(const Entries& e, std::initializer_list<PyObject*
     return true;
 }
 
-py::object make_parameter(const at::Tensor& t) {
-    return g_make_subclass(g_parameter_cls, py::reinterpret_steal<py::object>(THPVariable_Wrap(t)), false);
+py::object make_parameter(const at::Tensor& t) {  // == torch.nn.Parameter(t, requires_grad=False) for a plain tensor
+    py::object wrapped = py::reinterpret_steal<py::object>(THPVariable_Wrap(t));
+    PyObject* r = PyObject_CallFunctionObjArgs(g_make_subclass, g_parameter_cls, wrapped.ptr(), Py_False, nullptr);
+    if (!r) throw py::error_already_set();
+    return py::reinterpret_steal<py::object>(r);
+}
+
+void drop(PyObject* dict, PyObject* name) {  // del dict[name] if present
+    if (PyDict_GetItem(dict, name) && PyDict_DelItem(dict, name) != 0) PyErr_Clear();
 }
 
 void set_status(PyObject* module, PyObject* status) {
@@ -246,8 +254,8 @@ void w4_finish_compress(py::list jobs, py::object status) {
         const int64_t rows = PyLong_AsLongLong(PyTuple_GET_ITEM(job, 2)), cols = PyLong_AsLongLong(PyTuple_GET_ITEM(job, 3));
         Entries e;
         if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
-        PyDict_DelItem(e.params, N.weight);
-        if (PyDict_GetItem(e.params, N.weight_zero_point)) PyDict_DelItem(e.params, N.weight_zero_point);
+        drop(e.params, N.weight);
+        drop(e.params, N.weight_zero_point);
         at::Tensor shape = at::empty({2}, at::TensorOptions().dtype(at::kLong));  // int64, CPU: as upstream (pack_quantized/base.py:105)
         shape.data_ptr<int64_t>()[0] = rows;
         shape.data_ptr<int64_t>()[1] = cols;
@@ -313,7 +321,7 @@ void w4_finish_decompress(py::list jobs, py::object status) {
         const at::Tensor& out = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));
         Entries e;
         if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
-        PyDict_DelItem(e.params, N.weight_packed);
+        drop(e.params, N.weight_packed);
         PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
         set_status(m, status.ptr());
     }
@@ -372,10 +380,10 @@ py::list quantized_modules(py::object model) {
 PYBIND11_MODULE(_hostpath, mod) {
     N.init();
     py::module_ torch_mod = py::module_::import("torch");
-    g_make_subclass = torch_mod.attr("Tensor").attr("_make_subclass");
-    g_parameter_cls = torch_mod.attr("nn").attr("Parameter");
-    g_module_setattr = torch_mod.attr("nn").attr("Module").attr("__setattr__");
-    g_module_delattr = torch_mod.attr("nn").attr("Module").attr("__delattr__");
+    g_make_subclass = py::object(torch_mod.attr("Tensor").attr("_make_subclass")).release().ptr();
+    g_parameter_cls = py::object(torch_mod.attr("nn").attr("Parameter")).release().ptr();
+    g_module_setattr = py::object(torch_mod.attr("nn").attr("Module").attr("__setattr__")).release().ptr();
+    g_module_delattr = py::object(torch_mod.attr("nn").attr("Module").attr("__delattr__")).release().ptr();
     mod.def("w4_plan_compress", &w4_plan_compress);
     mod.def("w4_finish_compress", &w4_finish_compress);
     mod.def("w4_plan_decompress", &w4_plan_decompress);
