@@ -58,11 +58,22 @@ def convert_file(inverse_weight_map, save_path, converter: Converter):
     return _write_file(_process_file(inverse_weight_map, converter), save_path)
 
 
-def _process_file(inverse_weight_map, converter: Converter):
+def _process_file(inverse_weight_map, converter: Converter, stream_results: bool = False):
+    """`stream_results` (the pipelined `convert_files` only): the converter may hand its tensors over while their D2H copies are still in
+    flight — CompressedTensorsDequantizer then returns a ReadyDict whose events `write_safetensors` waits on tensor by tensor"""
+    from .converters import streaming_results
+
+    def run():
+        tensors = load_tensors_from_inverse_weight_map(inverse_weight_map)
+        if stream_results:
+            with streaming_results():
+                return converter.process(tensors)
+        return converter.process(tensors)
+
     if torch.cuda.is_available():
         with torch.cuda.stream(torch.cuda.Stream()):  # this thread's own stream
-            return converter.process(load_tensors_from_inverse_weight_map(inverse_weight_map))
-    return converter.process(load_tensors_from_inverse_weight_map(inverse_weight_map))
+            return run()
+    return run()
 
 
 def _write_file(tensors, save_path):
@@ -94,7 +105,7 @@ def convert_files(items, converter: Converter, max_workers: int = 1):
         def start(inv, path):
             slots.acquire()
             try:
-                tensors = _process_file(inv, converter)
+                tensors = _process_file(inv, converter, stream_results=True)
             except BaseException:
                 slots.release()
                 raise

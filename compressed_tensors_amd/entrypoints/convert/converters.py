@@ -5,7 +5,9 @@ MI355X design of `CompressedTensorsDequantizer.process`: the compressed tensors 
 of a shard are moved to the GPU, decompressed by ONE batched launch per scheme where the codec allows it
 (`BaseCompressor.decompress_many`, W4A16 -> `ct_unpack_dequant_batch`), cast, and copied back into pinned
 host buffers on the caller's stream; nothing is decompressed on the CPU."""
+import contextlib
 import re
+import threading
 from collections import defaultdict
 from typing import Dict, Iterable, List, Optional, Set
 
@@ -104,6 +106,43 @@ def _args_from_dict(d: Optional[dict]) -> Optional[QuantizationArgs]:
 
 
 _H2D_ALIGN = 256
+_READY_BYTES = 32 << 20  # one event per ~32 MB of D2H copies
+
+
+_STREAMING = threading.local()
+
+
+@contextlib.contextmanager
+def streaming_results():
+    """inside this context (per thread) a converter that supports it hands its tensors over while their D2H copies are still in flight"""
+    prev = getattr(_STREAMING, "on", False)
+    _STREAMING.on = True
+    try:
+        yield
+    finally:
+        _STREAMING.on = prev
+
+
+class ReadyDict(dict):
+    """a shard's converted tensors: host tensors whose device-to-host copies may still be in flight.  `ready[name]` is the event
+    recorded behind the copy of `name` (absent: the tensor is complete); `keep` holds what must stay alive until then.  Consumers
+    that do not know about it call `wait()` first."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.ready = {}
+        self.keep = []
+
+    def wait(self, name=None) -> None:
+        if name is not None:
+            ev = self.ready.pop(name, None)
+            if ev is not None:
+                ev.synchronize()
+            return
+        for ev in set(self.ready.values()):
+            ev.synchronize()
+        self.ready.clear()
+        self.keep.clear()
 
 
 def _stage_to_device(state_dicts, dev, host_only=()):
@@ -140,6 +179,10 @@ class CompressedTensorsDequantizer(Converter):
 
     def __init__(self, model_dir, ignore: Iterable[str] = (), dtype=torch.bfloat16, device=None):
         self.dtype = dtype
+        # `process` may return while the D2H copies are still in flight (a ReadyDict whose events the writer waits on tensor by tensor):
+        # per thread inside `with streaming_results():` (what convert_files' pipelined shard threads use), or for every call of this
+        # converter with `stream_results = True`; off, `process` synchronises before it returns, as every other caller expects
+        self.stream_results = False
         self.device = torch.device(device) if device is not None else None
         files = get_checkpoint_files(model_dir)
         cfg_path = files.get(CONFIG_NAME) or files.get("params.json")
@@ -167,8 +210,9 @@ class CompressedTensorsDequantizer(Converter):
         from ... import _lib
 
         dev = self.device or _lib.require_device()
-        out: Dict[str, torch.Tensor] = {}
-        keep = []  # the pinned H2D staging buffers, alive until the stream has been synchronised below
+        out = ReadyDict()
+        ready = out.ready  # tensor name -> the event behind its D2H copy (empty once everything has landed)
+        keep = out.keep    # the pinned H2D staging buffers, alive until the stream has been synchronised / the shard has been written
         for scheme in self.schemes:
             comp = self._compressor(scheme)
             names = comp.compression_param_names(scheme)
@@ -185,14 +229,35 @@ class CompressedTensorsDequantizer(Converter):
             # ONE pinned staging buffer per scheme and shard (a pinned allocation per tensor costs more than its copy)
             sizes = [(w.numel() * w.element_size() + 63) // 64 * 64 for w in weights]
             stage = torch.empty(sum(sizes), dtype=torch.uint8, pin_memory=True)
-            off = 0
-            for module_name, w, n in zip(modules, weights, sizes):
-                host = stage[off:off + w.numel() * w.element_size()].view(w.dtype).view(w.shape)
-                host.copy_(w, non_blocking=True)
-                out[f"{module_name}.weight"] = host
+            # the D2H copies leave in the order the writer stores the tensors (sorted names) and an event follows every ~32 MB of them:
+            # `write_safetensors` waits for a tensor's event, not for the whole shard, so the copies run under the file write (round 4)
+            order = sorted(range(len(modules)), key=lambda i: modules[i])
+            offs, off = [0] * len(modules), 0
+            for i, n in enumerate(sizes):
+                offs[i] = off
                 off += n
-        torch.cuda.current_stream(dev).synchronize()
-        del keep
+            pending, since = [], 0
+            for i in order:
+                w = weights[i]
+                host = stage[offs[i]:offs[i] + w.numel() * w.element_size()].view(w.dtype).view(w.shape)
+                host.copy_(w, non_blocking=True)
+                name = f"{modules[i]}.weight"
+                out[name] = host
+                pending.append(name)
+                since += sizes[i]
+                if since >= _READY_BYTES:
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    ready.update(dict.fromkeys(pending, ev))
+                    pending, since = [], 0
+            if pending:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                ready.update(dict.fromkeys(pending, ev))
+        if not (self.stream_results or getattr(_STREAMING, "on", False)):
+            torch.cuda.current_stream(dev).synchronize()
+            ready.clear()
+            del keep
         # remaining (ignored / untargeted) tensors pass through, KV-cache qparams are dropped
         for name, t in tensors.items():
             if name.endswith(KV_CACHE_PARAM_NAMES):

@@ -182,9 +182,15 @@ def write_safetensors(tensors: Dict[str, torch.Tensor], path) -> None:
         off += n
     blob = json.dumps(header, separators=(",", ":")).encode()
     blob += b" " * ((8 - len(blob) % 8) % 8)
+    wait = getattr(tensors, "wait", None)  # converters.ReadyDict: a tensor's D2H copy may still be in flight — wait for ITS event only
+    names = sorted(tensors)
     with open(path, "wb") as f:
         f.write(len(blob).to_bytes(8, "little"))
         f.write(blob)
-        for t in views:
+        for name, t in zip(names, views):
+            if wait is not None:
+                wait(name)
             if t.numel():
                 f.write(memoryview(host_bytes(t)))
+    if wait is not None:
+        wait()
