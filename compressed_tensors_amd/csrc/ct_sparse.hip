@@ -1676,10 +1676,7 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
             cus = c;
         }
         // wave-tiles per wave: as many as the registers hold, fewer when the tensor would otherwise leave CUs without a workgroup
-        // (two 8-wave workgroups fit a CU; 4-wave workgroups, four per CU, measured the same: 41.8-43.3 us against 42.0-42.3).
-        // Tapering — the last one / two / three residency rounds made of HALF-size workgroups, so that the launch's tail is as long as a
-        // short workgroup's lifetime — measured 46.7 / 50.8 / 54.5 us against 42.5: every additional round of workgroups costs ~4 us of
-        // fixed latency (start, table build, barrier, hand-off hop) whatever its size; fewer and bigger rounds, not smaller last ones.
+        // (two 8-wave workgroups fit a CU; 4-wave workgroups, four per CU, measured the same: 41.8-43.3 us against 42.0-42.3)
         constexpr int wgs_per_cu = 2;
         int64_t tpw = cdiv64(wts, (int64_t)cus * wgs_per_cu * kResWaves);
         if (tpw > kResKeep) tpw = kResKeep;
