@@ -379,3 +379,58 @@ def test_write_safetensors_reads_back_with_the_safetensors_library(tmp_path):
     assert np.array_equal(dst[0], src) and np.array_equal(dst[1], tensors["f.u8"].numpy())
     with pytest.raises(ValueError):
         parallel_copy([(np.zeros(3, dtype=np.uint8), np.zeros(4, dtype=np.uint8))])
+
+
+def test_convert_files_pipeline_order_errors_and_bound(tmp_path):
+    """`convert_files` (the two-stage pipeline behind convert_checkpoint): results come back in input order, a failing shard's exception
+    reaches the caller, and never more than 2 x max_workers converted shards exist at once — with a stand-in converter, no GPU"""
+    import threading
+    import time
+
+    import importlib
+
+    cc = importlib.import_module("compressed_tensors_amd.entrypoints.convert.convert_checkpoint")  # the package re-exports the function under this name
+
+    alive, peak, lock = [0], [0], threading.Lock()
+
+    class Slow:
+        def process(self, tensors):
+            with lock:
+                alive[0] += 1
+                peak[0] = max(peak[0], alive[0])
+            time.sleep(0.01)
+            return {k + ".out": v.clone() for k, v in tensors.items()}
+
+    files = []
+    for i in range(9):
+        fn = tmp_path / f"in{i}.safetensors"
+        save_file({f"t{i}": torch.full((4,), float(i))}, str(fn))
+        files.append(({str(fn): None}, tmp_path / "out" / f"o{i}.safetensors"))
+    orig = cc._write_file
+
+    def slow_write(tensors, path):
+        time.sleep(0.03)
+        try:
+            return orig(tensors, path)
+        finally:
+            with lock:
+                alive[0] -= 1
+
+    cc._write_file = slow_write
+    try:
+        res = cc.convert_files(files, Slow(), max_workers=2)
+    finally:
+        cc._write_file = orig
+    assert [list(m) for _, m in res] == [[f"t{i}.out"] for i in range(9)] and all(t == 16 for t, _ in res)
+    assert peak[0] <= 4, peak[0]
+    for i in range(9):
+        assert torch.equal(load_file(str(tmp_path / "out" / f"o{i}.safetensors"))[f"t{i}.out"], torch.full((4,), float(i)))
+
+    class Boom(Slow):
+        def process(self, tensors):
+            if "t3" in tensors:
+                raise RuntimeError("shard 3 is broken")
+            return super().process(tensors)
+
+    with pytest.raises(RuntimeError, match="shard 3 is broken"):
+        cc.convert_files(files, Boom(), max_workers=3)
