@@ -253,6 +253,26 @@ def mailbox(device_index: int) -> Mailbox:
     return mb
 
 
+_HOSTPATH = []  # [module or None], resolved on first use
+
+
+def hostpath():
+    """the C++ host extension (csrc/host/ct_hostpath.cpp, built by __graft_entry__.build()) with the C-ABI entries it launches bound
+    by address, or None when it has not been built — every caller keeps a Python path that does the same work more slowly"""
+    if not _HOSTPATH:
+        try:
+            from . import _hostpath as hp
+        except ImportError:
+            hp = None
+        if hp is not None:
+            lib = load()
+            hp.bind_abi({name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+                         for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
+                                      "ct_marlin24_compress_w4_full")})
+        _HOSTPATH.append(hp)
+    return _HOSTPATH[0]
+
+
 def stream_wait(stream) -> None:
     """block until everything queued on `stream` (a StreamHandle) has completed: a spin on hipStreamQuery, no copy, no event"""
     check(load().ct_stream_wait(stream))

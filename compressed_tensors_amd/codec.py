@@ -821,6 +821,18 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
     count / scan / host read / scatter form that sizes `values` exactly before writing it."""
     if tensor.ndim < 1:
         raise ValueError("bitmask compression expects at least a 1-D tensor")
+    if not two_pass and tensor.is_cuda and tensor.device.index == torch.cuda.current_device():
+        # the same steps without the interpreter (csrc/host/ct_hostpath.cpp:bitmask_compress): this call cannot overlap its own
+        # kernel — it returns nnz — so every microsecond of host work around the launch is a microsecond of the call
+        hp = _lib.hostpath()
+        if hp is not None:
+            x = _bits_view(tensor)
+            s = stream_of(x)
+            mb = _lib.mailbox(s.device_index)
+            r = hp.bitmask_compress(x, _elem_code(x), mb.host, mb.dev, s)
+            if r is not None:
+                _lib.check(r[0])
+                return (r[1] if x is tensor else r[1].view(tensor.dtype)), r[2], r[3]
     dev = _compute_device(tensor)
     x = _dev(_bits_view(tensor), dev)
     dt = _elem_code(x)

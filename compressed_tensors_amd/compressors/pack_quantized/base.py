@@ -10,7 +10,7 @@ import math
 
 import torch
 
-from ... import codec
+from ... import _lib, codec
 from ...config import CompressionFormat
 from ...quantization.quant_args import enum_value
 from ...utils import getattr_chain
@@ -20,19 +20,10 @@ __all__ = ["PackedQuantizationCompressor"]
 
 PACK_ZP_STRATS = ("group", "channel")
 
-_HOSTPATH = []  # [module or None], resolved on first use
-
-
 def _hostpath():
-    """the C++ host loop of the batched module paths (csrc/host/ct_hostpath.cpp, built by __graft_entry__.build()), or None when it
-    has not been built: the Python loop below does the same work, four times slower per module"""
-    if not _HOSTPATH:
-        try:
-            from ... import _hostpath as hp
-        except ImportError:
-            hp = None
-        _HOSTPATH.append(hp)
-    return _HOSTPATH[0]
+    """the C++ host loop of the batched module paths (`_lib.hostpath`), or None when it has not been built: the Python loop below does
+    the same work, four times slower per module"""
+    return _lib.hostpath()
 
 
 _DTYPE_OF_CODE = {1: torch.float16, 2: torch.bfloat16}

@@ -99,6 +99,7 @@ def _ring(device) -> _FlagRing:
 @BaseCompressor.register(name=CompressionFormat.marlin_24.value)
 class Marlin24Compressor(BaseCompressor):
     COMPRESSION_PARAM_NAMES = ("weight_packed", "scale_packed", "meta")
+    batch_is_atomic = True  # compress_modules validates every module before it replaces any: a caller must not split a batch
 
     @classmethod
     @contextlib.contextmanager
@@ -210,6 +211,18 @@ class Marlin24Compressor(BaseCompressor):
                 else:  # the call itself raises (upstream's behaviour): the verdict lands in the thread's pinned mailbox word
                     stream = _lib.stream_of_device(weight.device)
                     mb = _lib.mailbox(stream.device_index)
+                    hp = _lib.hostpath() if stream.device_index == torch.cuda.current_device() else None
+                    if hp is not None:  # allocate / launch / spin / read the verdict without the interpreter (ct_hostpath.cpp:marlin24_w4_full)
+                        status, violated, packed, meta, scale_packed = hp.marlin24_w4_full(
+                            weight, codec.DT[weight.dtype], scale2d, codec.DT[scale2d.dtype], zero_point, -1 if zero_point is None else codec.DT[zero_point.dtype],
+                            weight.shape[1] if not g or g > weight.shape[1] else int(g), is_group, mb.host + 8, mb.dev + 8, stream)
+                        _lib.check(status)
+                        if violated:
+                            raise ValueError(_STRUCTURE_ERROR)
+                        state_dict["weight_packed"] = packed
+                        state_dict["scale_packed"] = scale_packed
+                        state_dict["meta"] = meta
+                        return state_dict
                     mb.words[1] = 0
                     flag_ptr = mb.dev + 8
                 packed, meta, scale_packed, _ = codec.marlin24_compress_w4_full(weight, scale2d, zero_point, group_size=g, group_perm=is_group,

@@ -9,6 +9,10 @@
 // dictionaries under the running kernel, exactly as compressed_tensors_amd/utils/module.py:swap_direct_entries does
 // (reference: compressors/base.py:95-131, utils/module.py:33-65, compressors/pack_quantized/base.py:62-163).
 //
+// Also here (second half of the file): the host side of the two plug-in calls that wait for the device before they return — the
+// sparse-bitmask compress and the default mode of the marlin-24 compress — where the interpreter's 15-20 us sat in series with a
+// 30-42 us kernel.
+//
 // A module that is anything but the plain case (a buffer among its entries, a trainable parameter that stays, a class with its own
 // __setattr__, an asymmetric scheme, activation ordering, an unusual layout) is handed back untouched in `rest`; the Python path,
 // which covers every case, takes it.  The Python path is also what runs when this extension has not been built.
@@ -17,6 +21,8 @@
 
 #include <cstdint>
 #include <map>
+#include <stdexcept>
+#include <string>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -330,15 +336,22 @@ void w4_finish_decompress(py::list jobs, py::object status) {
 // the quantized modules of a model in `named_modules(remove_duplicate=True)` order (pre-order over `_modules`, every module once):
 // model_compressor.py:152-164,191-195 with is_module_quantized (quantization/utils/helpers.py:229-250: a scheme with at least one of
 // weights / input_activations / output_activations).  300 modules cost the interpreter 0.3 ms per walk; here ~30 us.
-struct Walker {
+// named_modules(remove_duplicate=True) order (pre-order, children in `_modules` order, a module reached twice is visited once), resumable: `take(n)`
+// returns the next n quantized modules and keeps its place, so that a caller can launch the first table of a large model after walking
+// only that table's modules and walk the rest under the running kernel.  The tree must not gain or lose modules between two takes (the
+// codecs only rewrite `_parameters`).
+struct ModuleWalk {
     PyObject* modules_name = PyUnicode_InternFromString("_modules");
     PyObject* scheme_name = PyUnicode_InternFromString("quantization_scheme");
     PyObject* arg_names[3] = {PyUnicode_InternFromString("weights"), PyUnicode_InternFromString("input_activations"),
                               PyUnicode_InternFromString("output_activations")};
     std::unordered_set<PyObject*> seen;
-    py::list out;
+    std::vector<std::pair<py::object, Py_ssize_t>> stack;  // (a module's `_modules` dictionary, position of its iteration)
+    py::object root;  // until the first take
 
-    void visit(PyObject* module) {
+    explicit ModuleWalk(py::object model) : root(std::move(model)) {}
+
+    void enter(PyObject* module, py::list& out) {
         if (!seen.insert(module).second) return;
         PyObject* scheme = lookup_plain(module, scheme_name);
         if (scheme) {
@@ -359,21 +372,130 @@ struct Walker {
         }
         PyObject* children = lookup_plain(module, modules_name);
         if (!children) return;
-        if (PyDict_Check(children)) {
-            PyObject *key, *value;
-            Py_ssize_t pos = 0;
-            while (PyDict_Next(children, &pos, &key, &value))
-                if (value != Py_None) visit(value);
-        }
-        Py_DECREF(children);
+        if (PyDict_Check(children) && PyDict_Size(children) > 0) stack.emplace_back(py::reinterpret_steal<py::object>(children), 0);
+        else Py_DECREF(children);
     }
+
+    // the next `n` quantized modules (all that are left when n < 0)
+    py::list take(Py_ssize_t n) {
+        py::list out;
+        if (root) {
+            py::object r = std::move(root);
+            root = py::object();
+            enter(r.ptr(), out);
+        }
+        while (!stack.empty() && (n < 0 || PyList_GET_SIZE(out.ptr()) < n)) {
+            PyObject *key, *value;
+            const size_t top = stack.size() - 1;
+            if (PyDict_Next(stack[top].first.ptr(), &stack[top].second, &key, &value)) {
+                if (value != Py_None) enter(value, out);  // may push: `stack[top]` is not touched after this
+            } else {
+                stack.pop_back();
+            }
+        }
+        return out;
+    }
+
+    bool done() const { return !root && stack.empty(); }
 };
 
-py::list quantized_modules(py::object model) {
-    Walker w;
-    w.visit(model.ptr());
-    return w.out;
+py::list quantized_modules(py::object model) { return ModuleWalk(std::move(model)).take(-1); }
+
+// ------------------------------------------------------------------------------------------
+// The two plug-in calls that WAIT for the device before they return (include/ct_hip.h "Host mailbox"): the sparse-bitmask
+// compress (nnz sizes `values`) and the default mode of the marlin-24 compress (the 2:4 verdict raises from the call).  Their
+// kernels run 30-42 us at 8192^2; the interpreter's share of one call — four torch.empty, a twelve-argument ctypes call, the
+// mailbox wait, the slice — was 15-20 us in FRONT of and behind that, serial with it by construction.  Here the same steps
+// (allocate with ATen, launch through the C ABI, spin on the mailbox / the stream, narrow) run without the interpreter.  The C-ABI
+// entries are reached through their addresses (bind_abi: taken from the ctypes handle of libct_hip.so, so this extension links
+// nothing of HIP); a non-zero status is handed back for _lib.check to raise (ct_last_error is thread-local: same thread).
+// ------------------------------------------------------------------------------------------
+using bitmask_compress_fn = int (*)(const void*, int, int64_t, int64_t, void*, int64_t, uint8_t*, int64_t*, int64_t*, void*, int64_t, void*);
+using workspace_bytes_fn = int64_t (*)(int64_t, int64_t);
+using mailbox_wait_fn = int (*)(const int64_t*, int64_t, void*, int64_t*);
+using stream_wait_fn = int (*)(void*);
+using marlin_full_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int, int32_t*, int16_t*, void*, int*, int, void*);
+
+struct Abi {
+    bitmask_compress_fn bitmask_compress = nullptr;
+    workspace_bytes_fn bitmask_workspace_bytes = nullptr;
+    mailbox_wait_fn mailbox_wait = nullptr;
+    stream_wait_fn stream_wait = nullptr;
+    marlin_full_fn marlin_full = nullptr;
+} g_abi;
+
+void bind_abi(const std::map<std::string, uintptr_t>& addr) {
+    auto at = [&](const char* name) {
+        auto it = addr.find(name);
+        if (it == addr.end() || !it->second) throw std::runtime_error(std::string("bind_abi: no address for ") + name);
+        return it->second;
+    };
+    g_abi.bitmask_compress = reinterpret_cast<bitmask_compress_fn>(at("ct_bitmask_compress"));
+    g_abi.bitmask_workspace_bytes = reinterpret_cast<workspace_bytes_fn>(at("ct_bitmask_compress_workspace_bytes"));
+    g_abi.mailbox_wait = reinterpret_cast<mailbox_wait_fn>(at("ct_mailbox_wait_i64"));
+    g_abi.stream_wait = reinterpret_cast<stream_wait_fn>(at("ct_stream_wait"));
+    g_abi.marlin_full = reinterpret_cast<marlin_full_fn>(at("ct_marlin24_compress_w4_full"));
 }
+
+bool on_device(const at::Tensor& t) { return t.is_cuda() || (g_allow_cpu && t.is_cpu()); }
+
+// codec.bitmask_compress for a contiguous, 16-byte aligned device tensor whose device is the current one (the caller checks the
+// last; everything else is checked here and answered with None: the Python path takes the call).  `dt`: the C ABI's element code.
+// Returns (status, values, bitmask, row_offsets).
+py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host, uintptr_t mailbox_dev, uintptr_t stream) {
+    if (!g_abi.bitmask_compress || !on_device(x) || x.dim() < 1 || !x.is_contiguous() || (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) || x.numel() == 0)
+        return py::none();
+    const int64_t cols = x.size(-1), numel = x.numel(), rows = numel / cols;
+    const int64_t ws_bytes = g_abi.bitmask_workspace_bytes(rows, cols);
+    const auto opts = x.options();
+    at::Tensor bitmask = at::empty({rows, (cols + 7) / 8}, opts.dtype(at::kByte));
+    at::Tensor row_offsets = at::empty({rows}, opts.dtype(at::kLong));
+    at::Tensor workspace = at::empty({ws_bytes / 8 + 1}, opts.dtype(at::kLong));
+    at::Tensor buf = at::empty({numel}, opts);
+    int status;
+    int64_t nnz = -1;
+    {
+        py::gil_scoped_release nogil;  // as the ctypes calls this replaces: other threads run while this one spins
+        volatile int64_t* word = reinterpret_cast<volatile int64_t*>(mailbox_host);
+        *word = -1;
+        status = g_abi.bitmask_compress(x.data_ptr(), dt, rows, cols, buf.data_ptr(), numel, bitmask.data_ptr<uint8_t>(), row_offsets.data_ptr<int64_t>(),
+                                        reinterpret_cast<int64_t*>(mailbox_dev), workspace.data_ptr(), ws_bytes, reinterpret_cast<void*>(stream));
+        if (status == 0) status = g_abi.mailbox_wait(reinterpret_cast<const int64_t*>(mailbox_host), -1, reinterpret_cast<void*>(stream), &nnz);
+    }
+    if (status != 0) return py::make_tuple(status, py::none(), py::none(), py::none());
+    if (nnz < 0 || nnz > numel) throw std::runtime_error("bitmask_compress: the device reported an impossible number of kept values");
+    // keep the view unless it pins more than ~5/8 of the worst-case buffer for nothing (codec.bitmask_compress: same rule)
+    at::Tensor values = buf.narrow(0, 0, nnz);
+    if (8 * nnz < 3 * numel) values = values.clone();
+    return py::make_tuple(0, values, bitmask, row_offsets);
+}
+
+// the default (raise-from-the-call) mode of Marlin24Compressor.compress for int4: ct_marlin24_compress_w4_full, then a spin on the stream,
+// then the verdict word.  The caller has validated shapes / dtypes / contiguity (compressors/sparse/marlin_24.py).  Returns
+// (status, violated, weight_packed, meta, scale_packed).
+py::tuple marlin24_w4_full(const at::Tensor& weight, int wdt, const at::Tensor& scale, int sdt, const c10::optional<at::Tensor>& zp, int zdt, int64_t group,
+                           bool group_perm, uintptr_t flag_host, uintptr_t flag_dev, uintptr_t stream) {
+    if (!g_abi.marlin_full) throw std::runtime_error("marlin24_w4_full: bind_abi has not run");
+    const int64_t m = weight.size(0), k = weight.size(1);
+    const auto opts = weight.options();
+    at::Tensor packed = at::empty({k / 32, m * 2}, opts.dtype(at::kInt));
+    at::Tensor meta = at::empty({k / 32, m * 2}, opts.dtype(at::kShort));  // the (m, k/16) reordered matrix, viewed as upstream stores it
+    at::Tensor scale_packed = at::empty({k / group, m}, opts.dtype(at::kHalf));
+    int status;
+    int64_t verdict = 0;
+    {
+        py::gil_scoped_release nogil;
+        volatile int64_t* word = reinterpret_cast<volatile int64_t*>(flag_host);
+        *word = 0;
+        status = g_abi.marlin_full(weight.data_ptr(), wdt, scale.data_ptr(), sdt, zp.has_value() ? zp->data_ptr() : nullptr, zp.has_value() ? zdt : -1, m, k, group,
+                                   group_perm ? 1 : 0, packed.data_ptr<int32_t>(), meta.data_ptr<int16_t>(), scale_packed.data_ptr(), reinterpret_cast<int*>(flag_dev), 0,
+                                   reinterpret_cast<void*>(stream));
+        if (status == 0) status = g_abi.stream_wait(reinterpret_cast<void*>(stream));
+        verdict = *word;
+    }
+    return py::make_tuple(status, verdict != 0, packed, meta, scale_packed);
+}
+
 
 }  // namespace
 
@@ -389,6 +511,10 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("w4_plan_decompress", &w4_plan_decompress);
     mod.def("w4_finish_decompress", &w4_finish_decompress);
     mod.def("quantized_modules", &quantized_modules);
+    py::class_<ModuleWalk>(mod, "ModuleWalk").def(py::init<py::object>()).def("take", &ModuleWalk::take).def_property_readonly("done", &ModuleWalk::done);
+    mod.def("bind_abi", &bind_abi);
+    mod.def("bitmask_compress", &bitmask_compress);
+    mod.def("marlin24_w4_full", &marlin24_w4_full);
     mod.def("set_allow_cpu", [](bool v) { g_allow_cpu = v; });
     mod.attr("ITEM_WORDS") = 10;
 }

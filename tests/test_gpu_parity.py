@@ -881,6 +881,64 @@ def test_marlin24_rejects_dense_weight(cta, dev):
         cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
 
 
+def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
+    """the two plug-in calls that wait for the device — sparse-bitmask compress (nnz) and the default mode of marlin-24 compress (the
+    2:4 verdict) — run their host side in csrc/host/ct_hostpath.cpp when the extension is built; the Python host side stays for what
+    the extension declines (and for a build without it).  Same kernels either way: every output equal, the same ValueError, and the
+    native path really is the one the default call takes (counted)."""
+    from compressed_tensors_amd import _lib as ctlib
+
+    hp = ctlib.hostpath()
+    assert hp is not None, "compressed_tensors_amd/_hostpath.so is missing"
+    taken = {"bitmask_compress": 0, "marlin24_w4_full": 0}
+
+    class Counting:
+        def __getattr__(self, name):
+            fn = getattr(hp, name)
+            if name in taken:
+                def counted(*a, _fn=fn, _n=name):
+                    r = _fn(*a)
+                    taken[_n] += r is not None
+                    return r
+                return counted
+            return fn
+
+    g = torch.Generator().manual_seed(5)
+    dense = torch.randn(512, 1024, generator=g).to(BF16)
+    cases = [dense * (torch.rand(512, 1024, generator=g) < d) for d in (0.5, 0.1, 0.0, 1.0)]
+    cases += [cases[0].to(F16), cases[0].float(), cases[0][:, :1000].contiguous(), cases[0].t()]  # .t(): declined by the native path
+    w24 = torch.randn(256, 1024, generator=g).to(BF16)
+    w24 = w24 * O.sparse24_mask(w24).to(BF16)
+    scale, zp = O.calculate_qparams_minmax(w24.to(F16), num_bits=4, group_size=128, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True))
+    sd = {"weight": w24.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}
+    bad = dict(sd, weight=torch.randn(256, 1024, generator=g).to(BF16).to(dev))
+
+    def run():
+        out = [cta.codec.bitmask_compress(c.to(dev)) for c in cases]
+        out.append(tuple(cta.Marlin24Compressor.compress(sd, scheme)[k] for k in ("weight_packed", "scale_packed", "meta")))
+        with pytest.raises(ValueError, match="2:4 sparsity structure"):
+            cta.Marlin24Compressor.compress(bad, scheme)
+        return out
+
+    ctlib._HOSTPATH[0] = Counting()
+    try:
+        native = run()
+        ctlib._HOSTPATH[0] = None
+        python = run()
+    finally:
+        ctlib._HOSTPATH[0] = hp
+    assert taken == {"bitmask_compress": len(cases) - 1, "marlin24_w4_full": 2}, taken
+    for a, b in zip(native, python):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape and x.device == y.device and torch.equal(x.view(torch.uint8) if x.is_floating_point() else x,
+                                                                                                       y.view(torch.uint8) if y.is_floating_point() else y)
+    # and against the checker
+    v, bm, ro = native[0]
+    rv, rbm, rro = O.bitmask_compress(cases[0])
+    assert torch.equal(v.cpu().view(torch.int16), rv.view(torch.int16)) and torch.equal(bm.cpu(), rbm) and torch.equal(ro.cpu(), rro)
+
+
 @pytest.mark.parametrize("shape", [(192, 1024), (64, 288), (128, 256)])
 @pytest.mark.parametrize("wdt", [BF16, F16])
 def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt, shape):
@@ -1114,7 +1172,9 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
                 return counted
             return fn
 
-    pq._HOSTPATH[0] = Counting()
+    from compressed_tensors_amd import _lib as ctlib
+
+    ctlib._HOSTPATH[0] = Counting()
     try:
         cta.ModelCompressor().compress_model(model)
         for a, b in zip(model, ref):
@@ -1127,7 +1187,7 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
             cta.decompress_module(m)
         cta.ModelCompressor().decompress_model(model)
     finally:
-        pq._HOSTPATH[0] = hp
+        ctlib._HOSTPATH[0] = hp
     # symmetric: modules 0-3 are plain int4 group / channel modules -> the C++ loop; asymmetric schemes stay with the Python loop
     assert taken == ({"compress": 4, "decompress": 4} if symmetric else {"compress": 0, "decompress": 0}), taken
     for a, b in zip(model, ref):

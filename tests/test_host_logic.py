@@ -750,6 +750,7 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
     shapes, dtypes, status; also the module walk against named_modules(remove_duplicate=True) + is_module_quantized"""
     import copy
 
+    from compressed_tensors_amd import _lib as ctlib
     from compressed_tensors_amd import codec
     from compressed_tensors_amd.compressors.pack_quantized import base as pq
     from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
@@ -793,9 +794,9 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
         mods_b = [m for m in b.modules() if isinstance(m, torch.nn.Linear)]
         pq.PackedQuantizationCompressor.compress_modules(mods_a)  # C++ loop first, Python loop for what it hands back
         which["now"] = "py"
-        monkeypatch.setattr(pq, "_HOSTPATH", [None])  # the Python loop alone
+        monkeypatch.setattr(ctlib, "_HOSTPATH", [None])  # the Python loop alone
         pq.PackedQuantizationCompressor.compress_modules(mods_b)
-        monkeypatch.setattr(pq, "_HOSTPATH", [hp])
+        monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
         n_plain = {"plain": 5, "trainable_scale": 4, "buffer_zp": 4, "odd_class": 4, "g_idx": 4}[variant]
         assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "compress") >= n_plain - 0
         for x, y in zip(mods_a, mods_b):
@@ -805,7 +806,7 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
         which["now"] = "cpp"
         pq.PackedQuantizationCompressor.decompress_modules(mods_a)
         which["now"] = "py"
-        monkeypatch.setattr(pq, "_HOSTPATH", [None])
+        monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
         pq.PackedQuantizationCompressor.decompress_modules(mods_b)
         for x, y in zip(mods_a, mods_b):
             assert _module_state_no_ptr(x) == _module_state_no_ptr(y), variant
@@ -822,3 +823,150 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
 def _module_state_no_ptr(m):
     return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
             [(k, None if v is None else (type(v).__name__, tuple(v.shape))) for k, v in m._buffers.items()])
+
+
+def test_cpp_waiting_calls_on_a_stub_abi(cta):
+    """csrc/host/ct_hostpath.cpp:bitmask_compress / marlin24_w4_full — the two plug-in calls that wait for the device, without the
+    interpreter — against stand-ins for the five C-ABI entries they call (ctypes callbacks; CPU tensors): what is allocated, what is
+    handed to the launch, the pending word, the keep-the-view rule for `values`, the verdict, and a non-zero status coming back for
+    _lib.check.  The kernels behind the real entries are the GPU suite's business."""
+    import numpy as np
+
+    from compressed_tensors_amd import _lib as ctlib
+
+    hp = ctlib.hostpath()
+    assert hp is not None, "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    seen = {}
+
+    def bm(x, dt, rows, cols, values, cap, bitmask, ro, total, ws, ws_bytes, stream):
+        seen["bm"] = (dt, rows, cols, cap, ws_bytes, stream, ctypes.c_int64.from_address(total).value)
+        if seen.get("fail"):
+            return ctlib.CT_ERR_INVALID_ARG
+        a = np.ctypeslib.as_array(ctypes.cast(x, ctypes.POINTER(ctypes.c_int16)), (rows, cols))
+        keep = a != 0
+        nnz = int(keep.sum())
+        np.ctypeslib.as_array(ctypes.cast(values, ctypes.POINTER(ctypes.c_int16)), (cap,))[:nnz] = a[keep]
+        np.ctypeslib.as_array(ctypes.cast(bitmask, ctypes.POINTER(ctypes.c_uint8)), (rows, (cols + 7) // 8))[:] = np.packbits(keep, axis=1, bitorder="little")
+        np.ctypeslib.as_array(ctypes.cast(ro, ctypes.POINTER(ctypes.c_int64)), (rows,))[:] = np.concatenate([[0], np.cumsum(keep.sum(1))[:-1]])
+        ctypes.c_int64.from_address(total).value = nnz
+        return 0
+
+    def wait(word, pending, stream, out):
+        ctypes.c_int64.from_address(out).value = ctypes.c_int64.from_address(word).value
+        return 0
+
+    def marlin(w, wdt, s, sdt, zp, zdt, m, k, g, perm, packed, meta, sp, bad, clear, stream):
+        seen["marlin"] = (wdt, sdt, zp, zdt, m, k, g, perm, clear, stream, ctypes.c_int64.from_address(bad).value)
+        np.ctypeslib.as_array(ctypes.cast(packed, ctypes.POINTER(ctypes.c_int32)), (k // 32, 2 * m))[:] = 7
+        if seen.get("violate"):
+            ctypes.c_int32.from_address(bad).value = 1
+        return 0
+
+    V, L, I = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    cbs = {
+        "ct_bitmask_compress": ctypes.CFUNCTYPE(I, V, I, L, L, V, L, V, V, V, V, L, V)(bm),
+        "ct_bitmask_compress_workspace_bytes": ctypes.CFUNCTYPE(L, L, L)(lambda r, c: 4096 + 8 * r),
+        "ct_mailbox_wait_i64": ctypes.CFUNCTYPE(I, V, L, V, V)(wait),
+        "ct_stream_wait": ctypes.CFUNCTYPE(I, V)(lambda s: 0),
+        "ct_marlin24_compress_w4_full": ctypes.CFUNCTYPE(I, V, I, V, I, V, I, L, L, L, I, V, V, V, V, I, V)(marlin),
+    }
+    box = (ctypes.c_int64 * 8)()
+    host = ctypes.addressof(box)
+    hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
+    hp.set_allow_cpu(True)
+    try:
+        g = torch.Generator().manual_seed(3)
+        for density, shares in ((0.5, True), (0.2, False)):
+            x = torch.randint(1, 1000, (48, 96), generator=g, dtype=torch.int16) * (torch.rand(48, 96, generator=g) < density)
+            status, values, bitmask, ro = hp.bitmask_compress(x, 7, host, host, 1234)
+            assert status == 0 and seen["bm"] == (7, 48, 96, 48 * 96, 4096 + 8 * 48, 1234, -1)  # the pending word was set before the launch
+            keep = x != 0
+            assert values.dtype == x.dtype and torch.equal(values, x[keep])
+            assert torch.equal(bitmask, torch.from_numpy(np.packbits(keep.numpy(), axis=1, bitorder="little")))
+            assert torch.equal(ro, torch.cumsum(keep.sum(1), 0) - keep.sum(1))
+            # at least 3/8 of the worst case kept: a view of the worst-case buffer; less: a compact copy
+            assert (values.untyped_storage().nbytes() == 2 * x.numel()) == shares
+        assert hp.bitmask_compress(x.t(), 7, host, host, 0) is None and hp.bitmask_compress(x[:0], 7, host, host, 0) is None  # the Python path's cases
+        seen["fail"] = True
+        status, *rest = hp.bitmask_compress(x, 7, host, host, 0)
+        assert status == ctlib.CT_ERR_INVALID_ARG and rest == [None, None, None]
+
+        w = torch.zeros(64, 256, dtype=torch.bfloat16)
+        s = torch.ones(64, 2, dtype=torch.bfloat16)
+        for violate in (False, True):
+            seen["violate"] = violate
+            box[1] = 99
+            status, violated, packed, meta, sp = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+            assert status == 0 and violated is violate
+            assert seen["marlin"] == (2, 2, None, -1, 64, 256, 128, 1, 0, 77, 0)  # the verdict word was cleared before the launch; the kernel only ORs into it
+            assert packed.shape == (8, 128) and packed.dtype == torch.int32 and int(packed[0, 0]) == 7
+            assert meta.shape == (8, 128) and meta.dtype == torch.int16 and sp.shape == (2, 64) and sp.dtype == torch.float16
+    finally:
+        hp.set_allow_cpu(False)
+        ctlib._HOSTPATH.clear()  # the next hostpath() binds the real entries again
+        assert ctlib.hostpath() is hp
+
+
+def test_module_walk_is_resumable_and_model_compressor_streams_its_head(cta, monkeypatch):
+    """hp.ModuleWalk.take(n) — the walk of ModelCompressor in pieces — returns named_modules(remove_duplicate=True) order however it is
+    cut; ModelCompressor._apply_streamed hands a large model to the codecs as head (32 modules, launched before the rest of the tree
+    has been walked) + rest, a small model or a model of a batch-atomic codec (marlin-24 validates the whole batch before touching a
+    module) in ONE call, and honours the skip filter"""
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd.compressors import base as cbase
+    from compressed_tensors_amd.compressors.model_compressors import model_compressor as mcm
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+    from compressed_tensors_amd.quantization.utils import is_module_quantized
+
+    hp = ctlib.hostpath()
+    assert hp is not None
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    model = _tree(cta, scheme, [(16, 128)] * 75)
+    model.blocks[3].extra = torch.nn.LayerNorm(4)  # not quantized
+    model.blocks[5].proj.quantization_scheme = None  # a scheme attribute that says "not quantized"
+    want = [m for _, m in model.named_modules(remove_duplicate=True) if is_module_quantized(m)]
+    assert len(want) == 74
+    for cuts in ([-1], [0, 1, 5, 32, -1], [74, 5], [200], [10] * 9):
+        walk, got = hp.ModuleWalk(model), []
+        for n in cuts:
+            part = walk.take(n)
+            assert n < 0 or len(part) <= n
+            got += part
+        assert [id(m) for m in got] == [id(m) for m in want] and walk.done and walk.take(5) == []
+
+    calls = []
+
+    def record(kind):
+        def apply(modules, format=None, groups=None):
+            assert groups is None or [m for ms in groups.values() for m in ms] == list(modules)
+            calls.append((kind, [id(m) for m in modules]))
+        return apply
+
+    monkeypatch.setattr(mcm, "compress_modules", record("c"))
+    monkeypatch.setattr(mcm, "decompress_modules", record("d"))
+    mc = cta.ModelCompressor()
+    ids = [id(m) for m in want]
+    assert [id(m) for m in mc.compress_model(model)] == ids
+    mc.decompress_model(model)
+    assert calls == [("c", ids[:32]), ("c", ids[32:]), ("d", ids[:32]), ("d", ids[32:])]
+    # skip filter: applied to both parts
+    del calls[:]
+    want[1].quantization_status = want[40].quantization_status = QuantizationStatus.COMPRESSED
+    kept = [i for k, i in enumerate(ids) if k not in (1, 40)]
+    assert [id(m) for m in mc.compress_model(model, skip_compressed=True)] == kept
+    assert calls == [("c", [i for i in ids[:32] if i != ids[1]]), ("c", [i for i in ids[32:] if i != ids[40]])]
+    # a small model: one call
+    del calls[:]
+    small = _tree(cta, scheme, [(16, 128)] * 20)
+    mc.compress_model(small)
+    assert len(calls) == 1 and len(calls[0][1]) == 20
+    # a codec that validates its whole batch before touching a module is never handed half a model
+    del calls[:]
+    mc24 = cta.ModelCompressor(force_compression_format="marlin-24")
+    assert [id(m) for m in mc24.compress_model(model)] == ids and calls == [("c", ids)]
+    assert cbase.batches_may_be_split({"pack-quantized": [], "int-quantized": []}) and not cbase.batches_may_be_split({"pack-quantized": [], "marlin-24": []})
+    # without the C++ walk: the same list, one call
+    del calls[:]
+    monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
+    assert [id(m) for m in mc.compress_model(model)] == ids and calls == [("c", ids)]

@@ -146,3 +146,60 @@ if what == "hostmodel":
     out["compress_model (host, until it returns)"], _ = med(lambda: mc.compress_model(model), n=1)
     out["decompress_model (host, until it returns)"], _ = med(lambda: mc.decompress_model(model), n=1)
     print(json.dumps(out, indent=1))
+if what == "hostab":
+    # native (csrc/host/ct_hostpath.cpp) vs Python host side of the two waiting plug-in calls, and ModelCompressor with / without the
+    # streamed head, on one lease: A / B / A / B so that drift between leases does not decide
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd.compressors.model_compressors.model_compressor import ModelCompressor
+    from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
+
+    hp = _lib.hostpath()
+    ws_ = sparse_inputs(N, 6)
+    g = torch.Generator(device=dev).manual_seed(4)
+    w24 = []
+    for _ in range(6):
+        w = torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g)
+        w24.append(w.masked_fill_(~codec.sparse24_mask(w), 0))
+    sc, zp = codec.minmax_qparams(w24[0], num_bits=4, group_size=128, symmetric=True)
+    scheme24 = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True))
+    keep = {}
+
+    def bm(i):
+        keep["bt"] = BitmaskTensor.from_dense(ws_[i % 6])
+
+    def m24(i):
+        keep["m"] = cta.Marlin24Compressor.compress({"weight": w24[i % 6], "weight_scale": sc, "weight_zero_point": zp}, scheme24)
+
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    mods, kp = [(f"model.layers.{l}.{n}", r, c) for l in range(22) for (n, r, c) in B.TINYLLAMA_LAYER], []
+    for _, r, c in mods:
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        s_, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+        kp.append((w, s_, z, None, None))
+    model = B.tinyllama_module_tree(mods, kp, scheme)
+    mc = cta.ModelCompressor()
+
+    def model_ms(n=9):
+        ts = []
+        for k in range(n + 2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            mc.compress_model(model); torch.cuda.synchronize(); t1 = time.perf_counter()
+            mc.decompress_model(model); torch.cuda.synchronize(); t2 = time.perf_counter()
+            if k >= 2:
+                ts.append(((t2 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+        med = lambda j: round(sorted(t[j] for t in ts)[len(ts) // 2], 4)
+        return {"both": med(0), "compress": med(1), "decompress": med(2)}
+
+    out = []
+    for rnd in range(2):
+        for label, h in (("native", hp), ("python", None)):
+            _lib._HOSTPATH[0] = h
+            out.append({"host": label, "from_dense_us": [round(v, 2) for v in B.time_calls(bm)], "marlin_default_us": [round(v, 2) for v in B.time_calls(m24)]})
+        _lib._HOSTPATH[0] = hp
+        for head in (32, 16, 24, 48, 10 ** 9):
+            ModelCompressor._STREAM_HEAD = head
+            out.append({"stream_head": head, "model_ms": model_ms()})
+        ModelCompressor._STREAM_HEAD = 32
+    for o in out:
+        print(json.dumps(o))
