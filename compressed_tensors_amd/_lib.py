@@ -266,7 +266,8 @@ def hostpath():
             hp = None
         if hp is not None:
             lib = load()
-            hp.bind_abi({name: ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+            # lib[name]: the symbol itself — `lib.name` may have been replaced by a launch-counting wrapper (tests/ref_suite)
+            hp.bind_abi({name: ctypes.cast(lib[name], ctypes.c_void_p).value
                          for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
                                       "ct_marlin24_compress_w4_full")})
         _HOSTPATH.append(hp)

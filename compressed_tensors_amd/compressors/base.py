@@ -135,22 +135,15 @@ def _by_format(modules, format):
     return groups
 
 
-def compress_modules(modules, format: Optional[CompressionFormat] = None, groups=None):
-    """compress_module over a list, grouped by format so that a codec can batch its kernel launches (`groups`: the caller's own
-    `_by_format(modules, format)`)"""
-    for fmt, ms in (_by_format(modules, format) if groups is None else groups).items():
+def compress_modules(modules, format: Optional[CompressionFormat] = None):
+    """compress_module over a list, grouped by format so that a codec can batch its kernel launches"""
+    for fmt, ms in _by_format(modules, format).items():
         BaseCompressor.get_value_from_registry(fmt).compress_modules(ms)
 
 
-def decompress_modules(modules, format: Optional[CompressionFormat] = None, groups=None):
-    for fmt, ms in (_by_format(modules, format) if groups is None else groups).items():
+def decompress_modules(modules, format: Optional[CompressionFormat] = None):
+    for fmt, ms in _by_format(modules, format).items():
         BaseCompressor.get_value_from_registry(fmt).decompress_modules(ms)
-
-
-def batches_may_be_split(groups) -> bool:
-    """may a module list be handed to the codecs in two calls instead of one?  Not when a codec validates its whole batch before it
-    touches any module (marlin-24: `batch_is_atomic`) — splitting would leave the first part converted when the second is refused."""
-    return not any(getattr(BaseCompressor.get_value_from_registry(fmt), "batch_is_atomic", False) for fmt in groups)
 
 
 def decompress_module(module: torch.nn.Module, format: Optional[CompressionFormat] = None):

@@ -83,43 +83,6 @@ class ModelCompressor:
         mods = hp.quantized_modules(model) if hp is not None else [m for _, m in self._named_quantized_modules(model)]
         return [m for m in mods if not self._is_compressed(m)] if skip_compressed else mods
 
-    # modules of the first call of `_apply_streamed`: their kernel (~2.8 us per module of a 1B-parameter model) has to cover the host's
-    # walk + planning of the next call's first table (~1.5 us per module)
-    _STREAM_HEAD = 32
-
-    def _apply_streamed(self, model, apply, keep=None):
-        """`apply(modules, format, groups=...)` over every quantized module of `model` (one rank), as TWO calls when the model is large:
-        the first `_STREAM_HEAD` modules are found, planned and LAUNCHED before the rest of the tree has been walked, and the rest is
-        walked and planned under that running kernel — 60 us less in front of the first launch of a 154-module model, where the whole
-        job is two kernels of 0.43 ms.  One call when the model is small, when the C++ walk is not built, or when a codec refuses to
-        have its batch split.  `keep`: module filter (skip_compressed).  Returns the modules in walk order."""
-        from ..base import _by_format, batches_may_be_split
-        from ..pack_quantized.base import _hostpath
-
-        fmt = self.force_compression_format
-        hp = _hostpath()
-        if hp is None:
-            mods = self._quantized_modules(model)
-            mods = mods if keep is None else [m for m in mods if keep(m)]
-            apply(mods, fmt)
-            return mods
-        walk = hp.ModuleWalk(model)
-        head = walk.take(self._STREAM_HEAD)
-        head = head if keep is None else [m for m in head if keep(m)]
-        groups = _by_format(head, fmt)
-        if not walk.done and batches_may_be_split(groups):
-            apply(head, fmt, groups=groups)
-            head_done, groups = head, None
-        else:
-            head_done = []
-        tail = walk.take(-1)
-        tail = tail if keep is None else [m for m in tail if keep(m)]
-        if head_done:
-            apply(tail, fmt)
-            return head_done + tail
-        apply(head + tail, fmt, groups=groups if not tail else None)
-        return head + tail
-
     @staticmethod
     def _is_compressed(m) -> bool:
         return getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED
@@ -152,7 +115,11 @@ class ModelCompressor:
         fmt = self.force_compression_format
         # grouped by format: the pack-quantized codec turns its group into ONE kernel launch
         if not is_distributed():  # one rank: every module is this rank's (what replace_module_parallel does without a process group)
-            mine = self._apply_streamed(model, compress_modules, (lambda m: not self._is_compressed(m)) if skip_compressed else None)
+            # (handing the first 32 modules to the codec before the rest of the tree has been walked — an earlier first launch — measured
+            # slower: 1.14 vs 1.10 ms for compress + decompress of a 154-module model; the host, not the first launch, is what the wall
+            # clock follows, and the split costs it a second grouping and a fourth launch.  DESIGN.md 5.5)
+            mine = self._quantized_modules(model, skip_compressed)
+            compress_modules(mine, fmt)
         else:
             mine = self._parallel(model, lambda ms: compress_modules(ms, fmt), recouple, skip_compressed)
         self._finish_compress(model, recouple)
@@ -196,8 +163,8 @@ class ModelCompressor:
         distributed decompression, :196) — also the right thing after a shard-per-rank compress, where each rank
         holds a different subset.  `recouple=True` (opt-in, needs a replicated compressed model): each rank
         decompresses its LPT share only and the dense weights are then replicated by one broadcast per owner."""
+        modules = self._quantized_modules(model)
         fmt = self.force_compression_format
-        modules = self._quantized_modules(model) if is_distributed() else None
         if recouple and is_distributed():
             def apply(ms):
                 decompress_modules([m for m in ms if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
@@ -207,7 +174,7 @@ class ModelCompressor:
         elif is_distributed():
             decompress_modules([m for m in modules if getattr(m, "quantization_status", None) == QuantizationStatus.COMPRESSED], fmt)
         else:
-            self._apply_streamed(model, decompress_modules)
+            decompress_modules(modules, fmt)
         if self.quantization_config is not None and hasattr(self.quantization_config, "quantization_status"):
             self.quantization_config.quantization_status = QuantizationStatus.DECOMPRESSED
         self.remove_decompression_hook(model)

@@ -99,7 +99,6 @@ def _ring(device) -> _FlagRing:
 @BaseCompressor.register(name=CompressionFormat.marlin_24.value)
 class Marlin24Compressor(BaseCompressor):
     COMPRESSION_PARAM_NAMES = ("weight_packed", "scale_packed", "meta")
-    batch_is_atomic = True  # compress_modules validates every module before it replaces any: a caller must not split a batch
 
     @classmethod
     @contextlib.contextmanager
@@ -190,6 +189,22 @@ class Marlin24Compressor(BaseCompressor):
         cls.validate_quant_compatability(weights)
 
         group_size = getattr(weights, "group_size", None)
+        if int(weights.num_bits) == 4 and getattr(_local, "depth", 0) == 0 and weight.is_cuda and weight.device.index == torch.cuda.current_device():
+            # the default mode — the call itself raises, as upstream — cannot overlap its own kernel: the layout tests, the allocations,
+            # the launch, the spin on the stream and the read of the verdict word all run in csrc/host/ct_hostpath.cpp when it is built
+            # (None: not the one-launch layout, the Python path below takes the call)
+            hp = _lib.hostpath()
+            if hp is not None:
+                stream = _lib.stream_of_device(weight.device)
+                mb = _lib.mailbox(stream.device_index)
+                r = hp.marlin24_compress_default(weight, scale, zero_point, 0 if enum_value(weights.strategy) == "channel" else int(group_size or -1),
+                                                 mb.host + 8, mb.dev + 8, stream)
+                if r is not None:
+                    _lib.check(r[0])
+                    if r[1]:
+                        raise ValueError(_STRUCTURE_ERROR)
+                    state_dict["weight_packed"], state_dict["scale_packed"], state_dict["meta"] = r[2], r[4], r[3]
+                    return state_dict
         fused_ok = (weight.dtype in (torch.float16, torch.bfloat16) and scale.dtype in (torch.float16, torch.bfloat16) and weight.dim() == 2
                     and weight.shape[0] % 64 == 0 and weight.shape[1] % 16 == 0
                     and (enum_value(weights.strategy) == "channel" or (group_size and group_size % 16 == 0 and weight.shape[1] % group_size == 0)))
@@ -211,18 +226,6 @@ class Marlin24Compressor(BaseCompressor):
                 else:  # the call itself raises (upstream's behaviour): the verdict lands in the thread's pinned mailbox word
                     stream = _lib.stream_of_device(weight.device)
                     mb = _lib.mailbox(stream.device_index)
-                    hp = _lib.hostpath() if stream.device_index == torch.cuda.current_device() else None
-                    if hp is not None:  # allocate / launch / spin / read the verdict without the interpreter (ct_hostpath.cpp:marlin24_w4_full)
-                        status, violated, packed, meta, scale_packed = hp.marlin24_w4_full(
-                            weight, codec.DT[weight.dtype], scale2d, codec.DT[scale2d.dtype], zero_point, -1 if zero_point is None else codec.DT[zero_point.dtype],
-                            weight.shape[1] if not g or g > weight.shape[1] else int(g), is_group, mb.host + 8, mb.dev + 8, stream)
-                        _lib.check(status)
-                        if violated:
-                            raise ValueError(_STRUCTURE_ERROR)
-                        state_dict["weight_packed"] = packed
-                        state_dict["scale_packed"] = scale_packed
-                        state_dict["meta"] = meta
-                        return state_dict
                     mb.words[1] = 0
                     flag_ptr = mb.dev + 8
                 packed, meta, scale_packed, _ = codec.marlin24_compress_w4_full(weight, scale2d, zero_point, group_size=g, group_perm=is_group,

@@ -336,10 +336,9 @@ void w4_finish_decompress(py::list jobs, py::object status) {
 // the quantized modules of a model in `named_modules(remove_duplicate=True)` order (pre-order over `_modules`, every module once):
 // model_compressor.py:152-164,191-195 with is_module_quantized (quantization/utils/helpers.py:229-250: a scheme with at least one of
 // weights / input_activations / output_activations).  300 modules cost the interpreter 0.3 ms per walk; here ~30 us.
-// named_modules(remove_duplicate=True) order (pre-order, children in `_modules` order, a module reached twice is visited once), resumable: `take(n)`
-// returns the next n quantized modules and keeps its place, so that a caller can launch the first table of a large model after walking
-// only that table's modules and walk the rest under the running kernel.  The tree must not gain or lose modules between two takes (the
-// codecs only rewrite `_parameters`).
+// named_modules(remove_duplicate=True) order (pre-order, children in `_modules` order, a module reached twice is visited once), on an explicit
+// stack; `take(n)` returns the next n quantized modules and keeps its place.  (Resumable because ModelCompressor once launched the first 32
+// modules of a model before walking the rest; that measured slower — DESIGN.md 5.5 — and the one caller left takes everything.)
 struct ModuleWalk {
     PyObject* modules_name = PyUnicode_InternFromString("_modules");
     PyObject* scheme_name = PyUnicode_InternFromString("quantization_scheme");
@@ -497,6 +496,45 @@ py::tuple marlin24_w4_full(const at::Tensor& weight, int wdt, const at::Tensor& 
 }
 
 
+// C ABI element code of a tensor's dtype (include/ct_hip.h enum ct_dtype), -1 for a type the ABI has no code for
+int dtype_code(at::ScalarType t) {
+    switch (t) {
+        case at::kFloat: return 0;
+        case at::kHalf: return 1;
+        case at::kBFloat16: return 2;
+        case at::kChar: return 3;
+        case at::kInt: return 4;
+        case at::kByte: case at::kBool: return 5;
+        case at::kShort: return 6;
+        case at::kLong: return 7;
+        default: return -1;
+    }
+}
+
+// Marlin24Compressor.compress for an int4 scheme outside a deferred-check context, from the popped state-dict entries on: the layout tests
+// of the one-launch path (compressors/sparse/marlin_24.py, same conditions), then marlin24_w4_full.  `group_size`: the scheme's, 0 for a
+// channel-wise scheme, negative for a group scheme without a group size.  None when the tensors are not the one-launch case: the Python path takes the call.
+py::object marlin24_compress_default(const at::Tensor& weight, const at::Tensor& scale, const c10::optional<at::Tensor>& zp, int64_t group_size, uintptr_t flag_host,
+                                     uintptr_t flag_dev, uintptr_t stream) {
+    const bool channel = group_size == 0;
+    if (group_size < 0 || !g_abi.marlin_full || !on_device(weight) || weight.dim() != 2 || !half_type(weight.scalar_type()) || !half_type(scale.scalar_type()) || scale.dim() < 1 ||
+        scale.dim() > 2)
+        return py::none();
+    const int64_t m = weight.size(0), k = weight.size(1);
+    if (m == 0 || m % 64 != 0 || k % 256 != 0 || k == 0 || !(channel || (group_size % 16 == 0 && k % group_size == 0)) || !weight.is_contiguous() || !aligned16(weight))
+        return py::none();
+    at::Tensor scale2d = scale.dim() == 2 ? scale : scale.reshape({scale.size(0), -1});
+    if (!on_device(scale2d) || !scale2d.is_contiguous() || scale2d.device() != weight.device() || (m * scale2d.size(1)) % 64 != 0) return py::none();
+    int zdt = -1;
+    if (zp.has_value()) {
+        zdt = dtype_code(zp->scalar_type());
+        if (zdt < 0 || !on_device(*zp) || !zp->is_contiguous() || zp->device() != weight.device()) return py::none();
+    }
+    const int64_t group = (channel || group_size > k) ? k : group_size;
+    const bool group_perm = !channel && group_size < k / 2;  // the in-dimension of the COMPRESSED weight decides (marlin_24.py: is_group)
+    return marlin24_w4_full(weight, dtype_code(weight.scalar_type()), scale2d, dtype_code(scale2d.scalar_type()), zp, zdt, group, group_perm, flag_host, flag_dev, stream);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(_hostpath, mod) {
@@ -511,10 +549,10 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("w4_plan_decompress", &w4_plan_decompress);
     mod.def("w4_finish_decompress", &w4_finish_decompress);
     mod.def("quantized_modules", &quantized_modules);
-    py::class_<ModuleWalk>(mod, "ModuleWalk").def(py::init<py::object>()).def("take", &ModuleWalk::take).def_property_readonly("done", &ModuleWalk::done);
     mod.def("bind_abi", &bind_abi);
     mod.def("bitmask_compress", &bitmask_compress);
     mod.def("marlin24_w4_full", &marlin24_w4_full);
+    mod.def("marlin24_compress_default", &marlin24_compress_default);
     mod.def("set_allow_cpu", [](bool v) { g_allow_cpu = v; });
     mod.attr("ITEM_WORDS") = 10;
 }

@@ -890,7 +890,7 @@ def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
 
     hp = ctlib.hostpath()
     assert hp is not None, "compressed_tensors_amd/_hostpath.so is missing"
-    taken = {"bitmask_compress": 0, "marlin24_w4_full": 0}
+    taken = {"bitmask_compress": 0, "marlin24_compress_default": 0}
 
     class Counting:
         def __getattr__(self, name):
@@ -916,7 +916,8 @@ def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
 
     def run():
         out = [cta.codec.bitmask_compress(c.to(dev)) for c in cases]
-        out.append(tuple(cta.Marlin24Compressor.compress(sd, scheme)[k] for k in ("weight_packed", "scale_packed", "meta")))
+        got = cta.Marlin24Compressor.compress(sd, scheme)
+        out.append(tuple(got[k] for k in ("weight_packed", "scale_packed", "meta")))
         with pytest.raises(ValueError, match="2:4 sparsity structure"):
             cta.Marlin24Compressor.compress(bad, scheme)
         return out
@@ -928,7 +929,7 @@ def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
         python = run()
     finally:
         ctlib._HOSTPATH[0] = hp
-    assert taken == {"bitmask_compress": len(cases) - 1, "marlin24_w4_full": 2}, taken
+    assert taken == {"bitmask_compress": len(cases) - 1, "marlin24_compress_default": 2}, taken
     for a, b in zip(native, python):
         for x, y in zip(a, b):
             assert x.dtype == y.dtype and x.shape == y.shape and x.device == y.device and torch.equal(x.view(torch.uint8) if x.is_floating_point() else x,

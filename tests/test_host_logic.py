@@ -901,72 +901,20 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
             assert seen["marlin"] == (2, 2, None, -1, 64, 256, 128, 1, 0, 77, 0)  # the verdict word was cleared before the launch; the kernel only ORs into it
             assert packed.shape == (8, 128) and packed.dtype == torch.int32 and int(packed[0, 0]) == 7
             assert meta.shape == (8, 128) and meta.dtype == torch.int16 and sp.shape == (2, 64) and sp.dtype == torch.float16
+        # the same call from the state-dict entries on (Marlin24Compressor.compress): layout tests, element codes, group / permutation choice
+        seen["violate"] = False
+        D = hp.marlin24_compress_default
+        assert D(w, s, None, 128, host + 8, host + 8, 5)[0] == 0 and seen["marlin"][:9] == (2, 2, None, -1, 64, 256, 128, 0, 0)  # 128 == k / 2: single-column permutation
+        s64 = torch.ones(64, 4, dtype=torch.float16)
+        zp = torch.zeros(64, 4, dtype=torch.int8)
+        assert D(w, s64, zp, 64, host + 8, host + 8, 5)[0] == 0
+        assert seen["marlin"][:2] == (2, 1) and seen["marlin"][2] == zp.data_ptr() and seen["marlin"][3:9] == (3, 64, 256, 64, 1, 0)
+        assert D(w, torch.ones(64, dtype=torch.bfloat16), None, 0, host + 8, host + 8, 5)[0] == 0 and seen["marlin"][4:8] == (64, 256, 256, 0)  # channel-wise, 1-D scale
+        for args in ((w[:32], s[:32], None, 128), (w[:, :128], s[:, :1], None, 128), (w.float(), s, None, 128), (w, s.float(), None, 128), (w, s, None, -1),
+                     (w, s, None, 96), (w.t(), s, None, 128), (w, s.t(), None, 128), (w, s, torch.zeros(64, 2, dtype=torch.float64), 128),
+                     (w[:, 8:264], s, None, 128)):
+            assert D(*args, host + 8, host + 8, 5) is None, [tuple(a.shape) if hasattr(a, "shape") else a for a in args]
     finally:
         hp.set_allow_cpu(False)
         ctlib._HOSTPATH.clear()  # the next hostpath() binds the real entries again
         assert ctlib.hostpath() is hp
-
-
-def test_module_walk_is_resumable_and_model_compressor_streams_its_head(cta, monkeypatch):
-    """hp.ModuleWalk.take(n) — the walk of ModelCompressor in pieces — returns named_modules(remove_duplicate=True) order however it is
-    cut; ModelCompressor._apply_streamed hands a large model to the codecs as head (32 modules, launched before the rest of the tree
-    has been walked) + rest, a small model or a model of a batch-atomic codec (marlin-24 validates the whole batch before touching a
-    module) in ONE call, and honours the skip filter"""
-    from compressed_tensors_amd import _lib as ctlib
-    from compressed_tensors_amd.compressors import base as cbase
-    from compressed_tensors_amd.compressors.model_compressors import model_compressor as mcm
-    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
-    from compressed_tensors_amd.quantization.utils import is_module_quantized
-
-    hp = ctlib.hostpath()
-    assert hp is not None
-    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
-    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
-    model = _tree(cta, scheme, [(16, 128)] * 75)
-    model.blocks[3].extra = torch.nn.LayerNorm(4)  # not quantized
-    model.blocks[5].proj.quantization_scheme = None  # a scheme attribute that says "not quantized"
-    want = [m for _, m in model.named_modules(remove_duplicate=True) if is_module_quantized(m)]
-    assert len(want) == 74
-    for cuts in ([-1], [0, 1, 5, 32, -1], [74, 5], [200], [10] * 9):
-        walk, got = hp.ModuleWalk(model), []
-        for n in cuts:
-            part = walk.take(n)
-            assert n < 0 or len(part) <= n
-            got += part
-        assert [id(m) for m in got] == [id(m) for m in want] and walk.done and walk.take(5) == []
-
-    calls = []
-
-    def record(kind):
-        def apply(modules, format=None, groups=None):
-            assert groups is None or [m for ms in groups.values() for m in ms] == list(modules)
-            calls.append((kind, [id(m) for m in modules]))
-        return apply
-
-    monkeypatch.setattr(mcm, "compress_modules", record("c"))
-    monkeypatch.setattr(mcm, "decompress_modules", record("d"))
-    mc = cta.ModelCompressor()
-    ids = [id(m) for m in want]
-    assert [id(m) for m in mc.compress_model(model)] == ids
-    mc.decompress_model(model)
-    assert calls == [("c", ids[:32]), ("c", ids[32:]), ("d", ids[:32]), ("d", ids[32:])]
-    # skip filter: applied to both parts
-    del calls[:]
-    want[1].quantization_status = want[40].quantization_status = QuantizationStatus.COMPRESSED
-    kept = [i for k, i in enumerate(ids) if k not in (1, 40)]
-    assert [id(m) for m in mc.compress_model(model, skip_compressed=True)] == kept
-    assert calls == [("c", [i for i in ids[:32] if i != ids[1]]), ("c", [i for i in ids[32:] if i != ids[40]])]
-    # a small model: one call
-    del calls[:]
-    small = _tree(cta, scheme, [(16, 128)] * 20)
-    mc.compress_model(small)
-    assert len(calls) == 1 and len(calls[0][1]) == 20
-    # a codec that validates its whole batch before touching a module is never handed half a model
-    del calls[:]
-    mc24 = cta.ModelCompressor(force_compression_format="marlin-24")
-    assert [id(m) for m in mc24.compress_model(model)] == ids and calls == [("c", ids)]
-    assert cbase.batches_may_be_split({"pack-quantized": [], "int-quantized": []}) and not cbase.batches_may_be_split({"pack-quantized": [], "marlin-24": []})
-    # without the C++ walk: the same list, one call
-    del calls[:]
-    monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
-    assert [id(m) for m in mc.compress_model(model)] == ids and calls == [("c", ids)]

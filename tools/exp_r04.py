@@ -147,11 +147,11 @@ if what == "hostmodel":
     out["decompress_model (host, until it returns)"], _ = med(lambda: mc.decompress_model(model), n=1)
     print(json.dumps(out, indent=1))
 if what == "hostab":
-    # native (csrc/host/ct_hostpath.cpp) vs Python host side of the two waiting plug-in calls, and ModelCompressor with / without the
-    # streamed head, on one lease: A / B / A / B so that drift between leases does not decide
+    # native (csrc/host/ct_hostpath.cpp) vs Python host side of the two waiting plug-in calls, and ModelCompressor on the 154-module tree,
+    # on one lease: A / B / A / B so that drift between leases does not decide.  (Run Q also compared a streamed head of 16 / 24 / 32 / 48
+    # modules in ModelCompressor against one call: 1.151 / 1.142 / 1.144 / 1.128 vs 1.104 ms — removed, profiles/r04_host_native_ab.jsonl)
     import compressed_tensors_amd as cta
-    from compressed_tensors_amd.compressors.model_compressors.model_compressor import ModelCompressor
-    from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
+        from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
 
     hp = _lib.hostpath()
     ws_ = sparse_inputs(N, 6)
@@ -197,9 +197,6 @@ if what == "hostab":
             _lib._HOSTPATH[0] = h
             out.append({"host": label, "from_dense_us": [round(v, 2) for v in B.time_calls(bm)], "marlin_default_us": [round(v, 2) for v in B.time_calls(m24)]})
         _lib._HOSTPATH[0] = hp
-        for head in (32, 16, 24, 48, 10 ** 9):
-            ModelCompressor._STREAM_HEAD = head
-            out.append({"stream_head": head, "model_ms": model_ms()})
-        ModelCompressor._STREAM_HEAD = 32
+        out.append({"model_ms": model_ms()})
     for o in out:
         print(json.dumps(o))
