@@ -151,7 +151,7 @@ if what == "hostab":
     # on one lease: A / B / A / B so that drift between leases does not decide.  (Run Q also compared a streamed head of 16 / 24 / 32 / 48
     # modules in ModelCompressor against one call: 1.151 / 1.142 / 1.144 / 1.128 vs 1.104 ms — removed, profiles/r04_host_native_ab.jsonl)
     import compressed_tensors_amd as cta
-        from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
+    from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
 
     hp = _lib.hostpath()
     ws_ = sparse_inputs(N, 6)
