@@ -17,6 +17,17 @@ if mode == "pywait":  # the two waiting plug-in calls take their Python host pat
             return getattr(hp, name)
 
     _lib._HOSTPATH[0] = Hidden()
+elif mode == "lateimport":  # as pywait, and the extension itself is not imported before the model leg asks for it
+    from compressed_tensors_amd import _lib
+
+    class Lazy:
+        def __getattr__(self, name):
+            if name in ("bitmask_compress", "marlin24_compress_default"):
+                return lambda *a: None
+            _lib._HOSTPATH.clear()
+            return getattr(_lib.hostpath(), name)
+
+    _lib._HOSTPATH[:] = [Lazy()]
 elif mode == "nogc":
     import gc
 
