@@ -37,6 +37,16 @@ PyObject* g_parameter_cls = nullptr;   // torch.nn.Parameter
 PyObject* g_module_setattr = nullptr;  // torch.nn.Module.__setattr__
 PyObject* g_module_delattr = nullptr;  // torch.nn.Module.__delattr__
 std::unordered_map<PyTypeObject*, bool> g_plain_type;
+// One thread-local word, touched on purpose (module init and every entry point).  glibc before 2.39 (BZ #19924; this image: 2.35): after a dlopen
+// of ANY library that carries a TLS segment, every `__tls_get_addr` of a thread — PyTorch makes dozens per tensor it creates or releases — takes the
+// dynamic linker's slow path until that thread has touched the TLS of the NEWEST such library; a process that has imported torch and friends is usually
+// in that state, and stays in it.  This extension is imported lazily, at the first call that needs it, normally after everything else has been loaded:
+// touching its own TLS then puts the calling thread back on the fast path.  Measured on the 154-module checkpoint:
+// w4_finish_compress / w4_finish_decompress — the functions that release and create tensors — 20-25 % faster, and the reason a build of this file
+// without -DNDEBUG (pybind11 then counts references in a thread_local) was FASTER than one with it, and faster imported late than early.
+thread_local volatile int64_t g_tls_touch = 0;
+inline void touch_tls() { g_tls_touch = g_tls_touch + 1; }
+
 bool g_allow_cpu = false;  // tests only (tests/test_host_logic.py): run the host logic on CPU tensors, with the launch stubbed out
 
 struct Names {
@@ -204,6 +214,7 @@ py::dict batches_to_python(std::map<std::pair<int, int>, Batch>& batches) {
 
 // infos[i]: group size of module i's scheme (0 = channel-wise), or < 0 when the scheme is not a symmetric int4 group / channel scheme
 py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
+    touch_tls();
     std::map<std::pair<int, int>, Batch> batches;  // (device index, dtype code 1 = fp16 / 2 = bf16) -> table
     py::list rest;
     Infos infos(infos_arg.ptr());
@@ -252,6 +263,7 @@ py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
 
 // after the launch: `weight` (and the zero point a symmetric scheme does not store) leave, `weight_packed` and `weight_shape` arrive
 void w4_finish_compress(py::list jobs, py::object status) {
+    touch_tls();
     const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
@@ -273,6 +285,7 @@ void w4_finish_compress(py::list jobs, py::object status) {
 
 // infos[i]: 1 when module i's scheme is a symmetric int4 scheme (the strategy is inferred from the scale's shape, as `dequantize` does), else 0
 py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
+    touch_tls();
     std::map<std::pair<int, int>, Batch> batches;
     py::list rest;
     Infos infos(infos_arg.ptr());
@@ -320,6 +333,7 @@ py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
 }
 
 void w4_finish_decompress(py::list jobs, py::object status) {
+    touch_tls();
     const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
@@ -398,7 +412,10 @@ struct ModuleWalk {
     bool done() const { return !root && stack.empty(); }
 };
 
-py::list quantized_modules(py::object model) { return ModuleWalk(std::move(model)).take(-1); }
+py::list quantized_modules(py::object model) {
+    touch_tls();
+    return ModuleWalk(std::move(model)).take(-1);
+}
 
 // ------------------------------------------------------------------------------------------
 // The two plug-in calls that WAIT for the device before they return (include/ct_hip.h "Host mailbox"): the sparse-bitmask
@@ -442,6 +459,7 @@ bool on_device(const at::Tensor& t) { return t.is_cuda() || (g_allow_cpu && t.is
 // last; everything else is checked here and answered with None: the Python path takes the call).  `dt`: the C ABI's element code.
 // Returns (status, values, bitmask, row_offsets).
 py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host, uintptr_t mailbox_dev, uintptr_t stream) {
+    touch_tls();
     if (!g_abi.bitmask_compress || !on_device(x) || x.dim() < 1 || !x.is_contiguous() || (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) || x.numel() == 0)
         return py::none();
     const int64_t cols = x.size(-1), numel = x.numel(), rows = numel / cols;
@@ -516,6 +534,7 @@ int dtype_code(at::ScalarType t) {
 // channel-wise scheme, negative for a group scheme without a group size.  None when the tensors are not the one-launch case: the Python path takes the call.
 py::object marlin24_compress_default(const at::Tensor& weight, const at::Tensor& scale, const c10::optional<at::Tensor>& zp, int64_t group_size, uintptr_t flag_host,
                                      uintptr_t flag_dev, uintptr_t stream) {
+    touch_tls();
     const bool channel = group_size == 0;
     if (group_size < 0 || !g_abi.marlin_full || !on_device(weight) || weight.dim() != 2 || !half_type(weight.scalar_type()) || !half_type(scale.scalar_type()) || scale.dim() < 1 ||
         scale.dim() > 2)
@@ -538,6 +557,7 @@ py::object marlin24_compress_default(const at::Tensor& weight, const at::Tensor&
 }  // namespace
 
 PYBIND11_MODULE(_hostpath, mod) {
+    touch_tls();
     N.init();
     py::module_ torch_mod = py::module_::import("torch");
     g_make_subclass = py::object(torch_mod.attr("Tensor").attr("_make_subclass")).release().ptr();

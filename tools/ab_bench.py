@@ -1,5 +1,5 @@
 """dev helper (run U): bench.py under one perturbation, to find what moves `tinyllama_checkpoint.api` between contexts.
-python tools/ab_bench.py asis|pywait|nogc|nocpu [bench args]"""
+python tools/ab_bench.py asis|pywait|lateimport|timed|timed_late|cpufirst|nogc|nocpu [bench args]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 mode = sys.argv.pop(1)
@@ -68,6 +68,15 @@ elif mode in ("timed", "timed_late"):  # where the host time of the model path g
     for n in ("compress_model", "decompress_model", "_finish_compress", "remove_decompression_hook"):
         setattr(mcm.ModelCompressor, n, timed("ModelCompressor." + n, getattr(mcm.ModelCompressor, n)))
     atexit.register(lambda: print(json.dumps({k: [v[0], round(v[1] / v[0] * 1e6, 1)] for k, v in acc.items()}), file=sys.stderr))
+elif mode == "cpufirst":  # the order of runs Q-W: extension imported, then the CPU baseline leg, then everything else
+    import torch
+
+    from compressed_tensors_amd import _lib
+
+    _lib.hostpath()
+    torch.cuda.set_device(0)
+    bench.cpu_baseline(torch.device("cuda:0"))
+    sys.argv.append("--no-cpu-baseline")
 elif mode == "nogc":
     import gc
 
