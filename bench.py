@@ -1590,9 +1590,9 @@ def main():
             if rank == 0:
                 result["row_sharded"] = leg
     if rank == 0:
-        # LAST, after every GPU leg: the CPU baseline leaves the process with os.cpu_count() OpenMP workers behind it, and the host-bound
-        # figure of the run — ModelCompressor on the 154-module tree — measured 1.16-1.68 ms after it against 1.03-1.08 ms before it
-        # on the same lease (runs T-W); the baseline itself does not care where it runs
+        # LAST, after every GPU leg: the CPU baseline's imports dlopen libraries with TLS segments, after which glibc 2.35 keeps this thread on
+        # the slow __tls_get_addr path (BZ 19924) — the host-bound figure of the run, ModelCompressor on the 154-module tree, measured
+        # 1.16-1.68 ms behind it against 1.03-1.08 ms in front of it on the same lease (runs T-Y); the baseline does not care
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"], result["cpu_baseline_port"] = cpu_baseline(dev)
         result["oracle_slice_check"] = oracle_slice_check(dev)  # never skipped: no configuration runs without the real checker
