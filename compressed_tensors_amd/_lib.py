@@ -267,9 +267,15 @@ def hostpath():
         if hp is not None:
             lib = load()
             # lib[name]: the symbol itself — `lib.name` may have been replaced by a launch-counting wrapper (tests/ref_suite)
-            hp.bind_abi({name: ctypes.cast(lib[name], ctypes.c_void_p).value
-                         for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
-                                      "ct_marlin24_compress_w4_full")})
+            abi = {name: ctypes.cast(lib[name], ctypes.c_void_p).value
+                   for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
+                                "ct_marlin24_compress_w4_full")}
+            try:  # the HIP runtime libct_hip.so is linked against, only if it is already in the process (RTLD_NOLOAD: never a second copy)
+                hip = ctypes.CDLL("libamdhip64.so", mode=os.RTLD_NOLOAD | os.RTLD_NOW)
+                abi["hipStreamSynchronize"] = ctypes.cast(hip.hipStreamSynchronize, ctypes.c_void_p).value
+            except (OSError, AttributeError):
+                pass  # the marlin-24 default mode then waits through ct_stream_wait
+            hp.bind_abi(abi)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
 

@@ -438,7 +438,26 @@ struct Abi {
     mailbox_wait_fn mailbox_wait = nullptr;
     stream_wait_fn stream_wait = nullptr;
     marlin_full_fn marlin_full = nullptr;
+    stream_wait_fn hip_stream_synchronize = nullptr;  // optional: hipStreamSynchronize of the HIP runtime that is already loaded
 } g_abi;
+
+// 1: the waits below as described there; 0: only through ct_mailbox_wait_i64 / ct_stream_wait (tools/exp_r04.py compares the two on one lease)
+int g_wait_mode = 1;
+
+// the word a kernel stores into pinned host memory, as soon as it differs from `pending`: plain reads of the (cached, coherent) word with a pause
+// between them — ct_mailbox_wait_i64 looks at the stream every 64 reads, and a hipStreamQuery is 1-2 us during which the word is not looked at.  After
+// ~1 ms without the word (a failed launch, a kernel that does not write it) the C-ABI wait takes over, with its stream check and its error reporting.
+inline bool spin_for_word(const volatile int64_t* word, int64_t pending, int64_t* value) {
+    for (unsigned spin = 0; spin < (1u << 18); ++spin) {
+        const int64_t v = *word;
+        if (v != pending) {
+            *value = v;
+            return true;
+        }
+        __builtin_ia32_pause();
+    }
+    return false;
+}
 
 void bind_abi(const std::map<std::string, uintptr_t>& addr) {
     auto at = [&](const char* name) {
@@ -451,6 +470,8 @@ void bind_abi(const std::map<std::string, uintptr_t>& addr) {
     g_abi.mailbox_wait = reinterpret_cast<mailbox_wait_fn>(at("ct_mailbox_wait_i64"));
     g_abi.stream_wait = reinterpret_cast<stream_wait_fn>(at("ct_stream_wait"));
     g_abi.marlin_full = reinterpret_cast<marlin_full_fn>(at("ct_marlin24_compress_w4_full"));
+    auto opt = addr.find("hipStreamSynchronize");
+    g_abi.hip_stream_synchronize = opt != addr.end() && opt->second ? reinterpret_cast<stream_wait_fn>(opt->second) : nullptr;
 }
 
 bool on_device(const at::Tensor& t) { return t.is_cuda() || (g_allow_cpu && t.is_cpu()); }
@@ -477,7 +498,8 @@ py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host,
         *word = -1;
         status = g_abi.bitmask_compress(x.data_ptr(), dt, rows, cols, buf.data_ptr(), numel, bitmask.data_ptr<uint8_t>(), row_offsets.data_ptr<int64_t>(),
                                         reinterpret_cast<int64_t*>(mailbox_dev), workspace.data_ptr(), ws_bytes, reinterpret_cast<void*>(stream));
-        if (status == 0) status = g_abi.mailbox_wait(reinterpret_cast<const int64_t*>(mailbox_host), -1, reinterpret_cast<void*>(stream), &nnz);
+        if (status == 0 && !(g_wait_mode && spin_for_word(word, -1, &nnz)))
+            status = g_abi.mailbox_wait(reinterpret_cast<const int64_t*>(mailbox_host), -1, reinterpret_cast<void*>(stream), &nnz);
     }
     if (status != 0) return py::make_tuple(status, py::none(), py::none(), py::none());
     if (nnz < 0 || nnz > numel) throw std::runtime_error("bitmask_compress: the device reported an impossible number of kept values");
@@ -507,7 +529,11 @@ py::tuple marlin24_w4_full(const at::Tensor& weight, int wdt, const at::Tensor& 
         status = g_abi.marlin_full(weight.data_ptr(), wdt, scale.data_ptr(), sdt, zp.has_value() ? zp->data_ptr() : nullptr, zp.has_value() ? zdt : -1, m, k, group,
                                    group_perm ? 1 : 0, packed.data_ptr<int32_t>(), meta.data_ptr<int16_t>(), scale_packed.data_ptr(), reinterpret_cast<int*>(flag_dev), 0,
                                    reinterpret_cast<void*>(stream));
-        if (status == 0) status = g_abi.stream_wait(reinterpret_cast<void*>(stream));
+        // the verdict is final only when the whole launch has completed.  hipStreamSynchronize waits on the queue's completion signal itself; a
+        // spin on hipStreamQuery (ct_stream_wait) sees it 3-4 us later (`profiles/r04_host_wait_forms.json`: 22.2 vs 17.8 us around a tiny kernel).
+        // An error from it is re-asked through ct_stream_wait, which reports it the C ABI's way.
+        if (status == 0 && !(g_wait_mode && g_abi.hip_stream_synchronize && g_abi.hip_stream_synchronize(reinterpret_cast<void*>(stream)) == 0))
+            status = g_abi.stream_wait(reinterpret_cast<void*>(stream));
         verdict = *word;
     }
     return py::make_tuple(status, verdict != 0, packed, meta, scale_packed);
@@ -574,5 +600,6 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("marlin24_w4_full", &marlin24_w4_full);
     mod.def("marlin24_compress_default", &marlin24_compress_default);
     mod.def("set_allow_cpu", [](bool v) { g_allow_cpu = v; });
+    mod.def("set_wait_mode", [](int v) { g_wait_mode = v; });
     mod.attr("ITEM_WORDS") = 10;
 }

@@ -901,6 +901,26 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
             assert seen["marlin"] == (2, 2, None, -1, 64, 256, 128, 1, 0, 77, 0)  # the verdict word was cleared before the launch; the kernel only ORs into it
             assert packed.shape == (8, 128) and packed.dtype == torch.int32 and int(packed[0, 0]) == 7
             assert meta.shape == (8, 128) and meta.dtype == torch.int16 and sp.shape == (2, 64) and sp.dtype == torch.float16
+        # with the HIP runtime's own hipStreamSynchronize bound, the verdict waits on it; if it reports an error, ct_stream_wait is asked (and reports)
+        waits = {"sync": 0, "query": 0, "sync_rc": 0}
+
+        def sync(stream):
+            waits["sync"] += 1
+            return waits["sync_rc"]
+
+        def query_wait(stream):
+            waits["query"] += 1
+            return 0
+
+        cbs["hipStreamSynchronize"] = ctypes.CFUNCTYPE(I, V)(sync)
+        cbs["ct_stream_wait"] = ctypes.CFUNCTYPE(I, V)(query_wait)
+        hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and waits == {"sync": 1, "query": 0, "sync_rc": 0}
+        waits["sync_rc"] = 700
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 1)
+        hp.set_wait_mode(0)
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 2)
+        hp.set_wait_mode(1)
         # the same call from the state-dict entries on (Marlin24Compressor.compress): layout tests, element codes, group / permutation choice
         seen["violate"] = False
         D = hp.marlin24_compress_default

@@ -193,9 +193,11 @@ if what == "hostab":
 
     out = []
     for rnd in range(2):
-        for label, h in (("native", hp), ("python", None)):
+        for label, h, mode in (("native", hp, 1), ("native, waits through ct_mailbox_wait_i64 / ct_stream_wait only", hp, 0), ("python", None, 1)):
             _lib._HOSTPATH[0] = h
+            hp.set_wait_mode(mode)
             out.append({"host": label, "from_dense_us": [round(v, 2) for v in B.time_calls(bm)], "marlin_default_us": [round(v, 2) for v in B.time_calls(m24)]})
+        hp.set_wait_mode(1)
         _lib._HOSTPATH[0] = hp
         out.append({"model_ms": model_ms()})
     for o in out:
