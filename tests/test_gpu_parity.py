@@ -940,6 +940,60 @@ def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
     assert torch.equal(v.cpu().view(torch.int16), rv.view(torch.int16)) and torch.equal(bm.cpu(), rbm) and torch.equal(ro.cpu(), rro)
 
 
+def test_waiting_calls_from_several_threads(cta, dev):
+    """the calls that wait for the device drop the GIL while they spin, so Python threads really are inside them at the same time: every
+    thread has its own mailbox word (`_lib.mailbox`: per thread and device), every call its own workspace, the launches share the default
+    stream — four threads x (sparse-bitmask compress of its own tensors, marlin-24 compress in default mode with and without a 2:4
+    violation), every result equal to what one thread gets"""
+    import threading
+
+    g = torch.Generator().manual_seed(9)
+    sets = []
+    for t in range(4):
+        ws = [(torch.randn(256 + 64 * t, 512, generator=g) * (torch.rand(256 + 64 * t, 512, generator=g) < 0.3 + 0.15 * t)).to(BF16).to(dev) for _ in range(3)]
+        w24 = torch.randn(128, 512, generator=g).to(BF16)
+        w24 = w24 * O.sparse24_mask(w24).to(BF16)
+        scale, zp = O.calculate_qparams_minmax(w24.to(F16), num_bits=4, group_size=128, symmetric=True)
+        sets.append((ws, {"weight": w24.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}))
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True))
+    dense = {"weight": torch.randn(128, 512, generator=g).to(BF16).to(dev), "weight_scale": sets[0][1]["weight_scale"], "weight_zero_point": sets[0][1]["weight_zero_point"]}
+
+    def work(t, rounds):
+        ws, sd = sets[t]
+        out = []
+        for r in range(rounds):
+            out.append([tuple(x.clone() for x in cta.codec.bitmask_compress(w)) for w in ws])
+            got = cta.Marlin24Compressor.compress(sd, scheme)
+            out.append([(got["weight_packed"].clone(), got["scale_packed"].clone(), got["meta"].clone())])
+            if (r + t) % 2:
+                with pytest.raises(ValueError, match="2:4 sparsity structure"):
+                    cta.Marlin24Compressor.compress(dense, scheme)
+        return out
+
+    want = [work(t, 1) for t in range(4)]
+    results, errors = [None] * 4, []
+
+    def run(t):
+        try:
+            torch.cuda.set_device(dev)
+            results[t] = work(t, 12)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        for k, group in enumerate(results[t]):
+            ref = want[t][k % 2]
+            for a, b in zip(group, ref):
+                for x, y in zip(a, b):
+                    assert x.shape == y.shape and torch.equal(x.view(torch.uint8) if x.is_floating_point() else x, y.view(torch.uint8) if y.is_floating_point() else y), (t, k)
+
+
 @pytest.mark.parametrize("shape", [(192, 1024), (64, 288), (128, 256)])
 @pytest.mark.parametrize("wdt", [BF16, F16])
 def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt, shape):
