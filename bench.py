@@ -1003,6 +1003,10 @@ def roofline_rows(result):
         if a.get("ms_both"):
             row("ModelCompressor.compress_model + decompress_model", "config 5 through the drop-in API (154-module tree), wall time", t["alg_bytes_all_ranks"], a["ms_both"] * 1e3,
                 api_over_kernels=a["api_over_kernels"])
+        aa = a.get("asymmetric") or {}
+        if aa.get("ms_both"):
+            row("ModelCompressor.compress_model + decompress_model (asymmetric scheme)", "config 5 with int8 zero points stored packed, drop-in API, wall time",
+                t["alg_bytes_all_ranks"], aa["ms_both"] * 1e3, api_over_kernels=aa["api_over_kernels"])
     q = leg("minmax_qparams")
     if q:
         row("qparams_absmax_kernel", "min-max observer int4 g128 8192x8192 bf16", q["alg_bytes"], q["us"])
@@ -1104,6 +1108,13 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max):
             api = tinyllama_api_leg(dev, mine, keep, best, fq)
         except Exception as e:
             api = {"error": repr(e)}
+        try:  # the same tree with the asymmetric scheme: its zero points ride a second table per direction (the C++ host loop takes these too)
+            fqa = codec.fake_quantize_tensor(wa0, sa0, za0, num_bits=BITS, strategy="group", group_size=GROUP)
+            a2 = tinyllama_api_leg(dev, mine, [(w, sa, za, None, None) for (w, _, _, _, _), (sa, za, _, _) in zip(keep, asym)], t_asym, fqa, symmetric=False)
+            api["asymmetric"] = {k: a2[k] for k in ("ms_both", "ms_both_min_max", "ms_host_until_compress_model_returns", "ms_host_until_decompress_model_returns",
+                                                    "ms_kernels_only", "api_over_kernels", "round_trip_equals_fake_quantize")}
+        except Exception as e:
+            api["asymmetric"] = {"error": repr(e)}
     return {"api": api, "workload": "TinyLlama-1.1B-shaped checkpoint (154 Linear modules, 1.94 GB bf16), W4A16 g128 compress + decompress, "
                         f"LPT module shards over {world} rank(s), no collectives",
             "modules_this_rank": len(mine), "alg_bytes_all_ranks": total_bytes, "rank0_share_of_bytes": round(my_bytes / total_bytes, 4),
@@ -1141,14 +1152,14 @@ def tinyllama_module_tree(mine, keep, scheme):
     return root
 
 
-def tinyllama_api_leg(dev, mine, keep, kernels_s, fq0):
+def tinyllama_api_leg(dev, mine, keep, kernels_s, fq0, symmetric=True):
     """ModelCompressor().compress_model(model) + .decompress_model(model) on the 154-module tree: WALL time, weights resident in HBM,
     median of 7 cycles after 2 warm-up cycles (reference model_compressors/model_compressor.py:138-207, utils/module.py:33-65).
     Everything the drop-in does is inside the timed region: the module walk, the format resolution, the table build and its upload,
     the output allocations, the two launches and the per-module parameter replacement."""
     import compressed_tensors_amd as cta
 
-    args = cta.QuantizationArgs(num_bits=BITS, group_size=GROUP, symmetric=True, strategy="group")
+    args = cta.QuantizationArgs(num_bits=BITS, group_size=GROUP, symmetric=symmetric, strategy="group")
     scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
     model = tinyllama_module_tree(mine, keep, scheme)
     mc = cta.ModelCompressor()

@@ -33,6 +33,7 @@ __all__ = [
     "unpack_bitmasks",
     "W4Batch",
     "launch_w4_words",
+    "launch_zp4_words",
     "w4_batch_eligible",
     "q8_batch_group",
     "zp4_batch",
@@ -653,6 +654,18 @@ def launch_w4_words(words: torch.Tensor, n: int, direction: str, dtype: torch.dt
         raise ValueError(_lib.last_error())
     table = _upload_table(words, device)
     call("ct_quant_pack_batch" if d == 0 else "ct_unpack_dequant_batch", table.data_ptr(), n, blocks, DT[dtype], _lib.stream_on(device))
+
+
+def launch_zp4_words(words: torch.Tensor, n: int, direction: str, device: torch.device) -> None:
+    """`zp4_batch` for a table that already exists as a flat CPU int64 tensor (src, 0, 0, dst, unpacked rows, cols, 0, 0, 0, 0 per item;
+    built by the C++ host loop): plan, upload, ONE `ct_zp4_pack_dim0_batch` launch on `device`'s current stream"""
+    if not n:
+        return
+    blocks = int(_lib.load().ct_zp4_batch_plan(words.data_ptr(), n))
+    if blocks < 0:
+        raise ValueError(_lib.last_error())
+    table = _upload_table(words, device)
+    call("ct_zp4_pack_dim0_batch", table.data_ptr(), n, blocks, 0 if direction == "pack" else 1, _lib.stream_on(device))
 
 
 _ITEM_WORDS = 10  # struct ct_w4_item of include/ct_hip.h in 64-bit words: 4 pointers, rows, cols, group, first_block, units, {upg_shift, upg}

@@ -41,19 +41,33 @@ def _launch_chunks(n: int):
 
 
 def _plain_w4_scheme(scheme):
-    """(is a symmetric int4 group / channel scheme without activation arguments, group size or 0 for channel-wise): the schemes whose
-    modules the C++ host loop takes (an asymmetric scheme's packed zero points, an activation scheme's extra zero-point names and
-    everything else stay with the Python loop)"""
+    """(is an int4 group / channel scheme without activation arguments, group size or 0 for channel-wise, stores packed zero points): the
+    schemes whose modules the C++ host loop takes (an activation scheme's extra zero-point names and everything else stay with the
+    Python loop)"""
     wa = scheme.weights
     if (wa is None or getattr(scheme, "input_activations", None) is not None or getattr(scheme, "output_activations", None) is not None
-            or not wa.symmetric or int(wa.num_bits) != 4 or enum_value(getattr(wa, "type", "int")) != "int"):
-        return False, -1
+            or int(wa.num_bits) != 4 or enum_value(getattr(wa, "type", "int")) != "int"):
+        return False, -1, False
     st = enum_value(wa.strategy)
+    asym = not wa.symmetric  # group / channel are exactly PACK_ZP_STRATS
     if st == "channel":
-        return True, 0
+        return True, 0, asym
     if st == "group" and getattr(wa, "group_size", None):
-        return True, int(wa.group_size)
-    return False, -1
+        return True, int(wa.group_size), asym
+    return False, -1, False
+
+
+_ASYMMETRIC = 1 << 40  # csrc/host/ct_hostpath.cpp: kAsymmetric
+
+
+def _compress_info(scheme) -> int:
+    ok, group, asym = _plain_w4_scheme(scheme)
+    return (group + (_ASYMMETRIC if asym else 0)) if ok else -1
+
+
+def _decompress_info(scheme) -> int:
+    ok, _, asym = _plain_w4_scheme(scheme)
+    return (2 if asym else 1) if ok else 0
 
 
 def _layout_kwargs(weights):
@@ -182,16 +196,17 @@ class PackedQuantizationCompressor(BaseCompressor):
 
         hp = _hostpath()
         if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
-            # the plain case — symmetric int4, parameters only, nn.Module's own attribute hooks — in C++: table rows, output allocations
+            # the plain case — int4 group / channel, parameters only, nn.Module's own attribute hooks — in C++: table rows, output allocations
             # and, after the launch, the parameter dictionaries; whatever it does not take comes back in `modules`
             modules = list(modules)
-            info = lambda scheme: _plain_w4_scheme(scheme)[1]  # asked once per distinct scheme object and chunk
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):  # the first launch leaves after a fifth of the planning, not after all of it
-                planned, back = hp.w4_plan_compress(modules[lo:hi], info)
+                planned, back = hp.w4_plan_compress(modules[lo:hi], _compress_info)  # (asked once per distinct scheme object and chunk)
                 rest += back
-                for (dev_index, code), (words, n, jobs) in planned.items():
-                    codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+                for (dev_index, code), (words, n, jobs, zp_words, zp_n) in planned.items():
+                    device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
+                    codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], device)
+                    codec.launch_zp4_words(zp_words, zp_n, "pack", device)  # the asymmetric modules' zero points: pack_to_int32(zp, 4, packed_dim=0)
                     pending.append(jobs)
             for jobs in pending:  # the parameter dictionaries, under the kernels
                 hp.w4_finish_compress(jobs, QuantizationStatus.COMPRESSED)
@@ -332,13 +347,14 @@ class PackedQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         hp = _hostpath()
         if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
-            info = lambda scheme: int(_plain_w4_scheme(scheme)[0])
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):
-                planned, back = hp.w4_plan_decompress(modules[lo:hi], info)
+                planned, back = hp.w4_plan_decompress(modules[lo:hi], _decompress_info)
                 rest += back
-                for (dev_index, code), (words, n, jobs) in planned.items():
-                    codec.launch_w4_words(words, n, "decompress", _DTYPE_OF_CODE[code], torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu"))
+                for (dev_index, code), (words, n, jobs, zp_words, zp_n) in planned.items():
+                    device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
+                    codec.launch_zp4_words(zp_words, zp_n, "unpack", device)  # first: the weights' table points at the unpacked zero points
+                    codec.launch_w4_words(words, n, "decompress", _DTYPE_OF_CODE[code], device)
                     pending.append(jobs)
             for jobs in pending:
                 hp.w4_finish_decompress(jobs, QuantizationStatus.DECOMPRESSED)

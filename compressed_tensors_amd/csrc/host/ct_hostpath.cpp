@@ -14,7 +14,7 @@
 // 30-42 us kernel.
 //
 // A module that is anything but the plain case (a buffer among its entries, a trainable parameter that stays, a class with its own
-// __setattr__, an asymmetric scheme, activation ordering, an unusual layout) is handed back untouched in `rest`; the Python path,
+// __setattr__, activation arguments, activation ordering, an unusual layout) is handed back untouched in `rest`; the Python path,
 // which covers every case, takes it.  The Python path is also what runs when this extension has not been built.
 #include <torch/csrc/autograd/python_variable.h>
 #include <torch/extension.h>
@@ -197,22 +197,31 @@ bool dict_has(PyObject* module, PyObject* name) {
 }
 
 struct Batch {
-    std::vector<int64_t> words;  // 10 per item: struct ct_w4_item
+    std::vector<int64_t> words;     // 10 per item: struct ct_w4_item
+    std::vector<int64_t> zp_words;  // the same layout, one item per ASYMMETRIC module: its zero points through ct_zp4_pack_dim0_batch
     py::list jobs;
-    int n = 0;
+    int n = 0, zp_n = 0;
 };
+
+at::Tensor words_tensor(const std::vector<int64_t>& v) {
+    at::Tensor t = at::empty({(int64_t)v.size()}, at::TensorOptions().dtype(at::kLong));
+    if (!v.empty()) std::memcpy(t.data_ptr(), v.data(), v.size() * sizeof(int64_t));
+    return t;
+}
 
 py::dict batches_to_python(std::map<std::pair<int, int>, Batch>& batches) {
     py::dict out;
     for (auto& kv : batches) {
-        at::Tensor words = at::empty({(int64_t)kv.second.words.size()}, at::TensorOptions().dtype(at::kLong));
-        std::memcpy(words.data_ptr(), kv.second.words.data(), kv.second.words.size() * sizeof(int64_t));
-        out[py::make_tuple(kv.first.first, kv.first.second)] = py::make_tuple(words, kv.second.n, kv.second.jobs);
+        const Batch& b = kv.second;
+        out[py::make_tuple(kv.first.first, kv.first.second)] = py::make_tuple(words_tensor(b.words), b.n, b.jobs, words_tensor(b.zp_words), b.zp_n);
     }
     return out;
 }
 
-// infos[i]: group size of module i's scheme (0 = channel-wise), or < 0 when the scheme is not a symmetric int4 group / channel scheme
+// infos[i]: group size of module i's scheme (0 = channel-wise), + kAsymmetric when the scheme stores packed zero points
+// (pack_to_int32(zp, 4, packed_dim=0), pack_quantized/base.py:107-110), or < 0 when the scheme is not an int4 group / channel scheme
+constexpr int64_t kAsymmetric = int64_t(1) << 40;
+
 py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
     touch_tls();
     std::map<std::pair<int, int>, Batch> batches;  // (device index, dtype code 1 = fp16 / 2 = bf16) -> table
@@ -221,7 +230,9 @@ py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
     const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
-        const int64_t ginfo = infos.of(m, i);
+        const int64_t info = infos.of(m, i);
+        const bool asym = info >= kAsymmetric;
+        const int64_t ginfo = asym ? info - kAsymmetric : info;
         Entries e;
         bool ok = ginfo >= 0 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
         const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
@@ -242,7 +253,7 @@ py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
                  scale->size(1) == cols / group;
             if (ok && zp)
                 ok = zp->scalar_type() == at::kChar && zp->sizes() == scale->sizes() && zp->is_contiguous() && aligned16(*zp) && zp->device() == w->device();
-            ok = ok && staying_entries_are_final(e, {N.weight, N.weight_zero_point});
+            ok = ok && (zp || !asym) && staying_entries_are_final(e, {N.weight, N.weight_zero_point});
         }
         if (!ok) {
             rest.append(py::reinterpret_borrow<py::object>(m));
@@ -254,14 +265,24 @@ py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
                                   (int64_t)(uintptr_t)packed.data_ptr(), rows, cols, group, 0, 0, 0};
         b.words.insert(b.words.end(), item, item + 10);
         b.n += 1;
+        py::object zp_packed = py::none(), zp_ref = py::none();
+        if (asym) {  // int8 (R, G) -> int32 (ceil(R / 8), G), one more launch for all of them
+            at::Tensor zpp = at::empty({(rows * 4 + 31) / 32, zp->size(1)}, w->options().dtype(at::kInt));
+            const int64_t zitem[10] = {(int64_t)(uintptr_t)zp->data_ptr(), 0, 0, (int64_t)(uintptr_t)zpp.data_ptr(), rows, zp->size(1), 0, 0, 0, 0};
+            b.zp_words.insert(b.zp_words.end(), zitem, zitem + 10);
+            b.zp_n += 1;
+            zp_packed = py::reinterpret_steal<py::object>(THPVariable_Wrap(zpp));
+            zp_ref = py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_zero_point));
+        }
         // the job keeps the inputs alive until the launch has been issued (the table holds raw pointers)
         b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(packed)), rows, cols,
-                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight))));
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)), zp_packed, zp_ref));
     }
     return py::make_tuple(batches_to_python(batches), rest);
 }
 
-// after the launch: `weight` (and the zero point a symmetric scheme does not store) leave, `weight_packed` and `weight_shape` arrive
+// after the launch: `weight` (and the zero point a symmetric scheme does not store) leave, `weight_packed` and `weight_shape` arrive, an asymmetric
+// scheme's zero point is replaced by its packed form
 void w4_finish_compress(py::list jobs, py::object status) {
     touch_tls();
     const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
@@ -272,18 +293,21 @@ void w4_finish_compress(py::list jobs, py::object status) {
         const int64_t rows = PyLong_AsLongLong(PyTuple_GET_ITEM(job, 2)), cols = PyLong_AsLongLong(PyTuple_GET_ITEM(job, 3));
         Entries e;
         if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        PyObject* zp_packed = PyTuple_GET_ITEM(job, 5);
         drop(e.params, N.weight);
-        drop(e.params, N.weight_zero_point);
+        if (zp_packed == Py_None) drop(e.params, N.weight_zero_point);  // a symmetric scheme stores none (compressors/base.py: symmetric_zp_keys)
         at::Tensor shape = at::empty({2}, at::TensorOptions().dtype(at::kLong));  // int64, CPU: as upstream (pack_quantized/base.py:105)
         shape.data_ptr<int64_t>()[0] = rows;
         shape.data_ptr<int64_t>()[1] = cols;
         PyDict_SetItem(e.params, N.weight_packed, make_parameter(packed).ptr());
         PyDict_SetItem(e.params, N.weight_shape, make_parameter(shape).ptr());
+        if (zp_packed != Py_None) PyDict_SetItem(e.params, N.weight_zero_point, make_parameter(THPVariable_Unpack(zp_packed)).ptr());  // in place: same position
         set_status(m, status.ptr());
     }
 }
 
-// infos[i]: 1 when module i's scheme is a symmetric int4 scheme (the strategy is inferred from the scale's shape, as `dequantize` does), else 0
+// infos[i]: 1 when module i's scheme is a symmetric int4 scheme (the strategy is inferred from the scale's shape, as `dequantize` does), 2 when it is
+// an asymmetric int4 group / channel scheme (zero points stored packed along rows), else 0
 py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
     touch_tls();
     std::map<std::pair<int, int>, Batch> batches;
@@ -292,16 +316,19 @@ py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
     const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
         PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
-        const bool scheme_ok = infos.of(m, i) == 1;
+        const int64_t info = infos.of(m, i);
+        const bool scheme_ok = info == 1 || info == 2, asym = info == 2;
         Entries e;
         bool ok = scheme_ok && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
-        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr;
+        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr, *zpp = nullptr;
         int64_t rows = 0, cols = 0, group = 0;
         if (ok) {
             packed = e.tensor(N.weight_packed);
             scale = e.tensor(N.weight_scale);
             shape_t = e.tensor(N.weight_shape);
-            ok = packed && scale && shape_t && !e.has(N.weight_g_idx) && !e.has(N.weight_zero_point) && !e.has(N.weight) && (packed->is_cuda() || g_allow_cpu) &&
+            zpp = e.tensor(N.weight_zero_point);
+            ok = packed && scale && shape_t && !e.has(N.weight_g_idx) && (asym ? zpp != nullptr : !e.has(N.weight_zero_point)) && !e.has(N.weight) &&
+                 (packed->is_cuda() || g_allow_cpu) &&
                  packed->is_contiguous() && packed->scalar_type() == at::kInt && aligned16(*packed) && packed->dim() == 2 && scale->dim() == 2 &&
                  half_type(scale->scalar_type()) && scale->is_contiguous() && aligned16(*scale) && scale->device() == packed->device() &&
                  shape_t->device().is_cpu() && shape_t->scalar_type() == at::kLong && shape_t->numel() == 2 && shape_t->is_contiguous();
@@ -314,7 +341,10 @@ py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
         if (ok) {
             group = scale->size(1) == 1 ? cols : cols / scale->size(1);  // (R, 1): channel; (R, G): group (forward.py:99-130)
             ok = cols % 32 == 0 && group % 32 == 0 && cols % group == 0 && scale->size(0) == rows && scale->size(1) == cols / group && packed->size(0) == rows &&
-                 packed->size(1) == cols / 8 && staying_entries_are_final(e, {N.weight_packed});
+                 packed->size(1) == cols / 8 && staying_entries_are_final(e, {N.weight_packed, N.weight_zero_point});
+            if (ok && asym)
+                ok = zpp->scalar_type() == at::kInt && zpp->dim() == 2 && zpp->size(0) == (rows * 4 + 31) / 32 && zpp->size(1) == scale->size(1) &&
+                     zpp->is_contiguous() && zpp->device() == packed->device();
         }
         if (!ok) {
             rest.append(py::reinterpret_borrow<py::object>(m));
@@ -322,12 +352,23 @@ py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
         }
         at::Tensor out = at::empty({rows, cols}, scale->options());
         Batch& b = batches[{packed->is_cuda() ? (int)packed->device().index() : -1, scale->scalar_type() == at::kHalf ? 1 : 2}];
-        const int64_t item[10] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), 0, (int64_t)(uintptr_t)out.data_ptr(), rows, cols,
+        py::object zp_obj = py::none(), zpp_ref = py::none();
+        int64_t zp_ptr = 0;
+        if (asym) {  // int32 (ceil(R / 8), G) -> int8 (R, G): unpacked by the launch that runs BEFORE the weights' (the table below points at it)
+            at::Tensor zp = at::empty({rows, scale->size(1)}, packed->options().dtype(at::kChar));
+            const int64_t zitem[10] = {(int64_t)(uintptr_t)zpp->data_ptr(), 0, 0, (int64_t)(uintptr_t)zp.data_ptr(), rows, scale->size(1), 0, 0, 0, 0};
+            b.zp_words.insert(b.zp_words.end(), zitem, zitem + 10);
+            b.zp_n += 1;
+            zp_ptr = (int64_t)(uintptr_t)zp.data_ptr();
+            zp_obj = py::reinterpret_steal<py::object>(THPVariable_Wrap(zp));
+            zpp_ref = py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_zero_point));
+        }
+        const int64_t item[10] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp_ptr, (int64_t)(uintptr_t)out.data_ptr(), rows, cols,
                                   group, 0, 0, 0};
         b.words.insert(b.words.end(), item, item + 10);
         b.n += 1;
         b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
-                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_packed))));
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_packed)), zp_obj, zpp_ref));
     }
     return py::make_tuple(batches_to_python(batches), rest);
 }
@@ -341,8 +382,10 @@ void w4_finish_decompress(py::list jobs, py::object status) {
         const at::Tensor& out = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));
         Entries e;
         if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        PyObject* zp = PyTuple_GET_ITEM(job, 3);
         drop(e.params, N.weight_packed);
         PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
+        if (zp != Py_None) PyDict_SetItem(e.params, N.weight_zero_point, make_parameter(THPVariable_Unpack(zp)).ptr());  // unpacked, int8, in place
         set_status(m, status.ptr());
     }
 }

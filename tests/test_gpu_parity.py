@@ -1214,7 +1214,7 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
 
     hp = pq._hostpath()
     assert hp is not None, "compressed_tensors_amd/_hostpath.so is missing: the batched module paths fell back to the Python loop"
-    taken = {"compress": 0, "decompress": 0}
+    taken, zp_tables = {"compress": 0, "decompress": 0}, {"compress": 0, "decompress": 0}
 
     class Counting:
         def __getattr__(self, name):
@@ -1222,7 +1222,8 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
             if name in ("w4_plan_compress", "w4_plan_decompress"):
                 def counted(modules, infos, _fn=fn, _k=name.rsplit("_", 1)[1]):
                     planned, rest = _fn(modules, infos)
-                    taken[_k] += sum(n for _, n, _ in planned.values())
+                    taken[_k] += sum(t[1] for t in planned.values())
+                    zp_tables[_k] += sum(t[4] for t in planned.values())
                     return planned, rest
                 return counted
             return fn
@@ -1243,8 +1244,9 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
         cta.ModelCompressor().decompress_model(model)
     finally:
         ctlib._HOSTPATH[0] = hp
-    # symmetric: modules 0-3 are plain int4 group / channel modules -> the C++ loop; asymmetric schemes stay with the Python loop
-    assert taken == ({"compress": 4, "decompress": 4} if symmetric else {"compress": 0, "decompress": 0}), taken
+    # modules 0-3 are plain int4 group / channel modules -> the C++ loop, symmetric or not; an asymmetric scheme's zero points ride a second table
+    assert taken == {"compress": 4, "decompress": 4}, taken
+    assert zp_tables == ({"compress": 0, "decompress": 0} if symmetric else {"compress": 4, "decompress": 4}), zp_tables
     for a, b in zip(model, ref):
         assert eq(a.weight.data.cpu(), b.weight.data.cpu()) and a.weight.dtype == b.weight.dtype
 

@@ -742,7 +742,7 @@ def _tree(cta, scheme, shapes, *, trainable_scale=False, buffer_zp=False, odd_cl
     return root
 
 
-@pytest.mark.parametrize("variant", ["plain", "trainable_scale", "buffer_zp", "odd_class", "g_idx"])
+@pytest.mark.parametrize("variant", ["plain", "trainable_scale", "buffer_zp", "odd_class", "g_idx", "asymmetric", "asymmetric_buffer_zp"])
 def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
     """csrc/host/ct_hostpath.cpp (the per-module loop of PackedQuantizationCompressor.compress_modules / decompress_modules in C++) against
     the Python loop it replaces, on CPU tensors with the two launches stubbed out: the same table (pointers, shapes, groups), the
@@ -758,10 +758,12 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
 
     hp = pq._hostpath()
     assert hp is not None, "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
-    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    asym = variant.startswith("asymmetric")
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=not asym, strategy="group")
     scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
-    shapes = [(64, 256), (32, 512), (96, 128), (64, 384), (16, 256)]
-    a = _tree(cta, scheme, shapes, **({} if variant == "plain" else {variant: True}))
+    shapes = [(64, 256), (32, 512), (96, 128), (64, 384), (20, 256)]  # (20 rows: the packed zero points round up to 3 rows)
+    flags = {"plain": {}, "asymmetric": {}, "asymmetric_buffer_zp": {"buffer_zp": True}}.get(variant, {variant: True})
+    a = _tree(cta, scheme, shapes, **flags)
     b = copy.deepcopy(a)
     for x, y in zip(a.modules(), b.modules()):
         if hasattr(x, "quantization_scheme"):
@@ -783,7 +785,20 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
             if self.rec[2]:
                 tables[which["now"]].append(self.rec)
 
+    def fake_zp_words(words, n, direction, device):
+        if n:
+            tables[which["now"]].append(("zp-" + direction, None, words.reshape(n, 10)[:, 4:6].tolist()))
+
+    def fake_zp_batch(pairs, direction):
+        pairs = list(pairs)
+        if pairs:
+            tables[which["now"]].append(("zp-" + direction, None, [list((src if direction == "pack" else dst).shape) for src, dst in pairs]))
+
     monkeypatch.setattr(codec, "launch_w4_words", fake_words)
+    monkeypatch.setattr(codec, "launch_zp4_words", fake_zp_words)
+    monkeypatch.setattr(codec, "zp4_batch", fake_zp_batch)
+    monkeypatch.setattr(codec, "pack_to_int32", lambda zp, bits, packed_dim=1: torch.zeros((zp.shape[0] * 4 + 31) // 32, zp.shape[1], dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_from_int32", lambda p, bits, shape, packed_dim=1: torch.zeros(tuple(shape), dtype=torch.int8))
     monkeypatch.setattr(codec, "W4Batch", FakeBatch)
     monkeypatch.setattr(codec, "quantize_and_pack", lambda w, *a_, **k: torch.zeros(w.shape[0], w.shape[1] // 8, dtype=torch.int32))
     monkeypatch.setattr(codec, "unpack_and_dequantize", lambda p, shape, scale, *a_, **k: torch.zeros(shape, dtype=scale.dtype))
@@ -797,7 +812,10 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
         monkeypatch.setattr(ctlib, "_HOSTPATH", [None])  # the Python loop alone
         pq.PackedQuantizationCompressor.compress_modules(mods_b)
         monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
-        n_plain = {"plain": 5, "trainable_scale": 4, "buffer_zp": 4, "odd_class": 4, "g_idx": 4}[variant]
+        n_plain = {"plain": 5, "trainable_scale": 4, "buffer_zp": 4, "odd_class": 4, "g_idx": 4, "asymmetric": 5, "asymmetric_buffer_zp": 4}[variant]
+        if asym:  # every zero point packed by a batched launch (the C++ loop's, plus the Python loop's for what was handed back), and stored packed
+            assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "zp-pack") == len(mods_a)
+            assert all(x.weight_zero_point.dtype == torch.int32 and x.weight_zero_point.shape == ((x.out_features * 4 + 31) // 32, x.in_features // 128) for x in mods_a)
         assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "compress") >= n_plain - 0
         for x, y in zip(mods_a, mods_b):
             assert _module_state_no_ptr(x) == _module_state_no_ptr(y), variant
@@ -812,9 +830,14 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
             assert _module_state_no_ptr(x) == _module_state_no_ptr(y), variant
             assert x.quantization_status == QuantizationStatus.DECOMPRESSED == y.quantization_status
             assert x.weight.shape == (x.out_features, x.in_features) and x.weight.dtype == torch.bfloat16
+            if asym:
+                assert x.weight_zero_point.dtype == torch.int8 and x.weight_zero_point.shape == (x.out_features, x.in_features // 128)
         # the same work reached the launches, whichever loop built the table
         flat = lambda ts, d: sorted(tuple(r) for t in ts if t[0] == d for r in t[2])
-        for d in ("compress", "decompress"):
+        if asym:  # the zero points are unpacked BEFORE the weights' launch that reads them
+            order = [t[0] for t in tables["cpp"] if t[0] in ("zp-unpack", "decompress")]
+            assert order[:2] == ["zp-unpack", "decompress"], order
+        for d in ("compress", "decompress", "zp-pack", "zp-unpack"):
             assert flat(tables["cpp"], d) == flat(tables["py"], d), (variant, d)
     finally:
         hp.set_allow_cpu(False)

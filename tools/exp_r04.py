@@ -133,13 +133,13 @@ if what == "hostmodel":
     infos = [128] * len(ms)
     t_plan, (planned, rest) = med(lambda: hp.w4_plan_compress(ms, infos), n=1)
     out["w4_plan_compress (one call: allocates 154 outputs)"] = t_plan
-    (key, (words, n, jobs)), = planned.items()
+    (key, (words, n, jobs, _zw, _zn)), = planned.items()
     out["launch_w4_words compress (plan + pinned upload + launch)"], _ = med(lambda: codec.launch_w4_words(words, n, "compress", torch.bfloat16, dev), n=5)
     t0 = time.perf_counter(); hp.w4_finish_compress(jobs, QuantizationStatus.COMPRESSED); out["w4_finish_compress"] = round((time.perf_counter() - t0) * 1e6, 1)
     torch.cuda.synchronize()
     t_plan, (planned, rest) = med(lambda: hp.w4_plan_decompress(ms, [1] * len(ms)), n=1)
     out["w4_plan_decompress"] = t_plan
-    (key, (words, n, jobs)), = planned.items()
+    (key, (words, n, jobs, _zw, _zn)), = planned.items()
     out["launch_w4_words decompress"], _ = med(lambda: codec.launch_w4_words(words, n, "decompress", torch.bfloat16, dev), n=5)
     t0 = time.perf_counter(); hp.w4_finish_decompress(jobs, QuantizationStatus.DECOMPRESSED); out["w4_finish_decompress"] = round((time.perf_counter() - t0) * 1e6, 1)
     torch.cuda.synchronize()
