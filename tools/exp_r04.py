@@ -202,3 +202,35 @@ if what == "hostab":
         out.append({"model_ms": model_ms()})
     for o in out:
         print(json.dumps(o))
+if what == "asymab":
+    # ModelCompressor on the 154-module tree with the ASYMMETRIC int4 scheme: C++ host loop against the Python loop, A / B / A / B on one lease
+    import compressed_tensors_amd as cta
+
+    hp = _lib.hostpath()
+    args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    g = torch.Generator(device=dev).manual_seed(4)
+    mods, kp = [(f"model.layers.{l}.{n}", r, c) for l in range(22) for (n, r, c) in B.TINYLLAMA_LAYER], []
+    for _, r, c in mods:
+        w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+        s_, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=False)
+        kp.append((w, s_, z, None, None))
+    model = B.tinyllama_module_tree(mods, kp, scheme)
+    mc = cta.ModelCompressor()
+
+    def model_ms(n=7):
+        ts = []
+        for k in range(n + 2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            mc.compress_model(model); torch.cuda.synchronize(); t1 = time.perf_counter()
+            mc.decompress_model(model); torch.cuda.synchronize(); t2 = time.perf_counter()
+            if k >= 2:
+                ts.append(((t2 - t0) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+        med = lambda j: round(sorted(t[j] for t in ts)[len(ts) // 2], 4)
+        return {"both": med(0), "compress": med(1), "decompress": med(2)}
+
+    for rnd in range(2):
+        for label, h in (("C++ host loop", hp), ("Python loop", None)):
+            _lib._HOSTPATH[0] = h
+            print(json.dumps({"host": label, "asymmetric_model_ms": model_ms()}))
+    _lib._HOSTPATH[0] = hp
