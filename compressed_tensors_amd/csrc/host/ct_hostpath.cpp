@@ -122,7 +122,10 @@ struct Infos {
         if (it != cache.end()) v = it->second;
         else {
             PyObject* r = PyObject_CallFunctionObjArgs(src, scheme, nullptr);
-            if (!r) throw py::error_already_set();
+            if (!r) {
+                Py_DECREF(scheme);
+                throw py::error_already_set();
+            }
             v = PyLong_AsLongLong(r);
             Py_DECREF(r);
             cache.emplace(scheme, v);  // (the module keeps the scheme alive for the duration of the call)
