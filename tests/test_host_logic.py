@@ -961,3 +961,121 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
         hp.set_allow_cpu(False)
         ctlib._HOSTPATH.clear()  # the next hostpath() binds the real entries again
         assert ctlib.hostpath() is hp
+
+
+def test_cpp_host_loop_fuzz_against_the_python_loop(cta, monkeypatch):
+    """random module trees — symmetric / asymmetric, group / channel / odd group sizes, zero points present / absent / as buffers / of the
+    wrong dtype, trainable scales, classes with their own __setattr__, activation ordering, fp32 weights, ragged shapes, activation
+    schemes, already-compressed modules — through compress_modules + decompress_modules with the C++ loop in front and with the Python
+    loop alone: every module must end in the same state (names, order, kinds, trainability, shapes, dtypes, status) and the same work
+    must reach the launches.  CPU tensors, launches stubbed: this is about the host logic that decides and rewrites."""
+    import copy
+    import random
+
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.compressors.pack_quantized import base as pq
+
+    hp = ctlib.hostpath()
+    assert hp is not None
+    tables = {"cpp": [], "py": []}
+    which = {"now": "cpp"}
+    rec = lambda *t: tables[which["now"]].append(t)
+    monkeypatch.setattr(codec, "launch_w4_words", lambda words, n, direction, dtype, device: n and rec(direction, sorted(map(tuple, words.reshape(n, 10)[:, 4:7].tolist()))))
+    monkeypatch.setattr(codec, "launch_zp4_words", lambda words, n, direction, device: n and rec("zp-" + direction, sorted(map(tuple, words.reshape(n, 10)[:, 4:6].tolist()))))
+    monkeypatch.setattr(codec, "zp4_batch", lambda pairs, direction: (lambda ps: ps and rec("zp-" + direction, sorted(tuple((s if direction == "pack" else d).shape) for s, d in ps)))(list(pairs)))
+
+    class FakeBatch:
+        def __init__(self, entries, direction, dtype, kind="w4", bits=8):
+            self.rec = (direction, sorted((int(e[4]), int(e[5]), int(e[6])) for e in entries))
+
+        def launch(self, stream=None):
+            if self.rec[1]:
+                rec(*self.rec)
+
+    monkeypatch.setattr(codec, "W4Batch", FakeBatch)
+    monkeypatch.setattr(codec, "pack_to_int32", lambda v, bits, packed_dim=1: torch.zeros(((v.shape[0] * bits + 31) // 32, v.shape[1]) if packed_dim == 0 else (v.shape[0], (v.shape[1] * bits + 31) // 32), dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_from_int32", lambda p, bits, shape, packed_dim=1: torch.zeros(tuple(shape), dtype=torch.int8))
+    monkeypatch.setattr(codec, "quantize_and_pack", lambda w, *a_, **k: torch.zeros(w.shape[0], (w.shape[1] * 4 + 31) // 32, dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_and_dequantize", lambda p, shape, scale, *a_, **k: torch.zeros(tuple(shape), dtype=scale.dtype))
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+
+    class Odd(torch.nn.Linear):
+        def __setattr__(self, name, value):
+            super().__setattr__(name, value)
+
+    rng = random.Random(20260927)
+
+    def build():
+        schemes = []
+        for _ in range(rng.randint(1, 3)):
+            sym = rng.random() < 0.5
+            if rng.random() < 0.25:
+                wa = cta.QuantizationArgs(num_bits=4, symmetric=sym, strategy="channel")
+            else:
+                wa = cta.QuantizationArgs(num_bits=4, group_size=rng.choice([32, 64, 128, 128, 40]), symmetric=sym, strategy="group")
+            ia = cta.QuantizationArgs(num_bits=8, symmetric=True, strategy="tensor") if rng.random() < 0.1 else None
+            schemes.append(cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=ia))
+        root = torch.nn.Module()
+        root.blocks = torch.nn.ModuleList()
+        for _ in range(rng.randint(1, 9)):
+            scheme = rng.choice(schemes)
+            wa = scheme.weights
+            g = wa.group_size if wa.strategy == "group" else None
+            r = rng.choice([16, 20, 32, 64])
+            c = rng.choice([128, 256, 384, 640]) if rng.random() < 0.9 else 96
+            if g and c % g:
+                c = g * rng.randint(1, 4)
+            wdt = torch.float32 if rng.random() < 0.08 else rng.choice([torch.bfloat16, torch.float16])
+            lin = (Odd if rng.random() < 0.08 else torch.nn.Linear)(c, r, bias=rng.random() < 0.2, device="meta")
+            if lin.bias is not None:
+                lin.bias = torch.nn.Parameter(torch.zeros(r, dtype=wdt))
+            lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=wdt), requires_grad=rng.random() < 0.5)
+            cols = c // g if g else 1
+            lin.weight_scale = torch.nn.Parameter(torch.ones(r, cols, dtype=wdt), requires_grad=rng.random() < 0.1)
+            zp = torch.zeros(r, cols, dtype=torch.int8 if rng.random() < 0.92 else torch.int32)
+            roll = rng.random()
+            if roll < 0.1:
+                lin.register_buffer("weight_zero_point", zp)
+            elif roll < 0.9 or not wa.symmetric:
+                lin.weight_zero_point = torch.nn.Parameter(zp, requires_grad=False)
+            if rng.random() < 0.06:
+                lin.weight_g_idx = torch.nn.Parameter(torch.arange(c, dtype=torch.int32) // (g or c), requires_grad=False)
+            lin.quantization_scheme = scheme
+            blk = torch.nn.Module()
+            blk.proj = lin
+            root.blocks.append(blk)
+        return root
+
+    def state(m):
+        return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
+                [(k, None if v is None else (type(v).__name__, tuple(v.shape), v.dtype)) for k, v in m._buffers.items()], getattr(m, "quantization_status", None))
+
+    hp.set_allow_cpu(True)
+    taken = 0
+    try:
+        for trial in range(150):
+            a = build()
+            b = copy.deepcopy(a)
+            for x, y in zip(a.modules(), b.modules()):
+                if hasattr(x, "quantization_scheme"):
+                    y.quantization_scheme = x.quantization_scheme
+            ma = [m for m in a.modules() if isinstance(m, torch.nn.Linear)]
+            mb = [m for m in b.modules() if isinstance(m, torch.nn.Linear)]
+            for step in ("compress_modules", "decompress_modules"):
+                tables["cpp"].clear(); tables["py"].clear()
+                which["now"] = "cpp"
+                monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
+                getattr(pq.PackedQuantizationCompressor, step)(ma)
+                taken += sum(len(t[1]) for t in tables["cpp"] if t[0] in ("compress", "decompress"))
+                which["now"] = "py"
+                monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
+                getattr(pq.PackedQuantizationCompressor, step)(mb)
+                for x, y in zip(ma, mb):
+                    assert state(x) == state(y), (trial, step, state(x), state(y))
+                merged = lambda ts: {d: sorted(r for t in ts if t[0] == d for r in t[1]) for d in {t[0] for t in ts}}
+                assert merged(tables["cpp"]) == merged(tables["py"]), (trial, step)
+    finally:
+        hp.set_allow_cpu(False)
+        monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
+    assert taken > 300  # the batched launches really were exercised
