@@ -262,8 +262,16 @@ def hostpath():
     if not _HOSTPATH:
         try:
             from . import _hostpath as hp
-        except ImportError:
+        except ImportError as e:
             hp = None
+            # "file absent" is the documented optional case and stays quiet; anything else (a torch / CPython ABI mismatch of the
+            # prebuilt binary, a missing libtorch_python symbol) would silently cost the model API its C++ loop: say so, once
+            built = any(f.startswith("_hostpath.") and f.endswith(".so") for f in os.listdir(os.path.dirname(os.path.abspath(__file__))))
+            if built:
+                import warnings
+
+                warnings.warn(f"compressed_tensors_amd: _hostpath.so is present but did not import ({e!r}); the Python host loop is used "
+                              "instead (same results, more host time per module) — rebuild with __graft_entry__.build()", RuntimeWarning)
         if hp is not None:
             lib = load()
             # lib[name]: the symbol itself — `lib.name` may have been replaced by a launch-counting wrapper (tests/ref_suite)
@@ -278,6 +286,11 @@ def hostpath():
             hp.bind_abi(abi)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
+
+
+def host_path_kind() -> str:
+    """"native" when the C++ host loop is the one the plug-in classes run, "python" otherwise (bench.py prints it in its line)"""
+    return "native" if hostpath() is not None else "python"
 
 
 def stream_wait(stream) -> None:
