@@ -208,7 +208,23 @@ def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, acto
         oc = O.pack_quantized_compress(sd, num_bits=BITS, strategy="group", group_size=GROUP, symmetric=symmetric)
         od = O.pack_quantized_decompress(oc, num_bits=BITS, strategy="group", symmetric=symmetric)
         ok = ok and torch.equal(pk[sl].cpu(), oc["weight_packed"]) and torch.equal(out[sl].cpu().view(torch.int16), od["weight"].view(torch.int16))
-    return {"alg_bytes_per_direction": one, "sets": nsets,
+    pair = {}
+    if n <= 4096 and symmetric and not actorder and nsets >= 4:
+        # what a caller with q / k or gate / up PAIRS of this size has — `ct_quant_pack_batch` / `ct_unpack_dequant_batch`
+        # with n = 2 (codec.quantize_and_pack_many): two tensors per launch, tables prebuilt, HBM-cold rotation over the same sets
+        tabs_c, tabs_d = [], []
+        for j in range(0, nsets - 1, 2):
+            (w0, s0, _, p0, o0), (w1, s1, _, p1, o1) = sets[j], sets[j + 1]
+            tabs_c.append(codec.W4Batch([(w0, s0, None, p0, n, n, GROUP), (w1, s1, None, p1, n, n, GROUP)], "compress", dtype))
+            tabs_d.append(codec.W4Batch([(p0, s0, None, o0, n, n, GROUP), (p1, s1, None, o1, n, n, GROUP)], "decompress", dtype))
+        npair = len(tabs_c)
+        us_pc = time_kernel(lambda i: tabs_c[i % npair].launch(stream), iters)
+        us_pd = time_kernel(lambda i: tabs_d[i % npair].launch(stream), iters, offset=npair // 2)
+        ok = ok and torch.equal(sets[1][4], codec.fake_quantize_tensor(sets[1][0], sets[1][1], sets[1][2], num_bits=BITS, strategy="group", group_size=GROUP))
+        pair = {"pair_batch": {"entry": "ct_quant_pack_batch / ct_unpack_dequant_batch with n = 2 (codec.quantize_and_pack_many)", "alg_bytes_per_direction": 2 * one,
+                               "compress_us": round(us_pc, 2), "compress_frac_hbm": round(2 * one / us_pc / 1e3 / HBM_PEAK_GBPS, 4),
+                               "decompress_us": round(us_pd, 2), "decompress_frac_hbm": round(2 * one / us_pd / 1e3 / HBM_PEAK_GBPS, 4)}}
+    return {"alg_bytes_per_direction": one, "sets": nsets, **pair,
             "compress_us": round(us_c, 2), "compress_GBps": round(one / us_c / 1e3, 1), "compress_frac_hbm": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4),
             "decompress_us": round(us_d, 2), "decompress_GBps": round(one / us_d / 1e3, 1), "decompress_frac_hbm": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4),
             "compress_us_cache_warm": round(warm_c, 2), "decompress_us_cache_warm": round(warm_d, 2),
@@ -977,8 +993,11 @@ def roofline_rows(result):
             row("bitmask_decompress16_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, decompress", b["f32_alg_bytes"], b["f32_decompress_us"], bit_exact=b["f32_bit_exact"])
     k4 = leg("kernels_4096")
     if k4:
-        row("w4_quant_pack_lean_kernel<bf16>", "W4A16 g128 4096x4096 bf16, compress", k4["alg_bytes_per_direction"], k4["compress_us"])
-        row("w4_unpack_dequant_kernel<bf16>", "W4A16 g128 4096x4096 bf16, decompress", k4["alg_bytes_per_direction"], k4["decompress_us"])
+        pb = k4.get("pair_batch") or {}
+        pc = dict(pair_us=pb["compress_us"], pair_frac=pb["compress_frac_hbm"]) if pb else {}
+        pd = dict(pair_us=pb["decompress_us"], pair_frac=pb["decompress_frac_hbm"]) if pb else {}
+        row("w4_quant_pack_lean_kernel<bf16>", "W4A16 g128 4096x4096 bf16, compress", k4["alg_bytes_per_direction"], k4["compress_us"], **pc)
+        row("w4_unpack_dequant_kernel<bf16>", "W4A16 g128 4096x4096 bf16, decompress", k4["alg_bytes_per_direction"], k4["decompress_us"], **pd)
     ko = leg("kernels_other") or {}
     for key in ("fp16_8192", "bf16_8192_asymmetric", "bf16_8192_actorder"):
         v = ko.get(key)
@@ -993,7 +1012,7 @@ def roofline_rows(result):
     if m:
         row("marlin24_fused_w4_lean_kernel", "marlin-24 2:4 + int4 g128 8192x8192 bf16 (config 4), kernel", m["alg_bytes"], m["kernels_us"], bit_exact=m["bit_exact_vs_oracle"])
         row("Marlin24Compressor.compress (default: the call raises the 2:4 ValueError)", "config 4 through the plug-in class, wall time per call",
-            m["alg_bytes"], m["compress_us_default"], bit_exact=m["bit_exact_vs_oracle"])
+            m["alg_bytes"], m["compress_us_default"], bit_exact=m["bit_exact_vs_oracle"], deferred_check_us=m["compress_us_deferred_check"])
         row("Marlin24Compressor.compress (deferred_structure_check)", "config 4 through the plug-in class inside the batch context", m["alg_bytes"],
             m["compress_us_deferred_check"], bit_exact=m["bit_exact_vs_oracle"])
     t = leg("tinyllama_checkpoint")

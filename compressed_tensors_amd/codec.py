@@ -22,6 +22,8 @@ __all__ = [
     "fake_quantize_tensor",
     "quantize_and_pack",
     "unpack_and_dequantize",
+    "quantize_and_pack_many",
+    "unpack_and_dequantize_many",
     "minmax_qparams",
     "minmax_qparams_float",
     "generate_gparam",
@@ -721,6 +723,62 @@ class W4Batch:
             call("ct_q8_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), s)
 
 
+def quantize_and_pack_many(items, *, num_bits, strategy, group_size=None):
+    """`quantize_and_pack` for a LIST of (weight, scale, zero_point or None) on one GPU: the tensors a W4 batch takes (`w4_batch_eligible`:
+    int4, 2-D 16-bit weights, group / channel scales) leave in ONE `ct_quant_pack_batch` launch — what a caller holding q / k / v or
+    gate / up pairs should use instead of one call per tensor (a small tensor's single launch is bound by its ramp and its launch
+    boundary: 4096 x 4096 alone reaches 58-61 % of the HBM peak, bench.py reports the pair next to it) — and the others one by one.
+    Returns the packed int32 tensors in order.  Mirrors the loop body of compressors/pack_quantized/base.py:96-104 per item."""
+    items = [(x, s, z) for x, s, z in items]
+    out = [None] * len(items)
+    entries, where = [], []
+    for i, (x, s, z) in enumerate(items):
+        if (x.is_cuda and x.is_contiguous() and _aligned16(x)
+                and w4_batch_eligible(x.shape, x.dtype, s, z, num_bits=num_bits, strategy=strategy, group_size=group_size, device=x.device)
+                and (not entries or (x.device == entries[0][0].device and x.dtype == entries[0][0].dtype))):
+            rows, cols = int(x.shape[0]), int(x.shape[1])
+            group = cols if _strategy_name(strategy) == "channel" else int(group_size)
+            dst = torch.empty((rows, cols // 8), dtype=torch.int32, device=x.device)
+            entries.append((x, s, z, dst, rows, cols, group))
+            where.append(i)
+        else:
+            out[i] = quantize_and_pack(x, s, z, num_bits=num_bits, strategy=strategy, group_size=group_size)
+    if entries:
+        batch = W4Batch(entries, "compress", entries[0][0].dtype)
+        batch.launch()
+        batch.table.record_stream(torch.cuda.current_stream(batch.device))
+        for i, e in zip(where, entries):
+            out[i] = e[3]
+    return out
+
+
+def unpack_and_dequantize_many(items, *, num_bits, strategy, group_size=None):
+    """the inverse of `quantize_and_pack_many` for a list of (packed, shape, scale, zero_point or None): ONE `ct_unpack_dequant_batch`
+    launch for the eligible tensors (output dtype = the scale's), `unpack_and_dequantize` for the rest
+    (compressors/pack_quantized/base.py:147-161 per item; `zero_point` is the UNPACKED int8 zero point)."""
+    items = [(p, tuple(int(v) for v in shape), s, z) for p, shape, s, z in items]
+    out = [None] * len(items)
+    entries, where = [], []
+    for i, (p, shape, s, z) in enumerate(items):
+        if (p.is_cuda and p.dtype is torch.int32 and p.is_contiguous() and _aligned16(p) and len(shape) == 2
+                and w4_batch_eligible(shape, s.dtype, s, z, num_bits=num_bits, strategy=strategy, group_size=group_size, device=p.device)
+                and tuple(p.shape) == (shape[0], shape[1] // 8)
+                and (not entries or (p.device == entries[0][0].device and s.dtype == entries[0][1].dtype))):
+            group = shape[1] if _strategy_name(strategy) == "channel" else int(group_size)
+            dst = torch.empty(shape, dtype=s.dtype, device=p.device)
+            entries.append((p, s, z, dst, shape[0], shape[1], group))
+            where.append(i)
+        else:
+            out[i] = unpack_and_dequantize(p, shape, s, z, num_bits=num_bits, strategy=strategy, group_size=group_size)
+    if entries:
+        batch = W4Batch(entries, "decompress", entries[0][1].dtype)
+        batch.launch()
+        batch.table.record_stream(torch.cuda.current_stream(batch.device))
+        for i, e in zip(where, entries):
+            out[i] = e[3]
+    return out
+
+
 def zp4_batch(pairs, direction: str) -> None:
     """`pack_to_int32(zp, 4, packed_dim=0)` ("pack": int8 (R, G) -> int32 (ceil(R / 8), G)) or its inverse ("unpack") for a list of
     (src, dst) tensor pairs on one GPU in ONE launch (`ct_zp4_pack_dim0_batch`); dst tensors are allocated by the caller."""
@@ -874,6 +932,8 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
         mb.words[0] = -1
         call("ct_bitmask_compress", ptr(x), dt, rows, cols, ptr(buf), numel, ptr(bitmask), ptr(row_offsets), mb.dev, ptr(ws), ws_bytes, s)
         nnz = mb.wait_word(0, -1, s)
+        if nnz < 0 or nnz > numel:  # the stream drained and the word still holds the pending mark (or junk): never slice with it
+            raise RuntimeError(f"ct_bitmask_compress finished without reporting the number of non-zeros (mailbox word {nnz}, numel {numel})")
         # keep the view unless it pins more than ~5/8 of the worst-case buffer for nothing (at the 50 % sparsity of BASELINE config 3
         # nnz lands on either side of numel / 2: a `2 * nnz >= numel` rule cloned 67 MB on a coin flip), else release the slack
         values = buf[:nnz] if 8 * nnz >= 3 * numel else buf[:nnz].clone()

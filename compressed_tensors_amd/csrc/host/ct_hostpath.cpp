@@ -36,7 +36,8 @@ PyObject* g_make_subclass = nullptr;   // torch.Tensor._make_subclass
 PyObject* g_parameter_cls = nullptr;   // torch.nn.Parameter
 PyObject* g_module_setattr = nullptr;  // torch.nn.Module.__setattr__
 PyObject* g_module_delattr = nullptr;  // torch.nn.Module.__delattr__
-std::unordered_map<PyTypeObject*, bool> g_plain_type;
+struct PlainEntry { bool plain; unsigned int tag; };
+std::unordered_map<PyTypeObject*, PlainEntry> g_plain_type;
 // One thread-local word, touched on purpose (module init and every entry point).  glibc before 2.39 (BZ #19924; this image: 2.35): after a dlopen
 // of ANY library that carries a TLS segment, every `__tls_get_addr` of a thread — PyTorch makes dozens per tensor it creates or releases — takes the
 // dynamic linker's slow path until that thread has touched the TLS of the NEWEST such library; a process that has imported torch and friends is usually
@@ -70,15 +71,24 @@ struct Names {
 // does the module's class keep nn.Module's own attribute hooks?  (then writing `_parameters` directly cannot be told from setattr)
 bool plain_type(PyObject* module) {
     PyTypeObject* tp = Py_TYPE(module);
+    // keyed by the type object, which the table keeps alive (a freed type's address can be reused by another class), and validated by the
+    // type's version tag: CPython invalidates it whenever the class or one of its bases is modified (a later `Cls.__setattr__ = ...`)
+    const bool tagged = (tp->tp_flags & Py_TPFLAGS_VALID_VERSION_TAG) != 0;
     auto it = g_plain_type.find(tp);
-    if (it != g_plain_type.end()) return it->second;
-    PyObject* s = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.setattr);
+    if (it != g_plain_type.end() && tagged && it->second.tag == tp->tp_version_tag) return it->second.plain;
+    PyObject* s = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.setattr);  // (the lookup assigns a fresh version tag)
     PyObject* d = PyObject_GetAttr(reinterpret_cast<PyObject*>(tp), N.delattr);
     const bool plain = s && d && s == g_module_setattr && d == g_module_delattr;
     Py_XDECREF(s);
     Py_XDECREF(d);
     PyErr_Clear();
-    g_plain_type.emplace(tp, plain);
+    const unsigned int tag = (tp->tp_flags & Py_TPFLAGS_VALID_VERSION_TAG) ? tp->tp_version_tag : 0u;
+    if (it == g_plain_type.end()) {
+        Py_INCREF(tp);
+        g_plain_type.emplace(tp, PlainEntry{plain, tag});
+    } else {
+        it->second = PlainEntry{plain, tag};
+    }
     return plain;
 }
 

@@ -257,7 +257,7 @@ class CompressedTensorsDequantizer(Converter):
         if not (self.stream_results or getattr(_STREAMING, "on", False)):
             torch.cuda.current_stream(dev).synchronize()
             ready.clear()
-            del keep
+            keep.clear()  # the list lives on in the returned ReadyDict: empty it, or the pinned H2D staging stays alive for the shard's lifetime
         # remaining (ignored / untargeted) tensors pass through, KV-cache qparams are dropped
         for name, t in tensors.items():
             if name.endswith(KV_CACHE_PARAM_NAMES):

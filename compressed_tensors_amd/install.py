@@ -99,6 +99,13 @@ def make_hip_subclass(up_cls, amd_cls):
         def _ct_split(cls, modules, probe_names):
             ours, rest = [], []
             for m in modules:
+                # an upstream-OFFLOADED module keeps its tensors in an OffloadCache (a MutableMapping that onloads on access): probing
+                # it would pull the weight onto the GPU just to test `.is_cuda`, and the batched path would then hold EVERY module's
+                # onloaded tensors until the single launch — the whole model resident where upstream holds one module at a time.  Such
+                # modules take upstream's per-module path, untouched.
+                if not isinstance(m._parameters, dict) or not isinstance(m._buffers, dict):
+                    rest.append(m)
+                    continue
                 scheme = getattr(m, "quantization_scheme", None)
                 probe = None
                 for n in probe_names:
@@ -326,6 +333,7 @@ def _unwrap_model_compressor() -> None:
 
 
 _FN_REBOUND = []  # (module, attribute name, original function)
+_FN_SWAP = {}  # id(original function) -> (original, dispatching wrapper); lives from the first install(patch_functions=True) to uninstall()
 
 
 def _patch_functions() -> None:
@@ -379,18 +387,23 @@ def _patch_functions() -> None:
     def take_fake_quantize(x, scale, zero_point, args, g_idx=None, global_scale=None):
         return x.is_cuda and x.dim() == 2 and global_scale is None and simple_args(args) and x.dtype in floats and scale.dtype in floats
 
-    new = [
-        (up_helpers.pack_to_int32, dispatching(up_helpers.pack_to_int32, codec.pack_to_int32, take_pack)),
-        (up_helpers.unpack_from_int32, dispatching(up_helpers.unpack_from_int32, codec.unpack_from_int32, take_unpack)),
-        (up_forward.dequantize, dispatching(up_forward.dequantize, amd_forward.dequantize, take_dequantize)),
-        (up_forward.fake_quantize, dispatching(up_forward.fake_quantize, amd_forward.fake_quantize, take_fake_quantize)),
-    ]
-    swap = {id(o): (o, n) for o, n in new}
+    # every install(patch_functions=True) re-scans sys.modules (as _rebind_names does for the classes): an upstream module imported
+    # since the last call holds the ORIGINAL function under its own name and is covered now.  The wrappers are made once (ids of the
+    # originals -> wrapper); an attribute that already holds a wrapper is not in the table, so nothing is recorded twice.
+    if not _FN_SWAP:
+        def orig_of(fn):
+            return getattr(fn, "_ct_original", fn)
+
+        for orig, ours, take in ((orig_of(up_helpers.pack_to_int32), codec.pack_to_int32, take_pack),
+                                 (orig_of(up_helpers.unpack_from_int32), codec.unpack_from_int32, take_unpack),
+                                 (orig_of(up_forward.dequantize), amd_forward.dequantize, take_dequantize),
+                                 (orig_of(up_forward.fake_quantize), amd_forward.fake_quantize, take_fake_quantize)):
+            _FN_SWAP[id(orig)] = (orig, dispatching(orig, ours, take))
     for mod_name, mod in list(sys.modules.items()):
         if mod is None or not (mod_name == "compressed_tensors" or mod_name.startswith("compressed_tensors.")):
             continue
         for attr, val in list(vars(mod).items()):
-            hit = swap.get(id(val))
+            hit = _FN_SWAP.get(id(val))
             if hit is not None and callable(val):
                 setattr(mod, attr, hit[1])
                 _FN_REBOUND.append((mod, attr, hit[0]))
@@ -414,7 +427,7 @@ def install(rebind_names: bool = True, wrap_model_compressor: bool = True, patch
         _rebind_names(table, _SAVED)
     if wrap_model_compressor:
         _wrap_model_compressor()
-    if patch_functions and not _FN_REBOUND:
+    if patch_functions:
         _patch_functions()
     return compressed_tensors
 
@@ -442,5 +455,6 @@ def uninstall():
         setattr(mod, attr, orig)
     _REBOUND.clear()
     _FN_REBOUND.clear()
+    _FN_SWAP.clear()
     _unwrap_model_compressor()
     uninstall_from(up_registry._REGISTRY[BaseCompressor], _SAVED)

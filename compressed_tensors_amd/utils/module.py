@@ -90,9 +90,11 @@ def swap_direct_entries(module: torch.nn.Module, remove, add: dict, status=None)
                 module._non_persistent_buffers_set.discard(name)
                 if name not in add:
                     params[name] = torch.nn.Parameter(t.data, requires_grad=False)
-    for name, t in params.items():
+    for name, t in list(params.items()):
         if t is not None and t.requires_grad and name not in add:
-            t.requires_grad_(False)
+            # a fresh Parameter, as upstream's replace_direct_state_dict makes for every staying entry: freezing the object in place
+            # would also freeze it for any other holder (a tied bias, an optimizer's param group)
+            params[name] = _make_subclass(type(t) if isinstance(t, _Parameter) else _Parameter, t.data, False)
     for name, value in add.items():
         params[name] = _make_subclass(_Parameter, value, False)  # == torch.nn.Parameter(value, requires_grad=False) for a plain tensor
     if status is not None:

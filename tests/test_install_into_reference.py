@@ -232,3 +232,77 @@ def test_install_patch_functions_rebinds_and_falls_through_on_cpu(upstream):
     ct_amd.uninstall()
     assert (helpers_mod.pack_to_int32, helpers_mod.unpack_from_int32, forward_mod.dequantize, forward_mod.fake_quantize) == originals
     assert base_mod.pack_to_int32 is originals[0] and base_mod.unpack_from_int32 is originals[1]
+
+
+def test_patch_functions_rescans_modules_imported_since_the_last_install(upstream):
+    """`_patch_functions` ran once only — an upstream module imported after the first install(patch_functions=True)
+    kept the eager functions.  Every install() now re-scans sys.modules; the wrappers are made once, nothing is recorded twice."""
+    import types
+
+    ct, ct_amd = upstream
+    import compressed_tensors.compressors.pack_quantized.helpers as helpers_mod
+    import compressed_tensors.quantization.lifecycle.forward as forward_mod
+
+    originals = (helpers_mod.pack_to_int32, forward_mod.dequantize)
+    ct_amd.install(patch_functions=True)
+    wrappers = (helpers_mod.pack_to_int32, forward_mod.dequantize)
+    n_first = len(ct_amd._FN_REBOUND)
+    late = types.ModuleType("compressed_tensors._imported_late")
+    late.pack_to_int32, late.dequantize = originals  # what `from ... import pack_to_int32` before install() leaves behind
+    sys.modules[late.__name__] = late
+    try:
+        ct_amd.install(patch_functions=True)
+        assert (late.pack_to_int32, late.dequantize) == wrappers
+        assert (helpers_mod.pack_to_int32, forward_mod.dequantize) == wrappers  # not wrapped a second time
+        assert len(ct_amd._FN_REBOUND) == n_first + 2
+        ct_amd.install(patch_functions=True)
+        assert len(ct_amd._FN_REBOUND) == n_first + 2
+        ct_amd.uninstall()
+        assert (late.pack_to_int32, late.dequantize) == originals and (helpers_mod.pack_to_int32, forward_mod.dequantize) == originals
+        ct_amd.install(patch_functions=True)  # a fresh cycle builds fresh wrappers around the ORIGINALS, not around stale wrappers
+        assert helpers_mod.pack_to_int32._ct_original is originals[0]
+    finally:
+        del sys.modules[late.__name__]
+
+
+def test_offloaded_modules_are_left_to_upstreams_per_module_path(upstream):
+    """a module whose `_parameters` is an upstream OffloadCache (offload/cache/base.py:14, a MutableMapping that
+    onloads on access) must not be probed or batched by the wrapped ModelCompressor loops: `_ct_split` hands it to upstream's
+    per-module path without reading a single entry"""
+    from collections.abc import MutableMapping
+
+    ct, ct_amd = upstream
+    from compressed_tensors.compressors import BaseCompressor
+    from compressed_tensors.quantization import QuantizationArgs, QuantizationScheme
+
+    class RecordingCache(MutableMapping):  # stands in for OffloadCache: every read is an onload
+        def __init__(self, data):
+            self.data, self.reads = dict(data), []
+
+        def __getitem__(self, k):
+            self.reads.append(k)
+            return self.data[k]
+
+        def __setitem__(self, k, v):
+            self.data[k] = v
+
+        def __delitem__(self, k):
+            del self.data[k]
+
+        def __iter__(self):
+            return iter(self.data)
+
+        def __len__(self):
+            return len(self.data)
+
+    ct_amd.install()
+    cls = BaseCompressor.get_value_from_registry("pack-quantized")
+    scheme = QuantizationScheme(targets=["Linear"], weights=QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group"))
+    plain, off = torch.nn.Linear(256, 8, bias=False), torch.nn.Linear(256, 8, bias=False)
+    for m in (plain, off):
+        m.quantization_scheme = scheme
+    cache = RecordingCache(off._parameters)
+    off.__dict__["_parameters"] = cache
+    ours, rest = cls._ct_split([plain, off], ("weight",))
+    assert off in rest and off not in ours and cache.reads == []
+    assert plain in rest  # a CPU module: upstream's code as well, but it WAS probed (a plain dict lookup is free)
