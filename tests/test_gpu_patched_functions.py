@@ -82,7 +82,7 @@ def test_patched_dequantize_and_fake_quantize_reach_the_kernels(patched, kw, dty
     x = torch.randn(192, 512, dtype=torch.float32).mul_(0.07).to(dtype)
     scale, zp = _qparams(x, args)
     scale = scale.to(dtype)
-    x_q = p.originals.quantize(x, scale, zp, args)  # upstream, CPU
+    x_q = p.originals.quantize(x, scale, zp, args, dtype=torch.int8)  # upstream, CPU: the int8 codes a compressor stores (naive_quantized/base.py:100-108)
     ref_dq = p.originals.dequantize(x_q, scale, zp, args=args)
     ref_dq_inferred = p.originals.dequantize(x_q, scale, zp)  # strategy inferred from the scale's shape (forward.py:99-130)
     ref_fq = p.originals.fake_quantize(x, scale, zp, args)
