@@ -13,6 +13,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libct_hip.so")
+# the diagnostics build of the same library (ct_sparse.hip compiled -DCT_DIAG: the CT_BITMASK_RESIDENT* knobs and the per-workgroup
+# time stamps).  Never loaded by the package: a test or a dev tool that wants the knobs sets `_lib.LIB_PATH = _lib.DIAG_LIB_PATH`
+# in its own process before the first load().
+DIAG_LIB_PATH = os.path.join(_HERE, "libct_hip_diag.so")
 
 # element type codes of include/ct_hip.h
 F32, F16, BF16, I8, I32, U8, I16, I64, F8 = range(9)
@@ -95,6 +99,7 @@ _PROTOTYPES = {
     "ct_marlin24_quant_compress": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _S], _I),
     "ct_marlin24_compress_w4": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _P, _S], _I),
     "ct_marlin24_compress_w4_full": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _P, _I, _S], _I),
+    "ct_marlin24_compress_w4_verdict": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _P, _S], _I),
     "ct_selftest_m24_div": ([_I, _c.c_uint32, _c.c_uint32, _P, _S], _I),
     "ct_marlin24_pack_weights": ([_P, _I, _I, _I, _L, _L, _I, _P, _S], _I),
     "ct_marlin24_pack_scales": ([_P, _I, _L, _L, _I, _P, _S], _I),
@@ -277,7 +282,7 @@ def hostpath():
             # lib[name]: the symbol itself — `lib.name` may have been replaced by a launch-counting wrapper (tests/ref_suite)
             abi = {name: ctypes.cast(lib[name], ctypes.c_void_p).value
                    for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
-                                "ct_marlin24_compress_w4_full")}
+                                "ct_marlin24_compress_w4_full", "ct_marlin24_compress_w4_verdict")}
             try:  # the HIP runtime libct_hip.so is linked against, only if it is already in the process (RTLD_NOLOAD: never a second copy)
                 hip = ctypes.CDLL("libamdhip64.so", mode=os.RTLD_NOLOAD | os.RTLD_NOW)
                 abi["hipStreamSynchronize"] = ctypes.cast(hip.hipStreamSynchronize, ctypes.c_void_p).value

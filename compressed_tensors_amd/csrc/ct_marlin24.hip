@@ -7,6 +7,7 @@
 // oracle, which in turn is pinned against the surviving reference primitives.
 #include "ct_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -27,6 +28,10 @@ __host__ __device__ __forceinline__ int64_t meta_reorder_offset(int64_t r, int64
 // the 2:4 structure verdict: every violating lane stores the same 1 (idempotent, no read-modify-write), at system scope — the slot may
 // live in pinned host memory (ct_mailbox_alloc: the default, check-per-call mode of Marlin24Compressor) where a device atomic
 // would need PCIe atomics
+// ticket trees of the verdict mode (marlin24_fused_w4_lean_kernel): root at word 0, leaf i at word 32 * (1 + i) — one 128-byte line each
+constexpr unsigned kM24Trees = 16, kM24TreeWords = 32 * 65;
+__device__ unsigned int g_m24_tickets[kM24Trees * kM24TreeWords];
+
 __device__ __forceinline__ void raise_flag(int* bad) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // 4-bit code of a quad from its non-zero flags (:111-153)
@@ -613,7 +618,8 @@ template <int XDT, int SDT>
 __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const uint16_t* __restrict__ w, const uint16_t* __restrict__ scale,
                                                                         const int8_t* __restrict__ zp, int64_t m, int64_t k, int64_t cdiv,
                                                                         int64_t scale_cols, int32_t* __restrict__ packed, uint16_t* __restrict__ meta,
-                                                                        int* __restrict__ bad, uint16_t* __restrict__ scale_packed, int scale_single, int xcd_rows) {
+                                                                        int* __restrict__ bad, uint16_t* __restrict__ scale_packed, int scale_single, int xcd_rows,
+                                                                        unsigned int* __restrict__ tickets, long long* __restrict__ verdict_word) {
     constexpr bool NEWTON = !(XDT == CT_BF16 && SDT == CT_BF16);
     __shared__ __attribute__((aligned(16))) uint16_t s_meta[8][128];
     __shared__ __attribute__((aligned(16))) uint8_t s_code[64][128 + 8];  // +8: rows start on different banks
@@ -737,16 +743,51 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
             s_meta[cl >> 1][mpos0 + it * 16] = (uint16_t)word;
         }
     }
-    if (violation || vmax >= 16u * 24u) raise_flag(bad);  // a quad with three or more non-zero codes
+    const bool lane_bad = violation || vmax >= 16u * 24u;  // a quad with three or more non-zero codes
     // the permutation row of the packing phase is requested here — the weight registers are dead (and so is the rare exact path, which
     // needs the registers itself: requested above it, the row cost the fifth wave per SIMD) — so that its ~1 us (an L2 hit) passes
     // under the barrier and the metadata store instead of in front of the packing loop, where round 3 fetched it
     const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
-    __syncthreads();
+    // Round 5, verdict mode (`tickets` != nullptr; ct_marlin24_compress_w4_verdict): the host wants "does the WHOLE tensor keep 2:4?" as early
+    // as the device knows it, without waiting for the launch to drain (hipStreamSynchronize added ~15 us to the default-mode class call).
+    // Every workgroup reports once, through a two-level ticket tree: leaf counter b % leaves (count in the low half, violating workgroups in
+    // the high half of ONE 32-bit atomic), the last arrival of a leaf reports to the root, the last arrival at the root stores
+    // 1 | (violated << 1) into the caller's (pinned, host-visible) word at system scope and leaves every counter it closed at zero for the
+    // next launch.  A flat counter would take 2048 same-address atomics at ~40 ns each (they execute at the memory side on this multi-XCD
+    // part: DESIGN.md 5.4) — longer than the kernel; <= 64 leaves of <= ~32 arrivals close in parallel.  The verdict travels IN the atomics'
+    // values, so no fence orders anything.  The atomic is issued here and its result first read after the packing stores below.
+    unsigned int leaf_old = 0;
+    int wg_bad = 0;
+    if (tickets != nullptr) {  // workgroup-uniform
+        wg_bad = __syncthreads_or(lane_bad ? 1 : 0);
+        if (tid == 0) {
+            const unsigned leaves = gridDim.x < 64u ? gridDim.x : 64u;
+            leaf_old = __hip_atomic_fetch_add(tickets + 32u * (1u + blockIdx.x % leaves), 1u + (wg_bad ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        if (lane_bad) raise_flag(bad);
+        __syncthreads();
+    }
     {
         const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
         const int64_t pair_base = ((int64_t)tile_c * 8 + pair) * m * 2 + (int64_t)tile_r * 128;
         stream_store8(meta + pair_base + chunk * 4, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
+    }
+    // the tree is closed HERE, ahead of the packing loop (the leaf atomic was issued above the metadata store; only wave 0 waits for it): the
+    // verdict of the launch's last workgroup then travels while that workgroup packs, instead of starting its two round trips after it
+    if (tickets != nullptr && tid == 0) {
+        const unsigned leaves = gridDim.x < 64u ? gridDim.x : 64u, leaf = blockIdx.x % leaves;
+        const unsigned leaf_size = gridDim.x / leaves + (leaf < gridDim.x % leaves ? 1u : 0u);
+        if ((leaf_old & 0xffffu) + 1u == leaf_size) {  // the leaf's last arrival (leaf sizes stay below 2^16: the entry refuses launches of 64 x 65535 tiles and more)
+            const unsigned leaf_bad = (leaf_old >> 16) + (wg_bad ? 1u : 0u);
+            __hip_atomic_store(tickets + 32u * (1u + leaf), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned root_old = __hip_atomic_fetch_add(tickets, 1u + (leaf_bad ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((root_old & 0xffffu) + 1u == leaves) {
+                const bool any_bad = (root_old >> 16) != 0u || leaf_bad != 0u;
+                __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(verdict_word, any_bad ? 3ll : 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
     const uint8_t* sc = &s_code[0][0];
     const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
@@ -943,7 +984,7 @@ int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sd
 // returns CT_OK + 1 when the launch also wrote scale_packed
 static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
                                      int32_t* packed, int16_t* meta, int* bad, bool clear_bad, void* scale_packed, int scale_single, bool* fused_scales,
-                                     ct_stream_t stream) {
+                                     ct_stream_t stream, long long* verdict_word = nullptr) {
     if (fused_scales) *fused_scales = false;
     CT_REQUIRE(wdt == CT_F16 || wdt == CT_BF16, "marlin-24 weights must be 16-bit floats, got dtype %d", wdt);
     CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
@@ -953,6 +994,21 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
     CT_REQUIRE(aligned16(w) && (reinterpret_cast<uintptr_t>(meta) & 7u) == 0 && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 && bad != nullptr,
                "misaligned buffers");
     CT_REQUIRE((m / 64) * (k / 256) < ((int64_t)1 << 31), "tensor too large for one launch");
+    unsigned int* tickets = nullptr;
+    if (verdict_word != nullptr) {
+        const bool lean_ok = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8);
+        if (!lean_ok || (m / 64) * (k / 256) >= (int64_t)64 * 65535 || m == 0 || k == 0) {
+            CT_UNSUPPORTED("ct_marlin24_compress_w4_verdict: layout outside the one-launch kernel (16-bit scales, int8 or no zero point, < 4.2 M tiles)");
+        }
+        // one ticket tree per launch in flight: 16 trees per device, handed out round robin (a tree is back at zero when its launch's
+        // last workgroup has reported; the default-mode call this serves waits for exactly that before it returns, so a host thread
+        // never has two launches on one tree, and sixteen threads can be in the call at once)
+        static std::atomic<unsigned> next_tree{0};
+        unsigned int* base = nullptr;
+        hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_m24_tickets));
+        if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict tickets");
+        tickets = base + (size_t)(next_tree.fetch_add(1u) % kM24Trees) * kM24TreeWords;
+    }
     if (clear_bad) {
         hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
         if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4 memset");
@@ -965,7 +1021,7 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
 #define CT_M24_LEAN(X, S)                                                                                                                      \
     hipLaunchKernelGGL((marlin24_fused_w4_lean_kernel<X, S>), dim3(tg), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(w), \
                        static_cast<const uint16_t*>(scale), static_cast<const int8_t*>(zp), m, k, c, k / c, packed, reinterpret_cast<uint16_t*>(meta), bad, \
-                       static_cast<uint16_t*>(scale_packed), scale_single, xcd_rows)
+                       static_cast<uint16_t*>(scale_packed), scale_single, xcd_rows, tickets, verdict_word)
         const int xcd_rows = (m / 64) % 8 == 0 ? 1 : 0;  // the row blocks divide evenly over the eight XCDs
         if (wdt == CT_BF16 && sdt == CT_BF16) CT_M24_LEAN(CT_BF16, CT_BF16);
         else if (wdt == CT_BF16) CT_M24_LEAN(CT_BF16, CT_F16);
@@ -1004,6 +1060,15 @@ int ct_marlin24_compress_w4_full(const void* w, int wdt, const void* scale, int 
         hipLaunchKernelGGL(marlin24_pack_scales_kernel<false>, dim3(grid_1d(m * groups)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale), m,
                            groups, group_perm ? 0 : 1, static_cast<uint16_t*>(scale_packed));
     CT_LAUNCH_CHECK("ct_marlin24_compress_w4_full");
+}
+
+int ct_marlin24_compress_w4_verdict(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
+                                    int group_perm, int32_t* packed, int16_t* meta, void* scale_packed, int64_t* verdict_word, ct_stream_t stream) {
+    CT_REQUIRE(sdt == CT_F16 || sdt == CT_BF16, "marlin-24 scales must be 16-bit floats, got dtype %d", sdt);
+    CT_REQUIRE(scale_packed != nullptr && verdict_word != nullptr && (reinterpret_cast<uintptr_t>(verdict_word) & 7u) == 0, "scale_packed / verdict_word NULL or misaligned");
+    static int unused_flag;  // the kernel's `bad` argument is not touched in verdict mode; the shared argument check wants a non-null pointer
+    return marlin24_compress_w4_impl(w, wdt, scale, sdt, zp, zdt, m, k, cdiv, packed, meta, &unused_flag, false, scale_packed, group_perm ? 0 : 1, nullptr, stream,
+                                     reinterpret_cast<long long*>(verdict_word));
 }
 
 int ct_selftest_m24_div(int mode, uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {

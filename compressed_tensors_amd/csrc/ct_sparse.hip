@@ -1094,7 +1094,22 @@ __device__ __forceinline__ unsigned long long op_load(const unsigned long long* 
 // start of blocks [CUs, 2 CUs) by one load phase so that a CU's two workgroups alternate load / store phases: 48.2 -> 44.6 us, kept for
 // launches of at least two residency rounds; (4) other workgroup shapes without the stagger — 4 waves x 4 tiles (four per CU) 47.9 us,
 // 8 x 2 (three per CU) 46.8, 8 x 3 50.5, 4 x 2 (six per CU) 47.9 against 48.2 for 8 x 4: the shape is not the lever either.
+// Diagnostics (-DCT_DIAG: libct_hip_diag.so, built next to the product library and loaded only by the tests / dev tools that force the
+// alternative forms): per-workgroup time stamps in the kernel's argument list and the CT_BITMASK_RESIDENT* environment knobs of the
+// launcher.  The shipped library has neither.
+#ifdef CT_DIAG
+#define CT_STAMPS_PARAM unsigned long long* __restrict__ stamps,
+#define CT_STAMPS_ARG(x) x,
+#define CT_STAMP(k) if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + k] = wall_clock64()
+#define CT_STAMP_T0(k) if (stamps && b < kResStampWGs) stamps[b * 4 + k] = wall_clock64()
+#else
+#define CT_STAMPS_PARAM
+#define CT_STAMPS_ARG(x)
+#define CT_STAMP(k) (void)0
+#define CT_STAMP_T0(k) (void)0
+#endif
 typedef u32x4 u32x4_a2_t __attribute__((aligned(2)));
+typedef u32x2 u32x2_a1_t __attribute__((aligned(1)));
 constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB, 64 VGPRs)
 constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
 constexpr int kResMaxWGs = 8192;  // count words in the workspace: 1 GiB of 16-bit elements per launch, more goes in chunks
@@ -1105,19 +1120,19 @@ constexpr int kResRoundWords = 64; // "inclusive count through residency round r
 // offset inside the kernel are in 16-byte units / 16-bit halves exactly as for ES = 2; only the non-zero test (per 32-bit element, flag
 // doubled), the bitmask that leaves (one bit per ELEMENT: the nibbles of two adjacent units make a byte), the row offsets and the totals
 // (halved on the way out) differ.
-template <int KEEP, int WAVES, int ES>
+template <int KEEP, int WAVES, int ES, int ROWB = 0>
 __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u32x4* __restrict__ x, bool is_float, int64_t units, int64_t upr, int64_t rows, int tpw,
                                                                     uint16_t* __restrict__ vout, int64_t capacity, uint8_t* __restrict__ bitmask,
                                                                     int mask_dwords, int64_t* __restrict__ row_offsets, int64_t u0,
                                                                     const unsigned long long* __restrict__ base, unsigned long long* __restrict__ slots,
                                                                     unsigned long long* __restrict__ run_out, uint32_t gen, unsigned long long wait_ticks,
-                                                                    unsigned long long* __restrict__ stamps, int stagger_lo, int stagger_hi, unsigned stagger_ticks,
+                                                                    CT_STAMPS_PARAM int stagger_lo, int stagger_hi, unsigned stagger_ticks,
                                                                     unsigned stagger_slope_q8, int round_wgs, unsigned long long* __restrict__ round_words) {
     constexpr int kSlabData = kWT * 8 + 8;      // compacted run of one wave-tile
     constexpr int kSlab = kSlabData + 64;       // + one dump slot per lane
     __shared__ __attribute__((aligned(16))) uint16_t s_val[WAVES][kSlab];
-    __shared__ __attribute__((aligned(16))) uint16_t s_lut[256 * 8];
-    __shared__ __attribute__((aligned(16))) uint32_t s_mask[WAVES][KEEP][64];  // packed masks (unit i * 64 + lane in byte i)
+    __shared__ __attribute__((aligned(16))) uint16_t s_lut[ROWB ? 8 : 256 * 8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_mask[ROWB ? 1 : WAVES][ROWB ? 1 : KEEP][ROWB ? 4 : 64];  // packed masks (unit i * 64 + lane in byte i)
     __shared__ int s_cnt[WAVES];
     __shared__ long long s_part[WAVES];
     __shared__ int s_miss[WAVES * 64];
@@ -1137,7 +1152,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
         const unsigned long long wait = stagger_ticks + (((unsigned long long)(b - stagger_lo) * stagger_slope_q8) >> 8);
         while (wall_clock64() - s0 < wait) __builtin_amdgcn_s_sleep(16);
     }
-    if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 0] = wall_clock64();
+    CT_STAMP(0);
     // ---- phase A.  Round 4: every load is UNCONDITIONAL straight-line code (unit index clamped to the chunk's last unit; a unit
     // beyond the chunk, or a tile beyond this wave's `tpw`, contributes no flags), so that hipcc's wait-count pass can count the
     // loads: a tile is consumed behind `s_waitcnt vmcnt(12 / 8 / 4 / 0)` as it lands.  With a load behind a branch the pass gives up
@@ -1156,8 +1171,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
             keep[i][q] = x[u < units32 ? u : units32 - 1u];
         }
     }
-    build_compact_lut(s_lut, tid);
-    __syncthreads();
+    if constexpr (!ROWB) {
+        build_compact_lut(s_lut, tid);
+        __syncthreads();
+    }
     const uint32_t slab_a = lds_addr(s_val[wave]), dump_a = slab_a + 2u * (uint32_t)(kSlabData + lane), lut_a = lds_addr(s_lut);
     const u32x4* slab_v = reinterpret_cast<const u32x4*>(s_val[wave]);
     int tot[KEEP];  // wave-uniform
@@ -1165,6 +1182,68 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
     const int64_t first_r = next_r;
     uint32_t pks[KEEP];
     int cnt = 0;
+    // ---- ROWB (round 5; shipped for 32-bit payloads): compaction by ROWS OF 64 ELEMENTS instead of by 16-byte units.  A tile is staged into the
+    // wave's slab as it lands (4 x ds_write_b128) and read back TRANSPOSED, one element per lane (64 consecutive elements per instruction,
+    // conflict-free); the non-zero test of a row is one compare whose result IS the row's 64 bitmask bits (a ballot in an SGPR pair), a
+    // lane's rank is mbcnt of that mask plus a scalar running count, and the survivors of the row go back into the slab (in place: they
+    // land at or below the row's own start) as ONE exec-masked store to CONSECUTIVE addresses.  No selector table, no dump slots, no DPP
+    // scan, no LDS bank conflicts; lane r keeps the flags of row r, so the bitmask leaves as 8 contiguous bytes per lane.
+    // Measured at 8192^2, 50 % zeros (profiles/r05_bitmask_rowform.jsonl): float32 78.6 -> 74.4 us (65.4 -> 69.1 % of the HBM peak) — 16 rows
+    // per tile; 16-bit payloads (32 rows per tile) 41.6 -> 44.1 us, so they keep the unit form: per-workgroup stamps put the whole
+    // difference into start -> published (7.2 -> 9.7 us).  The row form spends ~8 SCALAR instructions per row (ballot popcount, running
+    // count, row base, exec install / restore) and a CU has ONE scalar unit for its 16 resident waves: 32 rows x 4 tiles x 16 waves x 8 =
+    // 16 K issue cycles per residency round against 6 per row of vector work on four SIMDs.  Hand-written v_cmp_class_f16 + s_mov exec
+    // (6 VALU + 8 SALU per row instead of the compiler's and / cmp / s_and_saveexec / s_cbranch / s_or) and the last tile's count ahead of
+    // its compaction measured 44.1 / 46.6 us.  The unit form's LDS bank conflicts (52 % of its LDS cycles) are real but not its limit.
+    constexpr int EPU = 16 / ES;            // elements per 16-byte unit
+    constexpr int RROWS = kWT * EPU / 64;   // rows of 64 elements per wave-tile: 32 (16-bit) / 16 (32-bit)
+    constexpr int UPROW = 64 / EPU;         // units per row
+    uint32_t mlo[KEEP], mhi[KEEP];          // lane r: the flags of row r of tile i
+    if constexpr (ROWB) {
+        typedef typename ElemT<ES>::type elem_t;
+        typedef __attribute__((address_space(3))) elem_t lds_elem_t;
+        u32x4* slab_w = reinterpret_cast<u32x4*>(s_val[wave]);
+        const uint32_t slab_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)slab_a);  // wave-uniform: the row addresses are SGPR + lane offset
+        const uint32_t lane_e = (uint32_t)lane * (uint32_t)ES;
+        const uint32_t ekeep = ES == 4 ? keepbits : (keepbits & 0xffffu);
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const uint32_t t_u0 = (uint32_t)(wt0 * kWT) + (uint32_t)(i * kWT);  // the tile's first unit inside the chunk
+            const bool any = i < tpw && t_u0 < units32;                         // wave-uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slab_w[q * 64 + lane] = keep[i][q];
+            if (any && t_u0 + (uint32_t)kWT > units32) {  // the chunk's last, partial tile (wave-uniform, rare): units beyond the end are staged as zeros
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (t_u0 + (uint32_t)(q * 64 + lane) >= units32) slab_w[q * 64 + lane] = u32x4{0u, 0u, 0u, 0u};
+            }
+            uint32_t lo = 0, hi = 0;
+            int run = 0;
+            if (any) {
+                elem_t v[RROWS];
+#pragma unroll
+                for (int r = 0; r < RROWS; ++r) v[r] = *(lds_elem_t*)(uintptr_t)(slab_s + (uint32_t)(r * 64 * ES) + lane_e);  // every read precedes the first in-place write
+#pragma unroll
+                for (int r = 0; r < RROWS; ++r) {
+                    const uint32_t row_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slab_s + (uint32_t)run * (uint32_t)ES));  // stays scalar
+                    const bool nzr = ((uint32_t)v[r] & ekeep) != 0u;
+                    const unsigned long long m = __ballot(nzr);
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (nzr) *(lds_elem_t*)(uintptr_t)(rank * (uint32_t)ES + row_base) = v[r];
+                    run += __popcll(m);
+                    // lane r keeps row r's flags (this clang has no writelane builtin; the ballot lives in an SGPR pair)
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)m), "n"(r));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(m >> 32)), "n"(r));
+                }
+            }
+            mlo[i] = lo;
+            mhi[i] = hi;
+            tot[i] = run << SH;  // in 16-bit halves, as everything downstream counts
+            cnt += tot[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) keep[i][q] = slab_v[q * 64 + lane];  // vector q * 64 + lane of the compacted tile (garbage past tot)
+        }
+    }
     // ranks, compaction through the wave's slab, read back in place — of ONE wave-tile (LDS and VALU only)
     auto pass2 = [&](int i) {
         uint32_t mm[4], rank[4];
@@ -1179,6 +1258,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
     // all four tiles plus one poll round trip, not the other workgroups' loads.)  The tiles before the last one are ranked and
     // compacted AS THEY LAND, in the shadow of the loads still in flight; only the LAST tile's flags gate the publish and only its
     // pass 2 sits behind it.
+    if constexpr (!ROWB) {
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         uint32_t pk = 0;
@@ -1193,6 +1273,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
         if (i < KEEP - 1) pass2(i);
     }
     cnt = __builtin_amdgcn_readlane(wave_incl_scan(cnt), 63);
+    }
     if (lane == 0) s_cnt[wave] = cnt;
     __syncthreads();
     if (tid == 0) {
@@ -1200,15 +1281,34 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) wg += s_cnt[w];
         op_store(slots + b, ((unsigned long long)gen << 32) | (uint32_t)wg);
-        if (stamps && b < kResStampWGs) stamps[b * 4 + 1] = wall_clock64();
+        CT_STAMP_T0(1);
     }
     // ---- the last tile's pass 2, while the word travels.  (Round 4, measured and dropped: requesting the round word and the first sweep
     // of count words HERE, ahead of this pass, so that the ~2.5 us poll round trip runs under it — with the flags masked branch-free so
     // that the pass does not wait for those loads — 46.3-47.0 us against 42.2: the early attempt fails more often than the late one, a
     // failed attempt costs a full extra round trip, and published -> resolved grew from 3.3 to 4.6 us; moving the bitmask stores
     // behind the hand-off changed nothing, 46.3.)
-    pass2(KEEP - 1);
+    if constexpr (!ROWB) pass2(KEEP - 1);
     // ---- rows that start inside one of this wave's tiles: their offset relative to the tile, completed in phase B
+    if constexpr (ROWB) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
+            if (i < tpw && next_r < rows && next_u < uend) {  // wave-uniform
+                // kept elements before row r of the tile: exclusive scan of the rows' popcounts (lane r holds row r's flags)
+                const int rc = lane < RROWS ? __popc(mlo[i]) + __popc(mhi[i]) : 0;
+                const int excl = wave_incl_scan(rc) - rc;
+                for (; next_r < rows && next_u < uend; ++next_r, next_u += upr) {
+                    const int q = (int)(next_u - ubeg);          // unit inside the tile
+                    const int r = q / UPROW, bit = (q % UPROW) * EPU;
+                    const uint32_t flo = (uint32_t)__builtin_amdgcn_readlane((int)mlo[i], r), fhi = (uint32_t)__builtin_amdgcn_readlane((int)mhi[i], r);
+                    const unsigned long long below = (((unsigned long long)fhi << 32) | flo) & ((1ull << bit) - 1ull);
+                    const int rk = (__builtin_amdgcn_readlane(excl, r) + __popcll(below)) << SH;  // in halves; phase B adds the tile's offset
+                    if (lane == (q & 63)) row_offsets[next_r] = (int64_t)rk;
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         const int64_t ubeg = u0 + (wt0 + i) * kWT, uend = ubeg + kWT;
@@ -1225,8 +1325,28 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
             }
         }
     }
-    // ---- the bitmask leaves while the counts travel: output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the
-    // packed masks of lanes 4 (L & 15) .. + 3
+    }
+    // ---- the bitmask leaves while the counts travel.  ROWB: lane r holds the 64 flags of row r = 8 consecutive bitmask bytes
+    if constexpr (ROWB) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int64_t wt = wt0 + i;
+            if (i < tpw && wt * kWT < units && lane < RROWS) {
+                // a mask byte covers 8 elements: one 16-bit unit, or two 32-bit units
+                const int64_t ub = wt * kWT + (int64_t)lane * UPROW;  // first unit of this lane's row
+                uint8_t* dst = bitmask + (ES == 4 ? (ub >> 1) : ub);
+                if ((wt + 1) * kWT <= units) {
+                    *reinterpret_cast<u32x2_a1_t*>(dst) = u32x2{mlo[i], mhi[i]};
+                } else {
+                    const unsigned long long mm = ((unsigned long long)mhi[i] << 32) | mlo[i];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        if (ub + (ES == 4 ? 2 * t : t) < units) dst[t] = (uint8_t)(mm >> (8 * t));
+                }
+            }
+        }
+    } else {
+    // output dword of lane L = units 4L .. 4L+3 of the tile = byte (L >> 4) of the packed masks of lanes 4 (L & 15) .. + 3
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) {
         const int64_t wt = wt0 + i;
@@ -1258,6 +1378,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
                 }
             }
         }
+    }
     }
     // ---- hand-off: lane t watches the words of workgroups t, t + 512, ...  A word that does not arrive within the time budget is
     // not an error: the workgroup COUNTS that workgroup's share of x itself (self-help; never observed outside the forced test).
@@ -1323,7 +1444,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
         if (lane == 0) s_part[wave] = part;
     }
     __syncthreads();
-    if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 2] = wall_clock64();
+    CT_STAMP(2);
     if (round_wgs > 0 && tid == 0 && (b + 1) % round_wgs == 0 && b + 1 < (int)gridDim.x) {  // the last workgroup of a residency round
         long long incl = 0;
 #pragma unroll
@@ -1367,7 +1488,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
             if ((wt + 1) * kWT >= units && wt * kWT < units && lane == 0) op_store(run_out, (unsigned long long)(run >> SH));  // the chunk's last wave-tile
         }
     }
-    if (stamps && tid == 0 && b < kResStampWGs) stamps[b * 4 + 3] = wall_clock64();
+    CT_STAMP(3);
 }
 
 // ------------------------------------------------------------------------- 2:4
@@ -1660,7 +1781,11 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
     // below for 16-bit elements (x read twice; 32-bit ones then take the generic path), which
     // are also what the caller falls back to when the resident form reports -1; 3 = time stamps of the first 1024 workgroups in the
     // workspace (tools/exp_r04.py bmstamps)
+#ifdef CT_DIAG
     static const int resident_mode = []() { const char* e = std::getenv("CT_BITMASK_RESIDENT"); return e ? std::atoi(e) : 1; }();
+#else
+    constexpr int resident_mode = 1;
+#endif
     if ((es == 2 || es == 4) && cols % 8 == 0 && aligned16(x) && resident_mode) {
         const int64_t upr = cols * es / 16;  // 16-byte units per row
         const int64_t units = rows * upr;
@@ -1682,11 +1807,15 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
         if (tpw > kResKeep) tpw = kResKeep;
         if (tpw < 1) tpw = 1;
         const int64_t wg_wts = (int64_t)kResWaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
+#ifdef CT_DIAG
         static const int64_t max_wgs = []() {  // per launch: the count words of the workspace (the knob exists for the chunking tests)
             const char* e = std::getenv("CT_BITMASK_RESIDENT_MAX_WGS");
             const int64_t v = e ? (int64_t)std::atoll(e) : (int64_t)kResMaxWGs;
             return v < 1 ? (int64_t)1 : (v > kResMaxWGs ? (int64_t)kResMaxWGs : v);
         }();
+#else
+        constexpr int64_t max_wgs = kResMaxWGs;  // per launch: the count words of the workspace
+#endif
         const int64_t chunk_wts = max_wgs * wg_wts;
         const int64_t nchunks = cdiv64(wts, chunk_wts);
         if (nchunks <= 4096) {
@@ -1703,11 +1832,15 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
             auto tag_of = [](uint32_t c) { return 0x80000000u | (c % 0x7ffffffeu); };
             unsigned long long* slots = static_cast<unsigned long long*>(workspace);
             unsigned long long* ctl = slots + kResMaxWGs;  // [2] / [3] running totals (alternating between chunks)
+#ifdef CT_DIAG
             unsigned long long* stamps = resident_mode == 3 ? ctl + 4 : nullptr;
             static const unsigned long long wait_ticks = []() {  // 100 MHz ticks; default 2 ms, then self-help
                 const char* e = std::getenv("CT_BITMASK_RESIDENT_WAIT_US");
                 return (unsigned long long)(e ? std::atoll(e) : 2000ll) * 100ull;
             }();
+#else
+            constexpr unsigned long long wait_ticks = 2000ull * 100ull;  // 100 MHz ticks: 2 ms, then self-help
+#endif
             for (int64_t k = 0; k < nchunks; ++k) {
                 const int64_t w0 = k * chunk_wts;
                 const int64_t cw = (wts - w0) < chunk_wts ? (wts - w0) : chunk_wts;
@@ -1733,14 +1866,14 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 // raw count words of the earlier rounds (44.9 -> 44.6 us by itself; kept: it halves the polling of the later rounds)
                 const int round_wgs = (wgs_per_cu * cus <= kResMaxWGs && cdiv64(nwg, wgs_per_cu * (int64_t)cus) <= kResRoundWords) ? wgs_per_cu * cus : 0;
                 unsigned long long* round_words = ctl + 4 + 4 * kResStampWGs;
-#define CT_RESIDENT_W(ES_, W_)                                                                                                                    \
-    hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, W_, ES_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                       \
+#define CT_RESIDENT_W(ES_, W_, R_)                                                                                                                \
+    hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, W_, ES_, R_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                   \
                        static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
                        values_capacity * (ES_ / 2), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out,        \
-                       tag_of(gen0 + (uint32_t)k), wait_ticks, k == 0 ? stamps : nullptr, stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
+                       tag_of(gen0 + (uint32_t)k), wait_ticks, CT_STAMPS_ARG(k == 0 ? stamps : nullptr) stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
                        round_wgs, round_words)
-                if (es == 4) CT_RESIDENT_W(4, kResWaves);
-                else CT_RESIDENT_W(2, kResWaves);
+                if (es == 4) CT_RESIDENT_W(4, kResWaves, 1);  // the row form: 69 % against 65 % of the HBM peak at 8192^2 float32
+                else CT_RESIDENT_W(2, kResWaves, 0);          // the unit form: the row form is scalar-bound at 32 rows per tile
 #undef CT_RESIDENT_W
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");

@@ -487,6 +487,7 @@ using workspace_bytes_fn = int64_t (*)(int64_t, int64_t);
 using mailbox_wait_fn = int (*)(const int64_t*, int64_t, void*, int64_t*);
 using stream_wait_fn = int (*)(void*);
 using marlin_full_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int, int32_t*, int16_t*, void*, int*, int, void*);
+using marlin_verdict_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int, int32_t*, int16_t*, void*, int64_t*, void*);
 
 struct Abi {
     bitmask_compress_fn bitmask_compress = nullptr;
@@ -494,6 +495,7 @@ struct Abi {
     mailbox_wait_fn mailbox_wait = nullptr;
     stream_wait_fn stream_wait = nullptr;
     marlin_full_fn marlin_full = nullptr;
+    marlin_verdict_fn marlin_verdict = nullptr;  // optional (an older libct_hip.so): the full entry + a stream wait then
     stream_wait_fn hip_stream_synchronize = nullptr;  // optional: hipStreamSynchronize of the HIP runtime that is already loaded
 } g_abi;
 
@@ -526,6 +528,8 @@ void bind_abi(const std::map<std::string, uintptr_t>& addr) {
     g_abi.mailbox_wait = reinterpret_cast<mailbox_wait_fn>(at("ct_mailbox_wait_i64"));
     g_abi.stream_wait = reinterpret_cast<stream_wait_fn>(at("ct_stream_wait"));
     g_abi.marlin_full = reinterpret_cast<marlin_full_fn>(at("ct_marlin24_compress_w4_full"));
+    auto mv = addr.find("ct_marlin24_compress_w4_verdict");
+    g_abi.marlin_verdict = mv != addr.end() && mv->second ? reinterpret_cast<marlin_verdict_fn>(mv->second) : nullptr;
     auto opt = addr.find("hipStreamSynchronize");
     g_abi.hip_stream_synchronize = opt != addr.end() && opt->second ? reinterpret_cast<stream_wait_fn>(opt->second) : nullptr;
 }
@@ -578,21 +582,41 @@ py::tuple marlin24_w4_full(const at::Tensor& weight, int wdt, const at::Tensor& 
     at::Tensor scale_packed = at::empty({k / group, m}, opts.dtype(at::kHalf));
     int status;
     int64_t verdict = 0;
+    bool violated = false;
     {
         py::gil_scoped_release nogil;
         volatile int64_t* word = reinterpret_cast<volatile int64_t*>(flag_host);
         *word = 0;
-        status = g_abi.marlin_full(weight.data_ptr(), wdt, scale.data_ptr(), sdt, zp.has_value() ? zp->data_ptr() : nullptr, zp.has_value() ? zdt : -1, m, k, group,
-                                   group_perm ? 1 : 0, packed.data_ptr<int32_t>(), meta.data_ptr<int16_t>(), scale_packed.data_ptr(), reinterpret_cast<int*>(flag_dev), 0,
-                                   reinterpret_cast<void*>(stream));
-        // the verdict is final only when the whole launch has completed.  hipStreamSynchronize waits on the queue's completion signal itself; a
-        // spin on hipStreamQuery (ct_stream_wait) sees it 3-4 us later (`profiles/r04_host_wait_forms.json`: 22.2 vs 17.8 us around a tiny kernel).
-        // An error from it is re-asked through ct_stream_wait, which reports it the C ABI's way.
-        if (status == 0 && !(g_wait_mode && g_abi.hip_stream_synchronize && g_abi.hip_stream_synchronize(reinterpret_cast<void*>(stream)) == 0))
-            status = g_abi.stream_wait(reinterpret_cast<void*>(stream));
-        verdict = *word;
+        const void* zptr = zp.has_value() ? zp->data_ptr() : nullptr;
+        // Round 5: the launch's last-reporting workgroup stores the verdict (1 = 2:4 holds, 3 = violated) into the pinned word as soon as every
+        // workgroup has evaluated its tiles — the host spins on the word as bitmask_compress does for nnz, instead of waiting for the stream to
+        // drain (hipStreamSynchronize: +15 us over the kernel on the class call).  The outputs follow in stream order.
+        status = -1;
+        if (g_wait_mode && g_abi.marlin_verdict) {
+            status = g_abi.marlin_verdict(weight.data_ptr(), wdt, scale.data_ptr(), sdt, zptr, zp.has_value() ? zdt : -1, m, k, group, group_perm ? 1 : 0,
+                                          packed.data_ptr<int32_t>(), meta.data_ptr<int16_t>(), scale_packed.data_ptr(), reinterpret_cast<int64_t*>(flag_dev),
+                                          reinterpret_cast<void*>(stream));
+            if (status == 0) {
+                if (!spin_for_word(word, 0, &verdict))  // ~1 ms without a verdict: the stream's own completion (and its error, if any)
+                    status = g_abi.mailbox_wait(reinterpret_cast<const int64_t*>(flag_host), 0, reinterpret_cast<void*>(stream), &verdict);
+                if (status == 0 && verdict != 1 && verdict != 3) throw std::runtime_error("marlin24_w4_full: the launch finished without a 2:4 verdict");
+                violated = verdict == 3;
+            }
+        }
+        if (status == -1 || status == 2 /* CT_ERR_UNSUPPORTED: not the one-launch layout */) {
+            *word = 0;
+            status = g_abi.marlin_full(weight.data_ptr(), wdt, scale.data_ptr(), sdt, zptr, zp.has_value() ? zdt : -1, m, k, group, group_perm ? 1 : 0,
+                                       packed.data_ptr<int32_t>(), meta.data_ptr<int16_t>(), scale_packed.data_ptr(), reinterpret_cast<int*>(flag_dev), 0,
+                                       reinterpret_cast<void*>(stream));
+            // the flag is final only when the whole launch has completed.  hipStreamSynchronize waits on the queue's completion signal itself; a
+            // spin on hipStreamQuery (ct_stream_wait) sees it 3-4 us later (`profiles/r04_host_wait_forms.json`: 22.2 vs 17.8 us around a tiny kernel).
+            // An error from it is re-asked through ct_stream_wait, which reports it the C ABI's way.
+            if (status == 0 && !(g_wait_mode && g_abi.hip_stream_synchronize && g_abi.hip_stream_synchronize(reinterpret_cast<void*>(stream)) == 0))
+                status = g_abi.stream_wait(reinterpret_cast<void*>(stream));
+            violated = *word != 0;
+        }
     }
-    return py::make_tuple(status, verdict != 0, packed, meta, scale_packed);
+    return py::make_tuple(status, violated, packed, meta, scale_packed);
 }
 
 

@@ -366,6 +366,17 @@ int ct_marlin24_compress_w4_full(const void* w, int wdt, const void* scale, int 
                                  int64_t m, int64_t k, int64_t cdiv, int group_perm, int32_t* packed, int16_t* meta,
                                  void* scale_packed, int* bad, int clear_bad, ct_stream_t stream);
 
+/* the same one-launch compress for a caller that must RAISE from the call when the weight is not 2:4 (upstream's
+ * Marlin24Compressor.compress -> validate_sparsity_structure, historical sparse_quantized_compressors/marlin_24.py; the mask test is
+ * utils/semi_structured_conversions.py / tensor_follows_mask_structure): instead of a flag that is final only when the stream has
+ * drained, the launch's last-reporting workgroup stores 1 (every quad of every row keeps at most two non-zero codes) or 3
+ * (violated) into *verdict_word at system scope as soon as every workgroup has evaluated its tiles — the caller zeroes the word
+ * (pinned, device-mapped host memory: ct_mailbox_alloc) before the call and spins on it; outputs follow on `stream` as usual.
+ * CT_ERR_UNSUPPORTED for a layout the one-launch kernel does not take (use ct_marlin24_compress_w4_full + a stream wait). */
+int ct_marlin24_compress_w4_verdict(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
+                                    int64_t m, int64_t k, int64_t cdiv, int group_perm, int32_t* packed, int16_t* meta,
+                                    void* scale_packed, int64_t* verdict_word, ct_stream_t stream);
+
 /* marlin-24 weight packing (historical Marlin24Compressor.pack_weight_24 with the table of
  * utils/permutations_24.py:20-45).  q: codes of dtype dt (CT_I32 / CT_I8 / float holding
  * integers), laid out (size_k, size_n) [transposed == 0] or as the un-transposed 2:4-compressed

@@ -1015,6 +1015,8 @@ def test_marlin24_fused_front_end_vs_unfused(cta, dev, wdt, shape):
 _BITMASK_FORMS_CODE = r"""
 import sys, torch
 sys.path.insert(0, %r)
+from compressed_tensors_amd import _lib
+_lib.LIB_PATH = _lib.DIAG_LIB_PATH  # the CT_BITMASK_RESIDENT* knobs exist in the diagnostics build only (-DCT_DIAG)
 from compressed_tensors_amd import codec
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(5)
@@ -1114,6 +1116,7 @@ def test_bitmask_resident_self_help_total(dev):
 import sys, torch
 sys.path.insert(0, %r)
 from compressed_tensors_amd import _lib
+_lib.LIB_PATH = _lib.DIAG_LIB_PATH  # CT_BITMASK_RESIDENT_WAIT_US exists in the diagnostics build only (-DCT_DIAG)
 lib = _lib.load(); dev = torch.device("cuda:0")
 N = 4096
 w = torch.randn(N, N, dtype=torch.bfloat16, device=dev)
@@ -2071,6 +2074,70 @@ def test_marlin24_deferred_structure_check(cta, dev):
     with pytest.raises(ValueError, match="2:4 sparsity structure"):
         M.compress(sd(False, 10), scheme)
     M.compress(good[0], scheme)
+
+
+@pytest.mark.parametrize("shape", [(64, 256), (192, 768), (4096, 1024), (2048, 8192)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_marlin24_verdict_word_through_the_c_abi(cta, dev, shape):
+    """`ct_marlin24_compress_w4_verdict` (round 5): the launch's last-reporting workgroup stores 1 (2:4 holds) or 3 (violated) into the
+    caller's pinned word — one workgroup, a grid below / not a multiple of / far above the 64 leaves of the ticket tree; the outputs are
+    those of `ct_marlin24_compress_w4_full`; thirty launches in a row (the trees return to zero) alternate the two verdicts"""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    m, k = shape
+    g = torch.Generator(device=dev).manual_seed(m + k)
+    w = torch.randn(m, k, dtype=BF16, device=dev, generator=g)
+    w = w * cta.codec.sparse24_mask(w).to(w.dtype)
+    bad = w.clone()
+    bad[m - 1, k - 4:k] = torch.tensor([3.0, -3.0, 2.5, 2.0], dtype=BF16, device=dev)  # ONE dense quad (four non-zero codes), in the last tile
+    sc, _ = cta.codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+    ref = cta.codec.marlin24_compress_w4_full(w, sc, None, group_size=128, group_perm=128 < k // 2)
+    torch.cuda.synchronize()
+    assert int(ref[3].item()) == 0
+    mb = _lib.mailbox(dev.index or 0)
+    stream = _lib.stream_of_device(dev)
+    for rep in range(30):
+        x, want = (bad, 3) if rep % 3 == 1 else (w, 1)
+        packed = torch.empty_like(ref[0])
+        meta = torch.empty_like(ref[1])
+        sp = torch.empty_like(ref[2])
+        mb.words[1] = 0
+        rc = lib.ct_marlin24_compress_w4_verdict(x.data_ptr(), _lib.BF16, sc.data_ptr(), _lib.BF16, None, -1, m, k, 128, int(128 < k // 2), packed.data_ptr(),
+                                                 meta.data_ptr(), sp.data_ptr(), mb.dev + 8, stream)
+        assert rc == 0, _lib.last_error()
+        got = mb.wait_word(1, 0, stream)
+        assert got == want, (rep, got)
+        torch.cuda.synchronize()
+        assert mb.words[1] == want
+        if want == 1:
+            assert torch.equal(packed, ref[0]) and torch.equal(meta, ref[1]) and torch.equal(sp, ref[2])
+    # fp32 scales are outside the one-launch kernel: refused, nothing launched, the word untouched
+    mb.words[1] = 0
+    rc = lib.ct_marlin24_compress_w4_verdict(w.data_ptr(), _lib.BF16, sc.float().data_ptr(), _lib.F32, None, -1, m, k, 128, 0, packed.data_ptr(), meta.data_ptr(),
+                                             sp.data_ptr(), mb.dev + 8, stream)
+    assert rc != 0 and mb.words[1] == 0
+
+
+def test_marlin24_default_mode_raises_from_the_call_without_draining_the_stream(cta, dev):
+    """the class call in default mode (the ValueError comes from the call itself, as upstream): verdict through the pinned word — same
+    outputs as the deferred mode, the error for a dense weight, and again a clean call afterwards; with a kernel queued BEHIND the
+    compress on the same stream the call still returns (it does not depend on the stream being empty)"""
+    M = cta.Marlin24Compressor
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True))
+    torch.manual_seed(5)
+    w = torch.randn(1024, 2048, dtype=BF16, device=dev)
+    w = w * cta.codec.sparse24_mask(w).to(w.dtype)
+    sc, zp = cta.codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+    sd = {"weight": w, "weight_scale": sc, "weight_zero_point": zp}
+    with M.deferred_structure_check():
+        ref = M.compress(sd, scheme)
+    for rep in range(20):
+        out = M.compress(sd, scheme)
+        assert all(torch.equal(out[k], ref[k]) for k in ("weight_packed", "scale_packed", "meta"))
+        if rep % 4 == 0:
+            dense = dict(sd, weight=torch.randn(1024, 2048, dtype=BF16, device=dev))
+            with pytest.raises(ValueError, match="2:4 sparsity structure"):
+                M.compress(dense, scheme)
 
 
 # ----------------------------------------------------------------------------- qparams of the FLOAT schemes

@@ -16,7 +16,7 @@ import ref_import  # noqa: E402
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_import.available(), reason="no reference on this machine: run oracle/stage_ref.py in the build container")]
 
-COUNTED = ("ct_dequantize", "ct_fake_quantize", "ct_quantize", "ct_pack_int32", "ct_unpack_int32")
+COUNTED = ("ct_dequantize", "ct_fake_quantize", "ct_quantize", "ct_pack_int32", "ct_unpack_int32", "ct_pack_int32_dim0", "ct_unpack_int32_dim0")
 
 
 @pytest.fixture()
@@ -113,14 +113,15 @@ def test_patched_pack_and_unpack_reach_the_kernels(patched, bits, shape, packed_
     ref = p.originals.pack_to_int32(q, bits, packed_dim=packed_dim)
     ref_back = p.originals.unpack_from_int32(ref, bits, torch.Size(shape), packed_dim=packed_dim)
     assert torch.equal(ref_back, q)
+    sfx = "_dim0" if packed_dim == 0 else ""  # packing along rows (the zero points of pack_quantized/base.py:107) has its own entry
     for mod in (p.helpers, p.base):  # base.py:11-14 binds the two names at import time: both bindings are the wrapper
         before = dict(p.counts)
         got = mod.pack_to_int32(q.to(dev), bits, packed_dim=packed_dim)
-        assert p.counts["ct_pack_int32"] == before.get("ct_pack_int32", 0) + 1, dict(p.counts)
+        assert p.counts["ct_pack_int32" + sfx] == before.get("ct_pack_int32" + sfx, 0) + 1, dict(p.counts)
         assert got.is_cuda and got.dtype == ref.dtype and got.shape == ref.shape
         assert torch.equal(got.cpu(), ref)
         back = mod.unpack_from_int32(got, bits, torch.Size(shape), packed_dim=packed_dim)
-        assert p.counts["ct_unpack_int32"] == before.get("ct_unpack_int32", 0) + 1, dict(p.counts)
+        assert p.counts["ct_unpack_int32" + sfx] == before.get("ct_unpack_int32" + sfx, 0) + 1, dict(p.counts)
         assert back.is_cuda and back.dtype == torch.int8 and torch.equal(back.cpu(), q)
 
 

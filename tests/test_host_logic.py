@@ -1079,3 +1079,27 @@ def test_cpp_host_loop_fuzz_against_the_python_loop(cta, monkeypatch):
         hp.set_allow_cpu(False)
         monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
     assert taken > 300  # the batched launches really were exercised
+
+
+def test_the_product_library_carries_no_diagnostic_knobs():
+    """the CT_BITMASK_RESIDENT* environment knobs and the time-stamp argument of the resident sparse compress are compiled
+    into libct_hip_diag.so only (-DCT_DIAG, loaded by the tests that force the alternative forms); the shipped libct_hip.so reads no
+    environment variable of its own and both libraries export the same C ABI"""
+    import re
+    import subprocess
+
+    from compressed_tensors_amd import _lib as ctlib
+
+    assert os.path.exists(ctlib.LIB_PATH) and os.path.exists(ctlib.DIAG_LIB_PATH)
+    with open(ctlib.LIB_PATH, "rb") as f:
+        product = f.read()
+    with open(ctlib.DIAG_LIB_PATH, "rb") as f:
+        diag = f.read()
+    assert b"CT_BITMASK_RESIDENT" not in product and b"CT_BITMASK_RESIDENT_WAIT_US" in diag
+    assert not re.search(rb"CT_[A-Z0-9_]{4,}\x00", product), "an environment-knob-like string is left in the product library"
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("ct_"))
+
+    assert exported(ctlib.LIB_PATH) == exported(ctlib.DIAG_LIB_PATH) == sorted(ctlib.EXPORTED_SYMBOLS)

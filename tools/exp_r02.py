@@ -1,4 +1,5 @@
-"""round-2 experiments (dev helper): python tools/exp_r02.py w4d|bitmask   (knobs come from the environment)"""
+"""round-2 experiments (dev helper): python tools/exp_r02.py w4d|bitmask   (knobs come from the environment)
+(round 5: the CT_BITMASK_RESIDENT* knobs live in libct_hip_diag.so only — set _lib.LIB_PATH = _lib.DIAG_LIB_PATH before the first load() to use them)"""
 import json, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

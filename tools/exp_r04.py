@@ -18,6 +18,9 @@ torch.cuda.set_device(dev)
 what = sys.argv[1]
 from compressed_tensors_amd import _lib, codec
 
+if any(k.startswith("CT_BITMASK_RESIDENT") for k in os.environ):
+    _lib.LIB_PATH = _lib.DIAG_LIB_PATH  # the knobs exist in the diagnostics build only (-DCT_DIAG)
+
 lib = _lib.load()
 stream = torch.cuda.current_stream(dev).cuda_stream
 N = 8192

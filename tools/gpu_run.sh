@@ -8,7 +8,7 @@
 #   bench2     the same once more (-> bench_run2.json)
 #   profile    tools/profile_round.sh <tag> (kernel trace + FETCH / WRITE / SQ counter passes; -> gpurun_out/profile_<tag>/)
 #   exp:<args> python tools/exp_r05.py <args with ',' for spaces>   (-> exp_<args>.jsonl)
-#   sh:<file>  bash <file> (an ad-hoc fragment under gpurun_out/, not tracked)
+#   sh:<file>  bash <file> (an ad-hoc fragment under tools/scratch/: git-ignored, but it travels to the box — gpurun_out/ does not)
 TAG=${1:?tag}; shift
 O=gpurun_out/$TAG; mkdir -p "$O"
 export TMPDIR=/tmp
