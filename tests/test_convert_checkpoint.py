@@ -221,7 +221,7 @@ def test_convert_checkpoint_end_to_end_rate_on_tmpfs():
         print(rec)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "convert_rate.json"), "w"), indent=1)
-        assert max(r["GBps_file_bytes"] for r in rates.values()) >= 6.0, rec
+        assert max(r["GBps_file_bytes"] for r in rates.values()) >= 12.0, rec  # measured 16.1-18.2 on four leases (profiles/r04_convert_rate.json, r05_convert_rate.json)
     finally:
         shutil.rmtree(root, ignore_errors=True)
 
