@@ -944,6 +944,41 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
         hp.set_wait_mode(0)
         assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 2)
         hp.set_wait_mode(1)
+        # round 5: with `ct_marlin24_compress_w4_verdict` bound, the verdict comes from the word the launch stores (1 = 2:4 holds, 3 = violated) — no
+        # stream wait at all; CT_ERR_UNSUPPORTED (a layout outside the one-launch kernel) falls back to the full entry + the stream wait; a launch
+        # that "finishes" without a verdict is an error, never a silent pass
+        vseen = {"calls": 0, "mode": "ok"}
+
+        def verdict(w_, wdt, s_, sdt, zp_, zdt, m, k, g, perm, packed, meta, sp, word, stream):
+            vseen["calls"] += 1
+            vseen["args"] = (wdt, sdt, zp_, zdt, m, k, g, perm, stream, ctypes.c_int64.from_address(word).value)
+            if vseen["mode"] == "unsupported":
+                return ctlib.CT_ERR_UNSUPPORTED
+            if vseen["mode"] != "silent":
+                ctypes.c_int64.from_address(word).value = 3 if vseen["mode"] == "violated" else 1
+            return 0
+
+        cbs["ct_marlin24_compress_w4_verdict"] = ctypes.CFUNCTYPE(I, V, I, V, I, V, I, L, L, L, I, V, V, V, V, V)(verdict)
+        hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
+        waits.update(sync=0, query=0, sync_rc=0)
+        seen.pop("marlin", None)
+        for mode, want in (("ok", False), ("violated", True)):
+            vseen["mode"] = mode
+            box[1] = 99
+            status, violated, packed, meta, sp = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+            assert status == 0 and violated is want and vseen["args"] == (2, 2, None, -1, 64, 256, 128, 1, 77, 0)  # the word was zeroed before the launch
+        assert "marlin" not in seen and waits == {"sync": 0, "query": 0, "sync_rc": 0}  # neither the flag entry nor any stream wait
+        vseen["mode"] = "unsupported"
+        seen["violate"] = True
+        status, violated, *_ = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+        assert status == 0 and violated is True and "marlin" in seen and waits["sync"] == 1
+        seen["violate"] = False
+        vseen["mode"] = "silent"  # the stub's ct_mailbox_wait_i64 hands back the word as it is: still 0 -> not a verdict
+        with pytest.raises(RuntimeError, match="without a 2:4 verdict"):
+            hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+        vseen["mode"] = "ok"
+        del cbs["ct_marlin24_compress_w4_verdict"]
+        hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})  # an older library without the entry: the full entry + wait
         # the same call from the state-dict entries on (Marlin24Compressor.compress): layout tests, element codes, group / permutation choice
         seen["violate"] = False
         D = hp.marlin24_compress_default
