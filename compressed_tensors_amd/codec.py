@@ -1108,7 +1108,7 @@ def marlin24_compress_w4_full(weight: torch.Tensor, scale: torch.Tensor, zero_po
 
 def selftest_m24_div(mode: int, s_lo_bits: int = 0, s_hi_bits: int = 65536) -> int:
     """mismatch count of the lean marlin-24 quotients against the IEEE divide (mode 0: fp16 / fp16 with the Newton step,
-    mode 1: bf16 / bf16 by one multiply)"""
+    mode 1: bf16 / bf16 by one multiply; mode 2: the kernel's reciprocal against `1.0f / s`, bit for bit)"""
     dev = _lib.require_device()
     out = torch.zeros(1, dtype=torch.int64, device=dev)
     call("ct_selftest_m24_div", int(mode), s_lo_bits, s_hi_bits, ptr(out), stream_of(out))

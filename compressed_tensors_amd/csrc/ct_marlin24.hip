@@ -605,10 +605,28 @@ __device__ __forceinline__ void marlin24_word_lean(const uint32_t (&ws)[8], floa
     word = __builtin_amdgcn_perm(0u, w, 0x0c0c0200u);
 }
 
+// floor(n / d) for a wave-uniform n < 2^32 from magic = floor(2^32 / d) (0xffffffff for d = 1): one multiply-high and one correction
+// (floor(n * magic / 2^32) >= floor(n / d) - 1)
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t magic) {
+    const uint32_t q = __umulhi(n, magic);
+    return q + ((n - q * d) >= d ? 1u : 0u);
+}
+
 // the lean scale range: see above (2^-12 keeps sub-fp16-normal weights at code 0)
-__device__ __forceinline__ float m24_lean_rcp(float s16) {
+__device__ __forceinline__ float m24_lean_rcp_ieee(float s16) {  // the reference form: the correctly rounded quotient (kept for the selftest)
     const float as = __builtin_fabsf(s16);
     return ((as >= 0x1p-12f) && (as <= 0x1p15f)) ? 1.0f / s16 : 0.0f;
+}
+// Round 5: v_rcp_f32 + two Newton steps instead of the IEEE divide sequence (div_scale, rcp, four fma, div_fmas, div_fixup + range fix-ups:
+// ~14 instructions -> 5).  In the lean range no scaling is needed, and for every fp16 scale the result is BIT-IDENTICAL to `1.0f / s16`:
+// ct_selftest_m24_div(mode 2) compares the two over all 65536 patterns on the device (tests/test_gpu_parity.py), modes 0 / 1 still check
+// every quotient that is built on it.
+__device__ __forceinline__ float m24_lean_rcp(float s16) {
+    const float as = __builtin_fabsf(s16);
+    float r = __builtin_amdgcn_rcpf(s16);
+    r = __builtin_fmaf(__builtin_fmaf(-s16, r, 1.0f), r, r);
+    r = __builtin_fmaf(__builtin_fmaf(-s16, r, 1.0f), r, r);
+    return ((as >= 0x1p-12f) && (as <= 0x1p15f)) ? r : 0.0f;
 }
 template <int XDT> struct m24_limit;  // largest sum of 16 squares that proves every element is an in-range finite value
 template <> struct m24_limit<CT_BF16> { static constexpr float v = 65280.0f * 65280.0f; };
@@ -619,7 +637,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
                                                                         const int8_t* __restrict__ zp, int64_t m, int64_t k, int64_t cdiv,
                                                                         int64_t scale_cols, int32_t* __restrict__ packed, uint16_t* __restrict__ meta,
                                                                         int* __restrict__ bad, uint16_t* __restrict__ scale_packed, int scale_single, int xcd_rows,
-                                                                        unsigned int* __restrict__ tickets, long long* __restrict__ verdict_word) {
+                                                                        unsigned int* __restrict__ tickets, long long* __restrict__ verdict_word, uint32_t tc_magic) {
     constexpr bool NEWTON = !(XDT == CT_BF16 && SDT == CT_BF16);
     __shared__ __attribute__((aligned(16))) uint16_t s_meta[8][128];
     __shared__ __attribute__((aligned(16))) uint8_t s_code[64][128 + 8];  // +8: rows start on different banks
@@ -632,19 +650,36 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     // lines meet in ONE L2 while the chip as a whole still streams one contiguous 512-row band of the weight: PMC traffic 173.2 -> 162.2 MB
     // (1.072x -> 1.004x the algorithmic bytes: the scale and zero-point matrices are no longer fetched once per XCD), 30.4 -> 29.9 us.
     // (Each XCD on a contiguous EIGHTH of the tiles — eight far-apart streams — measured 36.5 us.)
-    unsigned bid = blockIdx.x;
+    // Round 5: no runtime division on the way to the first load.  The quotients by `tiles_c` come from the host's floor(2^32 / tiles_c) and one
+    // scalar multiply-high each (a wave-uniform `/` is a 12-instruction float-reciprocal sequence in the VECTOR unit, two of them quarter-rate
+    // multiplies, and three of those sat in front of the address of the first weight load; the 64-bit `/ cdiv` pair of the scale_packed tail
+    // was another 156 vector + 343 scalar instructions per wave: of the 716 vector instructions a wave executed, ~180 were index arithmetic).
+    int tile_r, tile_c;
     if (xcd_rows) {
-        const unsigned x = bid & 7u, i = bid >> 3;
-        bid = ((i / (unsigned)tiles_c) * 8u + x) * (unsigned)tiles_c + (i % (unsigned)tiles_c);
+        const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+        const uint32_t q = udiv_magic(i, (uint32_t)tiles_c, tc_magic);
+        tile_r = (int)(q * 8u + x);
+        tile_c = (int)(i - q * (uint32_t)tiles_c);
+    } else {
+        tile_r = (int)udiv_magic(blockIdx.x, (uint32_t)tiles_c, tc_magic);
+        tile_c = (int)(blockIdx.x - (uint32_t)tile_r * (uint32_t)tiles_c);
     }
-    const int tile_r = (int)(bid / (unsigned)tiles_c), tile_c = (int)(bid - (unsigned)tile_r * (unsigned)tiles_c);
     const int tid = threadIdx.x;
     const uint32_t per = (uint32_t)(cdiv >> 4);
     const bool per_pow2 = (per & (per - 1)) == 0;
     const int per_shift = __builtin_ctz(per);
     const int cl = tid & 15, rl0 = tid >> 4;
     const uint32_t mc = (uint32_t)tile_c * 16u + (uint32_t)cl;
-    const uint32_t grp = per_pow2 ? (mc >> per_shift) : (mc / per);
+    uint32_t grp, g_first, g_last;  // this lane's group, the tile's first and last group
+    if (per_pow2) {  // wave-uniform; kept a BRANCH (hipcc turns `pow2 ? shift : divide` into both + a select: the divide then always runs)
+        grp = mc >> per_shift;
+        g_first = ((uint32_t)tile_c * 16u) >> per_shift;
+        g_last = ((uint32_t)tile_c * 16u + 15u) >> per_shift;
+    } else {
+        grp = mc / per;
+        g_first = ((uint32_t)tile_c * 16u) / per;
+        g_last = ((uint32_t)tile_c * 16u + 15u) / per;
+    }
     // position of this lane's metadata word inside its column pair's 256-byte run (meta_reorder_offset in local terms): the
     // row permutation only involves the row inside its 64-row group, the column swap stays inside the column pair
     int dr0 = (rl0 & 1) * 2 + ((rl0 & 7) >> 2) + ((rl0 & 3) >> 1) * 32 + (rl0 >> 3) * 4;
@@ -662,12 +697,13 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     // "conversion while the weights are in flight" waited for every weight first and the whole load latency of a workgroup was exposed
     // (the ISA showed it).  Now the conversion (a divide) and the LDS hand-over run under the weight loads, and the four words are
     // consumed behind vmcnt(6 / 4 / 2 / 0) as they land.
-    const uint32_t g_first = per_pow2 ? (((uint32_t)tile_c * 16u) >> per_shift) : (((uint32_t)tile_c * 16u) / per);
-    const uint32_t g_last = per_pow2 ? (((uint32_t)tile_c * 16u + 15u) >> per_shift) : (((uint32_t)tile_c * 16u + 15u) / per);
     const int ng = (int)(g_last - g_first) + 1;  // <= 16
     const int n_entries = 64 * ng;
     const int e0 = tid < n_entries ? tid : n_entries - 1;
-    const int rl_e = e0 / ng, gi_e = e0 - rl_e * ng;
+    int rl_e;
+    if ((ng & (ng - 1)) == 0) rl_e = e0 >> __builtin_ctz((unsigned)ng);  // ng: 1, 2, 4, ... for power-of-two groups (wave-uniform branch)
+    else rl_e = e0 / ng;
+    const int gi_e = e0 - rl_e * ng;
     const int64_t si_e = ((int64_t)tile_r * 64 + rl_e) * scale_cols + g_first + gi_e;
     // (inline asm: hipcc sinks an ordinary small load to its first use, below the eight wide ones, and a volatile one is waited for
     // on the spot; these two are issued here and waited for by hand — `vmcnt(8)`: everything but the eight weight loads issued after them)
@@ -811,9 +847,10 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     // (groups, size_n) matrix per group, permuted inside itself — a contiguous 128-byte run.  The tile that holds a group's
     // first column writes it (groups of <= 256 columns: all of the tile's; wider groups / channel-wise: one tile in several).
     if (scale_packed != nullptr) {
-        const int64_t col0 = (int64_t)tile_c * 256;
-        const int64_t g_first = (col0 + cdiv - 1) / cdiv;  // first group starting at or after col0
-        const int n_here = (int)(((col0 + 256 + cdiv - 1) / cdiv) - g_first);  // groups starting inside [col0, col0 + 256)
+        const uint32_t col0 = (uint32_t)tile_c * 256u, cd = (uint32_t)cdiv;  // cdiv <= k < 2^31 (the launcher clamps it)
+        const int cshift = per_shift + 4;  // cdiv = 16 * per
+        const int64_t g_first = per_pow2 ? ((col0 + cd - 1u) >> cshift) : ((col0 + cd - 1u) / cd);  // first group starting at or after col0
+        const int n_here = (int)((per_pow2 ? ((col0 + 256u + cd - 1u) >> cshift) : ((col0 + 256u + cd - 1u) / cd)) - (uint32_t)g_first);  // groups starting inside [col0, col0 + 256)
         for (int e = tid; e < n_here * 64; e += kBlock) {
             const int gi = e >> 6, j = e & 63;
             const int pj = scale_single ? j : ((j & ~7) + (((j & 7) >> 1) | ((j & 1) << 2)));  // scale_perm: [0, 4, 1, 5, 2, 6, 3, 7] per 8
@@ -828,6 +865,14 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
 // mode 1 = bf16 x in the fp16-exact range, bf16 scale in the lean range, single multiply.  Same pass criterion as selftest_f16_div_kernel.
 __global__ __launch_bounds__(kBlock) void selftest_m24_div_kernel(int mode, uint32_t s_lo, uint32_t s_hi, unsigned long long* mismatches) {
     unsigned long long local = 0;
+    if (mode == 2) {  // the kernel's reciprocal against the IEEE divide, bit for bit, for every fp16 pattern in [s_lo, s_hi)
+        for (uint32_t sb = s_lo + blockIdx.x * kBlock + threadIdx.x; sb < s_hi; sb += gridDim.x * kBlock) {
+            const float s = f16_bits_to_f(sb);
+            local += f_bits(m24_lean_rcp(s)) != f_bits(m24_lean_rcp_ieee(s)) ? 1ull : 0ull;
+        }
+        if (local) atomicAdd(mismatches, local);
+        return;
+    }
     for (uint32_t sb = s_lo + blockIdx.x; sb < s_hi; sb += gridDim.x) {
         const float s = mode == 0 ? f16_bits_to_f(sb) : round_to<CT_F16>(bf16_bits_to_f(sb));
         const float rs = m24_lean_rcp(s);
@@ -1004,9 +1049,16 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
         // last workgroup has reported; the default-mode call this serves waits for exactly that before it returns, so a host thread
         // never has two launches on one tree, and sixteen threads can be in the call at once)
         static std::atomic<unsigned> next_tree{0};
-        unsigned int* base = nullptr;
-        hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_m24_tickets));
-        if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict tickets");
+        static std::atomic<unsigned int*> tree_base[64];  // per device: the address of this device's copy of g_m24_tickets (looked up once)
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict device");
+        unsigned int* base = dev >= 0 && dev < 64 ? tree_base[dev].load(std::memory_order_relaxed) : nullptr;
+        if (base == nullptr) {
+            e = hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_m24_tickets));
+            if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict tickets");
+            if (dev >= 0 && dev < 64) tree_base[dev].store(base, std::memory_order_relaxed);
+        }
         tickets = base + (size_t)(next_tree.fetch_add(1u) % kM24Trees) * kM24TreeWords;
     }
     if (clear_bad) {
@@ -1021,8 +1073,9 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
 #define CT_M24_LEAN(X, S)                                                                                                                      \
     hipLaunchKernelGGL((marlin24_fused_w4_lean_kernel<X, S>), dim3(tg), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(w), \
                        static_cast<const uint16_t*>(scale), static_cast<const int8_t*>(zp), m, k, c, k / c, packed, reinterpret_cast<uint16_t*>(meta), bad, \
-                       static_cast<uint16_t*>(scale_packed), scale_single, xcd_rows, tickets, verdict_word)
+                       static_cast<uint16_t*>(scale_packed), scale_single, xcd_rows, tickets, verdict_word, tc_magic)
         const int xcd_rows = (m / 64) % 8 == 0 ? 1 : 0;  // the row blocks divide evenly over the eight XCDs
+        const uint32_t tc_magic = k / 256 == 1 ? 0xffffffffu : (uint32_t)(((uint64_t)1 << 32) / (uint64_t)(k / 256));
         if (wdt == CT_BF16 && sdt == CT_BF16) CT_M24_LEAN(CT_BF16, CT_BF16);
         else if (wdt == CT_BF16) CT_M24_LEAN(CT_BF16, CT_F16);
         else if (sdt == CT_BF16) CT_M24_LEAN(CT_F16, CT_BF16);
@@ -1072,7 +1125,7 @@ int ct_marlin24_compress_w4_verdict(const void* w, int wdt, const void* scale, i
 }
 
 int ct_selftest_m24_div(int mode, uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {
-    CT_REQUIRE((mode == 0 || mode == 1) && s_lo_bits <= s_hi_bits && s_hi_bits <= 65536u, "bad mode / scale bit range");
+    CT_REQUIRE((mode == 0 || mode == 1 || mode == 2) && s_lo_bits <= s_hi_bits && s_hi_bits <= 65536u, "bad mode / scale bit range");
     hipError_t e = hipMemsetAsync(mismatches, 0, sizeof(unsigned long long), as_stream(stream));
     if (e != hipSuccess) return hip_check(e, "ct_selftest_m24_div memset");
     if (s_lo_bits == s_hi_bits) return CT_OK;

@@ -403,7 +403,8 @@ int ct_selftest_f16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long lo
 int ct_selftest_bf16_div(uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
                          ct_stream_t stream);
 /* the quotients of the lean marlin-24 front end (ct_marlin24_compress_w4): mode 0 = fp16 x / fp16 scale by reciprocal +
- * Newton step, mode 1 = bf16 x / bf16 scale by ONE multiply with the reciprocal; s bits in [s_lo_bits, s_hi_bits) */
+ * Newton step, mode 1 = bf16 x / bf16 scale by ONE multiply with the reciprocal, mode 2 = the kernel's reciprocal (v_rcp_f32 + two
+ * Newton steps) against the IEEE 1.0f / s, bit for bit; s bits in [s_lo_bits, s_hi_bits) */
 int ct_selftest_m24_div(int mode, uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches,
                         ct_stream_t stream);
 

@@ -1066,6 +1066,39 @@ def test_bitmask_compress_forms_agree(env):
     assert r.returncode == 0 and "FORMS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16, F32, torch.int16, torch.int32], ids=["bf16", "fp16", "fp32", "int16", "int32"])
+def test_bitmask_compress_every_bit_pattern(cta, dev, dtype):
+    """the non-zero test of the sparse compress on every 16-bit pattern (and, for 32-bit payloads, every exponent x sign x {zero, lowest bit,
+    highest bit, all ones} significand): +-0 are zeros, denormals, NaNs and infinities are kept, integers by value — as `x != 0` in torch;
+    round 5's row form (32-bit payloads) and the unit form (16-bit) against the integer rule, values / bitmask / row offsets bit for bit"""
+    import numpy as np
+
+    if dtype.itemsize == 2:
+        bits = torch.arange(65536, dtype=torch.int32).to(torch.int16).reshape(128, 512)
+        x = bits.view(dtype)
+    else:
+        sign, expo = torch.arange(2, dtype=torch.int64), torch.arange(256, dtype=torch.int64)
+        frac = torch.tensor([0, 1, 1 << 22, (1 << 23) - 1, 0x2aaaaa, 12345, 1 << 12, 0x7ffffe], dtype=torch.int64)
+        bits = (sign[:, None, None] << 31) | (expo[None, :, None] << 23) | frac[None, None, :]
+        bits = bits.reshape(-1).repeat(4)  # 16384 elements
+        bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32).reshape(64, 256)
+        x = bits.view(dtype)
+    is_float = dtype in (BF16, F16, F32)
+    mask_sign = (1 << (8 * dtype.itemsize - 1)) - 1
+    keep = ((bits.to(torch.int64) & mask_sign) != 0) if is_float else (bits != 0)
+    assert torch.equal(keep, x != 0) or not is_float  # torch agrees with the integer rule (float `!=`: NaN != 0 is True, -0.0 != 0 is False)
+    iv = torch.int16 if dtype.itemsize == 2 else torch.int32
+    want_v = bits.to(iv)[keep]
+    want_bm = torch.from_numpy(np.packbits(keep.numpy(), axis=1, bitorder="little"))
+    want_ro = torch.cumsum(keep.sum(1), 0) - keep.sum(1)
+    for two_pass in (False, True):
+        v, bm, ro = cta.codec.bitmask_compress(x.to(dev), two_pass=two_pass)
+        assert v.dtype == dtype and torch.equal(v.cpu().view(iv), want_v) and torch.equal(bm.cpu(), want_bm) and torch.equal(ro.cpu(), want_ro), (dtype, two_pass)
+    back = cta.codec.bitmask_decompress(v, bm, x.shape, ro)
+    want_back = torch.where(keep, bits.to(iv), torch.zeros_like(bits.to(iv)))  # a dropped -0.0 comes back as +0.0
+    assert torch.equal(back.cpu().view(iv), want_back)
+
+
 def test_bitmask_compress_concurrent_streams(cta, dev):
     """resident compress kernels in flight at once on two streams (raw ABI, no host synchronisation between launches) next to a GEMM that
     occupies CUs: workgroups of one kernel wait for workgroups that are not resident yet.  Dependencies only point to earlier workgroups,
@@ -2043,6 +2076,7 @@ def test_marlin24_lean_quotients_are_exact(cta):
     the IEEE quotient for every scale in the lean range x all 65536 weights"""
     assert cta.codec.selftest_m24_div(0) == 0
     assert cta.codec.selftest_m24_div(1) == 0
+    assert cta.codec.selftest_m24_div(2) == 0  # round 5: v_rcp_f32 + two Newton steps == the IEEE `1.0f / s` for every fp16 scale, bit for bit
 
 
 def test_marlin24_deferred_structure_check(cta, dev):
