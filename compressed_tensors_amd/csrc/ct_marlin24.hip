@@ -834,12 +834,17 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     // 5 instead of 4 waves per SIMD: 35.6 us, no change; the 32-byte-per-lane read shape against lane-contiguous 16-byte reads
     // (tools/kbench/kbench_readshape.hip): 21.6 against 21.9 us for the 134 MB, no difference.  What is left is instruction
     // issue: 12.3 M vector instructions per launch, ~7 per element of packed-float / dot work that issues at half rate.)
+    // (round 5: the eight byte addresses are formed ONCE — table offset + this thread's k-tile half — and the four k-tiles of a thread are
+    // the immediate offsets 0 / 32 / 64 / 96 of the reads; the extract-and-add per read was 32 vector instructions per thread)
+    uint32_t src_base[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) src_base[e] = src_off[e] + (uint32_t)(tid >> 7) * 16u;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int t = (tid >> 7) + 2 * it;  // k-tile inside the workgroup tile
         uint32_t word = 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) word |= (uint32_t)sc[src_off[e] + t * 16] << (4 * e);
+        for (int e = 0; e < 8; ++e) word |= (uint32_t)sc[src_base[e] + (uint32_t)(it * 32)] << (4 * e);
         // streaming store: a plain one leaves the line dirty in the XCD's L2 and the kernel ends with a write-back bubble
         __builtin_nontemporal_store((int32_t)word, packed + ((int64_t)tile_c * 8 + t) * wpr + (int64_t)tile_r * 128 + (tid & 127));
     }
