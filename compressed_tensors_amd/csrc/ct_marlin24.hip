@@ -557,8 +557,8 @@ __device__ __forceinline__ float m24_sumsq(uint32_t d, float acc, std::integral_
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2_t, d), __builtin_bit_cast(h2_t, d), acc, false);
 }
 
-// 16 elements -> 8 kept codes as unsigned nibbles-in-bytes (c + 8), the 16-bit metadata word, 16 * (8 * count) folded into
-// vmax, the sum of squares of the inputs.  No zero point.
+// 16 elements -> 8 kept codes as unsigned nibbles-in-bytes (c + 8), the 16-bit metadata word, 8 * count (+ the table index) folded
+// into vmax, the sum of squares of the inputs.  No zero point.
 template <int XDT, bool NEWTON>
 __device__ __forceinline__ void marlin24_word_lean(const uint32_t (&ws)[8], float s16, float rs, u32x2& codes, uint32_t& word, uint32_t& vmax, float& sumsq) {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -583,23 +583,26 @@ __device__ __forceinline__ void marlin24_word_lean(const uint32_t (&ws)[8], floa
             u[h] = __builtin_bit_cast(uint32_t, t16);
         }
         P[q] = __builtin_amdgcn_perm(u[1], u[0], 0x06040200u);  // byte j = c_j + 8
-        const uint32_t nz = ((P[q] ^ 0x08080808u) + 0x0f0f0f0fu) & 0x10101010u;
-        R[q] = __builtin_amdgcn_udot4(nz, 0x0c080a09u, 0u, false);  // 16 * (m0 + 2 m1 + 4 m3 + 8 * count)
+        // v_msad_u8(a, ref, acc) = acc + the sum over the bytes with ref != 0 of |a - ref|: with ref = the code bytes (zero code = byte 0)
+        // and a = ref + weight (no carries: 15 + 12 < 256) every NON-ZERO code adds exactly its weight — the non-zero flags and their weighted
+        // sum in three instructions (xor, add, msad; round 4 took four: xor, add, and, v_dot4_u32_u8 — and its R came scaled by 16)
+        const uint32_t z = P[q] ^ 0x08080808u;
+        R[q] = __builtin_amdgcn_msad_u8(z + 0x0c080a09u, z, 0u);  // m0 + 2 m1 + 4 m3 + 8 * count
     }
     const uint32_t r01 = R[0] > R[1] ? R[0] : R[1], r23 = R[2] > R[3] ? R[2] : R[3];
     vmax = vmax > r01 ? vmax : r01;
     vmax = vmax > r23 ? vmax : r23;
-    const uint32_t idx4 = ((R[0] >> 4) & 7u) | (((R[1] >> 4) & 7u) << 8) | (((R[2] >> 4) & 7u) << 16) | (((R[3] >> 4) & 7u) << 24);
     constexpr uint64_t kLo = quad_position_table<false>(), kHi = quad_position_table<true>();
+    // R < 64: OR-ed together at byte distance, bits 0-2 of byte q are quad q's table index (three shift-ors and one mask; round 4 extracted
+    // and placed the four indices one by one: eight instructions)
+    const uint32_t idx4 = (R[0] | (R[1] << 8) | (R[2] << 16) | (R[3] << 24)) & 0x07070707u;
     const uint32_t lo4 = __builtin_amdgcn_perm((uint32_t)(kLo >> 32), (uint32_t)kLo, idx4);  // first kept position of each quad
     const uint32_t hi4 = __builtin_amdgcn_perm((uint32_t)(kHi >> 32), (uint32_t)kHi, idx4);  // second kept position
-    uint32_t two[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t sel = __builtin_amdgcn_perm(hi4, lo4, 0x0c0c0000u | ((4u + q) << 8) | (uint32_t)q);
-        two[q] = __builtin_amdgcn_perm(0u, P[q], sel);  // bytes 0, 1 = the kept codes (bytes 2, 3: don't care)
-    }
-    codes = u32x2{__builtin_amdgcn_perm(two[1], two[0], 0x05040100u), __builtin_amdgcn_perm(two[3], two[2], 0x05040100u)};
+    // the kept codes of TWO quads in one v_perm over the register pair (P[q + 1], P[q]): selector bytes = (first, second) position of quad q,
+    // the same of quad q + 1 with 4 added — three instructions per pair (round 4: a selector and a pick per quad plus a merge, five)
+    const uint32_t s01 = __builtin_amdgcn_perm(hi4, lo4, 0x05010400u) | 0x04040000u;
+    const uint32_t s23 = __builtin_amdgcn_perm(hi4, lo4, 0x07030602u) | 0x04040000u;
+    codes = u32x2{__builtin_amdgcn_perm(P[1], P[0], s01), __builtin_amdgcn_perm(P[3], P[2], s23)};
     const uint32_t qc4 = (hi4 << 2) | lo4;  // one 4-bit quad code per byte
     const uint32_t w = qc4 | __builtin_amdgcn_alignbit(qc4, qc4, 4);
     word = __builtin_amdgcn_perm(0u, w, 0x0c0c0200u);
@@ -632,6 +635,7 @@ template <int XDT> struct m24_limit;  // largest sum of 16 squares that proves e
 template <> struct m24_limit<CT_BF16> { static constexpr float v = 65280.0f * 65280.0f; };
 template <> struct m24_limit<CT_F16> { static constexpr float v = 16.0f * 65504.0f * 65504.0f; };
 
+constexpr int64_t kM24LeanMaxDim = (int64_t)1 << 24;  // rows / columns the lean kernel's 32-bit lane offsets cover (see the loads)
 template <int XDT, int SDT>
 __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const uint16_t* __restrict__ w, const uint16_t* __restrict__ scale,
                                                                         const int8_t* __restrict__ zp, int64_t m, int64_t k, int64_t cdiv,
@@ -704,31 +708,39 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     if ((ng & (ng - 1)) == 0) rl_e = e0 >> __builtin_ctz((unsigned)ng);  // ng: 1, 2, 4, ... for power-of-two groups (wave-uniform branch)
     else rl_e = e0 / ng;
     const int gi_e = e0 - rl_e * ng;
-    const int64_t si_e = ((int64_t)tile_r * 64 + rl_e) * scale_cols + g_first + gi_e;
     // (inline asm: hipcc sinks an ordinary small load to its first use, below the eight wide ones, and a volatile one is waited for
     // on the spot; these two are issued here and waited for by hand — `vmcnt(8)`: everything but the eight weight loads issued after them)
     uint32_t sb_e;
     int32_t zb_e;
-    {
-        const uint16_t* sp = scale + si_e;
-        const int8_t* zq = zp != nullptr ? zp + si_e : reinterpret_cast<const int8_t*>(sp);
-        asm volatile("global_load_ushort %0, %1, off" : "=v"(sb_e) : "v"(sp) : "memory");
-        asm volatile("global_load_sbyte %0, %1, off" : "=v"(zb_e) : "v"(zq) : "memory");
-    }
-    // all 128 bytes of this lane's four words are requested before the first one is used
+    // Round 5 (second half): every address of the hot path is a wave-uniform 64-bit base (scalar registers) plus a 32-bit lane offset —
+    // the `saddr` form of the global instructions — instead of 64-bit vector arithmetic per access (v_mad_u64_u32 + two v_mul_lo_u32 +
+    // v_add3 + v_lshl_add_u64 in front of each of the four packed stores, the same in front of the loads).  The launcher takes this
+    // kernel for m, k < 2^24 only (a tile's lane offsets then stay below 2^32).
     u32x4 wa[4], wb[4];
+    {
+        const int64_t s_uni = (int64_t)tile_r * 64 * scale_cols + g_first;                   // wave-uniform part of the entry's index
+        const uint32_t s_lane = (uint32_t)rl_e * (uint32_t)scale_cols + (uint32_t)gi_e;       // < 64 * scale_cols
+        const uint16_t* sbase = scale + s_uni;
+        const int8_t* zbase = zp != nullptr ? zp + s_uni : reinterpret_cast<const int8_t*>(sbase);
+        const uint32_t soff = s_lane * 2u, zoff = zp != nullptr ? s_lane : soff;
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(sb_e) : "v"(soff), "s"(sbase) : "memory");
+        asm volatile("global_load_sbyte %0, %1, %2" : "=v"(zb_e) : "v"(zoff), "s"(zbase) : "memory");
+        // all 128 bytes of this lane's four words are requested before the first one is used
+        const char* wbase = reinterpret_cast<const char*>(w + ((int64_t)tile_r * 64 * k + (int64_t)tile_c * 256));
+        const uint32_t woff = ((uint32_t)rl0 * (uint32_t)k + (uint32_t)cl * 16u) * 2u;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int64_t r = (int64_t)tile_r * 64 + it * 16 + rl0;
-        const u32x4* in = reinterpret_cast<const u32x4*>(w + r * k + (int64_t)mc * 16);
-        wa[it] = in[0];
-        wb[it] = in[1];
+        for (int it = 0; it < 4; ++it) {
+            const u32x4* in = reinterpret_cast<const u32x4*>(wbase + (size_t)(woff + (uint32_t)it * 32u * (uint32_t)k));
+            wa[it] = in[0];
+            wb[it] = in[1];
+        }
     }
     asm volatile("s_waitcnt vmcnt(8)" : "+v"(sb_e), "+v"(zb_e) : : "memory");
     {
         const float s16 = SDT == CT_F16 ? f16_bits_to_f(sb_e) : round_to<CT_F16>(bf16_bits_to_f(sb_e));  // scale.to(fp16)
         float rs = m24_lean_rcp(s16);
         if (zp != nullptr && zb_e != 0) rs = 0.0f;
+        rs = rs == 0.0f ? __builtin_nanf("") : rs;  // the "exact path" marker in LDS is a NaN: it poisons the word's sum of squares by itself
         if (tid < n_entries) {
             s_rs[rl_e][gi_e] = rs;
             if (NEWTON) s_s16[rl_e][gi_e] = s16;
@@ -742,6 +754,7 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         const float s16 = SDT == CT_F16 ? f16_bits_to_f(sb) : round_to<CT_F16>(bf16_bits_to_f(sb));
         float rs = m24_lean_rcp(s16);
         if (zp != nullptr && zp[si] != 0) rs = 0.0f;
+        rs = rs == 0.0f ? __builtin_nanf("") : rs;
         s_rs[rl][gi] = rs;
         if (NEWTON) s_s16[rl][gi] = s16;
         s_sbits[rl][gi] = SDT == CT_BF16 ? (uint16_t)f_to_f16_bits(s16) : (uint16_t)sb;
@@ -758,10 +771,12 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         const float s16 = NEWTON ? s_s16[rl][gl] : 0.0f;  // only the Newton step reads the scale itself
         u32x2 codes;
         uint32_t word;
-        float sumsq = 0.0f;
+        // (a NaN reciprocal — scale outside the lean range, non-zero zero point — starts the sum as NaN, so the one range test below also
+        // sends those words to the exact path: no separate compare of rs per word)
+        float sumsq = rs * 0.0f;
         uint32_t vm = 0;
         marlin24_word_lean<XDT, NEWTON>(ws, s16, rs, codes, word, vm, sumsq);
-        const bool special = !(sumsq <= m24_limit<XDT>::v) || rs == 0.0f;
+        const bool special = !(sumsq <= m24_limit<XDT>::v);
         redo |= special ? (1u << it) : 0u;
         vmax = (!special && vm > vmax) ? vm : vmax;
         *reinterpret_cast<u32x2*>(&s_code[rl][cl * 8]) = codes;
@@ -779,11 +794,12 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
             s_meta[cl >> 1][mpos0 + it * 16] = (uint16_t)word;
         }
     }
-    const bool lane_bad = violation || vmax >= 16u * 24u;  // a quad with three or more non-zero codes
+    const bool lane_bad = violation || vmax >= 24u;  // a quad with three or more non-zero codes
     // the permutation row of the packing phase is requested here — the weight registers are dead (and so is the rare exact path, which
     // needs the registers itself: requested above it, the row cost the fifth wave per SIMD) — so that its ~1 us (an L2 hit) passes
     // under the barrier and the metadata store instead of in front of the packing loop, where round 3 fetched it
-    const u32x4 so = *reinterpret_cast<const u32x4*>(&kMarlin4Src.off[tid & 127][0]);
+    // (entries 0-3 only: entry e + 4 is the byte behind entry e, see the packing loop)
+    const u32x2 so = *reinterpret_cast<const u32x2*>(&kMarlin4Src.off[tid & 127][0]);
     // Round 5, verdict mode (`tickets` != nullptr; ct_marlin24_compress_w4_verdict): the host wants "does the WHOLE tensor keep 2:4?" as early
     // as the device knows it, without waiting for the launch to drain (hipStreamSynchronize added ~15 us to the default-mode class call).
     // Every workgroup reports once, through a two-level ticket tree: leaf counter b % leaves (count in the low half, violating workgroups in
@@ -806,8 +822,9 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     }
     {
         const int pair = tid >> 5, chunk = tid & 31;  // 8 pairs x 32 chunks of 4 int16
-        const int64_t pair_base = ((int64_t)tile_c * 8 + pair) * m * 2 + (int64_t)tile_r * 128;
-        stream_store8(meta + pair_base + chunk * 4, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
+        char* mbase = reinterpret_cast<char*>(meta + ((int64_t)tile_c * 8 * m * 2 + (int64_t)tile_r * 128));  // wave-uniform
+        const uint32_t moff = ((uint32_t)pair * (uint32_t)m * 2u + (uint32_t)chunk * 4u) * 2u;
+        stream_store8(mbase + (size_t)moff, *reinterpret_cast<const u32x2*>(&s_meta[pair][chunk * 4]));
     }
     // the tree is closed HERE, ahead of the packing loop (the leaf atomic was issued above the metadata store; only wave 0 waits for it): the
     // verdict of the launch's last workgroup then travels while that workgroup packs, instead of starting its two round trips after it
@@ -826,27 +843,34 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         }
     }
     const uint8_t* sc = &s_code[0][0];
-    const uint32_t src_off[8] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16, so.z & 0xffffu, so.z >> 16, so.w & 0xffffu, so.w >> 16};
+    const uint32_t src_off[4] = {so.x & 0xffffu, so.x >> 16, so.y & 0xffffu, so.y >> 16};
     const int64_t wpr = m * 2;  // packed words per k-tile row (size_n * 16 * 4 / 32)
     // (a thread building FOUR consecutive words of one k-tile — four table rows, one 16-byte streaming store — measured slower:
     // 38.9 vs 36.2 us; the same word position in four k-tiles reuses one table row and its 4-byte stores are 512-byte runs.
     // Round 3: staging the words through 4 KB of LDS so that they leave as one 16-byte store per thread: 35.3 us, no change;
     // 5 instead of 4 waves per SIMD: 35.6 us, no change; the 32-byte-per-lane read shape against lane-contiguous 16-byte reads
-    // (tools/kbench/kbench_readshape.hip): 21.6 against 21.9 us for the 134 MB, no difference.  What is left is instruction
-    // issue: 12.3 M vector instructions per launch, ~7 per element of packed-float / dot work that issues at half rate.)
-    // (round 5: the eight byte addresses are formed ONCE — table offset + this thread's k-tile half — and the four k-tiles of a thread are
-    // the immediate offsets 0 / 32 / 64 / 96 of the reads; the extract-and-add per read was 32 vector instructions per thread)
-    uint32_t src_base[8];
+    // (tools/kbench/kbench_readshape.hip): 21.6 against 21.9 us for the 134 MB, no difference.)
+    // Round 5: the byte addresses are formed ONCE — table offset + this thread's k-tile half — and the four k-tiles of a thread are the
+    // immediate offsets 0 / 32 / 64 / 96 of the reads.  Nibbles e and e + 4 of a word are the codes of compressed columns 2a and 2a + 1
+    // of ONE row (permutations_24.py:26-33: the interleave [0, 2, 4, 6, 1, 3, 5, 7] over rows 2a, 2a + 1, 2a + 8, 2a + 9 of two 4-column
+    // blocks), i.e. two adjacent bytes of the code tile at an even address: four 16-bit reads instead of eight byte reads,
+    // v = n_e | n_(e+4) << 8.  v0 | v1 << 4 is the byte pair (n0 n1, n4 n5), v2 | v3 << 4 the pair (n2 n3, n6 n7), one v_perm interleaves
+    // them: 3 vector + 4 LDS instructions per word for 8 + 8.
+    uint32_t src_base[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) src_base[e] = src_off[e] + (uint32_t)(tid >> 7) * 16u;
+    for (int e = 0; e < 4; ++e) src_base[e] = src_off[e] + (uint32_t)(tid >> 7) * 16u;
+    char* pbase = reinterpret_cast<char*>(packed + ((int64_t)tile_c * 8 * wpr + (int64_t)tile_r * 128));  // wave-uniform
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int t = (tid >> 7) + 2 * it;  // k-tile inside the workgroup tile
-        uint32_t word = 0;
+        uint32_t v[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) word |= (uint32_t)sc[src_base[e] + (uint32_t)(it * 32)] << (4 * e);
+        for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const uint16_t*>(sc + src_base[e] + (uint32_t)(it * 32));
+        const uint32_t a = v[0] | (v[1] << 4), b = v[2] | (v[3] << 4);
+        const uint32_t word = __builtin_amdgcn_perm(b, a, 0x05010400u);
         // streaming store: a plain one leaves the line dirty in the XCD's L2 and the kernel ends with a write-back bubble
-        __builtin_nontemporal_store((int32_t)word, packed + ((int64_t)tile_c * 8 + t) * wpr + (int64_t)tile_r * 128 + (tid & 127));
+        const uint32_t poff = ((uint32_t)t * (uint32_t)wpr + (uint32_t)(tid & 127)) * 4u;
+        __builtin_nontemporal_store((int32_t)word, reinterpret_cast<int32_t*>(pbase + (size_t)poff));
     }
     // scale_packed (marlin24_pack_scales_kernel fused in): the 64 rows of this tile are one 64-entry row of the transposed
     // (groups, size_n) matrix per group, permuted inside itself — a contiguous 128-byte run.  The tile that holds a group's
@@ -1046,9 +1070,9 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
     CT_REQUIRE((m / 64) * (k / 256) < ((int64_t)1 << 31), "tensor too large for one launch");
     unsigned int* tickets = nullptr;
     if (verdict_word != nullptr) {
-        const bool lean_ok = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8);
+        const bool lean_ok = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8) && m < kM24LeanMaxDim && k < kM24LeanMaxDim;
         if (!lean_ok || (m / 64) * (k / 256) >= (int64_t)64 * 65535 || m == 0 || k == 0) {
-            CT_UNSUPPORTED("ct_marlin24_compress_w4_verdict: layout outside the one-launch kernel (16-bit scales, int8 or no zero point, < 4.2 M tiles)");
+            CT_UNSUPPORTED("ct_marlin24_compress_w4_verdict: layout outside the one-launch kernel (16-bit scales, int8 or no zero point, < 4.2 M tiles, sides < 2^24)");
         }
         // one ticket tree per launch in flight: 16 trees per device, handed out round robin (a tree is back at zero when its launch's
         // last workgroup has reported; the default-mode call this serves waits for exactly that before it returns, so a host thread
@@ -1073,7 +1097,8 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
     if (m == 0 || k == 0) return CT_OK;
     const int64_t c = cdiv > k ? k : cdiv;
     const unsigned tg = (unsigned)((m / 64) * (k / 256));
-    const bool lean = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8);
+    // (the lean kernel forms its lane offsets in 32 bits: sides below 2^24; anything larger takes the general fused kernel)
+    const bool lean = (sdt == CT_F16 || sdt == CT_BF16) && (zp == nullptr || zdt == CT_I8) && m < kM24LeanMaxDim && k < kM24LeanMaxDim;
     if (lean) {
 #define CT_M24_LEAN(X, S)                                                                                                                      \
     hipLaunchKernelGGL((marlin24_fused_w4_lean_kernel<X, S>), dim3(tg), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(w), \
