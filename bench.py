@@ -293,7 +293,8 @@ def valu_busy_from_profile(path=None):
             return {}
         path = cands[-1]
     alias = {"ct::w4_quant_pack_lean_kernel<2, true>": "w4_quant_pack_lean_kernel<bf16>",
-             "ct::w4_unpack_dequant_kernel<2, 2, false, false>": "w4_unpack_dequant_kernel<bf16>"}
+             "ct::w4_unpack_dequant_kernel<2, 2, false, false>": "w4_unpack_dequant_kernel<bf16>",   # until round 5 (bool ROWLEAD)
+             "ct::w4_unpack_dequant_kernel<2, 2, false, 2>": "w4_unpack_dequant_kernel<bf16>"}       # scale mode 2: scalar loads
     out = {}
     try:
         txt = open(path).read().splitlines()

@@ -807,10 +807,35 @@ __device__ __forceinline__ uint32_t row_leader_value(uint32_t v) {
 // word, 2-byte scale and 1-byte zero point — three per 8 elements in the asymmetric case, and that instruction rate,
 // not the byte rate, is what made asymmetric decompress slower than symmetric (37 vs 29 us at 8192^2).  (One lane per WAVE fetching
 // the wave's four scales / zero points and a scalar broadcast measured slower again: 36.2 vs 34.4 us.)
-template <int DT, int UNROLL, bool HAS_ZP, bool ROWLEAD = false>
+// SM = 2 (round 5; groups of exactly 128 elements = 16 units, units % 64 == 0, scale 8-byte and zero point 4-byte aligned): a wave's 64
+// consecutive units are FOUR consecutive groups, so their four 16-bit scales are one aligned 8-byte run and their four int8 zero points one
+// aligned dword at a wave-uniform address — two SCALAR loads (s_load_dwordx2 / s_load_dword through the constant address space: the scalar
+// data cache, no vector-memory instruction at all), a lane picks its group's entry with one shift (v_lshrrev_b64 by 16 x (lane >> 4)) resp.
+// one v_bfe_i32.  Vector-memory instructions per 8 elements: 2 (word in, 16 bytes out) instead of 4 (asymmetric) / 3 (symmetric).
+constexpr int kW4ScalePerLane = 0, kW4ScaleRowLead = 1, kW4ScaleScalar = 2;
+template <int DT, int UNROLL, bool HAS_ZP, int SM = kW4ScalePerLane>
 __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64_t base) {
+    constexpr bool ROWLEAD = SM == kW4ScaleRowLead;
     const uint32_t* in = static_cast<const uint32_t*>(p.x);
     uint32_t word[UNROLL];
+    uint64_t s4[UNROLL];  // SM = 2: the wave's four scales / zero points, requested AHEAD of the words (scalar loads are counted by lgkmcnt,
+    uint32_t z4[UNROLL];  // the words by vmcnt: neither waits for the other)
+    if constexpr (SM == kW4ScaleScalar) {
+        typedef const __attribute__((address_space(4))) uint32_t* const_u32_t;
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            const int64_t u0 = base + (int64_t)i * kBlock - (int64_t)(threadIdx.x & 63);  // the wave's first unit: a multiple of 64 (units % 64 == 0: in range or not as a wave)
+            const uint32_t si_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u0 >> 4));
+            const uint32_t si_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((u0 >> 4) >> 32));
+            int64_t si0 = (int64_t)(((uint64_t)si_hi << 32) | si_lo);  // wave-uniform, a multiple of 4
+            const int64_t si_last = (p.units >> 4) - 4;                 // unconditional (a branch would put a wait between these loads and the
+            si0 = si0 < si_last ? si0 : si_last;                        // words'): a wave beyond the tensor reads the last entries and drops them
+            const_u32_t sp = (const_u32_t)(uintptr_t)(static_cast<const uint16_t*>(p.scale) + si0);
+            s4[i] = ((uint64_t)sp[1] << 32) | sp[0];
+            z4[i] = 0;
+            if constexpr (HAS_ZP) z4[i] = *(const_u32_t)(uintptr_t)(static_cast<const int8_t*>(p.zp) + si0);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) {
         const int64_t u = base + (int64_t)i * kBlock;
@@ -820,9 +845,14 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
     for (int i = 0; i < UNROLL; ++i) {
         const int64_t u = base + (int64_t)i * kBlock;
         if (u >= p.units) continue;
-        const int64_t si = w4_scale_index(p, u);
+        const int64_t si = SM == kW4ScaleScalar ? 0 : w4_scale_index(p, u);
         float s, z;
-        if constexpr (ROWLEAD) {
+        if constexpr (SM == kW4ScaleScalar) {
+            const uint32_t g16 = (threadIdx.x & 48u);  // 16 x (lane >> 4)
+            const uint32_t sb = (uint32_t)(s4[i] >> g16);
+            s = DT == CT_BF16 ? bits_f(sb << 16) : f16_bits_to_f(sb & 0xffffu);
+            z = HAS_ZP ? (float)(int)__builtin_amdgcn_sbfe(z4[i], g16 >> 1, 8) : 0.0f;  // (the builtin returns unsigned: without the cast -3 became 4294967293.0)
+        } else if constexpr (ROWLEAD) {
             uint32_t sb = 0, zb = 0;
             if ((threadIdx.x & 15) == 0) {
                 sb = static_cast<const uint16_t*>(p.scale)[si];
@@ -836,7 +866,7 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
             z = HAS_ZP ? round_to<DT>(load_rt(p.zp, p.zdt, si)) : 0.0f;  // zp.to(scale.dtype)
         }
         float v[8];
-        if (HAS_ZP && (ROWLEAD || p.zdt == CT_I8)) {  // wave-uniform
+        if (HAS_ZP && (SM != kW4ScalePerLane || p.zdt == CT_I8)) {  // wave-uniform
             // (2^23 + nibble) - (2^23 + 8 + z) is exact: the un-bias and the zero point cost ONE subtract, as in the symmetric case
             const float off = 8388616.0f + z;
 #pragma unroll
@@ -853,11 +883,11 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
     }
 }
 
-template <int DT, int UNROLL, bool HAS_ZP, bool ROWLEAD = false>
+template <int DT, int UNROLL, bool HAS_ZP, int SM = kW4ScalePerLane>
 __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_kernel(W4Params p) {
     const int64_t stride = (int64_t)gridDim.x * kBlock * UNROLL;
     for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < p.units; base += stride)
-        w4_unpack_dequant_units<DT, UNROLL, HAS_ZP, ROWLEAD>(p, base);
+        w4_unpack_dequant_units<DT, UNROLL, HAS_ZP, SM>(p, base);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -914,7 +944,16 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const c
     // paid once per 2048 units); `stride` == chunk size, `limit` ends the walk after kBatchIter chunks
     const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kBatchIter;
     const int64_t limit = (first + stride * kBatchIter < p.units) ? first + stride * kBatchIter : p.units;
-    if (p.zp) {
+    // round 5: an item with groups of 128 (upg_shift == 4), units % 64 == 0 and aligned scale / zero-point tables takes the SCALAR-load form
+    // (a batch is always a launch of many residency rounds); the branch is workgroup-uniform
+    const bool scalar = it.upg_shift == 4 && (p.units & 63) == 0 && (reinterpret_cast<uintptr_t>(p.scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p.zp) & 3u) == 0;
+    if (scalar) {
+        if (p.zp) {
+            for (int64_t b = first + threadIdx.x; b < limit; b += stride) w4_unpack_dequant_units<DT, kBatchUnroll, true, kW4ScaleScalar>(p, b);
+        } else {
+            for (int64_t b = first + threadIdx.x; b < limit; b += stride) w4_unpack_dequant_units<DT, kBatchUnroll, false, kW4ScaleScalar>(p, b);
+        }
+    } else if (p.zp) {
         for (int64_t b = first + threadIdx.x; b < limit; b += stride) w4_unpack_dequant_units<DT, kBatchUnroll, true>(p, b);
     } else {
         for (int64_t b = first + threadIdx.x; b < limit; b += stride) w4_unpack_dequant_units<DT, kBatchUnroll, false>(p, b);
@@ -1957,8 +1996,14 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         // one scale / zero-point load per 16-lane row when a row never straddles a scale group
         // (asymmetric only: on the symmetric kernel the same trick measured 29.5 -> 31.1 us)
         const bool rowlead = zp && w.flat_scale && w.upg_shift >= 4 && w.upg_shift < 62 && w.units % 16 == 0 && zdt == CT_I8;
-#define CT_W4D(DT, ZP) CT_FOR_UNROLL(unroll, if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, true>), grid, dim3(kBlock), 0, as_stream(stream), w); \
-                                             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, false>), grid, dim3(kBlock), 0, as_stream(stream), w))
+        // round 5: groups of 128 on a tensor of many residency rounds fetch the wave's four scales / zero points by SCALAR loads — asymmetric
+        // 29.85 -> 28.55 us at 8192^2 (71.0 -> 74.1 % of 8 TB/s), symmetric 28.6-29.2 -> 28.4; a tensor of ONE round is latency-bound and loses
+        // with them (4096^2: 8.5 -> 10.2 us), so those keep the vector loads (tools/kbench/kbench_w4d.hip, profiles/r05_w4d_scale_modes.txt)
+        const bool scalar = w.flat_scale && w.upg_shift == 4 && w.units % 64 == 0 && w.units > 8 * (int64_t)kCUs * 8 * kBlock && (!zp || zdt == CT_I8) &&
+                            (reinterpret_cast<uintptr_t>(scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(zp) & 3u) == 0;
+#define CT_W4D(DT, ZP) CT_FOR_UNROLL(unroll, if (scalar) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScaleScalar>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                                             else if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScaleRowLead>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                                             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScalePerLane>), grid, dim3(kBlock), 0, as_stream(stream), w))
         if (sdt == CT_BF16) { if (zp) CT_W4D(CT_BF16, true); else CT_W4D(CT_BF16, false); }
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D

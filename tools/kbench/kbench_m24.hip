@@ -7,7 +7,10 @@
 // this way, scale_packed included, before they replaced it: gpurun_out/r05m1/kbench_m24.txt, copied to profiles/r05_marlin_variants.txt);
 // (2) HBM-cold time at 8192^2 bf16 g128 (6 rotating inputs, 5 blocks of 60 launches, median).  Not part of the product.
 // Build: tools/kbench/build_m24.sh
-#include "../../compressed_tensors_amd/csrc/ct_marlin24.hip"
+#ifndef CT_M24_SRC  // build_m24.sh <source> <binary>: an experimental copy of the kernel source instead of the product's
+#define CT_M24_SRC "../../compressed_tensors_amd/csrc/ct_marlin24.hip"
+#endif
+#include CT_M24_SRC
 
 #include <string.h>
 #include <algorithm>

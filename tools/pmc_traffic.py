@@ -17,6 +17,7 @@ ALIAS = {
     "ct::w4_quant_pack_lean_kernel<2, true>": "w4_quant_pack_lean_kernel<bf16>",
     "ct::w4_unpack_dequant_kernel<2, 2, false>": "w4_unpack_dequant_kernel<bf16>",
     "ct::w4_unpack_dequant_kernel<2, 2, false, false>": "w4_unpack_dequant_kernel<bf16>",
+    "ct::w4_unpack_dequant_kernel<2, 2, false, 2>": "w4_unpack_dequant_kernel<bf16>",
 }
 
 
