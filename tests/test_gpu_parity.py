@@ -559,6 +559,51 @@ def test_decompress_side_one_residency_round(cta, dev, shape, kind):
         assert eq(got.cpu(), O.dequantize(q, scale, None))
 
 
+@pytest.mark.parametrize("case", ["sym", "asym", "asym_fp16", "scale_view_off_by_2_bytes", "zp_view_off_by_1_byte", "group_64", "units_not_a_multiple_of_64"])
+def test_w4_decompress_scalar_scale_loads_and_their_fallbacks(cta, dev, case):
+    """round 5: a W4 tensor of many residency rounds (> 33.5 M elements) with groups of 128 fetches a wave's four scales / zero points by
+    scalar loads (s_load_dwordx2 / s_load_dword); anything else — another group size, units % 64 != 0, a scale table that is not 8-byte or
+    a zero-point table that is not 4-byte aligned — keeps the vector loads.  Every case must give the bits of the SAME tensor decompressed
+    in row blocks small enough to take the one-round kernels (vector loads), and its first rows the oracle's bits"""
+    rows, cols, gs, dt = 4160, 8192, 128, BF16
+    if case == "group_64":
+        gs = 64
+    if case == "units_not_a_multiple_of_64":
+        rows, cols = 4101, 8192 + 128
+    if case == "asym_fp16":
+        dt = F16
+    sym = case in ("sym", "group_64")
+    assert rows * cols > 8 * 256 * 8 * 256 * 8
+    g = torch.Generator(device=dev).manual_seed(len(case))
+    packed = torch.randint(-2 ** 31, 2 ** 31 - 1, (rows, cols // 8), dtype=torch.int32, device=dev, generator=g)
+    groups = cols // gs
+    sbuf = (torch.rand(rows * groups + 8, device=dev, generator=g) * 0.3 + 1e-3).to(dt)
+    zbuf = torch.randint(-8, 8, (rows * groups + 8,), dtype=torch.int8, device=dev, generator=g)
+    so = 1 if case == "scale_view_off_by_2_bytes" else 0
+    zo = 1 if case == "zp_view_off_by_1_byte" else 0
+    scale = sbuf[so:so + rows * groups].view(rows, groups)
+    zp = None if sym else zbuf[zo:zo + rows * groups].view(rows, groups)
+    if so:
+        assert scale.data_ptr() % 8 != 0
+    kw = dict(num_bits=4, strategy="group", group_size=gs)
+    got = cta.codec.unpack_and_dequantize(packed, (rows, cols), scale, zp, **kw)
+    step = 1024  # 8.4 M elements per block: one residency round, the vector-load kernels
+    for r0 in range(0, rows, step):
+        r1 = min(rows, r0 + step)
+        blk = cta.codec.unpack_and_dequantize(packed[r0:r1].contiguous(), (r1 - r0, cols), scale[r0:r1].contiguous(), None if zp is None else zp[r0:r1].contiguous(), **kw)
+        assert eq(got[r0:r1], blk), (case, r0)
+    q = O.unpack_from_int32(packed[:64].cpu(), 4, (64, cols))
+    assert eq(got[:64].cpu(), O.dequantize(q, scale[:64].cpu(), None if zp is None else zp[:64].cpu(), strategy="group", group_size=gs))
+    # the batched entry takes the same per-item decision (two items, the second with a table that keeps the vector loads)
+    half = rows // 2 // 64 * 64
+    items = [(packed[:half].contiguous(), (half, cols), scale[:half].contiguous(), None if zp is None else zp[:half].contiguous()),
+             (packed[half:].contiguous(), (rows - half, cols), sbuf[1:1 + (rows - half) * groups].view(rows - half, groups), None if zp is None else zp[half:].contiguous())]
+    outs = cta.codec.unpack_and_dequantize_many(items, **kw)
+    assert eq(outs[0], got[:half])
+    ref1 = cta.codec.unpack_and_dequantize(items[1][0], items[1][1], items[1][2].contiguous(), items[1][3], **kw)
+    assert eq(outs[1], ref1)
+
+
 def test_int8_per_tensor_full_size(cta, dev):
     """BASELINE config 1 on the GPU path: int8 per-tensor symmetric, 4096x4096 bf16"""
     torch.manual_seed(0)
