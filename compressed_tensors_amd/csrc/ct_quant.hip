@@ -898,7 +898,12 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_kernel(W4Params p) {
 // (wave-uniform scalar loads), then runs the same per-lane body as the single-tensor kernels.
 // ------------------------------------------------------------------------------------------
 constexpr int kBatchUnroll = 2;
-constexpr int kBatchIter = 4;  // chunks per workgroup in the batched decompress
+constexpr int kBatchIter = 4;  // chunks per workgroup in the batched 8-bit decompress
+// chunks per workgroup in the batched W4 decompress.  Round 5, with the scalar-load scale fetch (tools/time_batch.py, TinyLlama's 154 modules /
+// 1 x 8192^2 / 16 x 2048^2 / 1024 x 256^2): 1 chunk 442 / 28.9 / 35.4 / 51.4 us, 2 chunks **402** / 30.3 / 32.9 / 42.2, 4 chunks (rounds 2-4)
+// 426 / 33.6 / 33.9 / 40.2, 8 chunks 449 / 34.2 / 35.7 / 41.1: the table search (a chain of ~8 dependent scalar loads for 154 items) wants to be
+// paid rarely, the chunks of a workgroup run one after the other and want to be few
+constexpr int kW4BatchIter = 2;
 
 __device__ __forceinline__ const ct_w4_item& batch_find(const ct_w4_item* __restrict__ items, int n, int64_t block) {
     int lo = 0, hi = n - 1;
@@ -940,10 +945,10 @@ template <int DT>
 __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
     const W4Params p = batch_params(it);
-    // a workgroup owns kBatchIter consecutive chunks of kBlock * kBatchUnroll units (the table search is
-    // paid once per 2048 units); `stride` == chunk size, `limit` ends the walk after kBatchIter chunks
-    const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kBatchIter;
-    const int64_t limit = (first + stride * kBatchIter < p.units) ? first + stride * kBatchIter : p.units;
+    // a workgroup owns kW4BatchIter consecutive chunks of kBlock * kBatchUnroll units (the table search is
+    // paid once per 1024 units); `stride` == chunk size, `limit` ends the walk after kW4BatchIter chunks
+    const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kW4BatchIter;
+    const int64_t limit = (first + stride * kW4BatchIter < p.units) ? first + stride * kW4BatchIter : p.units;
     // round 5: an item with groups of 128 (upg_shift == 4), units % 64 == 0 and aligned scale / zero-point tables takes the SCALAR-load form
     // (a batch is always a launch of many residency rounds); the branch is workgroup-uniform
     const bool scalar = it.upg_shift == 4 && (p.units & 63) == 0 && (reinterpret_cast<uintptr_t>(p.scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p.zp) & 3u) == 0;
@@ -2062,7 +2067,7 @@ int64_t ct_w4_batch_plan(ct_w4_item* items, int n, int direction) {
         it.upg = (int32_t)(g / 8);
         it.upg_shift = log2_exact(it.upg);
         it.first_block = blocks;
-        blocks += direction == 0 ? cdiv64(it.units / 4, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll * kBatchIter);
+        blocks += direction == 0 ? cdiv64(it.units / 4, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll * kW4BatchIter);
     }
     if (blocks >= ((int64_t)1 << 31)) {
         set_error("ct_w4_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
