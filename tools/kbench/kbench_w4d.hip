@@ -98,7 +98,29 @@ static bool shape(int64_t rows, int64_t cols, bool time_it) {
     return ok;
 }
 
-int main() {
+template <int U>
+static void unroll_sweep(int64_t rows, int64_t cols) {  // scalar mode, symmetric and asymmetric, U units per lane
+    const int64_t e = rows * cols;
+    const int n = (int)std::max<int64_t>(4, (int64_t)(2 * 256 * 1048576LL) / (e / 2) + 1);
+    std::vector<uint32_t*> pk; std::vector<uint16_t*> outs;
+    uint16_t* scale; int8_t* zp;
+    CK(hipMalloc(&scale, rows * (cols / 128) * 2)); CK(hipMalloc(&zp, rows * (cols / 128)));
+    hipLaunchKernelGGL(fill_scale, dim3(256), dim3(256), 0, 0, scale, rows * (cols / 128), 5u, (int)CT_BF16);
+    hipLaunchKernelGGL(fill_zp, dim3(256), dim3(256), 0, 0, zp, rows * (cols / 128), 9u);
+    for (int i = 0; i < n; ++i) { uint32_t* p; CK(hipMalloc(&p, e / 2)); hipLaunchKernelGGL(fill_u32, dim3(2048), dim3(256), 0, 0, p, e / 8, 77u * i + 1u); pk.push_back(p); }
+    for (int i = 0; i < 4; ++i) { uint16_t* o; CK(hipMalloc(&o, e * 2)); outs.push_back(o); }
+    CK(hipDeviceSynchronize());
+    const double bs = (2.0 + 0.5 + 2.0 / 128) * e;
+    for (int rep = 0; rep < 2; ++rep) {
+        double a = timed([&](int i) { launch<CT_BF16, U, false, 2>(pk[i % n], scale, zp, outs[i % 4], rows, cols); }, 60);
+        double b = timed([&](int i) { launch<CT_BF16, U, true, 2>(pk[i % n], scale, zp, outs[i % 4], rows, cols); }, 60);
+        printf("sweep U=%d %lldx%lld scalar: sym %7.2f us (%5.2f %%)  asym %7.2f us\n", U, (long long)rows, (long long)cols, a, bs / a / 1e3 / 80.0, b); fflush(stdout);
+    }
+    for (auto p : pk) hipFree(p); for (auto o : outs) hipFree(o); hipFree(scale); hipFree(zp);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "sweep")) { unroll_sweep<1>(8192, 8192); unroll_sweep<2>(8192, 8192); unroll_sweep<4>(8192, 8192); unroll_sweep<8>(8192, 8192); return 0; }
     bool ok = true;
     ok &= shape<CT_BF16, 2>(2048, 2048, false);
     ok &= shape<CT_F16, 2>(1024, 4096, false);
