@@ -42,6 +42,27 @@ __global__ __launch_bounds__(kBlock) void mix_b(const u32x4* __restrict__ in, u3
         mask[u] = (uint8_t)(r[i].x + r[i].w);
     }
 }
+// ---- W4-compress-shaped mix: 134.2 MB in, 33.5 MB out
+__global__ __launch_bounds__(kBlock) void cmp_a(const u32x4* __restrict__ in, u32x4* __restrict__ out, int64_t lanes) {  // the shipped shape: 64 B per lane in, 16 B out
+    const int64_t l = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (l >= lanes) return;
+    u32x4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = in[l * 4 + i];
+    __builtin_nontemporal_store(u32x4{r[0].x ^ r[0].y ^ r[0].z ^ r[0].w, r[1].x ^ r[1].y ^ r[1].z ^ r[1].w, r[2].x ^ r[2].y ^ r[2].z ^ r[2].w, r[3].x ^ r[3].y ^ r[3].z ^ r[3].w}, out + l);
+}
+template <int U>
+__global__ __launch_bounds__(kBlock) void cmp_b(const u32x4* __restrict__ in, uint32_t* __restrict__ out, int64_t units) {  // 16 B per lane and step in (1 KiB per wave instruction), 4 B out
+    const int64_t base = (int64_t)blockIdx.x * kBlock * U + threadIdx.x;
+    u32x4 r[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) { const int64_t u = base + (int64_t)i * kBlock; if (u < units) r[i] = in[u]; }
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int64_t u = base + (int64_t)i * kBlock;
+        if (u < units) __builtin_nontemporal_store(r[i].x ^ r[i].y ^ r[i].z ^ r[i].w, out + u);
+    }
+}
 __global__ void fill(uint32_t* p, int64_t n, uint32_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = ((uint32_t)i + seed) * 0x9E3779B1u;
 }
@@ -74,6 +95,15 @@ int main() {
         printf("mix (b) lane = 2 x (16 B in, 8 B + 1 B out)          : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
         us = timed([&](int i) { hipLaunchKernelGGL((mix_b<4>), dim3((unsigned)((units + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, 0, in[i % 6], (u32x2*)vals[i & 1], (uint8_t*)mask[i & 1], units); }, 60);
         printf("mix (b) lane = 4 x (16 B in, 8 B + 1 B out)          : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+        const double cb = 2.0 * e + 0.5 * e;
+        us = timed([&](int i) { hipLaunchKernelGGL(cmp_a, dim3((unsigned)((lanes + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, in[i % 6], (u32x4*)vals[i & 1], lanes); }, 60);
+        printf("compress-shaped (a) lane = 64 B in, 16 B out         : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, cb / us / 1e3, cb / us / 1e3 / 80.0);
+        us = timed([&](int i) { hipLaunchKernelGGL((cmp_b<2>), dim3((unsigned)((units + kBlock * 2 - 1) / (kBlock * 2))), dim3(kBlock), 0, 0, in[i % 6], (uint32_t*)vals[i & 1], units); }, 60);
+        printf("compress-shaped (b) lane = 2 x (16 B in, 4 B out)    : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, cb / us / 1e3, cb / us / 1e3 / 80.0);
+        us = timed([&](int i) { hipLaunchKernelGGL((cmp_b<4>), dim3((unsigned)((units + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, 0, in[i % 6], (uint32_t*)vals[i & 1], units); }, 60);
+        printf("compress-shaped (b) lane = 4 x (16 B in, 4 B out)    : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, cb / us / 1e3, cb / us / 1e3 / 80.0);
+        us = timed([&](int i) { hipLaunchKernelGGL((cmp_b<8>), dim3((unsigned)((units + kBlock * 8 - 1) / (kBlock * 8))), dim3(kBlock), 0, 0, in[i % 6], (uint32_t*)vals[i & 1], units); }, 60);
+        printf("compress-shaped (b) lane = 8 x (16 B in, 4 B out)    : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, cb / us / 1e3, cb / us / 1e3 / 80.0);
         fflush(stdout);
     }
     return 0;
