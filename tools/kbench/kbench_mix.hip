@@ -63,6 +63,17 @@ __global__ __launch_bounds__(kBlock) void cmp_b(const u32x4* __restrict__ in, ui
         if (u < units) __builtin_nontemporal_store(r[i].x ^ r[i].y ^ r[i].z ^ r[i].w, out + u);
     }
 }
+// sparse-compress mix with the resident kernel's store shape: 16 B per lane, wave-contiguous, at a 2-byte-aligned (SHIFT = 2) or 16-byte-aligned address
+typedef u32x4 u32x4_a2 __attribute__((aligned(2)));
+__global__ __launch_bounds__(kBlock) void mix_d(const u32x4* __restrict__ in, uint8_t* __restrict__ vals, uint8_t* __restrict__ mask, int64_t units, int shift) {
+    const int64_t base = (int64_t)blockIdx.x * kBlock * 2 + threadIdx.x;
+    if (base + kBlock >= units) return;
+    const u32x4 a = in[base], b = in[base + kBlock];
+    const int64_t o = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 16 + shift;
+    __builtin_nontemporal_store(u32x4{a.x ^ a.z, a.y ^ a.w, b.x ^ b.z, b.y ^ b.w}, reinterpret_cast<u32x4_a2*>(vals + o));
+    mask[base] = (uint8_t)(a.x + a.w);
+    mask[base + kBlock] = (uint8_t)(b.x + b.w);
+}
 __global__ void fill(uint32_t* p, int64_t n, uint32_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = ((uint32_t)i + seed) * 0x9E3779B1u;
 }
@@ -85,7 +96,7 @@ int main() {
     std::vector<u32x4*> in;
     for (int i = 0; i < 6; ++i) { u32x4* p; CK(hipMalloc(&p, e * 2)); hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, (uint32_t*)p, e / 2, 17u * i); in.push_back(p); }
     void* vals[2]; void* mask[2];
-    for (int i = 0; i < 2; ++i) { CK(hipMalloc(&vals[i], e)); CK(hipMalloc(&mask[i], units)); }
+    for (int i = 0; i < 2; ++i) { CK(hipMalloc(&vals[i], e + 64)); CK(hipMalloc(&mask[i], units)); }
     CK(hipDeviceSynchronize());
     const double bytes = 2.0 * e + 1.0 * e + e / 8.0;
     for (int rep = 0; rep < 2; ++rep) {
@@ -95,6 +106,10 @@ int main() {
         printf("mix (b) lane = 2 x (16 B in, 8 B + 1 B out)          : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
         us = timed([&](int i) { hipLaunchKernelGGL((mix_b<4>), dim3((unsigned)((units + kBlock * 4 - 1) / (kBlock * 4))), dim3(kBlock), 0, 0, in[i % 6], (u32x2*)vals[i & 1], (uint8_t*)mask[i & 1], units); }, 60);
         printf("mix (b) lane = 4 x (16 B in, 8 B + 1 B out)          : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+        for (int shift : {0, 2, 4, 6, 8, 12}) {
+            us = timed([&](int i) { hipLaunchKernelGGL(mix_d, dim3((unsigned)((units + kBlock * 2 - 1) / (kBlock * 2))), dim3(kBlock), 0, 0, in[i % 6], (uint8_t*)vals[i & 1], (uint8_t*)mask[i & 1], units, shift); }, 60);
+            printf("mix (d) 2 x 16 B in, ONE 16 B out at offset %% 16 == %d  : %7.2f us  %7.1f GB/s  %5.2f %%\n", shift, us, bytes / us / 1e3, bytes / us / 1e3 / 80.0);
+        }
         const double cb = 2.0 * e + 0.5 * e;
         us = timed([&](int i) { hipLaunchKernelGGL(cmp_a, dim3((unsigned)((lanes + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0, in[i % 6], (u32x4*)vals[i & 1], lanes); }, 60);
         printf("compress-shaped (a) lane = 64 B in, 16 B out         : %7.2f us  %7.1f GB/s  %5.2f %%\n", us, cb / us / 1e3, cb / us / 1e3 / 80.0);
