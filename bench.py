@@ -1107,6 +1107,9 @@ def headline_line(result, cap=LINE_CAP):
         line["row_sharded"] = {**_pick(rs, ("ranks", "rows_this_rank", "error")),
                                **{k: _pick(v, ("us_per_tensor", "GBps_all_ranks", "frac_of_hbm_peak_per_gpu", "shard_equals_slice_of_single_rank_result"))
                                   for k, v in rs.items() if isinstance(v, dict)}}
+    w4k = result.get("w4a16_4096")
+    if isinstance(w4k, dict):
+        line["w4a16_4096"] = _pick(w4k, ("us_per_step", "GBps_all_ranks", "frac_of_hbm_peak_per_gpu", "ranks", "round_trip_equals_fake_quantize", "error"))
     line["details"] = DETAILS_FILE
     text = json.dumps(line, separators=(",", ":"))
     while len(text) > cap and len(roof["kernels"]) > 2:  # never expected (the test holds recorded results to the cap): shed rows, not the contract
@@ -1367,85 +1370,183 @@ def tinyllama_w8_leg(dev):
     return out
 
 
-def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters=20):
-    """SURVEY 8e for the single-tensor configs: ONE 8192x8192 tensor split by row blocks (`shard_rows`, multiples of 64
-    rows) over the ranks — strong scaling, no data-path collective.  Config 2 (W4A16 compress + decompress of the rank's
-    rows) and config 3 (sparse-bitmask compress + decompress; the shard's row_offsets are local, the global ones are
-    local + the number of non-zeros in the earlier shards).  Every rank also computes the whole tensor by itself once and
-    checks that its shard's outputs are exactly the corresponding slice of the single-rank result."""
-    from compressed_tensors_amd import codec
-    from compressed_tensors_amd.distributed.shard import shard_rows
+IC_BYTES = 256 * 2 ** 20  # the Infinity Cache (memory-side, shared by the eight XCDs)
 
-    a, b = shard_rows(N, rank=rank, world_size=world, multiple=64)
-    g = torch.Generator(device=dev).manual_seed(4242)  # the same tensor on every rank
-    kw = dict(num_bits=BITS, strategy="group", group_size=GROUP)
-    nsets = 6
-    full = [torch.randn(N, N, dtype=torch.bfloat16, device=dev, generator=g) for _ in range(nsets)]
-    scales = [codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=True) for w in full]
-    out = {"rows_this_rank": [a, b], "ranks": world}
 
-    # config 2
-    w0, (s0, z0) = full[0], scales[0]
-    p_full = codec.quantize_and_pack(w0, s0, z0, **kw)
-    d_full = codec.unpack_and_dequantize(p_full, (N, N), s0, None, **kw)
-    p_mine = codec.quantize_and_pack(w0[a:b], s0[a:b], z0[a:b], **kw)
-    d_mine = codec.unpack_and_dequantize(p_mine, (b - a, N), s0[a:b], None, **kw)
-    ok = torch.equal(p_mine, p_full[a:b]) and torch.equal(d_mine.view(torch.int16), d_full[a:b].view(torch.int16))
-    del p_full, d_full, d_mine
-    packs = [codec.quantize_and_pack(w[a:b], s[a:b], z[a:b], **kw) for w, (s, z) in zip(full, scales)]
+def rows_of_set(dev, set_index, a, b, n=N, dtype=torch.bfloat16, sparsity=None):
+    """rows [a, b) of synthetic tensor number `set_index`, generated 64 rows at a time from a (set, row block) seed: every rank — and a
+    single rank making the whole tensor — gets the same rows without anyone materialising more than its own shard"""
+    assert a % 64 == 0 and (b % 64 == 0 or b == n)
+    out = torch.empty(b - a, n, dtype=dtype, device=dev)
+    g = torch.Generator(device=dev)
+    for r in range(a, b, 64):
+        g.manual_seed(4242 + set_index * 100003 + r // 64)
+        hi = min(r + 64, b)
+        blk = torch.randn(hi - r, n, dtype=torch.float32, device=dev, generator=g)
+        if sparsity is not None:
+            blk = blk.masked_fill(torch.rand(hi - r, n, device=dev, generator=g) < sparsity, 0)
+        out[r - a:hi - a] = blk.to(dtype)
+    return out
 
-    def step2(i):
-        w, (s, z) = full[i % nsets], scales[i % nsets]
-        codec.quantize_and_pack(w[a:b], s[a:b], z[a:b], **kw)
-        codec.unpack_and_dequantize(packs[(i + nsets // 2) % nsets], (b - a, N), s[a:b], None, **kw)
 
-    def timed(step):
-        for i in range(3):
-            step(i)
+def timed_blocks(step, iters, barrier, allreduce_max):
+    """the protocol of the headline loop for a sharded leg: KERNEL_WARM_MS of the same launches, then BLOCKS blocks of `iters` steps, each
+    bracketed by barrier + synchronize on both sides, wall clock, MAX over the ranks; returns the per-block seconds per step"""
+    device_warmup([step], KERNEL_WARM_MS)
+    per = []
+    for _ in range(BLOCKS):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(iters):
             step(i)
         torch.cuda.synchronize()
-        return allreduce_max(time.perf_counter() - t0) / iters
+        barrier()
+        per.append(allreduce_max(time.perf_counter() - t0) / iters)
+    return per
 
-    t2 = timed(step2)
+
+def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters=MIN_LAUNCHES_PER_BLOCK):
+    """SURVEY 8e for the single-tensor configs: ONE 8192x8192 tensor split by row blocks (`shard_rows`, multiples of 64
+    rows) over the ranks — strong scaling, no data-path collective.  Config 2 (W4A16 compress + decompress of the rank's
+    rows) and config 3 (sparse-bitmask compress + decompress; the shard's row_offsets are local, the global ones are
+    local + the number of non-zeros in the earlier shards).
+
+    Round 6 (VERDICT r05 missing #1): on the protocol of the rest of this file — prebuilt C-ABI launches (no allocation, no Python codec
+    call in the timed loop), a fixed-duration device warm-up, BLOCKS blocks of >= MIN_LAUNCHES_PER_BLOCK steps, and enough rotating
+    tensors that THIS RANK's smallest read stream is >= 2x the 256 MiB Infinity Cache at the actual world size (16 x world tensors for
+    config 2: the rank's packed words; 8 x world for config 3: values + bitmask >= 2.3x) — the memory per rank stays ~4.8 GiB at any
+    world size, and every row is HBM-cold.  Every rank also computes tensor 0 whole, by itself, and checks that what its launches wrote
+    for its shard is exactly the corresponding slice of that single-rank result."""
+    from compressed_tensors_amd import _lib, codec
+    from compressed_tensors_amd.distributed.shard import shard_rows
+
+    lib = _lib.load()
+    BF16 = _lib.BF16
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    a, b = shard_rows(N, rank=rank, world_size=world, multiple=64)
+    rows = b - a
+    kw = dict(num_bits=BITS, strategy="group", group_size=GROUP)
+    out = {"rows_this_rank": [a, b], "ranks": world, "launches_per_block": iters, "blocks": BLOCKS}
+
+    # ---- config 2: the rank's packed words are the smallest read stream
+    packed_bytes = max(rows, 1) * N // 2
+    nsets = max(4, -(-2 * IC_BYTES // packed_bytes))
+    sets = []
+    for j in range(nsets):
+        w = rows_of_set(dev, j, a, b)
+        sc, zp = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=True)
+        sets.append((w, sc, zp, torch.empty(rows, N // 8, dtype=torch.int32, device=dev), torch.empty(rows, N, dtype=torch.bfloat16, device=dev)))
+    ca = [(w.data_ptr(), BF16, sc.data_ptr(), BF16, zp.data_ptr(), _lib.I8, rows, N, 1, GROUP, N // GROUP, None, BITS, BF16, pk.data_ptr(), stream)
+          for (w, sc, zp, pk, o) in sets]
+    da = [(pk.data_ptr(), rows, N // 8, N, BITS, sc.data_ptr(), BF16, None, -1, 1, GROUP, N // GROUP, None, o.data_ptr(), BF16, stream)
+          for (w, sc, zp, pk, o) in sets]
+
+    def step2(i):
+        rc = lib.ct_quant_pack(*ca[i % nsets]) or lib.ct_unpack_dequant(*da[(i + nsets // 2) % nsets])
+        if rc:
+            _lib.check(rc)
+
+    for i in range(nsets):  # every packed buffer populated, every output written once
+        step2(i)
+    per2 = timed_blocks(step2, iters, barrier, allreduce_max)
+    # the single-rank result of tensor 0 (the plug-in's tensor-level calls on the WHOLE tensor) against what this rank's launches wrote
+    w_full = rows_of_set(dev, 0, 0, N)
+    s_full, z_full = codec.minmax_qparams(w_full, num_bits=BITS, group_size=GROUP, symmetric=True)
+    p_full = codec.quantize_and_pack(w_full, s_full, z_full, **kw)
+    d_full = codec.unpack_and_dequantize(p_full, (N, N), s_full, None, **kw)
+    ok = (torch.equal(sets[0][0], w_full[a:b]) and torch.equal(sets[0][3], p_full[a:b]) and torch.equal(sets[0][4].view(torch.int16), d_full[a:b].view(torch.int16)))
+    del w_full, s_full, z_full, p_full, d_full
+    t2 = median(per2)
     alg2 = 2 * alg_bytes_one_direction()
     out["w4a16"] = {"us_per_tensor": round(t2 * 1e6, 2), "GBps_all_ranks": round(alg2 / t2 / 1e9, 1),
                     "frac_of_hbm_peak_per_gpu": round(alg2 / t2 / 1e9 / world / HBM_PEAK_GBPS, 4),
+                    "us_per_tensor_blocks": [round(x * 1e6, 2) for x in per2], "sets": nsets,
+                    "cache": f"HBM-cold: {nsets} rotating tensors, this rank's packed words {nsets * packed_bytes / 2 ** 20:.0f} MiB >= 2 x 256 MiB",
                     "shard_equals_slice_of_single_rank_result": bool(allreduce_min(1.0 if ok else 0.0) == 1.0)}
-    del packs, scales
+    del sets, ca, da
     torch.cuda.empty_cache()
 
-    # config 3
-    sparse = [w.masked_fill_(torch.rand(N, N, device=dev, generator=g) < 0.5, 0) for w in full]
-    x0 = sparse[0]
-    v_full, bm_full, ro_full = codec.bitmask_compress(x0)
-    v, bm, ro = codec.bitmask_compress(x0[a:b])
-    base = int(ro_full[a].item())
-    stop = int(ro_full[b].item()) if b < N else v_full.numel()
-    back = codec.bitmask_decompress(v, bm, (b - a, N), ro)
-    ok3 = (torch.equal(v.view(torch.int16), v_full[base:stop].view(torch.int16)) and torch.equal(bm, bm_full[a:b])
-           and torch.equal(ro + base, ro_full[a:b]) and torch.equal(back.view(torch.int16), x0[a:b].view(torch.int16)))
-    nnz = v_full.numel()
-    del v_full, bm_full, back
-    comp = [codec.bitmask_compress(x[a:b]) for x in sparse]
+    # ---- config 3
+    nb = 8 * world  # reads of the decompress direction: (67 + 8) MB x 8 per WHOLE tensor = 2.3x the Infinity Cache per rank at any world size
+    ws_bytes = int(lib.ct_bitmask_compress_workspace_bytes(rows, N))
+    items = []
+    for j in range(nb):
+        x = rows_of_set(dev, 1000 + j, a, b, sparsity=0.5)
+        v, bm, ro = codec.bitmask_compress(x)
+        items.append(dict(x=x, v=v.clone(), bm=bm, ro=ro, out=torch.empty_like(x), v2=torch.empty(rows * N, dtype=torch.bfloat16, device=dev), bm2=torch.empty_like(bm),
+                          ro2=torch.empty_like(ro), ws=torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)))
+    cargs = [(it["x"].data_ptr(), BF16, rows, N, it["v2"].data_ptr(), it["v2"].numel(), it["bm2"].data_ptr(), it["ro2"].data_ptr(), it["ws"][-1:].data_ptr(),
+              it["ws"].data_ptr(), ws_bytes, stream) for it in items]
+    dargs = [(it["v"].data_ptr(), it["v"].numel(), it["bm"].data_ptr(), it["ro"].data_ptr(), -1, BF16, rows, N, it["out"].data_ptr(), stream) for it in items]
 
     def step3(i):
-        codec.bitmask_compress(sparse[i % nsets][a:b])
-        cv, cb, co = comp[(i + nsets // 2) % nsets]
-        codec.bitmask_decompress(cv, cb, (b - a, N), co)
+        rc = lib.ct_bitmask_compress(*cargs[i % nb]) or lib.ct_bitmask_decompress(*dargs[(i + nb // 2) % nb])
+        if rc:
+            _lib.check(rc)
 
-    t3 = timed(step3)
+    for i in range(nb):
+        step3(i)
+    per3 = timed_blocks(step3, iters, barrier, allreduce_max)
+    x_full = rows_of_set(dev, 1000, 0, N, sparsity=0.5)
+    v_full, bm_full, ro_full = codec.bitmask_compress(x_full)
+    nnz = v_full.numel()
+    base = int(ro_full[a].item()) if a < N else nnz
+    stop = int(ro_full[b].item()) if b < N else nnz
+    it0 = items[0]
+    n0 = int(it0["ws"][-1].item())
+    ok3 = (n0 == stop - base and torch.equal(it0["v2"][:n0].view(torch.int16), v_full[base:stop].view(torch.int16)) and torch.equal(it0["bm2"], bm_full[a:b])
+           and torch.equal(it0["ro2"] + base, ro_full[a:b]) and torch.equal(it0["out"].view(torch.int16), x_full[a:b].view(torch.int16)))
+    del x_full, v_full, bm_full
+    t3 = median(per3)
     alg3 = 2 * (2 * N * N + 2 * nnz + N * N // 8 + 8 * N)
     out["sparse_bitmask"] = {"us_per_tensor": round(t3 * 1e6, 2), "GBps_all_ranks": round(alg3 / t3 / 1e9, 1),
                              "frac_of_hbm_peak_per_gpu": round(alg3 / t3 / 1e9 / world / HBM_PEAK_GBPS, 4),
+                             "us_per_tensor_blocks": [round(x * 1e6, 2) for x in per3], "sets": nb,
+                             "cache": f"HBM-cold: {nb} rotating tensors, this rank's values + bitmask {nb * (2 * nnz + N * N // 8) / world / 2 ** 20:.0f} MiB >= 2 x 256 MiB",
                              "row_offsets": "local per shard; global = local + nnz of the earlier shards",
                              "shard_equals_slice_of_single_rank_result": bool(allreduce_min(1.0 if ok3 else 0.0) == 1.0)}
-    out["workload"] = (f"ONE {N}x{N} bf16 tensor split by row blocks over {world} rank(s) (strong scaling, no collectives), through the "
-                       "plug-in's tensor-level API (allocation + launch per call)")
+    out["workload"] = (f"ONE {N}x{N} bf16 tensor split by row blocks over {world} rank(s) (strong scaling, no collectives), through the C ABI "
+                       f"(prebuilt launches on one stream; ct_quant_pack + ct_unpack_dequant, ct_bitmask_compress + ct_bitmask_decompress), "
+                       f"{BLOCKS} blocks of {iters} steps, median block, max over ranks")
     return out
+
+
+def w4_weak_leg(dev, n, rank, world, barrier, allreduce_max, steps=MIN_LAUNCHES_PER_BLOCK):
+    """north_star's second size at EVERY world size (VERDICT r05 missing #2): one `n` x `n` bf16 weight shard per rank (weak scaling, no
+    collective), W4A16 g128 compress + decompress through the C ABI on one stream, HBM-cold (packed words of the rotating sets >= 2x the
+    Infinity Cache per rank), BLOCKS blocks of `steps` steps between barriers, max over ranks; round trip of one set == fake_quantize."""
+    from compressed_tensors_amd import _lib, codec
+
+    lib = _lib.load()
+    BF16 = _lib.BF16
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    nsets = max(4, -(-2 * IC_BYTES // (n * n // 2)))
+    g = torch.Generator(device=dev).manual_seed(77 + rank)
+    sets = []
+    for _ in range(nsets):
+        w = torch.randn(n, n, dtype=torch.float32, device=dev, generator=g).to(torch.bfloat16)
+        sc, zp = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=True)
+        sets.append((w, sc, zp, torch.empty(n, n // 8, dtype=torch.int32, device=dev), torch.empty(n, n, dtype=torch.bfloat16, device=dev)))
+    ca = [(w.data_ptr(), BF16, sc.data_ptr(), BF16, zp.data_ptr(), _lib.I8, n, n, 1, GROUP, n // GROUP, None, BITS, BF16, pk.data_ptr(), stream) for (w, sc, zp, pk, o) in sets]
+    da = [(pk.data_ptr(), n, n // 8, n, BITS, sc.data_ptr(), BF16, None, -1, 1, GROUP, n // GROUP, None, o.data_ptr(), BF16, stream) for (w, sc, zp, pk, o) in sets]
+
+    def step(i):
+        rc = lib.ct_quant_pack(*ca[i % nsets]) or lib.ct_unpack_dequant(*da[(i + nsets // 2) % nsets])
+        if rc:
+            _lib.check(rc)
+
+    for i in range(nsets):
+        step(i)
+    per = timed_blocks(step, steps, barrier, allreduce_max)
+    w, sc, zp, pk, o = sets[0]
+    ok = torch.equal(o, codec.fake_quantize_tensor(w, sc, zp, num_bits=BITS, strategy="group", group_size=GROUP))
+    t = median(per)
+    alg = 2 * alg_bytes_one_direction(n)
+    return {"workload": f"W4A16 g128 compress+decompress, one {n}x{n} bf16 weight shard per rank, C ABI, one stream, HBM-cold ({nsets} rotating sets)",
+            "alg_bytes_per_step_per_gpu": alg, "us_per_step": round(t * 1e6, 2), "us_per_step_blocks": [round(x * 1e6, 2) for x in per],
+            "GBps_all_ranks": round(world * alg / t / 1e9, 1), "frac_of_hbm_peak_per_gpu": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4),
+            "ranks": world, "round_trip_equals_fake_quantize": bool(ok)}
 
 
 def self_launch(n: int) -> int:
@@ -1700,6 +1801,13 @@ def main():
                 leg = {"error": repr(e)}
             if rank == 0:
                 result["row_sharded"] = leg
+        torch.cuda.empty_cache()
+        try:  # north_star names 4096x4096 beside 8192x8192 "at 1/2/4/8 GPUs": the same step at the second size, at every world size
+            leg = w4_weak_leg(dev, 4096, rank, world, barrier, allreduce_max)
+        except Exception as e:
+            leg = {"error": repr(e)}
+        if rank == 0:
+            result["w4a16_4096"] = leg
     if rank == 0:
         # LAST, after every GPU leg: the CPU baseline's imports dlopen libraries with TLS segments, after which glibc 2.35 keeps this thread on
         # the slow __tls_get_addr path (BZ 19924) — the host-bound figure of the run, ModelCompressor on the 154-module tree, measured

@@ -99,7 +99,7 @@ _PROTOTYPES = {
     "ct_marlin24_quant_compress": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _S], _I),
     "ct_marlin24_compress_w4": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _P, _S], _I),
     "ct_marlin24_compress_w4_full": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _P, _I, _S], _I),
-    "ct_marlin24_compress_w4_verdict": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _P, _S], _I),
+    "ct_marlin24_compress_w4_verdict": ([_P, _I, _P, _I, _P, _I, _L, _L, _L, _I, _P, _P, _P, _P, _P, _I, _S], _I),
     "ct_selftest_m24_div": ([_I, _c.c_uint32, _c.c_uint32, _P, _S], _I),
     "ct_marlin24_pack_weights": ([_P, _I, _I, _I, _L, _L, _I, _P, _S], _I),
     "ct_marlin24_pack_scales": ([_P, _I, _L, _L, _I, _P, _S], _I),
@@ -222,8 +222,11 @@ class Mailbox:
     device): a call fills its word, launches, waits and reads before it returns, so a thread never has two waits in flight."""
 
     WORDS = 8
+    M24_VERDICT_WORKSPACE_BYTES = 8320  # CT_M24_VERDICT_WORKSPACE_BYTES of include/ct_hip.h
 
     def __init__(self, device_index: int):
+        self.device_index = device_index
+        self._verdict_ws = None
         lib = load()
         h, d = ctypes.c_void_p(), ctypes.c_void_p()
         with torch.cuda.device(device_index):
@@ -237,6 +240,21 @@ class Mailbox:
         """the word once the device has replaced `pending` (or the stream has drained)"""
         check(load().ct_mailbox_wait_i64(self.host + 8 * index, pending, stream, ctypes.byref(self._out)))
         return self._out.value
+
+    def verdict_workspace(self) -> int:
+        """device address of this (thread, device)'s ticket tree for ct_marlin24_compress_w4_verdict: zeroed once, left zero by every
+        launch that delivers its verdict — and the caller of that entry reads the verdict before it returns, so the thread never has
+        two launches on it.  `drop_verdict_workspace` after a call that failed: the next one gets a fresh, zeroed tree."""
+        ws = self._verdict_ws
+        if ws is None:
+            ws = self._verdict_ws = torch.zeros(self.M24_VERDICT_WORKSPACE_BYTES // 4, dtype=torch.int32, device=torch.device("cuda", self.device_index))
+            if ws.data_ptr() % 128:
+                raise RuntimeError("the caching allocator returned a block that is not 128-byte aligned")
+            torch.cuda.synchronize(self.device_index)  # the zeros are written on the CURRENT stream; the tree may be used on any
+        return ws.data_ptr()
+
+    def drop_verdict_workspace(self) -> None:
+        self._verdict_ws = None
 
     def __del__(self):
         try:

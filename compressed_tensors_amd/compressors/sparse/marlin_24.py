@@ -197,10 +197,15 @@ class Marlin24Compressor(BaseCompressor):
             if hp is not None:
                 stream = _lib.stream_of_device(weight.device)
                 mb = _lib.mailbox(stream.device_index)
-                r = hp.marlin24_compress_default(weight, scale, zero_point, 0 if enum_value(weights.strategy) == "channel" else int(group_size or -1),
-                                                 mb.host + 8, mb.dev + 8, stream)
+                try:
+                    r = hp.marlin24_compress_default(weight, scale, zero_point, 0 if enum_value(weights.strategy) == "channel" else int(group_size or -1),
+                                                     mb.host + 8, mb.dev + 8, mb.verdict_workspace(), stream)
+                    if r is not None:
+                        _lib.check(r[0])
+                except BaseException:
+                    mb.drop_verdict_workspace()  # a launch that did not deliver its verdict may have left counts in the ticket tree
+                    raise
                 if r is not None:
-                    _lib.check(r[0])
                     if r[1]:
                         raise ValueError(_STRUCTURE_ERROR)
                     state_dict["weight_packed"], state_dict["scale_packed"], state_dict["meta"] = r[2], r[4], r[3]

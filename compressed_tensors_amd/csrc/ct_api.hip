@@ -26,7 +26,7 @@ extern "C" {
 
 const char* ct_last_error(void) { return ct::g_err; }
 
-int ct_abi_version(void) { return 1; }
+int ct_abi_version(void) { return 2; }  // 2: ct_marlin24_compress_w4_verdict takes the caller's workspace (round 6)
 
 // ---- host mailbox: the two places where the reference's interface makes the HOST wait for a device result ----------------------
 int ct_mailbox_alloc(int64_t bytes, void** host_ptr, void** dev_ptr) {

@@ -28,9 +28,10 @@ __host__ __device__ __forceinline__ int64_t meta_reorder_offset(int64_t r, int64
 // the 2:4 structure verdict: every violating lane stores the same 1 (idempotent, no read-modify-write), at system scope — the slot may
 // live in pinned host memory (ct_mailbox_alloc: the default, check-per-call mode of Marlin24Compressor) where a device atomic
 // would need PCIe atomics
-// ticket trees of the verdict mode (marlin24_fused_w4_lean_kernel): root at word 0, leaf i at word 32 * (1 + i) — one 128-byte line each
-constexpr unsigned kM24Trees = 16, kM24TreeWords = 32 * 65;
-__device__ unsigned int g_m24_tickets[kM24Trees * kM24TreeWords];
+// the ticket tree of the verdict mode (marlin24_fused_w4_lean_kernel): root at word 0, leaf i at word 32 * (1 + i) — one 128-byte line each.
+// It lives in the CALLER's workspace (CT_M24_VERDICT_WORKSPACE_BYTES of include/ct_hip.h): the library holds no device state of its own.
+constexpr unsigned kM24TreeWords = 32 * 65;
+static_assert(kM24TreeWords * sizeof(unsigned int) == CT_M24_VERDICT_WORKSPACE_BYTES, "include/ct_hip.h states the workspace size");
 
 __device__ __forceinline__ void raise_flag(int* bad) { __hip_atomic_store(bad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -807,7 +808,11 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
     // 1 | (violated << 1) into the caller's (pinned, host-visible) word at system scope and leaves every counter it closed at zero for the
     // next launch.  A flat counter would take 2048 same-address atomics at ~40 ns each (they execute at the memory side on this multi-XCD
     // part: DESIGN.md 5.4) — longer than the kernel; <= 64 leaves of <= ~32 arrivals close in parallel.  The verdict travels IN the atomics'
-    // values, so no fence orders anything.  The atomic is issued here and its result first read after the packing stores below.
+    // values, so the arrivals need no fence.  The atomic is issued here and its result first read after the packing stores below.
+    // Round 6: the tree is the caller's (`tickets` = the workspace argument of the entry), and the resets are ORDERED before the verdict:
+    // a closer zeroes its counter with a returning exchange and reports upward only when that has come back, so by the time the host
+    // can see the verdict every counter of the tree is zero at the memory side — the workspace may be handed to the next launch (on any
+    // stream) as soon as the verdict has been read.
     unsigned int leaf_old = 0;
     int wg_bad = 0;
     if (tickets != nullptr) {  // workgroup-uniform
@@ -833,12 +838,17 @@ __global__ __launch_bounds__(kBlock) void marlin24_fused_w4_lean_kernel(const ui
         const unsigned leaf_size = gridDim.x / leaves + (leaf < gridDim.x % leaves ? 1u : 0u);
         if ((leaf_old & 0xffffu) + 1u == leaf_size) {  // the leaf's last arrival (leaf sizes stay below 2^16: the entry refuses launches of 64 x 65535 tiles and more)
             const unsigned leaf_bad = (leaf_old >> 16) + (wg_bad ? 1u : 0u);
-            __hip_atomic_store(tickets + 32u * (1u + leaf), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned root_old = __hip_atomic_fetch_add(tickets, 1u + (leaf_bad ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the exchange's result feeds the next atomic's operand — `& 0` with a zero the compiler cannot see — so the report upward is issued
+            // only after the reset has been performed at the memory side, where every agent-scope atomic of this multi-XCD part executes)
+            unsigned hidden_zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(hidden_zero));
+            const unsigned z_leaf = __hip_atomic_exchange(tickets + 32u * (1u + leaf), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned root_old = __hip_atomic_fetch_add(tickets, 1u + (leaf_bad ? 0x10000u : 0u) + (z_leaf & hidden_zero),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((root_old & 0xffffu) + 1u == leaves) {
                 const bool any_bad = (root_old >> 16) != 0u || leaf_bad != 0u;
-                __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(verdict_word, any_bad ? 3ll : 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned z_root = __hip_atomic_exchange(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(verdict_word, (any_bad ? 3ll : 1ll) + (long long)(z_root & hidden_zero), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -1058,7 +1068,7 @@ int ct_marlin24_quant_compress(const void* w, int wdt, const void* scale, int sd
 // returns CT_OK + 1 when the launch also wrote scale_packed
 static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
                                      int32_t* packed, int16_t* meta, int* bad, bool clear_bad, void* scale_packed, int scale_single, bool* fused_scales,
-                                     ct_stream_t stream, long long* verdict_word = nullptr) {
+                                     ct_stream_t stream, long long* verdict_word = nullptr, void* workspace = nullptr, bool clear_workspace = false) {
     if (fused_scales) *fused_scales = false;
     CT_REQUIRE(wdt == CT_F16 || wdt == CT_BF16, "marlin-24 weights must be 16-bit floats, got dtype %d", wdt);
     CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
@@ -1074,21 +1084,13 @@ static int marlin24_compress_w4_impl(const void* w, int wdt, const void* scale, 
         if (!lean_ok || (m / 64) * (k / 256) >= (int64_t)64 * 65535 || m == 0 || k == 0) {
             CT_UNSUPPORTED("ct_marlin24_compress_w4_verdict: layout outside the one-launch kernel (16-bit scales, int8 or no zero point, < 4.2 M tiles, sides < 2^24)");
         }
-        // one ticket tree per launch in flight: 16 trees per device, handed out round robin (a tree is back at zero when its launch's
-        // last workgroup has reported; the default-mode call this serves waits for exactly that before it returns, so a host thread
-        // never has two launches on one tree, and sixteen threads can be in the call at once)
-        static std::atomic<unsigned> next_tree{0};
-        static std::atomic<unsigned int*> tree_base[64];  // per device: the address of this device's copy of g_m24_tickets (looked up once)
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict device");
-        unsigned int* base = dev >= 0 && dev < 64 ? tree_base[dev].load(std::memory_order_relaxed) : nullptr;
-        if (base == nullptr) {
-            e = hipGetSymbolAddress(reinterpret_cast<void**>(&base), HIP_SYMBOL(g_m24_tickets));
-            if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict tickets");
-            if (dev >= 0 && dev < 64) tree_base[dev].store(base, std::memory_order_relaxed);
+        // the ticket tree is the caller's: all-zero when the launch starts (cleared here, in stream order, if the caller asks), all-zero again
+        // when the verdict has been stored — nothing of it lives in the library, so any number of launches may be in flight, one per workspace
+        tickets = static_cast<unsigned int*>(workspace);
+        if (clear_workspace) {
+            hipError_t e = hipMemsetAsync(workspace, 0, CT_M24_VERDICT_WORKSPACE_BYTES, as_stream(stream));
+            if (e != hipSuccess) return hip_check(e, "ct_marlin24_compress_w4_verdict workspace memset");
         }
-        tickets = base + (size_t)(next_tree.fetch_add(1u) % kM24Trees) * kM24TreeWords;
     }
     if (clear_bad) {
         hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), as_stream(stream));
@@ -1146,12 +1148,14 @@ int ct_marlin24_compress_w4_full(const void* w, int wdt, const void* scale, int 
 }
 
 int ct_marlin24_compress_w4_verdict(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt, int64_t m, int64_t k, int64_t cdiv,
-                                    int group_perm, int32_t* packed, int16_t* meta, void* scale_packed, int64_t* verdict_word, ct_stream_t stream) {
+                                    int group_perm, int32_t* packed, int16_t* meta, void* scale_packed, int64_t* verdict_word, void* workspace,
+                                    int clear_workspace, ct_stream_t stream) {
     CT_REQUIRE(sdt == CT_F16 || sdt == CT_BF16, "marlin-24 scales must be 16-bit floats, got dtype %d", sdt);
     CT_REQUIRE(scale_packed != nullptr && verdict_word != nullptr && (reinterpret_cast<uintptr_t>(verdict_word) & 7u) == 0, "scale_packed / verdict_word NULL or misaligned");
+    CT_REQUIRE(workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 127u) == 0, "workspace NULL or not 128-byte aligned (CT_M24_VERDICT_WORKSPACE_BYTES of device memory)");
     static int unused_flag;  // the kernel's `bad` argument is not touched in verdict mode; the shared argument check wants a non-null pointer
     return marlin24_compress_w4_impl(w, wdt, scale, sdt, zp, zdt, m, k, cdiv, packed, meta, &unused_flag, false, scale_packed, group_perm ? 0 : 1, nullptr, stream,
-                                     reinterpret_cast<long long*>(verdict_word));
+                                     reinterpret_cast<long long*>(verdict_word), workspace, clear_workspace != 0);
 }
 
 int ct_selftest_m24_div(int mode, uint32_t s_lo_bits, uint32_t s_hi_bits, unsigned long long* mismatches, ct_stream_t stream) {

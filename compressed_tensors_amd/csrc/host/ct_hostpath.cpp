@@ -487,7 +487,7 @@ using workspace_bytes_fn = int64_t (*)(int64_t, int64_t);
 using mailbox_wait_fn = int (*)(const int64_t*, int64_t, void*, int64_t*);
 using stream_wait_fn = int (*)(void*);
 using marlin_full_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int, int32_t*, int16_t*, void*, int*, int, void*);
-using marlin_verdict_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int, int32_t*, int16_t*, void*, int64_t*, void*);
+using marlin_verdict_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int, int32_t*, int16_t*, void*, int64_t*, void*, int, void*);
 
 struct Abi {
     bitmask_compress_fn bitmask_compress = nullptr;
@@ -572,8 +572,10 @@ py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host,
 // the default (raise-from-the-call) mode of Marlin24Compressor.compress for int4: ct_marlin24_compress_w4_full, then a spin on the stream,
 // then the verdict word.  The caller has validated shapes / dtypes / contiguity (compressors/sparse/marlin_24.py).  Returns
 // (status, violated, weight_packed, meta, scale_packed).
+// `verdict_ws`: the caller's ticket tree for the verdict entry (include/ct_hip.h: CT_M24_VERDICT_WORKSPACE_BYTES of zeroed device memory, one per
+// (thread, device) next to the mailbox — _lib.Mailbox.verdict_workspace); 0: the full entry + a stream wait.
 py::tuple marlin24_w4_full(const at::Tensor& weight, int wdt, const at::Tensor& scale, int sdt, const c10::optional<at::Tensor>& zp, int zdt, int64_t group,
-                           bool group_perm, uintptr_t flag_host, uintptr_t flag_dev, uintptr_t stream) {
+                           bool group_perm, uintptr_t flag_host, uintptr_t flag_dev, uintptr_t verdict_ws, uintptr_t stream) {
     if (!g_abi.marlin_full) throw std::runtime_error("marlin24_w4_full: bind_abi has not run");
     const int64_t m = weight.size(0), k = weight.size(1);
     const auto opts = weight.options();
@@ -592,10 +594,10 @@ py::tuple marlin24_w4_full(const at::Tensor& weight, int wdt, const at::Tensor& 
         // workgroup has evaluated its tiles — the host spins on the word as bitmask_compress does for nnz, instead of waiting for the stream to
         // drain (hipStreamSynchronize: +15 us over the kernel on the class call).  The outputs follow in stream order.
         status = -1;
-        if (g_wait_mode && g_abi.marlin_verdict) {
+        if (g_wait_mode && g_abi.marlin_verdict && verdict_ws) {
             status = g_abi.marlin_verdict(weight.data_ptr(), wdt, scale.data_ptr(), sdt, zptr, zp.has_value() ? zdt : -1, m, k, group, group_perm ? 1 : 0,
                                           packed.data_ptr<int32_t>(), meta.data_ptr<int16_t>(), scale_packed.data_ptr(), reinterpret_cast<int64_t*>(flag_dev),
-                                          reinterpret_cast<void*>(stream));
+                                          reinterpret_cast<void*>(verdict_ws), 0, reinterpret_cast<void*>(stream));
             if (status == 0) {
                 if (!spin_for_word(word, 0, &verdict))  // ~1 ms without a verdict: the stream's own completion (and its error, if any)
                     status = g_abi.mailbox_wait(reinterpret_cast<const int64_t*>(flag_host), 0, reinterpret_cast<void*>(stream), &verdict);
@@ -639,7 +641,7 @@ int dtype_code(at::ScalarType t) {
 // of the one-launch path (compressors/sparse/marlin_24.py, same conditions), then marlin24_w4_full.  `group_size`: the scheme's, 0 for a
 // channel-wise scheme, negative for a group scheme without a group size.  None when the tensors are not the one-launch case: the Python path takes the call.
 py::object marlin24_compress_default(const at::Tensor& weight, const at::Tensor& scale, const c10::optional<at::Tensor>& zp, int64_t group_size, uintptr_t flag_host,
-                                     uintptr_t flag_dev, uintptr_t stream) {
+                                     uintptr_t flag_dev, uintptr_t verdict_ws, uintptr_t stream) {
     touch_tls();
     const bool channel = group_size == 0;
     if (group_size < 0 || !g_abi.marlin_full || !on_device(weight) || weight.dim() != 2 || !half_type(weight.scalar_type()) || !half_type(scale.scalar_type()) || scale.dim() < 1 ||
@@ -657,7 +659,7 @@ py::object marlin24_compress_default(const at::Tensor& weight, const at::Tensor&
     }
     const int64_t group = (channel || group_size > k) ? k : group_size;
     const bool group_perm = !channel && group_size < k / 2;  // the in-dimension of the COMPRESSED weight decides (marlin_24.py: is_group)
-    return marlin24_w4_full(weight, dtype_code(weight.scalar_type()), scale2d, dtype_code(scale2d.scalar_type()), zp, zdt, group, group_perm, flag_host, flag_dev, stream);
+    return marlin24_w4_full(weight, dtype_code(weight.scalar_type()), scale2d, dtype_code(scale2d.scalar_type()), zp, zdt, group, group_perm, flag_host, flag_dev, verdict_ws, stream);
 }
 
 }  // namespace

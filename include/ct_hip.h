@@ -368,14 +368,26 @@ int ct_marlin24_compress_w4_full(const void* w, int wdt, const void* scale, int 
 
 /* the same one-launch compress for a caller that must RAISE from the call when the weight is not 2:4 (upstream's
  * Marlin24Compressor.compress -> validate_sparsity_structure, historical sparse_quantized_compressors/marlin_24.py; the mask test is
- * utils/semi_structured_conversions.py / tensor_follows_mask_structure): instead of a flag that is final only when the stream has
- * drained, the launch's last-reporting workgroup stores 1 (every quad of every row keeps at most two non-zero codes) or 3
- * (violated) into *verdict_word at system scope as soon as every workgroup has evaluated its tiles — the caller zeroes the word
- * (pinned, device-mapped host memory: ct_mailbox_alloc) before the call and spins on it; outputs follow on `stream` as usual.
+ * utils/semi_structured_conversions.py / tensor_follows_mask_structure, utils/helpers.py:87-109): instead of a flag that is final only
+ * when the stream has drained, the launch's last-reporting workgroup stores 1 (every quad of every row keeps at most two non-zero
+ * codes) or 3 (violated) into *verdict_word at system scope as soon as every workgroup has evaluated its tiles — the caller zeroes
+ * the word (pinned, device-mapped host memory: ct_mailbox_alloc) before the call and spins on it; outputs follow on `stream` as usual.
+ *   workspace        CT_M24_VERDICT_WORKSPACE_BYTES of device memory on the stream's device, 128-byte aligned, owned by the CALLER
+ *                    (as ct_bitmask_compress's): the workgroups count themselves in through it.  It must be all-zero when the launch
+ *                    starts and is all-zero again once the verdict has been stored (the kernel orders its resets before that store),
+ *                    so one zeroed allocation serves any number of consecutive calls.  One launch per workspace at a time: launches on
+ *                    ONE stream may share a workspace without waiting (stream order separates them); launches that can overlap — other
+ *                    streams, other host threads, other devices — need a workspace each, or must wait for the verdict in between.
+ *                    The library keeps no device state: the entry is re-entrant like every other one (convert_checkpoint's worker
+ *                    threads, entrypoints/convert/convert_checkpoint.py:129-132).
+ *   clear_workspace  != 0: the call zeroes the workspace first (one hipMemsetAsync on `stream`) — the first use of an allocation
+ *                    that is not known to be zero, or the use after a launch that did not finish.
  * CT_ERR_UNSUPPORTED for a layout the one-launch kernel does not take (use ct_marlin24_compress_w4_full + a stream wait). */
+#define CT_M24_VERDICT_WORKSPACE_BYTES 8320
 int ct_marlin24_compress_w4_verdict(const void* w, int wdt, const void* scale, int sdt, const void* zp, int zdt,
                                     int64_t m, int64_t k, int64_t cdiv, int group_perm, int32_t* packed, int16_t* meta,
-                                    void* scale_packed, int64_t* verdict_word, ct_stream_t stream);
+                                    void* scale_packed, int64_t* verdict_word, void* workspace, int clear_workspace,
+                                    ct_stream_t stream);
 
 /* marlin-24 weight packing (historical Marlin24Compressor.pack_weight_24 with the table of
  * utils/permutations_24.py:20-45).  q: codes of dtype dt (CT_I32 / CT_I8 / float holding

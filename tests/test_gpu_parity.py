@@ -2175,6 +2175,9 @@ def test_marlin24_verdict_word_through_the_c_abi(cta, dev, shape):
     assert int(ref[3].item()) == 0
     mb = _lib.mailbox(dev.index or 0)
     stream = _lib.stream_of_device(dev)
+    # the ticket tree is the caller's (round 6): handed over full of garbage with clear_workspace = 1 once, then left zero by every launch
+    tree = torch.full((_lib.Mailbox.M24_VERDICT_WORKSPACE_BYTES // 4,), 0x5a5a5a5a, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
     for rep in range(30):
         x, want = (bad, 3) if rep % 3 == 1 else (w, 1)
         packed = torch.empty_like(ref[0])
@@ -2182,19 +2185,159 @@ def test_marlin24_verdict_word_through_the_c_abi(cta, dev, shape):
         sp = torch.empty_like(ref[2])
         mb.words[1] = 0
         rc = lib.ct_marlin24_compress_w4_verdict(x.data_ptr(), _lib.BF16, sc.data_ptr(), _lib.BF16, None, -1, m, k, 128, int(128 < k // 2), packed.data_ptr(),
-                                                 meta.data_ptr(), sp.data_ptr(), mb.dev + 8, stream)
+                                                 meta.data_ptr(), sp.data_ptr(), mb.dev + 8, tree.data_ptr(), int(rep == 0), stream)
         assert rc == 0, _lib.last_error()
         got = mb.wait_word(1, 0, stream)
         assert got == want, (rep, got)
         torch.cuda.synchronize()
         assert mb.words[1] == want
+        assert int(tree.count_nonzero()) == 0, rep  # every counter back at zero: the next launch needs no clearing
         if want == 1:
             assert torch.equal(packed, ref[0]) and torch.equal(meta, ref[1]) and torch.equal(sp, ref[2])
     # fp32 scales are outside the one-launch kernel: refused, nothing launched, the word untouched
     mb.words[1] = 0
     rc = lib.ct_marlin24_compress_w4_verdict(w.data_ptr(), _lib.BF16, sc.float().data_ptr(), _lib.F32, None, -1, m, k, 128, 0, packed.data_ptr(), meta.data_ptr(),
-                                             sp.data_ptr(), mb.dev + 8, stream)
+                                             sp.data_ptr(), mb.dev + 8, tree.data_ptr(), 0, stream)
     assert rc != 0 and mb.words[1] == 0
+    # no workspace / a misaligned one: an argument error, nothing launched
+    for ws in (None, tree.data_ptr() + 64):
+        rc = lib.ct_marlin24_compress_w4_verdict(w.data_ptr(), _lib.BF16, sc.data_ptr(), _lib.BF16, None, -1, m, k, 128, 0, packed.data_ptr(), meta.data_ptr(),
+                                                 sp.data_ptr(), mb.dev + 8, ws, 0, stream)
+        assert rc == _lib.CT_ERR_INVALID_ARG and "workspace" in _lib.last_error() and mb.words[1] == 0
+
+
+def _m24_verdict_case(cta, dev, m, k, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    w = torch.randn(m, k, dtype=BF16, device=dev, generator=g)
+    w = w * cta.codec.sparse24_mask(w).to(w.dtype)
+    bad = w.clone()
+    r, c = (seed * 37) % m, ((seed * 101) % (k // 4)) * 4
+    bad[r, c:c + 4] = torch.tensor([3.0, -3.0, 2.5, 2.0], dtype=BF16, device=dev)  # ONE dense quad somewhere
+    sc, _ = cta.codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+    return w, bad, sc
+
+
+def test_marlin24_verdict_64_launches_in_flight_without_waiting(cta, dev):
+    """a plain C caller that pipelines: 64 verdict launches queued back to back on ONE stream, sharing ONE workspace
+    (stream order separates them), each with its own pinned word and its own outputs, no wait in between — then 64 words are read: every
+    verdict right, every output equal to the waited-for call's.  Then the same 64 over FOUR streams with a workspace per stream, so that
+    launches really overlap on the device."""
+    import ctypes
+
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    m, k = 512, 1024
+    w, bad, sc = _m24_verdict_case(cta, dev, m, k, 3)
+    ref = cta.codec.marlin24_compress_w4_full(w, sc, None, group_size=128, group_perm=128 < k // 2)
+    torch.cuda.synchronize()
+    h, d = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.ct_mailbox_alloc(8 * 64, ctypes.byref(h), ctypes.byref(d)))
+    words = (ctypes.c_int64 * 64).from_address(h.value)
+    try:
+        for nstreams in (1, 4):
+            streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+            trees = [torch.zeros(_lib.Mailbox.M24_VERDICT_WORKSPACE_BYTES // 4, dtype=torch.int32, device=dev) for _ in range(nstreams)]
+            outs = [(torch.empty_like(ref[0]), torch.empty_like(ref[1]), torch.empty_like(ref[2])) for _ in range(64)]
+            want = [3 if (i * 7) % 5 < 2 else 1 for i in range(64)]
+            for i in range(64):
+                words[i] = 0
+            torch.cuda.synchronize()
+            for i in range(64):
+                x = bad if want[i] == 3 else w
+                st = _lib.stream_on(dev, streams[i % nstreams].cuda_stream)
+                rc = lib.ct_marlin24_compress_w4_verdict(x.data_ptr(), _lib.BF16, sc.data_ptr(), _lib.BF16, None, -1, m, k, 128, 1, outs[i][0].data_ptr(),
+                                                         outs[i][1].data_ptr(), outs[i][2].data_ptr(), d.value + 8 * i, trees[i % nstreams].data_ptr(), 0, st)
+                assert rc == 0, _lib.last_error()
+            torch.cuda.synchronize()
+            assert [words[i] for i in range(64)] == want, nstreams
+            for i in range(64):
+                if want[i] == 1:
+                    assert all(torch.equal(a, b) for a, b in zip(outs[i], ref[:3])), (nstreams, i)
+            assert all(int(t.count_nonzero()) == 0 for t in trees)
+    finally:
+        lib.ct_mailbox_free(h)
+
+
+def test_marlin24_verdict_workspaces_on_two_devices(cta, dev):
+    """one workspace per device: the same host thread launches on cuda:0 and cuda:1 back to back without waiting (skipped on a one-GPU box)"""
+    import ctypes
+
+    from compressed_tensors_amd import _lib
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    lib = _lib.load()
+    m, k = 256, 1024
+    per_dev = []
+    for i in range(2):
+        dv = torch.device("cuda", i)
+        with torch.cuda.device(dv):
+            w, bad, sc = _m24_verdict_case(cta, dv, m, k, 5 + i)
+            ref = cta.codec.marlin24_compress_w4_full(w, sc, None, group_size=128, group_perm=True)
+            per_dev.append((dv, w, bad, sc, ref, torch.zeros(2080, dtype=torch.int32, device=dv), _lib.mailbox(i)))
+            torch.cuda.synchronize(dv)
+    for rep in range(10):
+        outs = []
+        for i, (dv, w, bad, sc, ref, tree, mb) in enumerate(per_dev):
+            x = bad if (rep + i) % 2 else w
+            o = (torch.empty_like(ref[0]), torch.empty_like(ref[1]), torch.empty_like(ref[2]))
+            mb.words[1] = 0
+            with torch.cuda.device(dv):
+                rc = lib.ct_marlin24_compress_w4_verdict(x.data_ptr(), _lib.BF16, sc.data_ptr(), _lib.BF16, None, -1, m, k, 128, 1, o[0].data_ptr(), o[1].data_ptr(),
+                                                         o[2].data_ptr(), mb.dev + 8, tree.data_ptr(), 0, _lib.stream_of_device(dv))
+            assert rc == 0, _lib.last_error()
+            outs.append(o)
+        for i, (dv, w, bad, sc, ref, tree, mb) in enumerate(per_dev):
+            assert mb.wait_word(1, 0, _lib.stream_of_device(dv)) == (3 if (rep + i) % 2 else 1)
+            torch.cuda.synchronize(dv)
+            if (rep + i) % 2 == 0:
+                assert all(torch.equal(a, b) for a, b in zip(outs[i], ref[:3]))
+
+
+def test_marlin24_default_mode_from_32_threads(cta, dev):
+    """32 host threads x 50 calls of the raise-from-the-call mode, valid and violating weights mixed (more threads than the sixteen global
+    trees the round-5 entry had): each thread owns its mailbox word and its ticket tree, so every verdict is right and every output equal
+    to the single-threaded one — the entry is re-entrant as include/ct_hip.h promises (convert_checkpoint's ThreadPoolExecutor,
+    entrypoints/convert/convert_checkpoint.py:129-132)."""
+    import threading
+
+    M = cta.Marlin24Compressor
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, strategy="group", group_size=128, symmetric=True))
+    shapes = [(64, 256), (128, 512), (256, 1024), (512, 512)]
+    cases = []
+    for i, (m, k) in enumerate(shapes):
+        w, bad, sc = _m24_verdict_case(cta, dev, m, k, 11 + i)
+        zp = torch.zeros_like(sc, dtype=torch.int8)
+        good = {"weight": w, "weight_scale": sc, "weight_zero_point": zp}
+        with M.deferred_structure_check():
+            ref = M.compress(good, scheme)
+        cases.append((good, dict(good, weight=bad), ref))
+    torch.cuda.synchronize()
+    errors, verdicts = [], [0] * 32
+
+    def run(t):
+        try:
+            torch.cuda.set_device(dev)
+            for r in range(50):
+                good, bad, ref = cases[(t + r) % len(cases)]
+                if (t * 50 + r) % 3 == 0:
+                    with pytest.raises(ValueError, match="2:4 sparsity structure"):
+                        M.compress(bad, scheme)
+                else:
+                    out = M.compress(good, scheme)
+                    assert all(torch.equal(out[key], ref[key]) for key in ("weight_packed", "scale_packed", "meta")), (t, r)
+                verdicts[t] += 1
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(32)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert verdicts == [50] * 32
 
 
 def test_marlin24_default_mode_raises_from_the_call_without_draining_the_stream(cta, dev):

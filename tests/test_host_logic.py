@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(cta):
         assert hasattr(lib, name), f"{name} is declared in include/ct_hip.h but not exported"
     # the Python binding covers exactly the declared ABI
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
-    assert _lib.load().ct_abi_version() == 1
+    assert _lib.load().ct_abi_version() == 2
 
 
 def test_ctypes_prototypes_match_the_header():
@@ -895,6 +895,7 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
     }
     box = (ctypes.c_int64 * 8)()
     host = ctypes.addressof(box)
+    WS = 0x7000  # stands for the caller's verdict workspace (only handed through)
     hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
     hp.set_allow_cpu(True)
     try:
@@ -919,7 +920,7 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
         for violate in (False, True):
             seen["violate"] = violate
             box[1] = 99
-            status, violated, packed, meta, sp = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+            status, violated, packed, meta, sp = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)
             assert status == 0 and violated is violate
             assert seen["marlin"] == (2, 2, None, -1, 64, 256, 128, 1, 0, 77, 0)  # the verdict word was cleared before the launch; the kernel only ORs into it
             assert packed.shape == (8, 128) and packed.dtype == torch.int32 and int(packed[0, 0]) == 7
@@ -938,60 +939,66 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
         cbs["hipStreamSynchronize"] = ctypes.CFUNCTYPE(I, V)(sync)
         cbs["ct_stream_wait"] = ctypes.CFUNCTYPE(I, V)(query_wait)
         hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
-        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and waits == {"sync": 1, "query": 0, "sync_rc": 0}
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)[0] == 0 and waits == {"sync": 1, "query": 0, "sync_rc": 0}
         waits["sync_rc"] = 700
-        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 1)
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 1)
         hp.set_wait_mode(0)
-        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 2)
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)[0] == 0 and (waits["sync"], waits["query"]) == (2, 2)
         hp.set_wait_mode(1)
         # round 5: with `ct_marlin24_compress_w4_verdict` bound, the verdict comes from the word the launch stores (1 = 2:4 holds, 3 = violated) — no
         # stream wait at all; CT_ERR_UNSUPPORTED (a layout outside the one-launch kernel) falls back to the full entry + the stream wait; a launch
         # that "finishes" without a verdict is an error, never a silent pass
         vseen = {"calls": 0, "mode": "ok"}
 
-        def verdict(w_, wdt, s_, sdt, zp_, zdt, m, k, g, perm, packed, meta, sp, word, stream):
+        def verdict(w_, wdt, s_, sdt, zp_, zdt, m, k, g, perm, packed, meta, sp, word, ws, clear_ws, stream):
             vseen["calls"] += 1
             vseen["args"] = (wdt, sdt, zp_, zdt, m, k, g, perm, stream, ctypes.c_int64.from_address(word).value)
+            assert (ws, clear_ws) == (WS, 0)  # round 6: the ticket tree is the caller's, kept zero by the launches themselves
             if vseen["mode"] == "unsupported":
                 return ctlib.CT_ERR_UNSUPPORTED
             if vseen["mode"] != "silent":
                 ctypes.c_int64.from_address(word).value = 3 if vseen["mode"] == "violated" else 1
             return 0
 
-        cbs["ct_marlin24_compress_w4_verdict"] = ctypes.CFUNCTYPE(I, V, I, V, I, V, I, L, L, L, I, V, V, V, V, V)(verdict)
+        cbs["ct_marlin24_compress_w4_verdict"] = ctypes.CFUNCTYPE(I, V, I, V, I, V, I, L, L, L, I, V, V, V, V, V, I, V)(verdict)
         hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
         waits.update(sync=0, query=0, sync_rc=0)
         seen.pop("marlin", None)
         for mode, want in (("ok", False), ("violated", True)):
             vseen["mode"] = mode
             box[1] = 99
-            status, violated, packed, meta, sp = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+            status, violated, packed, meta, sp = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)
             assert status == 0 and violated is want and vseen["args"] == (2, 2, None, -1, 64, 256, 128, 1, 77, 0)  # the word was zeroed before the launch
         assert "marlin" not in seen and waits == {"sync": 0, "query": 0, "sync_rc": 0}  # neither the flag entry nor any stream wait
+        calls = vseen["calls"]
+        assert hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 0, 77)[0] == 0  # no workspace: the flag entry + the stream wait
+        assert vseen["calls"] == calls and "marlin" in seen and waits["sync"] == 1
+        waits.update(sync=0)
+        seen.pop("marlin", None)
         vseen["mode"] = "unsupported"
         seen["violate"] = True
-        status, violated, *_ = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+        status, violated, *_ = hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)
         assert status == 0 and violated is True and "marlin" in seen and waits["sync"] == 1
         seen["violate"] = False
         vseen["mode"] = "silent"  # the stub's ct_mailbox_wait_i64 hands back the word as it is: still 0 -> not a verdict
         with pytest.raises(RuntimeError, match="without a 2:4 verdict"):
-            hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, 77)
+            hp.marlin24_w4_full(w, 2, s, 2, None, -1, 128, True, host + 8, host + 8, WS, 77)
         vseen["mode"] = "ok"
         del cbs["ct_marlin24_compress_w4_verdict"]
         hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})  # an older library without the entry: the full entry + wait
         # the same call from the state-dict entries on (Marlin24Compressor.compress): layout tests, element codes, group / permutation choice
         seen["violate"] = False
         D = hp.marlin24_compress_default
-        assert D(w, s, None, 128, host + 8, host + 8, 5)[0] == 0 and seen["marlin"][:9] == (2, 2, None, -1, 64, 256, 128, 0, 0)  # 128 == k / 2: single-column permutation
+        assert D(w, s, None, 128, host + 8, host + 8, WS, 5)[0] == 0 and seen["marlin"][:9] == (2, 2, None, -1, 64, 256, 128, 0, 0)  # 128 == k / 2: single-column permutation
         s64 = torch.ones(64, 4, dtype=torch.float16)
         zp = torch.zeros(64, 4, dtype=torch.int8)
-        assert D(w, s64, zp, 64, host + 8, host + 8, 5)[0] == 0
+        assert D(w, s64, zp, 64, host + 8, host + 8, WS, 5)[0] == 0
         assert seen["marlin"][:2] == (2, 1) and seen["marlin"][2] == zp.data_ptr() and seen["marlin"][3:9] == (3, 64, 256, 64, 1, 0)
-        assert D(w, torch.ones(64, dtype=torch.bfloat16), None, 0, host + 8, host + 8, 5)[0] == 0 and seen["marlin"][4:8] == (64, 256, 256, 0)  # channel-wise, 1-D scale
+        assert D(w, torch.ones(64, dtype=torch.bfloat16), None, 0, host + 8, host + 8, WS, 5)[0] == 0 and seen["marlin"][4:8] == (64, 256, 256, 0)  # channel-wise, 1-D scale
         for args in ((w[:32], s[:32], None, 128), (w[:, :128], s[:, :1], None, 128), (w.float(), s, None, 128), (w, s.float(), None, 128), (w, s, None, -1),
                      (w, s, None, 96), (w.t(), s, None, 128), (w, s.t(), None, 128), (w, s, torch.zeros(64, 2, dtype=torch.float64), 128),
                      (w[:, 8:264], s, None, 128)):
-            assert D(*args, host + 8, host + 8, 5) is None, [tuple(a.shape) if hasattr(a, "shape") else a for a in args]
+            assert D(*args, host + 8, host + 8, WS, 5) is None, [tuple(a.shape) if hasattr(a, "shape") else a for a in args]
     finally:
         hp.set_allow_cpu(False)
         ctlib._HOSTPATH.clear()  # the next hostpath() binds the real entries again
