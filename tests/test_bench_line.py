@@ -71,9 +71,17 @@ def test_multi_gpu_line_is_under_the_same_cap():
                            "w4a16": {"us_per_tensor": 20.1, "GBps_all_ranks": 16000.0, "frac_of_hbm_peak_per_gpu": 0.25, "shard_equals_slice_of_single_rank_result": True},
                            "sparse_bitmask": {"us_per_tensor": 30.1, "GBps_all_ranks": 14000.0, "frac_of_hbm_peak_per_gpu": 0.21, "row_offsets": "y" * 80,
                                               "shard_equals_slice_of_single_rank_result": True}}
+    full["row_sharded"]["w4a16"].update(sets=128, cache="z" * 120, us_per_tensor_blocks=[20.1] * 5)
+    full["row_sharded"]["sparse_bitmask"].update(sets=64, cache="z" * 120, us_per_tensor_blocks=[30.1] * 5)
+    full["tinyllama_checkpoint"].update(modules_per_rank=[19, 19, 19, 19, 19, 19, 20, 20], every_module_on_exactly_one_rank=True, rotating_copies=8, cache="c" * 100)
+    full["w4a16_4096"] = {"workload": "w" * 200, "us_per_step": 18.4, "us_per_step_blocks": [18.4] * 5, "GBps_all_ranks": 36700.0, "frac_of_hbm_peak_per_gpu": 0.573,
+                          "ranks": 8, "round_trip_equals_fake_quantize": True}
     text = bench.headline_line(full)
     line = json.loads(text)
     assert len(text) <= bench.LINE_CAP
+    assert line["w4a16_4096"]["ranks"] == 8 and line["w4a16_4096"]["GBps_all_ranks"] == 36700.0 and "workload" not in line["w4a16_4096"]
+    assert line["tinyllama_checkpoint"]["every_module_on_exactly_one_rank"] is True and sum(line["tinyllama_checkpoint"]["modules_per_rank"]) == 154
+    assert line["row_sharded"]["w4a16"]["sets"] == 128
     assert line["config"]["per_rank_GBps"] == [5956.7] * 8
     assert line["row_sharded"]["w4a16"]["shard_equals_slice_of_single_rank_result"] is True
     assert "tinyllama_checkpoint" in line
