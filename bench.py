@@ -242,6 +242,62 @@ def w4_variants_leg(dev):
     return out
 
 
+def other_widths_leg(dev):
+    """The bit widths next to 4 and 8 (the contract is 1 <= num_bits <= 8, pack_quantized/helpers.py:39-42): W3 / W2 / W6 g128 compress and
+    decompress at 8192x8192 bf16 through the C ABI (ct_quant_pack / ct_unpack_dequant take the lean kernels of ct_quant_wb.hip), HBM-cold
+    (packed words of the rotating sets >= 2x the Infinity Cache).  Gate per width: compress == quantize -> pack_to_int32, round trip ==
+    fake_quantize on set 0, and a 64-row slice against the CPU oracle."""
+    from compressed_tensors_amd import _lib, codec
+
+    lib = _lib.load()
+    BF16 = _lib.BF16
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = {"workload": f"W{{3,2,6}}A16 g128 compress / decompress, {N}x{N} bf16, C ABI, HBM-cold rotation"}
+    O = _oracle()
+    for bits in (3, 2, 6):
+        words = N * bits // 32
+        nsets = max(4, -(-2 * IC_BYTES // (N * words * 4)))
+        g = torch.Generator(device=dev).manual_seed(300 + bits)
+        sets = []
+        for _ in range(nsets):
+            w = torch.randn(N, N, dtype=torch.float32, device=dev, generator=g).to(torch.bfloat16)
+            sc, zp = codec.minmax_qparams(w, num_bits=bits, group_size=GROUP, symmetric=True)
+            sets.append((w, sc, zp, torch.empty(N, words, dtype=torch.int32, device=dev)))
+        outs = [torch.empty(N, N, dtype=torch.bfloat16, device=dev) for _ in range(4)]
+        ca = [(w.data_ptr(), BF16, sc.data_ptr(), BF16, zp.data_ptr(), _lib.I8, N, N, 1, GROUP, N // GROUP, None, bits, BF16, pk.data_ptr(), stream) for (w, sc, zp, pk) in sets]
+        da = [(pk.data_ptr(), N, words, N, bits, sc.data_ptr(), BF16, None, -1, 1, GROUP, N // GROUP, None, outs[i % 4].data_ptr(), BF16, stream)
+              for i, (w, sc, zp, pk) in enumerate(sets)]
+
+        def compress(i):
+            rc = lib.ct_quant_pack(*ca[i % nsets])
+            if rc:
+                _lib.check(rc)
+
+        def decompress(i):
+            rc = lib.ct_unpack_dequant(*da[i % nsets])
+            if rc:
+                _lib.check(rc)
+
+        for i in range(nsets):
+            compress(i)
+        one = 2 * N * N + 2 * N * (N // GROUP) + N * N * bits // 8
+        us_c = time_kernel(compress, 60)
+        us_d = time_kernel(decompress, 60, offset=nsets // 2)
+        w, sc, zp, pk = sets[0]
+        decompress(0)
+        kw = dict(num_bits=bits, strategy="group", group_size=GROUP)
+        ok = torch.equal(pk, codec.pack_to_int32(codec.quantize_tensor(w, sc, zp, dtype=torch.int8, **kw), bits)) and torch.equal(outs[0], codec.fake_quantize_tensor(w, sc, zp, **kw))
+        sl = slice(0, 64)
+        oc = O.pack_quantized_compress({"weight": w[sl].cpu(), "weight_scale": sc[sl].cpu(), "weight_zero_point": zp[sl].cpu()}, symmetric=True, **kw)
+        od = O.pack_quantized_decompress(oc, num_bits=bits, strategy="group", symmetric=True)
+        ok = ok and torch.equal(pk[sl].cpu(), oc["weight_packed"]) and torch.equal(outs[0][sl].cpu().view(torch.int16), od["weight"].view(torch.int16))
+        out[f"w{bits}"] = {"alg_bytes_per_direction": one, "sets": nsets, "compress_us": round(us_c, 2), "compress_frac_hbm": round(one / us_c / 1e3 / HBM_PEAK_GBPS, 4),
+                           "decompress_us": round(us_d, 2), "decompress_frac_hbm": round(one / us_d / 1e3 / HBM_PEAK_GBPS, 4), "bit_exact_vs_oracle_slice": bool(ok)}
+        del sets, outs, ca, da
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_gate(sets):
     """every benchmark run re-checks the timed kernels against INDEPENDENT kernels of the same library on the full
     8192 x 8192 tensor: fused compress == quantize(int8) -> pack_to_int32, and decompress(compress(W)) ==
@@ -558,6 +614,7 @@ def bitmask_leg(dev):
                                 it["ws"][-1:].data_ptr(), it["ws"].data_ptr(), ws_bytes, stream)
 
     nnz = items[0]["values"].numel()
+    nnz_of = lambda it: it["values"].numel()
     alg = 2 * N * N + 2 * nnz + N * N // 8 + 8 * N
     us_d = time_kernel(decompress, 24)
     us_c = time_kernel(compress, 24)
@@ -577,22 +634,32 @@ def bitmask_leg(dev):
         bts = [BitmaskTensor(shape=(N, N), compressed=it["values"], bitmask=it["bitmask"], row_offsets=it["ro"]) for it in items]
         last = {}
 
-        def api_compress(i):
+        def api_compress(i):  # the default: `compressed` owns exactly nnz elements (tensor[mask]'s size) — the kept prefix is copied out of the worst-case buffer
             last["bt"] = BitmaskTensor.from_dense(items[i % NB]["w"])
+
+        def api_compress_view(i):  # exact=False: no copy, `compressed` is a view of a dense-sized buffer (the result pins numel x 2 bytes)
+            last["btv"] = BitmaskTensor.from_dense(items[i % NB]["w"], exact=False)
 
         def api_decompress(i):
             last["dense"] = bts[i % NB].decompress()
 
         c_us, c_min, c_max = time_calls(api_compress)
-        bt = last["bt"]
+        v_us, v_min, v_max = time_calls(api_compress_view)
+        bt, btv = last["bt"], last["btv"]
         j = (MIN_LAUNCHES_PER_BLOCK - 1) % NB
         api_ok = (torch.equal(bt.compressed.view(torch.int16), items[j]["values"].view(torch.int16)) and torch.equal(bt.bitmask, items[j]["bitmask"])
-                  and torch.equal(bt.row_offsets, items[j]["ro"]))
+                  and torch.equal(bt.row_offsets, items[j]["ro"]) and torch.equal(btv.compressed.view(torch.int16), items[j]["values"].view(torch.int16)))
+        storage_exact, storage_view = bt.compressed.untyped_storage().nbytes(), btv.compressed.untyped_storage().nbytes()
         d_us, d_min, d_max = time_calls(api_decompress)
         api_ok = api_ok and torch.equal(last["dense"].view(torch.int16), items[j]["w"].view(torch.int16))
         last.clear()
         api = {"api_compress_us": round(c_us, 2), "api_compress_us_min_max": [round(c_min, 2), round(c_max, 2)],
                "api_compress_frac_hbm": round(alg / c_us / 1e3 / HBM_PEAK_GBPS, 4),
+               "api_compress_mode": "exact (default): values own nnz elements; + one asynchronous device copy of the kept prefix",
+               "api_compress_values_storage_bytes": storage_exact,
+               "api_compress_view_us": round(v_us, 2), "api_compress_view_us_min_max": [round(v_min, 2), round(v_max, 2)],
+               "api_compress_view_frac_hbm": round(alg / v_us / 1e3 / HBM_PEAK_GBPS, 4),
+               "api_compress_view_values_storage_bytes": storage_view, "api_compress_nnz_bytes": 2 * nnz_of(items[j]),
                "api_decompress_us": round(d_us, 2), "api_decompress_us_min_max": [round(d_min, 2), round(d_max, 2)],
                "api_decompress_frac_hbm": round(alg / d_us / 1e3 / HBM_PEAK_GBPS, 4), "api_bit_exact": bool(api_ok),
                "api": "BitmaskTensor.from_dense(w) / .decompress(): per-call wall time incl. the class's own allocations and the host wait for nnz "
@@ -983,8 +1050,11 @@ def roofline_rows(result):
         row("bitmask_decompress16_kernel", "sparse-bitmask 50 % 8192x8192 bf16 (config 3), decompress", b["alg_bytes"], b["decompress_us"], bit_exact=b["round_trip_bit_exact"])
         row("flat16_resident_kernel", "sparse-bitmask 50 % 8192x8192 bf16 (config 3), compress", b["alg_bytes"], b["compress_us"], bit_exact=b["round_trip_bit_exact"])
         if "api_compress_us" in b:
-            row("BitmaskTensor.from_dense", "config 3 through the plug-in class, wall time per call (allocations + host wait for nnz)", b["alg_bytes"], b["api_compress_us"],
-                bit_exact=b["api_bit_exact"])
+            row("BitmaskTensor.from_dense", "config 3 through the plug-in class, wall time per call (allocations + host wait for nnz); EXACT-size values (default)",
+                b["alg_bytes"], b["api_compress_us"], bit_exact=b["api_bit_exact"], values_storage_bytes=b.get("api_compress_values_storage_bytes"))
+            if "api_compress_view_us" in b:
+                row("BitmaskTensor.from_dense(exact=False)", "config 3 through the plug-in class; values are a VIEW of a dense-sized buffer (no copy, pins numel x 2 bytes)",
+                    b["alg_bytes"], b["api_compress_view_us"], bit_exact=b["api_bit_exact"], values_storage_bytes=b.get("api_compress_view_values_storage_bytes"))
             row("BitmaskTensor.decompress", "config 3 through the plug-in class, wall time per call", b["alg_bytes"], b["api_decompress_us"], bit_exact=b["api_bit_exact"])
         if "s24_compress_us" in b:
             row("sparse24_pair_kernel", "sparse-24-bitmask 8192x8192 bf16, compress", b["s24_alg_bytes"], b["s24_compress_us"], bit_exact=b["s24_bit_exact"])
@@ -1005,6 +1075,12 @@ def roofline_rows(result):
         if isinstance(v, dict):
             row("w4 compress", f"W4A16 g128 8192x8192 {key}", v["alg_bytes_per_direction"], v["compress_us"])
             row("w4 decompress", f"W4A16 g128 8192x8192 {key}", v["alg_bytes_per_direction"], v["decompress_us"])
+    ow = leg("other_widths") or {}
+    for b_ in (3, 2, 6):
+        v = ow.get(f"w{b_}")
+        if isinstance(v, dict):
+            row(f"wb_quant_pack_lean_kernel<bf16, {b_}>", f"W{b_}A16 g128 8192x8192 bf16, compress", v["alg_bytes_per_direction"], v["compress_us"], bit_exact=v["bit_exact_vs_oracle_slice"])
+            row(f"wb_unpack_dequant_kernel<bf16, {b_}>", f"W{b_}A16 g128 8192x8192 bf16, decompress", v["alg_bytes_per_direction"], v["decompress_us"], bit_exact=v["bit_exact_vs_oracle_slice"])
     i8 = leg("int8_per_tensor")
     if i8:
         row("q8_quant_kernel", "int8 per-tensor 4096x4096 bf16 (config 1), quantize", i8["alg_bytes_per_direction"], i8["quantize_us"])
@@ -1041,11 +1117,12 @@ def roofline_rows(result):
 LINE_CAP = 6000  # characters: the driver's record keeps the last 8081 of stdout, and the final line must sit inside that whole
 DETAILS_FILE = "bench_details.json"
 
-# short names for the rows roofline_rows() builds (kernel text, config text): the final line carries at most 14 of them
+# short names for the rows roofline_rows() builds (kernel text, config text): the final line carries at most 17 of them
 _HEADLINE_ROWS = (
     ("bitmask_decompress16_kernel", "(config 3), decompress", "cfg3 sparse-bitmask 50% 8192^2 bf16, decompress"),
     ("flat16_resident_kernel", "(config 3), compress", "cfg3 sparse-bitmask 50% 8192^2 bf16, compress"),
-    ("BitmaskTensor.from_dense", "", "cfg3 via the plug-in class, wall/call"),
+    ("BitmaskTensor.from_dense", "EXACT", "cfg3 via the plug-in class, exact-size values (default), wall/call"),
+    ("BitmaskTensor.from_dense(exact=False)", "", "cfg3 via the plug-in class, values = view of a dense-sized buffer, wall/call"),
     ("marlin24_fused_w4_lean_kernel", "", "cfg4 marlin-24 2:4+int4 g128 8192^2 bf16, kernel"),
     ("Marlin24Compressor.compress (default", "", "cfg4 via the plug-in class (call raises the 2:4 ValueError), wall/call"),
     ("w4_*_batch_kernel x 2", "", "cfg5 TinyLlama-1.1B-shaped W4A16 checkpoint, C ABI"),
@@ -1053,6 +1130,8 @@ _HEADLINE_ROWS = (
     ("ModelCompressor.compress_model + decompress_model (asymmetric", "", "cfg5 asymmetric (packed zero points) via ModelCompressor, wall"),
     ("w4_quant_pack_lean_kernel<bf16>", "4096x4096 bf16, compress", "W4A16 g128 4096^2 bf16, compress"),
     ("w4_unpack_dequant_kernel<bf16>", "4096x4096 bf16, decompress", "W4A16 g128 4096^2 bf16, decompress"),
+    ("wb_quant_pack_lean_kernel<bf16, 3>", "", "W3A16 g128 8192^2 bf16, compress"),
+    ("wb_unpack_dequant_kernel<bf16, 3>", "", "W3A16 g128 8192^2 bf16, decompress"),
     ("q8_quant_kernel", "", "cfg1 int8 per-tensor 4096^2 bf16, quantize"),
     ("q8_dequant_kernel", "", "cfg1 int8 per-tensor 4096^2 bf16, dequantize"),
 )
@@ -1063,7 +1142,7 @@ def _pick(d, keys):
 
 
 def headline_line(result, cap=LINE_CAP):
-    """The ONE line the driver parses: the contract keys, `config`, `roofline` (with <= 14 kernel rows) and `cpu_baseline`, serialised
+    """The ONE line the driver parses: the contract keys, `config`, `roofline` (with <= 17 kernel rows) and `cpu_baseline`, serialised
     in at most `cap` characters.  Everything else bench.py measures (per-dtype quantize legs, float formats, W8A8, thread sweeps, the
     restatement / port baselines, per-leg detail) stays in the full result, which main() writes to bench_details.json and to stderr.
     tests/test_bench_line.py feeds recorded results through this function and holds it to the cap and to the key list."""
@@ -1084,7 +1163,7 @@ def headline_line(result, cap=LINE_CAP):
         if kernel.endswith("decompress_model"):  # the symmetric row: its name is a prefix of the asymmetric one's
             hit = [x for x in hit if "asymmetric" not in x["kernel"]]
         if hit:
-            row = _pick(hit[0], ("alg_bytes", "us", "GBps", "frac", "bit_exact", "api_over_kernels", "deferred_check_us", "pair_us", "pair_frac"))
+            row = _pick(hit[0], ("alg_bytes", "us", "GBps", "frac", "bit_exact", "api_over_kernels", "deferred_check_us", "pair_us", "pair_frac", "values_storage_bytes"))
             rows.append({"kernel": kernel.split(" (")[0], "config": short, **row})
     roof["kernels"] = rows
     line["roofline"] = roof
@@ -1213,24 +1292,25 @@ def tinyllama_leg(dev, rank, world, barrier, allreduce_max, allreduce_sum_vec=No
         rot_ok = all(torch.equal(kc[0][4], codec.fake_quantize_tensor(kc[0][0], kc[0][1], kc[0][2], num_bits=BITS, strategy="group", group_size=GROUP)) for kc, _, _ in copies)
         del copies, kc0
         torch.cuda.empty_cache()
-    # the same checkpoint with an ASYMMETRIC scheme (W4A16_ASYM: int8 zero points, stored packed along rows): two launches per
-    # direction — the weights and all the zero points — instead of two per module
+    # the same checkpoint with an ASYMMETRIC scheme (W4A16_ASYM: int8 zero points, stored packed along rows): one launch per
+    # direction instead of two per module
     asym = []
     for (w, _, _, p, o) in keep:
         sa, za = codec.minmax_qparams(w, num_bits=BITS, group_size=GROUP, symmetric=False)
         asym.append((sa, za, torch.empty((-(-w.shape[0] * 4 // 32), za.shape[1]), dtype=torch.int32, device=dev), torch.empty_like(za)))
-    cba = codec.W4Batch([(w, sa, za, p, w.shape[0], w.shape[1], GROUP) for (w, _, _, p, _), (sa, za, _, _) in zip(keep, asym)], "compress", torch.bfloat16)
-    dba = codec.W4Batch([(p, sa, zu, o, w.shape[0], w.shape[1], GROUP) for (w, _, _, p, o), (sa, _, _, zu) in zip(keep, asym)], "decompress", torch.bfloat16)
+    # round 6: ONE launch per direction — the compress launch's tail workgroups write the stored (packed) zero points, the decompress launch reads
+    # them in that form and writes the unpacked int8 back (ct_w4_item.zp_packed); rounds 2-5 ran ct_zp4_pack_dim0_batch twice beside them
+    cba = codec.W4Batch([(w, sa, za, p, w.shape[0], w.shape[1], GROUP, zp_) for (w, _, _, p, _), (sa, za, zp_, _) in zip(keep, asym)], "compress", torch.bfloat16)
+    dba = codec.W4Batch([(p, sa, zu, o, w.shape[0], w.shape[1], GROUP, zp_) for (w, _, _, p, o), (sa, _, zp_, zu) in zip(keep, asym)], "decompress", torch.bfloat16)
 
     def batched_asym():
         cba.launch(stream)
-        codec.zp4_batch([(za, zp_) for (_, za, zp_, _) in asym], "pack")
-        codec.zp4_batch([(zp_, zu) for (_, _, zp_, zu) in asym], "unpack")
         dba.launch(stream)
 
     t_asym = timed(batched_asym)
     wa0, (sa0, za0, _, zu0) = keep[0][0], asym[0]
-    asym_ok = bool(torch.equal(zu0, za0) and torch.equal(keep[0][4], codec.fake_quantize_tensor(wa0, sa0, za0, num_bits=BITS, strategy="group", group_size=GROUP)))
+    asym_ok = bool(torch.equal(zu0, za0) and torch.equal(asym[0][2], codec.pack_to_int32(za0, BITS, packed_dim=0))
+                   and torch.equal(keep[0][4], codec.fake_quantize_tensor(wa0, sa0, za0, num_bits=BITS, strategy="group", group_size=GROUP)))
     batched()  # leave the symmetric results in the buffers for the check below
     total_bytes = sum(2 * (2 * r * c + 2 * r * (c // GROUP) + r * c // 2) for _, r, c in mods)
     w0, s0, z0, p0, o0 = keep[0]
@@ -1810,7 +1890,7 @@ def main():
         if world == 1 and not a.no_extra:
             del sets
             torch.cuda.empty_cache()
-            for key, leg in (("kernels_other", w4_variants_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("quantize_dequantize_fake_quantize", quantize_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
+            for key, leg in (("kernels_other", w4_variants_leg), ("other_widths", other_widths_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("quantize_dequantize_fake_quantize", quantize_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
                              ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg), ("tinyllama_w8a8", tinyllama_w8_leg)):
                 try:
                     result[key] = leg(dev)

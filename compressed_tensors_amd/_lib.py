@@ -65,6 +65,8 @@ _PROTOTYPES = {
     "ct_rtn_quant_channel8": ([_P, _I, _L, _L, _I, _I, _P, _P, _P, _S], _I),
     "ct_rtn_quant_pack_w4": ([_P, _I, _L, _L, _L, _I, _P, _P, _P, _S], _I),
     "ct_unpack_dequant": ([_P, _L, _L, _L, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _I, _S], _I),
+    "ct_quant_pack_w4_zp": ([_P, _I, _P, _P, _L, _L, _L, _P, _P, _S], _I),
+    "ct_unpack_dequant_w4_zp": ([_P, _P, _I, _P, _L, _L, _L, _P, _P, _S], _I),
     "ct_w4_batch_plan": ([_P, _I, _I], _L),
     "ct_quant_pack_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
@@ -113,7 +115,11 @@ _PROTOTYPES = {
 class W4Item(ctypes.Structure):
     """struct ct_w4_item of include/ct_hip.h"""
     _fields_ = [("src", _P), ("scale", _P), ("zp", _P), ("dst", _P), ("rows", _L), ("cols", _L), ("group", _L),
-                ("first_block", _L), ("units", _L), ("upg_shift", _c.c_int32), ("upg", _c.c_int32)]
+                ("first_block", _L), ("units", _L), ("upg_shift", _c.c_int32), ("upg", _c.c_int32),
+                ("zp_packed", _P), ("main_blocks", _L), ("g_magic", _c.c_uint32), ("g_shift", _c.c_int32)]
+
+
+ITEM_WORDS = ctypes.sizeof(W4Item) // 8  # 13: every host table of ct_w4_item rows is a flat array of this many 64-bit words per item
 
 
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOTYPES))

@@ -442,6 +442,62 @@ def unpack_and_dequantize(packed, shape, scale, zero_point=None, *, num_bits, st
     return _home(out, packed)
 
 
+def _w4_zp_fused_ok(x_or_packed, scale, zero_point, rows, cols, group) -> bool:
+    """the layout ct_quant_pack_w4_zp / ct_unpack_dequant_w4_zp take: 2-D, 16-bit scale of shape (rows, cols / group), everything
+    contiguous, 16-byte aligned and on one GPU"""
+    if scale is None or scale.dtype not in (torch.bfloat16, torch.float16) or not scale.is_cuda or not x_or_packed.is_cuda:
+        return False
+    if cols % 32 or group % 32 or cols % group or rows <= 0:
+        return False
+    if tuple(scale.shape) != (rows, cols // group) or not scale.is_contiguous() or not x_or_packed.is_contiguous():
+        return False
+    if zero_point is None or zero_point.device != scale.device or not zero_point.is_contiguous() or x_or_packed.device != scale.device:
+        return False
+    return _aligned16(x_or_packed, scale, zero_point)
+
+
+def quantize_and_pack_with_zp(x, scale, zero_point, *, num_bits, strategy, group_size=None):
+    """PackedQuantizationCompressor.compress of an ASYMMETRIC int4 scheme in ONE launch (compressors/pack_quantized/base.py:96-110):
+    returns (weight_packed int32 (R, C / 8), weight_zero_point int32 (ceil(R / 8), G) = pack_to_int32(zp, 4, packed_dim=0)), or None
+    when the tensors are not the layout `ct_quant_pack_w4_zp` takes (the caller then composes quantize_and_pack + pack_to_int32)."""
+    st = _strategy_name(strategy)
+    if int(num_bits) != 4 or x.dim() != 2 or st not in ("group", "channel") or x.dtype not in (torch.bfloat16, torch.float16):
+        return None
+    rows, cols = int(x.shape[0]), int(x.shape[1])
+    group = cols if st == "channel" else int(group_size or 0)
+    if group <= 0 or zero_point is None or zero_point.dtype is not torch.int8 or scale is None or scale.dtype is not x.dtype:
+        return None
+    if not _w4_zp_fused_ok(x, scale, zero_point, rows, cols, group) or tuple(zero_point.shape) != tuple(scale.shape):
+        return None
+    packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=x.device)
+    zpp = torch.empty(((rows * 4 + 31) // 32, cols // group), dtype=torch.int32, device=x.device)
+    call("ct_quant_pack_w4_zp", ptr(x), DT[x.dtype], ptr(scale), ptr(zero_point), rows, cols, group, ptr(packed), ptr(zpp), stream_of(x))
+    return packed, zpp
+
+
+def unpack_and_dequantize_with_zp(packed, shape, scale, zp_packed, *, num_bits, want_zero_point=True):
+    """PackedQuantizationCompressor.decompress of an ASYMMETRIC int4 scheme in ONE launch (base.py:147-161): the zero points are read in
+    their stored form.  Returns (weight of the scale's dtype, unpacked int8 zero point or None), or None when the tensors are not the
+    layout `ct_unpack_dequant_w4_zp` takes (groups of 128, cols % 512 == 0, ...): the caller then unpacks the zero points first."""
+    shape = tuple(int(v) for v in shape)
+    if int(num_bits) != 4 or len(shape) != 2 or scale is None or scale.dim() != 2 or scale.shape[1] == 0 or packed.dtype is not torch.int32:
+        return None
+    rows, cols = shape
+    if cols % scale.shape[1]:
+        return None
+    group = cols // scale.shape[1]
+    if not w4_packed_zp_readable(cols, group) or rows * (cols // 8) >= 1 << 31 or zp_packed is None or zp_packed.dtype is not torch.int32:
+        return None
+    if tuple(zp_packed.shape) != ((rows * 4 + 31) // 32, scale.shape[1]) or tuple(packed.shape) != (rows, cols // 8):
+        return None
+    if not _w4_zp_fused_ok(packed, scale, zp_packed, rows, cols, group):
+        return None
+    out = torch.empty(shape, dtype=scale.dtype, device=packed.device)
+    zp = torch.empty((rows, scale.shape[1]), dtype=torch.int8, device=packed.device) if want_zero_point else None
+    call("ct_unpack_dequant_w4_zp", ptr(packed), ptr(scale), DT[scale.dtype], ptr(zp_packed), rows, cols, group, ptr(out), ptr(zp), stream_of(packed))
+    return out, zp
+
+
 def minmax_qparams(x, *, num_bits, group_size=None, symmetric=True):
     """Min-max observer + calculate_qparams (quantization/utils/helpers.py:50-137) over groups of
     `group_size` consecutive columns (None: the whole row).  Returns (scale x.dtype (R, G),
@@ -659,7 +715,7 @@ def launch_w4_words(words: torch.Tensor, n: int, direction: str, dtype: torch.dt
 
 
 def launch_zp4_words(words: torch.Tensor, n: int, direction: str, device: torch.device) -> None:
-    """`zp4_batch` for a table that already exists as a flat CPU int64 tensor (src, 0, 0, dst, unpacked rows, cols, 0, 0, 0, 0 per item;
+    """`zp4_batch` for a table that already exists as a flat CPU int64 tensor (src, 0, 0, dst, unpacked rows, cols, 0 ... per item;
     built by the C++ host loop): plan, upload, ONE `ct_zp4_pack_dim0_batch` launch on `device`'s current stream"""
     if not n:
         return
@@ -670,19 +726,29 @@ def launch_zp4_words(words: torch.Tensor, n: int, direction: str, device: torch.
     call("ct_zp4_pack_dim0_batch", table.data_ptr(), n, blocks, 0 if direction == "pack" else 1, _lib.stream_on(device))
 
 
-_ITEM_WORDS = 10  # struct ct_w4_item of include/ct_hip.h in 64-bit words: 4 pointers, rows, cols, group, first_block, units, {upg_shift, upg}
+_ITEM_WORDS = _lib.ITEM_WORDS  # struct ct_w4_item of include/ct_hip.h in 64-bit words: 4 pointers, rows, cols, group, first_block, units,
+#                                {upg_shift, upg}, zp_packed, main_blocks, {g_magic, g_shift}
+_ITEM_TAIL = (0,) * (_ITEM_WORDS - 11)  # the derived words behind zp_packed
+
+
+def w4_packed_zp_readable(cols: int, group: int) -> bool:
+    """can the W4 decompress kernels take this tensor's zero points in their STORED (packed) form? (include/ct_hip.h, ct_w4_item.zp_packed:
+    groups of 128, whole waves per row)"""
+    return group == 128 and cols % 512 == 0
 
 
 class W4Batch:
     """A table of tensors processed by ONE kernel launch per direction — the per-module loop of ModelCompressor without a
     launch (and a ~5 us host call) per module.
 
-    entries: (src, scale, zero_point or None, dst, rows, cols, group) with src / dst in the order the direction needs
-    ("compress": weight -> codes).  kind "w4": W4A16 pack-quantized (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`,
+    entries: (src, scale, zero_point or None, dst, rows, cols, group[, zp_packed or None]) with src / dst in the order the direction needs
+    ("compress": weight -> codes).  `zp_packed` ("w4" only; round 6): the int32 (ceil(rows / 8), cols / group) STORED form of an
+    asymmetric scheme's zero points, written ("compress", beside the int8 `zero_point` that is quantized against) or read
+    ("decompress": the kernel takes the zero points from it and fills `zero_point`, if given, with the unpacked int8) by the SAME launch.  kind "w4": W4A16 pack-quantized (`ct_quant_pack_batch` / `ct_unpack_dequant_batch`,
     dst / src = packed int32 words); kind "int8" / "fp8": the 8-bit codecs (`ct_q8_quant_batch` / `ct_q8_dequant_batch`, one
     byte per element, `bits` = the INT scheme's num_bits; group may be rows * cols for a per-tensor scale).
 
-    The host table is one flat array of 64-bit words (10 per item, the layout of `struct ct_w4_item`) planned in place by the
+    The host table is one flat array of 64-bit words (13 per item, the layout of `struct ct_w4_item`) planned in place by the
     library and uploaded asynchronously from pinned memory."""
 
     def __init__(self, entries, direction: str, dtype: torch.dtype, kind: str = "w4", bits: int = 8):
@@ -696,8 +762,11 @@ class W4Batch:
         n = self.n = len(self.keep)
         flat = []
         dev = None
-        for src, scale, zp, dst, rows, cols, group in self.keep:
-            flat += (src.data_ptr(), scale.data_ptr(), 0 if zp is None else zp.data_ptr(), dst.data_ptr(), rows, cols, group, 0, 0, 0)
+        for e in self.keep:
+            src, scale, zp, dst, rows, cols, group = e[:7]
+            zpp = e[7] if len(e) > 7 else None
+            flat += (src.data_ptr(), scale.data_ptr(), 0 if zp is None else zp.data_ptr(), dst.data_ptr(), rows, cols, group, 0, 0, 0,
+                     0 if zpp is None else zpp.data_ptr(), *_ITEM_TAIL)
         self.blocks, self.table, self.device = 0, None, None
         if n:
             dev = self.keep[0][0].device
@@ -791,7 +860,7 @@ def zp4_batch(pairs, direction: str) -> None:
     flat = []
     for src, dst in pairs:
         unpacked = src if direction == "pack" else dst
-        flat += (src.data_ptr(), 0, 0, dst.data_ptr(), int(unpacked.shape[0]), int(unpacked.shape[1]), 0, 0, 0, 0)
+        flat += (src.data_ptr(), 0, 0, dst.data_ptr(), int(unpacked.shape[0]), int(unpacked.shape[1]), 0, 0, 0, 0, 0, *_ITEM_TAIL)
     words = array.array("q", flat)
     blocks = int(_lib.load().ct_zp4_batch_plan(words.buffer_info()[0], len(pairs)))
     if blocks < 0:
@@ -882,8 +951,15 @@ def _bitmask_workspace_bytes(rows: int, cols: int) -> int:
     return n
 
 
-def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
+def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False, exact: bool = True):
     """sparse-bitmask compression: returns (values, bitmask uint8 (R, ceil(C/8)), row_offsets int64 (R,)).
+
+    `exact` (round 6, default True): `values` owns exactly nnz elements, as `tensor[mask]` does (restated S1 over utils/helpers.py:306-343) —
+    the kernel writes into a worst-case sized buffer (nnz is not known before it has run) and the kept prefix is then copied out, one
+    asynchronous device copy of 2 x nnz x itemsize bytes that the caller does not wait for; the worst-case buffer goes back to the allocator.
+    `exact=False`: `values` is a VIEW of the worst-case buffer — no copy, but the result pins numel x itemsize bytes however sparse the
+    tensor is (a "compressed" 50 %-sparse weight then holds as much memory as the dense one): for a caller that consumes the values at
+    once (serialises them, copies them elsewhere) and drops them.
 
     Default: the fused form (`ct_bitmask_compress`; 16- and 32-bit elements: the register-resident kernel that reads the tensor once,
     otherwise count + scatter whose prefixes are sums of the counts; no scan kernel) into a worst-case sized value buffer, then
@@ -900,7 +976,7 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
             x = _bits_view(tensor)
             s = stream_of(x)
             mb = _lib.mailbox(s.device_index)
-            r = hp.bitmask_compress(x, _elem_code(x), mb.host, mb.dev, s)
+            r = hp.bitmask_compress(x, _elem_code(x), mb.host, mb.dev, s, bool(exact))
             if r is not None:
                 _lib.check(r[0])
                 return (r[1] if x is tensor else r[1].view(tensor.dtype)), r[2], r[3]
@@ -934,9 +1010,8 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False):
         nnz = mb.wait_word(0, -1, s)
         if nnz < 0 or nnz > numel:  # the stream drained and the word still holds the pending mark (or junk): never slice with it
             raise RuntimeError(f"ct_bitmask_compress finished without reporting the number of non-zeros (mailbox word {nnz}, numel {numel})")
-        # keep the view unless it pins more than ~5/8 of the worst-case buffer for nothing (at the 50 % sparsity of BASELINE config 3
-        # nnz lands on either side of numel / 2: a `2 * nnz >= numel` rule cloned 67 MB on a coin flip), else release the slack
-        values = buf[:nnz] if 8 * nnz >= 3 * numel else buf[:nnz].clone()
+        # exact: the kept prefix leaves the worst-case buffer (an asynchronous copy; nothing waits for it) unless the buffer is full anyway
+        values = buf[:nnz] if (not exact or nnz == numel) else buf[:nnz].clone()
     return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor), _home(row_offsets, tensor)
 
 

@@ -111,13 +111,22 @@ class PackedQuantizationCompressor(BaseCompressor):
 
         if enum_value(getattr(weights, "type", "int")) != "int":
             raise NotImplementedError("pack-quantized requires INT weights")
+        stores_zp = not weights.symmetric and enum_value(weights.strategy) in PACK_ZP_STRATS
         if _prepacked is not None:
             state_dict["weight_packed"] = _prepacked  # produced by the batched launch of compress_modules
         else:
-            state_dict["weight_packed"] = codec.quantize_and_pack(weight, scale, zero_point, g_idx=g_idx, **_layout_kwargs(weights))
+            fused = None
+            if stores_zp and g_idx is None and _prezp is None and zero_point is not None:
+                # the weight words AND the stored form of the zero points from ONE launch (ct_quant_pack_w4_zp; None: not its layout)
+                fused = codec.quantize_and_pack_with_zp(weight, scale, zero_point, num_bits=int(weights.num_bits), strategy=enum_value(weights.strategy),
+                                                        group_size=getattr(weights, "group_size", None))
+            if fused is not None:
+                state_dict["weight_packed"], _prezp = fused
+            else:
+                state_dict["weight_packed"] = codec.quantize_and_pack(weight, scale, zero_point, g_idx=g_idx, **_layout_kwargs(weights))
         state_dict["weight_shape"] = torch.tensor(weight.shape)  # int64, CPU: as upstream (:105)
 
-        if not weights.symmetric and enum_value(weights.strategy) in PACK_ZP_STRATS:
+        if stores_zp:
             assert zero_point is not None, "Asymmetric quant requires zero-point values"
             if _prezp is not None:
                 state_dict["weight_zero_point"] = _prezp  # packed by the batched launch of compress_modules
@@ -146,6 +155,12 @@ class PackedQuantizationCompressor(BaseCompressor):
         if not weights.symmetric and enum_value(weights.strategy) in PACK_ZP_STRATS:
             assert zero_point is not None, "Asymmetric quant requires zero-point values"
             zp_shape = (*shape[:-1], scale.shape[-1])
+            if _prezp is None and _preweight is None and g_idx is None and packed.is_cuda:
+                # ONE launch: the kernel reads the zero points in their stored form and writes the unpacked int8 form back beside the
+                # weight (ct_unpack_dequant_w4_zp; None: not its layout — groups of 128, cols % 512 == 0)
+                fused = codec.unpack_and_dequantize_with_zp(packed, shape, scale, zero_point, num_bits=int(weights.num_bits))
+                if fused is not None:
+                    _preweight, _prezp = fused
             zero_point = _prezp if _prezp is not None else codec.unpack_from_int32(zero_point, weights.num_bits, zp_shape, packed_dim=0)
             state_dict["weight_zero_point"] = zero_point
 
@@ -206,7 +221,9 @@ class PackedQuantizationCompressor(BaseCompressor):
                 for (dev_index, code), (words, n, jobs, zp_words, zp_n) in planned.items():
                     device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
                     codec.launch_w4_words(words, n, "compress", _DTYPE_OF_CODE[code], device)
-                    codec.launch_zp4_words(zp_words, zp_n, "pack", device)  # the asymmetric modules' zero points: pack_to_int32(zp, 4, packed_dim=0)
+                    # (the asymmetric modules' zero points — pack_to_int32(zp, 4, packed_dim=0) — are written by tail workgroups of that launch;
+                    # zp_n is 0 since round 6 and the call below a no-op, kept for a host extension built from an older source)
+                    codec.launch_zp4_words(zp_words, zp_n, "pack", device)
                     pending.append(jobs)
             for jobs in pending:  # the parameter dictionaries, under the kernels
                 hp.w4_finish_compress(jobs, QuantizationStatus.COMPRESSED)
@@ -255,19 +272,16 @@ class PackedQuantizationCompressor(BaseCompressor):
                 continue
             packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=w.device)
             entries, jobs = batches.setdefault((w.device, w.dtype), ([], []))
-            entries.append((w, scale, zp, packed, rows, cols, group))
+            zpp = None
+            if info[1] and enum_value(scheme.weights.strategy) in PACK_ZP_STRATS:
+                assert zp is not None, "Asymmetric quant requires zero-point values"
+                # the stored form of the zero points (pack_to_int32(zp, 4, packed_dim=0)): written by tail workgroups of the SAME launch
+                zpp = torch.empty((math.ceil(rows * 4 / 32), zp.shape[1]), dtype=torch.int32, device=w.device)
+            entries.append((w, scale, zp, packed, rows, cols, group, zpp))
             jobs.append((m, scheme, packed, zp, (rows, cols)))
         for (device, dtype), (entries, jobs) in batches.items():
             codec.W4Batch(entries, "compress", dtype).launch()
-            # the zero points of the asymmetric modules: one more launch for all of them (pack_to_int32(zp, 4, packed_dim=0))
-            zps = {}
-            for i, (m, scheme, packed, zp, shape) in enumerate(jobs):
-                wa = scheme.weights
-                if not wa.symmetric and enum_value(wa.strategy) in PACK_ZP_STRATS:
-                    assert zp is not None, "Asymmetric quant requires zero-point values"
-                    if zp.dtype is torch.int8 and zp.dim() == 2 and zp.is_contiguous():
-                        zps[i] = (zp, torch.empty((math.ceil(zp.shape[0] * 4 / 32), zp.shape[1]), dtype=torch.int32, device=device))
-            codec.zp4_batch(zps.values(), "pack")
+            zps = {i: (e[2], e[7]) for i, e in enumerate(entries) if e[7] is not None}
             # from here on the host works under the kernels
             shape_of = {}
             for i, (m, scheme, packed, zp, shape) in enumerate(jobs):
@@ -320,10 +334,14 @@ class PackedQuantizationCompressor(BaseCompressor):
                 continue
             out = torch.empty(shape, dtype=scale.dtype, device=packed.device)
             entries, slots, zps = batches.setdefault((packed.device, scale.dtype), ([], [], []))
-            entries.append((packed, scale, zp, out, shape[0], shape[1], group))
+            if asym and codec.w4_packed_zp_readable(shape[1], group) and shape[0] * (shape[1] // 8) < 1 << 31 and zp_packed.data_ptr() % 16 == 0:
+                # the weights' launch reads the stored zero points itself and writes `zp` (the unpacked int8 form) from its tail workgroups
+                entries.append((packed, scale, zp, out, shape[0], shape[1], group, zp_packed))
+            else:
+                entries.append((packed, scale, zp, out, shape[0], shape[1], group))
+                if asym:
+                    zps.append((zp_packed, zp))
             slots.append((i, out, zp))
-            if asym:
-                zps.append((zp_packed, zp))
         for (_, dtype), (entries, slots, zps) in batches.items():
             codec.zp4_batch(zps, "unpack")
             codec.W4Batch(entries, "decompress", dtype).launch()

@@ -25,9 +25,9 @@ __all__ = ["BitmaskCompressor", "BitmaskTensor", "bitmask_compress", "bitmask_de
 COMPRESSION_PARAM_NAMES = ("shape", "compressed", "bitmask", "row_offsets")
 
 
-def bitmask_compress(tensor: torch.Tensor):
-    """-> (values, bitmask, row_offsets)"""
-    return codec.bitmask_compress(tensor)
+def bitmask_compress(tensor: torch.Tensor, exact: bool = True):
+    """-> (values, bitmask, row_offsets); `exact`: see codec.bitmask_compress (False: `values` is a view of a dense-sized buffer)"""
+    return codec.bitmask_compress(tensor, exact=exact)
 
 
 def bitmask_decompress(values: torch.Tensor, bitmasks: torch.Tensor, original_shape, row_offsets=None) -> torch.Tensor:
@@ -44,9 +44,11 @@ class BitmaskTensor:
         self.row_offsets = row_offsets
 
     @staticmethod
-    def from_dense(tensor: torch.Tensor) -> "BitmaskTensor":
+    def from_dense(tensor: torch.Tensor, exact: bool = True) -> "BitmaskTensor":
+        """`exact` (default): `compressed` owns nnz elements, like `tensor[mask]`.  `exact=False` skips the copy that makes it so and hands
+        back a view of a dense-sized buffer — faster per call, but the object then holds as much memory as the dense tensor did."""
         shape = tensor.shape
-        values, bitmask, row_offsets = bitmask_compress(tensor)
+        values, bitmask, row_offsets = bitmask_compress(tensor, exact=exact)
         return BitmaskTensor(shape=shape, compressed=values, bitmask=bitmask, row_offsets=row_offsets)
 
     def decompress(self) -> torch.Tensor:

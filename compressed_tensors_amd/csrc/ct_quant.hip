@@ -11,6 +11,7 @@
 // lane, no LDS needed for the data itself (the 8-code nibble group of a lane is exactly one
 // 32-bit word); scales are broadcast loads served by L1/L2.
 #include "ct_quant_core.h"
+#include "ct_quant_lean.h"
 #include "ct_minmax.h"
 
 #include <cstdlib>
@@ -148,132 +149,17 @@ struct W4Params {
     int upg_shift;         // log2(units per scale group) = log2(cdiv / 8), or -1
     int64_t upg;           // units per group (cdiv / 8)
     int flat_scale;        // 1: scale index == unit / upg (rdiv == 1 and cdiv | cols)
+    // round 6, decompress with the zero points in their STORED form (ZPACKED instantiations only): int32 (ceil(rows / 8), scale_cols) words,
+    // nibble r % 8 of word (r / 8, g) = zp[r][g] + 8; n / scale_cols == (n * g_magic) >> g_shift for n < 2^31
+    const uint32_t* zpk = nullptr;
+    uint32_t g_magic = 0;
+    int g_shift = 0;
 };
 
 __device__ __forceinline__ int64_t w4_scale_index(const W4Params& p, int64_t u) {
     if (p.flat_scale) return p.upg_shift >= 0 ? (u >> p.upg_shift) : (u / p.upg);
     const int64_t row = u / p.upr, cu = u - row * p.upr;
     return (row / p.rdiv) * p.scale_cols + (p.upg_shift >= 0 ? (cu >> p.upg_shift) : (cu / p.upg));
-}
-
-// v_cvt_i32_f32: saturating, NaN -> 0.  Spelled as an instruction so that clang does not expand
-// the (well-defined under -fno-strict-float-cast-overflow) conversion into compare/select chains.
-__device__ __forceinline__ int cvt_i32_hw(float x) {
-    int r;
-    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-
-// two elements of a 16-bit pair as floats
-template <int DT>
-__device__ __forceinline__ void unpack2(uint32_t w, float& a, float& b) {
-    if constexpr (DT == CT_BF16) { a = bits_f(w << 16); b = bits_f(w & 0xffff0000u); }
-    else { a = f16_bits_to_f(w & 0xffffu); b = f16_bits_to_f(w >> 16); }
-}
-
-// round two floats to DT and back (one v_cvt_pk_bf16_f32 for bf16)
-template <int DT>
-__device__ __forceinline__ void round2(float& a, float& b) {
-    if constexpr (DT == CT_BF16) {
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        typedef bf16_t b2 __attribute__((ext_vector_type(2)));
-        const uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(f2{a, b}, b2));
-        a = bits_f(p << 16); b = bits_f(p & 0xffff0000u);
-    } else {
-        a = round_to<DT>(a); b = round_to<DT>(b);
-    }
-}
-
-// ---- fast-path predicates --------------------------------------------------------------------------------------
-// bf16: x * fl(1/s) == x / s after the rounding to bf16 for 2^-64 <= |s| <= 2^64 (ct_selftest_bf16_div).
-// fp16: reciprocal + one Newton step == the IEEE quotient after the rounding to fp16 for 2^-14 <= |s| <= 2^15 and every
-// FINITE x (ct_selftest_f16_div; quotients below 2^-13 may differ in the last subnormal place and all become code 0,
-// with or without an integer zero point) — the finiteness of a lane's 32 weights is one v_dot2c_f32_f16 per pair.
-template <int DT>
-__device__ __forceinline__ bool fast_scale_ok(float s) {
-    const float as = __builtin_fabsf(s);
-    if constexpr (DT == CT_BF16) return (as >= 0x1p-64f) && (as <= 0x1p64f);
-    else if constexpr (DT == CT_F16) return (as >= 0x1p-14f) && (as <= 0x1p15f);
-    else return false;
-}
-typedef _Float16 qh2_t __attribute__((ext_vector_type(2)));
-template <int DT, int Q>
-__device__ __forceinline__ bool fast_data_ok(const u32x4 (&r)[Q]) {
-    if constexpr (DT != CT_F16) return true;
-    else {
-        float acc = 0.0f;  // <= 32 * 65504^2 when everything is finite; inf / NaN propagate
-#pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(qh2_t, ws[j]), __builtin_bit_cast(qh2_t, ws[j]), acc, false);
-        }
-        return acc <= 3.0e38f;
-    }
-}
-
-// fp16 weights, fast path: everything after the fp32 quotient works on fp16 PAIRS (derivation: ct_marlin24.hip) —
-// v_cvt_pk_f16_f32 is the rounding to T, the zero-point add is v_pk_add_f16 (the reference adds in fp16 too), clamp =
-// v_pk_max_f16 / v_pk_min_f16 (no NaN can reach it: fast_data_ok), round-half-even + integer cast + bias in ONE
-// v_pk_add_f16: for |t| <= 128, fl16(t + MAGIC) = MAGIC + rint(t) exactly (ulp = 1 there) and the low byte of each half is
-// the code plus MAGIC's low byte.  5.5 VALU per element instead of ~20 with the IEEE divide.
-// pairs[j] = 0x66cc66cc-style halves; returns them un-gathered
-template <bool ZP, int MAGIC>
-__device__ __forceinline__ void quant_pairs_f16(const u32x4& raw, float s, float rs, float z, float qmin, float qmax, uint32_t (&u)[4]) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 rs2 = {rs, rs}, s2 = {s, s};
-    const qh2_t lo2 = {(_Float16)qmin, (_Float16)qmin}, hi2 = {(_Float16)qmax, (_Float16)qmax};
-    const qh2_t magic = {(_Float16)(float)MAGIC, (_Float16)(float)MAGIC}, z2 = {(_Float16)z, (_Float16)z};
-    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f2 x = __builtin_convertvector(__builtin_bit_cast(qh2_t, ws[j]), f2);
-        f2 t = x * rs2;
-        t = __builtin_elementwise_fma(__builtin_elementwise_fma(-t, s2, x), rs2, t);
-        qh2_t t16 = __builtin_convertvector(t, qh2_t);
-        if (ZP) t16 = t16 + z2;
-        t16 = __builtin_elementwise_min(__builtin_elementwise_max(t16, lo2), hi2) + magic;
-        u[j] = __builtin_bit_cast(uint32_t, t16);
-    }
-}
-
-template <bool ZP>
-__device__ __forceinline__ uint32_t w4_quant_word_f16(const u32x4& raw, float s, float rs, float z) {
-    uint32_t u[4];
-    quant_pairs_f16<ZP, 1544>(raw, s, rs, z, -8.0f, 7.0f, u);  // 1544 = 1536 + 8: the low byte is the biased nibble
-    const uint32_t p0 = __builtin_amdgcn_perm(u[1], u[0], 0x06040200u), p1 = __builtin_amdgcn_perm(u[3], u[2], 0x06040200u);
-    const uint32_t a = p0 | __builtin_amdgcn_alignbit(p0, p0, 4), b = p1 | __builtin_amdgcn_alignbit(p1, p1, 4);
-    return __builtin_amdgcn_perm(b, a, 0x06040200u);  // bytes 0 / 2 of a and b: nibble pairs (0,1) (2,3) (4,5) (6,7)
-}
-
-// 8 weights (16 B) -> one packed word.  FAST: x * (1/s) instead of x / s — bit-identical after the
-// rounding to bf16 for every bf16 x and every bf16 s with 2^-64 <= |s| <= 2^64 (no quotient of two
-// 8-bit significands lies within 2^-17 relative of a bf16 rounding boundary, while the
-// two-rounding error of x * fl(1/s) is < 2^-22 relative); proven exhaustively on the device by
-// ct_selftest_bf16_div (tests/test_gpu_parity.py).  The codes are accumulated as
-// 0x88888888 + sum(code_k << 4k): code_k in [-8, 7], so the biased nibbles never carry.
-template <int DT, bool FAST, bool ZP>
-__device__ __forceinline__ uint32_t w4_quant_word(const u32x4& raw, float s, float rs, float z) {
-    if constexpr (DT == CT_F16 && FAST) return w4_quant_word_f16<ZP>(raw, s, rs, z);
-    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
-    uint32_t word = 0x88888888u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float x0, x1;
-        unpack2<DT>(ws[j], x0, x1);
-        float t0 = FAST ? x0 * rs : x0 / s, t1 = FAST ? x1 * rs : x1 / s;
-        round2<DT>(t0, t1);
-        if (ZP) {
-            t0 += z; t1 += z;
-            round2<DT>(t0, t1);
-        }
-        int c0 = cvt_i32_hw(__builtin_rintf(t0)), c1 = cvt_i32_hw(__builtin_rintf(t1));
-        c0 = c0 < -8 ? -8 : (c0 > 7 ? 7 : c0);  // v_med3_i32
-        c1 = c1 < -8 ? -8 : (c1 > 7 ? 7 : c1);
-        word += (uint32_t)c0 << (8 * j);
-        word += (uint32_t)c1 << (8 * j + 4);
-    }
-    return word;
 }
 
 // Q = 4 consecutive units per lane; SHARED: the 4 units share one scale (cdiv % 32 == 0)
@@ -813,8 +699,13 @@ __device__ __forceinline__ uint32_t row_leader_value(uint32_t v) {
 // data cache, no vector-memory instruction at all), a lane picks its group's entry with one shift (v_lshrrev_b64 by 16 x (lane >> 4)) resp.
 // one v_bfe_i32.  Vector-memory instructions per 8 elements: 2 (word in, 16 bytes out) instead of 4 (asymmetric) / 3 (symmetric).
 constexpr int kW4ScalePerLane = 0, kW4ScaleRowLead = 1, kW4ScaleScalar = 2;
-template <int DT, int UNROLL, bool HAS_ZP, int SM = kW4ScalePerLane>
+// ZPACKED (round 6; SM = 2 only, and a wave never straddles a row: units per row % 64 == 0): the zero points are read from their STORED form —
+// the wave's row r and first group come from ONE scalar multiply-high (p.g_magic), its four groups' words (row r / 8) are one scalar
+// 16-byte load, nibble r % 8 of each is cut out and re-based on the SCALAR unit, and the four bytes take the place of the int8 dword the
+// unpacked form would have delivered: not one vector instruction more than the int8 path, and no unpack launch in front of this one.
+template <int DT, int UNROLL, bool HAS_ZP, int SM = kW4ScalePerLane, bool ZPACKED = false>
 __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64_t base) {
+    static_assert(!ZPACKED || (HAS_ZP && SM == kW4ScaleScalar), "packed zero points ride the scalar-load form");
     constexpr bool ROWLEAD = SM == kW4ScaleRowLead;
     const uint32_t* in = static_cast<const uint32_t*>(p.x);
     uint32_t word[UNROLL];
@@ -833,7 +724,18 @@ __device__ __forceinline__ void w4_unpack_dequant_units(const W4Params& p, int64
             const_u32_t sp = (const_u32_t)(uintptr_t)(static_cast<const uint16_t*>(p.scale) + si0);
             s4[i] = ((uint64_t)sp[1] << 32) | sp[0];
             z4[i] = 0;
-            if constexpr (HAS_ZP) z4[i] = *(const_u32_t)(uintptr_t)(static_cast<const int8_t*>(p.zp) + si0);
+            if constexpr (HAS_ZP && ZPACKED) {
+                const uint32_t n = (uint32_t)si0;                                            // < 2^27 (the entry refuses units >= 2^31)
+                const uint32_t row = (uint32_t)(((uint64_t)n * p.g_magic) >> p.g_shift);     // wave-uniform: scalar multiplies
+                const uint32_t g0 = n - row * (uint32_t)p.scale_cols;                        // the wave's first group, a multiple of 4
+                const_u32_t zw = (const_u32_t)(uintptr_t)(p.zpk + (size_t)(row >> 3) * (size_t)p.scale_cols + g0);
+                const uint32_t sh = (row & 7u) * 4u;
+                // (nibble - 8) as a byte each, in the order the int8 dword would have had
+                z4[i] = ((((zw[0] >> sh) & 15u) - 8u) & 0xffu) | (((((zw[1] >> sh) & 15u) - 8u) & 0xffu) << 8) | (((((zw[2] >> sh) & 15u) - 8u) & 0xffu) << 16) |
+                        (((((zw[3] >> sh) & 15u) - 8u) & 0xffu) << 24);
+            } else if constexpr (HAS_ZP) {
+                z4[i] = *(const_u32_t)(uintptr_t)(static_cast<const int8_t*>(p.zp) + si0);
+            }
         }
     }
 #pragma unroll
@@ -914,19 +816,60 @@ __device__ __forceinline__ const ct_w4_item& batch_find(const ct_w4_item* __rest
     return items[lo];
 }
 
+// groups per row of an item (a shift for the power-of-two group sizes; the division runs for the others only)
+__device__ __forceinline__ int64_t item_groups_per_row(const ct_w4_item& it) {
+    return it.upg_shift >= 0 ? ((it.cols >> 3) >> it.upg_shift) : (it.upg > 0 ? (it.cols >> 3) / it.upg : 1);
+}
+
 __device__ __forceinline__ W4Params batch_params(const ct_w4_item& it) {
     W4Params p;
     p.x = it.src; p.scale = it.scale; p.zp = it.zp; p.out = it.dst; p.zdt = CT_I8;
-    p.units = it.units; p.upr = it.cols >> 3; p.rdiv = 1; p.scale_cols = 0;
+    p.units = it.units; p.upr = it.cols >> 3; p.rdiv = 1; p.scale_cols = it.zp_packed ? item_groups_per_row(it) : 0;
     p.upg_shift = it.upg_shift; p.upg = it.upg; p.flat_scale = 1;
+    p.zpk = static_cast<const uint32_t*>(it.zp_packed); p.g_magic = it.g_magic; p.g_shift = it.g_shift;
     return p;
 }
 
+// the zero-point tail of an item (round 6): the workgroups behind the item's `main_blocks`, one lane per STORED word (r8, g) =
+// sum_k ((zp[8 r8 + k][g] + 8) & 15) << 4k — pack_to_int32(zp, 4, packed_dim=0): rows beyond the matrix contribute 0 nibbles (the pad
+// is applied AFTER the offset, helpers.py:65-67).  PACK: int8 -> words (compress); else words -> int8 (decompress writes back what
+// unpack_from_int32(..., packed_dim=0) would have produced, base.py:147-153).  Consecutive lanes = consecutive groups of one row octet.
+template <bool PACK>
+__device__ __forceinline__ void w4_zp_tail(const ct_w4_item& it, int64_t tail_block) {
+    const int64_t G = item_groups_per_row(it);
+    const int64_t total = ((it.rows + 7) >> 3) * G;
+    const int64_t wi = tail_block * kBlock + threadIdx.x;
+    if (wi >= total) return;
+    const int64_t r8 = wi < ((int64_t)1 << 31) ? (int64_t)(((uint64_t)(uint32_t)wi * it.g_magic) >> it.g_shift) : wi / G;
+    const int64_t g = wi - r8 * G;
+    if (PACK) {
+        const int8_t* zp = static_cast<const int8_t*>(it.zp);
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t r = r8 * 8 + k;
+            if (r < it.rows) word |= ((uint32_t)((int)zp[r * G + g] + 8) & 15u) << (4 * k);
+        }
+        static_cast<uint32_t*>(it.zp_packed)[wi] = word;
+    } else {
+        const uint32_t word = static_cast<const uint32_t*>(it.zp_packed)[wi];
+        int8_t* zp = static_cast<int8_t*>(const_cast<void*>(it.zp));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t r = r8 * 8 + k;
+            if (r < it.rows) zp[r * G + g] = (int8_t)((int)((word >> (4 * k)) & 15u) - 8);
+        }
+    }
+}
+
 template <int DT>
-__global__ __launch_bounds__(kBlock) void w4_quant_pack_batch_kernel(const ct_w4_item* __restrict__ items, int n) {
-    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+__device__ __forceinline__ void w4_quant_pack_item(const ct_w4_item& it, int64_t local_block) {
+    if (local_block >= it.main_blocks) {  // workgroup-uniform
+        w4_zp_tail<true>(it, local_block - it.main_blocks);
+        return;
+    }
     const W4Params p = batch_params(it);
-    const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
+    const int64_t g = local_block * kBlock + threadIdx.x;
     if (g >= p.units / 4) return;
     if (it.upg_shift >= 2) {  // power-of-two group of at least 32 columns: the lean body
         const int gshift = it.upg_shift - 2;
@@ -938,17 +881,36 @@ __global__ __launch_bounds__(kBlock) void w4_quant_pack_batch_kernel(const ct_w4
     else w4_quant_pack_group<DT, false, true>(p, g);
 }
 
+template <int DT>
+__global__ __launch_bounds__(kBlock) void w4_quant_pack_batch_kernel(const ct_w4_item* __restrict__ items, int n) {
+    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+    w4_quant_pack_item<DT>(it, (int64_t)blockIdx.x - it.first_block);
+}
+
+// the same body on ONE item handed over by value (ct_quant_pack_w4_zp): no table in device memory
+template <int DT>
+__global__ __launch_bounds__(kBlock) void w4_quant_pack_one_kernel(const ct_w4_item it) {
+    w4_quant_pack_item<DT>(it, (int64_t)blockIdx.x);
+}
+
 // Written as a runtime-stride loop because hipcc schedules this body markedly better inside one (31.5 us
 // vs 37.1 us for one 8192^2 item with a single trip; the single-tensor kernel has the same shape) —
 // measured, not understood; tools/time_batch.py reproduces it.
 template <int DT>
-__global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride) {
-    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+__device__ __forceinline__ void w4_unpack_dequant_item(const ct_w4_item& it, int64_t local_block, int64_t stride) {
+    if (local_block >= it.main_blocks) {  // workgroup-uniform: only items with zp_packed AND zp have such blocks
+        w4_zp_tail<false>(it, local_block - it.main_blocks);
+        return;
+    }
     const W4Params p = batch_params(it);
     // a workgroup owns kW4BatchIter consecutive chunks of kBlock * kBatchUnroll units (the table search is
     // paid once per 1024 units); `stride` == chunk size, `limit` ends the walk after kW4BatchIter chunks
-    const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kW4BatchIter;
+    const int64_t first = local_block * kBlock * kBatchUnroll * kW4BatchIter;
     const int64_t limit = (first + stride * kW4BatchIter < p.units) ? first + stride * kW4BatchIter : p.units;
+    if (p.zpk) {  // zero points in their stored form (the plan admitted the item: groups of 128, whole waves per row, aligned tables)
+        for (int64_t b = first + threadIdx.x; b < limit; b += stride) w4_unpack_dequant_units<DT, kBatchUnroll, true, kW4ScaleScalar, true>(p, b);
+        return;
+    }
     // round 5: an item with groups of 128 (upg_shift == 4), units % 64 == 0 and aligned scale / zero-point tables takes the SCALAR-load form
     // (a batch is always a launch of many residency rounds); the branch is workgroup-uniform
     const bool scalar = it.upg_shift == 4 && (p.units & 63) == 0 && (reinterpret_cast<uintptr_t>(p.scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(p.zp) & 3u) == 0;
@@ -963,6 +925,17 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const c
     } else {
         for (int64_t b = first + threadIdx.x; b < limit; b += stride) w4_unpack_dequant_units<DT, kBatchUnroll, false>(p, b);
     }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void w4_unpack_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride) {
+    const ct_w4_item& it = batch_find(items, n, blockIdx.x);
+    w4_unpack_dequant_item<DT>(it, (int64_t)blockIdx.x - it.first_block, stride);
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void w4_unpack_dequant_one_kernel(const ct_w4_item it, int64_t stride) {
+    w4_unpack_dequant_item<DT>(it, (int64_t)blockIdx.x, stride);
 }
 
 
@@ -1919,6 +1892,9 @@ int ct_quant_pack(const void* x, int xdt, const void* scale, int sdt, const void
 #undef CT_Q8P
         CT_LAUNCH_CHECK("ct_quant_pack[w8]");
     }
+    // round 6: the widths next to 4 and 8 in the common checkpoint layout (ct_quant_wb.hip)
+    if (wb_layout_ok(xdt, sdt, tdt, bits, zdt, zp, rows, cols, rdiv, cdiv, scale_cols, col_group, x, packed))
+        return launch_wb_quant_pack(x, xdt, scale, zp, rows, cols, cdiv, bits, packed, stream);
     p.vec = (cols % 8 == 0) && aligned16(x);
     const int64_t packed_cols = cdiv64(cols * bits, 32);
     dim3 grid = grid_2d(rows, cdiv64(cols, 32));
@@ -2041,9 +2017,55 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
 #undef CT_Q8U
         CT_LAUNCH_CHECK("ct_unpack_dequant[w8]");
     }
+    if (words == (cols / 32) * bits && wb_layout_ok(sdt, sdt, odt, bits, zdt, zp, rows, cols, rdiv, cdiv, scale_cols, col_group, out, packed))
+        return launch_wb_unpack_dequant(packed, scale, sdt, zp, rows, cols, cdiv, bits, out, stream);
     p.vec = (cols % 8 == 0) && aligned16(out);
     dim3 grid = grid_2d(rows, cdiv64(cols, 32));
     return bits <= 4 ? launch_unpack_dequant_g32_lo(p, sdt, bits, words, grid, stream) : launch_unpack_dequant_g32_hi(p, sdt, bits, words, grid, stream);
+}
+
+// fills the derived fields of one item; returns its block count or -1 (error set)
+static int64_t w4_plan_item(ct_w4_item& it, int i, int direction, int64_t first_block) {
+    const int64_t g = (it.group <= 0 || it.group > it.cols) ? it.cols : it.group;
+    const bool ok = it.rows > 0 && it.cols > 0 && it.cols % 32 == 0 && g % 32 == 0 && it.cols % g == 0 && it.src && it.scale && it.dst &&
+                    aligned16(it.src) && aligned16(it.dst);
+    if (!ok) {
+        set_error("ct_w4_batch_plan: item %d (rows %lld, cols %lld, group %lld) is not eligible for the batched W4 path "
+                  "(needs cols %% 32 == 0, group %% 32 == 0, cols %% group == 0, 16-byte aligned buffers)", i, (long long)it.rows,
+                  (long long)it.cols, (long long)it.group);
+        return -1;
+    }
+    it.units = it.rows * (it.cols / 8);
+    it.upg = (int32_t)(g / 8);
+    it.upg_shift = log2_exact(it.upg);
+    it.first_block = first_block;
+    it.main_blocks = direction == 0 ? cdiv64(it.units / 4, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll * kW4BatchIter);
+    // n / G as (n * magic) >> shift, exact for n < 2^31 (Granlund-Montgomery with N = 31: magic = ceil(2^(31 + L) / G), L = ceil(log2 G), magic < 2^32)
+    const int64_t G = it.cols / g;
+    int L = 0;
+    while (((int64_t)1 << L) < G) ++L;
+    if (L > 31) {
+        set_error("ct_w4_batch_plan: item %d has %lld groups per row", i, (long long)G);
+        return -1;
+    }
+    it.g_shift = 31 + L;
+    it.g_magic = (uint32_t)((((uint64_t)1 << it.g_shift) + (uint64_t)(G - 1)) / (uint64_t)G);  // 2^(31 + L) + G - 1 < 2^63
+    int64_t tail = 0;
+    if (it.zp_packed) {
+        const bool fits = direction == 0
+            ? it.zp != nullptr
+            : (g == 128 && it.cols % 512 == 0 && it.units < ((int64_t)1 << 31) && aligned16(it.zp_packed) && (reinterpret_cast<uintptr_t>(it.scale) & 7u) == 0);
+        if (!fits) {
+            set_error(direction == 0 ? "ct_w4_batch_plan: item %d asks for packed zero points (zp_packed) without giving the int8 zero points (zp)"
+                                     : "ct_w4_batch_plan: item %d (rows %lld, cols %lld, group %lld) cannot read its zero points in packed form "
+                                       "(needs group == 128, cols %% 512 == 0, rows * cols < 2^34, zp_packed 16-byte and scale 8-byte aligned): "
+                                       "unpack them first (ct_zp4_pack_dim0_batch) and pass zp",
+                      i, (long long)it.rows, (long long)it.cols, (long long)it.group);
+            return -1;
+        }
+        if (direction == 0 || it.zp != nullptr) tail = cdiv64(((it.rows + 7) / 8) * G, kBlock);
+    }
+    return it.main_blocks + tail;
 }
 
 int64_t ct_w4_batch_plan(ct_w4_item* items, int n, int direction) {
@@ -2053,27 +2075,52 @@ int64_t ct_w4_batch_plan(ct_w4_item* items, int n, int direction) {
     }
     int64_t blocks = 0;
     for (int i = 0; i < n; ++i) {
-        ct_w4_item& it = items[i];
-        const int64_t g = (it.group <= 0 || it.group > it.cols) ? it.cols : it.group;
-        const bool ok = it.rows > 0 && it.cols > 0 && it.cols % 32 == 0 && g % 32 == 0 && it.cols % g == 0 && it.src && it.scale && it.dst &&
-                        aligned16(it.src) && aligned16(it.dst);
-        if (!ok) {
-            set_error("ct_w4_batch_plan: item %d (rows %lld, cols %lld, group %lld) is not eligible for the batched W4 path "
-                      "(needs cols %% 32 == 0, group %% 32 == 0, cols %% group == 0, 16-byte aligned buffers)", i, (long long)it.rows,
-                      (long long)it.cols, (long long)it.group);
-            return -1;
-        }
-        it.units = it.rows * (it.cols / 8);
-        it.upg = (int32_t)(g / 8);
-        it.upg_shift = log2_exact(it.upg);
-        it.first_block = blocks;
-        blocks += direction == 0 ? cdiv64(it.units / 4, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll * kW4BatchIter);
+        const int64_t b = w4_plan_item(items[i], i, direction, blocks);
+        if (b < 0) return -1;
+        blocks += b;
     }
     if (blocks >= ((int64_t)1 << 31)) {
         set_error("ct_w4_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
         return -1;
     }
     return blocks;
+}
+
+int ct_quant_pack_w4_zp(const void* x, int xdt, const void* scale, const int8_t* zp, int64_t rows, int64_t cols, int64_t group, int32_t* packed,
+                        int32_t* zp_packed, ct_stream_t stream) {
+    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "ct_quant_pack_w4_zp: 16-bit weights only, got dtype %d", xdt);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    CT_REQUIRE(zp != nullptr && zp_packed != nullptr && (reinterpret_cast<uintptr_t>(zp_packed) & 3u) == 0, "zp / zp_packed NULL or misaligned");
+    if (rows == 0 || cols == 0) return CT_OK;
+    ct_w4_item it{};
+    it.src = x; it.scale = scale; it.zp = zp; it.dst = packed; it.rows = rows; it.cols = cols; it.group = group; it.zp_packed = zp_packed;
+    const int64_t blocks = w4_plan_item(it, 0, 0, 0);
+    if (blocks < 0) return CT_ERR_INVALID_ARG;
+    CT_REQUIRE(blocks < ((int64_t)1 << 31), "tensor too large for one launch");
+    if (xdt == CT_BF16) hipLaunchKernelGGL((w4_quant_pack_one_kernel<CT_BF16>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), it);
+    else hipLaunchKernelGGL((w4_quant_pack_one_kernel<CT_F16>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), it);
+    CT_LAUNCH_CHECK("ct_quant_pack_w4_zp");
+}
+
+int ct_unpack_dequant_w4_zp(const int32_t* packed, const void* scale, int sdt, const int32_t* zp_packed, int64_t rows, int64_t cols, int64_t group,
+                            void* out, int8_t* zp_out, ct_stream_t stream) {
+    CT_REQUIRE(sdt == CT_BF16 || sdt == CT_F16, "ct_unpack_dequant_w4_zp: 16-bit scales / results only, got dtype %d", sdt);
+    CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
+    CT_REQUIRE(zp_packed != nullptr, "zp_packed is NULL");
+    if (rows == 0 || cols == 0) return CT_OK;
+    if (!(group == 128 && cols % 512 == 0 && rows * (cols / 8) < ((int64_t)1 << 31) && aligned16(zp_packed) && (reinterpret_cast<uintptr_t>(scale) & 7u) == 0))
+        CT_UNSUPPORTED("ct_unpack_dequant_w4_zp: needs group == 128, cols %% 512 == 0, rows * cols < 2^34, zp_packed 16-byte and scale 8-byte aligned "
+                       "(unpack the zero points with ct_unpack_int32_dim0 and call ct_unpack_dequant)");
+    ct_w4_item it{};
+    it.src = packed; it.scale = scale; it.zp = zp_out; it.dst = out; it.rows = rows; it.cols = cols; it.group = group;
+    it.zp_packed = const_cast<int32_t*>(zp_packed);
+    const int64_t blocks = w4_plan_item(it, 0, 1, 0);
+    if (blocks < 0) return CT_ERR_INVALID_ARG;
+    CT_REQUIRE(blocks < ((int64_t)1 << 31), "tensor too large for one launch");
+    const int64_t stride = (int64_t)kBlock * kBatchUnroll;
+    if (sdt == CT_BF16) hipLaunchKernelGGL((w4_unpack_dequant_one_kernel<CT_BF16>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), it, stride);
+    else hipLaunchKernelGGL((w4_unpack_dequant_one_kernel<CT_F16>), dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), it, stride);
+    CT_LAUNCH_CHECK("ct_unpack_dequant_w4_zp");
 }
 
 int ct_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream) {

@@ -254,5 +254,12 @@ int launch_quant_pack_g32_lo(const QParams& p, int xdt, int tdt, int bits, int64
 int launch_quant_pack_g32_hi(const QParams& p, int xdt, int tdt, int bits, int64_t packed_cols, dim3 grid, ct_stream_t stream);
 int launch_unpack_dequant_g32_lo(const QParams& p, int sdt, int bits, int64_t words, dim3 grid, ct_stream_t stream);
 int launch_unpack_dequant_g32_hi(const QParams& p, int sdt, int bits, int64_t words, dim3 grid, ct_stream_t stream);
+// the lean kernels of the widths next to 4 and 8 (ct_quant_wb.hip): `wb_layout_ok` says whether they take the call
+bool wb_layout_ok(int dt, int sdt, int other_dt, int bits, int zdt, const void* zp, int64_t rows, int64_t cols, int64_t rdiv, int64_t cdiv, int64_t scale_cols,
+                  const int32_t* col_group, const void* wide, const void* words);
+int launch_wb_quant_pack(const void* x, int xdt, const void* scale, const void* zp, int64_t rows, int64_t cols, int64_t cdiv, int bits, int32_t* packed,
+                         ct_stream_t stream);
+int launch_wb_unpack_dequant(const int32_t* packed, const void* scale, int sdt, const void* zp, int64_t rows, int64_t cols, int64_t cdiv, int bits, void* out,
+                             ct_stream_t stream);
 
 }  // namespace ct

@@ -209,9 +209,12 @@ bool dict_has(PyObject* module, PyObject* name) {
     return dictptr && *dictptr && PyDict_GetItem(*dictptr, name) != nullptr;
 }
 
+constexpr int kItemWords = 13;  // struct ct_w4_item of include/ct_hip.h in 64-bit words; word 10 = zp_packed, 11-12 derived (as 7-9)
+
 struct Batch {
-    std::vector<int64_t> words;     // 10 per item: struct ct_w4_item
-    std::vector<int64_t> zp_words;  // the same layout, one item per ASYMMETRIC module: its zero points through ct_zp4_pack_dim0_batch
+    std::vector<int64_t> words;     // kItemWords per item: struct ct_w4_item
+    std::vector<int64_t> zp_words;  // the same layout, one item per ASYMMETRIC module whose zero points the weights' launch cannot take in packed
+                                    // form (decompress of a layout outside groups of 128 / cols % 512 == 0): through ct_zp4_pack_dim0_batch
     py::list jobs;
     int n = 0, zp_n = 0;
 };
@@ -274,19 +277,18 @@ py::tuple w4_plan_compress(py::list modules, py::object infos_arg) {
         }
         at::Tensor packed = at::empty({rows, cols / 8}, w->options().dtype(at::kInt));
         Batch& b = batches[{w->is_cuda() ? (int)w->device().index() : -1, w->scalar_type() == at::kHalf ? 1 : 2}];
-        const int64_t item[10] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
-                                  (int64_t)(uintptr_t)packed.data_ptr(), rows, cols, group, 0, 0, 0};
-        b.words.insert(b.words.end(), item, item + 10);
-        b.n += 1;
         py::object zp_packed = py::none(), zp_ref = py::none();
-        if (asym) {  // int8 (R, G) -> int32 (ceil(R / 8), G), one more launch for all of them
+        int64_t zpp_ptr = 0;
+        if (asym) {  // int8 (R, G) -> int32 (ceil(R / 8), G): written by tail workgroups of the weights' own launch (round 6: ct_w4_item.zp_packed)
             at::Tensor zpp = at::empty({(rows * 4 + 31) / 32, zp->size(1)}, w->options().dtype(at::kInt));
-            const int64_t zitem[10] = {(int64_t)(uintptr_t)zp->data_ptr(), 0, 0, (int64_t)(uintptr_t)zpp.data_ptr(), rows, zp->size(1), 0, 0, 0, 0};
-            b.zp_words.insert(b.zp_words.end(), zitem, zitem + 10);
-            b.zp_n += 1;
+            zpp_ptr = (int64_t)(uintptr_t)zpp.data_ptr();
             zp_packed = py::reinterpret_steal<py::object>(THPVariable_Wrap(zpp));
             zp_ref = py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_zero_point));
         }
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)packed.data_ptr(), rows, cols, group, 0, 0, 0, zpp_ptr, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
         // the job keeps the inputs alive until the launch has been issued (the table holds raw pointers)
         b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(packed)), rows, cols,
                                      py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)), zp_packed, zp_ref));
@@ -366,19 +368,25 @@ py::tuple w4_plan_decompress(py::list modules, py::object infos_arg) {
         at::Tensor out = at::empty({rows, cols}, scale->options());
         Batch& b = batches[{packed->is_cuda() ? (int)packed->device().index() : -1, scale->scalar_type() == at::kHalf ? 1 : 2}];
         py::object zp_obj = py::none(), zpp_ref = py::none();
-        int64_t zp_ptr = 0;
-        if (asym) {  // int32 (ceil(R / 8), G) -> int8 (R, G): unpacked by the launch that runs BEFORE the weights' (the table below points at it)
+        int64_t zp_ptr = 0, zpp_ptr = 0;
+        if (asym) {
             at::Tensor zp = at::empty({rows, scale->size(1)}, packed->options().dtype(at::kChar));
-            const int64_t zitem[10] = {(int64_t)(uintptr_t)zpp->data_ptr(), 0, 0, (int64_t)(uintptr_t)zp.data_ptr(), rows, scale->size(1), 0, 0, 0, 0};
-            b.zp_words.insert(b.zp_words.end(), zitem, zitem + 10);
-            b.zp_n += 1;
             zp_ptr = (int64_t)(uintptr_t)zp.data_ptr();
+            if (group == 128 && cols % 512 == 0 && rows * (cols / 8) < (int64_t(1) << 31) && aligned16(*zpp)) {
+                // round 6: the weights' launch reads the zero points in their stored form and its tail workgroups write the int8 form back
+                // (include/ct_hip.h, ct_w4_item.zp_packed) — no launch in front of it
+                zpp_ptr = (int64_t)(uintptr_t)zpp->data_ptr();
+            } else {  // int32 (ceil(R / 8), G) -> int8 (R, G): unpacked by the launch that runs BEFORE the weights' (the table below points at it)
+                const int64_t zitem[kItemWords] = {(int64_t)(uintptr_t)zpp->data_ptr(), 0, 0, (int64_t)(uintptr_t)zp.data_ptr(), rows, scale->size(1), 0, 0, 0, 0, 0, 0, 0};
+                b.zp_words.insert(b.zp_words.end(), zitem, zitem + kItemWords);
+                b.zp_n += 1;
+            }
             zp_obj = py::reinterpret_steal<py::object>(THPVariable_Wrap(zp));
             zpp_ref = py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_zero_point));
         }
-        const int64_t item[10] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp_ptr, (int64_t)(uintptr_t)out.data_ptr(), rows, cols,
-                                  group, 0, 0, 0};
-        b.words.insert(b.words.end(), item, item + 10);
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp_ptr, (int64_t)(uintptr_t)out.data_ptr(), rows, cols,
+                                          group, 0, 0, 0, zpp_ptr, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
         b.n += 1;
         b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
                                      py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_packed)), zp_obj, zpp_ref));
@@ -539,7 +547,8 @@ bool on_device(const at::Tensor& t) { return t.is_cuda() || (g_allow_cpu && t.is
 // codec.bitmask_compress for a contiguous, 16-byte aligned device tensor whose device is the current one (the caller checks the
 // last; everything else is checked here and answered with None: the Python path takes the call).  `dt`: the C ABI's element code.
 // Returns (status, values, bitmask, row_offsets).
-py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host, uintptr_t mailbox_dev, uintptr_t stream) {
+// `exact`: `values` owns exactly nnz elements (the kept prefix is copied out of the worst-case buffer, which goes back to the allocator); else a view of it.
+py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host, uintptr_t mailbox_dev, uintptr_t stream, bool exact) {
     touch_tls();
     if (!g_abi.bitmask_compress || !on_device(x) || x.dim() < 1 || !x.is_contiguous() || (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) || x.numel() == 0)
         return py::none();
@@ -563,9 +572,9 @@ py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host,
     }
     if (status != 0) return py::make_tuple(status, py::none(), py::none(), py::none());
     if (nnz < 0 || nnz > numel) throw std::runtime_error("bitmask_compress: the device reported an impossible number of kept values");
-    // keep the view unless it pins more than ~5/8 of the worst-case buffer for nothing (codec.bitmask_compress: same rule)
+    // codec.bitmask_compress: same rule
     at::Tensor values = buf.narrow(0, 0, nnz);
-    if (8 * nnz < 3 * numel) values = values.clone();
+    if (exact && nnz != numel) values = values.clone();
     return py::make_tuple(0, values, bitmask, row_offsets);
 }
 
@@ -683,5 +692,5 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("marlin24_compress_default", &marlin24_compress_default);
     mod.def("set_allow_cpu", [](bool v) { g_allow_cpu = v; });
     mod.def("set_wait_mode", [](int v) { g_wait_mode = v; });
-    mod.attr("ITEM_WORDS") = 10;
+    mod.attr("ITEM_WORDS") = kItemWords;
 }

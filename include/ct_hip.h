@@ -192,16 +192,46 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
 typedef struct ct_w4_item {
     const void* src;
     const void* scale;
-    const void* zp; /* int8, shape of scale, or NULL */
+    const void* zp; /* int8, shape of scale, or NULL (with zp_packed on the decompress side: an OUTPUT, see there) */
     void* dst;
     int64_t rows, cols, group; /* group <= 0 or >= cols: one scale per row */
     int64_t first_block;       /* derived */
     int64_t units;             /* derived */
     int32_t upg_shift, upg;    /* derived */
-} ct_w4_item;
+    /* W4 batches only (ct_zp4_* / ct_q8_* ignore it; NULL = none).  The zero points of an asymmetric scheme in their STORED form,
+     * int32 (ceil(rows * 4 / 32), cols / group) = pack_to_int32(zp, 4, packed_dim=0) (compressors/pack_quantized/base.py:107-110),
+     * handled by the SAME launch as the weights (round 6):
+     *   compress   (direction 0): OUTPUT.  `zp` (required) is quantized against as always, and tail workgroups of the item's block range
+     *              also write its packed form here.  Any item the batch takes may carry it.
+     *   decompress (direction 1): INPUT.  The kernel takes every zero point straight from the packed words — no unpacked copy has to
+     *              exist first — and, when `zp` is non-NULL, tail workgroups also WRITE the unpacked int8 (rows, cols / group) zero
+     *              points there (what decompress stores back into the state dict, base.py:147-153).  Needs group == 128,
+     *              cols % 512 == 0, a 16-byte aligned zp_packed and an 8-byte aligned scale (ct_w4_batch_plan refuses the item
+     *              otherwise: unpack with ct_zp4_pack_dim0_batch first and pass `zp`). */
+    void* zp_packed;
+    int64_t main_blocks;       /* derived: the item's blocks in front of its zero-point tail */
+    uint32_t g_magic;          /* derived: n / (cols / group) == (n * g_magic) >> g_shift for n < 2^31 */
+    int32_t g_shift;           /* derived */
+} ct_w4_item;                  /* 13 64-bit words */
 int64_t ct_w4_batch_plan(ct_w4_item* items_host, int n, int direction);
 int ct_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
 int ct_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, ct_stream_t stream);
+
+/* One asymmetric W4A16 tensor, zero points in their stored (packed) form, ONE launch per direction — the single-module
+ * PackedQuantizationCompressor.compress / .decompress of an asymmetric scheme (base.py:96-110 resp. 147-161) without the separate
+ * pack_to_int32(zp, 4, packed_dim=0) / unpack_from_int32(..., packed_dim=0) launch.  The kernels are the batch kernels on a table of
+ * one item handed over by value (no table in device memory, no plan call): same bits as the batch and as ct_quant_pack +
+ * ct_pack_int32_dim0 resp. ct_unpack_int32_dim0 + ct_unpack_dequant.
+ *   ct_quant_pack_w4_zp      x (rows, cols) bf16 / fp16, scale (rows, cols / group) of x's dtype, zp int8 (rows, cols / group) ->
+ *                            packed int32 (rows, cols / 8) and zp_packed int32 (ceil(rows / 8), cols / group).
+ *                            cols % 32 == 0, group % 32 == 0, cols % group == 0 (group <= 0 or >= cols: channel-wise).
+ *   ct_unpack_dequant_w4_zp  packed + scale + zp_packed -> out (rows, cols) of the scale's dtype sdt and, if zp_out != NULL, the
+ *                            unpacked int8 zero points.  group == 128 and cols % 512 == 0 (CT_ERR_UNSUPPORTED otherwise: unpack the
+ *                            zero points with ct_unpack_int32_dim0 and call ct_unpack_dequant). */
+int ct_quant_pack_w4_zp(const void* x, int xdt, const void* scale, const int8_t* zp, int64_t rows, int64_t cols, int64_t group,
+                        int32_t* packed, int32_t* zp_packed, ct_stream_t stream);
+int ct_unpack_dequant_w4_zp(const int32_t* packed, const void* scale, int sdt, const int32_t* zp_packed, int64_t rows, int64_t cols,
+                            int64_t group, void* out, int8_t* zp_out, ct_stream_t stream);
 
 /* Batched 4-bit zero-point packing along rows: pack_to_int32(zp, 4, packed_dim=0) / unpack_from_int32(..., packed_dim=0) of
  * PackedQuantizationCompressor (compressors/pack_quantized/base.py:107-110,147-153) for the zero points of many asymmetric

@@ -187,6 +187,66 @@ def test_compressor_golden_big(golden, cta, dev, case):
         assert digest_matches(dd[k], rec), f"decompressed[{k}] differs from the reference"
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("bits", [1, 2, 3, 5, 6, 7])
+def test_lean_kernels_of_the_other_bit_widths_vs_oracle(cta, dev, bits, dtype):
+    """Round 6 (VERDICT r05 missing #3): the widths next to 4 and 8 (helpers.py:39-42 allows 1..8; the reference's own
+    test_pack_quant.py:143-146 parametrises them) in the common checkpoint layout take the lean kernels of ct_quant_wb.hip — one pack group
+    per lane on the compress side, one 8-element unit per lane with a wave-wide word exchange on the decompress side.  Packed words and
+    decompressed weights bit for bit against the CPU oracle: symmetric and asymmetric, groups of 32 / 64 / 128 / 96 (not a power of two) /
+    the whole row, unit counts that are not a multiple of 64 (partial wave windows), scales outside the reciprocal fast path, inf / NaN
+    weights, every code of the width in every position of a group."""
+    gen = torch.Generator().manual_seed(100 * bits + (1 if dtype is F16 else 0))
+    half = 1 << (bits - 1)
+    for (rows, cols, group, sym) in [(64, 1024, 128, True), (64, 1024, 128, False), (33, 384, 96, False), (7, 96, 32, True), (130, 2048, 64, False),
+                                     (5, 4096, None, True), (1, 32, 32, False), (256, 512, 128, True)]:
+        w = torch.randn(rows, cols, generator=gen)
+        w[0, :5] = torch.tensor([float("inf"), float("-inf"), float("nan"), 0.0, -0.0])
+        w = w.to(dtype)
+        s, z = O.calculate_qparams_minmax(w.masked_fill(~torch.isfinite(w.float()), 0), num_bits=bits, group_size=group, symmetric=sym)
+        if rows >= 5:  # scales outside the fast-path ranges (exact-division path), a zero point at each end
+            s[1, 0], s[2, 0] = torch.tensor(2.0 ** -20).to(dtype), torch.tensor(3.0e4).to(dtype)
+            if not sym:
+                z[3, 0], z[4, 0] = -half, half - 1
+        kw = dict(num_bits=bits, strategy="group" if group else "channel", group_size=group)
+        # every code in every position: w = code * scale exactly representable for small codes; random elsewhere
+        sd = {"weight": w, "weight_scale": s, "weight_zero_point": z}
+        ref_c = O.pack_quantized_compress(sd, symmetric=sym, **kw)
+        got = cta.codec.quantize_and_pack(w.to(dev), s.to(dev), z.to(dev), **kw)
+        assert got.shape == ref_c["weight_packed"].shape and torch.equal(got.cpu(), ref_c["weight_packed"]), (rows, cols, group, sym)
+        back = cta.codec.unpack_and_dequantize(got, (rows, cols), s.to(dev), None if sym else z.to(dev), num_bits=bits)
+        ref_d = O.pack_quantized_decompress(ref_c, num_bits=bits, strategy=kw["strategy"], symmetric=sym)
+        assert eq(back.cpu(), ref_d["weight"]), (rows, cols, group, sym)
+    # every code of the width at every position of a pack group, against the packer itself
+    q = ((torch.arange(32 * (1 << bits)) // 32 + torch.arange(32 * (1 << bits)) % 32) % (1 << bits) - half).to(torch.int8).reshape(-1, 32).repeat(1, 4).contiguous()
+    one = torch.ones(q.shape[0], 1, dtype=dtype)
+    words = O.pack_to_int32(q, bits).contiguous()
+    back = cta.codec.unpack_and_dequantize(words.to(dev), q.shape, one.to(dev), None, num_bits=bits)
+    assert torch.equal(back.cpu().float(), q.float())
+    again = cta.codec.quantize_and_pack(q.to(dtype).to(dev), one.to(dev), None, num_bits=bits, strategy="channel")
+    assert torch.equal(again.cpu(), words)
+
+
+@pytest.mark.parametrize("bits", [2, 3, 6])
+def test_lean_other_widths_full_size(cta, dev, bits):
+    """8192 x 8192 bf16 g128 (the size the roofline row is quoted on): compress on the device equals the oracle on a 256-row slice and
+    the composition quantize -> pack_to_int32 on the whole tensor; decompress(compress(W)) == fake_quantize(W)"""
+    n = 8192
+    w = torch.randn(n, n, dtype=torch.float32, device=dev, generator=torch.Generator(device=dev).manual_seed(bits)).to(BF16)
+    for sym in (True, False):
+        s, z = cta.codec.minmax_qparams(w, num_bits=bits, group_size=128, symmetric=sym)
+        kw = dict(num_bits=bits, strategy="group", group_size=128)
+        packed = cta.codec.quantize_and_pack(w, s, z, **kw)
+        q = cta.codec.quantize_tensor(w, s, z, dtype=torch.int8, **kw)
+        assert torch.equal(packed, cta.codec.pack_to_int32(q, bits))
+        sl = slice(4000, 4256)
+        ref = O.pack_quantized_compress({"weight": w[sl].cpu(), "weight_scale": s[sl].cpu(), "weight_zero_point": z[sl].cpu()}, symmetric=sym, **kw)
+        assert torch.equal(packed[sl].cpu(), ref["weight_packed"])
+        back = cta.codec.unpack_and_dequantize(packed, (n, n), s, None if sym else z, num_bits=bits)
+        assert torch.equal(back, cta.codec.fake_quantize_tensor(w, s, z, **kw))
+        assert eq(back[sl].cpu(), O.pack_quantized_decompress(ref, num_bits=bits, strategy="group", symmetric=sym)["weight"])
+
+
 def test_fuzz_parity_bounded():
     """tools/fuzz_parity.py (every public codec entry point against the oracle on random shapes / dtypes / strategies / special
     values) with a fixed seed and a bounded number of cases, so that the driver's -m gpu run re-runs it (VERDICT r02 #5)"""
@@ -474,6 +534,120 @@ def test_asymmetric_decompress_full_range(cta, dev, dtype):
     q8 = torch.randint(-128, 128, (rows, cols), generator=g, dtype=torch.int8)
     got8 = cta.codec.dequantize_tensor(q8.to(dev), s.to(dev), z.to(dev))
     assert eq(got8.cpu(), O.dequantize(q8, s, z))
+
+
+@pytest.mark.parametrize("dtype", [BF16, F16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("shape,group", [((8192, 8192), 128), ((2048, 5632), 128), ((20, 512), 128), ((1001, 1024), 128), ((64, 256), 32), ((96, 384), 64), ((40, 160), 0)],
+                         ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else f"g{v}")
+def test_w4_packed_zero_points_ride_in_the_weights_launch(cta, dev, dtype, shape, group):
+    """Round 6 (VERDICT r05 missing #4): the STORED form of an asymmetric scheme's zero points — pack_to_int32(zp, 4, packed_dim=0),
+    compressors/pack_quantized/base.py:107-110 — is written by tail workgroups of the compress launch (`ct_quant_pack_w4_zp`) and read
+    directly by the decompress launch, whose tail workgroups write the unpacked int8 form back (`ct_unpack_dequant_w4_zp`, base.py:147-153).
+    Against the CPU oracle (pack_to_int32 is pinned to reference goldens there): packed weight words, packed zero-point words (rows that
+    are not a multiple of 8: the padding nibbles are 0, not 8), decompressed weights, unpacked zero points; zero points at both ends of the
+    int4 range in every nibble position.  group 0 = channel-wise."""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    rows, cols = shape
+    g = group or cols
+    G = cols // g
+    gen = torch.Generator().manual_seed(rows + cols + g)
+    big = rows * cols > 1 << 22
+    w = torch.randn(shape, generator=gen).to(dtype) if not big else None
+    wd = torch.randn(shape, generator=torch.Generator(device=dev).manual_seed(5), device=dev, dtype=torch.float32).to(dtype) if big else w.to(dev)
+    sc, zp = cta.codec.minmax_qparams(wd, num_bits=4, group_size=group or None, symmetric=False)
+    zp = zp.clone()
+    zp[: min(rows, 16)] = torch.tensor([-8, 7, -1, 0, 3, -5, 6, -7, 7, -8, 1, 2, -3, 4, 5, -6], dtype=torch.int8, device=dev)[: min(rows, 16), None]  # every nibble position sees both ends
+    stream = _lib.stream_of_device(dev)
+    packed = torch.empty(rows, cols // 8, dtype=torch.int32, device=dev)
+    zpp = torch.full(((rows * 4 + 31) // 32, G), -1, dtype=torch.int32, device=dev)
+    rc = lib.ct_quant_pack_w4_zp(wd.data_ptr(), _lib.DT[dtype], sc.data_ptr(), zp.data_ptr(), rows, cols, g, packed.data_ptr(), zpp.data_ptr(), stream)
+    assert rc == 0, _lib.last_error()
+    kw = dict(num_bits=4, strategy="group" if group else "channel", group_size=group or None)
+    assert torch.equal(packed, cta.codec.quantize_and_pack(wd, sc, zp, **kw))  # the two-launch composition (itself pinned below / elsewhere)
+    assert torch.equal(zpp.cpu(), O.pack_to_int32(zp.cpu(), 4, packed_dim=0).contiguous())
+    sl = slice(0, min(rows, 64))
+    ref_c = O.pack_quantized_compress({"weight": wd[sl].cpu(), "weight_scale": sc[sl].cpu(), "weight_zero_point": zp[sl].cpu()}, symmetric=False, **kw)
+    assert torch.equal(packed[sl].cpu(), ref_c["weight_packed"])
+    if rows <= 64:
+        assert torch.equal(zpp.cpu(), ref_c["weight_zero_point"])
+    # decompress: the kernel takes the zero points from the stored words
+    readable = g == 128 and cols % 512 == 0
+    out = torch.empty(shape, dtype=dtype, device=dev)
+    zu = torch.full((rows, G), 99, dtype=torch.int8, device=dev)
+    rc = lib.ct_unpack_dequant_w4_zp(packed.data_ptr(), sc.data_ptr(), _lib.DT[dtype], zpp.data_ptr(), rows, cols, g, out.data_ptr(), zu.data_ptr(), stream)
+    if not readable:
+        assert rc == _lib.CT_ERR_UNSUPPORTED and "group == 128" in _lib.last_error()
+        assert cta.codec.unpack_and_dequantize_with_zp(packed, shape, sc, zpp, num_bits=4) is None  # the codec-level form declines: the caller composes
+    else:
+        assert rc == 0, _lib.last_error()
+        assert torch.equal(zu, zp)
+        want = cta.codec.unpack_and_dequantize(packed, shape, sc, zp, num_bits=4)
+        assert eq(out.cpu(), want.cpu())
+        ref_d = O.pack_quantized_decompress(ref_c, num_bits=4, strategy=kw["strategy"], symmetric=False)
+        assert eq(out[sl].cpu(), ref_d["weight"]) and torch.equal(zu[sl].cpu(), ref_d["weight_zero_point"])
+        out2 = torch.empty_like(out)  # without the write-back (zp_out NULL): no tail workgroups, same weights
+        assert lib.ct_unpack_dequant_w4_zp(packed.data_ptr(), sc.data_ptr(), _lib.DT[dtype], zpp.data_ptr(), rows, cols, g, out2.data_ptr(), None, stream) == 0
+        assert eq(out2.cpu(), out.cpu())
+    # the plug-in class takes these entries (one launch per direction) and still equals the oracle's state dicts
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=cta.QuantizationArgs(num_bits=4, group_size=group or None, symmetric=False,
+                                                                                       strategy="group" if group else "channel"))
+    names = []
+    real_call = cta.codec.call
+    cta.codec.call = lambda name, *a: (names.append(name), real_call(name, *a))[1]
+    try:
+        comp = cta.PackedQuantizationCompressor.compress({"weight": wd, "weight_scale": sc, "weight_zero_point": zp}, scheme)
+        n_c = len(names)
+        dec = cta.PackedQuantizationCompressor.decompress(comp, scheme)
+    finally:
+        cta.codec.call = real_call
+    assert names[:n_c] == ["ct_quant_pack_w4_zp"], names
+    assert names[n_c:] == (["ct_unpack_dequant_w4_zp"] if readable else ["ct_unpack_int32_dim0", "ct_unpack_dequant"]), names
+    assert torch.equal(comp["weight_packed"], packed) and torch.equal(comp["weight_zero_point"], zpp) and comp["weight_zero_point"].dtype == torch.int32
+    assert torch.equal(dec["weight_zero_point"], zp) and dec["weight_zero_point"].dtype == torch.int8
+    assert eq(dec["weight"].cpu(), cta.codec.unpack_and_dequantize(packed, shape, sc, zp, num_bits=4).cpu())
+
+
+def test_w4_batch_mixes_items_with_and_without_stored_zero_points(cta, dev):
+    """one `ct_quant_pack_batch` / `ct_unpack_dequant_batch` launch over a table that mixes symmetric items, asymmetric items whose zero
+    points ride in the launch (zp_packed) and asymmetric items that keep the unpacked int8 form: every output equal to the single-tensor
+    entries' (pinned against the oracle above)"""
+    gen = torch.Generator(device=dev).manual_seed(3)
+    shapes = [(2048, 2048), (256, 2048), (24, 512), (5632, 2048), (64, 1024), (2048, 5632), (8, 512)]
+    items = []
+    for i, (r, c) in enumerate(shapes):
+        w = torch.randn(r, c, generator=gen, device=dev, dtype=torch.float32).to(BF16)
+        sym = i % 3 == 0
+        sc, zp = cta.codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=sym)
+        items.append((w, sc, zp, sym, i % 3 == 1))
+    kw = dict(num_bits=4, strategy="group", group_size=128)
+    centries, want = [], []
+    for w, sc, zp, sym, carry in items:
+        r, c = w.shape
+        pk = torch.empty(r, c // 8, dtype=torch.int32, device=dev)
+        zpp = torch.empty((r * 4 + 31) // 32, c // 128, dtype=torch.int32, device=dev) if carry else None
+        centries.append((w, sc, zp, pk, r, c, 128, zpp))
+        want.append((cta.codec.quantize_and_pack(w, sc, zp, **kw), cta.codec.pack_to_int32(zp, 4, packed_dim=0)))
+    cta.codec.W4Batch(centries, "compress", BF16).launch()
+    for e, (wp, wz) in zip(centries, want):
+        assert torch.equal(e[3], wp)
+        if e[7] is not None:
+            assert torch.equal(e[7], wz)
+    dentries = []
+    for (w, sc, zp, sym, carry), (wp, wz) in zip(items, want):
+        r, c = w.shape
+        out = torch.empty_like(w)
+        if carry:  # stored form in, unpacked form written back
+            dentries.append((wp, sc, torch.full_like(zp, 55), out, r, c, 128, wz))
+        else:
+            dentries.append((wp, sc, None if sym else zp, out, r, c, 128))
+    cta.codec.W4Batch(dentries, "decompress", BF16).launch()
+    for (w, sc, zp, sym, carry), e in zip(items, dentries):
+        assert torch.equal(e[3], cta.codec.fake_quantize_tensor(w, sc, zp, **kw))  # value equality: fake_quantize may carry -0.0
+        assert eq(e[3].cpu(), cta.codec.unpack_and_dequantize(e[0], w.shape, sc, None if sym else zp, num_bits=4).cpu())  # bit for bit: the single-tensor entry
+        if carry:
+            assert torch.equal(e[2], zp)
 
 
 @pytest.mark.parametrize("N", [4096, 8192])
@@ -926,6 +1100,35 @@ def test_marlin24_rejects_dense_weight(cta, dev):
         cta.Marlin24Compressor.compress({"weight": w.to(dev), "weight_scale": scale.to(dev), "weight_zero_point": zp.to(dev)}, scheme)
 
 
+@pytest.mark.parametrize("native", [True, False], ids=["cpp-host", "python-host"])
+def test_from_dense_values_own_exactly_nnz_elements_by_default(cta, dev, native):
+    """`tensor[mask]` returns nnz elements (restated S1 over utils/helpers.py:306-343) — so does
+    `BitmaskTensor.from_dense` by default, at every density: the storage behind `compressed` is nnz x itemsize bytes (+ the allocator's
+    rounding), not the dense-sized buffer the kernel wrote into.  `exact=False` is the opt-in view (no copy, dense-sized storage)."""
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskTensor
+
+    hp = ctlib.hostpath()
+    assert hp is not None
+    g = torch.Generator(device=dev).manual_seed(11)
+    ctlib._HOSTPATH[0] = hp if native else None
+    try:
+        for dtype in (BF16, F32):
+            for density in (0.5, 0.9, 0.375, 0.05, 0.0, 1.0):
+                w = torch.randn(1024, 2048, device=dev, generator=g).to(dtype)
+                w = w * (torch.rand(1024, 2048, device=dev, generator=g) < density) if density < 1.0 else w.abs() + 1
+                nnz = int((w != 0).sum())
+                bt = BitmaskTensor.from_dense(w)
+                assert bt.compressed.numel() == nnz and torch.equal(bt.compressed, w[w != 0])
+                assert bt.compressed.untyped_storage().nbytes() <= nnz * w.element_size() + (2 << 20), (dtype, density)
+                assert torch.equal(bt.decompress(), w)
+                view = BitmaskTensor.from_dense(w, exact=False)
+                assert torch.equal(view.compressed, bt.compressed) and torch.equal(view.bitmask, bt.bitmask) and torch.equal(view.row_offsets, bt.row_offsets)
+                assert view.compressed.untyped_storage().nbytes() == w.numel() * w.element_size()
+    finally:
+        ctlib._HOSTPATH[0] = hp
+
+
 def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
     """the two plug-in calls that wait for the device — sparse-bitmask compress (nnz) and the default mode of marlin-24 compress (the
     2:4 verdict) — run their host side in csrc/host/ct_hostpath.cpp when the extension is built; the Python host side stays for what
@@ -1325,9 +1528,11 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
         cta.ModelCompressor().decompress_model(model)
     finally:
         ctlib._HOSTPATH[0] = hp
-    # modules 0-3 are plain int4 group / channel modules -> the C++ loop, symmetric or not; an asymmetric scheme's zero points ride a second table
+    # modules 0-3 are plain int4 group / channel modules -> the C++ loop, symmetric or not.  Round 6: an asymmetric scheme's zero points are packed by
+    # the weights' own launch (no second table on the compress side); on the decompress side they ride in the weights' launch when the kernel can read
+    # the stored form (groups of 128, cols % 512 == 0: module 0) and through the zero-point table otherwise (modules 1-3)
     assert taken == {"compress": 4, "decompress": 4}, taken
-    assert zp_tables == ({"compress": 0, "decompress": 0} if symmetric else {"compress": 4, "decompress": 4}), zp_tables
+    assert zp_tables == ({"compress": 0, "decompress": 0} if symmetric else {"compress": 0, "decompress": 3}), zp_tables
     for a, b in zip(model, ref):
         assert eq(a.weight.data.cpu(), b.weight.data.cpu()) and a.weight.dtype == b.weight.dtype
 

@@ -694,14 +694,17 @@ def test_batch_table_words_match_the_struct(cta):
     from compressed_tensors_amd import _lib, codec
 
     assert ctypes.sizeof(_lib.W4Item) == 8 * codec._ITEM_WORDS
-    shapes = [(2048, 2048, 128), (256, 2048, 128), (5632, 2048, 128), (2048, 5632, 5632)]
+    assert codec._ITEM_WORDS == 13  # round 6: + zp_packed, main_blocks, {g_magic, g_shift}
+    shapes = [(2048, 2048, 128), (256, 2048, 128), (5632, 2048, 128), (2048, 5632, 5632), (1001, 5632, 128), (64, 96, 32)]
     flat, structs = [], (_lib.W4Item * len(shapes))()
     for i, (r, c, g) in enumerate(shapes):
-        ptrs = [0x10000 * (4 * i + k + 1) for k in range(4)]
-        flat += (*ptrs, r, c, g, 0, 0, 0)
+        ptrs = [0x10000 * (5 * i + k + 1) for k in range(4)]
+        zpp = 0x10000 * (5 * i + 5) if g == 128 and c % 512 == 0 and i % 2 == 0 else 0  # some items carry the stored form of their zero points
+        flat += (*ptrs, r, c, g, 0, 0, 0, zpp, 0, 0)
         it = structs[i]
         it.src, it.scale, it.zp, it.dst = ptrs
         it.rows, it.cols, it.group = r, c, g
+        it.zp_packed = zpp or None
     assert len(flat) == codec._ITEM_WORDS * len(shapes)
     words = array.array("q", flat)
     lib = _lib.load()
@@ -712,8 +715,26 @@ def test_batch_table_words_match_the_struct(cta):
         blocks_s = lib.ct_w4_batch_plan(ctypes.cast(s, ctypes.c_void_p), len(shapes), direction)
         assert blocks_w == blocks_s > 0
         assert bytes(w) == bytes(s)
+        first = 0
         for i, (r, c, g) in enumerate(shapes):
-            assert (s[i].rows, s[i].cols, s[i].group) == (r, c, g) and s[i].units == r * c // 8
+            assert (s[i].rows, s[i].cols, s[i].group) == (r, c, g) and s[i].units == r * c // 8 and s[i].first_block == first
+            main = -(-(r * c // 32) // 256) if direction == 0 else -(-(r * c // 8) // 1024)
+            G = c // g
+            tail = -(-(-(-r // 8) * G) // 256) if s[i].zp_packed else 0  # one lane per stored word (ceil(rows / 8), G)
+            assert s[i].main_blocks == main
+            first += main + tail
+            # n // G == (n * g_magic) >> g_shift for every n the kernels divide (word / group indices below 2^31)
+            for nn in (0, 1, G - 1, G, G + 1, 12345 * G + G - 1, 2 ** 31 - 1, 2 ** 31 - G, 7 * G * 1000 + 3):
+                assert (nn * s[i].g_magic) >> s[i].g_shift == nn // G, (G, nn)
+        assert blocks_s == first
+    # the stored form can only be READ by the decompress kernels for groups of 128 and cols % 512 == 0; the plan says so instead of mis-reading
+    bad = (_lib.W4Item * 1)()
+    bad[0].src, bad[0].scale, bad[0].zp, bad[0].dst, bad[0].zp_packed = 0x10000, 0x20000, 0x30000, 0x40000, 0x50000
+    bad[0].rows, bad[0].cols, bad[0].group = 64, 256, 64
+    assert lib.ct_w4_batch_plan(ctypes.cast(bad, ctypes.c_void_p), 1, 1) == -1 and "packed form" in _lib.last_error()
+    assert lib.ct_w4_batch_plan(ctypes.cast(bad, ctypes.c_void_p), 1, 0) > 0  # compress: any batch item may ask for it
+    bad[0].zp = None
+    assert lib.ct_w4_batch_plan(ctypes.cast(bad, ctypes.c_void_p), 1, 0) == -1 and "without giving" in _lib.last_error()
 
 
 def _tree(cta, scheme, shapes, *, trainable_scale=False, buffer_zp=False, odd_class=False, g_idx=False):
@@ -774,12 +795,13 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
     which = {"now": "cpp"}
 
     def fake_words(words, n, direction, dtype, device):
-        rows = words.reshape(n, 10)[:, 4:7].tolist()
+        w = words.reshape(n, codec._ITEM_WORDS)
+        rows = [r[4:7] + [bool(r[10])] for r in w.tolist()]  # rows, cols, group, carries the stored form of its zero points (ct_w4_item.zp_packed)
         tables[which["now"]].append((direction, dtype, rows))
 
     class FakeBatch:
         def __init__(self, entries, direction, dtype, kind="w4", bits=8):
-            self.rec = (direction, dtype, [[int(e[4]), int(e[5]), int(e[6])] for e in entries])
+            self.rec = (direction, dtype, [[int(e[4]), int(e[5]), int(e[6]), len(e) > 7 and e[7] is not None] for e in entries])
 
         def launch(self, stream=None):
             if self.rec[2]:
@@ -787,7 +809,7 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
 
     def fake_zp_words(words, n, direction, device):
         if n:
-            tables[which["now"]].append(("zp-" + direction, None, words.reshape(n, 10)[:, 4:6].tolist()))
+            tables[which["now"]].append(("zp-" + direction, None, words.reshape(n, codec._ITEM_WORDS)[:, 4:6].tolist()))
 
     def fake_zp_batch(pairs, direction):
         pairs = list(pairs)
@@ -800,6 +822,8 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
     monkeypatch.setattr(codec, "pack_to_int32", lambda zp, bits, packed_dim=1: torch.zeros((zp.shape[0] * 4 + 31) // 32, zp.shape[1], dtype=torch.int32))
     monkeypatch.setattr(codec, "unpack_from_int32", lambda p, bits, shape, packed_dim=1: torch.zeros(tuple(shape), dtype=torch.int8))
     monkeypatch.setattr(codec, "W4Batch", FakeBatch)
+    monkeypatch.setattr(codec, "quantize_and_pack_with_zp", lambda *a_, **k: None)  # the single-module one-launch forms decline: the stubs compose
+    monkeypatch.setattr(codec, "unpack_and_dequantize_with_zp", lambda *a_, **k: None)
     monkeypatch.setattr(codec, "quantize_and_pack", lambda w, *a_, **k: torch.zeros(w.shape[0], w.shape[1] // 8, dtype=torch.int32))
     monkeypatch.setattr(codec, "unpack_and_dequantize", lambda p, shape, scale, *a_, **k: torch.zeros(shape, dtype=scale.dtype))
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)  # the Python loop's own device test
@@ -813,8 +837,9 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
         pq.PackedQuantizationCompressor.compress_modules(mods_b)
         monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
         n_plain = {"plain": 5, "trainable_scale": 4, "buffer_zp": 4, "odd_class": 4, "g_idx": 4, "asymmetric": 5, "asymmetric_buffer_zp": 4}[variant]
-        if asym:  # every zero point packed by a batched launch (the C++ loop's, plus the Python loop's for what was handed back), and stored packed
-            assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "zp-pack") == len(mods_a)
+        if asym:  # round 6: every zero point packed by the WEIGHTS' launch (its items carry zp_packed; no zp-pack launch is left), and stored packed
+            assert not [t for t in tables["cpp"] + tables["py"] if t[0] == "zp-pack"]
+            assert sum(r[3] for t in tables["cpp"] if t[0] == "compress" for r in t[2]) == len(mods_a)
             assert all(x.weight_zero_point.dtype == torch.int32 and x.weight_zero_point.shape == ((x.out_features * 4 + 31) // 32, x.in_features // 128) for x in mods_a)
         assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "compress") >= n_plain - 0
         for x, y in zip(mods_a, mods_b):
@@ -834,9 +859,13 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
                 assert x.weight_zero_point.dtype == torch.int8 and x.weight_zero_point.shape == (x.out_features, x.in_features // 128)
         # the same work reached the launches, whichever loop built the table
         flat = lambda ts, d: sorted(tuple(r) for t in ts if t[0] == d for r in t[2])
-        if asym:  # the zero points are unpacked BEFORE the weights' launch that reads them
+        if asym:  # zero points the weights' launch cannot read in stored form (here: cols % 512 != 0) are unpacked BEFORE that launch; the others ride in it
             order = [t[0] for t in tables["cpp"] if t[0] in ("zp-unpack", "decompress")]
             assert order[:2] == ["zp-unpack", "decompress"], order
+            for t in tables["cpp"] + tables["py"]:
+                if t[0] == "decompress":
+                    assert all(r[3] == (r[1] % 512 == 0 and r[2] == 128) for r in t[2]), t
+            assert sum(len(t[2]) for t in tables["cpp"] if t[0] == "zp-unpack") == sum(1 for x in mods_a if x.in_features % 512)
         for d in ("compress", "decompress", "zp-pack", "zp-unpack"):
             assert flat(tables["cpp"], d) == flat(tables["py"], d), (variant, d)
     finally:
@@ -900,19 +929,19 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
     hp.set_allow_cpu(True)
     try:
         g = torch.Generator().manual_seed(3)
-        for density, shares in ((0.5, True), (0.2, False)):
+        for density, exact in ((0.5, True), (0.5, False), (0.2, True), (0.2, False)):
             x = torch.randint(1, 1000, (48, 96), generator=g, dtype=torch.int16) * (torch.rand(48, 96, generator=g) < density)
-            status, values, bitmask, ro = hp.bitmask_compress(x, 7, host, host, 1234)
+            status, values, bitmask, ro = hp.bitmask_compress(x, 7, host, host, 1234, exact)
             assert status == 0 and seen["bm"] == (7, 48, 96, 48 * 96, 4096 + 8 * 48, 1234, -1)  # the pending word was set before the launch
             keep = x != 0
             assert values.dtype == x.dtype and torch.equal(values, x[keep])
             assert torch.equal(bitmask, torch.from_numpy(np.packbits(keep.numpy(), axis=1, bitorder="little")))
             assert torch.equal(ro, torch.cumsum(keep.sum(1), 0) - keep.sum(1))
-            # at least 3/8 of the worst case kept: a view of the worst-case buffer; less: a compact copy
-            assert (values.untyped_storage().nbytes() == 2 * x.numel()) == shares
-        assert hp.bitmask_compress(x.t(), 7, host, host, 0) is None and hp.bitmask_compress(x[:0], 7, host, host, 0) is None  # the Python path's cases
+            # exact (round 6, the default of the Python callers): `values` owns nnz elements, like tensor[mask]; otherwise a view of the worst-case buffer
+            assert values.untyped_storage().nbytes() == (2 * int(keep.sum()) if exact else 2 * x.numel())
+        assert hp.bitmask_compress(x.t(), 7, host, host, 0, True) is None and hp.bitmask_compress(x[:0], 7, host, host, 0, True) is None  # the Python path's cases
         seen["fail"] = True
-        status, *rest = hp.bitmask_compress(x, 7, host, host, 0)
+        status, *rest = hp.bitmask_compress(x, 7, host, host, 0, True)
         assert status == ctlib.CT_ERR_INVALID_ARG and rest == [None, None, None]
 
         w = torch.zeros(64, 256, dtype=torch.bfloat16)
@@ -1023,13 +1052,17 @@ def test_cpp_host_loop_fuzz_against_the_python_loop(cta, monkeypatch):
     tables = {"cpp": [], "py": []}
     which = {"now": "cpp"}
     rec = lambda *t: tables[which["now"]].append(t)
-    monkeypatch.setattr(codec, "launch_w4_words", lambda words, n, direction, dtype, device: n and rec(direction, sorted(map(tuple, words.reshape(n, 10)[:, 4:7].tolist()))))
-    monkeypatch.setattr(codec, "launch_zp4_words", lambda words, n, direction, device: n and rec("zp-" + direction, sorted(map(tuple, words.reshape(n, 10)[:, 4:6].tolist()))))
+    IW = codec._ITEM_WORDS  # (rows, cols, group, carries the stored form of its zero points)
+    monkeypatch.setattr(codec, "launch_w4_words", lambda words, n, direction, dtype, device: n and rec(direction, sorted((*r[4:7], bool(r[10])) for r in words.reshape(n, IW).tolist())))
+    monkeypatch.setattr(codec, "launch_zp4_words", lambda words, n, direction, device: n and rec("zp-" + direction, sorted(map(tuple, words.reshape(n, IW)[:, 4:6].tolist()))))
+    # the single-module one-launch forms decline (None): the per-module path composes the stubs below, as it does for a layout they do not take
+    monkeypatch.setattr(codec, "quantize_and_pack_with_zp", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "unpack_and_dequantize_with_zp", lambda *a_, **k: None)
     monkeypatch.setattr(codec, "zp4_batch", lambda pairs, direction: (lambda ps: ps and rec("zp-" + direction, sorted(tuple((s if direction == "pack" else d).shape) for s, d in ps)))(list(pairs)))
 
     class FakeBatch:
         def __init__(self, entries, direction, dtype, kind="w4", bits=8):
-            self.rec = (direction, sorted((int(e[4]), int(e[5]), int(e[6])) for e in entries))
+            self.rec = (direction, sorted((int(e[4]), int(e[5]), int(e[6]), len(e) > 7 and e[7] is not None) for e in entries))
 
         def launch(self, stream=None):
             if self.rec[1]:
