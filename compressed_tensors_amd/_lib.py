@@ -93,6 +93,10 @@ _PROTOTYPES = {
     "ct_bitmask_decompress": ([_P, _L, _P, _P, _L, _I, _L, _L, _P, _S], _I),
     "ct_bitmask_compress_workspace_bytes": ([_L, _L], _L),
     "ct_bitmask_compress": ([_P, _I, _L, _L, _P, _L, _P, _P, _P, _P, _L, _S], _I),
+    "ct_bitmask_batch_plan": ([_P, _I, _P], _L),
+    "ct_bitmask_compress_batch": ([_P, _I, _L, _I, _P, _L, _S], _I),
+    "ct_copy_batch_plan": ([_P, _I], _L),
+    "ct_copy_batch": ([_P, _I, _L, _S], _I),
     "ct_bitmask_row_popcount": ([_P, _L, _L, _P, _S], _I),
     "ct_sparse24_compress": ([_P, _I, _L, _L, _P, _P, _S], _I),
     "ct_sparse24_mask": ([_P, _I, _L, _P, _S], _I),
@@ -117,6 +121,18 @@ class W4Item(ctypes.Structure):
     _fields_ = [("src", _P), ("scale", _P), ("zp", _P), ("dst", _P), ("rows", _L), ("cols", _L), ("group", _L),
                 ("first_block", _L), ("units", _L), ("upg_shift", _c.c_int32), ("upg", _c.c_int32),
                 ("zp_packed", _P), ("main_blocks", _L), ("g_magic", _c.c_uint32), ("g_shift", _c.c_int32)]
+
+
+class BitmaskItem(ctypes.Structure):
+    """struct ct_bitmask_item of include/ct_hip.h (a row of ct_bitmask_compress_batch's table)"""
+    _fields_ = [("x", _P), ("values", _P), ("bitmask", _P), ("row_offsets", _P), ("total", _P), ("rows", _L), ("cols", _L), ("values_capacity", _L),
+                ("dt", _c.c_int32), ("is_float", _c.c_int32), ("first_block", _L), ("units", _L), ("upr", _L), ("slots_offset", _L),
+                ("nwg", _c.c_int32), ("tpw", _c.c_int32), ("mask_dwords", _c.c_int32), ("gen", _c.c_uint32)]
+
+
+class CopyItem(ctypes.Structure):
+    """struct ct_copy_item of include/ct_hip.h"""
+    _fields_ = [("src", _P), ("dst", _P), ("bytes", _L), ("first_block", _L)]
 
 
 ITEM_WORDS = ctypes.sizeof(W4Item) // 8  # 13: every host table of ct_w4_item rows is a flat array of this many 64-bit words per item
@@ -227,7 +243,8 @@ class Mailbox:
     has to wait for — the sparse-bitmask codec's nnz, marlin-24's structure verdict — without a D2H copy.  One per (thread,
     device): a call fills its word, launches, waits and reads before it returns, so a thread never has two waits in flight."""
 
-    WORDS = 8
+    WORDS = 264  # 0: nnz of a sparse-bitmask compress, 1: marlin-24's verdict, 8..263: the nnz words of a batch (codec.bitmask_compress_many:
+    BATCH_WORD0, BATCH_WORDS = 8, 256  # two windows of 128 tensors in flight)
     M24_VERDICT_WORKSPACE_BYTES = 8320  # CT_M24_VERDICT_WORKSPACE_BYTES of include/ct_hip.h
 
     def __init__(self, device_index: int):
@@ -306,7 +323,8 @@ def hostpath():
             # lib[name]: the symbol itself — `lib.name` may have been replaced by a launch-counting wrapper (tests/ref_suite)
             abi = {name: ctypes.cast(lib[name], ctypes.c_void_p).value
                    for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
-                                "ct_marlin24_compress_w4_full", "ct_marlin24_compress_w4_verdict")}
+                                "ct_marlin24_compress_w4_full", "ct_marlin24_compress_w4_verdict", "ct_bitmask_batch_plan", "ct_bitmask_compress_batch",
+                                "ct_copy_batch_plan", "ct_copy_batch")}
             try:  # the HIP runtime libct_hip.so is linked against, only if it is already in the process (RTLD_NOLOAD: never a second copy)
                 hip = ctypes.CDLL("libamdhip64.so", mode=os.RTLD_NOLOAD | os.RTLD_NOW)
                 abi["hipStreamSynchronize"] = ctypes.cast(hip.hipStreamSynchronize, ctypes.c_void_p).value

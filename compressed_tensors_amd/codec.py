@@ -1015,6 +1015,37 @@ def bitmask_compress(tensor: torch.Tensor, two_pass: bool = False, exact: bool =
     return _home(values.view(tensor.dtype), tensor), _home(bitmask, tensor), _home(row_offsets, tensor)
 
 
+def bitmask_compress_many(tensors, exact: bool = True, arena_bytes: int = 1 << 30):
+    """`bitmask_compress` for a LIST of tensors (a checkpoint's sparse weights): [(values, bitmask, row_offsets), ...] in order.  The tensors on
+    the current GPU go through the C++ host loop in windows — their compress launches are queued back to back, each reporting nnz into its own
+    mailbox word, and the host sizes the results afterwards: one wait per window instead of ~9 us of waiting per tensor (a single call cannot
+    overlap its own kernel; a batch can).  `exact` as in `bitmask_compress`; in exact mode a window's kernels share ONE worst-case arena of at
+    most `arena_bytes` (never less than one tensor) instead of a worst-case allocation per tensor, and the exact-size results are filled by
+    one batched copy.  A window is ONE kernel launch (`ct_bitmask_compress_batch`): a single launch of a checkpoint-sized tensor is a latency
+    chain at 2-27 % of the HBM rate, the tensors of a table run theirs side by side.  Everything the loop does not take (CPU tensors, other
+    devices, views, 8-bit payloads, no host extension) is compressed one by one."""
+    tensors = list(tensors)
+    out = [None] * len(tensors)
+    hp = _lib.hostpath()
+    if hp is not None and torch.cuda.is_available():
+        cur = torch.cuda.current_device()
+        idx = [i for i, t in enumerate(tensors) if t.ndim >= 1 and t.is_cuda and t.device.index == cur and t.numel() > 0 and t.is_contiguous()]
+        if idx:
+            xs = [_bits_view(tensors[i]) for i in idx]
+            dts = [DT[x.dtype] if (x.dtype in DT and x.element_size() in (1, 2, 4)) else -1 for x in xs]
+            s = _lib.stream_on(xs[0].device)
+            mb = _lib.mailbox(s.device_index)
+            r = hp.bitmask_compress_many(xs, dts, mb.host, mb.dev, mb.BATCH_WORD0, mb.BATCH_WORDS, s, bool(exact), int(arena_bytes))
+            _lib.check(r[0])
+            for i, x, res in zip(idx, xs, r[1:]):
+                if res is not None:
+                    out[i] = (res[0] if x is tensors[i] else res[0].view(tensors[i].dtype), res[1], res[2])
+    for i, t in enumerate(tensors):
+        if out[i] is None:
+            out[i] = bitmask_compress(t, exact=exact)
+    return out
+
+
 def bitmask_decompress(values: torch.Tensor, bitmask: torch.Tensor, shape, row_offsets: Optional[torch.Tensor] = None,
                        fixed_row_nnz: Optional[int] = None) -> torch.Tensor:
     """sparse-bitmask decompression: zeros(shape) with `values` written at the set bits."""

@@ -51,6 +51,14 @@ class BitmaskTensor:
         values, bitmask, row_offsets = bitmask_compress(tensor, exact=exact)
         return BitmaskTensor(shape=shape, compressed=values, bitmask=bitmask, row_offsets=row_offsets)
 
+    @staticmethod
+    def from_dense_many(tensors, exact: bool = True) -> "list":
+        """`from_dense` for a list of tensors with ONE host wait per window of tensors instead of one per tensor
+        (codec.bitmask_compress_many): what a checkpoint of sparse weights should go through"""
+        tensors = list(tensors)
+        parts = codec.bitmask_compress_many(tensors, exact=exact)
+        return [BitmaskTensor(shape=t.shape, compressed=v, bitmask=b, row_offsets=r) for t, (v, b, r) in zip(tensors, parts)]
+
     def decompress(self) -> torch.Tensor:
         return bitmask_decompress(self.compressed, self.bitmask, self.shape, self.row_offsets)
 
@@ -98,9 +106,12 @@ class BitmaskCompressor(BaseCompressor):
     @classmethod
     def compress_state_dict(cls, model_state: Dict[str, torch.Tensor], targets=None) -> Dict[str, torch.Tensor]:
         out = {}
+        picked = [name for name in model_state if name.endswith(".weight") and (targets is None or name[: -len(".weight")] in targets)]
+        # every weight of the checkpoint in one batched pass (one host wait per window of tensors, not one per tensor)
+        done = dict(zip(picked, BitmaskTensor.from_dense_many([model_state[name] for name in picked])))
         for name, value in model_state.items():
-            if name.endswith(".weight") and (targets is None or name[: -len(".weight")] in targets):
-                out.update(BitmaskTensor.from_dense(value).dict(name_prefix=name[: -len(".weight")]))
+            if name in done:
+                out.update(done[name].dict(name_prefix=name[: -len(".weight")]))
             else:
                 out[name] = value
         return out

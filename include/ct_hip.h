@@ -347,6 +347,44 @@ int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols);
 int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void* values,
                         int64_t values_capacity, uint8_t* bitmask, int64_t* row_offsets, int64_t* total,
                         void* workspace, int64_t workspace_bytes, ct_stream_t stream);
+/* The same compress for a TABLE of tensors in ONE launch (round 6): a checkpoint's sparse weights, e.g. what the restated
+ * BitmaskCompressor.compress_state_dict loops over.  One ct_bitmask_compress launch of a checkpoint-sized tensor is a latency chain
+ * (9 us for 1 MB, 10 us for 8 MB, 17 us for 23 MB of bf16: 2-27 % of the HBM rate); in one grid the tensors' chains run side by
+ * side.  16- or 32-bit payloads (ONE element size per table), cols % 8 == 0, x and values 16-byte aligned, at most 1 GiB of payload
+ * per tensor.  Protocol as the W4 batch: fill x / dt / rows / cols / values / values_capacity / bitmask / row_offsets / total of every
+ * item, call ct_bitmask_batch_plan on the HOST copy (derived fields; returns the workgroup count or -1 and, in *workspace_bytes, the
+ * size of the one workspace the launch needs: 8-byte aligned device memory, need not be initialised), copy the table to the device,
+ * launch.  total[0] of every item receives its nnz (a word of a ct_mailbox_alloc block, for a host that waits; or device memory).
+ * Outputs are bit-identical to ct_bitmask_compress item by item. */
+typedef struct ct_bitmask_item {
+    const void* x;
+    void* values;
+    uint8_t* bitmask;
+    int64_t* row_offsets;
+    int64_t* total;
+    int64_t rows, cols, values_capacity; /* capacity in elements; numel is always enough */
+    int32_t dt;                          /* element type code */
+    int32_t is_float;                    /* derived */
+    int64_t first_block, units, upr, slots_offset; /* derived */
+    int32_t nwg, tpw, mask_dwords;                 /* derived */
+    uint32_t gen;                                  /* derived */
+} ct_bitmask_item;                       /* 15 64-bit words */
+int64_t ct_bitmask_batch_plan(ct_bitmask_item* items_host, int n, int64_t* workspace_bytes);
+int ct_bitmask_compress_batch(const ct_bitmask_item* items_dev, int n, int64_t total_blocks, int element_size, void* workspace,
+                              int64_t workspace_bytes, ct_stream_t stream);
+
+/* n byte ranges copied by one launch (the exact-size `values` of a batch leave the worst-case arena the kernels wrote into:
+ * tensor[mask] owns nnz elements, restated S1 over utils/helpers.py:306-343).  ct_copy_batch_plan fills first_block on the host
+ * copy and returns the workgroup count (16 KiB per workgroup) or -1. */
+typedef struct ct_copy_item {
+    const void* src;
+    void* dst;
+    int64_t bytes;
+    int64_t first_block; /* derived */
+} ct_copy_item;
+int64_t ct_copy_batch_plan(ct_copy_item* items_host, int n);
+int ct_copy_batch(const ct_copy_item* items_dev, int n, int64_t total_blocks, ct_stream_t stream);
+
 /* sparse-bitmask decompress: out = zeros; out[mask] = values.  row_offsets may be NULL only if
  * fixed_row_nnz >= 0 (every row holds exactly that many values: the 2:4 codec).  16-bit payloads with
  * cols % 32 == 0 and 32-bit payloads with cols % 16 == 0 (as pairs of halves) take the LDS-window

@@ -1129,6 +1129,135 @@ def test_from_dense_values_own_exactly_nnz_elements_by_default(cta, dev, native)
         ctlib._HOSTPATH[0] = hp
 
 
+def test_bitmask_compress_batch_through_the_c_abi(cta, dev):
+    """`ct_bitmask_batch_plan` + `ct_bitmask_compress_batch` + `ct_copy_batch` called the way a C host would (ctypes structures, no Python
+    codec in between): a table of 16-bit tensors of very different sizes — one workgroup, a partial last tile, rows that are not a multiple
+    of anything, an all-zero and a dense tensor, 8192 x 8192 (two residency rounds, next to small neighbours) — every output bit-identical
+    to `ct_bitmask_compress` item by item and to the CPU oracle; then the float32 table; then a table that mixes element sizes is refused."""
+    import ctypes
+
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    stream = _lib.stream_of_device(dev)
+    g = torch.Generator(device=dev).manual_seed(4)
+    for dtype in (BF16, F32):
+        shapes = [(1, 8), (3, 40), (64, 256), (257, 1000), (2048, 2048), (256, 2048), (5632, 2048), (8192, 8192 if dtype is BF16 else 2048), (100, 64), (33, 4096)]
+        xs = []
+        for i, (r, c) in enumerate(shapes):
+            w = torch.randn(r, c, device=dev, generator=g).to(dtype)
+            dens = [0.5, 0.3, 0.0, 0.7, 0.5, 0.9, 0.5, 0.5, 1.0, 0.02][i]
+            xs.append(w * (torch.rand(r, c, device=dev, generator=g) < dens) if dens < 1.0 else w.abs() + 1)
+        n = len(xs)
+        items = (_lib.BitmaskItem * n)()
+        totals = torch.full((n,), -7, dtype=torch.int64, device=dev)
+        outs = []
+        for i, x in enumerate(xs):
+            r, c = x.shape
+            v, bm, ro = torch.empty(r * c, dtype=dtype, device=dev), torch.empty(r, (c + 7) // 8, dtype=torch.uint8, device=dev), torch.empty(r, dtype=torch.int64, device=dev)
+            outs.append((v, bm, ro))
+            it = items[i]
+            it.x, it.values, it.bitmask, it.row_offsets, it.total = x.data_ptr(), v.data_ptr(), bm.data_ptr(), ro.data_ptr(), totals[i:].data_ptr()
+            it.rows, it.cols, it.values_capacity, it.dt = r, c, r * c, _lib.DT[dtype]
+        ws_bytes = ctypes.c_int64()
+        blocks = lib.ct_bitmask_batch_plan(ctypes.cast(items, ctypes.c_void_p), n, ctypes.byref(ws_bytes))
+        assert blocks > 0 and ws_bytes.value > 0, _lib.last_error()
+        assert [items[i].first_block for i in range(n)] == [sum(items[j].nwg for j in range(i)) for i in range(n)]
+        table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        ws = torch.empty(ws_bytes.value // 8 + 1, dtype=torch.int64, device=dev)
+        for rep in range(3):  # the workspace is reused as it is: every launch has its own generation tags
+            if rep:
+                blocks = lib.ct_bitmask_batch_plan(ctypes.cast(items, ctypes.c_void_p), n, ctypes.byref(ws_bytes))
+                table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+            totals.fill_(-7)
+            rc = lib.ct_bitmask_compress_batch(table.data_ptr(), n, blocks, xs[0].element_size(), ws.data_ptr(), ws_bytes.value, stream)
+            assert rc == 0, _lib.last_error()
+            torch.cuda.synchronize()
+            for i, (x, (v, bm, ro)) in enumerate(zip(xs, outs)):
+                rv, rbm, rro = cta.codec.bitmask_compress(x)
+                nnz = int(totals[i])
+                assert nnz == rv.numel(), (i, nnz, rv.numel())
+                assert torch.equal(v[:nnz], rv) and torch.equal(bm, rbm) and torch.equal(ro, rro), (dtype, i)
+        # the oracle on the items it finishes quickly
+        for i in (1, 3, 5, 9):
+            ov, obm, oro = O.bitmask_compress(xs[i].cpu())
+            assert torch.equal(outs[i][0][: ov.numel()].cpu().view(torch.uint8), ov.view(torch.uint8)) and torch.equal(outs[i][1].cpu(), obm) and torch.equal(outs[i][2].cpu(), oro)
+        # the batched copy: every kept prefix into its own exact-size buffer
+        cp = (_lib.CopyItem * n)()
+        exact = [torch.empty(int(totals[i]), dtype=dtype, device=dev) for i in range(n)]
+        for i in range(n):
+            cp[i].src, cp[i].dst, cp[i].bytes = outs[i][0].data_ptr(), exact[i].data_ptr(), exact[i].numel() * exact[i].element_size()
+        cblocks = lib.ct_copy_batch_plan(ctypes.cast(cp, ctypes.c_void_p), n)
+        assert cblocks >= 0
+        ctab = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).to(dev)
+        assert lib.ct_copy_batch(ctab.data_ptr(), n, cblocks, stream) == 0
+        torch.cuda.synchronize()
+        assert all(torch.equal(e, o[0][: e.numel()]) for e, o in zip(exact, outs))
+    # a misaligned source / destination / odd byte count takes the byte path of the copy kernel
+    src = torch.arange(100000, dtype=torch.int32, device=dev).view(torch.uint8)
+    dst = torch.zeros(100000 * 4 + 64, dtype=torch.uint8, device=dev)
+    one = (_lib.CopyItem * 2)()
+    one[0].src, one[0].dst, one[0].bytes = src.data_ptr() + 3, dst.data_ptr() + 5, 70001
+    one[1].src, one[1].dst, one[1].bytes = src.data_ptr() + 160000, dst.data_ptr() + 160000, 33333
+    cb = lib.ct_copy_batch_plan(ctypes.cast(one, ctypes.c_void_p), 2)
+    tab = torch.frombuffer(bytearray(bytes(one)), dtype=torch.uint8).to(dev)
+    assert lib.ct_copy_batch(tab.data_ptr(), 2, cb, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst[5:70006], src[3:70004]) and torch.equal(dst[160000:193333], src[160000:193333]) and int(dst[70006:160000].sum()) == 0
+    # one element size per table
+    mixed = (_lib.BitmaskItem * 2)()
+    for i, x in enumerate((xs[2], xs[2].to(BF16))):
+        v, bm, ro = torch.empty(x.numel(), dtype=x.dtype, device=dev), torch.empty(x.shape[0], x.shape[1] // 8, dtype=torch.uint8, device=dev), torch.empty(x.shape[0], dtype=torch.int64, device=dev)
+        mixed[i].x, mixed[i].values, mixed[i].bitmask, mixed[i].row_offsets, mixed[i].total = x.data_ptr(), v.data_ptr(), bm.data_ptr(), ro.data_ptr(), totals.data_ptr()
+        mixed[i].rows, mixed[i].cols, mixed[i].values_capacity, mixed[i].dt = x.shape[0], x.shape[1], x.numel(), _lib.DT[x.dtype]
+    assert lib.ct_bitmask_batch_plan(ctypes.cast(mixed, ctypes.c_void_p), 2, ctypes.byref(ws_bytes)) == -1 and "ONE element size" in _lib.last_error()
+
+
+@pytest.mark.parametrize("exact", [True, False], ids=["exact", "view"])
+def test_from_dense_many_equals_from_dense(cta, dev, exact):
+    """Round 6: a list of tensors through `BitmaskTensor.from_dense_many` — windows of compress launches, one mailbox
+    word each, ONE host wait per window — gives exactly what `from_dense` gives tensor by tensor: a TinyLlama layer's shapes at several
+    densities, a float32 and an int8-viewed fp8 tensor, a CPU tensor and a transposed view (both taken one by one), an empty list; a small
+    arena budget (every window one tensor) and more tensors than mailbox words (several windows)"""
+    from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskCompressor, BitmaskTensor
+
+    g = torch.Generator(device=dev).manual_seed(21)
+    shapes = [(2048, 2048), (256, 2048), (256, 2048), (2048, 2048), (5632, 2048), (5632, 2048), (2048, 5632)]
+    ws = []
+    for rep in range(10):  # 70 tensors: more than the 56 words of a window
+        for i, (r, c) in enumerate(shapes):
+            if rep > 1 and r * c > 1 << 22:
+                r //= 8
+            w = torch.randn(r, c, device=dev, generator=g).to(BF16)
+            ws.append(w * (torch.rand(r, c, device=dev, generator=g) < (0.1 + 0.1 * ((i + rep) % 9))))
+    ws.append(torch.randn(300, 1000, device=dev, generator=g) * (torch.rand(300, 1000, device=dev, generator=g) < 0.5))  # float32
+    ws.append((torch.randn(128, 256, device=dev, generator=g) * (torch.rand(128, 256, device=dev, generator=g) < 0.5)).to(torch.float8_e4m3fn))
+    ws.append(ws[0].cpu())
+    ws.append(ws[1].t())
+    assert BitmaskTensor.from_dense_many([]) == []
+    for budget in (None, 1):
+        if budget is None:
+            many = BitmaskTensor.from_dense_many(ws, exact=exact)
+        else:
+            parts = cta.codec.bitmask_compress_many(ws[:9], exact=exact, arena_bytes=budget)
+            many = [BitmaskTensor(shape=t.shape, compressed=v, bitmask=b, row_offsets=r) for t, (v, b, r) in zip(ws[:9], parts)]
+        for w, bt in zip(ws, many):
+            one = BitmaskTensor.from_dense(w, exact=exact)
+            assert bt.shape == one.shape and bt.compressed.dtype == w.dtype and bt.compressed.device == w.device
+            assert torch.equal(bt.compressed.view(torch.uint8), one.compressed.view(torch.uint8)) and torch.equal(bt.bitmask, one.bitmask) and torch.equal(bt.row_offsets, one.row_offsets)
+            if w.is_cuda and w.is_contiguous():
+                nnz_bytes = int((w.float() != 0).sum()) * w.element_size()
+                assert bt.compressed.untyped_storage().nbytes() <= (nnz_bytes + (2 << 20) if exact else w.numel() * w.element_size())
+            assert torch.equal(bt.decompress().float(), w.float())
+    # and the state-dict interface on top of it
+    state = {f"model.layers.{i}.w.weight": w for i, w in enumerate(ws[:12])}
+    state["model.norm.bias"] = torch.ones(8, device=dev)
+    comp = BitmaskCompressor.compress_state_dict(state)
+    assert "model.norm.bias" in comp and "model.layers.3.w.compressed" in comp and "model.layers.3.w.weight" not in comp
+    back = BitmaskCompressor.decompress_state_dict(comp)
+    assert sorted(back) == sorted(state) and all(torch.equal(back[k].float(), state[k].float()) for k in state)
+
+
 def test_waiting_calls_native_host_path_equals_the_python_host_path(cta, dev):
     """the two plug-in calls that wait for the device — sparse-bitmask compress (nnz) and the default mode of marlin-24 compress (the
     2:4 verdict) — run their host side in csrc/host/ct_hostpath.cpp when the extension is built; the Python host side stays for what

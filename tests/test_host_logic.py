@@ -694,6 +694,8 @@ def test_batch_table_words_match_the_struct(cta):
     from compressed_tensors_amd import _lib, codec
 
     assert ctypes.sizeof(_lib.W4Item) == 8 * codec._ITEM_WORDS
+    assert ctypes.sizeof(_lib.BitmaskItem) == 8 * 15 and ctypes.sizeof(_lib.CopyItem) == 8 * 4  # csrc/host/ct_hostpath.cpp fills these as 15 / 4 words
+    assert _lib.BitmaskItem.dt.offset == 64 and _lib.BitmaskItem.first_block.offset == 72 and _lib.BitmaskItem.nwg.offset == 104 and _lib.BitmaskItem.gen.offset == 116
     assert codec._ITEM_WORDS == 13  # round 6: + zp_packed, main_blocks, {g_magic, g_shift}
     shapes = [(2048, 2048, 128), (256, 2048, 128), (5632, 2048, 128), (2048, 5632, 5632), (1001, 5632, 128), (64, 96, 32)]
     flat, structs = [], (_lib.W4Item * len(shapes))()
@@ -943,6 +945,81 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
         seen["fail"] = True
         status, *rest = hp.bitmask_compress(x, 7, host, host, 0, True)
         assert status == ctlib.CT_ERR_INVALID_ARG and rest == [None, None, None]
+
+        # the batched form (round 6): a window of tensors = ONE table launch (ct_bitmask_compress_batch), one mailbox word per tensor, results sized
+        # after the window and — in exact mode — filled by ONE batched copy; declined tensors come back as None
+        seen.pop("fail")
+        xs = [torch.randint(1, 1000, (16 + 8 * i, 64), generator=g, dtype=torch.int16) * (torch.rand(16 + 8 * i, 64, generator=g) < 0.2 + 0.15 * i) for i in range(5)]
+        xs.insert(2, xs[0].t())  # a view: not taken
+        xs.append(torch.randint(1, 9, (8, 64), generator=g, dtype=torch.int32))  # another element size: a window of its own
+        launches, copies = [], []
+
+        def batch_plan(items, n, ws_bytes):
+            rows = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_int64)), (n, 15))
+            if seen.get("fail"):
+                return -1
+            rows[:, 9] = np.arange(n)  # first_block: one "workgroup" per item in this stand-in
+            ctypes.c_int64.from_address(ws_bytes).value = 64 * n
+            return n
+
+        def batch_launch(items, n, blocks, es, ws, ws_bytes, stream):
+            rows = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_int64)), (n, 15)).copy()
+            launches.append((n, es, [int(t - host) for t in rows[:, 4]], stream, ws_bytes))
+            for r in rows:
+                x, values, bitmask, ro, total, nrows, ncols, cap, dt = (int(v) for v in r[:9])
+                ctype, npdt = (ctypes.c_int16, np.int16) if es == 2 else (ctypes.c_int32, np.int32)
+                a = np.ctypeslib.as_array(ctypes.cast(x, ctypes.POINTER(ctype)), (nrows, ncols))
+                keep = a != 0
+                nnz = int(keep.sum())
+                np.ctypeslib.as_array(ctypes.cast(values, ctypes.POINTER(ctype)), (cap,))[:nnz] = a[keep]
+                np.ctypeslib.as_array(ctypes.cast(bitmask, ctypes.POINTER(ctypes.c_uint8)), (nrows, (ncols + 7) // 8))[:] = np.packbits(keep, axis=1, bitorder="little")
+                np.ctypeslib.as_array(ctypes.cast(ro, ctypes.POINTER(ctypes.c_int64)), (nrows,))[:] = np.concatenate([[0], np.cumsum(keep.sum(1))[:-1]])
+                ctypes.c_int64.from_address(total).value = nnz
+            return 0
+
+        def copy_plan(items, n):
+            rows = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_int64)), (n, 4))
+            rows[:, 3] = np.arange(n)
+            return n
+
+        def copy_launch(items, n, blocks, stream):
+            rows = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_int64)), (n, 4))
+            copies.append(n)
+            for src, dst, nbytes, _ in rows.tolist():
+                ctypes.memmove(dst, src, nbytes)
+            return 0
+
+        cbs["ct_bitmask_batch_plan"] = ctypes.CFUNCTYPE(L, V, I, V)(batch_plan)
+        cbs["ct_bitmask_compress_batch"] = ctypes.CFUNCTYPE(I, V, I, L, I, V, L, V)(batch_launch)
+        cbs["ct_copy_batch_plan"] = ctypes.CFUNCTYPE(L, V, I)(copy_plan)
+        cbs["ct_copy_batch"] = ctypes.CFUNCTYPE(I, V, I, L, V)(copy_launch)
+        hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
+        dts = [7] * 6 + [4]  # (int16 rides the code of int64 in this stand-in's `dt` slot: it is only handed through; int32: 4)
+        for exact in (True, False):
+            for budget in (1 << 30, 1):  # 1 byte: every window holds exactly one tensor
+                launches.clear()
+                copies.clear()
+                r = hp.bitmask_compress_many(xs, dts, host, host, 2, 6, 1234, exact, budget)
+                assert r[0] == 0 and len(r) == 1 + len(xs) and r[3] is None
+                got = [(n, es, words) for n, es, words, _, _ in launches]
+                if budget > 1:  # windows of <= 3 tensors, one element size each; two in flight: they take the two halves of the six words in turn
+                    assert got == [(3, 2, [16, 24, 32]), (2, 2, [40, 48]), (1, 4, [16])], got
+                else:
+                    assert got == [(1, 2, [16]), (1, 2, [40]), (1, 2, [16]), (1, 2, [40]), (1, 2, [16]), (1, 4, [40])], got
+                assert all(st == 1234 for _, _, _, st, _ in launches)
+                assert copies == ([n for n, _, _ in got] if exact else [])  # one batched copy per window, none for views
+                for x, res in zip(xs, r[1:]):
+                    if res is None:
+                        continue
+                    values, bitmask, ro = res
+                    keep = x != 0
+                    assert values.dtype == x.dtype and torch.equal(values, x[keep]) and torch.equal(ro, torch.cumsum(keep.sum(1), 0) - keep.sum(1))
+                    assert torch.equal(bitmask, torch.from_numpy(np.packbits(keep.numpy(), axis=1, bitorder="little")))
+                    assert values.untyped_storage().nbytes() == (x.element_size() * int(keep.sum()) if exact else x.element_size() * x.numel())
+        assert hp.bitmask_compress_many(xs, [7, 7, 7, -1, 7, 7, 4], host, host, 2, 6, 0, True, 1 << 20)[4] is None  # no element code: left to the caller
+        assert hp.bitmask_compress_many([xs[0].to(torch.int8)], [3], host, host, 2, 6, 0, True, 1 << 20) == [0, None]  # 8-bit payloads: the single-tensor path
+        seen["fail"] = True
+        assert hp.bitmask_compress_many(xs, dts, host, host, 2, 6, 0, True, 1 << 20) == [ctlib.CT_ERR_INVALID_ARG]
 
         w = torch.zeros(64, 256, dtype=torch.bfloat16)
         s = torch.ones(64, 2, dtype=torch.bfloat16)
