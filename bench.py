@@ -737,8 +737,46 @@ def bitmask_leg(dev):
         del sets32, v32, o32
     except Exception as e:
         f32 = {"f32_error": repr(e)}
+    # 8-bit payloads (FP8 / int8 weights, gathered as bytes): round 6 put them on the resident kernel's row form
+    i8 = {}
+    try:
+        I8, NI = _lib.I8, 8  # 8 x 67 MB of reads
+        sets8 = []
+        for _ in range(NI):
+            w = torch.randint(-127, 128, (N, N), device=dev, generator=g, dtype=torch.int16).to(torch.int8)
+            sets8.append(w.masked_fill_(torch.rand(N, N, device=dev, generator=g) < 0.5, 0))
+        v8 = torch.empty(N * N, dtype=torch.int8, device=dev)
+        bm8, ro8 = torch.empty(N, N // 8, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.int64, device=dev)
+        wk8 = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+        o8 = [torch.empty(N, N, dtype=torch.int8, device=dev) for _ in range(2)]
+
+        def c8(i):
+            lib.ct_bitmask_compress(sets8[i % NI].data_ptr(), I8, N, N, v8.data_ptr(), v8.numel(), bm8.data_ptr(), ro8.data_ptr(), wk8[-1:].data_ptr(), wk8.data_ptr(), ws_bytes, stream)
+
+        us_c8 = time_kernel(c8, 24)
+        c8(0)
+        torch.cuda.synchronize()
+        nnz8 = int(wk8[-1].item())
+        w0 = sets8[0]
+        m0 = w0 != 0
+        cnt0 = m0.sum(-1)
+        ok8 = (nnz8 == int(cnt0.sum().item()) and torch.equal(v8[:nnz8], w0[m0]) and torch.equal(ro8, torch.cumsum(cnt0, 0) - cnt0)
+               and torch.equal(bm8, (m0.view(N, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8)))
+
+        def d8(i):
+            lib.ct_bitmask_decompress(v8.data_ptr(), nnz8, bm8.data_ptr(), ro8.data_ptr(), -1, I8, N, N, o8[i % 2].data_ptr(), stream)
+
+        us_d8 = time_kernel(d8, 24)
+        ok8 = ok8 and torch.equal(o8[0], w0)
+        alg8 = N * N + nnz8 + N * N // 8 + 8 * N
+        i8 = {"i8_alg_bytes": alg8, "i8_compress_us": round(us_c8, 2), "i8_compress_frac_hbm": round(alg8 / us_c8 / 1e3 / HBM_PEAK_GBPS, 4),
+              "i8_decompress_us": round(us_d8, 2), "i8_decompress_frac_hbm": round(alg8 / us_d8 / 1e3 / HBM_PEAK_GBPS, 4), "i8_bit_exact": bool(ok8),
+              "i8_workload": f"sparse-bitmask 50 % unstructured {N}x{N} int8 (FP8 weights ride the same bytes), C ABI, {NI} rotating inputs; outputs against eager torch ops on the device"}
+        del sets8, v8, o8
+    except Exception as e:
+        i8 = {"i8_error": repr(e)}
     return {
-        **s24, **f32, **api,
+        **s24, **f32, **i8, **api,
         "workload": f"sparse-bitmask 50% unstructured {N}x{N} bf16 (nnz={nnz})",
         "alg_bytes": alg,
         "decompress_us": round(us_d, 2), "decompress_GBps": round(alg / us_d / 1e3, 1), "decompress_frac_hbm": round(alg / us_d / 1e3 / HBM_PEAK_GBPS, 4),
@@ -1062,6 +1100,9 @@ def roofline_rows(result):
         if "f32_compress_us" in b:
             row("flat16_resident_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, compress", b["f32_alg_bytes"], b["f32_compress_us"], bit_exact=b["f32_bit_exact"])
             row("bitmask_decompress16_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, decompress", b["f32_alg_bytes"], b["f32_decompress_us"], bit_exact=b["f32_bit_exact"])
+        if "i8_compress_us" in b:
+            row("flat16_resident_kernel<8-bit payloads, row form>", "sparse-bitmask 50 % 8192x8192 int8 / fp8 bytes, compress", b["i8_alg_bytes"], b["i8_compress_us"], bit_exact=b["i8_bit_exact"])
+            row("bitmask_decompress_kernel<8-bit payloads>", "sparse-bitmask 50 % 8192x8192 int8 / fp8 bytes, decompress", b["i8_alg_bytes"], b["i8_decompress_us"], bit_exact=b["i8_bit_exact"])
     k4 = leg("kernels_4096")
     if k4:
         pb = k4.get("pair_batch") or {}

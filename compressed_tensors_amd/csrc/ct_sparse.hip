@@ -827,9 +827,22 @@ __device__ __forceinline__ uint32_t nz_mask16_fast(const u32x4& r, uint32_t keep
 __device__ __forceinline__ uint32_t nz_mask32_pairs(const u32x4& r, uint32_t keep) {
     return ((r.x & keep) ? 0x03u : 0u) | ((r.y & keep) ? 0x0cu : 0u) | ((r.z & keep) ? 0x30u : 0u) | ((r.w & keep) ? 0xc0u : 0u);
 }
+// 8-bit payloads (round 6): one flag per BYTE of the unit, byte j of dword k -> bit 4 k + j (only counted: the row form makes its own masks)
+__device__ __forceinline__ uint32_t nz_mask8(const u32x4& r) {
+    const uint32_t ws[4] = {r.x, r.y, r.z, r.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t w = ws[k];
+        const uint32_t nzb = ((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w;  // bit 7 of each byte: the byte is non-zero
+        m |= (((nzb >> 7) & 1u) | ((nzb >> 14) & 2u) | ((nzb >> 21) & 4u) | ((nzb >> 28) & 8u)) << (4 * k);
+    }
+    return m;
+}
 template <int ES>
 __device__ __forceinline__ uint32_t nz_mask_unit(const u32x4& r, uint32_t keep) {
     if constexpr (ES == 4) return nz_mask32_pairs(r, keep);
+    else if constexpr (ES == 1) return nz_mask8(r);
     else return nz_mask16_fast(r, keep);
 }
 // a doubled mask byte -> the element nibble (bits 0, 2, 4, 6)
@@ -1109,6 +1122,7 @@ __device__ __forceinline__ unsigned long long op_load(const unsigned long long* 
 #define CT_STAMP_T0(k) (void)0
 #endif
 typedef u32x4 u32x4_a2_t __attribute__((aligned(2)));
+typedef u32x4 u32x4_a1_t __attribute__((aligned(1)));
 typedef u32x2 u32x2_a1_t __attribute__((aligned(1)));
 constexpr int kResKeep = 4;       // wave-tiles a wave keeps in registers (16 KB, 64 VGPRs)
 constexpr int kResWaves = 8;      // waves per workgroup: ~106 VGPRs -> 4 waves per SIMD = two workgroups per CU
@@ -1143,6 +1157,10 @@ __device__ __forceinline__ void flat16_resident_body(const int b, const int nwg,
     const int64_t wt0 = ((int64_t)b * WAVES + wave) * tpw;  // tpw <= KEEP wave-tiles per wave
     const uint32_t keepbits = is_float ? (ES == 4 ? 0x7fffffffu : 0x7fff7fffu) : 0xffffffffu;
     constexpr int SH = ES == 4 ? 1 : 0;  // halves per element, as a shift
+    // round 6, ES = 1 (the row form only): everything downstream of the compaction counts in GRANULES — 16-bit halves for 16- / 32-bit payloads,
+    // BYTES for 8-bit ones (`capacity`, the count words, the running totals, the offsets into `vout`); a 16-byte vector holds GPV of them
+    static_assert(ES != 1 || ROWB, "8-bit payloads take the row form");
+    constexpr int GRB = ES == 1 ? 1 : 2, GPV = 16 / GRB;
     if (tid == 0) s_nmiss = 0;
     // ---- stagger: the workgroups of the first residency round start their loads spread over one load phase (workgroup b waits
     // stagger_ticks + (b - stagger_lo) x slope), so that from then on a CU's two workgroups — and the chip as a whole — read, compute /
@@ -1206,7 +1224,7 @@ __device__ __forceinline__ void flat16_resident_body(const int b, const int nwg,
         u32x4* slab_w = reinterpret_cast<u32x4*>(s_val[wave]);
         const uint32_t slab_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)slab_a);  // wave-uniform: the row addresses are SGPR + lane offset
         const uint32_t lane_e = (uint32_t)lane * (uint32_t)ES;
-        const uint32_t ekeep = ES == 4 ? keepbits : (keepbits & 0xffffu);
+        const uint32_t ekeep = ES == 4 ? keepbits : (ES == 2 ? (keepbits & 0xffffu) : 0xffu);
 #pragma unroll
         for (int i = 0; i < KEEP; ++i) {
             const uint32_t t_u0 = (uint32_t)(wt0 * kWT) + (uint32_t)(i * kWT);  // the tile's first unit inside the chunk
@@ -1221,25 +1239,31 @@ __device__ __forceinline__ void flat16_resident_body(const int b, const int nwg,
             uint32_t lo = 0, hi = 0;
             int run = 0;
             if (any) {
-                elem_t v[RROWS];
+                // (8-bit payloads: 64 rows per tile — read and compacted 32 rows at a time, so that the rows in flight stay 32 registers; the
+                // survivors of rows [0, 32) land at or below row 32's start, never on a row that has not been read yet)
+                constexpr int RCH = RROWS > 32 ? 32 : RROWS;
 #pragma unroll
-                for (int r = 0; r < RROWS; ++r) v[r] = *(lds_elem_t*)(uintptr_t)(slab_s + (uint32_t)(r * 64 * ES) + lane_e);  // every read precedes the first in-place write
+                for (int c0 = 0; c0 < RROWS; c0 += RCH) {
+                    elem_t v[RCH];
 #pragma unroll
-                for (int r = 0; r < RROWS; ++r) {
-                    const uint32_t row_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slab_s + (uint32_t)run * (uint32_t)ES));  // stays scalar
-                    const bool nzr = ((uint32_t)v[r] & ekeep) != 0u;
-                    const unsigned long long m = __ballot(nzr);
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (nzr) *(lds_elem_t*)(uintptr_t)(rank * (uint32_t)ES + row_base) = v[r];
-                    run += __popcll(m);
-                    // lane r keeps row r's flags (this clang has no writelane builtin; the ballot lives in an SGPR pair)
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)m), "n"(r));
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(m >> 32)), "n"(r));
+                    for (int r = 0; r < RCH; ++r) v[r] = *(lds_elem_t*)(uintptr_t)(slab_s + (uint32_t)((c0 + r) * 64 * ES) + lane_e);  // every read of the chunk precedes its first in-place write
+#pragma unroll
+                    for (int r = 0; r < RCH; ++r) {
+                        const uint32_t row_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(slab_s + (uint32_t)run * (uint32_t)ES));  // stays scalar
+                        const bool nzr = ((uint32_t)v[r] & ekeep) != 0u;
+                        const unsigned long long m = __ballot(nzr);
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (nzr) *(lds_elem_t*)(uintptr_t)(rank * (uint32_t)ES + row_base) = v[r];
+                        run += __popcll(m);
+                        // lane r keeps row r's flags (this clang has no writelane builtin; the ballot lives in an SGPR pair)
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)m), "n"(c0 + r));
+                        asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(m >> 32)), "n"(c0 + r));
+                    }
                 }
             }
             mlo[i] = lo;
             mhi[i] = hi;
-            tot[i] = run << SH;  // in 16-bit halves, as everything downstream counts
+            tot[i] = run << SH;  // in granules (16-bit halves; bytes for 8-bit payloads), as everything downstream counts
             cnt += tot[i];
 #pragma unroll
             for (int q = 0; q < 4; ++q) keep[i][q] = slab_v[q * 64 + lane];  // vector q * 64 + lane of the compacted tile (garbage past tot)
@@ -1335,14 +1359,14 @@ __device__ __forceinline__ void flat16_resident_body(const int b, const int nwg,
             if (i < tpw && wt * kWT < units && lane < RROWS) {
                 // a mask byte covers 8 elements: one 16-bit unit, or two 32-bit units
                 const int64_t ub = wt * kWT + (int64_t)lane * UPROW;  // first unit of this lane's row
-                uint8_t* dst = bitmask + (ES == 4 ? (ub >> 1) : ub);
+                uint8_t* dst = bitmask + (ES == 4 ? (ub >> 1) : (ES == 1 ? ub * 2 : ub));  // a mask byte: two 32-bit units / one 16-bit unit / half an 8-bit unit
                 if ((wt + 1) * kWT <= units) {
                     *reinterpret_cast<u32x2_a1_t*>(dst) = u32x2{mlo[i], mhi[i]};
                 } else {
                     const unsigned long long mm = ((unsigned long long)mhi[i] << 32) | mlo[i];
 #pragma unroll
                     for (int t = 0; t < 8; ++t)
-                        if (ub + (ES == 4 ? 2 * t : t) < units) dst[t] = (uint8_t)(mm >> (8 * t));
+                        if (ub + (ES == 4 ? 2 * t : (ES == 1 ? t / 2 : t)) < units) dst[t] = (uint8_t)(mm >> (8 * t));
                 }
             }
         }
@@ -1472,17 +1496,24 @@ __device__ __forceinline__ void flat16_resident_body(const int b, const int nwg,
                     if (lane == l) row_offsets[next_r] = (row_offsets[next_r] + run) >> SH;
                 }
             }
-            const int64_t lim = run + total < capacity ? run + total : capacity;  // one past the last element this tile may write
+            const int64_t lim = run + total < capacity ? run + total : capacity;  // one past the last granule this tile may write
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int64_t gi = run + ((int64_t)(q * 64 + lane) << 3);
-                if (gi + 8 <= lim) {
-                    __builtin_nontemporal_store(keep[i][q], reinterpret_cast<u32x4_a2_t*>(vout + gi));  // 2-byte aligned
+                const int64_t gi = run + (int64_t)(q * 64 + lane) * GPV;
+                if (gi + GPV <= lim) {
+                    if constexpr (GRB == 1) __builtin_nontemporal_store(keep[i][q], reinterpret_cast<u32x4_a1_t*>(reinterpret_cast<uint8_t*>(vout) + gi));  // 1-byte aligned
+                    else __builtin_nontemporal_store(keep[i][q], reinterpret_cast<u32x4_a2_t*>(vout + gi));  // 2-byte aligned
                 } else if (gi < lim) {
                     const uint32_t ws[4] = {keep[i][q].x, keep[i][q].y, keep[i][q].z, keep[i][q].w};
+                    if constexpr (GRB == 1) {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        if (gi + t < lim) vout[gi + t] = (uint16_t)((t & 1) ? (ws[t >> 1] >> 16) : ws[t >> 1]);
+                        for (int t = 0; t < 16; ++t)
+                            if (gi + t < lim) reinterpret_cast<uint8_t*>(vout)[gi + t] = (uint8_t)(ws[t >> 2] >> (8 * (t & 3)));
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            if (gi + t < lim) vout[gi + t] = (uint16_t)((t & 1) ? (ws[t >> 1] >> 16) : ws[t >> 1]);
+                    }
                 }
             }
             run += total;
@@ -1533,9 +1564,9 @@ __global__ __launch_bounds__(kResWaves * 64, 4) void flat16_resident_batch_kerne
         if (items[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const ct_bitmask_item it = items[lo];  // by value: every field is read here, ahead of any store
-    flat16_resident_body<kResKeep, kResWaves, ES, ES == 4 ? 1 : 0>(
+    flat16_resident_body<kResKeep, kResWaves, ES, ES == 2 ? 0 : 1>(
         (int)((int64_t)blockIdx.x - it.first_block), it.nwg, as_global(static_cast<const u32x4*>(it.x)), it.is_float != 0, it.units, it.upr, it.rows, it.tpw,
-        as_global(static_cast<uint16_t*>(it.values)), it.values_capacity * (ES / 2), as_global(it.bitmask), it.mask_dwords, as_global(it.row_offsets), 0, nullptr,
+        as_global(static_cast<uint16_t*>(it.values)), it.values_capacity * (ES == 4 ? 2 : 1), as_global(it.bitmask), it.mask_dwords, as_global(it.row_offsets), 0, nullptr,
         workspace + it.slots_offset, as_global(reinterpret_cast<unsigned long long*>(it.total)), it.gen, wait_ticks, CT_STAMPS_ARG(nullptr) 0, 0, 0u, 0u, 0, nullptr);
 }
 
@@ -1888,7 +1919,8 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
 #else
     constexpr int resident_mode = 1;
 #endif
-    if ((es == 2 || es == 4) && cols % 8 == 0 && aligned16(x) && resident_mode) {
+    // (round 6: 8-bit payloads — FP8 / int8 weights viewed as bytes — ride the row form too: a unit is 16 elements, the counts are in bytes)
+    if ((((es == 2 || es == 4) && cols % 8 == 0) || (es == 1 && cols % 16 == 0)) && aligned16(x) && resident_mode) {
         const int64_t upr = cols * es / 16;  // 16-byte units per row
         const int64_t units = rows * upr;
         const int64_t wts = cdiv64(units, kWT);
@@ -1946,7 +1978,7 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 const int64_t u0 = w0 * kWT;
                 const int64_t cu = (units - u0) < cw * kWT ? (units - u0) : cw * kWT;
                 const int64_t nwg = cdiv64(cw, wg_wts);
-                uint8_t* bm0 = bitmask + (es == 4 ? u0 / 2 : u0);  // a mask byte covers one 16-bit unit or two 32-bit units
+                uint8_t* bm0 = bitmask + (es == 4 ? u0 / 2 : (es == 1 ? u0 * 2 : u0));  // a mask byte covers one 16-bit unit, two 32-bit units or half an 8-bit unit
                 const int mask_dwords = (es == 4 || cu % 4 == 0) && ((reinterpret_cast<uintptr_t>(bm0) & 3u) == 0);
                 // the chunk's running total: straight into *total for the last chunk, else into one of two alternating workspace words
                 unsigned long long* run_out = k + 1 == nchunks ? reinterpret_cast<unsigned long long*>(total) : ctl + 2 + (k & 1);
@@ -1968,11 +2000,12 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
 #define CT_RESIDENT_W(ES_, W_, R_)                                                                                                                \
     hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, W_, ES_, R_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                   \
                        static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
-                       values_capacity * (ES_ / 2), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out,        \
+                       values_capacity * (ES_ == 4 ? 2 : 1), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out, \
                        tag_of(gen0 + (uint32_t)k), wait_ticks, CT_STAMPS_ARG(k == 0 ? stamps : nullptr) stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
                        round_wgs, round_words)
-                if (es == 4) CT_RESIDENT_W(4, kResWaves, 1);  // the row form: 69 % against 65 % of the HBM peak at 8192^2 float32
-                else CT_RESIDENT_W(2, kResWaves, 0);          // the unit form: the row form is scalar-bound at 32 rows per tile
+                if (es == 4) CT_RESIDENT_W(4, kResWaves, 1);       // the row form: 69 % against 65 % of the HBM peak at 8192^2 float32
+                else if (es == 1) CT_RESIDENT_W(1, kResWaves, 1);  // 8-bit payloads: the row form, 64 rows per tile
+                else CT_RESIDENT_W(2, kResWaves, 0);               // the unit form: the row form is scalar-bound at 32 rows per tile
 #undef CT_RESIDENT_W
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
@@ -2028,11 +2061,11 @@ int64_t ct_bitmask_batch_plan(ct_bitmask_item* items, int n, int64_t* workspace_
     for (int i = 0; i < n; ++i) {
         ct_bitmask_item& it = items[i];
         const int es = dt_size(it.dt);
-        const bool ok = (es == 2 || es == 4) && es == es0 && it.rows > 0 && it.cols > 0 && it.cols % 8 == 0 && it.x && it.values && it.bitmask && it.row_offsets && it.total &&
+        const bool ok = (es == 1 || es == 2 || es == 4) && es == es0 && it.rows > 0 && it.cols > 0 && it.cols % (es == 1 ? 16 : 8) == 0 && it.x && it.values && it.bitmask && it.row_offsets && it.total &&
                         aligned16(it.x) && aligned16(it.values) && it.values_capacity >= 0 && (reinterpret_cast<uintptr_t>(it.total) & 7u) == 0;
         if (!ok) {
-            set_error("ct_bitmask_batch_plan: item %d (rows %lld, cols %lld, dtype %d) is not eligible for the batched sparse-bitmask compress (16- or 32-bit "
-                      "payloads of ONE element size per table, cols %% 8 == 0, non-empty, x / values 16-byte aligned, no NULL pointer)", i, (long long)it.rows,
+            set_error("ct_bitmask_batch_plan: item %d (rows %lld, cols %lld, dtype %d) is not eligible for the batched sparse-bitmask compress (8-, 16- or 32-bit "
+                      "payloads of ONE element size per table, cols x element size %% 16 == 0, non-empty, x / values 16-byte aligned, no NULL pointer)", i, (long long)it.rows,
                       (long long)it.cols, it.dt);
             return -1;
         }
@@ -2067,12 +2100,15 @@ int64_t ct_bitmask_batch_plan(ct_bitmask_item* items, int n, int64_t* workspace_
 
 int ct_bitmask_compress_batch(const ct_bitmask_item* items_dev, int n, int64_t total_blocks, int element_size, void* workspace, int64_t workspace_bytes,
                               ct_stream_t stream) {
-    CT_REQUIRE(element_size == 2 || element_size == 4, "batched sparse-bitmask compress: 16- or 32-bit payloads, got element size %d", element_size);
+    CT_REQUIRE(element_size == 1 || element_size == 2 || element_size == 4, "batched sparse-bitmask compress: 8-, 16- or 32-bit payloads, got element size %d", element_size);
     CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
     if (n == 0 || total_blocks == 0) return CT_OK;
     CT_REQUIRE(items_dev != nullptr && workspace != nullptr && workspace_bytes >= 16 && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "table / workspace NULL or misaligned");
     constexpr unsigned long long wait_ticks = 2000ull * 100ull;  // 100 MHz ticks: 2 ms, then self-help (as the single-tensor launch)
-    if (element_size == 4)
+    if (element_size == 1)
+        hipLaunchKernelGGL((flat16_resident_batch_kernel<1>), dim3((unsigned)total_blocks), dim3(kResWaves * 64), 0, as_stream(stream), items_dev, n,
+                           static_cast<unsigned long long*>(workspace), wait_ticks);
+    else if (element_size == 4)
         hipLaunchKernelGGL((flat16_resident_batch_kernel<4>), dim3((unsigned)total_blocks), dim3(kResWaves * 64), 0, as_stream(stream), items_dev, n,
                            static_cast<unsigned long long*>(workspace), wait_ticks);
     else

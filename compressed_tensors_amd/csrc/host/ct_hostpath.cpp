@@ -601,7 +601,7 @@ py::object bitmask_compress(const at::Tensor& x, int dt, uintptr_t mailbox_host,
 // one launch and one wait per window.  `exact`: the kernel writes into ONE worst-case arena and every `values` is an exact-size allocation
 // filled by ONE batched copy (ct_copy_batch); otherwise every tensor gets its own worst-case buffer and `values` is a view of it.
 // A window ends after `nwords` tensors, `arena_budget` bytes of worst-case space (never less than one tensor), or a change of element size
-// (a table holds ONE element size).  `dts[i]` < 0, 8-bit payloads and whatever the single-tensor path would decline -> None at that position
+// (a table holds ONE element size).  `dts[i]` < 0, rows that are not whole 16-byte units and whatever the single-tensor path would decline -> None at that position
 // (the Python caller takes those one by one).
 at::Tensor upload_words(const std::vector<int64_t>& v, const at::TensorOptions& dev_opts) {
     // pinned staging: the copy is asynchronous and the caching host allocator recycles the block only when the copy has completed
@@ -636,8 +636,9 @@ py::list bitmask_compress_many(const std::vector<at::Tensor>& xs, const std::vec
     auto pad = [](int64_t b) { return (b + 255) / 256 * 256; };
     auto eligible = [&](size_t i) {
         const at::Tensor& x = xs[i];
-        return dts[i] >= 0 && (x.element_size() == 2 || x.element_size() == 4) && on_device(x) && x.dim() >= 1 && x.is_contiguous() &&
-               (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) == 0 && x.numel() > 0 && x.size(-1) % 8 == 0 && x.numel() * (int64_t)x.element_size() <= (int64_t(1) << 30);
+        const int64_t es = (int64_t)x.element_size();
+        return dts[i] >= 0 && (es == 1 || es == 2 || es == 4) && on_device(x) && x.dim() >= 1 && x.is_contiguous() &&
+               (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) == 0 && x.numel() > 0 && (x.size(-1) * es) % 16 == 0 && x.numel() * es <= (int64_t(1) << 30);
     };
     auto fail = [](int status) {
         py::list out;

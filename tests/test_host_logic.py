@@ -1017,7 +1017,7 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
                     assert torch.equal(bitmask, torch.from_numpy(np.packbits(keep.numpy(), axis=1, bitorder="little")))
                     assert values.untyped_storage().nbytes() == (x.element_size() * int(keep.sum()) if exact else x.element_size() * x.numel())
         assert hp.bitmask_compress_many(xs, [7, 7, 7, -1, 7, 7, 4], host, host, 2, 6, 0, True, 1 << 20)[4] is None  # no element code: left to the caller
-        assert hp.bitmask_compress_many([xs[0].to(torch.int8)], [3], host, host, 2, 6, 0, True, 1 << 20) == [0, None]  # 8-bit payloads: the single-tensor path
+        assert hp.bitmask_compress_many([xs[0][:, :36].contiguous()], [7], host, host, 2, 6, 0, True, 1 << 20) == [0, None]  # rows that are not whole 16-byte units: the single-tensor path
         seen["fail"] = True
         assert hp.bitmask_compress_many(xs, dts, host, host, 2, 6, 0, True, 1 << 20) == [ctlib.CT_ERR_INVALID_ARG]
 
