@@ -2058,6 +2058,14 @@ int64_t ct_bitmask_batch_plan(ct_bitmask_item* items, int n, int64_t* workspace_
     const int es0 = n > 0 ? dt_size(items[0].dt) : 2;
     auto tag_of = [](uint32_t c) { return 0x80000000u | (c % 0x7ffffffeu); };
     const uint32_t gen0 = resident_generation().fetch_add((uint32_t)(n > 0 ? n : 1)) + 1u;
+    // wave-tiles per wave.  A single tensor spreads thin (fewer tiles per wave) so that every CU gets a workgroup; a TABLE fills the chip with its
+    // tensors, and what limits it is bytes in flight per resident workgroup x 2 workgroups per CU / a workgroup's lifetime (a latency chain of
+    // ~8-12 us whatever it carries): with 1-2 tiles per wave (the single-tensor rule on 1-23 MB tensors) 154 tensors ran at 3.4 TB/s.  If the whole
+    // table still makes at least two residency rounds with full registers, every item takes kResKeep tiles per wave.
+    int64_t all_wts = 0;
+    for (int i = 0; i < n; ++i)
+        if (items[i].rows > 0 && items[i].cols > 0) all_wts += cdiv64(items[i].rows * (items[i].cols * dt_size(items[i].dt) / 16), kWT);
+    const bool full_tiles = all_wts >= (int64_t)2 * 2 * cus * kResWaves * kResKeep;
     for (int i = 0; i < n; ++i) {
         ct_bitmask_item& it = items[i];
         const int es = dt_size(it.dt);
@@ -2073,7 +2081,7 @@ int64_t ct_bitmask_batch_plan(ct_bitmask_item* items, int n, int64_t* workspace_
         it.upr = it.cols * es / 16;
         it.units = it.rows * it.upr;
         const int64_t wts = cdiv64(it.units, kWT);
-        int64_t tpw = cdiv64(wts, (int64_t)cus * 2 * kResWaves);  // as the single-tensor launch: as many tiles as the registers hold, fewer for a small tensor
+        int64_t tpw = full_tiles ? kResKeep : cdiv64(wts, (int64_t)cus * 2 * kResWaves);  // else as the single-tensor launch: fewer tiles for a small tensor
         if (tpw > kResKeep) tpw = kResKeep;
         if (tpw < 1) tpw = 1;
         const int64_t nwg = cdiv64(wts, (int64_t)kResWaves * tpw);

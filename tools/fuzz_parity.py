@@ -218,7 +218,7 @@ def case_batches(g):
     dt = rng.choice([BF16, F16])
     kind = rng.choice(["w4", "w4", "int8", "fp8"])
     n = rng.randint(1, 6)
-    ents, dents, refs, zps = [], [], [], []
+    ents, dents, refs, zps, carried = [], [], [], [], []
     bits = 4 if kind == "w4" else 8 if kind == "fp8" else rng.choice([8, 8, 6])
     for _ in range(n):
         rows = rng.choice([1, 3, 32, 33, 200])
@@ -253,7 +253,17 @@ def case_batches(g):
             refs.append((O.pack_to_int32(q, 4).contiguous(), O.dequantize(q, s, z)))
             packed = torch.empty((rows, cols // 8), dtype=torch.int32, device=dev)
             out = torch.empty((rows, cols), dtype=dt, device=dev)
-            ents.append((xd, sd, zd, packed, rows, cols, group)); dents.append((packed, sd, zd, out, rows, cols, group))
+            carry = z is not None and rng.random() < 0.6  # round 6: the stored zero points ride in the weights' launches (ct_w4_item.zp_packed)
+            zpp = torch.full((-(-rows * 4 // 32), z.shape[1]), -1, dtype=torch.int32, device=dev) if carry else None
+            ents.append((xd, sd, zd, packed, rows, cols, group, zpp))
+            if carry and codec.w4_packed_zp_readable(cols, group):
+                back = torch.full_like(zd, 77)
+                dents.append((packed, sd, back, out, rows, cols, group, zpp))
+                carried.append((zd, zpp, back, O.pack_to_int32(z, 4, packed_dim=0).contiguous()))
+            else:
+                dents.append((packed, sd, zd, out, rows, cols, group))
+                if carry:
+                    carried.append((zd, zpp, None, O.pack_to_int32(z, 4, packed_dim=0).contiguous()))
             if z is not None:
                 zp_packed = torch.empty((-(-rows * 4 // 32), z.shape[1]), dtype=torch.int32, device=dev)
                 zps.append((zd, zp_packed, torch.empty_like(zd), O.pack_to_int32(z, 4, packed_dim=0).contiguous()))
@@ -266,9 +276,11 @@ def case_batches(g):
             ents.append((xd, sd, zd, qd, rows, cols, group)); dents.append((qd, sd, zd, out, rows, cols, group))
     codec.W4Batch(ents, "compress", dt, kind=kind, bits=bits).launch()
     codec.W4Batch(dents, "decompress", dt, kind=kind).launch()
-    for (xd, sd, zd, code, rows, cols, group), (_, _, _, out, *_), (rq, rd) in zip(ents, dents, refs):
+    for (xd, sd, zd, code, rows, cols, group, *_), (_, _, _, out, *_), (rq, rd) in zip(ents, dents, refs):
         ok = eq_f8(code.cpu(), rq) if kind == "fp8" else torch.equal(code.cpu(), rq)
         assert ok and eq(out.cpu(), rd), ("batch", kind, dt, bits, rows, cols, group, zd is None)
+    for zd, zpp, back, ref in carried:
+        assert torch.equal(zpp.cpu(), ref) and (back is None or torch.equal(back, zd)), ("zp carried in the launch", tuple(zd.shape))
     if zps:
         codec.zp4_batch([(a, b) for a, b, _, _ in zps], "pack")
         codec.zp4_batch([(b, c) for _, b, c, _ in zps], "unpack")
@@ -276,7 +288,47 @@ def case_batches(g):
             assert torch.equal(b.cpu(), ref) and torch.equal(c, a), ("zp batch", tuple(a.shape))
 
 
-CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn, case_qparams_float, case_channel8, case_sparse24, case_marlin, case_batches, case_batches]
+def case_w4_zp(g):
+    """round 6: the single-module asymmetric W4 entries (stored zero points written / read by the weights' own launch) through the class"""
+    import compressed_tensors_amd as cta
+
+    dt = rng.choice([BF16, F16])
+    group = rng.choice([32, 64, 128, 128, 128, None])
+    rows = rng.choice([1, 7, 8, 20, 64, 129])
+    cols = (group or 32) * rng.choice([1, 2, 4, 8, 16])
+    x = rand_x((rows, cols), dt, g, allow_nonfinite=rng.random() < 0.3)
+    fin = torch.nan_to_num(x.float(), nan=0.0, posinf=1.0, neginf=-1.0).to(dt)
+    s, z = O.calculate_qparams_minmax(fin, num_bits=4, group_size=group, symmetric=False)
+    kw = dict(num_bits=4, strategy="group" if group else "channel", group_size=group)
+    ref_c = O.pack_quantized_compress({"weight": x, "weight_scale": s, "weight_zero_point": z}, symmetric=False, **kw)
+    ref_d = O.pack_quantized_decompress(ref_c, num_bits=4, strategy=kw["strategy"], symmetric=False)
+    args = cta.QuantizationArgs(num_bits=4, group_size=group, symmetric=False, strategy=kw["strategy"])
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    got_c = cta.PackedQuantizationCompressor.compress({"weight": x.to(dev), "weight_scale": s.to(dev), "weight_zero_point": z.to(dev)}, scheme)
+    assert torch.equal(got_c["weight_packed"].cpu(), ref_c["weight_packed"]) and torch.equal(got_c["weight_zero_point"].cpu(), ref_c["weight_zero_point"]), ("w4_zp compress", dt, rows, cols, group)
+    got_d = cta.PackedQuantizationCompressor.decompress(got_c, scheme)
+    assert eq(got_d["weight"].cpu(), ref_d["weight"]) and torch.equal(got_d["weight_zero_point"].cpu(), ref_d["weight_zero_point"]), ("w4_zp decompress", dt, rows, cols, group)
+
+
+def case_bitmask_many(g):
+    """round 6: a list of tensors through ONE table launch (8- / 16- / 32-bit payloads, exact-size results by the batched copy)"""
+    xs = []
+    for _ in range(rng.randint(1, 7)):
+        dt = rng.choice([BF16, F16, F32, torch.int8, BF16])
+        rows, cols = rng.choice([1, 3, 17, 64, 300]), rng.choice([8, 16, 24, 48, 64, 1008, 4096, 8192])
+        x = torch.randn((rows, cols), generator=g)
+        x = x.masked_fill(torch.rand((rows, cols), generator=g) < rng.choice([0.0, 0.1, 0.5, 0.9, 1.0]), 0)
+        xs.append((x * 50).to(dt) if dt == torch.int8 else x.to(dt))
+    exact = rng.random() < 0.7
+    got = codec.bitmask_compress_many([x.to(dev) for x in xs], exact=exact, arena_bytes=rng.choice([1, 1 << 16, 1 << 30]))
+    for x, (v, bm, ro) in zip(xs, got):
+        rv, rb, rro = O.bitmask_compress(x)
+        assert v.numel() == rv.numel() and torch.equal(v.cpu().view(torch.uint8), rv.view(torch.uint8)) and torch.equal(bm.cpu(), rb) and torch.equal(ro.cpu(), rro), ("bitmask many", x.dtype, tuple(x.shape))
+        if exact:
+            assert v.untyped_storage().nbytes() <= rv.numel() * x.element_size() + (2 << 20)
+
+
+CASES = [case_quant, case_quant, case_quant, case_pack, case_bitmask, case_bitmask, case_fp4, case_rtn, case_qparams_float, case_channel8, case_sparse24, case_marlin, case_batches, case_batches, case_w4_zp, case_bitmask_many]
 t0, n = time.time(), 0
 while time.time() - t0 < budget and n < max_cases:
     g = torch.Generator().manual_seed(rng.randint(0, 2 ** 31))
