@@ -1199,6 +1199,10 @@ def headline_line(result, cap=LINE_CAP):
                                              "ms_per_step_without_device_warmup"))
     rows_in = r.get("kernels", [])
     rows = [_pick(x, ("kernel", "config", "alg_bytes", "us", "min_us", "GBps", "frac", "valu_busy_frac")) for x in rows_in[:2]]  # the headline kernels
+    for x in rows:  # (say in the row itself that this one figure is not measured in the run)
+        if "valu_busy_frac" in x:
+            x["valu_busy_src"] = "committed SQ counter pass, not live"
+    line["value_note"] = "value: the step's two launches on two HIP streams; value_one_stream is the figure comparable with roofline.frac"
     for kernel, cfg_part, short in _HEADLINE_ROWS:
         hit = [x for x in rows_in[2:] if x.get("kernel", "").startswith(kernel) and cfg_part in x.get("config", "")]
         if kernel.endswith("decompress_model"):  # the symmetric row: its name is a prefix of the asymmetric one's

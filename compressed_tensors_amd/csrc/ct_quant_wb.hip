@@ -160,6 +160,8 @@ __global__ __launch_bounds__(kBlock) void wb_unpack_dequant_kernel(const uint32_
             if constexpr (HAS_ZP) z4[i] = *(const_u32_t)(uintptr_t)(zp + si0);
         }
     }
+    // (BITS <= 2: a window is 16 / 32 words, half a load instruction or less.  Letting the TWO windows of a lane's two units share one load —
+    // lanes [0, 32) window 0, lanes [32, 64) window 1 — measured SLOWER: W2 decompress 29.2 -> 30.9 us at 8192^2.  Round 6, dropped.)
 #pragma unroll
     for (int i = 0; i < UNROLL; ++i) {
         const int64_t u0 = base + (int64_t)i * kBlock - (int64_t)lane;

@@ -94,7 +94,9 @@ def swap_direct_entries(module: torch.nn.Module, remove, add: dict, status=None)
         if t is not None and t.requires_grad and name not in add:
             # a fresh Parameter, as upstream's replace_direct_state_dict makes for every staying entry: freezing the object in place
             # would also freeze it for any other holder (a tied bias, an optimizer's param group)
-            params[name] = _make_subclass(type(t) if isinstance(t, _Parameter) else _Parameter, t.data, False)
+            # (a plain torch.nn.Parameter whatever subclass the entry was, as upstream's `torch.nn.Parameter(data, requires_grad=False)` and as
+            # the non-plain path above, which calls upstream's function: the two paths of this function agree — ADVICE r05)
+            params[name] = _make_subclass(_Parameter, t.data, False)
     for name, value in add.items():
         params[name] = _make_subclass(_Parameter, value, False)  # == torch.nn.Parameter(value, requires_grad=False) for a plain tensor
     if status is not None:

@@ -237,6 +237,11 @@ def test_swap_direct_entries_equals_replace_direct_state_dict(cta, hooked):
         if hasattr(torch.nn, "Buffer"):
             lin.wrapped_buf = torch.nn.Buffer(torch.ones(2))
         lin.weight_g_idx = torch.nn.Parameter(torch.arange(8, dtype=torch.int32), requires_grad=False)
+
+        class Tagged(torch.nn.Parameter):  # a Parameter SUBCLASS that stays and is trainable: upstream re-creates it as a plain Parameter
+            pass
+
+        lin.tagged = Tagged(torch.ones(2), requires_grad=True)
         return lin
 
     for remove, add_fn in (
@@ -255,6 +260,7 @@ def test_swap_direct_entries_equals_replace_direct_state_dict(cta, hooked):
         # same names, kinds, trainability, shapes and dtypes; storage differs between the two copies, except for the added tensors
         strip = lambda st: ({k: v and (v[0], v[1], v[3], v[4]) for k, v in st[0].items()}, {k: v and v[0] for k, v in st[1].items()}, st[2])
         assert strip(sa) == strip(sb)
+        assert type(a._parameters["tagged"]) is torch.nn.Parameter and type(b._parameters["tagged"]) is torch.nn.Parameter and not b._parameters["tagged"].requires_grad
         assert list(a._parameters) == list(b._parameters) or set(a._parameters) == set(b._parameters)
         for k, v in add.items():
             assert b._parameters[k].data_ptr() == v.data_ptr() and a._parameters[k].data_ptr() == v.data_ptr()
