@@ -7,7 +7,7 @@
 #   bench      the driver's command: python bench.py --gpus 1 --steps 20 --warmup 5 (stdout -> bench.json, stderr -> bench.err)
 #   bench2     the same once more (-> bench_run2.json)
 #   profile    tools/profile_round.sh <tag> (kernel trace + FETCH / WRITE / SQ counter passes; -> gpurun_out/profile_<tag>/)
-#   exp:<args> python tools/exp_r05.py <args with ',' for spaces>   (-> exp_<args>.jsonl)
+#   exp:<args> python tools/archive/exp_r05.py <args with ',' for spaces>   (-> exp_<args>.jsonl)
 #   sh:<file>  bash <file> (an ad-hoc fragment under tools/scratch/: git-ignored, but it travels to the box — gpurun_out/ does not)
 TAG=${1:?tag}; shift
 O=gpurun_out/$TAG; mkdir -p "$O"
@@ -28,7 +28,7 @@ for k in r['roofline']['kernels']: print('  %-48s %-70s %8.2f us %.4f' % (k['ker
 print('cpu_baseline',{x:r['cpu_baseline'][x] for x in ('value','cores','kind')} if 'cpu_baseline' in r else None)
 ";;
     profile) bash tools/profile_round.sh $TAG > $O/profile.log 2>&1; echo "profile rc=$?";;
-    exp:*) a="${step#exp:}"; timeout 900 python tools/exp_r05.py ${a//,/ } >> "$O/exp_${a%%,*}.jsonl" 2>> $O/exp.err; echo "exp $a rc=$?"; tail -n 40 "$O/exp_${a%%,*}.jsonl";;
+    exp:*) a="${step#exp:}"; timeout 900 python tools/archive/exp_r05.py ${a//,/ } >> "$O/exp_${a%%,*}.jsonl" 2>> $O/exp.err; echo "exp $a rc=$?"; tail -n 40 "$O/exp_${a%%,*}.jsonl";;
     sh:*) bash "${step#sh:}"; echo "sh rc=$?";;
     *) echo "unknown step $step";;
   esac
