@@ -24,9 +24,10 @@ ALIAS = {
 def parse(path, counter):
     out = {}
     for line in open(path):
-        m = re.match(r"^(ct::.*?)\s+" + counter + r"\s+(\d+)\s+([\d.]+)\s*$", line)
+        # kernel, counter, dispatches, avg_value [, full_n, full_avg_value]: the figure at the kernel's largest grid when the summary has it
+        m = re.match(r"^(ct::.*?)\s+" + counter + r"\s+(\d+)\s+([\d.]+)(?:\s+(\d+)\s+([\d.]+))?\s*$", line)
         if m:
-            out[m.group(1).strip()] = float(m.group(3))
+            out[m.group(1).strip()] = float(m.group(5) if m.group(5) is not None else m.group(3))
     return out
 
 
@@ -39,7 +40,7 @@ def main():
     fetch.update(parse(f"{src}/headline_fetch.txt", "FETCH_SIZE"))
     write.update(parse(f"{src}/headline_write.txt", "WRITE_SIZE"))
     res = {"_source": f"{src}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py",
-           "_formula": "bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950 read under-count) + WRITE_SIZE * 1024"}
+           "_formula": "bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950 read under-count) + WRITE_SIZE * 1024; launches at the kernel's largest grid only"}
     try:
         res["_srchash"] = open(f"{src}/srchash").read().strip()  # the library the counters were collected on (bench.py flags a mismatch as stale)
     except OSError:

@@ -40,10 +40,22 @@ def main():
     except sqlite3.Error:
         crow = []
     if crow:
-        print("\n# PMC counters: average value per dispatch")
-        print(f"{'kernel':<92} {'counter':<24} {'dispatches':>10} {'avg_value':>16}")
+        # full_*: the dispatches at the kernel's LARGEST grid only (round 6: a kernel that the bench also launches on small tensors — the sparse
+        # compress on a TinyLlama-shaped checkpoint — would otherwise report a meaningless mixture as its bytes per launch)
+        full = {}
+        try:
+            for name, cname, n, avg in cur.execute(
+                    f"select c.kernel_name, c.counter_name, count(*), avg(c.value) from counters_collection c join (select kernel_name as kn, max(grid_size_x) as gx "
+                    f"from counters_collection group by kernel_name) m on c.kernel_name = m.kn and c.grid_size_x = m.gx {flt2.replace('kernel_name', 'c.kernel_name')} "
+                    f"group by c.kernel_name, c.counter_name"):
+                full[(name, cname)] = (n, avg)
+        except sqlite3.Error:
+            pass
+        print("\n# PMC counters: average value per dispatch (full_*: at the kernel's largest grid only)")
+        print(f"{'kernel':<92} {'counter':<24} {'dispatches':>10} {'avg_value':>16} {'full_n':>8} {'full_avg_value':>16}")
         for name, cname, n, avg in crow:
-            print(f"{short(name):<92} {cname:<24} {n:>10} {avg:>16.1f}")
+            fn, favg = full.get((name, cname), (n, avg))
+            print(f"{short(name):<92} {cname:<24} {n:>10} {avg:>16.1f} {fn:>8} {favg:>16.1f}")
 
 
 if __name__ == "__main__":
