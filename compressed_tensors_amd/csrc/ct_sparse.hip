@@ -601,6 +601,165 @@ __device__ __forceinline__ uint32_t double_bits16(uint32_t x) {
     return x | (x << 1);
 }
 
+// ------------------------------------------------------------------------------------------
+// 8-bit payloads (round 6): the same LDS-window decompress at BYTE granularity — FP8 / int8 weights of a sparse checkpoint, moved as raw
+// bytes.  A unit is still one 16-byte store = 16 elements = TWO mask bytes; a tile is 1024 units = 16384 columns of a row.  Mask side: a
+// lane owns 4 consecutive units = two mask dwords, popcounts them, a DPP wave scan + 4 wave totals rank every unit, the owner publishes
+// the unit's rank through LDS to the consumer lane (unit i * 256 + tid: a wave store instruction writes 1 KiB contiguous).  Value side:
+// the tile's value run is staged global -> LDS; output dword j of a unit (elements 4j .. 4j + 3) is a window of the run starting at byte
+// rank + popc(mask16 & ((1 << 4j) - 1)): two aligned LDS dwords and ONE v_perm_b32 whose selector — a 64-entry LDS table keyed by the
+// window's alignment (2 bits) and the four mask bits — funnel-shifts, places up to four kept bytes and zeroes the rest.
+// The general kernel (one element at a time through a per-row prefix) ran 8192^2 int8 at 47 us = 29 % of the HBM peak.
+// Needs cols % 64 == 0 (whole lanes of 4 units, dword-aligned mask rows), 16-byte aligned values / out, 4-byte aligned bitmask.
+// ------------------------------------------------------------------------------------------
+// UPL = units per lane (4, 2 or 1): a tile is 256 x UPL units, so that a row of 8192 (4096) columns — every FP8 weight of an 8K (4K) model — is ONE
+// FULL tile instead of half (a quarter) of a 16384-column one: with UPL = 4 at 8192 columns half the lanes idled through the barriers and the scan
+// (35.5 us at 8192^2).
+template <bool SINGLE, int UPL>
+__global__ __launch_bounds__(kBlock) void bitmask_decompress8_kernel(const uint8_t* __restrict__ vin, int64_t values_len, const uint8_t* __restrict__ bitmask,
+                                                                     const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz, int64_t rows, int64_t cols,
+                                                                     uint8_t* __restrict__ out) {
+    constexpr int kUnits = kBlock * UPL;   // units per tile
+    constexpr int kTile8 = kUnits * 16;    // elements per tile
+    __shared__ __attribute__((aligned(16))) uint8_t s_val[kTile8 + 64];
+    __shared__ uint32_t s_sel[64];  // v_perm_b32 selectors indexed by (window offset & 3) << 4 | mask nibble
+    __shared__ __attribute__((aligned(16))) uint16_t s_rank[kUnits];  // wave-local rank of every unit (< 1024 x UPL)
+    __shared__ __attribute__((aligned(16))) int s_tot[4];
+    __shared__ __attribute__((aligned(16))) int s_pre[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (threadIdx.x < 64) {  // visible after the first barrier below
+        const uint32_t x = threadIdx.x >> 4, nb = threadIdx.x & 15u;
+        uint32_t sel = 0, src = x;  // bytes 0-3 of the selector's source = the low dword, 4-7 the high dword; 0x0c = constant zero
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool keep = (nb >> k) & 1u;
+            sel |= (keep ? src : 0x0cu) << (8 * k);
+            src += keep ? 1u : 0u;
+        }
+        s_sel[threadIdx.x] = sel;
+    }
+    const int64_t bcols = cols >> 4;  // units per row
+    const int64_t tiles_per_row = (cols + kTile8 - 1) / kTile8;
+    const int64_t ntiles = rows * tiles_per_row;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = SINGLE ? tile : tile / tiles_per_row;
+        const int64_t u0 = SINGLE ? 0 : (tile - row * tiles_per_row) * kUnits;  // first unit of the tile in its row
+        const int64_t left = bcols - u0;
+        const int nu = left < kUnits ? (int)left : kUnits;                      // units in this tile
+        const uint8_t* mrow = bitmask + row * (cols >> 3);                      // two mask bytes per unit
+        // the lane's own UPL consecutive units UPL tid .. UPL tid + UPL - 1 (the rank side)
+        uint32_t own[UPL];
+#pragma unroll
+        for (int k = 0; k < UPL; ++k) own[k] = (UPL * tid + k < nu) ? (uint32_t)*reinterpret_cast<const uint16_t*>(mrow + 2 * (u0 + UPL * tid + k)) : 0u;
+        uint32_t mb[UPL];  // the consumer lane's units i * 256 + tid: their 16 mask bits in the low half, the window offsets of dwords 1-3 above them
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) {
+            const int64_t v = u0 + i * kBlock + tid;
+            const uint32_t m16 = (i * kBlock + tid < nu) ? (uint32_t)*reinterpret_cast<const uint16_t*>(mrow + 2 * v) : 0u;
+            // (consumed here, ahead of the LDS-direct loads: hipcc waits vmcnt(0) at the first use of an ordinary load while one of those is in flight)
+            mb[i] = m16 | ((uint32_t)__popc(m16 & 0xfu) << 16) | ((uint32_t)__popc(m16 & 0xffu) << 20) | ((uint32_t)__popc(m16 & 0xfffu) << 24);
+        }
+        int64_t run = row_offsets ? row_offsets[row] : row * fixed_row_nnz;
+        run = run < 0 ? 0 : (run > values_len ? values_len : run);
+
+        int shift = 0, nvec = 0;
+        int64_t e0 = 0;
+        auto stage_issue = [&](int total) {
+            shift = (int)(run & 15);
+            nvec = (shift + total + 15) >> 4;
+            e0 = run - shift;
+            const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
+#pragma unroll
+            for (int k = 0; k < UPL; ++k) {
+                const int v = tid + k * kBlock;
+                if (v < nvec && e0 + (int64_t)(v + 1) * 16 <= values_len)
+                    __builtin_amdgcn_global_load_lds(g + v, (__attribute__((address_space(3))) void*)(s_val + (k * kBlock + wave * 64) * 16), 16, 0, 0);
+            }
+        };
+        auto stage_commit = [&]() {
+#pragma unroll
+            for (int k = 0; k < UPL; ++k) {
+                const int v = tid + k * kBlock;
+                if (v < nvec && e0 + (int64_t)(v + 1) * 16 > values_len) {  // a tail vector that would cross the end of the buffer
+                    for (int j = 0; j < 16; ++j) {
+                        const int64_t gi = e0 + (int64_t)v * 16 + j;
+                        s_val[v * 16 + j] = gi < values_len ? vin[gi] : (uint8_t)0;
+                    }
+                }
+            }
+            if (tid == 0 && kUnits < nvec) {  // the one possible extra vector (shift > 0, full tile)
+                const int v = kUnits;
+                for (int j = 0; j < 16; ++j) {
+                    const int64_t gi = e0 + (int64_t)v * 16 + j;
+                    s_val[v * 16 + j] = gi < values_len ? vin[gi] : (uint8_t)0;
+                }
+            }
+        };
+
+        if constexpr (!SINGLE) {
+            int c = 0;  // popcount of the row's mask bytes before this tile
+            for (int64_t d = tid; d < (u0 >> 1); d += kBlock) c += __popc(reinterpret_cast<const uint32_t*>(mrow)[d]);
+            c = wave_incl_scan(c);
+            if (lane == 63) s_pre[wave] = c;
+        }
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < UPL; ++k) c += __popc(own[k]);
+        const int incl = wave_incl_scan(c);
+        if (lane == 63) s_tot[wave] = incl;
+        {
+            uint32_t r = (uint32_t)(incl - c);
+#pragma unroll
+            for (int k = 0; k < UPL; ++k) {
+                s_rank[UPL * tid + k] = (uint16_t)r;
+                r += __popc(own[k]);
+            }
+        }
+        if constexpr (SINGLE) {
+            int64_t row_end = values_len;
+            if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1]; }
+            else row_end = run + fixed_row_nnz;
+            int64_t len = row_end - run;
+            len = len < 0 ? 0 : (len > kTile8 ? kTile8 : len);
+            stage_issue((int)len);
+            stage_commit();
+        }
+        __syncthreads();
+        const int t0 = s_tot[0], t1 = s_tot[1], t2 = s_tot[2], t3 = s_tot[3];
+        if constexpr (!SINGLE) {
+            run += (int64_t)s_pre[0] + s_pre[1] + s_pre[2] + s_pre[3];
+            run = run > values_len ? values_len : run;
+            stage_issue(t0 + t1 + t2 + t3);
+            stage_commit();
+            __syncthreads();
+        }
+        const int wprefix[4] = {0, t0, t0 + t1, t0 + t1 + t2};  // values before wave w's units
+        const char* sv = reinterpret_cast<const char*>(s_val);
+        uint8_t* orow = out + row * cols + (u0 << 4);
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) {
+            const int u = i * kBlock + tid;
+            if (u >= nu) continue;
+            // the owner of unit u is lane u / UPL: wave (u / UPL) / 64
+            const int ow = (u / UPL) >> 6;
+            const int wb = ow == 0 ? wprefix[0] : (ow == 1 ? wprefix[1] : (ow == 2 ? wprefix[2] : wprefix[3]));
+            const uint32_t mv = mb[i] & 0xffffu;
+            const uint32_t a0 = (uint32_t)s_rank[u] + (uint32_t)(wb + shift);  // byte offset of the unit's first kept element in the staged run
+            const uint32_t offs[4] = {0u, (mb[i] >> 16) & 0xfu, (mb[i] >> 20) & 0xfu, (mb[i] >> 24) & 0xfu};
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t aj = a0 + offs[j];
+                const uint32_t a = aj & ~3u;
+                const uint32_t lo = *reinterpret_cast<const uint32_t*>(sv + a), hi = *reinterpret_cast<const uint32_t*>(sv + a + 4);
+                w[j] = __builtin_amdgcn_perm(hi, lo, s_sel[((aj & 3u) << 4) | ((mv >> (4 * j)) & 15u)]);
+            }
+            stream_store16(orow + ((int64_t)u << 4), u32x4{w[0], w[1], w[2], w[3]});
+        }
+        __syncthreads();
+    }
+}
+
 // ES = 4 (round 3): 32-bit payloads as pairs of 16-bit halves — the value run, the ranks, the windows and the stores are those of a
 // 16-bit tensor with twice the columns whose mask has every bit doubled; only the mask loads (half as many real bytes) and the
 // offsets (doubled on the way in) differ.
@@ -2179,6 +2338,24 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
         else { if (hcols <= kTile16) CT_DEC16(true, 2); else CT_DEC16(false, 2); }
 #undef CT_DEC16
         CT_LAUNCH_CHECK("ct_bitmask_decompress[16]");
+    }
+    // 8-bit payloads with row offsets (the unstructured codec): the byte-granular LDS-window kernel.  The 2:4 codec (fixed_row_nnz) keeps the general
+    // kernel, whose 2:4-regular row path turns 8 value bytes + their mask bits into one 16-byte store directly.
+    if (es == 1 && fixed_row_nnz < 0 && cols % 16 == 0 && (cols <= 16384 || cols % 64 == 0) && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0 &&
+        values_len < ((int64_t)1 << 61)) {
+        // units per lane: the smallest tile that holds a whole row (a row of <= 16384 columns is then ONE tile: SINGLE), else 16384-column tiles
+        const int upl = cols <= 4096 ? 1 : (cols <= 8192 ? 2 : 4);
+        const int64_t tiles = rows * cdiv64(cols, (int64_t)kBlock * upl * 16);
+        const unsigned grid8 = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));
+#define CT_DEC8(SINGLE_, UPL_)                                                                                                                             \
+    hipLaunchKernelGGL((bitmask_decompress8_kernel<SINGLE_, UPL_>), dim3(grid8), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(values), \
+                       values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint8_t*>(out))
+        if (upl == 1) CT_DEC8(true, 1);
+        else if (upl == 2) CT_DEC8(true, 2);
+        else if (cols <= 16384) CT_DEC8(true, 4);
+        else CT_DEC8(false, 4);
+#undef CT_DEC8
+        CT_LAUNCH_CHECK("ct_bitmask_decompress[8]");
     }
     // 4096 resident-ish workgroups, grid-strided over rows: measured best on MI355X (tools/kbench)
     const unsigned grid = (unsigned)(rows < 4096 ? rows : 4096);

@@ -1135,7 +1135,9 @@ def test_sparse_bitmask_8bit_payloads_take_the_resident_kernel(cta, dev, dtype):
     "FP8 viewed as int8 for the gather") — ride the one-pass resident kernel's row form when a row is whole 16-byte units (cols % 16 == 0): a unit is
     16 elements = two bitmask bytes, the counts are in bytes, values leave at byte granularity.  Against the CPU oracle and eager torch on the
     device: one workgroup, partial last tiles, rows that straddle tiles, all-zero / dense tensors, every density, 8192 x 8192 (two residency
-    rounds); cols % 16 != 0 keeps the count / scan / scatter form; the batched entry takes 8-bit tables too."""
+    rounds); cols % 16 != 0 keeps the count / scan / scatter form; the batched entry takes 8-bit tables too.  The decompress side takes the
+    byte-granular LDS-window kernel when cols % 64 == 0 (single-tile rows, rows of several 16384-column tiles, value runs that start at every
+    offset inside a 16-byte vector, a run that ends at the very end of the buffer)."""
     g = torch.Generator(device=dev).manual_seed(8)
 
     def make(r, c, dens):
@@ -1146,7 +1148,9 @@ def test_sparse_bitmask_8bit_payloads_take_the_resident_kernel(cta, dev, dtype):
         return raw.view(dtype) if dtype is not torch.int8 else raw
 
     cases = [(1, 16, 0.5), (3, 48, 0.3), (64, 256, 0.0), (257, 1008, 0.7), (2048, 2048, 0.5), (100, 64, 1.0), (33, 4096, 0.02), (5632, 2048, 0.5), (8192, 8192, 0.5),
-             (17, 40, 0.5), (64, 1000, 0.5)]  # the last two: cols % 16 != 0 -> count / scan / scatter
+             (17, 40, 0.5), (64, 1000, 0.5),  # these two: cols % 16 != 0 -> count / scan / scatter
+             (3, 16384, 0.5), (5, 32768 + 64, 0.4), (2, 65536, 0.95), (7, 16384 + 4096, 0.0),  # rows of one whole tile / several tiles of the byte-window decompress
+             (33, 4096, 0.5), (9, 4096 + 16, 0.6), (11, 8192 + 48, 0.5), (5, 12288, 0.3), (4, 16384 - 16, 0.8)]  # 1 / 2 / 4 units per lane, partial tiles
     ws = [make(*c) for c in cases]
     for w in ws:
         v, bm, ro = cta.codec.bitmask_compress(w)
