@@ -1704,16 +1704,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void flat16_resident_kernel(const u3
 // search over the running block count (wave-uniform scalar loads), then runs the body above with the row's fields; no stagger, no per-round
 // words (they serve single tensors of several residency rounds).
 // ------------------------------------------------------------------------------------------
-// a pointer read from the table is a GENERIC pointer to the compiler (flat_load / flat_store: counted by vmcnt AND lgkmcnt, which would tie the body's
-// loads to its LDS traffic); through an explicit global address space the uses become global_load / global_store, as for a kernel argument
-template <class T>
-__device__ __forceinline__ T* as_global(T* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_assume(!__builtin_amdgcn_is_shared((const void*)p) && !__builtin_amdgcn_is_private((const void*)p));  // InferAddressSpaces reads this
-#endif
-    return p;
-}
-
+// (A pointer read from the table is a GENERIC pointer to the compiler: the body's accesses become flat_load / flat_store here, as in the W4 table kernels
+// — counted by vmcnt AND lgkmcnt.  An address-space round trip, `__builtin_assume(!is_shared && !is_private)` and a by-value copy of the row ahead of every
+// store all left the flat ops in place with this hipcc; the table kernels reach 0.58-0.74 of the HBM peak with them.)
 template <int ES>
 __global__ __launch_bounds__(kResWaves * 64, 4) void flat16_resident_batch_kernel(const ct_bitmask_item* __restrict__ items, int n, unsigned long long* __restrict__ workspace,
                                                                               unsigned long long wait_ticks) {
@@ -1724,9 +1717,9 @@ __global__ __launch_bounds__(kResWaves * 64, 4) void flat16_resident_batch_kerne
     }
     const ct_bitmask_item it = items[lo];  // by value: every field is read here, ahead of any store
     flat16_resident_body<kResKeep, kResWaves, ES, ES == 2 ? 0 : 1>(
-        (int)((int64_t)blockIdx.x - it.first_block), it.nwg, as_global(static_cast<const u32x4*>(it.x)), it.is_float != 0, it.units, it.upr, it.rows, it.tpw,
-        as_global(static_cast<uint16_t*>(it.values)), it.values_capacity * (ES == 4 ? 2 : 1), as_global(it.bitmask), it.mask_dwords, as_global(it.row_offsets), 0, nullptr,
-        workspace + it.slots_offset, as_global(reinterpret_cast<unsigned long long*>(it.total)), it.gen, wait_ticks, CT_STAMPS_ARG(nullptr) 0, 0, 0u, 0u, 0, nullptr);
+        (int)((int64_t)blockIdx.x - it.first_block), it.nwg, static_cast<const u32x4*>(it.x), it.is_float != 0, it.units, it.upr, it.rows, it.tpw,
+        static_cast<uint16_t*>(it.values), it.values_capacity * (ES == 4 ? 2 : 1), it.bitmask, it.mask_dwords, it.row_offsets, 0, nullptr,
+        workspace + it.slots_offset, reinterpret_cast<unsigned long long*>(it.total), it.gen, wait_ticks, CT_STAMPS_ARG(nullptr) 0, 0, 0u, 0u, 0, nullptr);
 }
 
 // a table of byte ranges copied by one launch (ct_copy_batch: the exact-size `values` of a batch leave the worst-case arena): 16 KiB per workgroup
@@ -1738,8 +1731,8 @@ __global__ __launch_bounds__(kBlock) void copy_batch_kernel(const ct_copy_item* 
     }
     const ct_copy_item& it = items[lo];
     const int64_t off = ((int64_t)blockIdx.x - it.first_block) * (kBlock * 64);
-    const uint8_t* src = as_global(static_cast<const uint8_t*>(it.src)) + off;
-    uint8_t* dst = as_global(static_cast<uint8_t*>(it.dst)) + off;
+    const uint8_t* src = static_cast<const uint8_t*>(it.src) + off;
+    uint8_t* dst = static_cast<uint8_t*>(it.dst) + off;
     const int64_t left = it.bytes - off < (int64_t)kBlock * 64 ? it.bytes - off : (int64_t)kBlock * 64;
     if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
         u32x4 v[4];
