@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-RECORDED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[345]_bench_line_driver_command*.json")))
+RECORDED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3456]_bench_line_driver_command*.json")))
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
             "roofline", "cpu_baseline")
 ROOFLINE = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "alg_bytes_per_launch", "traffic_source", "step", "kernels")
