@@ -1229,11 +1229,12 @@ def headline_line(result, cap=LINE_CAP):
     rs = result.get("row_sharded")
     if isinstance(rs, dict):
         line["row_sharded"] = {**_pick(rs, ("ranks", "rows_this_rank", "error")),
-                               **{k: _pick(v, ("us_per_tensor", "GBps_all_ranks", "frac_of_hbm_peak_per_gpu", "sets", "shard_equals_slice_of_single_rank_result"))
+                               **{k: _pick(v, ("us_per_tensor", "GBps_all_ranks", "frac_of_hbm_peak_per_gpu", "us_per_tensor_hip_graph", "sets", "shard_equals_slice_of_single_rank_result"))
                                   for k, v in rs.items() if isinstance(v, dict)}}
     w4k = result.get("w4a16_4096")
     if isinstance(w4k, dict):
-        line["w4a16_4096"] = _pick(w4k, ("us_per_step", "GBps_all_ranks", "frac_of_hbm_peak_per_gpu", "ranks", "round_trip_equals_fake_quantize", "error"))
+        line["w4a16_4096"] = _pick(w4k, ("us_per_step", "GBps_all_ranks", "frac_of_hbm_peak_per_gpu", "us_per_step_hip_graph", "frac_of_hbm_peak_per_gpu_hip_graph", "ranks",
+                                         "round_trip_equals_fake_quantize", "error"))
     line["details"] = DETAILS_FILE
     text = json.dumps(line, separators=(",", ":"))
     while len(text) > cap and len(roof["kernels"]) > 2:  # never expected (the test holds recorded results to the cap): shed rows, not the contract
@@ -1680,6 +1681,39 @@ def timed_blocks(step, iters, barrier, allreduce_max):
     return per
 
 
+def graph_blocks(launch_step, iters, dev, barrier, allreduce_max):
+    """the same `iters` steps captured ONCE into a HIP graph (torch.cuda.CUDAGraph over the C-ABI launches: they allocate nothing and never
+    synchronise, so they are capturable) and replayed per timed block — what a C host with a launch-bound inner loop would do; BLOCKS replays between
+    barriers, max over ranks.  `launch_step(i, stream)` issues step i on the raw stream it is given.  Returns per-block seconds per step."""
+    from compressed_tensors_amd import _lib
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for i in range(4):
+            launch_step(i, _lib.stream_on(dev, side.cuda_stream))
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st = _lib.stream_on(dev, torch.cuda.current_stream(dev).cuda_stream)
+        for i in range(iters):
+            launch_step(i, st)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    per = []
+    for _ in range(BLOCKS):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        graph.replay()
+        torch.cuda.synchronize()
+        barrier()
+        per.append(allreduce_max(time.perf_counter() - t0) / iters)
+    return per
+
+
 def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters=MIN_LAUNCHES_PER_BLOCK):
     """SURVEY 8e for the single-tensor configs: ONE 8192x8192 tensor split by row blocks (`shard_rows`, multiples of 64
     rows) over the ranks — strong scaling, no data-path collective.  Config 2 (W4A16 compress + decompress of the rank's
@@ -1724,6 +1758,17 @@ def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters
     for i in range(nsets):  # every packed buffer populated, every output written once
         step2(i)
     per2 = timed_blocks(step2, iters, barrier, allreduce_max)
+
+    def step2_on(i, st):  # the same two launches on a given stream (for the graph capture)
+        rc = lib.ct_quant_pack(*ca[i % nsets][:-1], st) or lib.ct_unpack_dequant(*da[(i + nsets // 2) % nsets][:-1], st)
+        if rc:
+            _lib.check(rc)
+
+    try:
+        per2g = graph_blocks(step2_on, iters, dev, barrier, allreduce_max)
+    except Exception as e:  # a graph capture must never take the leg down
+        per2g = None
+        out["hip_graph_error"] = repr(e)
     # the single-rank result of tensor 0 (the plug-in's tensor-level calls on the WHOLE tensor) against what this rank's launches wrote
     w_full = rows_of_set(dev, 0, 0, N)
     s_full, z_full = codec.minmax_qparams(w_full, num_bits=BITS, group_size=GROUP, symmetric=True)
@@ -1736,6 +1781,8 @@ def row_shard_leg(dev, rank, world, barrier, allreduce_max, allreduce_min, iters
     out["w4a16"] = {"us_per_tensor": round(t2 * 1e6, 2), "GBps_all_ranks": round(alg2 / t2 / 1e9, 1),
                     "frac_of_hbm_peak_per_gpu": round(alg2 / t2 / 1e9 / world / HBM_PEAK_GBPS, 4),
                     "us_per_tensor_blocks": [round(x * 1e6, 2) for x in per2], "sets": nsets,
+                    "us_per_tensor_hip_graph": None if per2g is None else round(median(per2g) * 1e6, 2),  # the same steps replayed from ONE captured HIP graph
+                    "GBps_all_ranks_hip_graph": None if per2g is None else round(alg2 / median(per2g) / 1e9, 1),
                     "cache": f"HBM-cold: {nsets} rotating tensors, this rank's packed words {nsets * packed_bytes / 2 ** 20:.0f} MiB >= 2 x 256 MiB",
                     "shard_equals_slice_of_single_rank_result": bool(allreduce_min(1.0 if ok else 0.0) == 1.0)}
     del sets, ca, da
@@ -1813,6 +1860,16 @@ def w4_weak_leg(dev, n, rank, world, barrier, allreduce_max, steps=MIN_LAUNCHES_
     for i in range(nsets):
         step(i)
     per = timed_blocks(step, steps, barrier, allreduce_max)
+
+    def step_on(i, st):
+        rc = lib.ct_quant_pack(*ca[i % nsets][:-1], st) or lib.ct_unpack_dequant(*da[(i + nsets // 2) % nsets][:-1], st)
+        if rc:
+            _lib.check(rc)
+
+    try:
+        perg = graph_blocks(step_on, steps, dev, barrier, allreduce_max)
+    except Exception:
+        perg = None
     w, sc, zp, pk, o = sets[0]
     ok = torch.equal(o, codec.fake_quantize_tensor(w, sc, zp, num_bits=BITS, strategy="group", group_size=GROUP))
     t = median(per)
@@ -1820,6 +1877,8 @@ def w4_weak_leg(dev, n, rank, world, barrier, allreduce_max, steps=MIN_LAUNCHES_
     return {"workload": f"W4A16 g128 compress+decompress, one {n}x{n} bf16 weight shard per rank, C ABI, one stream, HBM-cold ({nsets} rotating sets)",
             "alg_bytes_per_step_per_gpu": alg, "us_per_step": round(t * 1e6, 2), "us_per_step_blocks": [round(x * 1e6, 2) for x in per],
             "GBps_all_ranks": round(world * alg / t / 1e9, 1), "frac_of_hbm_peak_per_gpu": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4),
+            "us_per_step_hip_graph": None if perg is None else round(median(perg) * 1e6, 2),  # the same steps replayed from ONE captured HIP graph
+            "frac_of_hbm_peak_per_gpu_hip_graph": None if perg is None else round(alg / median(perg) / 1e9 / HBM_PEAK_GBPS, 4),
             "ranks": world, "round_trip_equals_fake_quantize": bool(ok)}
 
 

@@ -1173,6 +1173,68 @@ def test_sparse_bitmask_8bit_payloads_take_the_resident_kernel(cta, dev, dtype):
         assert v.dtype == w.dtype and torch.equal(v.view(torch.uint8), sv.view(torch.uint8)) and torch.equal(bm, sbm) and torch.equal(ro, sro)
 
 
+def test_c_abi_launches_are_hip_graph_capturable(cta, dev):
+    """The compute entries allocate nothing and never synchronise, so a caller can capture a launch-bound sequence of them into a HIP graph and
+    replay it: W4 compress + decompress, W3, the sparse decompress, the 2:4 compress and — with its workspace cleared INSIDE the
+    graph, because a launch's generation tag is baked in at capture time — the one-pass sparse compress.  Replayed three times on changing
+    inputs: every output equal to the eager calls'."""
+    from compressed_tensors_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(12)
+    n, c = 1024, 2048
+    w = torch.randn(n, c, device=dev, generator=g).to(BF16)
+    sc, zp = cta.codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=False)
+    sc3, zp3 = cta.codec.minmax_qparams(w, num_bits=3, group_size=128, symmetric=True)
+    x = w * (torch.rand(n, c, device=dev, generator=g) < 0.5)
+    packed, out = torch.empty(n, c // 8, dtype=torch.int32, device=dev), torch.empty_like(w)
+    packed3, out3 = torch.empty(n, c * 3 // 32, dtype=torch.int32, device=dev), torch.empty_like(w)
+    vals, bm, ro = torch.empty(n * c, dtype=BF16, device=dev), torch.empty(n, c // 8, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.int64, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    wsb = int(lib.ct_bitmask_compress_workspace_bytes(n, c))
+    ws = torch.empty(wsb // 8 + 1, dtype=torch.int64, device=dev)
+    dense = torch.empty_like(w)
+    v24, bm24 = torch.empty(n, c // 2, dtype=BF16, device=dev), torch.empty(n, c // 8, dtype=torch.uint8, device=dev)
+    B, I8 = _lib.BF16, _lib.I8
+
+    def launches(stream):
+        rcs = [lib.ct_quant_pack(w.data_ptr(), B, sc.data_ptr(), B, zp.data_ptr(), I8, n, c, 1, 128, c // 128, None, 4, B, packed.data_ptr(), stream),
+               lib.ct_unpack_dequant(packed.data_ptr(), n, c // 8, c, 4, sc.data_ptr(), B, zp.data_ptr(), I8, 1, 128, c // 128, None, out.data_ptr(), B, stream),
+               lib.ct_quant_pack(w.data_ptr(), B, sc3.data_ptr(), B, None, -1, n, c, 1, 128, c // 128, None, 3, B, packed3.data_ptr(), stream),
+               lib.ct_unpack_dequant(packed3.data_ptr(), n, c * 3 // 32, c, 3, sc3.data_ptr(), B, None, -1, 1, 128, c // 128, None, out3.data_ptr(), B, stream)]
+        ws.zero_()  # (on the capture stream: a memset node in front of the sparse compress, so that no count word of an earlier replay carries this launch's tag)
+        rcs += [lib.ct_bitmask_compress(x.data_ptr(), B, n, c, vals.data_ptr(), n * c, bm.data_ptr(), ro.data_ptr(), total.data_ptr(), ws.data_ptr(), wsb, stream),
+                lib.ct_bitmask_decompress(vals.data_ptr(), n * c, bm.data_ptr(), ro.data_ptr(), -1, B, n, c, dense.data_ptr(), stream),
+                lib.ct_sparse24_compress(w.data_ptr(), B, n, c, v24.data_ptr(), bm24.data_ptr(), stream)]
+        assert not any(rcs), (rcs, _lib.last_error())
+
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        launches(_lib.stream_on(dev, side.cuda_stream))  # warm-up outside the capture
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        launches(_lib.stream_on(dev, torch.cuda.current_stream(dev).cuda_stream))
+    for rep in range(3):
+        w.copy_(torch.randn(n, c, device=dev, generator=g).to(BF16))
+        x.copy_(w * (torch.rand(n, c, device=dev, generator=g) < 0.2 + 0.3 * rep))
+        for t in (packed, out, packed3, out3, vals, bm, ro, dense, v24, bm24):
+            t.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        kw = dict(num_bits=4, strategy="group", group_size=128)
+        assert torch.equal(packed, cta.codec.quantize_and_pack(w, sc, zp, **kw)) and eq(out.cpu(), cta.codec.unpack_and_dequantize(packed, (n, c), sc, zp, num_bits=4).cpu())
+        assert torch.equal(packed3, cta.codec.quantize_and_pack(w, sc3, None, num_bits=3, strategy="group", group_size=128))
+        assert eq(out3.cpu(), cta.codec.unpack_and_dequantize(packed3, (n, c), sc3, None, num_bits=3).cpu())
+        rv, rbm, rro = cta.codec.bitmask_compress(x)
+        nnz = int(total)
+        assert nnz == rv.numel() and torch.equal(vals[:nnz], rv) and torch.equal(bm, rbm) and torch.equal(ro, rro), rep
+        assert torch.equal(dense.view(torch.int16), torch.where(x != 0, x, torch.zeros_like(x)).view(torch.int16))
+        r24 = cta.codec.sparse24_bitmask_compress(w)
+        assert torch.equal(v24.view(torch.int16), r24[0].view(torch.int16).reshape(v24.shape)) and torch.equal(bm24, r24[1])
+
+
 def test_bitmask_compress_batch_through_the_c_abi(cta, dev):
     """`ct_bitmask_batch_plan` + `ct_bitmask_compress_batch` + `ct_copy_batch` called the way a C host would (ctypes structures, no Python
     codec in between): a table of 16-bit tensors of very different sizes — one workgroup, a partial last tile, rows that are not a multiple
@@ -2340,6 +2402,7 @@ def test_bench_many_ranks_on_one_gpu(world):
     rs = out["row_sharded"]
     assert rs["ranks"] == world and rs["rows_this_rank"] == [0, 8192 // world]
     assert rs["w4a16"]["shard_equals_slice_of_single_rank_result"] is True and rs["w4a16"]["sets"] == 16 * world and rs["w4a16"]["GBps_all_ranks"] > 0
+    assert rs["w4a16"]["us_per_tensor_hip_graph"] > 0 and out["w4a16_4096"]["us_per_step_hip_graph"] > 0  # the same steps replayed from one captured HIP graph
     assert rs["sparse_bitmask"]["shard_equals_slice_of_single_rank_result"] is True and rs["sparse_bitmask"]["sets"] == 8 * world
     k4 = out["w4a16_4096"]
     assert k4["ranks"] == world and k4["round_trip_equals_fake_quantize"] is True and k4["GBps_all_ranks"] > 0
