@@ -1562,6 +1562,40 @@ def sparse_checkpoint_leg(dev):
              for a, b in zip(many, loop)) and torch.equal(many[5].decompress().view(torch.int16), ws[5].view(torch.int16))
     ok = ok and all(int(btot[i]) == loop[i].compressed.numel() and torch.equal(bouts[i][0][: int(btot[i])].view(torch.int16), loop[i].compressed.view(torch.int16))
                     and torch.equal(bouts[i][1], loop[i].bitmask) and torch.equal(bouts[i][2], loop[i].row_offsets) for i in range(0, len(ws), 7))
+    # the way back: loading the checkpoint.  154 single launches (C ABI, preallocated outputs) / one table launch / the class-level list call / tensor by tensor
+    dd = [torch.empty_like(w) for w in ws]
+    dargs = [(b.compressed.data_ptr(), b.compressed.numel(), b.bitmask.data_ptr(), b.row_offsets.data_ptr(), -1, BF16, w.shape[0], w.shape[1], o.data_ptr(), stream)
+             for b, w, o in zip(loop, ws, dd)]
+
+    def dkernels():
+        for a in dargs:
+            rc = lib.ct_bitmask_decompress(*a)
+            if rc:
+                _lib.check(rc)
+
+    t_dk = timed(dkernels)
+    dtab = (_lib.BitmaskDItem * len(ws))()
+    for i, (b, w, o) in enumerate(zip(loop, ws, dd)):
+        dtab[i].values, dtab[i].bitmask, dtab[i].row_offsets, dtab[i].out = b.compressed.data_ptr(), b.bitmask.data_ptr(), b.row_offsets.data_ptr(), o.data_ptr()
+        dtab[i].rows, dtab[i].cols, dtab[i].values_len, dtab[i].dt = w.shape[0], w.shape[1], b.compressed.numel(), BF16
+    dblocks = int(lib.ct_bitmask_decompress_batch_plan(ctypes.cast(dtab, ctypes.c_void_p), len(ws)))
+    if dblocks < 0:
+        raise RuntimeError(_lib.last_error())
+    dtable = torch.frombuffer(bytearray(bytes(dtab)), dtype=torch.uint8).to(dev)
+
+    def dbatch():
+        rc = lib.ct_bitmask_decompress_batch(dtable.data_ptr(), len(ws), dblocks, 2, stream)
+        if rc:
+            _lib.check(rc)
+
+    for o in dd:
+        o.zero_()
+    t_db = timed(dbatch)
+    ok = ok and all(torch.equal(o.view(torch.int16), w.view(torch.int16)) for o, w in zip(dd[::7], ws[::7]))
+    ditems = [(b.compressed, b.bitmask, w.shape, b.row_offsets) for b, w in zip(loop, ws)]
+    t_dmany = timed(lambda: keep.__setitem__("d", codec.bitmask_decompress_many(ditems)))
+    ok = ok and all(torch.equal(o.view(torch.int16), w.view(torch.int16)) for o, w in zip(keep["d"][::5], ws[::5]))
+    t_dloop = timed(lambda: keep.__setitem__("d", [b.decompress() for b in loop]), n=3)
     nnz = sum(int(b.compressed.numel()) for b in many)
     numel = sum(w.numel() for w in ws)
     alg = 2 * numel + 2 * nnz + numel // 8 + 8 * sum(w.shape[0] for w in ws)
@@ -1573,6 +1607,9 @@ def sparse_checkpoint_leg(dev):
             "ms_from_dense_many": round(t_many * 1e3, 4), "many_over_kernels": round(t_many / t_k, 3), "many_over_one_table_launch": round(t_many / t_b, 3),
             "ms_from_dense_many_view": round(t_many_view * 1e3, 4), "many_view_over_kernels": round(t_many_view / t_k, 3),
             "ms_from_dense_one_by_one": round(t_loop * 1e3, 4), "one_by_one_over_kernels": round(t_loop / t_k, 3),
+            "decompress_ms_kernels_only": round(t_dk * 1e3, 4), "decompress_ms_one_table_launch": round(t_db * 1e3, 4),
+            "decompress_one_table_launch_frac_hbm": round(alg / t_db / 1e9 / HBM_PEAK_GBPS, 4),
+            "decompress_ms_many": round(t_dmany * 1e3, 4), "decompress_ms_one_by_one": round(t_dloop * 1e3, 4), "decompress_many_over_kernels": round(t_dmany / t_dk, 3),
             "values_storage_bytes": stored, "nnz_bytes": 2 * nnz,
             "note": "exact mode (default) adds one device copy of the kept values per tensor (2 x nnz x 2 bytes of traffic that `kernels only` does not have); "
                     "the view mode skips it and pins a dense-sized buffer per tensor",

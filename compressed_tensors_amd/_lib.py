@@ -95,6 +95,8 @@ _PROTOTYPES = {
     "ct_bitmask_compress": ([_P, _I, _L, _L, _P, _L, _P, _P, _P, _P, _L, _S], _I),
     "ct_bitmask_batch_plan": ([_P, _I, _P], _L),
     "ct_bitmask_compress_batch": ([_P, _I, _L, _I, _P, _L, _S], _I),
+    "ct_bitmask_decompress_batch_plan": ([_P, _I], _L),
+    "ct_bitmask_decompress_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_copy_batch_plan": ([_P, _I], _L),
     "ct_copy_batch": ([_P, _I, _L, _S], _I),
     "ct_bitmask_row_popcount": ([_P, _L, _L, _P, _S], _I),
@@ -128,6 +130,12 @@ class BitmaskItem(ctypes.Structure):
     _fields_ = [("x", _P), ("values", _P), ("bitmask", _P), ("row_offsets", _P), ("total", _P), ("rows", _L), ("cols", _L), ("values_capacity", _L),
                 ("dt", _c.c_int32), ("is_float", _c.c_int32), ("first_block", _L), ("units", _L), ("upr", _L), ("slots_offset", _L),
                 ("nwg", _c.c_int32), ("tpw", _c.c_int32), ("mask_dwords", _c.c_int32), ("gen", _c.c_uint32)]
+
+
+class BitmaskDItem(ctypes.Structure):
+    """struct ct_bitmask_ditem of include/ct_hip.h (a row of ct_bitmask_decompress_batch's table)"""
+    _fields_ = [("values", _P), ("bitmask", _P), ("row_offsets", _P), ("out", _P), ("rows", _L), ("cols", _L), ("values_len", _L),
+                ("dt", _c.c_int32), ("single", _c.c_int32), ("first_block", _L)]
 
 
 class CopyItem(ctypes.Structure):
@@ -324,7 +332,7 @@ def hostpath():
             abi = {name: ctypes.cast(lib[name], ctypes.c_void_p).value
                    for name in ("ct_bitmask_compress", "ct_bitmask_compress_workspace_bytes", "ct_mailbox_wait_i64", "ct_stream_wait",
                                 "ct_marlin24_compress_w4_full", "ct_marlin24_compress_w4_verdict", "ct_bitmask_batch_plan", "ct_bitmask_compress_batch",
-                                "ct_copy_batch_plan", "ct_copy_batch")}
+                                "ct_copy_batch_plan", "ct_copy_batch", "ct_bitmask_decompress_batch_plan", "ct_bitmask_decompress_batch")}
             try:  # the HIP runtime libct_hip.so is linked against, only if it is already in the process (RTLD_NOLOAD: never a second copy)
                 hip = ctypes.CDLL("libamdhip64.so", mode=os.RTLD_NOLOAD | os.RTLD_NOW)
                 abi["hipStreamSynchronize"] = ctypes.cast(hip.hipStreamSynchronize, ctypes.c_void_p).value

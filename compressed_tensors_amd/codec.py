@@ -1072,6 +1072,31 @@ def bitmask_decompress(values: torch.Tensor, bitmask: torch.Tensor, shape, row_o
     return _home(out.view(values.dtype), values)
 
 
+def bitmask_decompress_many(items):
+    """`bitmask_decompress` for a LIST of (values, bitmask, shape, row_offsets): [dense tensor, ...] in order — loading a sparse checkpoint.  The
+    16- / 32-bit tensors on the current GPU that have row offsets leave in ONE launch per element size (`ct_bitmask_decompress_batch`, through the
+    C++ host loop: allocation of the dense outputs, the table, the launch; nothing waits); everything else one by one."""
+    items = [(v, b, tuple(int(s) for s in shape), ro) for v, b, shape, ro in items]
+    out = [None] * len(items)
+    hp = _lib.hostpath()
+    if hp is not None and torch.cuda.is_available() and items:
+        cur = torch.cuda.current_device()
+        idx = [i for i, (v, b, shape, ro) in enumerate(items) if ro is not None and v.is_cuda and b.is_cuda and ro.is_cuda and v.device.index == cur and len(shape) >= 1
+               and v.element_size() in (2, 4) and v.dtype in DT and ro.dtype is torch.int64]
+        if idx:
+            vs = [_bits_view(items[i][0]).reshape(-1) for i in idx]
+            r = hp.bitmask_decompress_many(vs, [items[i][1] for i in idx], [items[i][3] for i in idx], [list(items[i][2]) for i in idx], [DT[v.dtype] for v in vs],
+                                           _lib.stream_on(vs[0].device))
+            _lib.check(r[0])
+            for i, v, res in zip(idx, vs, r[1:]):
+                if res is not None:
+                    out[i] = res if v.dtype is items[i][0].dtype else res.view(items[i][0].dtype)
+    for i, (v, b, shape, ro) in enumerate(items):
+        if out[i] is None:
+            out[i] = bitmask_decompress(v, b, shape, ro)
+    return out
+
+
 def sparse24_mask(tensor: torch.Tensor) -> torch.Tensor:
     """bool mask keeping the 2 largest-|x| of every 4 consecutive elements
     (mask_creator, utils/semi_structured_conversions.py:301-330; ties: lower index first)."""

@@ -125,11 +125,16 @@ class BitmaskCompressor(BaseCompressor):
                 groups.setdefault(prefix, {})[leaf] = value
             else:
                 out[name] = value
+        ready = []
         for prefix, parts in groups.items():
             if not all(k in parts for k in ("shape", "compressed", "bitmask")):
                 for leaf, v in parts.items():
                     out[f"{prefix}.{leaf}"] = v
                 continue
-            out[prefix + ".weight"] = bitmask_decompress(parts["compressed"], parts["bitmask"], parts["shape"].tolist(),
-                                                         parts.get("row_offsets"))
+            out[prefix + ".weight"] = None  # keeps its place in the dictionary's order
+            ready.append((prefix, parts))
+        # every complete group of the checkpoint in one batched pass (one launch per element size, codec.bitmask_decompress_many)
+        dense = codec.bitmask_decompress_many([(p["compressed"], p["bitmask"], p["shape"].tolist(), p.get("row_offsets")) for _, p in ready])
+        for (prefix, _), w in zip(ready, dense):
+            out[prefix + ".weight"] = w
         return out

@@ -763,18 +763,39 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress8_kernel(const uint8
 // ES = 4 (round 3): 32-bit payloads as pairs of 16-bit halves — the value run, the ranks, the windows and the stores are those of a
 // 16-bit tensor with twice the columns whose mask has every bit doubled; only the mask loads (half as many real bytes) and the
 // offsets (doubled on the way in) differ.
-template <bool SINGLE, int ES>
-__global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len_e,
-                                                                      const uint8_t* __restrict__ bitmask,
-                                                                      const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz_e,
-                                                                      int64_t rows, int64_t cols_e, uint16_t* __restrict__ out) {
+// Round 6: (1) the body is a device function over the tiles tile_first, tile_first + tile_step, ... — the single-tensor kernel below hands it
+// blockIdx.x / gridDim.x, the table kernel (ct_bitmask_decompress_batch) one tile of a table row's tensor; its LDS is the caller's (one struct whatever the
+// instantiation, so that a kernel that calls several of them does not add up their static arrays).
+// (2) FORM 2, "flat" (16-bit payloads whose rows are SHORTER than a tile): a tile is 1024 consecutive units of the FLATTENED tensor, whatever rows they
+// belong to.  The mask bytes, the outputs and — because a row's values start where the previous row's end: row_offsets is the exclusive prefix sum of the
+// rows' counts, fixed_row_nnz trivially so — the value run of such a tile are all contiguous, so the only thing a tile needs from the row structure is where
+// its FIRST unit's values start: row_offsets[row] + the popcount of that row's mask bytes in front of the tile (the prefix loop of the several-tiles-per-row
+// form).  With one row per workgroup a 2048-column row moved 6 KB per workgroup behind two dependent memory latencies and a TinyLlama-shaped checkpoint
+// decompressed at 2.5 TB/s — launches and tables alike (smaller tiles for short rows, 256 / 512 units, changed nothing: measured, dropped).
+struct Decomp16Lds {
+    __attribute__((aligned(16))) uint16_t val[kTile16 + 32];
+    uint32_t sel8[8];  // v_perm_b32 selectors indexed by (window misaligned) << 2 | (b1 << 1) | b0
+    __attribute__((aligned(16))) uint16_t rank[kTile16 / 8];  // wave-local rank of every unit
+    __attribute__((aligned(16))) int tot[4];
+    __attribute__((aligned(16))) int pre[4];
+};
+
+constexpr int kDecRows = 0, kDecSingle = 1, kDecFlat = 2;  // FORM: rows of several tiles / the row is one tile / flat tiles over short rows
+template <int FORM, int ES>
+__device__ __forceinline__ void bitmask_decompress16_tiles(Decomp16Lds& lds, const int64_t tile_first, const int64_t tile_step, const uint16_t* __restrict__ vin,
+                                                           int64_t values_len_e, const uint8_t* __restrict__ bitmask, const int64_t* __restrict__ row_offsets,
+                                                           int64_t fixed_row_nnz_e, int64_t rows, int64_t cols_e, uint16_t* __restrict__ out) {
+    static_assert(FORM != kDecFlat || ES == 2, "the flat form moves 16-bit payloads");
+    constexpr bool SINGLE = FORM == kDecSingle, FLAT = FORM == kDecFlat;
+    constexpr int UPL = 4;
     constexpr int SH = ES == 4 ? 1 : 0;
+    constexpr int kUnits = kBlock * UPL, kTile = kUnits * 8;  // units / 16-bit items per tile
     const int64_t values_len = values_len_e << SH, cols = cols_e << SH, fixed_row_nnz = fixed_row_nnz_e << SH;  // in 16-bit items from here on
-    __shared__ __attribute__((aligned(16))) uint16_t s_val[kTile16 + 32];
-    __shared__ uint32_t s_sel8[8];  // v_perm_b32 selectors indexed by (window misaligned) << 2 | (b1 << 1) | b0
-    __shared__ __attribute__((aligned(16))) uint16_t s_rank[kTile16 / 8];  // wave-local rank of every unit
-    __shared__ __attribute__((aligned(16))) int s_tot[4];
-    __shared__ __attribute__((aligned(16))) int s_pre[4];
+    uint16_t* const s_val = lds.val;
+    uint32_t* const s_sel8 = lds.sel8;
+    uint16_t* const s_rank = lds.rank;
+    int* const s_tot = lds.tot;
+    int* const s_pre = lds.pre;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (threadIdx.x < 8) {  // visible after the first barrier below
         const uint32_t x = threadIdx.x >> 2, b0 = threadIdx.x & 1u, b1 = (threadIdx.x >> 1) & 1u;
@@ -782,23 +803,25 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         s_sel8[threadIdx.x] = (b0 && b1) ? (w01 | (w23 << 16)) : b0 ? (w01 | 0x0c0c0000u) : b1 ? (0x0c0cu | (w01 << 16)) : 0x0c0c0c0cu;
     }
     const int64_t bcols = cols >> 3;
-    const int64_t tiles_per_row = (cols + kTile16 - 1) / kTile16;
-    const int64_t ntiles = rows * tiles_per_row;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row = SINGLE ? tile : tile / tiles_per_row;
-        const int64_t u0 = SINGLE ? 0 : (tile - row * tiles_per_row) * (kTile16 / 8);  // first unit of the tile in its row
-        const int64_t left = bcols - u0;
-        const int nu = left < kTile16 / 8 ? (int)left : kTile16 / 8;                    // units in this tile (multiple of 4)
+    const int64_t tiles_per_row = (cols + kTile - 1) / kTile;
+    const int64_t ntiles = FLAT ? (rows * bcols + kUnits - 1) / kUnits : rows * tiles_per_row;
+    for (int64_t tile = tile_first; tile < ntiles; tile += tile_step) {
+        // FLAT: the tile's first unit is unit u0 of row `row`, and its units run on through the following rows (everything below addresses them
+        // relative to the row's start, which is contiguous with the next row's)
+        const int64_t row = FLAT ? (tile * kUnits) / bcols : (SINGLE ? tile : tile / tiles_per_row);
+        const int64_t u0 = FLAT ? tile * kUnits - row * bcols : (SINGLE ? 0 : (tile - row * tiles_per_row) * kUnits);  // first unit of the tile in its row
+        const int64_t left = FLAT ? rows * bcols - tile * kUnits : bcols - u0;
+        const int nu = left < kUnits ? (int)left : kUnits;                      // units in this tile (a multiple of 4)
         const uint8_t* mrow = bitmask + row * (bcols >> SH);  // the real mask row: one byte per unit (ES = 2) / per two units (ES = 4)
-        uint32_t md = 0;
-        if (4 * tid < nu) {
+        uint32_t md = 0;  // the mask bytes of the lane's own 4 consecutive units 4 tid .. (the rank side), one per byte
+        if (UPL * tid < nu) {
             if constexpr (ES == 4) md = double_bits16(*reinterpret_cast<const uint16_t*>(mrow + ((u0 + 4 * tid) >> 1)));
             else md = *reinterpret_cast<const uint32_t*>(mrow + u0 + 4 * tid);
         }
-        // the consumer lane's own mask bytes (unit i*256 + tid): same cache lines as the dword above
-        uint32_t mb[4];
+        // the consumer lane's own mask bytes (unit i*256 + tid): same cache lines as the load above
+        uint32_t mb[UPL];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < UPL; ++i) {
             const int64_t v = u0 + i * kBlock + tid;
             mb[i] = 0u;
             if (i * kBlock + tid < nu) {
@@ -822,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             e0 = run - shift;
             const u32x4* g = reinterpret_cast<const u32x4*>(vin + e0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < UPL; ++k) {
                 const int v = tid + k * kBlock;
                 if (v < nvec && e0 + (int64_t)(v + 1) * 8 <= values_len)
                     __builtin_amdgcn_global_load_lds(g + v, (__attribute__((address_space(3))) void*)(s_val + (k * kBlock + wave * 64) * 8), 16, 0, 0);
@@ -830,7 +853,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         };
         auto stage_commit = [&]() {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < UPL; ++k) {
                 const int v = tid + k * kBlock;
                 if (v < nvec && e0 + (int64_t)(v + 1) * 8 > values_len) {  // a tail vector that would cross the end of the buffer
                     for (int j = 0; j < 8; ++j) {
@@ -839,8 +862,8 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
                     }
                 }
             }
-            if (tid == 0 && 4 * kBlock < nvec) {  // the one possible 1025th vector (shift > 0, full tile)
-                const int v = 4 * kBlock;
+            if (tid == 0 && kUnits < nvec) {  // the one possible extra vector (shift > 0, full tile)
+                const int v = kUnits;
                 for (int j = 0; j < 8; ++j) {
                     const int64_t gi = e0 + (int64_t)v * 8 + j;
                     s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
@@ -856,8 +879,8 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             if (lane == 63) s_pre[wave] = c;
         }
 
-        // ranks: wave-local exclusive prefix of the lane's dword + popcounts of its lower bytes.  Every ordinary load of
-        // this tile (mask dword, mask bytes, row offsets) is consumed BEFORE the LDS-direct loads are issued: hipcc waits
+        // ranks: wave-local exclusive prefix of the lane's mask bytes + popcounts of its lower bytes.  Every ordinary load of
+        // this tile (mask bytes, row offsets) is consumed BEFORE the LDS-direct loads are issued: hipcc waits
         // vmcnt(0) at the first use of an ordinary load while an LDS-direct load is in flight
         const int c = __popc(md);
         const int incl = wave_incl_scan(c);
@@ -865,15 +888,15 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         const uint32_t r0 = (uint32_t)(incl - c);
         const uint32_t r1 = r0 + __popc(md & 0xffu), r2 = r0 + __popc(md & 0xffffu), r3 = r0 + __popc(md & 0xffffffu);
         reinterpret_cast<u32x2*>(s_rank)[tid] = u32x2{r0 | (r1 << 16), r2 | (r3 << 16)};
-        uint32_t offs4[4];  // window offsets of the lane's four units, from its mask bytes
+        uint32_t offs4[UPL];  // window offsets of the lane's units, from its mask bytes
 #pragma unroll
-        for (int i = 0; i < 4; ++i) offs4[i] = (2u * __popc(mb[i] & 3u)) | ((2u * __popc(mb[i] & 15u)) << 8) | ((2u * __popc(mb[i] & 63u)) << 16) | (mb[i] << 24);
+        for (int i = 0; i < UPL; ++i) offs4[i] = (2u * __popc(mb[i] & 3u)) | ((2u * __popc(mb[i] & 15u)) << 8) | ((2u * __popc(mb[i] & 63u)) << 16) | (mb[i] << 24);
         if constexpr (SINGLE) {
             int64_t row_end = values_len;
             if (row_offsets) { if (row + 1 < rows) row_end = row_offsets[row + 1] << SH; }
             else row_end = run + fixed_row_nnz;
             int64_t len = row_end - run;
-            len = len < 0 ? 0 : (len > kTile16 ? kTile16 : len);
+            len = len < 0 ? 0 : (len > kTile ? kTile : len);
             stage_issue((int)len);
         }
         if constexpr (SINGLE) stage_commit();
@@ -887,15 +910,16 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
             __syncthreads();
         }
         // the owner lane of unit u = i*256 + tid is lane u/4 = i*64 + tid/4: wave i
-        const int wbase[4] = {0, t0, t0 + t1, t0 + t1 + t2};
+        const int wprefix[4] = {0, t0, t0 + t1, t0 + t1 + t2};
         const char* sv = reinterpret_cast<const char*>(s_val);
         uint16_t* orow = out + row * cols + (u0 << 3);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < UPL; ++i) {
             const int u = i * kBlock + tid;
             if (u >= nu) continue;
+            const int wb = wprefix[i];
             const uint32_t mv = offs4[i] >> 24;
-            const uint32_t r = (uint32_t)s_rank[u] + (uint32_t)(wbase[i] + shift);
+            const uint32_t r = (uint32_t)s_rank[u] + (uint32_t)(wb + shift);
             const uint32_t a0 = 2u * r;
             uint32_t w[4];
             // selectors from the 8-entry table (8 distinct banks: conflict-free), window offsets from popcounts
@@ -911,6 +935,39 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint
         }
         __syncthreads();  // (skipping this barrier on the last tile measured 1 us SLOWER)
     }
+}
+
+template <int FORM, int ES>
+__global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len_e,
+                                                                      const uint8_t* __restrict__ bitmask,
+                                                                      const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz_e,
+                                                                      int64_t rows, int64_t cols_e, uint16_t* __restrict__ out) {
+    __shared__ Decomp16Lds lds;
+    bitmask_decompress16_tiles<FORM, ES>(lds, (int64_t)blockIdx.x, (int64_t)gridDim.x, vin, values_len_e, bitmask, row_offsets, fixed_row_nnz_e, rows, cols_e, out);
+}
+
+// Round 6: the same kernel over a TABLE of tensors (ct_bitmask_decompress_batch) — loading a sparse checkpoint is 154 (TinyLlama) to thousands of
+// decompress launches of 1-23 MB each, ~5 us of host per launch around kernels of 3-10 us.  One grid: a workgroup finds its tensor by a binary
+// search over the running tile count and expands one tile of it.
+template <int ES>
+__global__ __launch_bounds__(kBlock) void bitmask_decompress16_batch_kernel(const ct_bitmask_ditem* __restrict__ items, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ct_bitmask_ditem& it = items[lo];
+    const int64_t tile = (int64_t)blockIdx.x - it.first_block;
+    const int64_t never = (int64_t)1 << 62;  // one tile per workgroup
+    __shared__ Decomp16Lds lds;  // ONE copy for the four forms below
+    const uint16_t* vin = static_cast<const uint16_t*>(it.values);
+    uint16_t* out = static_cast<uint16_t*>(it.out);
+    // `single` (ct_bitmask_decompress_batch_plan): the tile form — kDecRows / kDecSingle / kDecFlat
+    if constexpr (ES == 2) {
+        if (it.single == kDecFlat) { bitmask_decompress16_tiles<kDecFlat, 2>(lds, tile, never, vin, it.values_len, it.bitmask, it.row_offsets, -1, it.rows, it.cols, out); return; }
+    }
+    if (it.single == kDecSingle) bitmask_decompress16_tiles<kDecSingle, ES>(lds, tile, never, vin, it.values_len, it.bitmask, it.row_offsets, -1, it.rows, it.cols, out);
+    else bitmask_decompress16_tiles<kDecRows, ES>(lds, tile, never, vin, it.values_len, it.bitmask, it.row_offsets, -1, it.rows, it.cols, out);
 }
 
 // ------------------------------------------------------------------------- compress, fused flat form (16-bit)
@@ -2277,6 +2334,47 @@ int ct_bitmask_compress_batch(const ct_bitmask_item* items_dev, int n, int64_t t
     CT_LAUNCH_CHECK("ct_bitmask_compress_batch");
 }
 
+int64_t ct_bitmask_decompress_batch_plan(ct_bitmask_ditem* items, int n) {
+    if (n < 0 || (n > 0 && items == nullptr)) {
+        set_error("ct_bitmask_decompress_batch_plan: bad arguments");
+        return -1;
+    }
+    int64_t blocks = 0;
+    const int es0 = n > 0 ? dt_size(items[0].dt) : 2;
+    for (int i = 0; i < n; ++i) {
+        ct_bitmask_ditem& it = items[i];
+        const int es = dt_size(it.dt);
+        const bool ok = (es == 2 || es == 4) && es == es0 && it.rows > 0 && it.cols > 0 && (it.cols * es / 2) % 32 == 0 && it.values_len >= 0 && it.bitmask && it.row_offsets && it.out &&
+                        (it.values != nullptr || it.values_len == 0) && aligned16(it.values) && aligned16(it.out) && (reinterpret_cast<uintptr_t>(it.bitmask) & 3u) == 0;
+        if (!ok) {
+            set_error("ct_bitmask_decompress_batch_plan: item %d (rows %lld, cols %lld, dtype %d) is not eligible for the batched sparse-bitmask decompress (16- or 32-bit "
+                      "payloads of ONE element size per table, cols x element size %% 64 == 0, row_offsets given, values / out 16-byte and bitmask 4-byte aligned)", i,
+                      (long long)it.rows, (long long)it.cols, it.dt);
+            return -1;
+        }
+        const int64_t hcols = it.cols * es / 2;  // the row in 16-bit items
+        // the tile form (the kernel's dispatch): rows of several tiles / the row is one tile / 16-bit rows shorter than a tile: flat tiles
+        it.single = hcols > kTile16 ? kDecRows : (es == 2 && hcols < kTile16 ? kDecFlat : kDecSingle);
+        it.first_block = blocks;
+        blocks += it.single == kDecFlat ? cdiv64(it.rows * (hcols / 8), kTile16 / 8) : it.rows * cdiv64(hcols, kTile16);
+    }
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("ct_bitmask_decompress_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
+        return -1;
+    }
+    return blocks;
+}
+
+int ct_bitmask_decompress_batch(const ct_bitmask_ditem* items_dev, int n, int64_t total_blocks, int element_size, ct_stream_t stream) {
+    CT_REQUIRE(element_size == 2 || element_size == 4, "batched sparse-bitmask decompress: 16- or 32-bit payloads, got element size %d", element_size);
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    CT_REQUIRE(items_dev != nullptr, "table is NULL");
+    if (element_size == 4) hipLaunchKernelGGL((bitmask_decompress16_batch_kernel<4>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    else hipLaunchKernelGGL((bitmask_decompress16_batch_kernel<2>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    CT_LAUNCH_CHECK("ct_bitmask_decompress_batch");
+}
+
 int64_t ct_copy_batch_plan(ct_copy_item* items, int n) {
     if (n < 0 || (n > 0 && items == nullptr)) {
         set_error("ct_copy_batch_plan: bad arguments");
@@ -2324,11 +2422,15 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
         const int64_t hcols = cols * es / 2;  // the row in 16-bit items
         const int64_t tiles = rows * cdiv64(hcols, kTile16);
         const unsigned grid = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));  // exact grid measured best
-#define CT_DEC16(SINGLE_, ES_)                                                                                                                      \
-    hipLaunchKernelGGL((bitmask_decompress16_kernel<SINGLE_, ES_>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values), \
+#define CT_DEC16(FORM_, ES_)                                                                                                                        \
+    hipLaunchKernelGGL((bitmask_decompress16_kernel<FORM_, ES_>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values), \
                        values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out))
-        if (es == 4) { if (hcols <= kTile16) CT_DEC16(true, 4); else CT_DEC16(false, 4); }
-        else { if (hcols <= kTile16) CT_DEC16(true, 2); else CT_DEC16(false, 2); }
+        if (es == 4) { if (hcols <= kTile16) CT_DEC16(kDecSingle, 4); else CT_DEC16(kDecRows, 4); }
+        else if (hcols < kTile16) {  // round 6: rows shorter than a tile -> flat tiles of 1024 consecutive units (see the kernel)
+            const int64_t ftiles = cdiv64(rows * (hcols / 8), kTile16 / 8);
+            hipLaunchKernelGGL((bitmask_decompress16_kernel<kDecFlat, 2>), dim3((unsigned)(ftiles < ((int64_t)1 << 30) ? ftiles : ((int64_t)1 << 30))), dim3(kBlock), 0,
+                               as_stream(stream), static_cast<const uint16_t*>(values), values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out));
+        } else { if (hcols <= kTile16) CT_DEC16(kDecSingle, 2); else CT_DEC16(kDecRows, 2); }
 #undef CT_DEC16
         CT_LAUNCH_CHECK("ct_bitmask_decompress[16]");
     }

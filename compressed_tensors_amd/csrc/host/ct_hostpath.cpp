@@ -513,6 +513,8 @@ struct Abi {
     int (*bitmask_compress_batch)(const void*, int, int64_t, int, void*, int64_t, void*) = nullptr;
     int64_t (*copy_batch_plan)(void*, int) = nullptr;
     int (*copy_batch)(const void*, int, int64_t, void*) = nullptr;
+    int64_t (*bitmask_decompress_batch_plan)(void*, int) = nullptr;
+    int (*bitmask_decompress_batch)(const void*, int, int64_t, int, void*) = nullptr;
 } g_abi;
 
 // 1: the waits below as described there; 0: only through ct_mailbox_wait_i64 / ct_stream_wait (tools/exp_r04.py compares the two on one lease)
@@ -556,6 +558,8 @@ void bind_abi(const std::map<std::string, uintptr_t>& addr) {
     g_abi.bitmask_compress_batch = reinterpret_cast<int (*)(const void*, int, int64_t, int, void*, int64_t, void*)>(find("ct_bitmask_compress_batch"));
     g_abi.copy_batch_plan = reinterpret_cast<int64_t (*)(void*, int)>(find("ct_copy_batch_plan"));
     g_abi.copy_batch = reinterpret_cast<int (*)(const void*, int, int64_t, void*)>(find("ct_copy_batch"));
+    g_abi.bitmask_decompress_batch_plan = reinterpret_cast<int64_t (*)(void*, int)>(find("ct_bitmask_decompress_batch_plan"));
+    g_abi.bitmask_decompress_batch = reinterpret_cast<int (*)(const void*, int, int64_t, int, void*)>(find("ct_bitmask_decompress_batch"));
 }
 
 bool on_device(const at::Tensor& t) { return t.is_cuda() || (g_allow_cpu && t.is_cpu()); }
@@ -762,6 +766,68 @@ py::list bitmask_compress_many(const std::vector<at::Tensor>& xs, const std::vec
     return out;
 }
 
+// codec.bitmask_decompress_many (round 6): loading a sparse checkpoint — a LIST of (values, bitmask, row_offsets, shape) — in ONE launch per
+// element size (ct_bitmask_decompress_batch): the dense outputs are allocated here, the table is planned and uploaded, nothing is waited for.
+// `dts[i]` < 0 and whatever the table kernel does not take (8-bit payloads, rows that are not whole 64-byte runs, a missing row_offsets, another
+// device, views) -> None at that position: the Python caller decompresses those one by one.  Returns [status, result or None, ...].
+py::list bitmask_decompress_many(const std::vector<at::Tensor>& values, const std::vector<at::Tensor>& bitmasks, const std::vector<c10::optional<at::Tensor>>& row_offsets,
+                                 const std::vector<std::vector<int64_t>>& shapes, const std::vector<int>& dts, uintptr_t stream) {
+    touch_tls();
+    if (!g_abi.bitmask_decompress_batch_plan || !g_abi.bitmask_decompress_batch) throw std::runtime_error("bitmask_decompress_many: bind_abi has not bound the batch entries");
+    const size_t n = values.size();
+    if (bitmasks.size() != n || row_offsets.size() != n || shapes.size() != n || dts.size() != n) throw std::runtime_error("bitmask_decompress_many: bad arguments");
+    std::vector<py::object> results(n, py::none());
+    auto eligible = [&](size_t i, int64_t& rows, int64_t& cols) {
+        const at::Tensor &v = values[i], &b = bitmasks[i];
+        const int64_t es = (int64_t)v.element_size();
+        if (dts[i] < 0 || (es != 2 && es != 4) || shapes[i].empty() || !row_offsets[i].has_value()) return false;
+        cols = shapes[i].back();
+        rows = 1;
+        for (size_t k = 0; k + 1 < shapes[i].size(); ++k) rows *= shapes[i][k];
+        const at::Tensor& ro = *row_offsets[i];
+        return rows > 0 && cols > 0 && (cols * es) % 64 == 0 && on_device(v) && on_device(b) && on_device(ro) && v.device() == b.device() && ro.device() == b.device() &&
+               v.is_contiguous() && b.is_contiguous() && ro.is_contiguous() && v.dim() == 1 && b.scalar_type() == at::kByte && b.numel() == rows * ((cols + 7) / 8) &&
+               ro.scalar_type() == at::kLong && ro.numel() == rows && (reinterpret_cast<uintptr_t>(v.data_ptr()) & 15) == 0 && (reinterpret_cast<uintptr_t>(b.data_ptr()) & 3) == 0;
+    };
+    std::vector<bool> taken(n, false);
+    for (size_t start = 0; start < n; ++start) {
+        int64_t rows = 0, cols = 0;
+        if (taken[start] || !eligible(start, rows, cols)) continue;
+        const int64_t es = (int64_t)values[start].element_size();
+        const auto dev = bitmasks[start].device();
+        std::vector<int64_t> table;
+        std::vector<size_t> index;
+        std::vector<at::Tensor> outs;
+        for (size_t i = start; i < n; ++i) {
+            if (taken[i] || !eligible(i, rows, cols) || (int64_t)values[i].element_size() != es || bitmasks[i].device() != dev) continue;
+            taken[i] = true;
+            at::Tensor out = at::empty(shapes[i], values[i].options());
+            // struct ct_bitmask_ditem: values, bitmask, row_offsets, out, rows, cols, values_len, {dt, single}, first_block
+            const int64_t row[9] = {(int64_t)(uintptr_t)values[i].data_ptr(), (int64_t)(uintptr_t)bitmasks[i].data_ptr(), (int64_t)(uintptr_t)row_offsets[i]->data_ptr(),
+                                    (int64_t)(uintptr_t)out.data_ptr(), rows, cols, values[i].numel(), (int64_t)(uint32_t)dts[i], 0};
+            table.insert(table.end(), row, row + 9);
+            index.push_back(i);
+            outs.push_back(std::move(out));
+        }
+        const int64_t blocks = g_abi.bitmask_decompress_batch_plan(table.data(), (int)index.size());
+        int status = blocks < 0 ? 1 : 0;
+        if (status == 0 && blocks > 0) {
+            at::Tensor table_dev = upload_words(table, values[start].options());
+            status = g_abi.bitmask_decompress_batch(table_dev.data_ptr(), (int)index.size(), blocks, (int)es, reinterpret_cast<void*>(stream));
+        }
+        if (status != 0) {
+            py::list out;
+            out.append(py::int_(status));
+            return out;
+        }
+        for (size_t k = 0; k < index.size(); ++k) results[index[k]] = py::reinterpret_steal<py::object>(THPVariable_Wrap(outs[k]));
+    }
+    py::list out;
+    out.append(py::int_(0));
+    for (auto& r : results) out.append(r);
+    return out;
+}
+
 // the default (raise-from-the-call) mode of Marlin24Compressor.compress for int4: ct_marlin24_compress_w4_full, then a spin on the stream,
 // then the verdict word.  The caller has validated shapes / dtypes / contiguity (compressors/sparse/marlin_24.py).  Returns
 // (status, violated, weight_packed, meta, scale_packed).
@@ -873,6 +939,7 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("bind_abi", &bind_abi);
     mod.def("bitmask_compress", &bitmask_compress);
     mod.def("bitmask_compress_many", &bitmask_compress_many);
+    mod.def("bitmask_decompress_many", &bitmask_decompress_many);
     mod.def("marlin24_w4_full", &marlin24_w4_full);
     mod.def("marlin24_compress_default", &marlin24_compress_default);
     mod.def("set_allow_cpu", [](bool v) { g_allow_cpu = v; });

@@ -342,7 +342,8 @@ int ct_bitmask_scatter(const void* x, int dt, int64_t rows, int64_t cols, const 
  * 8-bit payloads / other column counts: count, scan, scatter.  `values` must hold `values_capacity` elements
  * (numel is always enough; the one-pass paths never write beyond the capacity and still report the
  * needed size in total).  `workspace` = ct_bitmask_compress_workspace_bytes(rows, cols) bytes, 8-byte
- * aligned, need not be initialised. */
+ * aligned, need not be initialised.  (HIP graphs: every compute entry of this header can be captured; this one and its batch form bake a
+ * per-launch generation tag into the launch, so a graph that contains them clears `workspace` inside the graph before the launch.) */
 int64_t ct_bitmask_compress_workspace_bytes(int64_t rows, int64_t cols);
 int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void* values,
                         int64_t values_capacity, uint8_t* bitmask, int64_t* row_offsets, int64_t* total,
@@ -372,6 +373,23 @@ typedef struct ct_bitmask_item {
 int64_t ct_bitmask_batch_plan(ct_bitmask_item* items_host, int n, int64_t* workspace_bytes);
 int ct_bitmask_compress_batch(const ct_bitmask_item* items_dev, int n, int64_t total_blocks, int element_size, void* workspace,
                               int64_t workspace_bytes, ct_stream_t stream);
+
+/* The decompress side of the same loop — loading a sparse checkpoint (the restated BitmaskCompressor.decompress_state_dict) — for a TABLE of
+ * tensors in one launch: out = zeros; out[mask] = values per item, bit-identical to ct_bitmask_decompress item by item.  16- or 32-bit payloads
+ * (ONE element size per table), cols x element size % 64 == 0, row_offsets given, values / out 16-byte and bitmask 4-byte aligned.
+ * ct_bitmask_decompress_batch_plan fills the derived fields on the host copy and returns the workgroup count or -1. */
+typedef struct ct_bitmask_ditem {
+    const void* values;
+    const uint8_t* bitmask;
+    const int64_t* row_offsets;
+    void* out;
+    int64_t rows, cols, values_len; /* values_len in elements */
+    int32_t dt;                     /* element type code */
+    int32_t single;                 /* derived */
+    int64_t first_block;            /* derived */
+} ct_bitmask_ditem;                 /* 9 64-bit words */
+int64_t ct_bitmask_decompress_batch_plan(ct_bitmask_ditem* items_host, int n);
+int ct_bitmask_decompress_batch(const ct_bitmask_ditem* items_dev, int n, int64_t total_blocks, int element_size, ct_stream_t stream);
 
 /* n byte ranges copied by one launch (the exact-size `values` of a batch leave the worst-case arena the kernels wrote into:
  * tensor[mask] owns nnz elements, restated S1 over utils/helpers.py:306-343).  ct_copy_batch_plan fills first_block on the host

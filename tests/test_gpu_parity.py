@@ -1173,6 +1173,60 @@ def test_sparse_bitmask_8bit_payloads_take_the_resident_kernel(cta, dev, dtype):
         assert v.dtype == w.dtype and torch.equal(v.view(torch.uint8), sv.view(torch.uint8)) and torch.equal(bm, sbm) and torch.equal(ro, sro)
 
 
+def test_bitmask_decompress_many_and_the_batch_entry(cta, dev):
+    """Round 6: loading a sparse checkpoint — `codec.bitmask_decompress_many` / `BitmaskCompressor.decompress_state_dict` expand a list of tensors with
+    ONE `ct_bitmask_decompress_batch` launch per element size: equal to `bitmask_decompress` tensor by tensor and to the original tensors, for rows of
+    one tile, rows of several tiles (> 8192 columns), partial tiles, all-zero / dense tensors, float32, and — taken one by one — 8-bit payloads, a
+    tensor without row offsets, a CPU tensor, rows that are not whole 64-byte runs.  The C-ABI entry is also called directly."""
+    import ctypes
+
+    from compressed_tensors_amd import _lib
+    from compressed_tensors_amd.compressors.sparse.sparse_bitmask import BitmaskCompressor
+
+    g = torch.Generator(device=dev).manual_seed(31)
+    specs = [(2048, 2048, BF16, 0.5), (256, 2048, BF16, 0.3), (5632, 2048, F16, 0.5), (64, 8192 + 4096, BF16, 0.6), (3, 32768, BF16, 0.5), (100, 64, BF16, 0.0),
+             (33, 4096, BF16, 1.0), (300, 1024, F32, 0.5), (17, 2048 + 32, BF16, 0.5), (128, 256, torch.int8, 0.5), (40, 24, BF16, 0.5), (64, 512, BF16, 0.5)]
+    ws = []
+    for r, c, dt, dens in specs:
+        w = torch.randn(r, c, device=dev, generator=g)
+        w = (w * 50).to(dt) if dt is torch.int8 else w.to(dt)
+        ws.append(w * (torch.rand(r, c, device=dev, generator=g) < dens) if dens < 1.0 else (w.abs() + 1).to(dt))
+    comp = [cta.codec.bitmask_compress(w) for w in ws]
+    items = [(v, bm, w.shape, ro) for w, (v, bm, ro) in zip(ws, comp)]
+    items[-1] = (items[-1][0], items[-1][1], items[-1][2], None)            # no row offsets: the per-tensor path rebuilds them
+    items.append((comp[0][0].cpu(), comp[0][1].cpu(), ws[0].shape, comp[0][2].cpu()))  # a CPU entry
+    ws = [torch.where(w != 0, w, torch.zeros_like(w)) for w in ws]  # (a dropped -0.0 comes back as +0.0)
+    want = ws + [ws[0].cpu()]
+    got = cta.codec.bitmask_decompress_many(items)
+    for (v, bm, shape, ro), o, w in zip(items, got, want):
+        assert o.dtype == w.dtype and o.device == w.device and tuple(o.shape) == tuple(w.shape)
+        assert torch.equal(o.view(torch.uint8), w.view(torch.uint8)), (tuple(w.shape), w.dtype)
+        assert torch.equal(o.view(torch.uint8), cta.codec.bitmask_decompress(v, bm, shape, ro).view(torch.uint8))
+    state = {f"layers.{i}.weight": w for i, w in enumerate(ws)}
+    state["norm.bias"] = torch.ones(4, device=dev)
+    back = BitmaskCompressor.decompress_state_dict(BitmaskCompressor.compress_state_dict(state))
+    assert list(back) == ["norm.bias"] + [f"layers.{i}.weight" for i in range(len(ws))] and all(torch.equal(back[k].view(torch.uint8), state[k].view(torch.uint8)) for k in state)
+    # the entry itself, the way a C host calls it
+    lib = _lib.load()
+    take = [i for i, (r, c, dt, _) in enumerate(specs) if dt is BF16 and (c * 2) % 64 == 0]
+    tab = (_lib.BitmaskDItem * len(take))()
+    outs = []
+    for k, i in enumerate(take):
+        v, bm, ro = comp[i]
+        o = torch.full_like(ws[i], 7)
+        outs.append(o)
+        tab[k].values, tab[k].bitmask, tab[k].row_offsets, tab[k].out = v.data_ptr() if v.numel() else None, bm.data_ptr(), ro.data_ptr(), o.data_ptr()
+        tab[k].rows, tab[k].cols, tab[k].values_len, tab[k].dt = ws[i].shape[0], ws[i].shape[1], v.numel(), _lib.BF16
+    blocks = lib.ct_bitmask_decompress_batch_plan(ctypes.cast(tab, ctypes.c_void_p), len(take))
+    assert blocks > 0, _lib.last_error()
+    table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+    assert lib.ct_bitmask_decompress_batch(table.data_ptr(), len(take), blocks, 2, _lib.stream_of_device(dev)) == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    assert all(torch.equal(o.view(torch.int16), ws[i].view(torch.int16)) for o, i in zip(outs, take))
+    tab[0].cols = 24  # rows that are not whole 64-byte runs: refused by the plan
+    assert lib.ct_bitmask_decompress_batch_plan(ctypes.cast(tab, ctypes.c_void_p), len(take)) == -1 and "not eligible" in _lib.last_error()
+
+
 def test_c_abi_launches_are_hip_graph_capturable(cta, dev):
     """The compute entries allocate nothing and never synchronise, so a caller can capture a launch-bound sequence of them into a HIP graph and
     replay it: W4 compress + decompress, W3, the sparse decompress, the 2:4 compress and — with its workspace cleared INSIDE the

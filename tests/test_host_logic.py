@@ -700,6 +700,7 @@ def test_batch_table_words_match_the_struct(cta):
     from compressed_tensors_amd import _lib, codec
 
     assert ctypes.sizeof(_lib.W4Item) == 8 * codec._ITEM_WORDS
+    assert ctypes.sizeof(_lib.BitmaskDItem) == 8 * 9 and _lib.BitmaskDItem.dt.offset == 56 and _lib.BitmaskDItem.first_block.offset == 64
     assert ctypes.sizeof(_lib.BitmaskItem) == 8 * 15 and ctypes.sizeof(_lib.CopyItem) == 8 * 4  # csrc/host/ct_hostpath.cpp fills these as 15 / 4 words
     assert _lib.BitmaskItem.dt.offset == 64 and _lib.BitmaskItem.first_block.offset == 72 and _lib.BitmaskItem.nwg.offset == 104 and _lib.BitmaskItem.gen.offset == 116
     assert codec._ITEM_WORDS == 13  # round 6: + zp_packed, main_blocks, {g_magic, g_shift}
@@ -1022,6 +1023,38 @@ def test_cpp_waiting_calls_on_a_stub_abi(cta):
                     assert values.dtype == x.dtype and torch.equal(values, x[keep]) and torch.equal(ro, torch.cumsum(keep.sum(1), 0) - keep.sum(1))
                     assert torch.equal(bitmask, torch.from_numpy(np.packbits(keep.numpy(), axis=1, bitorder="little")))
                     assert values.untyped_storage().nbytes() == (x.element_size() * int(keep.sum()) if exact else x.element_size() * x.numel())
+        # ... and the way back (round 6): a list of compressed tensors -> ONE table launch per element size, outputs allocated by the loop, nothing waited for
+        dlaunches = []
+
+        def dplan(items, n):
+            rows = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_int64)), (n, 9))
+            rows[:, 8] = np.arange(n)
+            return n
+
+        def dlaunch(items, n, blocks, es, stream):
+            rows = np.ctypeslib.as_array(ctypes.cast(items, ctypes.POINTER(ctypes.c_int64)), (n, 9)).copy()
+            dlaunches.append((n, es, stream))
+            ctype = ctypes.c_int16 if es == 2 else ctypes.c_int32
+            for values, bitmask, ro, outp, nrows, ncols, vlen, dt, _ in (tuple(int(v) for v in r) for r in rows):
+                m = np.unpackbits(np.ctypeslib.as_array(ctypes.cast(bitmask, ctypes.POINTER(ctypes.c_uint8)), (nrows, (ncols + 7) // 8)), axis=1, bitorder="little")[:, :ncols].astype(bool)
+                o = np.ctypeslib.as_array(ctypes.cast(outp, ctypes.POINTER(ctype)), (nrows, ncols))
+                o[:] = 0
+                if vlen:
+                    o[m] = np.ctypeslib.as_array(ctypes.cast(values, ctypes.POINTER(ctype)), (vlen,))[: int(m.sum())]
+            return 0
+
+        cbs["ct_bitmask_decompress_batch_plan"] = ctypes.CFUNCTYPE(L, V, I)(dplan)
+        cbs["ct_bitmask_decompress_batch"] = ctypes.CFUNCTYPE(I, V, I, L, I, V)(dlaunch)
+        hp.bind_abi({k: ctypes.cast(v, ctypes.c_void_p).value for k, v in cbs.items()})
+        good = [x for x in xs if x.is_contiguous()]
+        comp = [(x[x != 0], torch.from_numpy(np.packbits((x != 0).numpy(), axis=1, bitorder="little")), torch.cumsum((x != 0).sum(1), 0) - (x != 0).sum(1), list(x.shape)) for x in good]
+        ro_list = [c[2] for c in comp]
+        ro_list[1] = None  # no row offsets: not taken
+        r = hp.bitmask_decompress_many([c[0] for c in comp], [c[1] for c in comp], ro_list, [c[3] for c in comp], [7] * 5 + [4], 99)
+        assert r[0] == 0 and r[2] is None and dlaunches == [(4, 2, 99), (1, 4, 99)]  # one launch per element size
+        for x, res in zip(good, r[1:]):
+            assert res is None or (res.dtype == x.dtype and torch.equal(res, x))
+        assert hp.bitmask_decompress_many([comp[0][0]], [comp[0][1]], [comp[0][2]], [comp[0][3]], [-1], 0) == [0, None]
         assert hp.bitmask_compress_many(xs, [7, 7, 7, -1, 7, 7, 4], host, host, 2, 6, 0, True, 1 << 20)[4] is None  # no element code: left to the caller
         assert hp.bitmask_compress_many([xs[0][:, :36].contiguous()], [7], host, host, 2, 6, 0, True, 1 << 20) == [0, None]  # rows that are not whole 16-byte units: the single-tensor path
         seen["fail"] = True
