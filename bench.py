@@ -706,34 +706,43 @@ def bitmask_leg(dev):
             w = torch.randn(N, N, dtype=torch.float32, device=dev, generator=g)
             w = w.masked_fill(torch.rand(N, N, device=dev, generator=g) < 0.5, 0)
             sets32.append(w)
-        v32 = torch.empty(N * N, dtype=torch.float32, device=dev)
-        bm32, ro32 = torch.empty(N, N // 8, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.int64, device=dev)
+        # every rotating set has its own compressed image, so that the decompress launches read HBM-cold values and masks too
+        v32 = [torch.empty(N * N, dtype=torch.float32, device=dev) for _ in range(NF)]
+        bm32 = [torch.empty(N, N // 8, dtype=torch.uint8, device=dev) for _ in range(NF)]
+        ro32 = [torch.empty(N, dtype=torch.int64, device=dev) for _ in range(NF)]
         wk32 = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
         o32 = [torch.empty(N, N, dtype=torch.float32, device=dev) for _ in range(2)]
 
         def c32(i):
-            lib.ct_bitmask_compress(sets32[i % NF].data_ptr(), F32, N, N, v32.data_ptr(), v32.numel(), bm32.data_ptr(), ro32.data_ptr(), wk32[-1:].data_ptr(),
+            k = i % NF
+            lib.ct_bitmask_compress(sets32[k].data_ptr(), F32, N, N, v32[k].data_ptr(), v32[k].numel(), bm32[k].data_ptr(), ro32[k].data_ptr(), wk32[-1:].data_ptr(),
                                     wk32.data_ptr(), ws_bytes, stream)
 
         us_c32 = time_kernel(c32, 12)
-        c32(0)
-        torch.cuda.synchronize()
-        nnz32 = int(wk32[-1].item())
+        nnz32s = []
+        for k in range(NF):
+            c32(k)
+            torch.cuda.synchronize()
+            nnz32s.append(int(wk32[-1].item()))
+        nnz32 = nnz32s[0]
         w0 = sets32[0]
         m0 = w0 != 0
         cnt0 = m0.sum(-1)
-        ok32 = (nnz32 == int(cnt0.sum().item()) and torch.equal(v32[:nnz32], w0[m0]) and torch.equal(ro32, torch.cumsum(cnt0, 0) - cnt0)
-                and torch.equal(bm32, (m0.view(N, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8)))
+        ok32 = (nnz32 == int(cnt0.sum().item()) and torch.equal(v32[0][:nnz32], w0[m0]) and torch.equal(ro32[0], torch.cumsum(cnt0, 0) - cnt0)
+                and torch.equal(bm32[0], (m0.view(N, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8)))
 
         def d32(i):
-            lib.ct_bitmask_decompress(v32.data_ptr(), nnz32, bm32.data_ptr(), ro32.data_ptr(), -1, F32, N, N, o32[i % 2].data_ptr(), stream)
+            k = i % NF
+            lib.ct_bitmask_decompress(v32[k].data_ptr(), nnz32s[k], bm32[k].data_ptr(), ro32[k].data_ptr(), -1, F32, N, N, o32[i % 2].data_ptr(), stream)
 
         us_d32 = time_kernel(d32, 12)
+        d32(0)
+        torch.cuda.synchronize()
         ok32 = ok32 and torch.equal(o32[0], w0)
         alg32 = 4 * N * N + 4 * nnz32 + N * N // 8 + 8 * N
         f32 = {"f32_alg_bytes": alg32, "f32_compress_us": round(us_c32, 2), "f32_compress_frac_hbm": round(alg32 / us_c32 / 1e3 / HBM_PEAK_GBPS, 4),
                "f32_decompress_us": round(us_d32, 2), "f32_decompress_frac_hbm": round(alg32 / us_d32 / 1e3 / HBM_PEAK_GBPS, 4), "f32_bit_exact": bool(ok32),
-               "f32_workload": f"sparse-bitmask 50 % unstructured {N}x{N} float32, C ABI, {NF} rotating inputs; outputs against eager torch ops on the device"}
+               "f32_workload": f"sparse-bitmask 50 % unstructured {N}x{N} float32, C ABI, {NF} rotating sets (dense and compressed images); outputs against eager torch ops on the device"}
         del sets32, v32, o32
     except Exception as e:
         f32 = {"f32_error": repr(e)}
@@ -745,34 +754,65 @@ def bitmask_leg(dev):
         for _ in range(NI):
             w = torch.randint(-127, 128, (N, N), device=dev, generator=g, dtype=torch.int16).to(torch.int8)
             sets8.append(w.masked_fill_(torch.rand(N, N, device=dev, generator=g) < 0.5, 0))
-        v8 = torch.empty(N * N, dtype=torch.int8, device=dev)
-        bm8, ro8 = torch.empty(N, N // 8, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.int64, device=dev)
+        v8 = [torch.empty(N * N, dtype=torch.int8, device=dev) for _ in range(NI)]  # one compressed image per rotating set: decompress reads cold too
+        bm8 = [torch.empty(N, N // 8, dtype=torch.uint8, device=dev) for _ in range(NI)]
+        ro8 = [torch.empty(N, dtype=torch.int64, device=dev) for _ in range(NI)]
         wk8 = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
         o8 = [torch.empty(N, N, dtype=torch.int8, device=dev) for _ in range(2)]
 
         def c8(i):
-            lib.ct_bitmask_compress(sets8[i % NI].data_ptr(), I8, N, N, v8.data_ptr(), v8.numel(), bm8.data_ptr(), ro8.data_ptr(), wk8[-1:].data_ptr(), wk8.data_ptr(), ws_bytes, stream)
+            k = i % NI
+            lib.ct_bitmask_compress(sets8[k].data_ptr(), I8, N, N, v8[k].data_ptr(), v8[k].numel(), bm8[k].data_ptr(), ro8[k].data_ptr(), wk8[-1:].data_ptr(), wk8.data_ptr(),
+                                    ws_bytes, stream)
 
         us_c8 = time_kernel(c8, 24)
-        c8(0)
-        torch.cuda.synchronize()
-        nnz8 = int(wk8[-1].item())
+        nnz8s = []
+        for k in range(NI):
+            c8(k)
+            torch.cuda.synchronize()
+            nnz8s.append(int(wk8[-1].item()))
+        nnz8 = nnz8s[0]
         w0 = sets8[0]
         m0 = w0 != 0
         cnt0 = m0.sum(-1)
-        ok8 = (nnz8 == int(cnt0.sum().item()) and torch.equal(v8[:nnz8], w0[m0]) and torch.equal(ro8, torch.cumsum(cnt0, 0) - cnt0)
-               and torch.equal(bm8, (m0.view(N, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8)))
+        ok8 = (nnz8 == int(cnt0.sum().item()) and torch.equal(v8[0][:nnz8], w0[m0]) and torch.equal(ro8[0], torch.cumsum(cnt0, 0) - cnt0)
+               and torch.equal(bm8[0], (m0.view(N, N // 8, 8).to(torch.int32) * (1 << torch.arange(8, device=dev, dtype=torch.int32))).sum(-1).to(torch.uint8)))
 
         def d8(i):
-            lib.ct_bitmask_decompress(v8.data_ptr(), nnz8, bm8.data_ptr(), ro8.data_ptr(), -1, I8, N, N, o8[i % 2].data_ptr(), stream)
+            k = i % NI
+            lib.ct_bitmask_decompress(v8[k].data_ptr(), nnz8s[k], bm8[k].data_ptr(), ro8[k].data_ptr(), -1, I8, N, N, o8[i % 2].data_ptr(), stream)
 
         us_d8 = time_kernel(d8, 24)
+        d8(0)
+        torch.cuda.synchronize()
         ok8 = ok8 and torch.equal(o8[0], w0)
+        # the 2:4 codec on the same bytes (sparse-24-bitmask of FP8 / int8 weights)
+        for k in range(NI):
+            sets8[k].masked_fill_(~codec.sparse24_mask(sets8[k]), 0)
+        v24 = [torch.empty(N, N // 2, dtype=torch.int8, device=dev) for _ in range(NI)]
+
+        def c248(i):
+            k = i % NI
+            lib.ct_sparse24_compress(sets8[k].data_ptr(), I8, N, N, v24[k].data_ptr(), bm8[k].data_ptr(), stream)
+
+        def d248(i):
+            k = i % NI
+            lib.ct_bitmask_decompress(v24[k].data_ptr(), v24[k].numel(), bm8[k].data_ptr(), None, N // 2, I8, N, N, o8[i % 2].data_ptr(), stream)
+
+        us_c248 = time_kernel(c248, 24)
+        us_d248 = time_kernel(d248, 24)
+        d248(0)
+        torch.cuda.synchronize()
+        ok248 = torch.equal(o8[0], sets8[0])
+        alg248 = N * N + N * N // 2 + N * N // 8
+        i8_24 = {"i8_s24_alg_bytes": alg248, "i8_s24_compress_us": round(us_c248, 2), "i8_s24_compress_frac_hbm": round(alg248 / us_c248 / 1e3 / HBM_PEAK_GBPS, 4),
+                 "i8_s24_decompress_us": round(us_d248, 2), "i8_s24_decompress_frac_hbm": round(alg248 / us_d248 / 1e3 / HBM_PEAK_GBPS, 4), "i8_s24_round_trip": bool(ok248)}
         alg8 = N * N + nnz8 + N * N // 8 + 8 * N
         i8 = {"i8_alg_bytes": alg8, "i8_compress_us": round(us_c8, 2), "i8_compress_frac_hbm": round(alg8 / us_c8 / 1e3 / HBM_PEAK_GBPS, 4),
               "i8_decompress_us": round(us_d8, 2), "i8_decompress_frac_hbm": round(alg8 / us_d8 / 1e3 / HBM_PEAK_GBPS, 4), "i8_bit_exact": bool(ok8),
-              "i8_workload": f"sparse-bitmask 50 % unstructured {N}x{N} int8 (FP8 weights ride the same bytes), C ABI, {NI} rotating inputs; outputs against eager torch ops on the device"}
-        del sets8, v8, o8
+              "i8_workload": f"sparse-bitmask 50 % unstructured {N}x{N} int8 (FP8 weights ride the same bytes), C ABI, {NI} rotating sets (dense and compressed images); "
+                             "outputs against eager torch ops on the device", **i8_24}
+        del sets8, v8, o8, v24
     except Exception as e:
         i8 = {"i8_error": repr(e)}
     return {

@@ -615,10 +615,12 @@ __device__ __forceinline__ uint32_t double_bits16(uint32_t x) {
 // UPL = units per lane (4, 2 or 1): a tile is 256 x UPL units, so that a row of 8192 (4096) columns — every FP8 weight of an 8K (4K) model — is ONE
 // FULL tile instead of half (a quarter) of a 16384-column one: with UPL = 4 at 8192 columns half the lanes idled through the barriers and the scan
 // (35.5 us at 8192^2).
-template <bool SINGLE, int UPL>
+// FLAT (rows shorter than a tile, cols % 32 == 0): tiles of 1024 consecutive units of the flattened tensor, as the 16-bit kernel's flat form.
+template <bool SINGLE, int UPL, bool FLAT = false>
 __global__ __launch_bounds__(kBlock) void bitmask_decompress8_kernel(const uint8_t* __restrict__ vin, int64_t values_len, const uint8_t* __restrict__ bitmask,
                                                                      const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz, int64_t rows, int64_t cols,
                                                                      uint8_t* __restrict__ out) {
+    static_assert(!FLAT || (!SINGLE && UPL == 4), "flat tiles are full-size tiles with the row prefix of the several-tiles form");
     constexpr int kUnits = kBlock * UPL;   // units per tile
     constexpr int kTile8 = kUnits * 16;    // elements per tile
     __shared__ __attribute__((aligned(16))) uint8_t s_val[kTile8 + 64];
@@ -640,11 +642,11 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress8_kernel(const uint8
     }
     const int64_t bcols = cols >> 4;  // units per row
     const int64_t tiles_per_row = (cols + kTile8 - 1) / kTile8;
-    const int64_t ntiles = rows * tiles_per_row;
+    const int64_t ntiles = FLAT ? (rows * bcols + kUnits - 1) / kUnits : rows * tiles_per_row;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row = SINGLE ? tile : tile / tiles_per_row;
-        const int64_t u0 = SINGLE ? 0 : (tile - row * tiles_per_row) * kUnits;  // first unit of the tile in its row
-        const int64_t left = bcols - u0;
+        const int64_t row = FLAT ? (tile * kUnits) / bcols : (SINGLE ? tile : tile / tiles_per_row);
+        const int64_t u0 = FLAT ? tile * kUnits - row * bcols : (SINGLE ? 0 : (tile - row * tiles_per_row) * kUnits);  // first unit of the tile in its row
+        const int64_t left = FLAT ? rows * bcols - tile * kUnits : bcols - u0;
         const int nu = left < kUnits ? (int)left : kUnits;                      // units in this tile
         const uint8_t* mrow = bitmask + row * (cols >> 3);                      // two mask bytes per unit
         // the lane's own UPL consecutive units UPL tid .. UPL tid + UPL - 1 (the rank side)
@@ -681,6 +683,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress8_kernel(const uint8
             for (int k = 0; k < UPL; ++k) {
                 const int v = tid + k * kBlock;
                 if (v < nvec && e0 + (int64_t)(v + 1) * 16 > values_len) {  // a tail vector that would cross the end of the buffer
+#pragma unroll 1
                     for (int j = 0; j < 16; ++j) {
                         const int64_t gi = e0 + (int64_t)v * 16 + j;
                         s_val[v * 16 + j] = gi < values_len ? vin[gi] : (uint8_t)0;
@@ -689,6 +692,7 @@ __global__ __launch_bounds__(kBlock) void bitmask_decompress8_kernel(const uint8
             }
             if (tid == 0 && kUnits < nvec) {  // the one possible extra vector (shift > 0, full tile)
                 const int v = kUnits;
+#pragma unroll 1
                 for (int j = 0; j < 16; ++j) {
                     const int64_t gi = e0 + (int64_t)v * 16 + j;
                     s_val[v * 16 + j] = gi < values_len ? vin[gi] : (uint8_t)0;
@@ -856,6 +860,7 @@ __device__ __forceinline__ void bitmask_decompress16_tiles(Decomp16Lds& lds, con
             for (int k = 0; k < UPL; ++k) {
                 const int v = tid + k * kBlock;
                 if (v < nvec && e0 + (int64_t)(v + 1) * 8 > values_len) {  // a tail vector that would cross the end of the buffer
+#pragma unroll 1
                     for (int j = 0; j < 8; ++j) {
                         const int64_t gi = e0 + (int64_t)v * 8 + j;
                         s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
@@ -864,6 +869,7 @@ __device__ __forceinline__ void bitmask_decompress16_tiles(Decomp16Lds& lds, con
             }
             if (tid == 0 && kUnits < nvec) {  // the one possible extra vector (shift > 0, full tile)
                 const int v = kUnits;
+#pragma unroll 1
                 for (int j = 0; j < 8; ++j) {
                     const int64_t gi = e0 + (int64_t)v * 8 + j;
                     s_val[v * 8 + j] = gi < values_len ? vin[gi] : (uint16_t)0;
@@ -938,7 +944,7 @@ __device__ __forceinline__ void bitmask_decompress16_tiles(Decomp16Lds& lds, con
 }
 
 template <int FORM, int ES>
-__global__ __launch_bounds__(kBlock) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len_e,
+__global__ __launch_bounds__(kBlock, FORM == kDecRows ? 6 : 1) void bitmask_decompress16_kernel(const uint16_t* __restrict__ vin, int64_t values_len_e,
                                                                       const uint8_t* __restrict__ bitmask,
                                                                       const int64_t* __restrict__ row_offsets, int64_t fixed_row_nnz_e,
                                                                       int64_t rows, int64_t cols_e, uint16_t* __restrict__ out) {
@@ -2434,21 +2440,26 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
 #undef CT_DEC16
         CT_LAUNCH_CHECK("ct_bitmask_decompress[16]");
     }
-    // 8-bit payloads with row offsets (the unstructured codec): the byte-granular LDS-window kernel.  The 2:4 codec (fixed_row_nnz) keeps the general
-    // kernel, whose 2:4-regular row path turns 8 value bytes + their mask bits into one 16-byte store directly.
-    if (es == 1 && fixed_row_nnz < 0 && cols % 16 == 0 && (cols <= 16384 || cols % 64 == 0) && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0 &&
+    // 8-bit payloads: the byte-granular LDS-window kernel, for the unstructured codec (row offsets) and the 2:4 codec (fixed_row_nnz) alike — the
+    // general kernel's 2:4-regular row path ran 8192^2 int8 at 33.4 us HBM-cold, this one at 22.2-23.0.
+    if (es == 1 && cols % 16 == 0 && (cols <= 16384 || cols % 64 == 0) && vec_out && vec_in && (reinterpret_cast<uintptr_t>(bitmask) & 3u) == 0 &&
         values_len < ((int64_t)1 << 61)) {
-        // units per lane: the smallest tile that holds a whole row (a row of <= 16384 columns is then ONE tile: SINGLE), else 16384-column tiles
-        const int upl = cols <= 4096 ? 1 : (cols <= 8192 ? 2 : 4);
-        const int64_t tiles = rows * cdiv64(cols, (int64_t)kBlock * upl * 16);
-        const unsigned grid8 = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));
-#define CT_DEC8(SINGLE_, UPL_)                                                                                                                             \
-    hipLaunchKernelGGL((bitmask_decompress8_kernel<SINGLE_, UPL_>), dim3(grid8), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(values), \
+#define CT_DEC8(SINGLE_, UPL_, FLAT_, GRID_)                                                                                                                     \
+    hipLaunchKernelGGL((bitmask_decompress8_kernel<SINGLE_, UPL_, FLAT_>), dim3(GRID_), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(values), \
                        values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint8_t*>(out))
-        if (upl == 1) CT_DEC8(true, 1);
-        else if (upl == 2) CT_DEC8(true, 2);
-        else if (cols <= 16384) CT_DEC8(true, 4);
-        else CT_DEC8(false, 4);
+        if (cols < 8192 && cols % 32 == 0) {  // rows shorter than half a tile: flat tiles of 1024 units over the flattened tensor
+            const int64_t ftiles = cdiv64(rows * (cols / 16), 1024);
+            CT_DEC8(false, 4, true, (unsigned)(ftiles < ((int64_t)1 << 30) ? ftiles : ((int64_t)1 << 30)));
+        } else {
+            // units per lane: the smallest tile that holds a whole row (a row of <= 16384 columns is then ONE tile: SINGLE), else 16384-column tiles
+            const int upl = cols <= 4096 ? 1 : (cols <= 8192 ? 2 : 4);
+            const int64_t tiles = rows * cdiv64(cols, (int64_t)kBlock * upl * 16);
+            const unsigned grid8 = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));
+            if (upl == 1) CT_DEC8(true, 1, false, grid8);
+            else if (upl == 2) CT_DEC8(true, 2, false, grid8);
+            else if (cols <= 16384) CT_DEC8(true, 4, false, grid8);
+            else CT_DEC8(false, 4, false, grid8);
+        }
 #undef CT_DEC8
         CT_LAUNCH_CHECK("ct_bitmask_decompress[8]");
     }

@@ -942,7 +942,7 @@ def test_sparse24_vs_oracle(cta, dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn, BF16, F32], ids=["int8", "fp8", "bf16", "fp32"])
-@pytest.mark.parametrize("cols", [64, 1040, 8192])
+@pytest.mark.parametrize("cols", [64, 1040, 2080, 8192, 16384 + 64])
 def test_sparse24_decompress_regular_and_irregular_rows(cta, dev, dtype, cols):
     """the general bitmask decompress expands 2:4-regular rows locally (no prefix) and every other row through the prefix path; a
     tensor whose rows all keep cols / 2 elements but only some of which are 2:4-regular must come back exactly (oracle: the dense
@@ -1136,8 +1136,8 @@ def test_sparse_bitmask_8bit_payloads_take_the_resident_kernel(cta, dev, dtype):
     16 elements = two bitmask bytes, the counts are in bytes, values leave at byte granularity.  Against the CPU oracle and eager torch on the
     device: one workgroup, partial last tiles, rows that straddle tiles, all-zero / dense tensors, every density, 8192 x 8192 (two residency
     rounds); cols % 16 != 0 keeps the count / scan / scatter form; the batched entry takes 8-bit tables too.  The decompress side takes the
-    byte-granular LDS-window kernel when cols % 64 == 0 (single-tile rows, rows of several 16384-column tiles, value runs that start at every
-    offset inside a 16-byte vector, a run that ends at the very end of the buffer)."""
+    byte-granular LDS-window kernel (single-tile rows, rows of several 16384-column tiles, flat tiles over rows shorter than 8192 columns, value
+    runs that start at every offset inside a 16-byte vector, a run that ends at the very end of the buffer)."""
     g = torch.Generator(device=dev).manual_seed(8)
 
     def make(r, c, dens):
@@ -1150,7 +1150,8 @@ def test_sparse_bitmask_8bit_payloads_take_the_resident_kernel(cta, dev, dtype):
     cases = [(1, 16, 0.5), (3, 48, 0.3), (64, 256, 0.0), (257, 1008, 0.7), (2048, 2048, 0.5), (100, 64, 1.0), (33, 4096, 0.02), (5632, 2048, 0.5), (8192, 8192, 0.5),
              (17, 40, 0.5), (64, 1000, 0.5),  # these two: cols % 16 != 0 -> count / scan / scatter
              (3, 16384, 0.5), (5, 32768 + 64, 0.4), (2, 65536, 0.95), (7, 16384 + 4096, 0.0),  # rows of one whole tile / several tiles of the byte-window decompress
-             (33, 4096, 0.5), (9, 4096 + 16, 0.6), (11, 8192 + 48, 0.5), (5, 12288, 0.3), (4, 16384 - 16, 0.8)]  # 1 / 2 / 4 units per lane, partial tiles
+             (33, 4096, 0.5), (9, 4096 + 16, 0.6), (11, 8192 + 48, 0.5), (5, 12288, 0.3), (4, 16384 - 16, 0.8),  # 1 / 2 / 4 units per lane, partial tiles
+             (37, 2080, 0.5), (1000, 96, 0.4), (5, 8160, 0.6), (129, 32, 0.5)]  # flat tiles (cols < 8192, cols % 32 == 0): rows that straddle tiles, a partial last tile
     ws = [make(*c) for c in cases]
     for w in ws:
         v, bm, ro = cta.codec.bitmask_compress(w)
