@@ -2151,9 +2151,12 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
         }
         // wave-tiles per wave: as many as the registers hold, fewer when the tensor would otherwise leave CUs without a workgroup
         // (two 8-wave workgroups fit a CU; 4-wave workgroups, four per CU, measured the same: 41.8-43.3 us against 42.0-42.3)
-        constexpr int wgs_per_cu = 2;
+        // 8-bit payloads (round 6): ONE tile per wave and four workgroups per CU (55 VGPRs) — the row form's 64 rows per tile are instruction-bound, and
+        // full occupancy hides more of it: 8192^2 int8 36.0 -> 32.0 us
+        const int wgs_per_cu = es == 1 ? 4 : 2;
         int64_t tpw = cdiv64(wts, (int64_t)cus * wgs_per_cu * kResWaves);
-        if (tpw > kResKeep) tpw = kResKeep;
+        const int keep_cap = es == 1 ? 1 : kResKeep;
+        if (tpw > keep_cap) tpw = keep_cap;
         if (tpw < 1) tpw = 1;
         const int64_t wg_wts = (int64_t)kResWaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
 #ifdef CT_DIAG
@@ -2212,16 +2215,26 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
                 // raw count words of the earlier rounds (44.9 -> 44.6 us by itself; kept: it halves the polling of the later rounds)
                 const int round_wgs = (wgs_per_cu * cus <= kResMaxWGs && cdiv64(nwg, wgs_per_cu * (int64_t)cus) <= kResRoundWords) ? wgs_per_cu * cus : 0;
                 unsigned long long* round_words = ctl + 4 + 4 * kResStampWGs;
-#define CT_RESIDENT_W(ES_, W_, R_)                                                                                                                \
-    hipLaunchKernelGGL((flat16_resident_kernel<kResKeep, W_, ES_, R_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                   \
+#define CT_RESIDENT_WK(ES_, W_, R_, K_)                                                                                                              \
+    hipLaunchKernelGGL((flat16_resident_kernel<K_, W_, ES_, R_>), dim3((unsigned)nwg), dim3(W_ * 64), 0, as_stream(stream),                   \
                        static_cast<const u32x4*>(x) + u0, float_kind(dt), cu, upr, rows, (int)tpw, static_cast<uint16_t*>(values),                 \
                        values_capacity * (ES_ == 4 ? 2 : 1), bm0, mask_dwords, row_offsets, u0, k ? ctl + 2 + ((k - 1) & 1) : nullptr, slots, run_out, \
                        tag_of(gen0 + (uint32_t)k), wait_ticks, CT_STAMPS_ARG(k == 0 ? stamps : nullptr) stagger_lo, stagger_hi, stagger_ticks, stagger_slope_q8,       \
                        round_wgs, round_words)
-                if (es == 4) CT_RESIDENT_W(4, kResWaves, 1);       // the row form: 69 % against 65 % of the HBM peak at 8192^2 float32
-                else if (es == 1) CT_RESIDENT_W(1, kResWaves, 1);  // 8-bit payloads: the row form, 64 rows per tile
-                else CT_RESIDENT_W(2, kResWaves, 0);               // the unit form: the row form is scalar-bound at 32 rows per tile
-#undef CT_RESIDENT_W
+                // the kernel is instantiated per tiles-per-wave (round 6): its loads are unconditional straight-line code, so a wave of the KEEP = 4 kernel
+                // with tpw = 2 read two tiles it never used (4096^2 bf16: 18.3 -> 14.9 us with KEEP = 2)
+#define CT_RESIDENT_K(ES_, R_)                                                                 \
+    switch ((int)tpw) {                                                                         \
+        case 1: CT_RESIDENT_WK(ES_, kResWaves, R_, 1); break;                                   \
+        case 2: CT_RESIDENT_WK(ES_, kResWaves, R_, 2); break;                                   \
+        case 3: CT_RESIDENT_WK(ES_, kResWaves, R_, 3); break;                                   \
+        default: CT_RESIDENT_WK(ES_, kResWaves, R_, kResKeep); break;                           \
+    }
+                if (es == 4) CT_RESIDENT_K(4, 1)                     // the row form: 69 % against 65 % of the HBM peak at 8192^2 float32
+                else if (es == 1) CT_RESIDENT_WK(1, kResWaves, 1, 1);  // 8-bit payloads: the row form, 64 rows per tile
+                else CT_RESIDENT_K(2, 0)                             // the unit form: the row form is scalar-bound at 32 rows per tile
+#undef CT_RESIDENT_K
+#undef CT_RESIDENT_WK
             }
             CT_LAUNCH_CHECK("ct_bitmask_compress[resident]");
         }

@@ -1604,6 +1604,33 @@ def test_bitmask_compress_forms_agree(env):
     assert r.returncode == 0 and "FORMS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("dtype,shapes", [
+    (BF16, [(2048, 4096), (2048, 4096 + 8), (4096, 4096), (4100, 4096), (4096, 6144), (6000, 4096), (8192, 5120), (8192, 8192)]),
+    (F32, [(2048, 2048), (2049, 2048), (4096, 2048), (4096, 3072), (3000, 4096), (4096, 4096)]),
+    (torch.int8, [(4096, 4096), (8192, 8192), (8192, 8192 + 16), (3, 16)]),
+], ids=["bf16", "fp32", "int8"])
+def test_bitmask_compress_every_tiles_per_wave_instantiation(cta, dev, dtype, shapes):
+    """Round 6: the resident compress is instantiated per tiles-per-wave (1, 2, 3, 4 — the launch picks the one that matches the tensor's size, so that a
+    wave loads no tile it does not use) and 8-bit payloads take one tile per wave at four workgroups per CU.  Sizes on both sides of every boundary,
+    against eager torch on the device: values, bitmask, row offsets, total."""
+    g = torch.Generator(device=dev).manual_seed(61)
+    weights = (1 << torch.arange(8, device=dev, dtype=torch.int32))
+    for (r, c) in shapes:
+        if dtype is torch.int8:
+            w = torch.randint(-127, 128, (r, c), device=dev, generator=g, dtype=torch.int16).to(torch.int8)
+        else:
+            w = torch.randn(r, c, device=dev, generator=g, dtype=dtype)
+        w = w.masked_fill_(torch.rand(r, c, device=dev, generator=g) < 0.5, 0)
+        v, bm, ro = cta.codec.bitmask_compress(w)
+        m = w != 0
+        cnt = m.sum(-1)
+        assert v.numel() == int(cnt.sum()) and torch.equal(v, w[m]), (r, c)
+        assert torch.equal(ro, torch.cumsum(cnt, 0) - cnt), (r, c)
+        assert torch.equal(bm, (m.view(r, c // 8, 8).to(torch.int32) * weights).sum(-1).to(torch.uint8)), (r, c)
+        assert torch.equal(cta.codec.bitmask_decompress(v, bm, w.shape, ro), w), (r, c)
+        del w, v, bm, ro, m
+
+
 @pytest.mark.parametrize("dtype", [BF16, F16, F32, torch.int16, torch.int32], ids=["bf16", "fp16", "fp32", "int16", "int32"])
 def test_bitmask_compress_every_bit_pattern(cta, dev, dtype):
     """the non-zero test of the sparse compress on every 16-bit pattern (and, for 32-bit payloads, every exponent x sign x {zero, lowest bit,
