@@ -155,33 +155,35 @@ def time_calls(fn, iters=MIN_LAUNCHES_PER_BLOCK, offset=0):
     return median(per), min(per), max(per)
 
 
-def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, actorder=False):
+def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, actorder=False, cols=None):
     """HBM-cold per-kernel timing of the fused W4A16 g128 compress / decompress at another size, weight dtype, with an
     asymmetric scheme (int8 zero points) or with activation ordering (`weight_g_idx`: a random assignment of the columns to
-    the groups): enough rotating sets that the smallest read stream (the packed words) is >= 2x the 256 MiB Infinity Cache.
+    the groups; `cols`: a row length other than n, e.g. 28672 = 224 groups per row): enough rotating sets that the smallest read stream
+    (the packed words) is >= 2x the 256 MiB Infinity Cache.
     Parity: decompress(compress(W)) == fake_quantize(W) on one set (for actorder: fake_quantize with the same g_idx)."""
     from compressed_tensors_amd import _lib, codec
 
     lib = _lib.load()
     stream = torch.cuda.current_stream(dev).cuda_stream
     dt = _lib.DT[dtype]
-    nsets = max(4, -(-(2 * 256 * 2 ** 20) // (n * n // 2)))
+    c = n if cols is None else cols
+    nsets = max(4, -(-(2 * 256 * 2 ** 20) // (n * c // 2)))
     g = torch.Generator(device=dev).manual_seed(31 + n)
     g_idx = cg = None
     if actorder:
-        g_idx = (torch.randperm(n, device=dev, generator=g) // GROUP).to(torch.int32)
-        cg = codec.QuantLayout((n, n), torch.empty(n, n // GROUP, dtype=dtype, device=dev), "group", GROUP, None, g_idx).col_group
+        g_idx = (torch.randperm(c, device=dev, generator=g) // GROUP).to(torch.int32)
+        cg = codec.QuantLayout((n, c), torch.empty(n, c // GROUP, dtype=dtype, device=dev), "group", GROUP, None, g_idx).col_group
         order = torch.argsort(g_idx)
     sets = []
     for _ in range(nsets):
-        w = torch.randn(n, n, dtype=torch.float32, device=dev, generator=g).to(dtype)
+        w = torch.randn(n, c, dtype=torch.float32, device=dev, generator=g).to(dtype)
         scale, zp = codec.minmax_qparams(w[:, order].contiguous() if actorder else w, num_bits=BITS, group_size=GROUP, symmetric=symmetric)
-        sets.append((w, scale, zp, torch.empty(n, n // 8, dtype=torch.int32, device=dev), torch.empty(n, n, dtype=dtype, device=dev)))
+        sets.append((w, scale, zp, torch.empty(n, c // 8, dtype=torch.int32, device=dev), torch.empty(n, c, dtype=dtype, device=dev)))
     cgp = None if cg is None else cg.data_ptr()
-    ca = [(w.data_ptr(), dt, sc.data_ptr(), dt, zp.data_ptr(), _lib.I8, n, n, 1, GROUP, n // GROUP, cgp, BITS, dt, pk.data_ptr(), stream)
+    ca = [(w.data_ptr(), dt, sc.data_ptr(), dt, zp.data_ptr(), _lib.I8, n, c, 1, GROUP, c // GROUP, cgp, BITS, dt, pk.data_ptr(), stream)
           for (w, sc, zp, pk, out) in sets]
-    da = [(pk.data_ptr(), n, n // 8, n, BITS, sc.data_ptr(), dt, None if symmetric else zp.data_ptr(), -1 if symmetric else _lib.I8,
-           1, GROUP, n // GROUP, cgp, out.data_ptr(), dt, stream) for (w, sc, zp, pk, out) in sets]
+    da = [(pk.data_ptr(), n, c // 8, c, BITS, sc.data_ptr(), dt, None if symmetric else zp.data_ptr(), -1 if symmetric else _lib.I8,
+           1, GROUP, c // GROUP, cgp, out.data_ptr(), dt, stream) for (w, sc, zp, pk, out) in sets]
 
     def compress(i):
         rc = lib.ct_quant_pack(*ca[i % nsets])
@@ -195,7 +197,7 @@ def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, acto
 
     for i in range(nsets):
         compress(i)
-    one = alg_bytes_one_direction(n) + (0 if symmetric else n * (n // GROUP)) + (4 * n if actorder else 0)  # + int8 zero points, + the group table
+    one = (2 * n * c + 2 * n * (c // GROUP) + n * c * BITS // 8) + (0 if symmetric else n * (c // GROUP)) + (4 * c if actorder else 0)  # + int8 zero points, + the group table
     us_c, us_d = time_kernel(compress, iters), time_kernel(decompress, iters, offset=nsets // 2)
     # the same launches on ONE buffer set (Infinity-Cache-warm; reported beside the cold figure, never instead of it)
     warm_c, warm_d = time_kernel(lambda i: compress(0), iters), time_kernel(lambda i: decompress(0), iters)
@@ -209,7 +211,7 @@ def w4_kernel_point(dev, n, dtype=torch.bfloat16, symmetric=True, iters=60, acto
         od = O.pack_quantized_decompress(oc, num_bits=BITS, strategy="group", symmetric=symmetric)
         ok = ok and torch.equal(pk[sl].cpu(), oc["weight_packed"]) and torch.equal(out[sl].cpu().view(torch.int16), od["weight"].view(torch.int16))
     pair = {}
-    if n <= 4096 and symmetric and not actorder and nsets >= 4:
+    if n <= 4096 and c == n and symmetric and not actorder and nsets >= 4:
         # what a caller with q / k or gate / up PAIRS of this size has — `ct_quant_pack_batch` / `ct_unpack_dequant_batch`
         # with n = 2 (codec.quantize_and_pack_many): two tensors per launch, tables prebuilt, HBM-cold rotation over the same sets
         tabs_c, tabs_d = [], []
@@ -236,7 +238,8 @@ def w4_variants_leg(dev):
     out = {"workload": "W4A16 g128 fused compress / decompress kernels through the C ABI, HBM-cold rotation"}
     for key, kw in (("bf16_4096", dict(n=4096)), ("fp16_8192", dict(n=N, dtype=torch.float16)),
                     ("bf16_8192_asymmetric", dict(n=N, symmetric=False)), ("fp16_8192_asymmetric", dict(n=N, dtype=torch.float16, symmetric=False)),
-                    ("bf16_8192_actorder", dict(n=N, actorder=True))):
+                    ("bf16_8192_actorder", dict(n=N, actorder=True)),
+                    ("bf16_4096x28672_actorder", dict(n=4096, cols=28672, actorder=True, iters=36))):  # 224 groups per row (a 70B down_proj): the 256-group tables
         out[key] = w4_kernel_point(dev, **kw)
         torch.cuda.empty_cache()
     return out
@@ -1142,7 +1145,7 @@ def roofline_rows(result):
             row("bitmask_decompress16_kernel<float32 as pairs of halves>", "sparse-bitmask 50 % 8192x8192 float32, decompress", b["f32_alg_bytes"], b["f32_decompress_us"], bit_exact=b["f32_bit_exact"])
         if "i8_compress_us" in b:
             row("flat16_resident_kernel<8-bit payloads, row form>", "sparse-bitmask 50 % 8192x8192 int8 / fp8 bytes, compress", b["i8_alg_bytes"], b["i8_compress_us"], bit_exact=b["i8_bit_exact"])
-            row("bitmask_decompress_kernel<8-bit payloads>", "sparse-bitmask 50 % 8192x8192 int8 / fp8 bytes, decompress", b["i8_alg_bytes"], b["i8_decompress_us"], bit_exact=b["i8_bit_exact"])
+            row("bitmask_decompress8_kernel<8-bit payloads>", "sparse-bitmask 50 % 8192x8192 int8 / fp8 bytes, decompress", b["i8_alg_bytes"], b["i8_decompress_us"], bit_exact=b["i8_bit_exact"])
     k4 = leg("kernels_4096")
     if k4:
         pb = k4.get("pair_batch") or {}
@@ -1151,11 +1154,12 @@ def roofline_rows(result):
         row("w4_quant_pack_lean_kernel<bf16>", "W4A16 g128 4096x4096 bf16, compress", k4["alg_bytes_per_direction"], k4["compress_us"], **pc)
         row("w4_unpack_dequant_kernel<bf16>", "W4A16 g128 4096x4096 bf16, decompress", k4["alg_bytes_per_direction"], k4["decompress_us"], **pd)
     ko = leg("kernels_other") or {}
-    for key in ("fp16_8192", "bf16_8192_asymmetric", "bf16_8192_actorder"):
+    for key in ("fp16_8192", "bf16_8192_asymmetric", "bf16_8192_actorder", "bf16_4096x28672_actorder"):
         v = ko.get(key)
         if isinstance(v, dict):
-            row("w4 compress", f"W4A16 g128 8192x8192 {key}", v["alg_bytes_per_direction"], v["compress_us"])
-            row("w4 decompress", f"W4A16 g128 8192x8192 {key}", v["alg_bytes_per_direction"], v["decompress_us"])
+            shape = "4096x28672" if "28672" in key else "8192x8192"
+            row("w4 compress", f"W4A16 g128 {shape} {key}", v["alg_bytes_per_direction"], v["compress_us"])
+            row("w4 decompress", f"W4A16 g128 {shape} {key}", v["alg_bytes_per_direction"], v["decompress_us"])
     ow = leg("other_widths") or {}
     for b_ in (3, 2, 6):
         v = ow.get(f"w{b_}")

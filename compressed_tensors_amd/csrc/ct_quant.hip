@@ -272,25 +272,49 @@ __global__ __launch_bounds__(kBlock) void w4_gidx_rows_kernel(W4Params p, const 
             }
         }
     }
-    // 3. the R rows' entries -> LDS
+    // 3. the R rows' entries -> LDS.  Round 6: every load of the table is issued before the first conversion, with compile-time trip counts (row by
+    // row, MAXG / 256 entries per lane and row) — the earlier `for (e = tid; e < R * scale_cols; e += 256)` loop ran its iterations one memory
+    // latency after the other and divided by scale_cols in each: 4 dependent round trips at 224 groups per row (28672 columns of group 128)
+    constexpr int KG = MAXG > kBlock ? MAXG / kBlock : 1;
     bool nz = false;  // some zero point of these rows is not zero
-    for (int e = threadIdx.x; e < R * (int)p.scale_cols; e += kBlock) {
-        const int r = e / (int)p.scale_cols, g = e - r * (int)p.scale_cols;
-        if (row0 + r < rows) {
-            const int64_t si = (row0 + r) * p.scale_cols + g;
-            const float s = load_as_f<DT>(p.scale, si);
-            const float v = COMPRESS ? (DT == CT_BF16 ? bf16_fast_rcp(s) : f16_newton_rcp(s)) : s;
-            if constexpr (HAS_ZP) {
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const float z = round_to<DT>(load_rt(p.zp, p.zdt, si));
-                nz |= z != 0.0f;
-                *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, z};
-            } else {
-                *reinterpret_cast<float*>(s_tab + r * kRowBytes + g * 4) = v;
+    // (the zero point's dtype is decided ONCE, outside the loads: a dtype switch around every load ends in a merge point where the wait-count pass
+    // drains all loads — 4 x R dependent round trips instead of one; measured 32.9 -> 45.1 us at 8192^2 with the switch inside)
+    auto stage_table = [&](auto load_zp) {
+        float sv[R][KG], zv[HAS_ZP ? R : 1][HAS_ZP ? KG : 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const int g = (int)threadIdx.x + k * kBlock;
+                const bool ok = g < (int)p.scale_cols && row0 + r < rows;
+                const int64_t si = ok ? (row0 + r) * p.scale_cols + g : 0;  // (clamped: the loads are unconditional)
+                sv[r][k] = load_as_f<DT>(p.scale, si);
+                if constexpr (HAS_ZP) zv[r][k] = load_zp(si);
             }
-            if constexpr (COMPRESS) s_slow[r * MAXG + g] = s;
         }
-    }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                const int g = (int)threadIdx.x + k * kBlock;
+                if (g < (int)p.scale_cols && row0 + r < rows) {
+                    const float sc = sv[r][k];
+                    const float v = COMPRESS ? (DT == CT_BF16 ? bf16_fast_rcp(sc) : f16_newton_rcp(sc)) : sc;
+                    if constexpr (HAS_ZP) {
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const float z = round_to<DT>(zv[r][k]);
+                        nz |= z != 0.0f;
+                        *reinterpret_cast<f2*>(s_tab + r * kRowBytes + g * 8) = f2{v, z};
+                    } else {
+                        *reinterpret_cast<float*>(s_tab + r * kRowBytes + g * 4) = v;
+                    }
+                    if constexpr (COMPRESS) s_slow[r * MAXG + g] = sc;
+                }
+            }
+        }
+    };
+    if (HAS_ZP && p.zdt == CT_I8) stage_table([&](int64_t si) { return (float)static_cast<const int8_t*>(p.zp)[si]; });
+    else stage_table([&](int64_t si) { return HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f; });
     // LDS byte offsets of the groups, two per register
     uint32_t go[UL][4];
 #pragma unroll
@@ -1611,12 +1635,16 @@ template <bool COMPRESS>
 static int launch_w4_gidx(const W4Params& w, int dt, const void* zp, const int32_t* col_group, int64_t rows, ct_stream_t stream, const char* what) {
     const int chunks = (int)cdiv64(w.upr, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits) * kBlock);
     dim3 g((unsigned)(cdiv64(rows, kGidxRows) * chunks));
-#define CT_GIDXR(DT, ZP) do { if (w.scale_cols <= kGidxSmallGroups) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS, kGidxRows, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits), kGidxSmallGroups>), \
-                                                                                       g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows); \
-                              else hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS>), g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows); } while (0)
+    // the LDS tables are sized for 128 / 256 / 512 / 1024 groups per row (round 6: rows of 28672 columns — 224 groups — ran on the 1024-group tables at
+    // 3-5 workgroups per CU)
+#define CT_GIDXR_G(DT, ZP, MAXG_) hipLaunchKernelGGL((w4_gidx_rows_kernel<DT, ZP, COMPRESS, kGidxRows, (COMPRESS ? kGidxCompressUnits : kGidxDecompressUnits), MAXG_>), \
+                                                     g, dim3(kBlock), 0, as_stream(stream), w, col_group, chunks, rows)
+#define CT_GIDXR(DT, ZP) do { if (w.scale_cols <= kGidxSmallGroups) CT_GIDXR_G(DT, ZP, kGidxSmallGroups); else if (w.scale_cols <= 256) CT_GIDXR_G(DT, ZP, 256); \
+                              else if (w.scale_cols <= 512) CT_GIDXR_G(DT, ZP, 512); else CT_GIDXR_G(DT, ZP, kGidxMaxGroups); } while (0)
     if (dt == CT_BF16) { if (zp) CT_GIDXR(CT_BF16, true); else CT_GIDXR(CT_BF16, false); }
     else { if (zp) CT_GIDXR(CT_F16, true); else CT_GIDXR(CT_F16, false); }
 #undef CT_GIDXR
+#undef CT_GIDXR_G
     return hip_check(hipGetLastError(), what);
 }
 
@@ -1806,7 +1834,7 @@ static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, 
     if (!gscale && (qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        const int unroll = decomp_unroll(w.units);
+        const int unroll = decomp_unroll(w.units);  // (round 6 sweep, 2048^2 ... 8192^2, int8 and fp8: the rule is at or within 2 % of the best U at every size)
         dim3 g8(w4_grid(w.units, unroll));
 #define CT_Q8D(DT, ZP) CT_FOR_UNROLL(unroll, if (qdt == CT_F8E4M3) hipLaunchKernelGGL((f8_dequant_kernel<DT, U, ZP>), g8, dim3(kBlock), 0, as_stream(stream), w); \
                                              else hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 0>), g8, dim3(kBlock), 0, as_stream(stream), w))
@@ -1970,10 +1998,12 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
     if (words == cols / 8 && w4_eligible(sdt, sdt, odt, bits, rows, cols, rdiv, cdiv, col_group, packed, out) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        const int unroll = decomp_unroll(w.units);
+        // units per lane: TWO at every size (round 6).  decomp_unroll() — more units per lane on mid-size tensors so that they fit one residency round,
+        // tuned on the int8 dequantize — LOSES here: 4096 x 6144 13.2 -> 12.2 us, 5120^2 14.0 -> 13.0, asymmetric 5120^2 15.4 (U = 4) -> 13.4; equal
+        // elsewhere (4096^2 ... 8192^2, tools/scratch sweep recorded in DESIGN.md 5.2)
+        constexpr int unroll = 2;
         dim3 grid(w4_grid(w.units, unroll));
         // (a scales-first lean variant of this kernel measured SLOWER: 39-42 us vs 30 us)
-        // units per lane: decomp_unroll()
         // one scale / zero-point load per 16-lane row when a row never straddles a scale group
         // (asymmetric only: on the symmetric kernel the same trick measured 29.5 -> 31.1 us)
         const bool rowlead = zp && w.flat_scale && w.upg_shift >= 4 && w.upg_shift < 62 && w.units % 16 == 0 && zdt == CT_I8;
@@ -1982,9 +2012,9 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         // with them (4096^2: 8.5 -> 10.2 us), so those keep the vector loads (tools/kbench/kbench_w4d.hip, profiles/r05_w4d_scale_modes.txt)
         const bool scalar = w.flat_scale && w.upg_shift == 4 && w.units % 64 == 0 && w.units > 8 * (int64_t)kCUs * 8 * kBlock && (!zp || zdt == CT_I8) &&
                             (reinterpret_cast<uintptr_t>(scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(zp) & 3u) == 0;
-#define CT_W4D(DT, ZP) CT_FOR_UNROLL(unroll, if (scalar) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScaleScalar>), grid, dim3(kBlock), 0, as_stream(stream), w); \
-                                             else if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScaleRowLead>), grid, dim3(kBlock), 0, as_stream(stream), w); \
-                                             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScalePerLane>), grid, dim3(kBlock), 0, as_stream(stream), w))
+#define CT_W4D(DT, ZP) do { if (scalar) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, unroll, ZP, kW4ScaleScalar>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                            else if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, unroll, ZP, kW4ScaleRowLead>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, unroll, ZP, kW4ScalePerLane>), grid, dim3(kBlock), 0, as_stream(stream), w); } while (0)
         if (sdt == CT_BF16) { if (zp) CT_W4D(CT_BF16, true); else CT_W4D(CT_BF16, false); }
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D

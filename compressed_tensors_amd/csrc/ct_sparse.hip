@@ -2373,7 +2373,7 @@ int64_t ct_bitmask_decompress_batch_plan(ct_bitmask_ditem* items, int n) {
         }
         const int64_t hcols = it.cols * es / 2;  // the row in 16-bit items
         // the tile form (the kernel's dispatch): rows of several tiles / the row is one tile / 16-bit rows shorter than a tile: flat tiles
-        it.single = hcols > kTile16 ? kDecRows : (es == 2 && hcols < kTile16 ? kDecFlat : kDecSingle);
+        it.single = (es == 2 && hcols % kTile16 != 0) ? kDecFlat : (hcols > kTile16 ? kDecRows : kDecSingle);  // as the single-tensor launch
         it.first_block = blocks;
         blocks += it.single == kDecFlat ? cdiv64(it.rows * (hcols / 8), kTile16 / 8) : it.rows * cdiv64(hcols, kTile16);
     }
@@ -2445,7 +2445,10 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
     hipLaunchKernelGGL((bitmask_decompress16_kernel<FORM_, ES_>), dim3(grid), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(values), \
                        values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out))
         if (es == 4) { if (hcols <= kTile16) CT_DEC16(kDecSingle, 4); else CT_DEC16(kDecRows, 4); }
-        else if (hcols < kTile16) {  // round 6: rows shorter than a tile -> flat tiles of 1024 consecutive units (see the kernel)
+        else if (hcols % kTile16 != 0) {
+            // round 6: rows that are not whole tiles -> flat tiles of 1024 consecutive units (see the kernel).  Short rows first (2048 columns: one row per
+            // workgroup moved 6 KB); long rows too — the last tile of an 11008-column row is a third full: 4096 x 11008 30.1 -> 26.5 us, 12288 30.0 -> 27.5,
+            // 13824 39.5 -> 37.4, 28672 119.8 -> 116.2
             const int64_t ftiles = cdiv64(rows * (hcols / 8), kTile16 / 8);
             hipLaunchKernelGGL((bitmask_decompress16_kernel<kDecFlat, 2>), dim3((unsigned)(ftiles < ((int64_t)1 << 30) ? ftiles : ((int64_t)1 << 30))), dim3(kBlock), 0,
                                as_stream(stream), static_cast<const uint16_t*>(values), values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint16_t*>(out));
@@ -2460,7 +2463,9 @@ int ct_bitmask_decompress(const void* values, int64_t values_len, const uint8_t*
 #define CT_DEC8(SINGLE_, UPL_, FLAT_, GRID_)                                                                                                                     \
     hipLaunchKernelGGL((bitmask_decompress8_kernel<SINGLE_, UPL_, FLAT_>), dim3(GRID_), dim3(kBlock), 0, as_stream(stream), static_cast<const uint8_t*>(values), \
                        values_len, bitmask, row_offsets, fixed_row_nnz, rows, cols, static_cast<uint8_t*>(out))
-        if (cols < 8192 && cols % 32 == 0) {  // rows shorter than half a tile: flat tiles of 1024 units over the flattened tensor
+        if ((cols < 8192 || (cols > 16384 && cols % 16384 != 0)) && cols % 32 == 0) {
+            // flat tiles of 1024 units over the flattened tensor: rows shorter than half a tile, and rows of several tiles whose last one would be
+            // partial (3584 x 18944 29.2 -> 24.8 us); between 8192 and 16384 columns the single partial tile wins (4096 x 11008 17.2 against 17.8)
             const int64_t ftiles = cdiv64(rows * (cols / 16), 1024);
             CT_DEC8(false, 4, true, (unsigned)(ftiles < ((int64_t)1 << 30) ? ftiles : ((int64_t)1 << 30)));
         } else {

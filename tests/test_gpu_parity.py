@@ -942,7 +942,7 @@ def test_sparse24_vs_oracle(cta, dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.int8, torch.float8_e4m3fn, BF16, F32], ids=["int8", "fp8", "bf16", "fp32"])
-@pytest.mark.parametrize("cols", [64, 1040, 2080, 8192, 16384 + 64])
+@pytest.mark.parametrize("cols", [64, 1040, 2080, 8192, 11008, 16384 + 64])
 def test_sparse24_decompress_regular_and_irregular_rows(cta, dev, dtype, cols):
     """the general bitmask decompress expands 2:4-regular rows locally (no prefix) and every other row through the prefix path; a
     tensor whose rows all keep cols / 2 elements but only some of which are 2:4-regular must come back exactly (oracle: the dense
@@ -1186,7 +1186,9 @@ def test_bitmask_decompress_many_and_the_batch_entry(cta, dev):
 
     g = torch.Generator(device=dev).manual_seed(31)
     specs = [(2048, 2048, BF16, 0.5), (256, 2048, BF16, 0.3), (5632, 2048, F16, 0.5), (64, 8192 + 4096, BF16, 0.6), (3, 32768, BF16, 0.5), (100, 64, BF16, 0.0),
-             (33, 4096, BF16, 1.0), (300, 1024, F32, 0.5), (17, 2048 + 32, BF16, 0.5), (128, 256, torch.int8, 0.5), (40, 24, BF16, 0.5), (64, 512, BF16, 0.5)]
+             (33, 4096, BF16, 1.0), (300, 1024, F32, 0.5), (17, 2048 + 32, BF16, 0.5), (128, 256, torch.int8, 0.5), (40, 24, BF16, 0.5),
+             (9, 11008, BF16, 0.5), (5, 8192 + 64, F16, 0.3), (3, 28672, BF16, 0.7), (4, 16384, BF16, 0.5),  # long rows: flat tiles unless the row is whole tiles
+             (64, 512, BF16, 0.5)]
     ws = []
     for r, c, dt, dens in specs:
         w = torch.randn(r, c, device=dev, generator=g)

@@ -99,7 +99,7 @@ def case_pack(g):
 
 def case_bitmask(g):
     dt = rng.choice([BF16, F16, F32, torch.int8])
-    rows, cols = rng.choice([1, 3, 17, 64, 300]), rng.choice([1, 8, 24, 40, 64, 1000, 4096, 8192, 8200, 16384 + 32])
+    rows, cols = rng.choice([1, 3, 17, 64, 300]), rng.choice([1, 8, 24, 40, 64, 96, 1000, 2080, 4096, 8160, 8192, 8200, 16384 + 32])
     x = torch.randn((rows, cols), generator=g)
     x = x.masked_fill(torch.rand((rows, cols), generator=g) < rng.choice([0.0, 0.1, 0.5, 0.9, 1.0]), 0)
     x = (x * 50).to(dt) if dt == torch.int8 else x.to(dt)
@@ -183,7 +183,7 @@ def case_channel8(g):
 
 def case_sparse24(g):
     dt = rng.choice([BF16, F16, torch.int8, F32])
-    rows, cols = rng.choice([1, 4, 33, 64]), 8 * rng.choice([1, 2, 9, 64, 130, 512, 1024])
+    rows, cols = rng.choice([1, 4, 33, 64]), 8 * rng.choice([1, 2, 9, 64, 130, 260, 512, 1020, 1024, 2056])
     x = torch.randn((rows, cols), generator=g)
     x = (x * 40).to(dt) if dt == torch.int8 else x.to(dt)
     mask = codec.sparse24_mask(x.to(dev))
