@@ -1617,6 +1617,13 @@ static int decomp_unroll(int64_t units) {
     if (units <= 8 * round_lanes) return 8;
     return 2;
 }
+// The W4 and packed-W8 decompress (group scales: one scale load per unit): four units per lane only where they make the tensor ONE residency round
+// (2 .. 4 rounds of lanes: 4096^2 9.8 -> 8.5 us); eight never pay — HBM-cold, round 6: 4096 x 6144 12.9 (U = 2) / 14.4 (4) / 14.0 (8) us, 5120^2
+// 13.4 / 15.1 / 14.5, packed W8 5120^2 15.0 / 17.2 / 23.2 (117 VGPRs at U = 8) — decomp_unroll()'s mid band cost those kernels 10-35 %.
+static int decomp_unroll_grouped(int64_t units) {
+    const int64_t round_lanes = (int64_t)kCUs * 8 * kBlock;
+    return (units > 2 * round_lanes && units <= 4 * round_lanes) ? 4 : 2;
+}
 #define CT_FOR_UNROLL(u, ...)                                   \
     do {                                                        \
         if ((u) == 8) { constexpr int U = 8; __VA_ARGS__; }      \
@@ -1998,10 +2005,8 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
     if (words == cols / 8 && w4_eligible(sdt, sdt, odt, bits, rows, cols, rdiv, cdiv, col_group, packed, out) &&
         (reinterpret_cast<uintptr_t>(packed) & 3u) == 0) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        // units per lane: TWO at every size (round 6).  decomp_unroll() — more units per lane on mid-size tensors so that they fit one residency round,
-        // tuned on the int8 dequantize — LOSES here: 4096 x 6144 13.2 -> 12.2 us, 5120^2 14.0 -> 13.0, asymmetric 5120^2 15.4 (U = 4) -> 13.4; equal
-        // elsewhere (4096^2 ... 8192^2, tools/scratch sweep recorded in DESIGN.md 5.2)
-        constexpr int unroll = 2;
+        // units per lane: decomp_unroll_grouped()
+        const int unroll = decomp_unroll_grouped(w.units);
         dim3 grid(w4_grid(w.units, unroll));
         // (a scales-first lean variant of this kernel measured SLOWER: 39-42 us vs 30 us)
         // one scale / zero-point load per 16-lane row when a row never straddles a scale group
@@ -2012,9 +2017,9 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
         // with them (4096^2: 8.5 -> 10.2 us), so those keep the vector loads (tools/kbench/kbench_w4d.hip, profiles/r05_w4d_scale_modes.txt)
         const bool scalar = w.flat_scale && w.upg_shift == 4 && w.units % 64 == 0 && w.units > 8 * (int64_t)kCUs * 8 * kBlock && (!zp || zdt == CT_I8) &&
                             (reinterpret_cast<uintptr_t>(scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(zp) & 3u) == 0;
-#define CT_W4D(DT, ZP) do { if (scalar) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, unroll, ZP, kW4ScaleScalar>), grid, dim3(kBlock), 0, as_stream(stream), w); \
-                            else if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, unroll, ZP, kW4ScaleRowLead>), grid, dim3(kBlock), 0, as_stream(stream), w); \
-                            else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, unroll, ZP, kW4ScalePerLane>), grid, dim3(kBlock), 0, as_stream(stream), w); } while (0)
+#define CT_W4D(DT, ZP) CT_FOR_UNROLL(unroll, if (scalar) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScaleScalar>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                                             else if (rowlead) hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScaleRowLead>), grid, dim3(kBlock), 0, as_stream(stream), w); \
+                                             else hipLaunchKernelGGL((w4_unpack_dequant_kernel<DT, U, ZP, kW4ScalePerLane>), grid, dim3(kBlock), 0, as_stream(stream), w))
         if (sdt == CT_BF16) { if (zp) CT_W4D(CT_BF16, true); else CT_W4D(CT_BF16, false); }
         else { if (zp) CT_W4D(CT_F16, true); else CT_W4D(CT_F16, false); }
 #undef CT_W4D
@@ -2039,7 +2044,8 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
     if (bits == 8 && words == cols / 4 && cols % 32 == 0 && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(packed) & 7u) == 0) {
         W4Params w = make_w4(packed, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        const int unroll = decomp_unroll(w.units);
+        // units per lane: decomp_unroll_grouped() (at 8 units per lane this variant — it un-biases the packed bytes — needs 117 VGPRs)
+        const int unroll = decomp_unroll_grouped(w.units);
         dim3 g8(w4_grid(w.units, unroll));
 #define CT_Q8U(DT, ZP) CT_FOR_UNROLL(unroll, hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 128>), g8, dim3(kBlock), 0, as_stream(stream), w))
         if (sdt == CT_BF16) { if (zp) CT_Q8U(CT_BF16, true); else CT_Q8U(CT_BF16, false); }

@@ -2157,6 +2157,16 @@ int ct_bitmask_compress(const void* x, int dt, int64_t rows, int64_t cols, void*
         int64_t tpw = cdiv64(wts, (int64_t)cus * wgs_per_cu * kResWaves);
         const int keep_cap = es == 1 ? 1 : kResKeep;
         if (tpw > keep_cap) tpw = keep_cap;
+        if (es == 2 && tpw == kResKeep) {
+            // several residency rounds: a nearly empty last round costs up to 6 % (18944 x 3584 = 2.02 rounds of 512 workgroups: 48.6 us; with two tiles per
+            // wave — 78 VGPRs, three workgroups per CU — 2.7 rounds of 768: 45.8).  Two tiles when they fill their rounds clearly better; sweep in DESIGN 5.4
+            auto fill = [&](int64_t t, int64_t slots) {
+                const int64_t nw = cdiv64(wts, (int64_t)kResWaves * t);
+                return (double)nw / (double)(cdiv64(nw, slots) * slots);
+            };
+            const double f4 = fill(kResKeep, 2 * (int64_t)cus), f2 = fill(2, 3 * (int64_t)cus);
+            if (f4 < 0.8 && f2 > f4 + 0.15) tpw = 2;
+        }
         if (tpw < 1) tpw = 1;
         const int64_t wg_wts = (int64_t)kResWaves * tpw;             // wave-tiles per workgroup (<= 128 KB)
 #ifdef CT_DIAG
