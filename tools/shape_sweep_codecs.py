@@ -29,7 +29,7 @@ def line(name, r, c, alg, uc, ud, ok=True):
 
 for (r, c) in shapes:
     nsets = min(600, max(3, -(-(2 * 256 * 2 ** 20) // (r * c))))  # the kept values / the int8 codes (r x c bytes) >= 2 x the Infinity Cache
-    n = max(2 * nsets, 40 if r * c > 3e7 else 150)
+    n = max(2 * nsets, 120 if r * c > 3e7 else 200)
     g = torch.Generator(device=dev).manual_seed(5)
     ws = [torch.randn(r, c, device=dev, generator=g, dtype=torch.bfloat16) for _ in range(nsets)]
     if "sparse" in which:
