@@ -154,10 +154,24 @@ struct W4Params {
     const uint32_t* zpk = nullptr;
     uint32_t g_magic = 0;
     int g_shift = 0;
+    // block strategy (scale rows of `rdiv` weight rows: FP8 / int8 block 128 x 128): the row, the scale row and the column group of a unit as
+    // 32-bit multiply-highs, n / d == (n * magic) >> shift for n, d < 2^31 (make_w4) — the 64-bit divisions below cost the quantize kernels
+    // 3-4 us of 39 at 8192^2 (two per scale index; profiles/r06_shape_sweep_floats.txt)
+    int nf_fast = 0;
+    uint32_t upr_magic = 0, rdiv_magic = 0, upg_magic = 0;
+    int upr_shift = 0, rdiv_shift = 0, upg_mshift = 0;
 };
 
 __device__ __forceinline__ int64_t w4_scale_index(const W4Params& p, int64_t u) {
     if (p.flat_scale) return p.upg_shift >= 0 ? (u >> p.upg_shift) : (u / p.upg);
+    if (p.nf_fast) {
+        const uint32_t n = (uint32_t)u;
+        const uint32_t row = (uint32_t)(((uint64_t)n * p.upr_magic) >> p.upr_shift);
+        const uint32_t cu = n - row * (uint32_t)p.upr;
+        const uint32_t rb = (uint32_t)(((uint64_t)row * p.rdiv_magic) >> p.rdiv_shift);
+        const uint32_t cg = p.upg_shift >= 0 ? (cu >> p.upg_shift) : (uint32_t)(((uint64_t)cu * p.upg_magic) >> p.upg_mshift);
+        return (int64_t)rb * p.scale_cols + (int64_t)cg;
+    }
     const int64_t row = u / p.upr, cu = u - row * p.upr;
     return (row / p.rdiv) * p.scale_cols + (p.upg_shift >= 0 ? (cu >> p.upg_shift) : (cu / p.upg));
 }
@@ -1592,6 +1606,19 @@ static W4Params make_w4(const void* x, const void* scale, const void* zp, int zd
     if (rdiv >= rows && cdiv >= cols) {  // one scale for the whole tensor: index 0 without any division
         p.flat_scale = 1;
         p.upg_shift = 62;
+    }
+    if (!p.flat_scale && p.units < ((int64_t)1 << 31) && p.upr >= 1 && rdiv >= 1 && rdiv < ((int64_t)1 << 31) && p.upg >= 1) {
+        // Granlund-Montgomery with N = 31: magic = ceil(2^(31 + L) / d), L = ceil(log2 d), magic < 2^32, exact for n < 2^31
+        auto magic31 = [](int64_t d, uint32_t& magic, int& shift) {
+            int L = 0;
+            while (((int64_t)1 << L) < d) ++L;
+            shift = 31 + L;
+            magic = (uint32_t)((((uint64_t)1 << shift) + (uint64_t)(d - 1)) / (uint64_t)d);
+        };
+        magic31(p.upr, p.upr_magic, p.upr_shift);
+        magic31(rdiv, p.rdiv_magic, p.rdiv_shift);
+        magic31(p.upg, p.upg_magic, p.upg_mshift);
+        p.nf_fast = 1;
     }
     return p;
 }

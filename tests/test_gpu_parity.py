@@ -7,7 +7,7 @@ import re
 import pytest
 import torch
 from _golden import cases
-from test_oracle_golden import _kw, eq
+from test_oracle_golden import _kw, eq, eq_f8
 
 import oracle as O
 
@@ -324,6 +324,34 @@ def test_quant_paths_vs_oracle(cta, dev, xdt, sdt, bits, strategy, gs, shape, sy
     # symmetric call without a zero point takes the no-zp kernel path
     q0 = cta.codec.quantize_and_pack(x.to(dev), scale.to(dev), None, **kw)
     assert eq(q0.cpu(), O.pack_to_int32(O.quantize(x, scale, None, dtype=torch.int8, **kw), bits).contiguous())
+
+
+@pytest.mark.parametrize("qtype", ["float", "int"])
+@pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("shape,block,sym", [((384, 2304), [128, 128], True), ((256, 1024), [128, 128], False), ((200, 1200), [24, 40], False),
+                                             ((130, 4112), [64, 16], True), ((96, 2304), [32, 768], False)],
+                         ids=["128x128_288_units", "128x128_asym", "odd_blocks_ragged", "ragged_rows_16_wide", "wide_blocks"])
+def test_block_strategy_flat_kernels_vs_oracle(cta, dev, qtype, dt, shape, block, sym):
+    """FP8 / int8 block quantization (the scale of element (r, c) is scale[r // bh][c // bw], forward.py:198-216) on the flat 8-bit kernels: their scale
+    index is three 32-bit multiply-highs (w4_scale_index, nf_fast); rows that are not a power-of-two number of units, ragged last blocks, zero points"""
+    r, c = shape
+    bh, bw = block
+    g = torch.Generator().manual_seed(r + c)
+    x = torch.randn(shape, generator=g).mul(3.0).to(dt)
+    sp = special_values(dt)
+    x.view(-1)[: sp.numel()] = sp
+    scale = (torch.rand((-(-r // bh), -(-c // bw)), generator=g) * 0.05 + 0.01).to(dt)
+    zp = None if sym else torch.randint(-9, 9, scale.shape, generator=g, dtype=torch.int8)
+    odt = torch.float8_e4m3fn if qtype == "float" else torch.int8
+    kw = dict(num_bits=8, strategy="block", block_structure=block, qtype=qtype)
+    q_ref = O.quantize(x, scale, zp, dtype=odt, **kw)
+    q = cta.codec.quantize_tensor(x.to(dev), scale.to(dev), None if sym else zp.to(dev), dtype=odt, **kw)
+    assert eq_f8(q.cpu(), q_ref) if qtype == "float" else eq(q.cpu(), q_ref)
+    dkw = dict(strategy="block", block_structure=block)
+    back = cta.codec.dequantize_tensor(q, scale.to(dev), None if sym else zp.to(dev), **dkw)
+    assert eq(back.cpu(), O.dequantize(q_ref, scale, zp, **dkw))
+    fq = cta.codec.fake_quantize_tensor(x.to(dev), scale.to(dev), None if sym else zp.to(dev), **kw)
+    assert eq(fq.cpu(), O.fake_quantize(x, scale, zp, **kw))
 
 
 @pytest.mark.parametrize("dt", [BF16, F16], ids=["bf16", "fp16"])
