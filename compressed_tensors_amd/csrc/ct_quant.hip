@@ -1632,17 +1632,18 @@ static unsigned w4_grid(int64_t items, int unroll) {
     return (unsigned)g;
 }
 
-// units per lane on the decompress side (4- or 8-byte loads, 16-byte stores, one block apart).  2 is the optimum for tensors of many
-// residency rounds (8192^2: U = 1 / 2 / 4 / 8 -> 33.3 / 28.9 / 33.9 / 31.0 us), but a tensor that FITS one residency round of the chip —
-// 256 CUs x 8 workgroups of 256 lanes — should be launched as one: at 4096^2 U = 2 / 4 / 8 -> 9.4 / 8.6 / 8.6 us for W4 and
-// 10.7 / 9.6 / 9.7 us for int8, at 2048 x 5632 7.0 / 6.7 / 6.7 us, at 8192 x 4096 16.1 / 17.3 / 16.0 us (a second, partial round is what
-// costs: U = 4 there is 4096 workgroups).  tools/kbench/kbench_prod.hip `small`, profiles/r03_kbench_prod.txt.
-static int decomp_unroll(int64_t units) {
+// units per lane of the 8-bit dequantize kernels (8-byte loads, 16-byte stores, one block apart), in residency rounds of the chip's lanes — 256 CUs x 8
+// workgroups of 256 lanes.  HBM-cold, real shapes, int8 and FP8 (tools/shape_sweep_floats.py with the rule overridden, profiles/r06_dequant8_units_per_lane.txt),
+// U = 2 / 4 / 8: 3584^2 (3.1 rounds) 10.5 / 11.0 / 9.9 us, 8192 x 2048 (4) 11.1 / 11.4 / 10.0, 4096 x 6144 (6) 14.8 / 15.8 / 13.8, 5120^2 (6.25) 15.3 / 16.4 / 14.7,
+// 8192 x 4096 (8) 18.9 / 19.9 / 20.8, 8192^2 (16) 33 / 34 / 31-35: eight units per lane while the tensor is 2 .. 8 rounds of lanes (fewer, longer workgroups
+// fill the chip once), two beyond — and two whenever a lane's units do not share their scale (per-row groups: 5120^2 g128 15.5 / 16.3 / 16.5, asymmetric
+// 15.9 / 16.5 / 19.1), or, with zero points, above six rounds (channel-wise asymmetric 5120^2 15.9 / 16.6 / 17.9).  (The round-3 rule — 2 / 4 / 8 at <= 2 / 4 / 8
+// rounds — came from squares measured with their codes in the Infinity Cache: it cost 10 % at 3584^2 and at 8192 x 4096.)
+static int decomp_unroll(int64_t units, bool per_row_groups, bool has_zp) {
     const int64_t round_lanes = (int64_t)kCUs * 8 * kBlock;
-    if (units <= 2 * round_lanes) return 2;
-    if (units <= 4 * round_lanes) return 4;
-    if (units <= 8 * round_lanes) return 8;
-    return 2;
+    if (per_row_groups || units <= 2 * round_lanes || units >= 8 * round_lanes) return 2;
+    if (has_zp && units > 6 * round_lanes) return 2;
+    return 8;
 }
 // The W4 and packed-W8 decompress (group scales: one scale load per unit): four units per lane only where they make the tensor ONE residency round
 // (2 .. 4 rounds of lanes: 4096^2 9.8 -> 8.5 us); eight never pay — HBM-cold, round 6: 4096 x 6144 12.9 (U = 2) / 14.4 (4) / 14.0 (8) us, 5120^2
@@ -1868,7 +1869,7 @@ static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, 
     if (!gscale && (qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
-        const int unroll = decomp_unroll(w.units);  // (round 6 sweep, 2048^2 ... 8192^2, int8 and fp8: the rule is at or within 2 % of the best U at every size)
+        const int unroll = decomp_unroll(w.units, rdiv == 1 && cdiv < cols, zp != nullptr);
         dim3 g8(w4_grid(w.units, unroll));
 #define CT_Q8D(DT, ZP) CT_FOR_UNROLL(unroll, if (qdt == CT_F8E4M3) hipLaunchKernelGGL((f8_dequant_kernel<DT, U, ZP>), g8, dim3(kBlock), 0, as_stream(stream), w); \
                                              else hipLaunchKernelGGL((q8_dequant_kernel<DT, U, ZP, 0>), g8, dim3(kBlock), 0, as_stream(stream), w))
