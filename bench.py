@@ -1077,7 +1077,17 @@ def float_formats_leg(dev):
     out["float8_channel"] = {"alg_bytes_per_direction": alg, "quantize": rate(alg, time_kernel(fq, 36)), "dequantize": rate(alg, time_kernel(fd, 36, offset=6))}
     rc = lambda i: lib.ct_rtn_quant_channel8(ws[i % nsets].data_ptr(), BF16, N, N, 1, 1, q8[i % nsets].data_ptr(), sc[i % nsets].data_ptr(), None, stream)
     out["float8_channel"]["rtn_one_pass"] = rate(alg, time_kernel(rc, 36))  # observer + scale + quantize in one pass over the weight
-    del q8
+    # float8_e4m3fn, block 128 x 128 (the FP8-block checkpoints' strategy, forward.py:198-216): scale[r // 128][c // 128]
+    B = 128
+    sb = [(w.view(N // B, B, N // B, B).abs().amax(dim=(1, 3)).float() / 448.0).to(torch.bfloat16).contiguous() for w in ws]
+    bq = lambda i: lib.ct_quantize_fp8(ws[i % nsets].data_ptr(), BF16, sb[i % nsets].data_ptr(), BF16, None, -1, N, N, B, B, N // B, None, BF16,
+                                       q8[i % nsets].data_ptr(), F8, stream)
+    bd = lambda i: lib.ct_dequantize(q8[i % nsets].data_ptr(), F8, sb[i % nsets].data_ptr(), BF16, None, -1, N, N, B, B, N // B, None, back.data_ptr(), BF16, stream)
+    for i in range(nsets):
+        bq(i)
+    alg_b = 3 * N * N + 2 * (N // B) * (N // B)
+    out["float8_block128"] = {"alg_bytes_per_direction": alg_b, "quantize": rate(alg_b, time_kernel(bq, 36)), "dequantize": rate(alg_b, time_kernel(bd, 36, offset=6))}
+    del q8, sb
     # FP4
     p4 = [torch.empty(N, N // 2, dtype=torch.uint8, device=dev) for _ in range(nsets)]
     for name, group, sdt, sbytes_in in (("nvfp4", 16, torch.float32, 4), ("mxfp4", 32, torch.bfloat16, 2)):

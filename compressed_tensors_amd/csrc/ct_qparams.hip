@@ -141,6 +141,44 @@ __global__ __launch_bounds__(kBlock) void qparams_wave_kernel(const void* __rest
         const int64_t c0 = g * cdiv, c1 = (c0 + cdiv < cols) ? c0 + cdiv : cols;
         MinMax m;
         m.mn = __builtin_inff(); m.mx = -__builtin_inff(); m.nan = 0;
+        if constexpr (XDT != CT_F32) {
+            // Round 6: symmetric schemes on 16-bit weights (channel-wise int8 / FP8 observers, generate_gparam's row maxima): max |x| on the raw pairs
+            // (ct_minmax.h) with EIGHT unconditional 16-byte loads in flight per lane — the float path below (four loads behind a bounds test each, five
+            // VALU per element) ran these rows at 0.41-0.69 of the HBM peak (profiles/r06_shape_sweep_rtn.txt)
+            if (vec && symmetric) {
+                const int64_t nu = (c1 - c0) >> 3;
+                const u32x4* xin = reinterpret_cast<const u32x4*>(x) + ((r * cols + c0) >> 3);
+                uint32_t acc = 0;
+                int64_t ub = 0;  // wave-uniform
+                for (; nu - ub >= 512; ub += 512) {
+                    u32x4 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = xin[ub + 64 * q + lane];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, v[q].x), v[q].y), v[q].z), v[q].w);
+                }
+                // the row's tail: the index is clamped to the row's last unit (a unit read twice does not change a maximum)
+                if (nu - ub > 256) {
+                    u32x4 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int64_t u = ub + 64 * q + lane; v[q] = xin[u < nu ? u : nu - 1]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, v[q].x), v[q].y), v[q].z), v[q].w);
+                } else if (nu - ub > 0) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int64_t u = ub + 64 * q + lane; v[q] = xin[u < nu ? u : nu - 1]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = absmax_acc(absmax_acc(absmax_acc(absmax_acc(acc, v[q].x), v[q].y), v[q].z), v[q].w);
+                }
+                m = absmax_finish<XDT>(absmax_group_reduce(acc, 64));
+                if (lane == 0) {
+                    if (kind == QP_INT) emit_qparams<XDT>(m, bits, 1, scale_out, zp_out, gi);
+                    else emit_qparams_float<XDT>(m, kind, gscale, scale_out, gi);
+                }
+                continue;
+            }
+        }
         if (vec) {
             // 16-byte units, four in flight per lane (a 5632- or 11008-wide row of a channel-wise scheme is not a power of two of
             // units and lands here: with one 2-byte load per lane and trip this kernel ran at 0.8 TB/s)

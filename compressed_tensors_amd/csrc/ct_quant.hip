@@ -1997,14 +1997,19 @@ int ct_rtn_quant_channel8(const void* x, int xdt, int64_t rows, int64_t cols, in
     const int upr = (int)(cols / 8);
     // measured at 8192^2 (10 rotating sets): workgroup per row 37.6 (fp8) / 40.5 (int8) / 53.4 us (int8 asymmetric: three reductions
     // through LDS); wave per row 46.2 / 46.2 / 49.9 us.  So: wave per row for asymmetric schemes only.
-    if (!symmetric && upr <= 64 * 16 && cdiv64(rows, kBlock / 64) < ((int64_t)1 << 31)) {  // rows of up to 8192 elements: one wave per row
+    // Short rows (round 6, HBM-cold, profiles/r06_rtn8_wave_or_workgroup.txt): a workgroup per row of 1536 / 2048 columns keeps 3-4 KB in flight per
+    // workgroup between two barriers — 24576 x 1536: 33.7 (int8) / 44.1 us (fp8) against 23.2 / 25.7 with a wave per row, 16384 x 2048: 24.6 / 34.1 against
+    // 21.2 / 23.9; from 3584 columns on the workgroup form wins (8192 x 3584: 19.2 / 21.4 against 34.5 / 22.5).  So: wave per row for rows of at most 2048
+    // columns, and for asymmetric schemes up to 8192.
+    const bool want_wave = !symmetric || upr <= 256;
+    if (want_wave && upr <= 64 * 16 && cdiv64(rows, kBlock / 64) < ((int64_t)1 << 31)) {  // rows of up to 8192 elements: one wave per row
         const int needw = (upr + 63) / 64;
         const unsigned gw = (unsigned)cdiv64(rows, kBlock / 64);
 #define CT_RW8(DT, MU, F8) hipLaunchKernelGGL((rtn_channel8_wave_kernel<DT, MU, F8>), dim3(gw), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), rows, upr, \
                                               symmetric, static_cast<u32x2*>(out), scale_out, zp_out)
 #define CT_RW8_U(DT, F8) do { if (needw <= 2) CT_RW8(DT, 2, F8); else if (needw <= 4) CT_RW8(DT, 4, F8); else if (needw <= 8) CT_RW8(DT, 8, F8); else CT_RW8(DT, 16, F8); } while (0)
-        if (xdt == CT_BF16) CT_RW8_U(CT_BF16, false);  // asymmetric is INT only (checked above)
-        else CT_RW8_U(CT_F16, false);
+        if (xdt == CT_BF16) { if (fp8) CT_RW8_U(CT_BF16, true); else CT_RW8_U(CT_BF16, false); }
+        else { if (fp8) CT_RW8_U(CT_F16, true); else CT_RW8_U(CT_F16, false); }
 #undef CT_RW8_U
 #undef CT_RW8
         CT_LAUNCH_CHECK("ct_rtn_quant_channel8[wave]");
