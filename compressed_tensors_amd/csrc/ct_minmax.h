@@ -113,6 +113,58 @@ __device__ __forceinline__ uint32_t absmax_group_reduce(uint32_t acc, int lpg) {
     return acc;
 }
 
+// ---- asymmetric schemes on 16-bit weights: min AND max on the raw pairs (round 6) ---------------------------------
+// key = b ^ ((b >> 15, arithmetic) & 0x7fff) maps a sign-magnitude 16-bit float onto the int16 whose order is the float order (negative
+// values: -1 - magnitude; -0.0 -> -1 < +0.0 -> 0, which no quantization parameter can tell apart), a positive NaN above +inf and a
+// negative one below -inf — so a NaN anywhere in the group ends up as the group's maximum or minimum and is seen at the end.  Three packed
+// ops for the key and one packed min / max each per two elements: 2.5 VALU per element against 5 (unpack, NaN test, fmin, fmax), and two
+// packed ops per DPP step against five.  The key map is an involution.
+typedef int16_t i16x2_t __attribute__((ext_vector_type(2)));
+struct MinMaxKey {
+    uint32_t mn, mx;  // two int16 keys each
+};
+__device__ __forceinline__ uint32_t mm_key_pair(uint32_t pair_bits) {
+    const i16x2_t sign = __builtin_bit_cast(i16x2_t, pair_bits) >> 15;
+    return pair_bits ^ (__builtin_bit_cast(uint32_t, sign) & 0x7fff7fffu);
+}
+__device__ __forceinline__ MinMaxKey mmk_init() { return MinMaxKey{0x7fff7fffu, 0x80008000u}; }
+__device__ __forceinline__ MinMaxKey mmk_merge(MinMaxKey a, uint32_t kmn, uint32_t kmx) {
+    a.mn = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(i16x2_t, a.mn), __builtin_bit_cast(i16x2_t, kmn)));
+    a.mx = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2_t, a.mx), __builtin_bit_cast(i16x2_t, kmx)));
+    return a;
+}
+__device__ __forceinline__ MinMaxKey mmk_acc(MinMaxKey a, uint32_t pair_bits) {
+    const uint32_t k = mm_key_pair(pair_bits);
+    return mmk_merge(a, k, k);
+}
+template <int CTRL>
+__device__ __forceinline__ MinMaxKey mmk_dpp(MinMaxKey a) {
+    return mmk_merge(a, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.mn, CTRL, 0xf, 0xf, false), (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.mx, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ MinMaxKey mmk_group_reduce(MinMaxKey a, int lpg) {
+    if (lpg >= 2) a = mmk_dpp<0xB1>(a);
+    if (lpg >= 4) a = mmk_dpp<0x4E>(a);
+    if (lpg >= 8) a = mmk_dpp<0x141>(a);
+    if (lpg >= 16) a = mmk_dpp<0x140>(a);
+    for (int d = 16; d < lpg; d <<= 1) a = mmk_merge(a, (uint32_t)__shfl_xor((int)a.mn, d, 64), (uint32_t)__shfl_xor((int)a.mx, d, 64));
+    return a;
+}
+// the MinMax the float reduction would have produced (up to the sign of a zero)
+template <int XDT>
+__device__ __forceinline__ MinMax mmk_finish(MinMaxKey a) {
+    static_assert(XDT == CT_BF16 || XDT == CT_F16, "16-bit weights only");
+    const int mn_lo = (int)(int16_t)(a.mn & 0xffffu), mn_hi = (int)(int16_t)(a.mn >> 16);
+    const int mx_lo = (int)(int16_t)(a.mx & 0xffffu), mx_hi = (int)(int16_t)(a.mx >> 16);
+    const int kmn = mn_lo < mn_hi ? mn_lo : mn_hi, kmx = mx_lo > mx_hi ? mx_lo : mx_hi;
+    const uint32_t bmn = ((uint32_t)kmn ^ ((uint32_t)(kmn >> 15) & 0x7fffu)) & 0xffffu, bmx = ((uint32_t)kmx ^ ((uint32_t)(kmx >> 15) & 0x7fffu)) & 0xffffu;
+    constexpr uint32_t inf = XDT == CT_BF16 ? 0x7f80u : 0x7c00u;
+    MinMax m;
+    m.nan = ((bmn & 0x7fffu) > inf) | ((bmx & 0x7fffu) > inf);
+    m.mn = XDT == CT_BF16 ? bits_f(bmn << 16) : f16_bits_to_f(bmn);
+    m.mx = XDT == CT_BF16 ? bits_f(bmx << 16) : f16_bits_to_f(bmx);
+    return m;
+}
+
 // the MinMax the float reduction would have produced, as far as a symmetric scheme can tell: {0, amax, nan}
 template <int XDT>
 __device__ __forceinline__ MinMax absmax_finish(uint32_t acc) {

@@ -672,21 +672,14 @@ __global__ __launch_bounds__(kBlock) void rtn_w4_kernel(const u32x4* __restrict_
         }
         m = absmax_finish<DT>(absmax_group_reduce(acc, lpg));
     } else {
+        // asymmetric (round 6): min and max on the raw pairs as order-preserving int16 keys (ct_minmax.h) — the float form (unpack, NaN test, fmin,
+        // fmax: 5 VALU per element) made this kernel 37 us at 8192^2 against 31 for the symmetric one
+        MinMaxKey k = mmk_init();
         if (live) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t ws[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float a, b;
-                    unpack2<DT>(ws[j], a, b);
-                    m.nan |= (a != a) | (b != b);
-                    m.mn = __builtin_fminf(m.mn, __builtin_fminf(a, b));
-                    m.mx = __builtin_fmaxf(m.mx, __builtin_fmaxf(a, b));
-                }
-            }
+            for (int i = 0; i < 4; ++i) k = mmk_acc(mmk_acc(mmk_acc(mmk_acc(k, r[i].x), r[i].y), r[i].z), r[i].w);
         }
-        m = group_reduce(m, lpg);
+        m = mmk_finish<DT>(mmk_group_reduce(k, lpg));
     }
     if (!live) return;
     float s, z;
@@ -1106,8 +1099,62 @@ __global__ __launch_bounds__(kBlock) void q8_dequant_kernel(W4Params p) {
 //   quantize:   lane = 2 units (32 B in, 16 B out): t = rnd_T(x / s) [+ zp], clamp to +-448, v_cvt_pk_fp8_f32
 //   dequantize: lane = UNROLL units one block apart (8 B in, 16 B out each): v_cvt_pk_f32_fp8, (q - z) * s
 // ------------------------------------------------------------------------------------------
+// fp16 weights -> float8 (round 6): everything after the fp32 quotient on fp16 PAIRS, as quant_pairs_f16 does for the integer codes — reciprocal + one
+// Newton step as two v_pk_fma_f32, v_cvt_pk_f16_f32 is the rounding to T, the zero-point add is v_pk_add_f16, the clamp v_pk_max_f16 / v_pk_min_f16.  The
+// scalar form below (fast_quotient's selects and its sub-2^-13 branch, four roundings and two NaN-propagating clamps per element: ~20 VALU per element) held
+// the FP8 quantize of fp16 weights at 51-57 us for 8192^2 against 35 for bf16 (profiles/r06_shape_sweep_floats.txt).  Preconditions, tested per 16-byte unit
+// on the raw pairs (f8_f16_unit_ok): every element finite (inf / NaN: the Newton correction would turn inf into NaN), and zero or at least 2^-13 |s| in
+// magnitude — below that the shortcut's quotient may differ from the IEEE one in the last fp16-subnormal place (ct_selftest_f16_div), i.e. be -0 where the
+// divide gives -2^-24, and `+ zero_point` turns the first into +0 and leaves the second negative.  A -0 weight needs no care HERE (the Newton step returns +0
+// for it, and -0 + z == +0 + z); WITHOUT a zero point the sign of a zero result is the weight's, so a unit that holds a -0 takes the scalar form too.
+template <bool ZP>
+__device__ __forceinline__ bool f8_f16_unit_ok(const u32x4& raw, float s) {
+    // |x| >= thr  <=>  bits(|x|) >= bits(thr) for non-negative fp16; thr = 2^-13 |s| rounded to fp16 and moved one place up
+    const uint32_t thr = f_to_f16_bits(__builtin_fabsf(s) * 0x1p-13f) + 1u;  // >= 1; |s| <= 2^15 on the fast path: no overflow
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    u16x2_t mx = {0, 0}, mn = {0xffff, 0xffff}, nz = {0xffff, 0xffff};
+    const u16x2_t one = {1, 1};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const u16x2_t xa = __builtin_bit_cast(u16x2_t, ws[j] & 0x7fff7fffu);
+        mx = __builtin_elementwise_max(mx, xa);
+        mn = __builtin_elementwise_min(mn, xa - one);  // wraps: a zero becomes 0xffff and passes
+        if (!ZP) nz = __builtin_elementwise_min(nz, __builtin_bit_cast(u16x2_t, ws[j] ^ 0x80008000u));  // 0 for a -0
+    }
+    const uint32_t hi16 = mx.x > mx.y ? mx.x : mx.y, lo16 = mn.x < mn.y ? mn.x : mn.y;
+    return hi16 <= 0x7bffu && lo16 >= thr - 1u && (ZP || (nz.x != 0 && nz.y != 0));
+}
+
+template <bool ZP>
+__device__ __forceinline__ void f8_quant_words_f16(const u32x4& raw, float s, float rs, float z, uint32_t& lo, uint32_t& hi) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 rs2 = {rs, rs}, s2 = {s, s};
+    const qh2_t lo2 = {(_Float16)-448.0f, (_Float16)-448.0f}, hi2 = {(_Float16)448.0f, (_Float16)448.0f}, z2 = {(_Float16)z, (_Float16)z};
+    const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
+    int acc[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f2 x = __builtin_convertvector(__builtin_bit_cast(qh2_t, ws[j]), f2);
+        f2 t = x * rs2;
+        t = __builtin_elementwise_fma(__builtin_elementwise_fma(-t, s2, x), rs2, t);
+        qh2_t t16 = __builtin_convertvector(t, qh2_t);
+        if (ZP) t16 = t16 + z2;
+        t16 = __builtin_elementwise_min(__builtin_elementwise_max(t16, lo2), hi2);
+        const f2 c = __builtin_convertvector(t16, f2);
+        if (j & 1) acc[j >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(c.x, c.y, acc[j >> 1], true);
+        else acc[j >> 1] = __builtin_amdgcn_cvt_pk_fp8_f32(c.x, c.y, acc[j >> 1], false);
+    }
+    lo = (uint32_t)acc[0]; hi = (uint32_t)acc[1];
+}
+
 template <int DT, bool FAST, bool ZP>
 __device__ __forceinline__ void f8_quant_words(const u32x4& raw, float s, float rs, float z, uint32_t& lo, uint32_t& hi) {
+    if constexpr (DT == CT_F16 && FAST) {
+        if (f8_f16_unit_ok<ZP>(raw, s)) {  // lanes almost always agree
+            f8_quant_words_f16<ZP>(raw, s, rs, z, lo, hi);
+            return;
+        }
+    }
     const uint32_t ws[4] = {raw.x, raw.y, raw.z, raw.w};
     int acc[2] = {0, 0};
 #pragma unroll

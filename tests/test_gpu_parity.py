@@ -2327,6 +2327,29 @@ def test_fp8_hardware_conversion_all_inputs(cta, dev, xdt):
         assert eq(got.cpu(), O.dequantize(codes, s, None))
 
 
+def test_fp8_quantize_of_fp16_weights_every_input_times_scales(cta, dev):
+    """the packed-fp16 form of the FP8 quantize (f8_quant_words_f16: reciprocal + Newton step on pairs) and its per-unit precondition (finite, zero or a
+    quotient of at least 2^-13): EVERY fp16 input against 96 channel scales — the ends of the fast range 2^-14 / 2^15 and just outside it, powers of two,
+    scales that put subnormal inputs on either side of the 2^-13 line, random ones — with the compressors' all-zero zero point and without one, bit for bit (the sign of a
+    zero result included) against the oracle; sorted and shuffled inputs (a unit of 8 mixes tiny / non-finite elements with ordinary ones)"""
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(F16)
+    fixed = [2.0 ** -14, 2.0 ** -14 * 1.001, 2.0 ** -15, 2.0 ** 15, 2.0 ** 15 * 0.999, 65504.0, 2.0 ** -11, 2.0 ** -10, 2.0 ** -9, 1.0, -1.0, 448.0, 1 / 448.0, 3.0, -0.37]
+    scales = torch.cat([torch.tensor(fixed), 2.0 ** torch.linspace(-14, 15, 49), torch.rand(32, generator=g) * 2.0 ** torch.randint(-14, 4, (32,), generator=g).float()])
+    s = scales.to(F16).reshape(-1, 1)
+    s[s == 0] = 1.0
+    kw = dict(num_bits=8, strategy="channel", qtype="float")
+    for x1 in (x0, x0[torch.randperm(65536, generator=g)]):
+        x = x1.reshape(1, -1).repeat(s.shape[0], 1).contiguous()
+        for z in (torch.zeros(s.shape, dtype=F8), None):  # without a zero point a -0 weight stays -0
+            got = cta.codec.quantize_tensor(d(x, dev), d(s, dev), d(z, dev), dtype=F8, **kw)
+            assert eq_f8(got.cpu(), O.quantize(x, s, z, dtype=F8, **kw)), z is None
+        # the one-pass channel-wise compress shares the word builder (its own scale: amax / 448)
+        q, sc, _ = cta.codec.rtn_quantize_channel8(d(x[:8, :16384].contiguous(), dev), qtype="float", symmetric=True)
+        s_ref = O.calculate_qparams_float(x[:8, :16384], kind="fp8")
+        assert eq(sc.cpu(), s_ref) and eq_f8(q.cpu(), O.quantize(x[:8, :16384], s_ref, torch.zeros_like(s_ref, dtype=F8), dtype=F8, **kw))
+
+
 def test_fp8_full_size_roundtrip(cta, dev):
     """8192 x 8192 bf16, channel scales: dequantize(quantize(x)) is idempotent under a second round trip and every
     code is a finite float8 value"""

@@ -11,6 +11,7 @@ shapes = [(8192, 8192), (28672, 8192), (8192, 28672), (14336, 4096), (4096, 1433
 if os.environ.get("SHAPES"):
     shapes = [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
 which = os.environ.get("WHICH", "fp8,int8,fp4,w4dt").split(",")
+WDT = {"bf16": torch.bfloat16, "fp16": torch.float16, "f32": torch.float32}[os.environ.get("DTYPE", "bf16")]  # the weights' (and scales') dtype of the fp8 / int8 / fp4 legs
 
 
 def timeit(fn, nsets, n):
@@ -52,7 +53,7 @@ for (r, c) in shapes:
     # the smallest read stream of any leg here is r x c / 2 bytes (the FP4 codes)
     nsets8 = min(600, max(3, -(-(2 * 256 * 2 ** 20) // (r * c))))
     n8 = max(2 * nsets8, 90 if r * c > 3e7 else 200)
-    ws = [torch.randn(r, c, device=dev, generator=g, dtype=torch.bfloat16) for _ in range(nsets8)]
+    ws = [torch.randn(r, c, device=dev, generator=g, dtype=torch.float32).to(WDT) for _ in range(nsets8)]
     if "fp8" in which or "int8" in which:
         cases = []
         if "fp8" in which:
@@ -65,7 +66,7 @@ for (r, c) in shapes:
             if strategy == "block" and (r % 128 or c % 128): continue
             if strategy == "group" and c % gs: continue
             qmax = 448.0 if qtype == "float" else 127.0
-            ss = [scale_like(w, strategy, gs, block, qmax, torch.bfloat16) for w in ws]
+            ss = [scale_like(w, strategy, gs, block, qmax, WDT) for w in ws]
             zs = [None if sym else torch.randint(-20, 20, s.shape, device=dev, generator=g, dtype=torch.int8) for s in ss]
             odt = F8 if qtype == "float" else torch.int8
             kw = dict(num_bits=8, strategy=strategy, group_size=gs, block_structure=block, qtype=qtype)
@@ -75,7 +76,8 @@ for (r, c) in shapes:
             ud = timeit(lambda i: codec.dequantize_tensor(qs[i], ss[i], zs[i], **dkw), nsets8, n8)
             back = codec.dequantize_tensor(qs[0], ss[0], zs[0], **dkw)
             ok = torch.equal(back, codec.fake_quantize_tensor(ws[0], ss[0], zs[0], **kw))
-            alg = 3 * r * c + ss[0].numel() * (2 + (0 if sym else 1))
+            es = ws[0].element_size()
+            alg = (es + 1) * r * c + ss[0].numel() * (es + (0 if sym else 1))
             line(name, r, c, alg, uc, alg, ud, ok)
             del qs, ss, zs
     if "fp4" in which and c % 32 == 0:
@@ -85,15 +87,16 @@ for (r, c) in shapes:
                 gsc = torch.tensor([3.7], device=dev)
                 kind = "f8e4m3"
             else:
-                ss = [torch.full((r, c // group), 0.5, device=dev, dtype=torch.bfloat16) for _ in range(nsets8)]
+                ss = [torch.full((r, c // group), 0.5, device=dev, dtype=WDT) for _ in range(nsets8)]
                 gsc, kind = None, "e8m0"
             ps = [codec.fp4_quantize_and_pack(x, s, gsc, group_size=group) for x, s in zip(ws, ss)]
             cs = [s.to(F8) if fmt == "nvfp4" else torch.full(s.shape, 126, dtype=torch.uint8, device=dev) for s in ss]
             nsets = min(nsets8 * 2, len(ws))  # the packed codes are r x c / 2 bytes: the rotation below is as cold as this leg's sets allow
             uc = timeit(lambda i: codec.fp4_quantize_and_pack(ws[i], ss[i], gsc, group_size=group), nsets8, n8)
             ud = timeit(lambda i: codec.fp4_unpack_and_dequantize(ps[i], cs[i], gsc, group_size=group, scale_kind=kind), nsets8, n8)
-            alg_c = r * c * 2.5 + ss[0].numel() * ss[0].element_size()
-            alg_d = r * c * 2.5 + ss[0].numel()
+            es = ws[0].element_size()
+            alg_c = r * c * (es + 0.5) + ss[0].numel() * ss[0].element_size()
+            alg_d = r * c * (es + 0.5) + ss[0].numel()
             line(fmt, r, c, alg_c, uc, alg_d, ud, True)
             del ss, ps, cs
     if "w4dt" in which and c % 128 == 0:
