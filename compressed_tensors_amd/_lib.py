@@ -85,6 +85,7 @@ _PROTOTYPES = {
     "ct_selftest_fp4_div": ([_I, _c.c_uint32, _c.c_uint32, _P, _S], _I),
     "ct_minmax_qparams": ([_P, _I, _L, _L, _L, _I, _I, _P, _P, _S], _I),
     "ct_minmax_qparams_float": ([_P, _I, _L, _L, _L, _I, _P, _P, _S], _I),
+    "ct_generate_gparam": ([_P, _I, _L, _L, _P, _P, _S], _I),
     "ct_pack_bitmasks": ([_P, _L, _L, _P, _S], _I),
     "ct_unpack_bitmasks": ([_P, _L, _L, _P, _S], _I),
     "ct_bitmask_count": ([_P, _I, _L, _L, _P, _P, _S], _I),

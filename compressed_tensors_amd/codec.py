@@ -553,12 +553,13 @@ def generate_gparam(x: torch.Tensor) -> torch.Tensor:
     dev = _compute_device(x2)
     xd = _dev(x2, dev)
     rows, cols = xd.shape
+    if rows == 0 or cols == 0:
+        raise ValueError("generate_gparam of an empty tensor")
     row_amax = torch.empty((rows, 1), dtype=xd.dtype, device=dev)
-    call("ct_minmax_qparams_float", ptr(xd), DT[xd.dtype], rows, cols, max(cols, 1), 5, None, ptr(row_amax), stream_of(xd))
-    amax = row_amax.amax().reshape(1).clamp(min=torch.finfo(xd.dtype).tiny)  # clamp does not propagate NaN upstream either
-    recip = (torch.ones(1, dtype=torch.float32, device=dev) / amax.float()).to(xd.dtype)
-    gs = (recip.float() * (448.0 * 6.0)).to(xd.dtype).float()
-    return _home(torch.nan_to_num(gs, nan=1.0, posinf=1.0, neginf=1.0), x)
+    gs = torch.empty(1, dtype=torch.float32, device=dev)
+    # the row maxima, then ONE workgroup: amax -> clamp(min=tiny) -> reciprocal -> x 2688 -> non-finite = 1 (seven tiny tensor ops cost 45-65 us of launches here)
+    call("ct_generate_gparam", ptr(xd), DT[xd.dtype], rows, cols, ptr(row_amax), ptr(gs), stream_of(xd))
+    return _home(gs, x)
 
 
 def rtn_quantize_and_pack(x: torch.Tensor, *, group_size: Optional[int] = None, symmetric: bool = True):

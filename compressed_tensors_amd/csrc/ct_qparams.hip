@@ -222,6 +222,47 @@ __global__ __launch_bounds__(kBlock) void qparams_wave_kernel(const void* __rest
     }
 }
 
+// generate_gparam's tail (helpers.py:308-337) on the device: the row maxima (kind 5) -> amax -> 448 * 6 / amax in x's dtype as the eager expression
+// evaluates it (`float / tensor` = reciprocal, then product: two roundings), float32, non-finite -> 1.  One workgroup: a checkpoint's rows are few.
+// (The host composed this from seven tiny tensor ops: 45-65 us of launches behind a 10-26 us reduction — profiles/r06_shape_sweep_rtn.txt.)
+template <int XDT>
+__global__ __launch_bounds__(kBlock) void gparam_finish_kernel(const void* __restrict__ row_amax, int64_t rows, float* __restrict__ gs_out) {
+    __shared__ float s_mx[kBlock / 64];
+    __shared__ int s_nan[kBlock / 64];
+    float mx = 0.0f;
+    int nan = 0;
+    for (int64_t base = threadIdx.x; base < rows; base += 8 * kBlock) {  // eight loads in flight per lane (index clamped: a value read twice changes no maximum)
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = base + (int64_t)k * kBlock;
+            v[k] = load_as_f<XDT>(row_amax, i < rows ? i : rows - 1);  // >= 0, or NaN
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            nan |= (v[k] != v[k]);
+            mx = __builtin_fmaxf(mx, v[k]);
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        mx = __builtin_fmaxf(mx, __shfl_xor(mx, d, 64));
+        nan |= __shfl_xor(nan, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_nan[threadIdx.x >> 6] = nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; ++w) { mx = __builtin_fmaxf(mx, s_mx[w]); nan |= s_nan[w]; }
+        const float tiny = XDT == CT_F16 ? 0x1p-14f : 0x1p-126f;  // torch.finfo(dtype).tiny
+        float amax = nan ? __builtin_nanf("") : mx;
+        amax = amax < tiny ? tiny : amax;                          // clamp(min=tiny): a NaN passes through
+        const float recip = round_to<XDT>(1.0f / amax);
+        const float gs = round_to<XDT>(recip * 2688.0f);           // FP8_E4M3_DATA.max * FP4_E2M1_DATA.max
+        gs_out[0] = __builtin_isfinite(gs) ? gs : 1.0f;            // nan_to_num(nan=1, posinf=1, neginf=1)
+    }
+}
+
 }  // namespace ct
 
 using namespace ct;
@@ -278,6 +319,19 @@ static int minmax_qparams_impl(const void* x, int xdt, int64_t rows, int64_t col
 int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int bits, int symmetric, void* scale_out, int8_t* zp_out,
                       ct_stream_t stream) {
     return minmax_qparams_impl(x, xdt, rows, cols, cdiv, bits, symmetric, scale_out, zp_out, QP_INT, nullptr, stream);
+}
+
+int ct_generate_gparam(const void* x, int xdt, int64_t rows, int64_t cols, void* row_amax, float* global_scale_out, ct_stream_t stream) {
+    CT_REQUIRE(row_amax != nullptr && global_scale_out != nullptr, "ct_generate_gparam needs its scratch (rows elements of x's dtype) and its output");
+    CT_REQUIRE(rows >= 1 && cols >= 1, "generate_gparam of an empty tensor");
+    int rc = minmax_qparams_impl(x, xdt, rows, cols, cols, 8, 1, row_amax, nullptr, QP_AMAX, nullptr, stream);
+    if (rc) return rc;
+    switch (xdt) {
+        case CT_BF16: hipLaunchKernelGGL((gparam_finish_kernel<CT_BF16>), dim3(1), dim3(kBlock), 0, as_stream(stream), row_amax, rows, global_scale_out); break;
+        case CT_F16: hipLaunchKernelGGL((gparam_finish_kernel<CT_F16>), dim3(1), dim3(kBlock), 0, as_stream(stream), row_amax, rows, global_scale_out); break;
+        default: hipLaunchKernelGGL((gparam_finish_kernel<CT_F32>), dim3(1), dim3(kBlock), 0, as_stream(stream), row_amax, rows, global_scale_out); break;
+    }
+    CT_LAUNCH_CHECK("ct_generate_gparam");
 }
 
 int ct_minmax_qparams_float(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int kind, const float* global_scale, void* scale_out,

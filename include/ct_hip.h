@@ -268,6 +268,13 @@ int ct_minmax_qparams(const void* x, int xdt, int64_t rows, int64_t cols, int64_
 int ct_minmax_qparams_float(const void* x, int xdt, int64_t rows, int64_t cols, int64_t cdiv, int kind,
                             const float* global_scale, void* scale_out, ct_stream_t stream);
 
+/* generate_gparam of a whole weight (quantization/utils/helpers.py:308-337, the NVFP4 global scale): amax = max |x| (NaN if any
+ * element is), clamped from below to finfo(x dtype).tiny; global_scale = rnd_X(rnd_X(1 / amax) * 2688) as float32 — `float / tensor`
+ * is evaluated by torch as reciprocal times float, two roundings to x's dtype; a non-finite result becomes 1.  Two launches: the
+ * row maxima (kind 5 above) into `row_amax` (scratch: rows elements of x's dtype), then one workgroup.  global_scale_out: device float32[1]. */
+int ct_generate_gparam(const void* x, int xdt, int64_t rows, int64_t cols, void* row_amax, float* global_scale_out,
+                       ct_stream_t stream);
+
 /* ---------------------------------------------------------------------------- FP4 (E2M1) codecs
  * nvfp4-pack-quantized / mxfp4-pack-quantized weight paths (compressors/nvfp4/base.py:68-139,
  * mxfp4/base.py:27-65): quantize(x, scale, global_scale) -> cast_to_fp4 -> pack_fp4_to_uint8 fused, and the

@@ -3116,6 +3116,25 @@ def test_qparams_float_vs_oracle(cta, dev, xdt, kind, gsize):
     assert eq(cta.codec.generate_gparam(d(xf, dev)).cpu(), O.generate_gparam(xf))
 
 
+@pytest.mark.parametrize("xdt", [BF16, F16, F32])
+def test_generate_gparam_on_the_device(cta, dev, xdt):
+    """ct_generate_gparam (row maxima + one finishing workgroup) against the oracle's restatement of helpers.py:308-337: ordinary weights of several
+    shapes (wide rows, many rows, 3-D), all zeros (amax clamps to tiny, the quotient overflows -> 1), a NaN, an inf, the dtype's largest value,
+    subnormal-only weights, a negative maximum"""
+    g = torch.Generator().manual_seed(41)
+    cases = [torch.randn((300, 1000), generator=g) * 7, torch.randn((5, 8192 * 3), generator=g) * 0.02, torch.randn((2100, 64), generator=g), torch.randn((4, 16, 96), generator=g),
+             torch.zeros((16, 64)), -torch.rand((8, 128), generator=g) - 3.0, torch.full((8, 64), 1e-40), torch.randn((1, 8), generator=g)]
+    nan = torch.randn((64, 256), generator=g); nan[17, 5] = float("nan")
+    inf = torch.randn((64, 256), generator=g); inf[63, 255] = -float("inf")
+    big = torch.randn((64, 256), generator=g); big[0, 0] = torch.finfo(xdt).max
+    for x in cases + [nan, inf, big]:
+        x = x.to(xdt)
+        got = cta.codec.generate_gparam(d(x, dev))
+        assert got.dtype == F32 and got.shape == (1,) and eq(got.cpu(), O.generate_gparam(x)), (tuple(x.shape), float(got))
+    with pytest.raises(ValueError):
+        cta.codec.generate_gparam(torch.empty((0, 64), dtype=xdt, device=dev))
+
+
 def test_float_schemes_end_to_end_from_the_dense_weight(cta, dev):
     """observer -> calculate_qparams -> compress -> decompress for every FLOAT scheme, all on the device, against the
     oracle's composition of the same steps"""
