@@ -45,6 +45,7 @@ __all__ = [
     "compress_mx_scale",
     "decompress_mx_scale",
     "fp4_quantize_and_pack",
+    "fp4_quantize_and_pack_stored",
     "fp4_unpack_and_dequantize",
     "marlin24_quant_compress",
     "marlin24_compress_w4",
@@ -1327,6 +1328,51 @@ def decompress_mx_scale(scale: torch.Tensor) -> torch.Tensor:
     return 2.0 ** (scale.to(torch.int32) - 127).to(torch.bfloat16)
 
 
+_MX_CODE_TABLES = {}
+
+
+def _mx_code_table(dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """compress_mx_scale(scale, uint8) (mx_utils.py:18-31) of EVERY 16-bit pattern of `dtype`, evaluated once by that very expression on the host and
+    kept on `device` (64 KB): the MXFP4 compress kernel reads its groups' stored codes from it, so they are upstream's for every input"""
+    key = (dtype, device)
+    t = _MX_CODE_TABLES.get(key)
+    if t is None:
+        every = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dtype)
+        t = _MX_CODE_TABLES[key] = compress_mx_scale(every, torch.uint8).contiguous().to(device)
+    return t
+
+
+def _gs_fast(global_scale, dev):
+    """the global scale as a contiguous float32 tensor of one element on `dev` (as _gs_arg; without tensor ops when it already is one)"""
+    if global_scale is None:
+        return None
+    if global_scale.dtype is torch.float32 and global_scale.numel() == 1 and global_scale.device == dev and global_scale.data_ptr() % 4 == 0:
+        return global_scale
+    return _dev(global_scale, dev).to(torch.float32).reshape(-1)[:1].contiguous()
+
+
+def fp4_quantize_and_pack_stored(weight: torch.Tensor, scale: torch.Tensor, global_scale: Optional[torch.Tensor], *, group_size: int, scale_dtype: torch.dtype):
+    """`fp4_quantize_and_pack` plus the scale in its STORED form from the same launch — NVFP4 (group 16): `scale.to(float8_e4m3fn)`; MXFP4 (group 32):
+    `compress_mx_scale(scale, uint8)` — or None when the layout is outside that kernel (the caller then converts the scale itself).  Returns
+    (packed, stored_scale)."""
+    want = torch.float8_e4m3fn if group_size == 16 else torch.uint8
+    if (scale_dtype is not want or weight.dim() != 2 or weight.dtype not in (torch.bfloat16, torch.float16) or not weight.is_cuda or scale.device != weight.device
+            or scale.dtype not in _FLOATS or (group_size == 32 and scale.dtype is torch.float32) or (global_scale is not None) != (group_size == 16)
+            or not weight.is_contiguous() or not scale.is_contiguous() or weight.data_ptr() % 16 or scale.data_ptr() % 8):
+        return None
+    rows, cols = weight.shape
+    if cols % group_size or (rows * cols) % 32 or tuple(scale.shape) != (rows, cols // group_size) or rows == 0:
+        return None
+    dev = weight.device
+    gs = _gs_fast(global_scale, dev)
+    out = torch.empty((rows, cols // 2), dtype=torch.uint8, device=dev)
+    stored = torch.empty((rows, cols // group_size), dtype=want, device=dev)
+    lut = _mx_code_table(scale.dtype, dev) if group_size == 32 else None
+    call("ct_fp4_quant_pack_stored", ptr(weight), DT[weight.dtype], ptr(scale), DT[scale.dtype], ptr(gs), rows, cols, int(group_size), ptr(out), ptr(stored), ptr(lut),
+         stream_of(weight))
+    return out, stored
+
+
 def fp4_quantize_and_pack(weight: torch.Tensor, scale: torch.Tensor, global_scale: Optional[torch.Tensor], *, group_size: int) -> torch.Tensor:
     """quantize(x, scale, global_scale, FP4 args) -> cast_to_fp4 -> pack_fp4_to_uint8 in one launch
     (compressors/nvfp4/base.py:88-95): uint8 (rows, cols / 2)."""
@@ -1341,18 +1387,18 @@ def fp4_quantize_and_pack(weight: torch.Tensor, scale: torch.Tensor, global_scal
     rows, cols = w.shape
     if tuple(s.shape) != (rows, cols // group_size):
         raise ValueError(f"scale shape {tuple(s.shape)} does not match ({rows}, {cols // group_size}) for group size {group_size}")
-    gs = None
-    if global_scale is not None:
-        gs = _dev(global_scale, dev).to(torch.float32).reshape(-1)[:1].contiguous()
+    gs = _gs_fast(global_scale, dev)
     out = torch.empty((rows, cols // 2), dtype=torch.uint8, device=dev)
     call("ct_fp4_quant_pack", ptr(w), DT[w.dtype], ptr(s), DT[s.dtype], ptr(gs), rows, cols, int(group_size), ptr(out), stream_of(w))
     return _home(out, weight)
 
 
 def fp4_unpack_and_dequantize(packed: torch.Tensor, scale: torch.Tensor, global_scale: Optional[torch.Tensor], *, group_size: int,
-                              scale_kind: str = "plain", dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+                              scale_kind: str = "plain", dtype: torch.dtype = torch.bfloat16, return_scale: bool = False):
     """unpack_fp4_from_uint8 -> dequantize(x_q, scale, global_scale) in one launch (nvfp4/base.py:118-131).  `scale` is
-    the STORED scale: float8-e4m3 (scale_kind "f8e4m3"), E8M0 uint8 ("e8m0") or a float tensor ("plain")."""
+    the STORED scale: float8-e4m3 (scale_kind "f8e4m3"), E8M0 uint8 ("e8m0") or a float tensor ("plain").
+    `return_scale`: also the decompressed scale as bfloat16 — `scale.to(bfloat16)` resp. `decompress_mx_scale(scale)` — written by the same launch:
+    returns (weight, scale_bf16)."""
     if packed.dtype != torch.uint8 or packed.dim() != 2:
         raise ValueError("packed FP4 weights are 2-D uint8 tensors")
     dev = _compute_device(packed)
@@ -1361,10 +1407,13 @@ def fp4_unpack_and_dequantize(packed: torch.Tensor, scale: torch.Tensor, global_
     kind = _FP4_SCALE_KIND[scale_kind]
     sview = s.view(torch.uint8) if kind == 1 else s
     sdt = DT[sview.dtype] if kind == 0 else -1
-    gs = None
-    if global_scale is not None:
-        gs = _dev(global_scale, dev).to(torch.float32).reshape(-1)[:1].contiguous()
+    gs = _gs_fast(global_scale, dev)
     out = torch.empty((rows, cols), dtype=dtype, device=dev)
+    if return_scale:
+        sout = torch.empty((rows, cols // int(group_size)), dtype=torch.bfloat16, device=dev)
+        if rows and cols:
+            call("ct_fp4_unpack_dequant_scale", ptr(p), rows, cols, ptr(sview), kind, sdt, ptr(gs), int(group_size), ptr(out), DT[dtype], ptr(sout), stream_of(p))
+        return _home(out, packed), _home(sout, packed)
     call("ct_fp4_unpack_dequant", ptr(p), rows, cols, ptr(sview), kind, sdt, ptr(gs), int(group_size), ptr(out), DT[dtype], stream_of(p))
     return _home(out, packed)
 

@@ -11,7 +11,9 @@ from ... import codec
 from ...config import CompressionFormat
 from ...quantization.quant_args import enum_value
 from ...utils import getattr_chain
-from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor
+from ...quantization.quant_args import QuantizationStatus
+from ...utils.module import direct_entry, swap_direct_entries
+from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor, symmetric_zp_keys
 
 __all__ = ["NVFP4PackedCompressor", "MXFP4PackedCompressor"]
 
@@ -56,9 +58,48 @@ class NVFP4PackedCompressor(BaseCompressor):
         global_scale = state_dict.get("weight_global_scale", None)
         if state_dict.get("weight_zero_point") is not None and not getattr_chain(scheme, "weights.symmetric", True):
             raise NotImplementedError("Asymmetric Quantization is not supported for FP4")
-        state_dict["weight_packed"] = codec.fp4_quantize_and_pack(weight, scale, global_scale, group_size=cls.GROUP)
-        state_dict["weight_scale"] = cls._compress_scale(scale, scheme.weights)
+        # the packed weight and the stored scale from ONE launch where the layout allows (16-bit weights on the GPU, the scheme's usual scale dtype);
+        # otherwise the scale conversion is the reference's expression
+        sdt = getattr(scheme.weights, "scale_dtype", None) or (torch.float8_e4m3fn if cls.GROUP == 16 else torch.uint8)
+        fused = codec.fp4_quantize_and_pack_stored(weight, scale, global_scale, group_size=cls.GROUP, scale_dtype=sdt)
+        if fused is not None:
+            state_dict["weight_packed"], state_dict["weight_scale"] = fused
+        else:
+            state_dict["weight_packed"] = codec.fp4_quantize_and_pack(weight, scale, global_scale, group_size=cls.GROUP)
+            state_dict["weight_scale"] = cls._compress_scale(scale, scheme.weights)
         return cls._remove_symmetric_zp(state_dict, scheme)
+
+    # ------------------------------------------------------------------ module loops (round 6)
+    # `ModelCompressor` on an FP4 checkpoint was bound by the interpreter, not the GPU: 28 (NVFP4) / 44 us (MXFP4) of host work per module and
+    # direction beside kernels of 2-30 us (a Llama-3-8B-shaped tree ran at 0.34 / 0.22 of the HBM peak).  The loops below do what
+    # `compress_module` / `decompress_module` do for the usual module — the weight and its scale tensor from ONE launch, the parameter
+    # dictionary rewritten as a delta (same resulting entries, in the same order, as replace_direct_state_dict leaves them) — and hand
+    # everything else to the generic path.
+    @classmethod
+    def compress_modules(cls, modules) -> None:
+        for m in modules:
+            scheme = getattr(m, "quantization_scheme")
+            w, sc, gs = direct_entry(m, "weight"), direct_entry(m, "weight_scale"), direct_entry(m, "weight_global_scale")
+            fused = None
+            if w is not None and sc is not None and (direct_entry(m, "weight_zero_point") is None or getattr_chain(scheme, "weights.symmetric", True)):
+                sdt = getattr(scheme.weights, "scale_dtype", None) or (torch.float8_e4m3fn if cls.GROUP == 16 else torch.uint8)
+                fused = codec.fp4_quantize_and_pack_stored(w.data, sc.data, None if gs is None else gs.data, group_size=cls.GROUP, scale_dtype=sdt)
+            if fused is None:
+                cls.compress_module(m)
+                continue
+            remove = ["weight", "weight_scale"] + [k for k in symmetric_zp_keys(scheme) if direct_entry(m, k) is not None]
+            swap_direct_entries(m, remove, {"weight_packed": fused[0], "weight_scale": fused[1]}, status=QuantizationStatus.COMPRESSED)
+
+    @classmethod
+    def decompress_modules(cls, modules) -> None:
+        for m in modules:
+            packed, sc, gs = direct_entry(m, "weight_packed"), direct_entry(m, "weight_scale"), direct_entry(m, "weight_global_scale")
+            if packed is None or sc is None or not packed.is_cuda or sc.device != packed.device:
+                cls.decompress_module(m)
+                continue
+            weight, scale = codec.fp4_unpack_and_dequantize(packed.data, sc.data, None if gs is None else gs.data, group_size=cls.GROUP, scale_kind=cls._scale_kind(),
+                                                            dtype=torch.bfloat16, return_scale=True)
+            swap_direct_entries(m, ["weight_packed", "weight_scale"], {"weight_scale": scale, "weight": weight}, status=QuantizationStatus.DECOMPRESSED)
 
     @classmethod
     def compress_rtn(cls, weight: torch.Tensor, scheme, global_scale=None) -> dict:
@@ -81,9 +122,9 @@ class NVFP4PackedCompressor(BaseCompressor):
         packed = state_dict.pop("weight_packed")
         scale = state_dict.get("weight_scale")
         global_scale = state_dict.get("weight_global_scale", None)
-        state_dict["weight"] = codec.fp4_unpack_and_dequantize(packed, scale, global_scale, group_size=cls.GROUP, scale_kind=cls._scale_kind(),
-                                                               dtype=torch.bfloat16)
-        state_dict["weight_scale"] = cls._decompress_scale(scale, torch.bfloat16)
+        # the weight and the decompressed (bfloat16) scale from one launch
+        state_dict["weight"], state_dict["weight_scale"] = codec.fp4_unpack_and_dequantize(
+            packed, scale, global_scale, group_size=cls.GROUP, scale_kind=cls._scale_kind(), dtype=torch.bfloat16, return_scale=True)
         return state_dict
 
     @classmethod

@@ -154,13 +154,30 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_kernel(const u32x4* __r
 // the common shape, lean: every lane owns 4 full units (tensor size % 32 == 0) and the scale dtype is a template
 // parameter, so the lane's one (group 32) or two (group 16) scales are fetched by a single small load BEFORE the 64
 // bytes of weights (same idea as w4_quant_pack_lean), and the fast / slow quotient choice is made once per lane.
+// tensor.to(float8_e4m3fn) of one float as torch evaluates it (c10/util/Float8_e4m3fn.h, the conversion the reference's `scale.to(scale_dtype)` runs,
+// nvfp4/base.py:96-100): round to nearest even, a magnitude that rounds beyond 448 — above the tie at 464 — or a NaN becomes the NaN code 0x7f, sign kept
+__device__ __forceinline__ uint32_t f32_to_fp8_as_torch(float v) {
+    const float a = __builtin_fabsf(v);
+    const uint32_t sign = (f_bits(v) >> 24) & 0x80u;
+    uint32_t b;
+    if (!(a <= 464.0f)) b = 0x7fu;        // NaN, inf, overflow
+    else if (a >= 448.0f) b = 0x7eu;      // [448, 464]: 448 (the tie goes to the even mantissa)
+    else b = f2_to_fp8x2(a, 0.0f) & 0xffu;
+    return b | sign;
+}
+
+// STORED (round 6): the lane also writes its groups' scales in their stored form — NVFP4: float8_e4m3fn bytes; MXFP4: the E8M0 codes of
+// compress_mx_scale (mx_utils.py:18-31: 127 + floor(log2(scale)) through int32 to uint8, log2 in the scale's dtype), read from a 65536-entry table
+// that the host builds by running that very expression over every 16-bit pattern — so the class call needs no tensor ops beside the launch
 template <int XDT, int SDT, int GROUP, bool GLOBAL>
 __global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4* __restrict__ in, const void* __restrict__ scale,
-                                                                     const float* __restrict__ global_scale, u32x4* __restrict__ out, int64_t lanes) {
+                                                                     const float* __restrict__ global_scale, u32x4* __restrict__ out, int64_t lanes,
+                                                                     uint8_t* __restrict__ stored, const uint8_t* __restrict__ mx_lut) {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= lanes) return;
     constexpr int NS = 32 / GROUP;  // scales per lane
     float s[2];
+    uint32_t sraw = 0;  // the 16-bit patterns of the lane's scales (SDT != F32)
     if constexpr (SDT == CT_F32) {
         if constexpr (NS == 2) {
             typedef float f2 __attribute__((ext_vector_type(2)));
@@ -173,10 +190,18 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4
         uint32_t b;
         if constexpr (NS == 2) b = __builtin_nontemporal_load(static_cast<const uint32_t*>(scale) + g);
         else b = __builtin_nontemporal_load(static_cast<const uint16_t*>(scale) + g);
+        sraw = b;
         if constexpr (SDT == CT_BF16) { s[0] = bits_f(b << 16); s[1] = NS == 2 ? bits_f(b & 0xffff0000u) : s[0]; }
         else { s[0] = f16_bits_to_f(b & 0xffffu); s[1] = NS == 2 ? f16_bits_to_f(b >> 16) : s[0]; }
     }
     const float gs = GLOBAL ? global_scale[0] : 1.0f;
+    if (stored) {  // kernel-uniform
+        if constexpr (GROUP == 16) {
+            reinterpret_cast<uint16_t*>(stored)[g] = (uint16_t)(f32_to_fp8_as_torch(s[0]) | (f32_to_fp8_as_torch(s[1]) << 8));
+        } else if constexpr (SDT != CT_F32) {
+            stored[g] = mx_lut[sraw & 0xffffu];
+        }
+    }
     asm volatile("" ::: "memory");  // keep the small loads ahead of the big ones
     u32x4 r[4];
 #pragma unroll
@@ -286,7 +311,7 @@ __device__ __forceinline__ float decode_scale(const void* scale, int kind, int s
 template <int ODT, int UNROLL, bool GLOBAL>
 __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32_t* __restrict__ in, const void* __restrict__ scale, int kind, int sdt,
                                                                     const float* __restrict__ global_scale, void* __restrict__ out, int64_t units,
-                                                                    int upg_shift, int64_t stride) {
+                                                                    int upg_shift, int64_t stride, uint16_t* __restrict__ scale_out) {
     const float gs = GLOBAL ? global_scale[0] : 1.0f;
     for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < units; base += stride) {
         uint32_t word[UNROLL];
@@ -300,6 +325,9 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32
             const int64_t u = base + (int64_t)i * kBlock;
             if (u >= units) continue;
             const float s = decode_scale(scale, kind, sdt, u >> upg_shift);
+            // the decompressed scale the reference hands back beside the weight (nvfp4/base.py:133-137 `scale.to(bfloat16)`, mx_utils.py:34-44
+            // `2.0 ** (code - 127)` as bfloat16): written by the lane that owns the group's first unit
+            if (scale_out && (u & (((int64_t)1 << upg_shift) - 1)) == 0) scale_out[u >> upg_shift] = (uint16_t)f_to_bf16_bits(s);
             const float s_eff = GLOBAL ? s / gs : s;
             float v[8];
 #pragma unroll
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_kernel(const uint8_t* __res
 template <int ODT, int UNROLL>
 __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_nv_kernel(const uint32_t* __restrict__ in, const uint8_t* __restrict__ scale,
                                                                        const float* __restrict__ global_scale, void* __restrict__ out, int64_t units,
-                                                                       int64_t stride) {
+                                                                       int64_t stride, uint16_t* __restrict__ scale_out) {
     __shared__ float s_eff[256];
     static_assert(kBlock == 256, "one table entry per thread");
     s_eff[threadIdx.x] = __builtin_amdgcn_cvt_f32_fp8((int)threadIdx.x, 0) / global_scale[0];
@@ -416,6 +444,7 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_nv_kernel(const uin
             const int64_t u = base + (int64_t)i * kBlock;
             if (u >= units) continue;
             const float s = s_eff[sb[i]];
+            if (scale_out && (u & 1) == 0) scale_out[u >> 1] = (uint16_t)f_to_bf16_bits(__builtin_amdgcn_cvt_f32_fp8((int)sb[i], 0));  // scale.to(bfloat16): exact
             float v[8];
             fp4_word_values(word[i], v);
 #pragma unroll
@@ -434,8 +463,8 @@ using namespace ct;
 
 extern "C" {
 
-int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const float* global_scale, int64_t rows, int64_t cols, int64_t group,
-                      uint8_t* packed, ct_stream_t stream) {
+static int fp4_quant_pack_impl(const void* x, int xdt, const void* scale, int sdt, const float* global_scale, int64_t rows, int64_t cols, int64_t group,
+                              uint8_t* packed, uint8_t* stored, const uint8_t* mx_lut, ct_stream_t stream) {
     CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "FP4 compression expects 16-bit float weights, got dtype %d", xdt);
     CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
     CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
@@ -449,10 +478,15 @@ int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const 
     const int shift = group == 16 ? 1 : 2;
     CT_REQUIRE(cdiv64(lanes, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
     dim3 grid((unsigned)cdiv64(lanes, kBlock));
-    if (units % 4 == 0 && (reinterpret_cast<uintptr_t>(scale) & 7u) == 0) {
+    const bool lean = units % 4 == 0 && (reinterpret_cast<uintptr_t>(scale) & 7u) == 0;
+    if (stored) {  // the stored scales ride the lean kernel only; NVFP4 any float scale, MXFP4 16-bit scales through the caller's table
+        if (!lean || (group == 32 && (sdt == CT_F32 || mx_lut == nullptr)) || (group == 16 && (reinterpret_cast<uintptr_t>(stored) & 1u)))
+            CT_UNSUPPORTED("ct_fp4_quant_pack_stored: this layout takes ct_fp4_quant_pack and the host's scale conversion");
+    }
+    if (lean) {
         dim3 lg((unsigned)cdiv64(lanes, kBlock));
 #define CT_FP4L(XD, SD, G, GL) hipLaunchKernelGGL((fp4_quant_pack_lean_kernel<XD, SD, G, GL>), lg, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), scale, \
-                                                  global_scale, reinterpret_cast<u32x4*>(packed), lanes)
+                                                  global_scale, reinterpret_cast<u32x4*>(packed), lanes, stored, mx_lut)
 #define CT_FP4L_G(XD, SD) do { if (group == 16) { if (global_scale) CT_FP4L(XD, SD, 16, true); else CT_FP4L(XD, SD, 16, false); } \
                                else { if (global_scale) CT_FP4L(XD, SD, 32, true); else CT_FP4L(XD, SD, 32, false); } } while (0)
 #define CT_FP4L_S(XD) do { if (sdt == CT_F32) CT_FP4L_G(XD, CT_F32); else if (sdt == CT_BF16) CT_FP4L_G(XD, CT_BF16); else CT_FP4L_G(XD, CT_F16); } while (0)
@@ -470,8 +504,19 @@ int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const 
     CT_LAUNCH_CHECK("ct_fp4_quant_pack");
 }
 
-int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind, int sdt, const float* global_scale,
-                          int64_t group, void* out, int odt, ct_stream_t stream) {
+int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const float* global_scale, int64_t rows, int64_t cols, int64_t group,
+                      uint8_t* packed, ct_stream_t stream) {
+    return fp4_quant_pack_impl(x, xdt, scale, sdt, global_scale, rows, cols, group, packed, nullptr, nullptr, stream);
+}
+
+int ct_fp4_quant_pack_stored(const void* x, int xdt, const void* scale, int sdt, const float* global_scale, int64_t rows, int64_t cols, int64_t group,
+                             uint8_t* packed, uint8_t* scale_stored, const uint8_t* mx_code_table, ct_stream_t stream) {
+    CT_REQUIRE(scale_stored != nullptr, "ct_fp4_quant_pack_stored needs the stored-scale output");
+    return fp4_quant_pack_impl(x, xdt, scale, sdt, global_scale, rows, cols, group, packed, scale_stored, mx_code_table, stream);
+}
+
+static int fp4_unpack_dequant_impl(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind, int sdt, const float* global_scale,
+                                   int64_t group, void* out, int odt, uint16_t* scale_out, ct_stream_t stream) {
     CT_REQUIRE(odt == CT_BF16 || odt == CT_F16, "FP4 decompression writes 16-bit floats, got dtype %d", odt);
     CT_REQUIRE(scale_kind >= SC_PLAIN && scale_kind <= SC_E8M0, "bad scale kind %d", scale_kind);
     CT_REQUIRE(scale_kind != SC_PLAIN || is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
@@ -488,17 +533,28 @@ int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, con
     const int64_t stride = (int64_t)1 << 40;  // one trip; the loop form schedules better (see ct_quant.hip)
     if (scale_kind == SC_F8E4M3 && global_scale && group == 16) {
         if (odt == CT_BF16) hipLaunchKernelGGL((fp4_unpack_dequant_nv_kernel<CT_BF16, U>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(packed),
-                                               static_cast<const uint8_t*>(scale), global_scale, out, units, stride);
+                                               static_cast<const uint8_t*>(scale), global_scale, out, units, stride, scale_out);
         else hipLaunchKernelGGL((fp4_unpack_dequant_nv_kernel<CT_F16, U>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(packed),
-                                static_cast<const uint8_t*>(scale), global_scale, out, units, stride);
+                                static_cast<const uint8_t*>(scale), global_scale, out, units, stride, scale_out);
         CT_LAUNCH_CHECK("ct_fp4_unpack_dequant[nvfp4]");
     }
 #define CT_FP4D(DT, GL) hipLaunchKernelGGL((fp4_unpack_dequant_kernel<DT, U, GL>), grid, dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const uint32_t*>(packed), \
-                                          scale, scale_kind, sdt, global_scale, out, units, shift, stride)
+                                          scale, scale_kind, sdt, global_scale, out, units, shift, stride, scale_out)
     if (odt == CT_BF16) { if (global_scale) CT_FP4D(CT_BF16, true); else CT_FP4D(CT_BF16, false); }
     else { if (global_scale) CT_FP4D(CT_F16, true); else CT_FP4D(CT_F16, false); }
 #undef CT_FP4D
     CT_LAUNCH_CHECK("ct_fp4_unpack_dequant");
+}
+
+int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind, int sdt, const float* global_scale,
+                          int64_t group, void* out, int odt, ct_stream_t stream) {
+    return fp4_unpack_dequant_impl(packed, rows, cols, scale, scale_kind, sdt, global_scale, group, out, odt, nullptr, stream);
+}
+
+int ct_fp4_unpack_dequant_scale(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind, int sdt, const float* global_scale,
+                                int64_t group, void* out, int odt, void* scale_bf16_out, ct_stream_t stream) {
+    CT_REQUIRE(scale_bf16_out != nullptr && (reinterpret_cast<uintptr_t>(scale_bf16_out) & 1u) == 0, "ct_fp4_unpack_dequant_scale needs the (2-byte aligned) scale output");
+    return fp4_unpack_dequant_impl(packed, rows, cols, scale, scale_kind, sdt, global_scale, group, out, odt, static_cast<uint16_t*>(scale_bf16_out), stream);
 }
 
 static int fp4_prim(const void* x, int xdt, void* out, int64_t n, int mode, ct_stream_t stream, const char* what) {

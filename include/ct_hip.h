@@ -288,6 +288,21 @@ int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const 
 int ct_fp4_unpack_dequant(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind,
                           int sdt, const float* global_scale, int64_t group, void* out, int odt,
                           ct_stream_t stream);
+/* The same two launches with the scale tensors of the compressors' state dicts written by the kernel (round 6: the class calls composed them from 1-4
+ * tensor ops per module — 5-20 us of launches beside a 10-30 us kernel):
+ *   ct_fp4_quant_pack_stored: also writes the STORED scale — NVFP4: `scale.to(float8_e4m3fn)` bytes (rows, cols/16) (nvfp4/base.py:96-100; torch's
+ *     conversion: RNE, a magnitude rounding beyond 448 or a NaN -> 0x7f | sign); MXFP4: `compress_mx_scale(scale, uint8)` codes (rows, cols/32)
+ *     (mx_utils.py:18-31), read from `mx_code_table`, a device uint8[65536] the caller fills ONCE per scale dtype with that expression evaluated over
+ *     every 16-bit pattern (so the codes are the reference's for every input, log2's rounding in the scale dtype included); NULL for NVFP4.
+ *     CT_ERR_UNSUPPORTED (nothing launched) unless rows * cols % 32 == 0, the scale is 8-byte aligned and, for MXFP4, 16-bit with a table.
+ *   ct_fp4_unpack_dequant_scale: also writes the decompressed scale as bfloat16 (rows, cols/group) — `scale.to(bfloat16)` of the float8 bytes
+ *     (nvfp4/base.py:133-137) resp. `decompress_mx_scale` = 2 ** (code - 127) (mx_utils.py:34-44). */
+int ct_fp4_quant_pack_stored(const void* x, int xdt, const void* scale, int sdt, const float* global_scale,
+                             int64_t rows, int64_t cols, int64_t group, uint8_t* packed, uint8_t* scale_stored,
+                             const uint8_t* mx_code_table, ct_stream_t stream);
+int ct_fp4_unpack_dequant_scale(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind,
+                                int sdt, const float* global_scale, int64_t group, void* out, int odt,
+                                void* scale_bf16_out, ct_stream_t stream);
 
 /* Round-to-nearest MXFP4 in one pass: per 32-element group the min-max observer, calculate_qparams' MX branch
  * (helpers.py:50-137, mxfp_utils.py:118-143), quantize -> cast_to_fp4 -> pack (nvfp4/base.py:88-95) and

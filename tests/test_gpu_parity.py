@@ -3116,6 +3116,98 @@ def test_qparams_float_vs_oracle(cta, dev, xdt, kind, gsize):
     assert eq(cta.codec.generate_gparam(d(xf, dev)).cpu(), O.generate_gparam(xf))
 
 
+@pytest.mark.parametrize("fmt", ["nvfp4-pack-quantized", "mxfp4-pack-quantized"])
+def test_fp4_module_loops_equal_the_generic_module_path(cta, dev, fmt):
+    """NVFP4 / MXFP4PackedCompressor.compress_modules / decompress_modules (one launch per module and direction, parameters rewritten as a delta)
+    leave a module exactly as compress_module / decompress_module do: the same entries in the same order, bit-identical tensors, non-trainable
+    Parameters, the status — with a bias, a symmetric scheme's zero point, an input global scale and a trainable stray parameter on the module;
+    a module the one-launch form declines (float32 weight scale of an MX scheme) takes the generic path inside the loop"""
+    from compressed_tensors_amd.quantization import calculate_qparams_from_weight
+
+    comp = cta.BaseCompressor.get_value_from_registry(fmt)
+    scheme = _fp4_scheme(cta, fmt)
+    g = torch.Generator().manual_seed(77)
+
+    def make(shape, scale_float32=False):
+        w = (torch.randn(shape, generator=g) * 0.05).to(BF16).to(dev)
+        lin = torch.nn.Linear(shape[1], shape[0], bias=True, device=dev, dtype=BF16)
+        lin.weight = torch.nn.Parameter(w, requires_grad=False)
+        gs = cta.codec.generate_gparam(w) if fmt.startswith("nvfp4") else None
+        scale, zp = calculate_qparams_from_weight(w, scheme.weights, global_scale=gs) if gs is not None else calculate_qparams_from_weight(w, scheme.weights)
+        lin.weight_scale = torch.nn.Parameter(scale.float() if scale_float32 else scale, requires_grad=False)
+        lin.weight_zero_point = torch.nn.Parameter(zp, requires_grad=False)
+        if gs is not None:
+            lin.weight_global_scale = torch.nn.Parameter(gs, requires_grad=False)
+        lin.input_global_scale = torch.nn.Parameter(torch.ones(1, device=dev), requires_grad=False)
+        lin.stray = torch.nn.Parameter(torch.ones(3, device=dev), requires_grad=True)
+        lin.quantization_scheme = scheme
+        return lin
+
+    def same(a, b):
+        assert list(a._parameters) == list(b._parameters) and list(a._buffers) == list(b._buffers)
+        for k in a._parameters:
+            x, y = a._parameters[k], b._parameters[k]
+            assert type(x) is type(y) and x.requires_grad == y.requires_grad and x.dtype == y.dtype and x.shape == y.shape, k
+            assert torch.equal(x.data.view(torch.uint8) if x.dtype == F8 else x.data, y.data.view(torch.uint8) if y.dtype == F8 else y.data), k
+        assert a.quantization_status == b.quantization_status
+
+    import copy
+    for shape, f32 in (((64, 512), False), ((48, 96), False), ((64, 512), True)):
+        if f32 and fmt.startswith("nvfp4"):
+            continue  # NVFP4 scales ARE float32
+        a = make(shape, f32)
+        b = copy.deepcopy(a)
+        b.quantization_scheme = scheme
+        comp.compress_modules([a])
+        comp.compress_module(b)
+        same(a, b)
+        assert "weight" not in a._parameters and "weight_zero_point" not in a._parameters and a._parameters["weight_packed"].dtype == torch.uint8
+        comp.decompress_modules([a])
+        comp.decompress_module(b)
+        same(a, b)
+        assert a._parameters["weight"].dtype == BF16 and a._parameters["weight_scale"].dtype == BF16
+
+
+@pytest.mark.parametrize("xdt", [BF16, F16])
+def test_fp4_scales_written_by_the_codec_launches(cta, dev, xdt):
+    """round 6: the compressors' scale tensors come out of the weight launches — the STORED scale on the way in (NVFP4 `scale.to(float8_e4m3fn)` with
+    torch's overflow-to-NaN rule at every boundary; MXFP4 `compress_mx_scale` for EVERY 16-bit scale pattern, through the code table), the bfloat16 scale
+    on the way back (all 256 stored bytes of both kinds) — each against the reference's own expression evaluated on the CPU"""
+    g = torch.Generator().manual_seed(23)
+    # NVFP4: float32 scales, 64 x 256 of them
+    rows, cols = 64, 16 * 256
+    w = (torch.randn((rows, cols), generator=g) * 0.5).to(xdt)
+    edge = torch.tensor([0.0, -0.0, 2.0 ** -9, 2.0 ** -10, 2.0 ** -10 * 1.0001, 2.0 ** -11, 3 * 2.0 ** -10, 1e-30, 447.9, 448.0, 455.9, 464.0, 464.00003, 479.9, 480.0, 1e9, float("inf"),
+                         -float("inf"), float("nan"), -448.0, -464.0, -464.1, -1e-3, 0.0625, 0.0703125, 17.0, 18.0, 19.0, 1.0625, 1.1875, 240.0, 248.0, 232.0])
+    sc = torch.exp(torch.randn((rows, cols // 16), generator=g) * 4.0) * torch.where(torch.rand((rows, cols // 16), generator=g) < 0.1, -1.0, 1.0)
+    sc.view(-1)[: edge.numel()] = edge
+    gs = torch.tensor([3.0])
+    got = cta.codec.fp4_quantize_and_pack_stored(d(w, dev), d(sc, dev), d(gs, dev), group_size=16, scale_dtype=F8)
+    assert got is not None
+    assert eq_f8(got[1].cpu(), sc.to(F8)) and torch.equal(got[0].cpu(), cta.codec.fp4_quantize_and_pack(d(w, dev), d(sc, dev), d(gs, dev), group_size=16).cpu())
+    assert torch.equal(got[1].cpu().view(torch.uint8)[sc == sc], sc.to(F8).view(torch.uint8)[sc == sc])  # the sign of a zero / of an overflow included
+    # MXFP4: every pattern of the scale dtype exactly once
+    rows, cols = 64, 32 * 1024
+    w = (torch.randn((rows, cols), generator=g) * 0.5).to(xdt)
+    every = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(xdt).reshape(rows, cols // 32)
+    got = cta.codec.fp4_quantize_and_pack_stored(d(w, dev), d(every, dev), None, group_size=32, scale_dtype=torch.uint8)
+    assert got is not None
+    ref_codes = (127 + torch.floor(torch.log2(every)).to(torch.int32)).to(torch.uint8)  # mx_utils.py:18-31
+    assert torch.equal(got[1].cpu(), ref_codes) and torch.equal(got[0].cpu(), cta.codec.fp4_quantize_and_pack(d(w, dev), d(every, dev), None, group_size=32).cpu())
+    # layouts outside the kernel are declined (the class then converts the scale itself)
+    assert cta.codec.fp4_quantize_and_pack_stored(d(w, dev), d(every.float(), dev), None, group_size=32, scale_dtype=torch.uint8) is None
+    assert cta.codec.fp4_quantize_and_pack_stored(d(w, dev), d(every, dev), None, group_size=32, scale_dtype=torch.int16) is None
+    # the way back: all 256 stored bytes, both kinds
+    codes = torch.arange(256, dtype=torch.uint8).repeat(8).reshape(8, 256)
+    packed = torch.randint(0, 256, (8, 256 * 16), generator=g, dtype=torch.uint8)
+    wv, sv = cta.codec.fp4_unpack_and_dequantize(d(packed[:, : 256 * 8].contiguous(), dev), d(codes.view(F8), dev), d(gs, dev), group_size=16, scale_kind="f8e4m3", return_scale=True)
+    assert sv.dtype == BF16 and eq(sv.cpu(), codes.view(F8).to(BF16))
+    assert eq(wv.cpu(), cta.codec.fp4_unpack_and_dequantize(d(packed[:, : 256 * 8].contiguous(), dev), d(codes.view(F8), dev), d(gs, dev), group_size=16, scale_kind="f8e4m3").cpu())
+    wv, sv = cta.codec.fp4_unpack_and_dequantize(d(packed, dev), d(codes, dev), None, group_size=32, scale_kind="e8m0", return_scale=True)
+    assert sv.dtype == BF16 and eq(sv.cpu(), 2.0 ** (codes.to(torch.int32) - 127).to(BF16))  # mx_utils.py:34-44
+    assert eq(wv.cpu(), cta.codec.fp4_unpack_and_dequantize(d(packed, dev), d(codes, dev), None, group_size=32, scale_kind="e8m0").cpu())
+
+
 @pytest.mark.parametrize("xdt", [BF16, F16, F32])
 def test_generate_gparam_on_the_device(cta, dev, xdt):
     """ct_generate_gparam (row maxima + one finishing workgroup) against the oracle's restatement of helpers.py:308-337: ordinary weights of several
