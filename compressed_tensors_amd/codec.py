@@ -1319,12 +1319,21 @@ def unpack_fp4_from_uint8(a: torch.Tensor, m: int, n: int, dtype: Optional[torch
 
 def compress_mx_scale(scale: torch.Tensor, scale_dtype: torch.dtype = torch.uint8) -> torch.Tensor:
     """compressors/mx_utils.py:18-31: E8M0 code 127 + floor(log2(scale)); log2 is evaluated in the scale's dtype, as
-    upstream (a small tensor: one element per 32 weights)."""
+    upstream (a small tensor: one element per 32 weights).  16-bit scales on the GPU: ONE launch that reads the codes from the table of this very
+    expression over every 16-bit pattern (`_mx_code_table`) instead of four tensor ops."""
+    if scale.is_cuda and scale_dtype is torch.uint8 and scale.dtype in (torch.bfloat16, torch.float16) and scale.is_contiguous() and scale.numel():
+        out = torch.empty(scale.shape, dtype=torch.uint8, device=scale.device)
+        call("ct_mx_scale_compress", ptr(scale), DT[scale.dtype], scale.numel(), ptr(_mx_code_table(scale.dtype, scale.device)), ptr(out), stream_of(scale))
+        return out
     return (127 + torch.floor(torch.log2(scale)).to(torch.int32)).to(scale_dtype)
 
 
 def decompress_mx_scale(scale: torch.Tensor) -> torch.Tensor:
-    """compressors/mx_utils.py:34-44: 2 ** (code - 127) as bfloat16"""
+    """compressors/mx_utils.py:34-44: 2 ** (code - 127) as bfloat16 (uint8 codes on the GPU: one launch)"""
+    if scale.is_cuda and scale.dtype is torch.uint8 and scale.is_contiguous() and scale.numel():
+        out = torch.empty(scale.shape, dtype=torch.bfloat16, device=scale.device)
+        call("ct_mx_scale_decompress", ptr(scale), scale.numel(), ptr(out), stream_of(scale))
+        return out
     return 2.0 ** (scale.to(torch.int32) - 127).to(torch.bfloat16)
 
 

@@ -457,6 +457,20 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_nv_kernel(const uin
     }
 }
 
+// the MX scale tensors by themselves (mx_utils.py:18-44; the MXFP8 codec and upstream's helpers call them): one launch each instead of four tensor ops
+__global__ __launch_bounds__(kBlock) void mx_scale_compress_kernel(const uint16_t* __restrict__ scale_bits, int64_t n, const uint8_t* __restrict__ table,
+                                                                   uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = table[scale_bits[i]];
+}
+__global__ __launch_bounds__(kBlock) void mx_scale_decompress_kernel(const uint8_t* __restrict__ codes, int64_t n, uint16_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const uint32_t e = codes[i];
+        out[i] = (uint16_t)f_to_bf16_bits(e == 0 ? 0x1p-127f : bits_f(e << 23));  // 2 ** (e - 127) as bfloat16; e = 255: 2^128 = inf
+    }
+}
+
 }  // namespace ct
 
 using namespace ct;
@@ -555,6 +569,23 @@ int ct_fp4_unpack_dequant_scale(const uint8_t* packed, int64_t rows, int64_t col
                                 int64_t group, void* out, int odt, void* scale_bf16_out, ct_stream_t stream) {
     CT_REQUIRE(scale_bf16_out != nullptr && (reinterpret_cast<uintptr_t>(scale_bf16_out) & 1u) == 0, "ct_fp4_unpack_dequant_scale needs the (2-byte aligned) scale output");
     return fp4_unpack_dequant_impl(packed, rows, cols, scale, scale_kind, sdt, global_scale, group, out, odt, static_cast<uint16_t*>(scale_bf16_out), stream);
+}
+
+int ct_mx_scale_compress(const void* scale, int sdt, int64_t n, const uint8_t* code_table, uint8_t* codes_out, ct_stream_t stream) {
+    CT_REQUIRE(sdt == CT_BF16 || sdt == CT_F16, "ct_mx_scale_compress takes 16-bit scales (the table has one entry per 16-bit pattern), got dtype %d", sdt);
+    CT_REQUIRE(n >= 0 && code_table != nullptr && (reinterpret_cast<uintptr_t>(scale) & 1u) == 0, "bad arguments");
+    if (n == 0) return CT_OK;
+    CT_REQUIRE(cdiv64(n, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
+    hipLaunchKernelGGL(mx_scale_compress_kernel, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, as_stream(stream), static_cast<const uint16_t*>(scale), n, code_table, codes_out);
+    CT_LAUNCH_CHECK("ct_mx_scale_compress");
+}
+
+int ct_mx_scale_decompress(const uint8_t* codes, int64_t n, void* scale_bf16_out, ct_stream_t stream) {
+    CT_REQUIRE(n >= 0 && (reinterpret_cast<uintptr_t>(scale_bf16_out) & 1u) == 0, "bad arguments");
+    if (n == 0) return CT_OK;
+    CT_REQUIRE(cdiv64(n, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
+    hipLaunchKernelGGL(mx_scale_decompress_kernel, dim3((unsigned)cdiv64(n, kBlock)), dim3(kBlock), 0, as_stream(stream), codes, n, static_cast<uint16_t*>(scale_bf16_out));
+    CT_LAUNCH_CHECK("ct_mx_scale_decompress");
 }
 
 static int fp4_prim(const void* x, int xdt, void* out, int64_t n, int mode, ct_stream_t stream, const char* what) {

@@ -303,6 +303,11 @@ int ct_fp4_quant_pack_stored(const void* x, int xdt, const void* scale, int sdt,
 int ct_fp4_unpack_dequant_scale(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind,
                                 int sdt, const float* global_scale, int64_t group, void* out, int odt,
                                 void* scale_bf16_out, ct_stream_t stream);
+/* compress_mx_scale / decompress_mx_scale (compressors/mx_utils.py:18-44) on their own — the MXFP8 codec's scale conversions and upstream's helpers:
+ * codes_out[i] = code_table[bits of scale[i]] (16-bit scales; the table as above) resp. scale_bf16_out[i] = 2 ** (codes[i] - 127) as bfloat16
+ * (code 0: the bfloat16 subnormal 2^-127, code 255: inf). */
+int ct_mx_scale_compress(const void* scale, int sdt, int64_t n, const uint8_t* code_table, uint8_t* codes_out, ct_stream_t stream);
+int ct_mx_scale_decompress(const uint8_t* codes, int64_t n, void* scale_bf16_out, ct_stream_t stream);
 
 /* Round-to-nearest MXFP4 in one pass: per 32-element group the min-max observer, calculate_qparams' MX branch
  * (helpers.py:50-137, mxfp_utils.py:118-143), quantize -> cast_to_fp4 -> pack (nvfp4/base.py:88-95) and

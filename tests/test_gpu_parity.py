@@ -3194,6 +3194,10 @@ def test_fp4_scales_written_by_the_codec_launches(cta, dev, xdt):
     assert got is not None
     ref_codes = (127 + torch.floor(torch.log2(every)).to(torch.int32)).to(torch.uint8)  # mx_utils.py:18-31
     assert torch.equal(got[1].cpu(), ref_codes) and torch.equal(got[0].cpu(), cta.codec.fp4_quantize_and_pack(d(w, dev), d(every, dev), None, group_size=32).cpu())
+    # the helpers by themselves (the MXFP8 codec's scale conversions): one launch each, the same codes
+    assert torch.equal(cta.codec.compress_mx_scale(d(every, dev)).cpu(), ref_codes)
+    all_codes = torch.arange(256, dtype=torch.uint8).reshape(4, 64)
+    assert eq(cta.codec.decompress_mx_scale(d(all_codes, dev)).cpu(), 2.0 ** (all_codes.to(torch.int32) - 127).to(BF16))
     # layouts outside the kernel are declined (the class then converts the scale itself)
     assert cta.codec.fp4_quantize_and_pack_stored(d(w, dev), d(every.float(), dev), None, group_size=32, scale_dtype=torch.uint8) is None
     assert cta.codec.fp4_quantize_and_pack_stored(d(w, dev), d(every, dev), None, group_size=32, scale_dtype=torch.int16) is None
