@@ -1615,6 +1615,105 @@ def llama8b_api_leg(dev):
             "timing": "wall clock, synchronize on both sides, median of 5 cycles after 2 warm-up cycles; HBM-cold by size (31.5 GB working set)"}
 
 
+def fp4_api_leg(dev):
+    """The float-4 formats through the plug-in API at a real checkpoint's module sizes (round 6): 16 layers of a Llama-3-8B-shaped tree (112 Linear modules,
+    3.49 G weights, 6.98 GB bf16, synthetic), NVFP4 (groups of 16, float8 scales under a global scale) and MXFP4 (groups of 32, E8M0 scales),
+    `ModelCompressor().compress_model(model)` + `.decompress_model(model)` — wall clock, median of 5 cycles after 2 warm-up cycles, HBM-cold by size —
+    beside the same modules' launches through the C ABI into preallocated outputs (`ct_fp4_quant_pack_stored` + `ct_fp4_unpack_dequant_scale`, one per
+    module and direction; these formats have no table launch).  alg bytes per element and direction: 2 + 0.5 + the stored scale (1/16 resp. 1/32 B)
+    + the float scale read (4/16 resp. 2/32 B) resp. the bfloat16 scale written (2/16, 2/32 B)."""
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd import _lib, codec
+
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    F8 = torch.float8_e4m3fn
+    out = {"workload": "16 layers of a Llama-3-8B-shaped tree (112 Linear modules, 3.49 G weights, 6.98 GB bf16, synthetic), NVFP4 / MXFP4, compress + decompress",
+           "timing": "wall clock, synchronize on both sides, median of 5 cycles after 2 warm-up cycles"}
+    for fmt, group, sdt_store in (("nvfp4", 16, F8), ("mxfp4", 32, torch.uint8)):
+        g = torch.Generator(device=dev).manual_seed(909)
+        if fmt == "nvfp4":
+            args = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8)
+        else:
+            args = cta.QuantizationArgs(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)
+        scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+        scheme.format = fmt + "-pack-quantized"
+        root = torch.nn.Module()
+        root.layers = torch.nn.ModuleList()
+        keep, alg, first = [], 0, None
+        for layer in range(16):
+            blk = torch.nn.Module()
+            root.layers.append(blk)
+            for (proj, r, c) in LLAMA8B_LAYER:
+                w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+                gs = codec.generate_gparam(w) if fmt == "nvfp4" else None
+                sc = codec.minmax_qparams_float(w, kind=fmt, group_size=group, global_scale=gs)
+                lin = torch.nn.Linear(c, r, bias=False, device="meta")
+                lin.weight = torch.nn.Parameter(w, requires_grad=False)
+                lin.weight_scale = torch.nn.Parameter(sc, requires_grad=False)
+                if gs is not None:
+                    lin.weight_global_scale = torch.nn.Parameter(gs, requires_grad=False)
+                lin.quantization_scheme = scheme
+                setattr(blk, proj, lin)
+                first = first or lin
+                keep.append((w, sc, gs, torch.empty(r, c // 2, dtype=torch.uint8, device=dev), torch.empty(r, c // group, dtype=sdt_store, device=dev),
+                             torch.empty(r, c, dtype=torch.bfloat16, device=dev), torch.empty(r, c // group, dtype=torch.bfloat16, device=dev)))
+                ng = r * c // group
+                alg += 2 * (2 * r * c + r * c // 2 + ng) + ng * sc.element_size() + 2 * ng
+        lut = codec._mx_code_table(torch.bfloat16, dev) if fmt == "mxfp4" else None
+        BF16 = _lib.BF16
+        ca = [(w.data_ptr(), BF16, sc.data_ptr(), _lib.DT[sc.dtype], None if gs is None else gs.data_ptr(), w.shape[0], w.shape[1], group, pk.data_ptr(), st.data_ptr(),
+               None if lut is None else lut.data_ptr(), stream) for (w, sc, gs, pk, st, o, so) in keep]
+        da = [(pk.data_ptr(), w.shape[0], w.shape[1], st.data_ptr(), 1 if fmt == "nvfp4" else 2, -1, None if gs is None else gs.data_ptr(), group, o.data_ptr(), BF16, so.data_ptr(), stream)
+              for (w, sc, gs, pk, st, o, so) in keep]
+
+        def kernels():
+            for x in ca:
+                _lib.check(lib.ct_fp4_quant_pack_stored(*x))
+            for x in da:
+                _lib.check(lib.ct_fp4_unpack_dequant_scale(*x))
+
+        kernels()
+        torch.cuda.synchronize()
+        ks = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kernels()
+            torch.cuda.synchronize()
+            ks.append(time.perf_counter() - t0)
+        kernels_s = median(ks)
+        want_w, want_s = keep[0][5].clone(), keep[0][6].clone()
+        keep = None
+        ca = da = None
+        torch.cuda.empty_cache()
+        mc = cta.ModelCompressor()
+
+        def cycle():
+            mc.compress_model(root)
+            mc.decompress_model(root)
+
+        cycle()
+        ok = bool(torch.equal(first.weight.data, want_w)) and bool(torch.equal(first.weight_scale.data, want_s))
+        cycle()
+        both, host = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cycle()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            both.append(time.perf_counter() - t0)
+            host.append(t1 - t0)
+        out[fmt] = {"alg_bytes": alg, "modules": 112, "ms_launches_only": round(kernels_s * 1e3, 3), "launches_frac_hbm": round(alg / kernels_s / 1e9 / HBM_PEAK_GBPS, 4),
+                    "ms_model_compressor": round(median(both) * 1e3, 3), "model_compressor_frac_hbm": round(alg / median(both) / 1e9 / HBM_PEAK_GBPS, 4),
+                    "api_over_launches": round(median(both) / kernels_s, 3), "us_host_per_module_and_direction": round(median(host) * 1e6 / 224, 2),
+                    "class_result_equals_c_abi_result": ok}
+        del root, first
+        torch.cuda.empty_cache()
+    return out
+
+
 def sparse_checkpoint_leg(dev):
     """A TinyLlama-1.1B-shaped checkpoint (154 tensors, 1.94 GB bf16), 50 % unstructured sparsity, through the sparse-bitmask codec's class API
     (VERDICT r05 next #6): `BitmaskTensor.from_dense_many` (one host wait per window of tensors) against `from_dense` tensor by tensor and
@@ -2271,7 +2370,7 @@ def main():
             torch.cuda.empty_cache()
             for key, leg in (("kernels_other", w4_variants_leg), ("other_widths", other_widths_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("quantize_dequantize_fake_quantize", quantize_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
                              ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg), ("tinyllama_w8a8", tinyllama_w8_leg),
-                             ("sparse_checkpoint", sparse_checkpoint_leg), ("llama8b_checkpoint", llama8b_api_leg)):
+                             ("sparse_checkpoint", sparse_checkpoint_leg), ("llama8b_checkpoint", llama8b_api_leg), ("fp4_checkpoint_api", fp4_api_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down

@@ -1,0 +1,70 @@
+"""ModelCompressor.compress_model + decompress_model wall time for FP8 / NVFP4 / MXFP4 / W4 schemes on TinyLlama- and Llama-3-8B-shaped trees:
+what the plug-in API costs per module for the formats that have no table launch"""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import compressed_tensors_amd as cta
+from compressed_tensors_amd import codec
+dev = torch.device("cuda:0")
+TINY = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048), ("gate_proj", 5632, 2048), ("up_proj", 5632, 2048), ("down_proj", 2048, 5632))
+L8B = (("q_proj", 4096, 4096), ("k_proj", 1024, 4096), ("v_proj", 1024, 4096), ("o_proj", 4096, 4096), ("gate_proj", 14336, 4096), ("up_proj", 14336, 4096), ("down_proj", 4096, 14336))
+F8 = torch.float8_e4m3fn
+
+def build(layer_shapes, nlayers, fmt):
+    root = torch.nn.Module(); root.layers = torch.nn.ModuleList()
+    g = torch.Generator(device=dev).manual_seed(1)
+    if fmt == "fp8":
+        args = cta.QuantizationArgs(num_bits=8, type="float", strategy="channel", symmetric=True)
+    elif fmt == "nvfp4":
+        args = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8)
+    elif fmt == "mxfp4":
+        args = cta.QuantizationArgs(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)
+    else:
+        args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
+    if fmt in ("nvfp4", "mxfp4"):
+        scheme.format = fmt + "-pack-quantized"
+    alg = 0
+    for l in range(nlayers):
+        blk = torch.nn.Module(); root.layers.append(blk)
+        for (proj, r, c) in layer_shapes:
+            w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+            lin = torch.nn.Linear(c, r, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(w, requires_grad=False)
+            if fmt == "fp8":
+                s = codec.minmax_qparams_float(w, kind="fp8"); z = torch.zeros(s.shape, dtype=F8, device=dev)
+                alg += 2 * (3 * r * c)
+            elif fmt == "nvfp4":
+                gs = codec.generate_gparam(w); s = codec.minmax_qparams_float(w, kind="nvfp4", group_size=16, global_scale=gs); z = None
+                lin.weight_global_scale = torch.nn.Parameter(gs, requires_grad=False)
+                alg += 2 * int(2.5 * r * c)
+            elif fmt == "mxfp4":
+                s = codec.minmax_qparams_float(w, kind="mxfp4", group_size=32); z = None
+                alg += 2 * int(2.5 * r * c)
+            else:
+                s, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+                alg += 2 * int(2.5 * r * c)
+            lin.weight_scale = torch.nn.Parameter(s, requires_grad=False)
+            if z is not None: lin.weight_zero_point = torch.nn.Parameter(z, requires_grad=False)
+            lin.quantization_scheme = scheme
+            setattr(blk, proj, lin)
+    return root, alg
+
+for name, shapes, nl in (("tinyllama 154 modules", TINY, 22), ("llama-8B-shaped 112 modules", L8B, 16)):
+    for fmt in ("w4", "fp8", "nvfp4", "mxfp4"):
+        model, alg = build(shapes, nl, fmt)
+        mc = cta.ModelCompressor()
+        def cycle():
+            mc.compress_model(model); mc.decompress_model(model)
+        try:
+            cycle(); cycle()
+        except Exception as e:
+            print(name, fmt, "FAILED", repr(e)[:300]); continue
+        both, host = [], []
+        for _ in range(5):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); cycle(); t1 = time.perf_counter(); torch.cuda.synchronize()
+            both.append(time.perf_counter() - t0); host.append(t1 - t0)
+        both.sort(); host.sort()
+        n = nl * 7
+        print(f"{name:30s} {fmt:6s}: wall {both[2]*1e3:8.3f} ms ({alg/both[2]/8e12:.3f} of HBM peak), host returns at {host[2]*1e3:8.3f} ms = {host[2]*1e6/n/2:.1f} us per module and direction", flush=True)
+        del model
+        torch.cuda.empty_cache()
