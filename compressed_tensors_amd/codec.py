@@ -1389,8 +1389,8 @@ def fp4_quantize_and_pack(weight: torch.Tensor, scale: torch.Tensor, global_scal
         raise ValueError("FP4 compression expects a 2-D weight")
     if weight.shape[1] % 2 != 0:
         raise ValueError("tensor must have an even number of columns for nvfp4 compression")
-    if weight.dtype not in (torch.bfloat16, torch.float16):
-        raise NotImplementedError(f"the MI355X FP4 path compresses 16-bit float weights, got {weight.dtype}")
+    if weight.dtype not in _FLOATS:
+        raise NotImplementedError(f"the MI355X FP4 path compresses float weights, got {weight.dtype}")
     dev = _compute_device(weight)
     w, s = _dev(weight, dev).contiguous(), _dev(scale, dev).contiguous()
     rows, cols = w.shape

@@ -151,6 +151,26 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_kernel(const u32x4* __r
     }
 }
 
+// float32 weights (round 6; rare — a float32 checkpoint — and declined before): one unit of 8 floats per lane, the quotient is the IEEE float32
+// divide (T = float32 whatever the scale's dtype), then cast_to_fp4 by the hardware conversion as above
+template <bool GLOBAL>
+__global__ __launch_bounds__(kBlock) void fp4_quant_pack_f32_kernel(const u32x4* __restrict__ in, const void* __restrict__ scale, int sdt,
+                                                                    const float* __restrict__ global_scale, uint32_t* __restrict__ out, int64_t units, int upg_shift) {
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (u >= units) return;
+    const u32x4 a = in[2 * u], b = in[2 * u + 1];
+    const float s = load_rt(scale, sdt, u >> upg_shift);
+    const float s_eff = GLOBAL ? s / global_scale[0] : s;
+    const uint32_t ws[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float q = bits_f(ws[k]) / s_eff;
+        t[k] = q != q ? 0.0f : q;  // cast_to_fp4 of a NaN: no threshold compares true and `x < 0` is false — +0 (the hardware conversion would saturate it to 6)
+    }
+    out[u] = fp4_word(t);
+}
+
 // the common shape, lean: every lane owns 4 full units (tensor size % 32 == 0) and the scale dtype is a template
 // parameter, so the lane's one (group 32) or two (group 16) scales are fetched by a single small load BEFORE the 64
 // bytes of weights (same idea as w4_quant_pack_lean), and the fast / slow quotient choice is made once per lane.
@@ -479,7 +499,7 @@ extern "C" {
 
 static int fp4_quant_pack_impl(const void* x, int xdt, const void* scale, int sdt, const float* global_scale, int64_t rows, int64_t cols, int64_t group,
                               uint8_t* packed, uint8_t* stored, const uint8_t* mx_lut, ct_stream_t stream) {
-    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "FP4 compression expects 16-bit float weights, got dtype %d", xdt);
+    CT_REQUIRE(is_float_dt(xdt), "FP4 compression expects float weights, got dtype %d", xdt);
     CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
     CT_REQUIRE(rows >= 0 && cols >= 0, "negative shape");
     CT_REQUIRE(group == 16 || group == 32, "FP4 group size must be 16 (nvfp4) or 32 (mxfp4), got %lld", (long long)group);
@@ -488,6 +508,16 @@ static int fp4_quant_pack_impl(const void* x, int xdt, const void* scale, int sd
     CT_REQUIRE(aligned16(x) && aligned16(packed), "buffers must be 16-byte aligned");
     if (rows == 0 || cols == 0) return CT_OK;
     const int64_t units = rows * (cols / 8);  // rows are contiguous and cols % 8 == 0: one flat unit stream
+    if (xdt == CT_F32) {
+        if (stored) CT_UNSUPPORTED("ct_fp4_quant_pack_stored: float32 weights take ct_fp4_quant_pack and the host's scale conversion");
+        CT_REQUIRE(cdiv64(units, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");
+        dim3 g32((unsigned)cdiv64(units, kBlock));
+        if (global_scale) hipLaunchKernelGGL((fp4_quant_pack_f32_kernel<true>), g32, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), scale, sdt, global_scale,
+                                             reinterpret_cast<uint32_t*>(packed), units, group == 16 ? 1 : 2);
+        else hipLaunchKernelGGL((fp4_quant_pack_f32_kernel<false>), g32, dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), scale, sdt, global_scale,
+                                reinterpret_cast<uint32_t*>(packed), units, group == 16 ? 1 : 2);
+        CT_LAUNCH_CHECK("ct_fp4_quant_pack[f32]");
+    }
     const int64_t lanes = cdiv64(units, 4);
     const int shift = group == 16 ? 1 : 2;
     CT_REQUIRE(cdiv64(lanes, kBlock) < ((int64_t)1 << 31), "tensor too large for one launch");

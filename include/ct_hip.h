@@ -280,7 +280,8 @@ int ct_generate_gparam(const void* x, int xdt, int64_t rows, int64_t cols, void*
  * mxfp4/base.py:27-65): quantize(x, scale, global_scale) -> cast_to_fp4 -> pack_fp4_to_uint8 fused, and the
  * inverse.  group: 16 (nvfp4) or 32 (mxfp4); cols % group == 0.  global_scale: device float32[1] or NULL.
  * packed: uint8 (rows, cols/2), element 2i in the low nibble of byte i.
- * compress: scale is the float scale tensor (rows, cols/group) the reference passes to quantize().
+ * compress: scale is the float scale tensor (rows, cols/group) the reference passes to quantize(); x: bf16 / fp16 weights (the lean kernels) or
+ * float32 ones (round 6: a plain one-unit-per-lane kernel, IEEE float32 quotient).
  * decompress: scale_kind 0 = float tensor of dtype sdt, 1 = the stored fp8-e4m3fn bytes (nvfp4), 2 = the stored
  * E8M0 exponent bytes (mxfp4); odt in {CT_BF16, CT_F16} (the reference always produces bf16). */
 int ct_fp4_quant_pack(const void* x, int xdt, const void* scale, int sdt, const float* global_scale,

@@ -3117,6 +3117,41 @@ def test_qparams_float_vs_oracle(cta, dev, xdt, kind, gsize):
 
 
 @pytest.mark.parametrize("fmt", ["nvfp4-pack-quantized", "mxfp4-pack-quantized"])
+def test_fp4_compress_of_float32_weights(cta, dev, fmt):
+    """a float32 checkpoint through the FP4 codecs (declined before round 6): the kernel's IEEE float32 quotient + hardware E2M1 rounding against the
+    oracle, special values and quotients on the rounding thresholds included; the class `compress` and `compress_rtn` on float32 weights"""
+    g = torch.Generator().manual_seed(5)
+    group = 16 if fmt.startswith("nvfp4") else 32
+    x = torch.randn((96, 512), generator=g) * 0.7
+    sp = torch.tensor([0.0, -0.0, 1e-30, -1e-30, float("inf"), -float("inf"), float("nan"), 1e30, 0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, -0.25, -0.75, -2.5, 6.0, 7.0])
+    x.view(-1)[: sp.numel()] = sp
+    if group == 16:
+        gs = torch.tensor([2.5])
+        s = (torch.rand((96, 512 // 16), generator=g) * 2 + 0.05).to(F8).float()
+        s[0, 0] = 1.0 * 2.5  # s_eff = 1: the special values above sit exactly on cast_to_fp4's thresholds
+    else:
+        gs = None
+        s = (2.0 ** torch.randint(-6, 3, (96, 512 // 32), generator=g).float()).to(BF16)
+        s[0, 0] = 1.0
+    got = cta.codec.fp4_quantize_and_pack(d(x, dev), d(s, dev), d(gs, dev), group_size=group)
+    ref = O.fp4_compress(x, s, gs, fmt=fmt)
+    assert torch.equal(got.cpu(), ref["weight_packed"])
+    comp = cta.BaseCompressor.get_value_from_registry(fmt)
+    scheme = _fp4_scheme(cta, fmt)
+    sd = {"weight": d(x, dev), "weight_scale": d(s, dev)}
+    if gs is not None:
+        sd["weight_global_scale"] = d(gs, dev)
+    out = comp.compress(sd, scheme)
+    assert torch.equal(out["weight_packed"].cpu(), ref["weight_packed"]) and torch.equal(out["weight_scale"].cpu().view(torch.uint8), ref["weight_scale"].view(torch.uint8))
+    xf = torch.nan_to_num(x, nan=0.0, posinf=3.0, neginf=-3.0).clamp(-9, 9)
+    rtn = comp.compress_rtn(d(xf, dev), scheme)
+    gs_r = O.generate_gparam(xf) if group == 16 else None
+    s_r = O.calculate_qparams_float(xf, kind="nvfp4" if group == 16 else "mxfp4", group_size=group, global_scale=gs_r)
+    ref_r = O.fp4_compress(xf, s_r, gs_r, fmt=fmt)
+    assert torch.equal(rtn["weight_packed"].cpu(), ref_r["weight_packed"]) and torch.equal(rtn["weight_scale"].cpu().view(torch.uint8), ref_r["weight_scale"].view(torch.uint8))
+
+
+@pytest.mark.parametrize("fmt", ["nvfp4-pack-quantized", "mxfp4-pack-quantized"])
 def test_fp4_module_loops_equal_the_generic_module_path(cta, dev, fmt):
     """NVFP4 / MXFP4PackedCompressor.compress_modules / decompress_modules (one launch per module and direction, parameters rewritten as a delta)
     leave a module exactly as compress_module / decompress_module do: the same entries in the same order, bit-identical tensors, non-trainable
