@@ -754,7 +754,7 @@ class W4Batch:
     library and uploaded asynchronously from pinned memory."""
 
     def __init__(self, entries, direction: str, dtype: torch.dtype, kind: str = "w4", bits: int = 8):
-        assert direction in ("compress", "decompress") and kind in ("w4", "int8", "fp8")
+        assert direction in ("compress", "decompress") and kind in ("w4", "int8", "fp8", "fp8z")  # fp8z: float8 codes with float8 zero points
         import array
 
         self.direction = 0 if direction == "compress" else 1
@@ -789,9 +789,9 @@ class W4Batch:
         if self.kind == "w4":
             call("ct_quant_pack_batch" if self.direction == 0 else "ct_unpack_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, s)
         elif self.direction == 0:
-            call("ct_q8_quant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), self.bits, s)
+            call("ct_q8_quant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, {"int8": 0, "fp8": 1, "fp8z": 2}[self.kind], self.bits, s)
         else:
-            call("ct_q8_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, int(self.kind == "fp8"), s)
+            call("ct_q8_dequant_batch", self.table.data_ptr(), self.n, self.blocks, self.dt, {"int8": 0, "fp8": 1, "fp8z": 2}[self.kind], s)
 
 
 def quantize_and_pack_many(items, *, num_bits, strategy, group_size=None):
@@ -873,7 +873,7 @@ def zp4_batch(pairs, direction: str) -> None:
     table.record_stream(torch.cuda.current_stream(dev))
 
 
-def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, group_size=None, g_idx=None):
+def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, group_size=None, g_idx=None, f8_zero_point=False):
     """Elements per scale (the table's `group`) if this tensor can join a one-launch 8-bit batch, else None.  2-D, 16-bit
     float dtype equal to the scale's, tensor / channel / group scales (strategy given, or inferred from the scale's shape like
     `dequantize` does, forward.py:99-130), cols % 16 == 0, group % 16 == 0, int8 or absent zero point of the scale's shape,
@@ -898,7 +898,9 @@ def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, 
         return None
     if group % 16:
         return None
-    if zero_point is not None and (zero_point.dtype != torch.int8 or zero_point.shape != scale.shape or zero_point.device != device
+    # (f8_zero_point, round 6: the float8 zero points a calibrated FLOAT scheme carries — all zeros for the symmetric schemes upstream allows, but
+    # read as the float8 values they are: kind "fp8z" of W4Batch)
+    if zero_point is not None and (zero_point.dtype != (_F8 if f8_zero_point else torch.int8) or zero_point.shape != scale.shape or zero_point.device != device
                                    or not zero_point.is_contiguous()):
         return None
     return group

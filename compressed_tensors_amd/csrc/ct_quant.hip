@@ -1248,9 +1248,10 @@ __global__ __launch_bounds__(kBlock) void f8_dequant_kernel(W4Params p) {
 // share one scale: cols (channel), a divisor of cols (group) or rows * cols (tensor).  Zero points: int8 or none.
 // ------------------------------------------------------------------------------------------
 template <int DT, bool FP8>
-__global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int qmin, int qmax) {
+__global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int qmin, int qmax, int zdt) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
-    const W4Params p = batch_params(it);
+    W4Params p = batch_params(it);
+    p.zdt = zdt;  // int8, or the float8 zero points a calibrated FLOAT scheme carries (round 6)
     const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
     if (g >= p.units / 2) return;
     if constexpr (FP8) {
@@ -1263,9 +1264,10 @@ __global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item
 }
 
 template <int DT, bool FP8>
-__global__ __launch_bounds__(kBlock) void q8_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride) {
+__global__ __launch_bounds__(kBlock) void q8_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride, int zdt) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
-    const W4Params p = batch_params(it);
+    W4Params p = batch_params(it);
+    p.zdt = zdt;
     const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kBatchIter;
     const int64_t limit = (first + stride * kBatchIter < p.units) ? first + stride * kBatchIter : p.units;
     // (a runtime-stride loop, like the W4 batch: hipcc schedules the body better inside one)
@@ -2302,13 +2304,15 @@ int ct_q8_quant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, 
     CT_REQUIRE(fp8 || (bits >= 1 && bits <= 8), "num_bits must be in [1, 8], got %d", bits);
     if (n == 0 || total_blocks == 0) return CT_OK;
     const int qmin = fp8 ? 0 : -(1 << (bits - 1)), qmax = fp8 ? 0 : (1 << (bits - 1)) - 1;
+    CT_REQUIRE(fp8 >= 0 && fp8 <= 2, "fp8 must be 0 (int8 codes), 1 (float8 codes, int8 zero points) or 2 (float8 codes, float8 zero points), got %d", fp8);
+    const int zdt = fp8 == 2 ? CT_F8E4M3 : CT_I8;
     const dim3 grid((unsigned)total_blocks);
     if (dt == CT_BF16) {
-        if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
-        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
+        if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
+        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
     } else {
-        if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
-        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax);
+        if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
+        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
     }
     CT_LAUNCH_CHECK("ct_q8_quant_batch");
 }
@@ -2318,13 +2322,15 @@ int ct_q8_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks
     CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
     if (n == 0 || total_blocks == 0) return CT_OK;
     const int64_t stride = (int64_t)kBlock * kBatchUnroll;
+    CT_REQUIRE(fp8 >= 0 && fp8 <= 2, "fp8 must be 0, 1 or 2 (float8 codes with float8 zero points), got %d", fp8);
+    const int zdt = fp8 == 2 ? CT_F8E4M3 : CT_I8;
     const dim3 grid((unsigned)total_blocks);
     if (dt == CT_BF16) {
-        if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
-        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
+        if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
+        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
     } else {
-        if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
-        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride);
+        if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
+        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
     }
     CT_LAUNCH_CHECK("ct_q8_dequant_batch");
 }

@@ -1884,7 +1884,7 @@ def test_batched_model_compress_matches_per_module(cta, dev, symmetric):
         assert eq(a.weight.data.cpu(), b.weight.data.cpu()) and a.weight.dtype == b.weight.dtype
 
 
-@pytest.mark.parametrize("kind", ["int8", "fp8", "int8-asym", "int6"])
+@pytest.mark.parametrize("kind", ["int8", "fp8", "fp8-zp", "int8-asym", "int6"])
 def test_batched_8bit_model_compress_matches_per_module(cta, dev, kind):
     """ModelCompressor with int-quantized / float-quantized / naive-quantized modules: ONE ct_q8_quant_batch / ct_q8_dequant_batch
     launch per direction (model_compressor.py:167-169,196-198 loops); every state dict identical to the per-module path,
@@ -1895,7 +1895,7 @@ def test_batched_8bit_model_compress_matches_per_module(cta, dev, kind):
     shapes = [(256, 2048), (64, 256), (2048, 256), (96, 128), (32, 40), (128, 384), (48, 512)]
     model = torch.nn.Sequential(*[torch.nn.Linear(c, r, bias=(i == 1)) for i, (r, c) in enumerate(shapes)]).to(dev).to(F16 if kind == "int6" else BF16)
     model[5] = model[5].float()  # fp32 weights: per module
-    fp8 = kind == "fp8"
+    fp8 = kind in ("fp8", "fp8-zp")  # "fp8-zp": the calibrated flow's float8 zero points are on the modules (batch kind "fp8z", round 6)
     sym = kind != "int8-asym"
     bits = 6 if kind == "int6" else 8
     for i, m in enumerate(model):
@@ -1909,12 +1909,18 @@ def test_batched_8bit_model_compress_matches_per_module(cta, dev, kind):
         m.register_parameter("weight_scale", torch.nn.Parameter(s, requires_grad=False))
         if not fp8:
             m.register_parameter("weight_zero_point", torch.nn.Parameter(z, requires_grad=False))
+        elif kind == "fp8-zp":
+            assert z.dtype == torch.float8_e4m3fn
+            if i == 2:  # not all zeros: the kernels must read the zero points as float8 values, not as bytes
+                z = torch.full(z.shape, 0.5, device=z.device).to(torch.float8_e4m3fn)
+            m.register_parameter("weight_zero_point", torch.nn.Parameter(z, requires_grad=False))
+            m.weight.data.view(-1)[:7] = torch.tensor([-0.0, 0.0, -1e-30, 1e-30, -0.0, 3.0, -3.0], dtype=m.weight.dtype, device=dev)  # -0 + zero point = +0
     ref = copy.deepcopy(model)
     for m in ref:
         cta.compress_module(m)
     comp = cta.ModelCompressor()
     comp.compress_model(model)
-    fmt = {"int8": "int-quantized", "int8-asym": "int-quantized", "fp8": "float-quantized", "int6": "naive-quantized"}[kind]
+    fmt = {"int8": "int-quantized", "int8-asym": "int-quantized", "fp8": "float-quantized", "fp8-zp": "float-quantized", "int6": "naive-quantized"}[kind]
     for a, b in zip(model, ref):
         assert enum_name(a.quantization_scheme.format) == fmt
         sa, sb = dict(a.named_parameters()), dict(b.named_parameters())
