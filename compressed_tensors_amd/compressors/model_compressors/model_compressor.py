@@ -132,27 +132,34 @@ class ModelCompressor:
         `compress_rtn`).  Bias and other parameters are kept.  Under torch.distributed the modules are sharded over the
         ranks exactly like `compress_model`.  No upstream counterpart: upstream separates calibration (observers,
         llm-compressor) from `compress_model`; the result equals that two-step flow with min-max observers."""
-        from ...utils.module import get_direct_state_dict, replace_direct_state_dict
+        from ...utils.module import direct_entry, swap_direct_entries
         from ..base import BaseCompressor
         from ..format import infer_module_format
 
         def apply(modules):
+            # the format resolution and its write-back to the scheme happen once per (scheme object, module type), and the parameter dictionary is
+            # rewritten as a delta (every `weight*` entry goes, the codec's entries come) — what get_direct_state_dict / replace_direct_state_dict did
+            # per module at 28-45 us of host time beside one 2-30 us kernel (round 6)
+            resolved = {}
             for module in modules:
                 scheme = module.quantization_scheme
-                fmt = self.force_compression_format or getattr(scheme, "format", None) or infer_module_format(type(module), scheme)
-                fmt = CompressionFormat(getattr(fmt, "value", fmt))
-                comp = BaseCompressor.get_value_from_registry(fmt.value)
-                if not hasattr(comp, "compress_rtn"):
-                    raise NotImplementedError(f"round-to-nearest compression is not implemented for format {fmt.value}")
-                sd = get_direct_state_dict(module)
-                new = {k: v for k, v in sd.items() if not k.startswith("weight")}
-                new.update(comp.compress_rtn(sd["weight"], scheme))
-                replace_direct_state_dict(module, new)
-                try:
-                    scheme.format = fmt
-                except Exception:
-                    scheme.format = fmt.value
-                module.quantization_status = QuantizationStatus.COMPRESSED
+                key = (id(scheme), type(module))
+                comp = resolved.get(key)
+                if comp is None:
+                    fmt = self.force_compression_format or getattr(scheme, "format", None) or infer_module_format(type(module), scheme)
+                    fmt = CompressionFormat(getattr(fmt, "value", fmt))
+                    comp = BaseCompressor.get_value_from_registry(fmt.value)
+                    if not hasattr(comp, "compress_rtn"):
+                        raise NotImplementedError(f"round-to-nearest compression is not implemented for format {fmt.value}")
+                    try:
+                        scheme.format = fmt
+                    except Exception:
+                        scheme.format = fmt.value
+                    resolved[key] = comp
+                weight = direct_entry(module, "weight")
+                new = comp.compress_rtn(weight.data, scheme)
+                remove = [k for k in (*module._parameters, *module._buffers) if k.startswith("weight")]
+                swap_direct_entries(module, remove, new, status=QuantizationStatus.COMPRESSED)
 
         mine = self._parallel(model, apply, recouple, skip_compressed=True)
         self._finish_compress(model, recouple)
