@@ -2050,13 +2050,15 @@ int ct_rtn_quant_channel8(const void* x, int xdt, int64_t rows, int64_t cols, in
     // workgroup between two barriers — 24576 x 1536: 33.7 (int8) / 44.1 us (fp8) against 23.2 / 25.7 with a wave per row, 16384 x 2048: 24.6 / 34.1 against
     // 21.2 / 23.9; from 3584 columns on the workgroup form wins (8192 x 3584: 19.2 / 21.4 against 34.5 / 22.5).  So: wave per row for rows of at most 2048
     // columns, and for asymmetric schemes up to 8192.
+    // (wave per row beyond 2048 columns stays behind the workgroup form with the 16-unit instantiation too: 14336 x 4096 36.4 against 32.8 us.  The 8-unit
+    // instantiation is not used: hipcc gives it 235-252 VGPRs — 91 for 16 units — which made rows of 2049-4096 columns 34.5 / 65 us instead of 19.9 / 36.4.)
     const bool want_wave = !symmetric || upr <= 256;
     if (want_wave && upr <= 64 * 16 && cdiv64(rows, kBlock / 64) < ((int64_t)1 << 31)) {  // rows of up to 8192 elements: one wave per row
         const int needw = (upr + 63) / 64;
         const unsigned gw = (unsigned)cdiv64(rows, kBlock / 64);
 #define CT_RW8(DT, MU, F8) hipLaunchKernelGGL((rtn_channel8_wave_kernel<DT, MU, F8>), dim3(gw), dim3(kBlock), 0, as_stream(stream), static_cast<const u32x4*>(x), rows, upr, \
                                               symmetric, static_cast<u32x2*>(out), scale_out, zp_out)
-#define CT_RW8_U(DT, F8) do { if (needw <= 2) CT_RW8(DT, 2, F8); else if (needw <= 4) CT_RW8(DT, 4, F8); else if (needw <= 8) CT_RW8(DT, 8, F8); else CT_RW8(DT, 16, F8); } while (0)
+#define CT_RW8_U(DT, F8) do { if (needw <= 2) CT_RW8(DT, 2, F8); else if (needw <= 4) CT_RW8(DT, 4, F8); else CT_RW8(DT, 16, F8); } while (0)
         if (xdt == CT_BF16) { if (fp8) CT_RW8_U(CT_BF16, true); else CT_RW8_U(CT_BF16, false); }
         else { if (fp8) CT_RW8_U(CT_F16, true); else CT_RW8_U(CT_F16, false); }
 #undef CT_RW8_U
