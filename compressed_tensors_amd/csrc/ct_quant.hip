@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void w4_unpack_dequant_f32_kernel(W4Params 
 // floats = two 16-byte accesses interleaved with its neighbour's: 88 / 68 / 123 us at 8192^2 for 335 / 335 / 537 MB).  Four such
 // quads per lane, a block apart, all loads first.
 enum { F32_Q = 0, F32_DQ = 1, F32_FQ = 2 };
-template <int MODE, bool HAS_ZP>
+template <int MODE, bool HAS_ZP, bool FP8 = false /* F32_DQ only: the codes are float8_e4m3fn values */>
 __global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, float qmin, float qmax, uint32_t xoff /* 0x80808080: codes stored + 128 (8-bit packed words) */) {
     constexpr int U = MODE == F32_DQ ? 8 : 4;  // dequantize loads only 4 bytes per quad: more of them in flight
     const int64_t quads = 2 * p.units;
@@ -532,7 +532,14 @@ __global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, 
         const float s = load_rt(p.scale, sdt, si);
         const float z = HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f;  // zp.to(float32): exact
         float v[4];
-        if constexpr (MODE == F32_DQ) {
+        if constexpr (MODE == F32_DQ && FP8) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 q01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c[i], false), q23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)c[i], true);  // x_q.to(float32): exact
+            const float q[4] = {q01.x, q01.y, q23.x, q23.y};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>(q[k], HAS_ZP, z, s);
+            stream_store16(static_cast<u32x4*>(p.out) + h, u32x4{f_bits(v[0]), f_bits(v[1]), f_bits(v[2]), f_bits(v[3])});
+        } else if constexpr (MODE == F32_DQ) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = dequant_core<CT_F32>((float)(int)(int8_t)((c[i] ^ xoff) >> (8 * k)), HAS_ZP, z, s);
             stream_store16(static_cast<u32x4*>(p.out) + h, u32x4{f_bits(v[0]), f_bits(v[1]), f_bits(v[2]), f_bits(v[3])});
@@ -557,7 +564,9 @@ __global__ __launch_bounds__(kBlock) void f32_quads_kernel(W4Params p, int sdt, 
 
 // fp32 -> int8 codes: a lane takes a whole unit (8 floats, two 16-byte loads, one 8-byte store) — the scale work is paid once per 8
 // elements and the store is twice as wide as in the quads form (68 -> see DESIGN 5.2 us at 8192^2)
-template <bool HAS_ZP>
+// FP8 = true: float32 -> float8_e4m3fn (FLOAT 8-bit, quant_args.py:463-486): the IEEE float32 quotient, the zero-point add, the clamp to +-448 and the
+// hardware's round-to-nearest-even conversion (exact on a clamped value; NaN stays NaN) — the any-layout kernel ran these shapes at 94-96 us for 8192^2
+template <bool HAS_ZP, bool FP8 = false>
 __global__ __launch_bounds__(kBlock) void f32_quant_units_kernel(W4Params p, int sdt, float qmin, float qmax) {
     constexpr int U = 2;
     const u32x4* in = static_cast<const u32x4*>(p.x);
@@ -579,8 +588,22 @@ __global__ __launch_bounds__(kBlock) void f32_quant_units_kernel(W4Params p, int
         const int64_t si = w4_scale_index(p, u);
         const float s = load_rt(p.scale, sdt, si);
         const float z = HAS_ZP ? load_rt(p.zp, p.zdt, si) : 0.0f;
-        const float rs = f32_fast_rcp(s);
         const uint32_t ws[8] = {a[i][0].x, a[i][0].y, a[i][0].z, a[i][0].w, a[i][1].x, a[i][1].y, a[i][1].z, a[i][1].w};
+        if constexpr (FP8) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                t[k] = bits_f(ws[k]) / s;
+                if (HAS_ZP) t[k] += z;  // kept for z == 0: a -0 quotient becomes +0, as upstream's `+=`
+                t[k] = clamp_nan(t[k], -448.0f, 448.0f);
+            }
+            int c0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], 0, false), c1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], 0, false);
+            c0 = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], c0, true);
+            c1 = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], c1, true);
+            stream_store8(out + u, u32x2{(uint32_t)c0, (uint32_t)c1});
+            continue;
+        }
+        const float rs = f32_fast_rcp(s);
         uint32_t lo = 0, hi = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1783,6 +1806,14 @@ static int quantize_impl(const void* x, int xdt, const void* scale, int sdt, con
         }
         return launch_f32_quads<F32_Q>(w, zp, sdt, p.qmin, p.qmax, stream, "ct_quantize[f32]");
     }
+    if (!gscale && fkind == 1 && xdt == CT_F32 && tdt == CT_F32 && odt == CT_F8E4M3 && is_float_dt(sdt) && f32_quads_ok(rows, cols, cdiv, col_group, x, out) &&
+        (reinterpret_cast<uintptr_t>(out) & 7u) == 0) {
+        W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        dim3 g(w4_grid(w.units, 2));
+        if (zp) hipLaunchKernelGGL((f32_quant_units_kernel<true, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, p.qmin, p.qmax);
+        else hipLaunchKernelGGL((f32_quant_units_kernel<false, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, p.qmin, p.qmax);
+        CT_LAUNCH_CHECK("ct_quantize[f32 -> fp8 units]");
+    }
     if (!gscale && fkind != 2 && (fkind ? odt == CT_F8E4M3 : odt == CT_I8) && q8_eligible(xdt, sdt, tdt, rows, cols, cdiv, col_group, x, out)) {
         W4Params w = make_w4(x, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         const bool shared = (cdiv % 16 == 0) || cdiv >= cols;
@@ -1914,6 +1945,13 @@ static int dequantize_impl(const void* xq, int qdt, const void* scale, int sdt, 
     if (!gscale && qdt == CT_I8 && sdt == CT_F32 && odt == CT_F32 && f32_quads_ok(rows, cols, cdiv, col_group, out, xq)) {
         W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
         return launch_f32_quads<F32_DQ>(w, zp, sdt, 0.0f, 0.0f, stream, "ct_dequantize[f32]");
+    }
+    if (!gscale && qdt == CT_F8E4M3 && sdt == CT_F32 && odt == CT_F32 && f32_quads_ok(rows, cols, cdiv, col_group, out, xq)) {
+        W4Params w = make_w4(xq, scale, zp, zdt, out, rows, cols, rdiv, cdiv, scale_cols);
+        dim3 g(w4_grid(2 * w.units, 8));
+        if (zp) hipLaunchKernelGGL((f32_quads_kernel<F32_DQ, true, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, 0.0f, 0.0f, 0u);
+        else hipLaunchKernelGGL((f32_quads_kernel<F32_DQ, false, true>), g, dim3(kBlock), 0, as_stream(stream), w, sdt, 0.0f, 0.0f, 0u);
+        CT_LAUNCH_CHECK("ct_dequantize[fp8 -> f32]");
     }
     if (!gscale && (qdt == CT_I8 || qdt == CT_F8E4M3) && !col_group && (sdt == CT_BF16 || sdt == CT_F16) && odt == sdt && rows > 0 && cols % 8 == 0 &&
         (cdiv % 8 == 0 || cdiv >= cols) && aligned16(out) && (reinterpret_cast<uintptr_t>(xq) & 7u) == 0) {

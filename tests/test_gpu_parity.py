@@ -2333,6 +2333,51 @@ def test_fp8_hardware_conversion_all_inputs(cta, dev, xdt):
         assert eq(got.cpu(), O.dequantize(codes, s, None))
 
 
+def test_fp8_of_float32_weights_flat_kernels(cta, dev):
+    """float32 weights -> float8_e4m3fn and back on the flat float32 kernels (f32_quant_units_kernel<.., FP8>, f32_quads_kernel<F32_DQ, .., FP8>): quotients that
+    sit exactly on a float8 rounding boundary (x = midpoint * s for scales with a short significand) and one / two ulps either side, the float8 subnormal
+    range, +-448 and beyond, inf / NaN / signed zeros / float32 subnormals, scales from 2^-110 to 2^110, float32 and bf16 scales, every strategy the flat
+    kernels take (tensor, channel, group, block), with no zero point, an all-zero one and a non-zero one; the dequantize side over every float8 code"""
+    g = torch.Generator().manual_seed(91)
+    rows, cols = 128, 1024
+    codes = torch.arange(256, dtype=torch.uint8).view(F8).float()
+    vals = codes[torch.isfinite(codes)].unique()
+    mids = (vals[:-1] + vals[1:]) / 2  # every rounding boundary of float8_e4m3fn (exact in float32)
+    pool = torch.cat([mids, vals, torch.tensor([448.0, -448.0, 464.0, -464.0, 447.99997, 2.0 ** -10, -(2.0 ** -10), 3 * 2.0 ** -10])])
+    scales = torch.tensor([0.125, 0.0390625, 3.0, 1.0 / 3.0, 0.1, 7.3e-5, 2.0 ** -90, 2.0 ** 90, 2.0 ** -110, 2.0 ** 110, 1e-3, 0.75, 5.0, 1.7, 2.0 ** -20, 9.5e4], dtype=F32)
+    s_row = scales[torch.arange(rows) % scales.numel()].reshape(rows, 1).clone()
+    x = (pool[torch.randint(0, pool.numel(), (rows, cols), generator=g)] * s_row).contiguous()
+    xb = x.view(torch.int32)
+    xb += torch.randint(-2, 3, (rows, cols), generator=g, dtype=torch.int32)
+    x[:, -32:] = torch.randn(rows, 32, generator=g) * s_row * 100
+    sp = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 3e38, -3e38, 1e-45, -1e-45, 1.17549435e-38, -1.17549435e-38], dtype=F32)
+    x[:, : sp.numel()] = sp
+    for sdt in (F32, BF16):
+        for strategy, shape, gs, block in (("channel", (rows, 1), None, None), ("tensor", (1,), None, None), ("group", (rows, cols // 128), 128, None),
+                                           ("block", (rows // 64, cols // 128), None, [64, 128])):
+            if strategy == "channel":
+                s = s_row.to(sdt)
+            elif strategy == "tensor":
+                s = torch.tensor([0.37], dtype=sdt)
+            elif strategy == "group":
+                s = s_row.expand(rows, cols // 128).contiguous().to(sdt)
+            else:
+                s = (torch.rand(shape, generator=g) * 3 + 0.01).to(sdt)
+            kw = dict(num_bits=8, strategy=strategy, group_size=gs, block_structure=block, qtype="float")
+            for z in (None, torch.zeros(s.shape, dtype=F8), (torch.randn(s.shape, generator=g) * 4).to(F8)):
+                got = cta.codec.quantize_tensor(d(x, dev), d(s, dev), d(z, dev), dtype=F8, **kw)
+                ref = O.quantize(x, s, z, dtype=F8, **kw)
+                assert eq_f8(got.cpu(), ref), (sdt, strategy, None if z is None else float(z.float().abs().max()))
+    allc = torch.arange(256, dtype=torch.uint8).repeat(rows * cols // 256).reshape(rows, cols).view(F8)
+    for strategy, s, gs, block in (("channel", s_row, None, None), ("group", (torch.rand((rows, cols // 128), generator=g) * 4 - 2), 128, None),
+                                   ("tensor", torch.tensor([-0.37]), None, None), ("block", torch.rand((rows // 64, cols // 128), generator=g) + 0.5, None, [64, 128])):
+        for z in (None, (torch.randn(s.shape, generator=g) * 4).to(F8)):
+            dkw = dict(strategy=strategy, group_size=gs, block_structure=block)
+            got = cta.codec.dequantize_tensor(d(allc, dev), d(s, dev), d(z, dev), **dkw)
+            ref = O.dequantize(allc, s, z, **dkw)
+            assert got.dtype == F32 and eq(got.cpu(), ref), (strategy, z is None)
+
+
 def test_fp8_quantize_of_fp16_weights_every_input_times_scales(cta, dev):
     """the packed-fp16 form of the FP8 quantize (f8_quant_words_f16: reciprocal + Newton step on pairs) and its per-unit precondition (finite, zero or a
     quotient of at least 2^-13): EVERY fp16 input against 96 channel scales — the ends of the fast range 2^-14 / 2^15 and just outside it, powers of two,
