@@ -716,6 +716,24 @@ def launch_w4_words(words: torch.Tensor, n: int, direction: str, dtype: torch.dt
     call("ct_quant_pack_batch" if d == 0 else "ct_unpack_dequant_batch", table.data_ptr(), n, blocks, DT[dtype], _lib.stream_on(device))
 
 
+_Q8_KINDS = ("int8", "fp8", "fp8z")
+
+
+def launch_q8_words(words: torch.Tensor, n: int, direction: str, dtype: torch.dtype, device: torch.device, kind: int, bits: int = 8) -> None:
+    """`launch_w4_words` for a table of the 8-bit codecs (`ct_q8_quant_batch` / `ct_q8_dequant_batch`); kind 0 int8, 1 fp8, 2 fp8 with float8 zero points"""
+    if not n:
+        return
+    d = 0 if direction == "compress" else 1
+    blocks = int(_lib.load().ct_q8_batch_plan(words.data_ptr(), n, d))
+    if blocks < 0:
+        raise ValueError(_lib.last_error())
+    table = _upload_table(words, device)
+    if d == 0:
+        call("ct_q8_quant_batch", table.data_ptr(), n, blocks, DT[dtype], kind, bits, _lib.stream_on(device))
+    else:
+        call("ct_q8_dequant_batch", table.data_ptr(), n, blocks, DT[dtype], kind, _lib.stream_on(device))
+
+
 def launch_zp4_words(words: torch.Tensor, n: int, direction: str, device: torch.device) -> None:
     """`zp4_batch` for a table that already exists as a flat CPU int64 tensor (src, 0, 0, dst, unpacked rows, cols, 0 ... per item;
     built by the C++ host loop): plan, upload, ONE `ct_zp4_pack_dim0_batch` launch on `device`'s current stream"""

@@ -17,6 +17,59 @@ from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor
 
 __all__ = ["NaiveQuantizationCompressor", "IntQuantizationCompressor", "FloatQuantizationCompressor"]
 
+_DTYPE_OF_CODE = {1: torch.float16, 2: torch.bfloat16}
+_STRATEGY_CODE = {"tensor": 0, "channel": 1, "group": 2}
+
+
+def _q8_compress_info(scheme) -> int:
+    """what the C++ host loop needs to know of a scheme (csrc/host/ct_hostpath.cpp, q8_plan_compress): group size, num_bits, FLOAT, strategy and the
+    zero points a symmetric scheme does not store — or -1 for a scheme whose modules stay with the Python loop"""
+    from ..base import symmetric_zp_keys
+
+    wa = getattr(scheme, "weights", None)
+    if wa is None:
+        return -1
+    qtype, st = enum_value(getattr(wa, "type", "int")), enum_value(wa.strategy)
+    bits = int(wa.num_bits)
+    if st not in _STRATEGY_CODE or qtype not in ("int", "float") or not 1 <= bits <= 8 or (qtype == "float" and bits != 8):
+        return -1
+    if enum_value(getattr(wa, "actorder", None)) == "group":
+        return -1
+    gs = int(getattr(wa, "group_size", None) or 0) if st == "group" else 0
+    if not 0 <= gs < (1 << 20):
+        return -1
+    drop = 0
+    for key in symmetric_zp_keys(scheme):
+        drop |= {"weight_zero_point": 1, "input_zero_point": 2, "output_zero_point": 4}[key]
+    return gs | (bits << 20) | ((qtype == "float") << 24) | (_STRATEGY_CODE[st] << 25) | (drop << 27)
+
+
+def _q8_decompress_info(scheme) -> int:
+    return 1 if getattr(scheme, "weights", None) is not None else 0
+
+
+def _native_q8(modules, direction: str, status):
+    """the plain modules of `modules` through the C++ host loop (table rows, output allocations, launches in windows, the parameter dictionaries under the
+    kernels); returns the modules it did not take.  None of it when the extension is not built or a global parameter-registration hook is installed."""
+    from ... import _lib
+    from ..pack_quantized.base import _launch_chunks
+
+    hp = _lib.hostpath()
+    if hp is None or not hasattr(hp, "q8_plan_compress") or torch.nn.modules.module._global_parameter_registration_hooks:
+        return modules
+    plan, info = (hp.q8_plan_compress, _q8_compress_info) if direction == "compress" else (hp.q8_plan_decompress, _q8_decompress_info)
+    rest, pending = [], []
+    for lo, hi in _launch_chunks(len(modules)):
+        planned, back = plan(modules[lo:hi], info)
+        rest += back
+        for (dev_index, code), (words, n, jobs, _zw, _zn) in planned.items():
+            device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
+            codec.launch_q8_words(words, n, direction, _DTYPE_OF_CODE[code & 15], device, (code >> 4) & 15, code >> 8)
+            pending.append(jobs)
+    for jobs in pending:
+        hp.q8_finish(jobs, status)
+    return rest
+
 
 @BaseCompressor.register(name=CompressionFormat.naive_quantized.value)
 class NaiveQuantizationCompressor(BaseCompressor):
@@ -165,6 +218,7 @@ class NaiveQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         if not cls._owns_codec():
             return super().compress_modules(modules)
+        modules = _native_q8(modules, "compress", QuantizationStatus.COMPRESSED)
         names = ("weight", "weight_scale", "weight_zero_point", "weight_g_idx")
         sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]  # the modules' own entries: no state-dict copies
         pre = cls._batch_compress(sds, [m.quantization_scheme for m in modules])
@@ -198,6 +252,7 @@ class NaiveQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         if not cls._owns_codec():
             return super().decompress_modules(modules)
+        modules = _native_q8(modules, "decompress", QuantizationStatus.DECOMPRESSED)
         names = ("weight", "weight_scale", "weight_zero_point", "weight_g_idx")
         sds = [{k: t for k in names if (t := direct_entry(m, k)) is not None} for m in modules]
         pre = cls._batch_decompress(sds)

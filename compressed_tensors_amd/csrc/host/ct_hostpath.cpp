@@ -414,6 +414,153 @@ void w4_finish_decompress(py::list jobs, py::object status) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 8-bit codecs (naive- / int- / float-quantized, reference compressors/naive_quantized/base.py:48-126): the same split — plan the table of
+// `ct_q8_quant_batch` / `ct_q8_dequant_batch` from the modules' own entries, launch, rewrite the dictionaries under the kernel.  Mirrors
+// NaiveQuantizationCompressor._batch_compress / _batch_decompress and codec.q8_batch_group (the Python loop: 7-9 us per module and direction, which a
+// 1B-parameter FP8 checkpoint's modules do not hide).
+// compress infos[i]: group_size (bits 0-19; 0 = none) | num_bits << 20 | FLOAT << 24 | strategy << 25 (0 tensor, 1 channel, 2 group) |
+//                    drop mask << 27 (bit 0 weight_zero_point, 1 input_zero_point, 2 output_zero_point: the zero points a symmetric scheme does not store), or < 0
+// batch key: (device index, dtype code | kind << 4 | num_bits << 8), kind 0 int8, 1 fp8, 2 fp8 with float8 zero points
+// ------------------------------------------------------------------------------------------
+PyObject* g_input_zero_point = nullptr;
+PyObject* g_output_zero_point = nullptr;
+
+// codec.q8_batch_group: elements per scale, or 0.  strategy < 0: inferred from the scale's shape (forward.py:99-130)
+int64_t q8_group(int64_t rows, int64_t cols, const at::Tensor& scale, const at::Tensor* zp, at::ScalarType wdt, const at::Device& dev, int strategy, int64_t group_size,
+                 bool f8z) {
+    if (!half_type(wdt) || scale.scalar_type() != wdt || scale.device() != dev || !scale.is_contiguous() || !aligned16(scale)) return 0;
+    if (rows <= 0 || cols % 16) return 0;
+    int64_t group = 0;
+    if (scale.numel() == 1 && scale.dim() <= 1 && (strategy < 0 || strategy == 0)) group = rows * cols;
+    else if (scale.dim() == 2 && scale.size(0) == rows && scale.size(1) == 1 && (strategy < 0 || strategy == 1)) group = cols;
+    else if (scale.dim() == 2 && scale.size(0) == rows && scale.size(1) > 1 && cols % scale.size(1) == 0 && (strategy < 0 || strategy == 2)) {
+        group = cols / scale.size(1);
+        if (strategy == 2 && group_size && group_size != group) return 0;
+    } else return 0;
+    if (group % 16) return 0;
+    if (zp && (zp->scalar_type() != (f8z ? at::kFloat8_e4m3fn : at::kChar) || zp->sizes() != scale.sizes() || zp->device() != dev || !zp->is_contiguous())) return 0;
+    return group;
+}
+
+py::tuple q8_plan_compress(py::list modules, py::object infos_arg) {
+    touch_tls();
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        const int64_t group_size = info & 0xfffff;
+        const int bits = (int)((info >> 20) & 15), strategy = (int)((info >> 25) & 3), dropmask = (int)((info >> 27) & 7);
+        const bool is_float = ((info >> 24) & 1) != 0;
+        Entries e;
+        bool ok = info >= 0 && plain_type(m) && e.open(m);
+        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
+        int64_t group = 0;
+        bool f8z = false;
+        if (ok) {
+            w = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            zp = e.tensor(N.weight_zero_point);
+            ok = w && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && w->dim() == 2 && (w->is_cuda() || g_allow_cpu) &&
+                 w->is_contiguous() && aligned16(*w) && bits >= 1 && bits <= 8 && (!is_float || bits == 8);
+        }
+        if (ok) {
+            f8z = is_float && zp && zp->scalar_type() == at::kFloat8_e4m3fn;
+            ok = !(is_float && zp && !f8z);
+            if (ok) group = q8_group(w->size(0), w->size(1), *scale, zp, w->scalar_type(), w->device(), strategy, group_size, f8z);
+            ok = ok && group > 0 &&
+                 staying_entries_are_final(e, {N.weight, (dropmask & 1) ? N.weight_zero_point : N.weight, (dropmask & 2) ? g_input_zero_point : N.weight,
+                                               (dropmask & 4) ? g_output_zero_point : N.weight});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        const int64_t rows = w->size(0), cols = w->size(1);
+        at::Tensor out = at::empty({rows, cols}, w->options().dtype(is_float ? at::kFloat8_e4m3fn : at::kChar));
+        const int kind = is_float ? (f8z ? 2 : 1) : 0;
+        Batch& b = batches[{w->is_cuda() ? (int)w->device().index() : -1, (w->scalar_type() == at::kHalf ? 1 : 2) | (kind << 4) | (bits << 8)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)out.data_ptr(), rows, cols, group, 0, 0, 0, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
+        // the job keeps the inputs alive until the launch has been issued (the table holds raw pointers)
+        PyObject* zp_obj = zp ? PyDict_GetItem(e.params, N.weight_zero_point) : Py_None;
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)), dropmask,
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)), py::reinterpret_borrow<py::object>(zp_obj)));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+// after the launch: the codes take the place of `weight` (same dictionary position, as swap_direct_entries), a symmetric scheme's zero points leave
+void q8_finish(py::list jobs, py::object status) {
+    touch_tls();
+    const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
+        PyObject* m = PyTuple_GET_ITEM(job, 0);
+        const at::Tensor& out = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));
+        const long dropmask = PyLong_AsLong(PyTuple_GET_ITEM(job, 2));
+        Entries e;
+        if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        if (dropmask & 1) drop(e.params, N.weight_zero_point);
+        if (dropmask & 2) drop(e.params, g_input_zero_point);
+        if (dropmask & 4) drop(e.params, g_output_zero_point);
+        PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
+        set_status(m, status.ptr());
+    }
+}
+
+// infos[i]: > 0 when the module's codec is the plain 8-bit one (the layout is read off the stored tensors, as `dequantize` does), else 0
+py::tuple q8_plan_decompress(py::list modules, py::object infos_arg) {
+    touch_tls();
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        Entries e;
+        bool ok = info > 0 && plain_type(m) && e.open(m);
+        const at::Tensor *q = nullptr, *scale = nullptr, *zp = nullptr;
+        int64_t group = 0;
+        int kind = -1;
+        if (ok) {
+            q = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            zp = e.tensor(N.weight_zero_point);
+            ok = q && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && q->dim() == 2 && (q->is_cuda() || g_allow_cpu) &&
+                 q->is_contiguous() && aligned16(*q);
+        }
+        if (ok) {
+            kind = q->scalar_type() == at::kChar ? 0 : q->scalar_type() == at::kFloat8_e4m3fn ? 1 : -1;
+            const bool f8z = kind == 1 && zp && zp->scalar_type() == at::kFloat8_e4m3fn;
+            ok = kind >= 0 && !(kind == 1 && zp && !f8z);
+            if (f8z) kind = 2;
+            if (ok) group = q8_group(q->size(0), q->size(1), *scale, zp, scale->scalar_type(), q->device(), -1, 0, f8z);
+            ok = ok && group > 0 && staying_entries_are_final(e, {N.weight});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        const int64_t rows = q->size(0), cols = q->size(1);
+        at::Tensor out = at::empty({rows, cols}, scale->options());
+        Batch& b = batches[{q->is_cuda() ? (int)q->device().index() : -1, (scale->scalar_type() == at::kHalf ? 1 : 2) | (kind << 4) | (8 << 8)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)q->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)out.data_ptr(), rows, cols, group, 0, 0, 0, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)), 0,
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)), py::none()));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
 // the quantized modules of a model in `named_modules(remove_duplicate=True)` order (pre-order over `_modules`, every module once):
 // model_compressor.py:152-164,191-195 with is_module_quantized (quantization/utils/helpers.py:229-250: a scheme with at least one of
 // weights / input_activations / output_activations).  300 modules cost the interpreter 0.3 ms per walk; here ~30 us.
@@ -935,6 +1082,11 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("w4_finish_compress", &w4_finish_compress);
     mod.def("w4_plan_decompress", &w4_plan_decompress);
     mod.def("w4_finish_decompress", &w4_finish_decompress);
+    g_input_zero_point = PyUnicode_InternFromString("input_zero_point");
+    g_output_zero_point = PyUnicode_InternFromString("output_zero_point");
+    mod.def("q8_plan_compress", &q8_plan_compress);
+    mod.def("q8_plan_decompress", &q8_plan_decompress);
+    mod.def("q8_finish", &q8_finish);
     mod.def("quantized_modules", &quantized_modules);
     mod.def("bind_abi", &bind_abi);
     mod.def("bitmask_compress", &bitmask_compress);

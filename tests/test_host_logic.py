@@ -881,6 +881,134 @@ def test_cpp_host_loop_matches_the_python_loop(cta, monkeypatch, variant):
         hp.set_allow_cpu(False)
 
 
+@pytest.mark.parametrize("variant", ["fp8", "fp8_zero_point", "fp8_static_input", "int8_channel", "int8_asymmetric_group", "int8_tensor", "int6", "trainable_scale",
+                                     "buffer_zp", "odd_class", "g_idx", "block", "float32"])
+def test_cpp_host_loop_of_the_8bit_codecs_matches_the_python_loop(cta, monkeypatch, variant):
+    """csrc/host/ct_hostpath.cpp q8_plan_compress / q8_plan_decompress / q8_finish (the per-module loop of NaiveQuantizationCompressor.compress_modules /
+    decompress_modules and its Int / Float subclasses in C++) against the Python loop, on CPU tensors with the launches stubbed out: the same table rows
+    (shapes, elements per scale, zero point present), kinds and bit widths reach the launches, the same modules are handed back, and every module is left in
+    the same state (names, order, kinds, trainability, shapes, dtypes, status) — incl. the zero points a symmetric scheme drops (weight and input)"""
+    import copy
+
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.compressors.naive_quantized import base as nq
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+
+    hp = ctlib.hostpath()
+    assert hp is not None and hasattr(hp, "q8_plan_compress"), "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    F8 = torch.float8_e4m3fn
+    wdt = torch.float32 if variant == "float32" else torch.bfloat16
+    ia = None
+    if variant.startswith("fp8") or variant in ("trainable_scale", "buffer_zp", "odd_class", "g_idx", "float32"):
+        wa = cta.QuantizationArgs(num_bits=8, type="float", strategy="channel", symmetric=True)
+        if variant == "fp8_static_input":
+            ia = cta.QuantizationArgs(num_bits=8, type="float", strategy="tensor", symmetric=True)
+    elif variant == "block":
+        wa = cta.QuantizationArgs(num_bits=8, type="float", strategy="block", block_structure=[16, 128], symmetric=True)
+    elif variant == "int8_channel":
+        wa = cta.QuantizationArgs(num_bits=8, type="int", strategy="channel", symmetric=True)
+    elif variant == "int8_asymmetric_group":
+        wa = cta.QuantizationArgs(num_bits=8, type="int", strategy="group", group_size=128, symmetric=False)
+    elif variant == "int8_tensor":
+        wa = cta.QuantizationArgs(num_bits=8, type="int", strategy="tensor", symmetric=True)
+    else:
+        wa = cta.QuantizationArgs(num_bits=6, type="int", strategy="channel", symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=ia)
+    st = wa.strategy if isinstance(wa.strategy, str) else wa.strategy.value
+    is_float = (wa.type if isinstance(wa.type, str) else wa.type.value) == "float"
+    with_zp = variant != "fp8"  # the calibrated flow attaches a zero point (float8 for FLOAT schemes); "fp8": none at all
+
+    class Odd(torch.nn.Linear):
+        def __setattr__(self, name, value):
+            super().__setattr__(name, value)
+
+    def tree():
+        root = torch.nn.Module()
+        root.blocks = torch.nn.ModuleList()
+        for k, (r, c) in enumerate([(64, 256), (32, 512), (96, 128), (64, 384), (16, 256)]):
+            lin = (Odd if variant == "odd_class" and k == 1 else torch.nn.Linear)(c, r, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=wdt), requires_grad=True)
+            sshape = {"tensor": (1,), "channel": (r, 1), "group": (r, c // 128), "block": (r // 16, c // 128)}[st]
+            lin.weight_scale = torch.nn.Parameter(torch.ones(sshape, dtype=wdt), requires_grad=variant == "trainable_scale" and k == 2)
+            if with_zp:
+                zp = torch.zeros(sshape, dtype=F8 if is_float else torch.int8)
+                if variant == "buffer_zp" and k == 0:
+                    lin.register_buffer("weight_zero_point", zp)
+                else:
+                    lin.weight_zero_point = torch.nn.Parameter(zp, requires_grad=False)
+            if ia is not None:
+                lin.input_scale = torch.nn.Parameter(torch.ones(1, dtype=wdt), requires_grad=False)
+                lin.input_zero_point = torch.nn.Parameter(torch.zeros(1, dtype=F8), requires_grad=False)
+            if variant == "g_idx" and k == 3:
+                lin.weight_g_idx = torch.nn.Parameter(torch.arange(c, dtype=torch.int32) // 128, requires_grad=False)
+            lin.quantization_scheme = scheme
+            root.blocks.append(lin)
+        return root
+
+    a, b = tree(), tree()
+    tables = {"cpp": [], "py": []}
+    which = {"now": "cpp"}
+    KIND = {"int8": 0, "fp8": 1, "fp8z": 2}
+
+    def fake_words(words, n, direction, dtype, device, kind, bits=8):
+        rows = [r[4:7] + [bool(r[2])] for r in words.reshape(n, codec._ITEM_WORDS).tolist()]
+        tables[which["now"]].append((direction, dtype, kind, bits if direction == "compress" else 8, rows))
+        native[direction] += n
+
+    class FakeBatch:
+        def __init__(self, entries, direction, dtype, kind="w4", bits=8):
+            self.rec = (direction, dtype, KIND[kind], int(bits) if direction == "compress" else 8, [[int(e[4]), int(e[5]), int(e[6]), e[2] is not None] for e in entries])
+
+        def launch(self, stream=None):
+            if self.rec[4]:
+                tables[which["now"]].append(self.rec)
+
+    singles = {"cpp": 0, "py": 0}
+    native = {"compress": 0, "decompress": 0}  # modules whose table rows the C++ loop wrote
+
+    def fake_quantize(w, scale, zp, **kw):
+        singles[which["now"]] += 1
+        return torch.zeros(w.shape, dtype=kw["dtype"])
+
+    def fake_dequantize(q, scale, zp, **kw):
+        singles[which["now"]] += 1
+        return torch.zeros(q.shape, dtype=scale.dtype)
+
+    monkeypatch.setattr(codec, "launch_q8_words", fake_words)
+    monkeypatch.setattr(codec, "W4Batch", FakeBatch)
+    monkeypatch.setattr(codec, "quantize_tensor", fake_quantize)
+    monkeypatch.setattr(codec, "dequantize_tensor", fake_dequantize)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    hp.set_allow_cpu(True)
+    try:
+        mods_a, mods_b = list(a.blocks), list(b.blocks)
+        klass = nq.FloatQuantizationCompressor if is_float else nq.IntQuantizationCompressor
+        for direction, status in (("compress", QuantizationStatus.COMPRESSED), ("decompress", QuantizationStatus.DECOMPRESSED)):
+            which["now"] = "cpp"
+            getattr(klass, direction + "_modules")(mods_a)
+            which["now"] = "py"
+            monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
+            getattr(klass, direction + "_modules")(mods_b)
+            monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
+            for x, y in zip(mods_a, mods_b):
+                assert _module_state_no_ptr(x) == _module_state_no_ptr(y), (variant, direction)
+                assert x.quantization_status == status == y.quantization_status
+                assert x.weight.dtype == ((F8 if is_float else torch.int8) if direction == "compress" else wdt)
+                assert ("weight_zero_point" in x._parameters) == (with_zp and not wa.symmetric)
+                assert "input_zero_point" not in x._parameters
+            flat = lambda ts: sorted((t[0], t[1], t[2], t[3], tuple(r)) for t in ts if t[0] == direction for r in t[4])
+            assert flat(tables["cpp"]) == flat(tables["py"]), (variant, direction)
+            assert singles["cpp"] == singles["py"]
+            # the C++ loop took the plain modules itself; a module with a trainable entry that stays, a buffer, a class with its own __setattr__, activation
+            # ordering, a block layout or float32 weights went back to the Python loop
+            expect_native = {"trainable_scale": 4 if direction == "compress" else 5, "buffer_zp": 4 if direction == "compress" else 5, "odd_class": 4, "g_idx": 4, "block": 0, "float32": 0,
+                             "int8_asymmetric_group": 4 if direction == "compress" else 5}.get(variant, 5)  # (96 x 128 in groups of 128: a (96, 1) scale)
+            assert native[direction] == expect_native, (variant, direction, native)
+    finally:
+        hp.set_allow_cpu(False)
+
+
 def _module_state_no_ptr(m):
     return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
             [(k, None if v is None else (type(v).__name__, tuple(v.shape))) for k, v in m._buffers.items()])
