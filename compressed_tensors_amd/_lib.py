@@ -344,6 +344,8 @@ def hostpath():
             except (OSError, AttributeError):
                 pass  # the marlin-24 default mode then waits through ct_stream_wait
             hp.bind_abi(abi)
+            if hasattr(hp, "bind_fp4"):  # the FP4 module loops launch these two by address
+                hp.bind_fp4(ctypes.cast(lib["ct_fp4_quant_pack_stored"], ctypes.c_void_p).value, ctypes.cast(lib["ct_fp4_unpack_dequant_scale"], ctypes.c_void_p).value)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
 

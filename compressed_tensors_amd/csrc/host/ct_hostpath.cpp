@@ -1043,6 +1043,142 @@ int dtype_code(at::ScalarType t) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// FP4 codecs (nvfp4-pack-quantized, group 16 under a global scale; mxfp4-pack-quantized, group 32; reference compressors/nvfp4/base.py:68-139,
+// mxfp4/base.py:27-65): NVFP4PackedCompressor.compress_modules / decompress_modules in C++.  One launch per module (`ct_fp4_quant_pack_stored` /
+// `ct_fp4_unpack_dequant_scale`, called by address on `stream` of device `device_index`, which the caller has made current) and the dictionary delta of
+// swap_direct_entries: weight, weight_scale (and a symmetric scheme's zero points) leave, weight_packed and the stored weight_scale arrive — resp. the
+// other way round.  The interpreter spent 14 us per module and direction on this (a TinyLlama-shaped NVFP4 tree ran at 0.13 of the HBM peak).  Modules
+// outside the plain case, or on another device, come back in the returned list for the Python loop.
+// compress infos[i]: 1 | drop mask << 1 (weight / input / output zero point of a symmetric scheme) when the scheme stores its scale in the format's usual
+// dtype and is symmetric or carries no zero point; else 0
+// ------------------------------------------------------------------------------------------
+using fp4_compress_fn = int (*)(const void*, int, const void*, int, const float*, int64_t, int64_t, int64_t, uint8_t*, uint8_t*, const uint8_t*, void*);
+using fp4_decompress_fn = int (*)(const uint8_t*, int64_t, int64_t, const void*, int, int, const float*, int64_t, void*, int, void*, void*);
+fp4_compress_fn g_fp4_compress = nullptr;
+fp4_decompress_fn g_fp4_decompress = nullptr;
+PyObject *g_weight_global_scale = nullptr;
+
+void bind_fp4(uintptr_t compress, uintptr_t decompress) {
+    g_fp4_compress = reinterpret_cast<fp4_compress_fn>(compress);
+    g_fp4_decompress = reinterpret_cast<fp4_decompress_fn>(decompress);
+}
+
+inline bool on_dev(const at::Tensor& t, int device_index) { return (t.is_cuda() && t.device().index() == device_index) || (g_allow_cpu && t.is_cpu()); }
+
+// the global scale as the kernel takes it: one float32 on the device (codec._gs_fast's no-op case)
+inline bool plain_gs(const at::Tensor& g, int device_index) {
+    return g.scalar_type() == at::kFloat && g.numel() == 1 && on_dev(g, device_index) && (reinterpret_cast<uintptr_t>(g.data_ptr()) & 3u) == 0;
+}
+
+py::list fp4_compress_modules(py::list modules, py::object infos_arg, int64_t group, int device_index, uintptr_t stream, uintptr_t lut_f16, uintptr_t lut_bf16,
+                              py::object status) {
+    touch_tls();
+    if (!g_fp4_compress) throw std::runtime_error("fp4_compress_modules: bind_fp4 has not been called");
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        const int dropmask = (int)((info >> 1) & 7);
+        Entries e;
+        bool ok = info > 0 && (info & 1) && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed);
+        const at::Tensor *w = nullptr, *scale = nullptr, *gs = nullptr;
+        if (ok) {
+            w = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            gs = e.tensor(g_weight_global_scale);
+            // (a zero point entry: dropped below for a symmetric scheme; present under an asymmetric one the Python path raises)
+            ok = w && scale && (gs != nullptr) == (group == 16) && (gs != nullptr || !e.has(g_weight_global_scale)) && !e.has(N.weight_packed) && w->dim() == 2 &&
+                 half_type(w->scalar_type()) && on_dev(*w, device_index) && w->is_contiguous() && aligned16(*w) && on_dev(*scale, device_index) &&
+                 scale->is_contiguous() && (reinterpret_cast<uintptr_t>(scale->data_ptr()) & 7u) == 0 &&
+                 (half_type(scale->scalar_type()) || (group == 16 && scale->scalar_type() == at::kFloat)) && (!gs || plain_gs(*gs, device_index)) &&
+                 (e.tensor(N.weight_zero_point) == nullptr || (dropmask & 1));
+        }
+        int64_t rows = 0, cols = 0;
+        if (ok) {
+            rows = w->size(0);
+            cols = w->size(1);
+            ok = rows > 0 && cols % group == 0 && (rows * cols) % 32 == 0 && scale->dim() == 2 && scale->size(0) == rows && scale->size(1) == cols / group &&
+                 staying_entries_are_final(e, {N.weight, N.weight_scale, (dropmask & 1) ? N.weight_zero_point : N.weight, (dropmask & 2) ? g_input_zero_point : N.weight,
+                                               (dropmask & 4) ? g_output_zero_point : N.weight});
+        }
+        const uintptr_t lut = group == 32 && ok ? (scale->scalar_type() == at::kHalf ? lut_f16 : lut_bf16) : 0;
+        if (ok && group == 32 && !lut) ok = false;
+        if (ok) {
+            at::Tensor packed = at::empty({rows, cols / 2}, w->options().dtype(at::kByte));
+            at::Tensor stored = at::empty({rows, cols / group}, w->options().dtype(group == 16 ? at::kFloat8_e4m3fn : at::kByte));
+            const int rc = g_allow_cpu && w->is_cpu() ? 0
+                                                      : g_fp4_compress(w->data_ptr(), dtype_code(w->scalar_type()), scale->data_ptr(), dtype_code(scale->scalar_type()),
+                                                                       gs ? static_cast<const float*>(gs->data_ptr()) : nullptr, rows, cols, group,
+                                                                       static_cast<uint8_t*>(packed.data_ptr()), static_cast<uint8_t*>(stored.data_ptr()),
+                                                                       reinterpret_cast<const uint8_t*>(lut), reinterpret_cast<void*>(stream));
+            if (rc == 0) {
+                drop(e.params, N.weight);
+                drop(e.params, N.weight_scale);
+                if (dropmask & 1) drop(e.params, N.weight_zero_point);
+                if (dropmask & 2) drop(e.params, g_input_zero_point);
+                if (dropmask & 4) drop(e.params, g_output_zero_point);
+                PyDict_SetItem(e.params, N.weight_packed, make_parameter(packed).ptr());
+                PyDict_SetItem(e.params, N.weight_scale, make_parameter(stored).ptr());
+                set_status(m, status.ptr());
+                continue;
+            }
+        }
+        rest.append(py::reinterpret_borrow<py::object>(m));  // (a refused launch too: the Python path repeats it and reports the library's message)
+    }
+    return rest;
+}
+
+py::list fp4_decompress_modules(py::list modules, int64_t group, int device_index, uintptr_t stream, py::object status) {
+    touch_tls();
+    if (!g_fp4_decompress) throw std::runtime_error("fp4_decompress_modules: bind_fp4 has not been called");
+    py::list rest;
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        Entries e;
+        bool ok = plain_type(m) && e.open(m) && !dict_has(m, N.weight);
+        const at::Tensor *packed = nullptr, *scale = nullptr, *gs = nullptr;
+        if (ok) {
+            packed = e.tensor(N.weight_packed);
+            scale = e.tensor(N.weight_scale);
+            gs = e.tensor(g_weight_global_scale);
+            ok = packed && scale && (gs != nullptr) == (group == 16) && (gs != nullptr || !e.has(g_weight_global_scale)) && !e.has(N.weight) &&
+                 packed->scalar_type() == at::kByte && packed->dim() == 2 && on_dev(*packed, device_index) && packed->is_contiguous() &&
+                 (reinterpret_cast<uintptr_t>(packed->data_ptr()) & 3u) == 0 && on_dev(*scale, device_index) && scale->is_contiguous() &&
+                 scale->scalar_type() == (group == 16 ? at::kFloat8_e4m3fn : at::kByte) && (!gs || plain_gs(*gs, device_index));
+        }
+        int64_t rows = 0, cols = 0;
+        if (ok) {
+            rows = packed->size(0);
+            cols = packed->size(1) * 2;
+            ok = rows > 0 && cols > 0 && cols % group == 0 && scale->dim() == 2 && scale->size(0) == rows && scale->size(1) == cols / group &&
+                 staying_entries_are_final(e, {N.weight_packed, N.weight_scale});
+        }
+        if (ok) {
+            at::Tensor out = at::empty({rows, cols}, packed->options().dtype(at::kBFloat16));  // unpack_fp4_from_uint8's default dtype (nvfp4/base.py:118-131)
+            at::Tensor sout = at::empty({rows, cols / group}, packed->options().dtype(at::kBFloat16));
+            const int rc = g_allow_cpu && packed->is_cpu()
+                               ? 0
+                               : g_fp4_decompress(static_cast<const uint8_t*>(packed->data_ptr()), rows, cols, scale->data_ptr(), group == 16 ? 1 : 2, -1,
+                                                  gs ? static_cast<const float*>(gs->data_ptr()) : nullptr, group, out.data_ptr(), dtype_code(at::kBFloat16),
+                                                  sout.data_ptr(), reinterpret_cast<void*>(stream));
+            if (rc == 0) {
+                drop(e.params, N.weight_packed);
+                drop(e.params, N.weight_scale);
+                PyDict_SetItem(e.params, N.weight_scale, make_parameter(sout).ptr());
+                PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
+                set_status(m, status.ptr());
+                continue;
+            }
+        }
+        rest.append(py::reinterpret_borrow<py::object>(m));
+    }
+    return rest;
+}
+
 // Marlin24Compressor.compress for an int4 scheme outside a deferred-check context, from the popped state-dict entries on: the layout tests
 // of the one-launch path (compressors/sparse/marlin_24.py, same conditions), then marlin24_w4_full.  `group_size`: the scheme's, 0 for a
 // channel-wise scheme, negative for a group scheme without a group size.  None when the tensors are not the one-launch case: the Python path takes the call.
@@ -1084,6 +1220,10 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("w4_finish_decompress", &w4_finish_decompress);
     g_input_zero_point = PyUnicode_InternFromString("input_zero_point");
     g_output_zero_point = PyUnicode_InternFromString("output_zero_point");
+    g_weight_global_scale = PyUnicode_InternFromString("weight_global_scale");
+    mod.def("bind_fp4", &bind_fp4);
+    mod.def("fp4_compress_modules", &fp4_compress_modules);
+    mod.def("fp4_decompress_modules", &fp4_decompress_modules);
     mod.def("q8_plan_compress", &q8_plan_compress);
     mod.def("q8_plan_decompress", &q8_plan_decompress);
     mod.def("q8_finish", &q8_finish);

@@ -1009,6 +1009,108 @@ def test_cpp_host_loop_of_the_8bit_codecs_matches_the_python_loop(cta, monkeypat
         hp.set_allow_cpu(False)
 
 
+@pytest.mark.parametrize("fmt", ["nvfp4", "mxfp4"])
+@pytest.mark.parametrize("variant", ["plain", "zero_point", "static_input", "trainable_scale", "buffer_zp", "odd_class", "f32_scale", "odd_global_scale", "other_scale_dtype"])
+def test_cpp_host_loop_of_the_fp4_codecs_matches_the_python_loop(cta, monkeypatch, fmt, variant):
+    """csrc/host/ct_hostpath.cpp fp4_compress_modules / fp4_decompress_modules against the Python loops of NVFP4PackedCompressor / MXFP4PackedCompressor on CPU
+    tensors (the launch itself skipped / stubbed): the same modules taken, every module left in the same state — names, ORDER, kinds, trainability, shapes,
+    dtypes, status — incl. the zero points a symmetric scheme drops"""
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.compressors.fp4 import base as fp4
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+
+    hp = ctlib.hostpath()
+    assert hp is not None and hasattr(hp, "fp4_compress_modules"), "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    F8 = torch.float8_e4m3fn
+    group = 16 if fmt == "nvfp4" else 32
+    if fmt == "mxfp4" and variant in ("f32_scale", "odd_global_scale"):
+        pytest.skip("NVFP4 only")
+    want = F8 if group == 16 else torch.uint8
+    sdt = (torch.uint8 if group == 16 else F8) if variant == "other_scale_dtype" else want
+    wa = (cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=sdt) if group == 16
+          else cta.QuantizationArgs(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=sdt))
+    ia = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor", symmetric=True) if variant == "static_input" else None
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=ia)
+    klass = fp4.NVFP4PackedCompressor if group == 16 else fp4.MXFP4PackedCompressor
+
+    class Odd(torch.nn.Linear):
+        def __setattr__(self, name, value):
+            super().__setattr__(name, value)
+
+    def tree():
+        mods = []
+        for k, (r, c) in enumerate([(64, 256), (32, 512), (96, 128), (8, 64)]):
+            lin = (Odd if variant == "odd_class" and k == 1 else torch.nn.Linear)(c, r, bias=True, device="meta")
+            lin.bias = torch.nn.Parameter(torch.zeros(r, dtype=torch.bfloat16), requires_grad=False)
+            lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=torch.bfloat16), requires_grad=True)
+            lin.weight_scale = torch.nn.Parameter(torch.ones(r, c // group, dtype=torch.float32 if variant == "f32_scale" else torch.bfloat16),
+                                                  requires_grad=variant == "trainable_scale" and k == 2)
+            if group == 16:
+                lin.weight_global_scale = torch.nn.Parameter(torch.ones(1, dtype=torch.float64 if variant == "odd_global_scale" and k == 0 else torch.float32), requires_grad=False)
+            if variant in ("zero_point", "buffer_zp"):
+                zp = torch.zeros(r, c // group, dtype=F8)
+                if variant == "buffer_zp" and k == 0:
+                    lin.register_buffer("weight_zero_point", zp)
+                else:
+                    lin.weight_zero_point = torch.nn.Parameter(zp, requires_grad=False)
+            if ia is not None:
+                lin.input_global_scale = torch.nn.Parameter(torch.ones(1), requires_grad=False)
+                lin.input_zero_point = torch.nn.Parameter(torch.zeros(1, dtype=F8), requires_grad=False)
+            lin.quantization_scheme = scheme
+            mods.append(lin)
+        return mods
+
+    calls = {"stored": 0, "plain": 0, "unpack": 0}
+
+    def fake_stored(weight, scale, gs, *, group_size, scale_dtype):
+        if scale_dtype is not want or (group_size == 32 and scale.dtype is torch.float32):
+            return None
+        calls["stored"] += 1
+        return torch.zeros(weight.shape[0], weight.shape[1] // 2, dtype=torch.uint8), torch.zeros(scale.shape, dtype=want)
+
+    def fake_pack(weight, scale, gs, *, group_size):
+        calls["plain"] += 1
+        return torch.zeros(weight.shape[0], weight.shape[1] // 2, dtype=torch.uint8)
+
+    def fake_unpack(packed, scale, gs, *, group_size, scale_kind="plain", dtype=torch.bfloat16, return_scale=False):
+        calls["unpack"] += 1
+        w = torch.zeros(packed.shape[0], packed.shape[1] * 2, dtype=dtype)
+        return (w, torch.zeros(scale.shape, dtype=torch.bfloat16)) if return_scale else w
+
+    monkeypatch.setattr(codec, "fp4_quantize_and_pack_stored", fake_stored)
+    monkeypatch.setattr(codec, "fp4_quantize_and_pack", fake_pack)
+    monkeypatch.setattr(codec, "fp4_unpack_and_dequantize", fake_unpack)
+    monkeypatch.setattr(codec, "compress_mx_scale", lambda scale, dtype: torch.zeros(scale.shape, dtype=dtype))
+    monkeypatch.setattr(codec, "_mx_code_table", lambda dt, dev: torch.zeros(65536, dtype=torch.uint8))
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(ctlib, "stream_on", lambda device, handle=None: 0)
+    hp.set_allow_cpu(True)
+    try:
+        a, b = tree(), tree()
+        for direction, status in (("compress", QuantizationStatus.COMPRESSED), ("decompress", QuantizationStatus.DECOMPRESSED)):
+            before = dict(calls)
+            getattr(klass, direction + "_modules")(a)
+            python_calls_with_cpp = sum(calls.values()) - sum(before.values())
+            monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
+            getattr(klass, direction + "_modules")(b)
+            monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
+            for x, y in zip(a, b):
+                assert _module_state_no_ptr(x) == _module_state_no_ptr(y), (fmt, variant, direction)
+                assert x.quantization_status == status == y.quantization_status
+                assert "input_zero_point" not in x._parameters and "weight_zero_point" not in x._parameters
+            # modules the C++ loop left to the Python loop (each makes one codec call there)
+            left = {"trainable_scale": 0, "buffer_zp": 1 if direction == "compress" else 0, "odd_class": 1,
+                    "odd_global_scale": 1, "other_scale_dtype": 4}.get(variant, 0)
+            if variant == "other_scale_dtype" and direction == "decompress":
+                left = 4  # a stored scale of another dtype is not this format's byte layout
+            assert python_calls_with_cpp == left, (fmt, variant, direction, python_calls_with_cpp)
+    finally:
+        hp.set_allow_cpu(False)
+
+
 def _module_state_no_ptr(m):
     return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
             [(k, None if v is None else (type(v).__name__, tuple(v.shape))) for k, v in m._buffers.items()])
