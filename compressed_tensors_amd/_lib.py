@@ -79,6 +79,9 @@ _PROTOTYPES = {
     "ct_fp4_unpack_dequant": ([_P, _L, _L, _P, _I, _I, _P, _L, _P, _I, _S], _I),
     "ct_fp4_quant_pack_stored": ([_P, _I, _P, _I, _P, _L, _L, _L, _P, _P, _P, _S], _I),
     "ct_fp4_unpack_dequant_scale": ([_P, _L, _L, _P, _I, _I, _P, _L, _P, _I, _P, _S], _I),
+    "ct_fp4_batch_plan": ([_P, _I, _I], _L),
+    "ct_fp4_quant_pack_batch": ([_P, _I, _L, _I, _I, _I, _P, _S], _I),
+    "ct_fp4_unpack_dequant_batch": ([_P, _I, _L, _I, _I, _S], _I),
     "ct_mx_scale_compress": ([_P, _I, _L, _P, _P, _S], _I),
     "ct_mx_scale_decompress": ([_P, _L, _P, _S], _I),
     "ct_rtn_mxfp4_quant_pack": ([_P, _I, _L, _L, _P, _P, _P, _S], _I),
@@ -344,8 +347,6 @@ def hostpath():
             except (OSError, AttributeError):
                 pass  # the marlin-24 default mode then waits through ct_stream_wait
             hp.bind_abi(abi)
-            if hasattr(hp, "bind_fp4"):  # the FP4 module loops launch these two by address
-                hp.bind_fp4(ctypes.cast(lib["ct_fp4_quant_pack_stored"], ctypes.c_void_p).value, ctypes.cast(lib["ct_fp4_unpack_dequant_scale"], ctypes.c_void_p).value)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
 

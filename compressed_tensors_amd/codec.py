@@ -734,6 +734,23 @@ def launch_q8_words(words: torch.Tensor, n: int, direction: str, dtype: torch.dt
         call("ct_q8_dequant_batch", table.data_ptr(), n, blocks, DT[dtype], kind, _lib.stream_on(device))
 
 
+def launch_fp4_words(words: torch.Tensor, n: int, direction: str, device: torch.device, group: int, x_dtype=None, scale_dtype=None) -> None:
+    """`launch_w4_words` for a table of FP4 tensors (`ct_fp4_quant_pack_batch` / `ct_fp4_unpack_dequant_batch`): group 16 = NVFP4 (every item carries its global
+    scale), 32 = MXFP4; compress: the weights' and the float scales' dtype (one per table); decompress writes bfloat16"""
+    if not n:
+        return
+    d = 0 if direction == "compress" else 1
+    blocks = int(_lib.load().ct_fp4_batch_plan(words.data_ptr(), n, d))
+    if blocks < 0:
+        raise ValueError(_lib.last_error())
+    table = _upload_table(words, device)
+    if d == 0:
+        lut = _mx_code_table(scale_dtype, device) if group == 32 else None
+        call("ct_fp4_quant_pack_batch", table.data_ptr(), n, blocks, DT[x_dtype], DT[scale_dtype], int(group), ptr(lut), _lib.stream_on(device))
+    else:
+        call("ct_fp4_unpack_dequant_batch", table.data_ptr(), n, blocks, int(group), DT[torch.bfloat16], _lib.stream_on(device))
+
+
 def launch_zp4_words(words: torch.Tensor, n: int, direction: str, device: torch.device) -> None:
     """`zp4_batch` for a table that already exists as a flat CPU int64 tensor (src, 0, 0, dst, unpacked rows, cols, 0 ... per item;
     built by the C++ host loop): plan, upload, ONE `ct_zp4_pack_dim0_batch` launch on `device`'s current stream"""

@@ -77,19 +77,16 @@ class NVFP4PackedCompressor(BaseCompressor):
     # everything else to the generic path.
     @classmethod
     def _native(cls, modules, direction: str):
-        """the plain modules on the current GPU through the C++ loop (csrc/host/ct_hostpath.cpp: fp4_compress_modules / fp4_decompress_modules — the same
-        launch and the same dictionary delta as below at ~4 instead of 14 us of host work per module); returns the modules it left for the loop below"""
+        """the plain modules through the C++ loop (csrc/host/ct_hostpath.cpp: fp4_plan_compress / fp4_plan_decompress / fp4_finish) and ONE table launch per
+        window (`ct_fp4_quant_pack_batch` / `ct_fp4_unpack_dequant_batch`) — the same results and the same dictionary delta as the loop below at ~3 instead of
+        14 us of host work per module and without a launch per module; returns the modules it left for that loop"""
         from ... import _lib
+        from ..pack_quantized.base import _launch_chunks
 
         modules = list(modules)
         hp = _lib.hostpath()
-        if (hp is None or not hasattr(hp, "fp4_compress_modules") or not torch.cuda.is_available() or torch.nn.modules.module._global_parameter_registration_hooks
-                or cls._native_group() is None):
+        if hp is None or not hasattr(hp, "fp4_plan_compress") or torch.nn.modules.module._global_parameter_registration_hooks or cls._native_group() is None:
             return modules
-        dev = torch.device("cuda", torch.cuda.current_device())
-        stream = _lib.stream_on(dev)
-        if direction == "decompress":
-            return hp.fp4_decompress_modules(modules, cls.GROUP, dev.index, int(stream), QuantizationStatus.DECOMPRESSED)
         want = torch.float8_e4m3fn if cls.GROUP == 16 else torch.uint8
 
         def info(scheme) -> int:
@@ -101,9 +98,20 @@ class NVFP4PackedCompressor(BaseCompressor):
                 drop |= {"weight_zero_point": 1, "input_zero_point": 2, "output_zero_point": 4}[key]
             return 1 | (drop << 1)
 
-        luts = [codec._mx_code_table(dt, dev) for dt in (torch.float16, torch.bfloat16)] if cls.GROUP == 32 else None
-        return hp.fp4_compress_modules(modules, info, cls.GROUP, dev.index, int(stream), luts[0].data_ptr() if luts else 0, luts[1].data_ptr() if luts else 0,
-                                       QuantizationStatus.COMPRESSED)
+        compress = direction == "compress"
+        status = QuantizationStatus.COMPRESSED if compress else QuantizationStatus.DECOMPRESSED
+        codes = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}
+        rest, pending = [], []
+        for lo, hi in _launch_chunks(len(modules)):
+            planned, back = hp.fp4_plan_compress(modules[lo:hi], info, cls.GROUP) if compress else hp.fp4_plan_decompress(modules[lo:hi], cls.GROUP)
+            rest += back
+            for (dev_index, code), (words, n, jobs, _zw, _zn) in planned.items():
+                device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
+                codec.launch_fp4_words(words, n, direction, device, cls.GROUP, codes[code & 15], codes[code >> 4])
+                pending.append(jobs)
+        for jobs in pending:
+            hp.fp4_finish(jobs, status, compress)
+        return rest
 
     @classmethod
     def _native_group(cls):

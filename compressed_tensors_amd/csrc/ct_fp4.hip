@@ -190,11 +190,8 @@ __device__ __forceinline__ uint32_t f32_to_fp8_as_torch(float v) {
 // compress_mx_scale (mx_utils.py:18-31: 127 + floor(log2(scale)) through int32 to uint8, log2 in the scale's dtype), read from a 65536-entry table
 // that the host builds by running that very expression over every 16-bit pattern — so the class call needs no tensor ops beside the launch
 template <int XDT, int SDT, int GROUP, bool GLOBAL>
-__global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4* __restrict__ in, const void* __restrict__ scale,
-                                                                     const float* __restrict__ global_scale, u32x4* __restrict__ out, int64_t lanes,
-                                                                     uint8_t* __restrict__ stored, const uint8_t* __restrict__ mx_lut) {
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= lanes) return;
+__device__ __forceinline__ void fp4_quant_pack_lean_lane(const u32x4* __restrict__ in, const void* __restrict__ scale, const float* __restrict__ global_scale,
+                                                         u32x4* __restrict__ out, int64_t g, uint8_t* __restrict__ stored, const uint8_t* __restrict__ mx_lut) {
     constexpr int NS = 32 / GROUP;  // scales per lane
     float s[2];
     uint32_t sraw = 0;  // the 16-bit patterns of the lane's scales (SDT != F32)
@@ -234,6 +231,41 @@ __global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4
         w[i] = fp4_quant_unit<XDT, GLOBAL>(ws, s[NS == 2 ? i >> 1 : 0], gs, in_dtype);
     }
     stream_store16(out + g, u32x4{w[0], w[1], w[2], w[3]});
+}
+
+template <int XDT, int SDT, int GROUP, bool GLOBAL>
+__global__ __launch_bounds__(kBlock) void fp4_quant_pack_lean_kernel(const u32x4* __restrict__ in, const void* __restrict__ scale,
+                                                                     const float* __restrict__ global_scale, u32x4* __restrict__ out, int64_t lanes,
+                                                                     uint8_t* __restrict__ stored, const uint8_t* __restrict__ mx_lut) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= lanes) return;
+    fp4_quant_pack_lean_lane<XDT, SDT, GROUP, GLOBAL>(in, scale, global_scale, out, g, stored, mx_lut);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tables of FP4 tensors (round 6): ONE launch per direction for the modules of a checkpoint — the NVFP4 / MXFP4 counterpart of ct_quant_pack_batch /
+// ct_q8_quant_batch (ModelCompressor's per-module loop, model_compressor.py:167-169,196-198, over NVFP4PackedCompressor / MXFP4PackedCompressor.compress /
+// .decompress, nvfp4/base.py:68-139).  The table is `struct ct_w4_item` with the FP4 reading of its fields (include/ct_hip.h): zp = the tensor's global
+// scale (one float32, NVFP4) or NULL (MXFP4), zp_packed = the stored-scale output (compress) resp. the bfloat16 scale output (decompress).  One launch per
+// module left a Llama-3-8B-shaped NVFP4 tree at 0.58 of the HBM peak (ramp and tail of 224 launches on tensors of 8-117 MB) and a TinyLlama-shaped one
+// bound by 7 us of host work per module.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const ct_w4_item& fp4_batch_find(const ct_w4_item* __restrict__ items, int n, int64_t block) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    }
+    return items[lo];
+}
+
+template <int XDT, int SDT, int GROUP>
+__global__ __launch_bounds__(kBlock) void fp4_quant_pack_batch_kernel(const ct_w4_item* __restrict__ items, int n, const uint8_t* __restrict__ mx_lut) {
+    const ct_w4_item& it = fp4_batch_find(items, n, blockIdx.x);
+    const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
+    if (g >= (it.units >> 2)) return;
+    fp4_quant_pack_lean_lane<XDT, SDT, GROUP, GROUP == 16>(static_cast<const u32x4*>(it.src), it.scale, static_cast<const float*>(it.zp), static_cast<u32x4*>(it.dst), g,
+                                                           static_cast<uint8_t*>(it.zp_packed), mx_lut);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -329,11 +361,9 @@ __device__ __forceinline__ float decode_scale(const void* scale, int kind, int s
 
 // lane = UNROLL units one block apart (4 B in, 16 B out)
 template <int ODT, int UNROLL, bool GLOBAL>
-__global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32_t* __restrict__ in, const void* __restrict__ scale, int kind, int sdt,
-                                                                    const float* __restrict__ global_scale, void* __restrict__ out, int64_t units,
-                                                                    int upg_shift, int64_t stride, uint16_t* __restrict__ scale_out) {
-    const float gs = GLOBAL ? global_scale[0] : 1.0f;
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < units; base += stride) {
+__device__ __forceinline__ void fp4_unpack_dequant_units(const uint32_t* __restrict__ in, const void* __restrict__ scale, int kind, int sdt, float gs, void* __restrict__ out,
+                                                         int64_t units, int upg_shift, int64_t base, uint16_t* __restrict__ scale_out) {
+    {
         uint32_t word[UNROLL];
 #pragma unroll
         for (int i = 0; i < UNROLL; ++i) {
@@ -367,6 +397,15 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32
             store8<ODT>(out, u * 8, v);  // RNE to the output dtype
         }
     }
+}
+
+template <int ODT, int UNROLL, bool GLOBAL>
+__global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_kernel(const uint32_t* __restrict__ in, const void* __restrict__ scale, int kind, int sdt,
+                                                                    const float* __restrict__ global_scale, void* __restrict__ out, int64_t units,
+                                                                    int upg_shift, int64_t stride, uint16_t* __restrict__ scale_out) {
+    const float gs = GLOBAL ? global_scale[0] : 1.0f;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < units; base += stride)
+        fp4_unpack_dequant_units<ODT, UNROLL, GLOBAL>(in, scale, kind, sdt, gs, out, units, upg_shift, base, scale_out);
 }
 
 // ---- the stand-alone primitives behind the reference's ImplBackend entry points --------------------------------
@@ -441,6 +480,10 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_kernel(const uint8_t* __res
     }
 }
 
+template <int ODT, int UNROLL>
+__device__ __forceinline__ void fp4_unpack_dequant_nv_units(const uint32_t* __restrict__ in, const uint8_t* __restrict__ scale, const float* s_eff, void* __restrict__ out,
+                                                            int64_t units, int64_t base, uint16_t* __restrict__ scale_out);
+
 // nvfp4: there are only 256 possible scale bytes, so s_eff = fl32(float(fp8) / global) is tabulated once per block
 // (one IEEE divide per thread) and every unit replaces decode + divide by one LDS read
 template <int ODT, int UNROLL>
@@ -451,7 +494,14 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_nv_kernel(const uin
     static_assert(kBlock == 256, "one table entry per thread");
     s_eff[threadIdx.x] = __builtin_amdgcn_cvt_f32_fp8((int)threadIdx.x, 0) / global_scale[0];
     __syncthreads();
-    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < units; base += stride) {
+    for (int64_t base = (int64_t)blockIdx.x * kBlock * UNROLL + threadIdx.x; base < units; base += stride)
+        fp4_unpack_dequant_nv_units<ODT, UNROLL>(in, scale, s_eff, out, units, base, scale_out);
+}
+
+template <int ODT, int UNROLL>
+__device__ __forceinline__ void fp4_unpack_dequant_nv_units(const uint32_t* __restrict__ in, const uint8_t* __restrict__ scale, const float* s_eff, void* __restrict__ out,
+                                                            int64_t units, int64_t base, uint16_t* __restrict__ scale_out) {
+    {
         uint32_t word[UNROLL];
         uint32_t sb[UNROLL];
 #pragma unroll
@@ -474,6 +524,31 @@ __global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_nv_kernel(const uin
             }
             store8<ODT>(out, u * 8, v);
         }
+    }
+}
+
+constexpr int kFp4BatchUnroll = 2;
+constexpr int kFp4BatchIter = 2;  // chunks of kBlock * kFp4BatchUnroll units per workgroup (as the W4 table: the table search is paid once per two chunks)
+
+// decompress of a table: NVFP4 (NV = true: float8 scale bytes under the item's global scale, the 256-entry s_eff table per workgroup) or MXFP4 (E8M0 codes)
+template <int ODT, bool NV>
+__global__ __launch_bounds__(kBlock) void fp4_unpack_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n) {
+    __shared__ float s_eff[256];
+    const ct_w4_item& it = fp4_batch_find(items, n, blockIdx.x);
+    const int64_t units = it.units;
+    const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kFp4BatchUnroll * kFp4BatchIter;
+    if constexpr (NV) {
+        s_eff[threadIdx.x] = __builtin_amdgcn_cvt_f32_fp8((int)threadIdx.x, 0) / static_cast<const float*>(it.zp)[0];
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int c = 0; c < kFp4BatchIter; ++c) {
+        const int64_t base = first + (int64_t)c * kBlock * kFp4BatchUnroll + threadIdx.x;
+        if (base >= units) break;
+        if constexpr (NV) fp4_unpack_dequant_nv_units<ODT, kFp4BatchUnroll>(static_cast<const uint32_t*>(it.src), static_cast<const uint8_t*>(it.scale), s_eff, it.dst, units, base,
+                                                                            static_cast<uint16_t*>(it.zp_packed));
+        else fp4_unpack_dequant_units<ODT, kFp4BatchUnroll, false>(static_cast<const uint32_t*>(it.src), it.scale, SC_E8M0, -1, 1.0f, it.dst, units, 2, base,
+                                                                   static_cast<uint16_t*>(it.zp_packed));
     }
 }
 
@@ -599,6 +674,76 @@ int ct_fp4_unpack_dequant_scale(const uint8_t* packed, int64_t rows, int64_t col
                                 int64_t group, void* out, int odt, void* scale_bf16_out, ct_stream_t stream) {
     CT_REQUIRE(scale_bf16_out != nullptr && (reinterpret_cast<uintptr_t>(scale_bf16_out) & 1u) == 0, "ct_fp4_unpack_dequant_scale needs the (2-byte aligned) scale output");
     return fp4_unpack_dequant_impl(packed, rows, cols, scale, scale_kind, sdt, global_scale, group, out, odt, static_cast<uint16_t*>(scale_bf16_out), stream);
+}
+
+int64_t ct_fp4_batch_plan(ct_w4_item* items, int n, int direction) {
+    if (!items || n < 0 || (direction != 0 && direction != 1)) {
+        set_error("ct_fp4_batch_plan: bad arguments");
+        return -1;
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ct_w4_item& it = items[i];
+        const int64_t g = it.group;
+        // compress: the lean kernel's layout (every lane four full units, its scales one aligned small load); decompress: 4-byte aligned words, 16-byte aligned output
+        bool ok = it.rows > 0 && it.cols > 0 && (g == 16 || g == 32) && it.cols % g == 0 && (it.rows * it.cols) % 32 == 0 && it.src && it.scale && it.dst && it.zp_packed &&
+                  (it.zp != nullptr) == (g == 16);
+        if (ok && direction == 0)
+            ok = aligned16(it.src) && aligned16(it.dst) && (reinterpret_cast<uintptr_t>(it.scale) & 7u) == 0 && (reinterpret_cast<uintptr_t>(it.zp_packed) & 1u) == 0;
+        if (ok && direction == 1)
+            ok = (reinterpret_cast<uintptr_t>(it.src) & 3u) == 0 && aligned16(it.dst) && (reinterpret_cast<uintptr_t>(it.zp_packed) & 1u) == 0;
+        if (!ok) {
+            set_error("ct_fp4_batch_plan: item %d (rows %lld, cols %lld, group %lld) is not eligible for the batched FP4 path (needs group 16 with a global scale or group 32 "
+                      "without one, cols %% group == 0, rows * cols %% 32 == 0, the scale outputs, aligned buffers)", i, (long long)it.rows, (long long)it.cols, (long long)g);
+            return -1;
+        }
+        it.units = it.rows * (it.cols / 8);
+        it.upg = (int32_t)(g / 8);
+        it.upg_shift = g == 16 ? 1 : 2;
+        it.first_block = blocks;
+        it.main_blocks = direction == 0 ? cdiv64(it.units / 4, kBlock) : cdiv64(it.units, (int64_t)kBlock * kFp4BatchUnroll * kFp4BatchIter);
+        it.g_magic = 0;
+        it.g_shift = 0;
+        blocks += it.main_blocks;
+    }
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("ct_fp4_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
+        return -1;
+    }
+    return blocks;
+}
+
+int ct_fp4_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int xdt, int sdt, int group, const uint8_t* mx_code_table, ct_stream_t stream) {
+    CT_REQUIRE(xdt == CT_BF16 || xdt == CT_F16, "batched FP4 path: 16-bit weights only, got dtype %d", xdt);
+    CT_REQUIRE(is_float_dt(sdt), "scale dtype code %d is not a float type", sdt);
+    CT_REQUIRE(group == 16 || group == 32, "FP4 group size must be 16 (nvfp4) or 32 (mxfp4), got %d", group);
+    CT_REQUIRE(group == 16 || (sdt != CT_F32 && mx_code_table != nullptr), "MXFP4 tables take 16-bit scales and the E8M0 code table");
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    const dim3 grid((unsigned)total_blocks);
+#define CT_FP4B(XD, SD, G) hipLaunchKernelGGL((fp4_quant_pack_batch_kernel<XD, SD, G>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, mx_code_table)
+#define CT_FP4B_S(XD) do { if (group == 16) { if (sdt == CT_F32) CT_FP4B(XD, CT_F32, 16); else if (sdt == CT_BF16) CT_FP4B(XD, CT_BF16, 16); else CT_FP4B(XD, CT_F16, 16); } \
+                           else { if (sdt == CT_BF16) CT_FP4B(XD, CT_BF16, 32); else CT_FP4B(XD, CT_F16, 32); } } while (0)
+    if (xdt == CT_BF16) CT_FP4B_S(CT_BF16); else CT_FP4B_S(CT_F16);
+#undef CT_FP4B_S
+#undef CT_FP4B
+    CT_LAUNCH_CHECK("ct_fp4_quant_pack_batch");
+}
+
+int ct_fp4_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int group, int odt, ct_stream_t stream) {
+    CT_REQUIRE(odt == CT_BF16 || odt == CT_F16, "FP4 decompression writes 16-bit floats, got dtype %d", odt);
+    CT_REQUIRE(group == 16 || group == 32, "FP4 group size must be 16 (nvfp4) or 32 (mxfp4), got %d", group);
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    const dim3 grid((unsigned)total_blocks);
+    if (odt == CT_BF16) {
+        if (group == 16) hipLaunchKernelGGL((fp4_unpack_dequant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n);
+        else hipLaunchKernelGGL((fp4_unpack_dequant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    } else {
+        if (group == 16) hipLaunchKernelGGL((fp4_unpack_dequant_batch_kernel<CT_F16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n);
+        else hipLaunchKernelGGL((fp4_unpack_dequant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n);
+    }
+    CT_LAUNCH_CHECK("ct_fp4_unpack_dequant_batch");
 }
 
 int ct_mx_scale_compress(const void* scale, int sdt, int64_t n, const uint8_t* code_table, uint8_t* codes_out, ct_stream_t stream) {

@@ -1045,36 +1045,24 @@ int dtype_code(at::ScalarType t) {
 
 // ------------------------------------------------------------------------------------------
 // FP4 codecs (nvfp4-pack-quantized, group 16 under a global scale; mxfp4-pack-quantized, group 32; reference compressors/nvfp4/base.py:68-139,
-// mxfp4/base.py:27-65): NVFP4PackedCompressor.compress_modules / decompress_modules in C++.  One launch per module (`ct_fp4_quant_pack_stored` /
-// `ct_fp4_unpack_dequant_scale`, called by address on `stream` of device `device_index`, which the caller has made current) and the dictionary delta of
-// swap_direct_entries: weight, weight_scale (and a symmetric scheme's zero points) leave, weight_packed and the stored weight_scale arrive — resp. the
-// other way round.  The interpreter spent 14 us per module and direction on this (a TinyLlama-shaped NVFP4 tree ran at 0.13 of the HBM peak).  Modules
-// outside the plain case, or on another device, come back in the returned list for the Python loop.
+// mxfp4/base.py:27-65): NVFP4PackedCompressor.compress_modules / decompress_modules in C++, as the W4 and 8-bit loops above — the table of
+// `ct_fp4_quant_pack_batch` / `ct_fp4_unpack_dequant_batch` from the modules' own entries (struct ct_w4_item in its FP4 reading: zp = the module's global
+// scale, zp_packed = the stored / bfloat16 scale output), one launch per window, then the dictionary delta of swap_direct_entries under the kernel: weight,
+// weight_scale (and a symmetric scheme's zero points) leave, weight_packed and the stored weight_scale arrive — resp. the other way round.  The interpreter
+// spent 14 us per module and direction on this with one launch per module (a TinyLlama-shaped NVFP4 tree ran at 0.13 of the HBM peak, an 8B-shaped one at 0.58).
 // compress infos[i]: 1 | drop mask << 1 (weight / input / output zero point of a symmetric scheme) when the scheme stores its scale in the format's usual
-// dtype and is symmetric or carries no zero point; else 0
+// dtype; else 0.  batch key: (device index, weights' dtype code | scales' dtype code << 4) — dtype codes as `dtype_code` below.
 // ------------------------------------------------------------------------------------------
-using fp4_compress_fn = int (*)(const void*, int, const void*, int, const float*, int64_t, int64_t, int64_t, uint8_t*, uint8_t*, const uint8_t*, void*);
-using fp4_decompress_fn = int (*)(const uint8_t*, int64_t, int64_t, const void*, int, int, const float*, int64_t, void*, int, void*, void*);
-fp4_compress_fn g_fp4_compress = nullptr;
-fp4_decompress_fn g_fp4_decompress = nullptr;
-PyObject *g_weight_global_scale = nullptr;
+PyObject* g_weight_global_scale = nullptr;
 
-void bind_fp4(uintptr_t compress, uintptr_t decompress) {
-    g_fp4_compress = reinterpret_cast<fp4_compress_fn>(compress);
-    g_fp4_decompress = reinterpret_cast<fp4_decompress_fn>(decompress);
+// the global scale as the kernel takes it: one float32 on the tensor's device (codec._gs_fast's no-op case)
+inline bool plain_gs(const at::Tensor& g, const at::Device& dev) {
+    return g.scalar_type() == at::kFloat && g.numel() == 1 && g.device() == dev && (reinterpret_cast<uintptr_t>(g.data_ptr()) & 3u) == 0;
 }
 
-inline bool on_dev(const at::Tensor& t, int device_index) { return (t.is_cuda() && t.device().index() == device_index) || (g_allow_cpu && t.is_cpu()); }
-
-// the global scale as the kernel takes it: one float32 on the device (codec._gs_fast's no-op case)
-inline bool plain_gs(const at::Tensor& g, int device_index) {
-    return g.scalar_type() == at::kFloat && g.numel() == 1 && on_dev(g, device_index) && (reinterpret_cast<uintptr_t>(g.data_ptr()) & 3u) == 0;
-}
-
-py::list fp4_compress_modules(py::list modules, py::object infos_arg, int64_t group, int device_index, uintptr_t stream, uintptr_t lut_f16, uintptr_t lut_bf16,
-                              py::object status) {
+py::tuple fp4_plan_compress(py::list modules, py::object infos_arg, int64_t group) {
     touch_tls();
-    if (!g_fp4_compress) throw std::runtime_error("fp4_compress_modules: bind_fp4 has not been called");
+    std::map<std::pair<int, int>, Batch> batches;
     py::list rest;
     Infos infos(infos_arg.ptr());
     const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
@@ -1089,11 +1077,11 @@ py::list fp4_compress_modules(py::list modules, py::object infos_arg, int64_t gr
             w = e.tensor(N.weight);
             scale = e.tensor(N.weight_scale);
             gs = e.tensor(g_weight_global_scale);
-            // (a zero point entry: dropped below for a symmetric scheme; present under an asymmetric one the Python path raises)
+            // (a zero point entry: dropped for a symmetric scheme; present under an asymmetric one the Python path raises)
             ok = w && scale && (gs != nullptr) == (group == 16) && (gs != nullptr || !e.has(g_weight_global_scale)) && !e.has(N.weight_packed) && w->dim() == 2 &&
-                 half_type(w->scalar_type()) && on_dev(*w, device_index) && w->is_contiguous() && aligned16(*w) && on_dev(*scale, device_index) &&
+                 half_type(w->scalar_type()) && (w->is_cuda() || g_allow_cpu) && w->is_contiguous() && aligned16(*w) && scale->device() == w->device() &&
                  scale->is_contiguous() && (reinterpret_cast<uintptr_t>(scale->data_ptr()) & 7u) == 0 &&
-                 (half_type(scale->scalar_type()) || (group == 16 && scale->scalar_type() == at::kFloat)) && (!gs || plain_gs(*gs, device_index)) &&
+                 (half_type(scale->scalar_type()) || (group == 16 && scale->scalar_type() == at::kFloat)) && (!gs || plain_gs(*gs, w->device())) &&
                  (e.tensor(N.weight_zero_point) == nullptr || (dropmask & 1));
         }
         int64_t rows = 0, cols = 0;
@@ -1104,36 +1092,29 @@ py::list fp4_compress_modules(py::list modules, py::object infos_arg, int64_t gr
                  staying_entries_are_final(e, {N.weight, N.weight_scale, (dropmask & 1) ? N.weight_zero_point : N.weight, (dropmask & 2) ? g_input_zero_point : N.weight,
                                                (dropmask & 4) ? g_output_zero_point : N.weight});
         }
-        const uintptr_t lut = group == 32 && ok ? (scale->scalar_type() == at::kHalf ? lut_f16 : lut_bf16) : 0;
-        if (ok && group == 32 && !lut) ok = false;
-        if (ok) {
-            at::Tensor packed = at::empty({rows, cols / 2}, w->options().dtype(at::kByte));
-            at::Tensor stored = at::empty({rows, cols / group}, w->options().dtype(group == 16 ? at::kFloat8_e4m3fn : at::kByte));
-            const int rc = g_allow_cpu && w->is_cpu() ? 0
-                                                      : g_fp4_compress(w->data_ptr(), dtype_code(w->scalar_type()), scale->data_ptr(), dtype_code(scale->scalar_type()),
-                                                                       gs ? static_cast<const float*>(gs->data_ptr()) : nullptr, rows, cols, group,
-                                                                       static_cast<uint8_t*>(packed.data_ptr()), static_cast<uint8_t*>(stored.data_ptr()),
-                                                                       reinterpret_cast<const uint8_t*>(lut), reinterpret_cast<void*>(stream));
-            if (rc == 0) {
-                drop(e.params, N.weight);
-                drop(e.params, N.weight_scale);
-                if (dropmask & 1) drop(e.params, N.weight_zero_point);
-                if (dropmask & 2) drop(e.params, g_input_zero_point);
-                if (dropmask & 4) drop(e.params, g_output_zero_point);
-                PyDict_SetItem(e.params, N.weight_packed, make_parameter(packed).ptr());
-                PyDict_SetItem(e.params, N.weight_scale, make_parameter(stored).ptr());
-                set_status(m, status.ptr());
-                continue;
-            }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
         }
-        rest.append(py::reinterpret_borrow<py::object>(m));  // (a refused launch too: the Python path repeats it and reports the library's message)
+        at::Tensor packed = at::empty({rows, cols / 2}, w->options().dtype(at::kByte));
+        at::Tensor stored = at::empty({rows, cols / group}, w->options().dtype(group == 16 ? at::kFloat8_e4m3fn : at::kByte));
+        const int wcode = w->scalar_type() == at::kHalf ? 1 : 2, scode = scale->scalar_type() == at::kFloat ? 0 : scale->scalar_type() == at::kHalf ? 1 : 2;
+        Batch& b = batches[{w->is_cuda() ? (int)w->device().index() : -1, wcode | (scode << 4)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), gs ? (int64_t)(uintptr_t)gs->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)packed.data_ptr(), rows, cols, group, 0, 0, 0, (int64_t)(uintptr_t)stored.data_ptr(), 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
+        // the job keeps the inputs alive until the launch has been issued (the table holds raw pointers)
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(packed)),
+                                     py::reinterpret_steal<py::object>(THPVariable_Wrap(stored)), dropmask, py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)),
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_scale))));
     }
-    return rest;
+    return py::make_tuple(batches_to_python(batches), rest);
 }
 
-py::list fp4_decompress_modules(py::list modules, int64_t group, int device_index, uintptr_t stream, py::object status) {
+py::tuple fp4_plan_decompress(py::list modules, int64_t group) {
     touch_tls();
-    if (!g_fp4_decompress) throw std::runtime_error("fp4_decompress_modules: bind_fp4 has not been called");
+    std::map<std::pair<int, int>, Batch> batches;
     py::list rest;
     const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
     for (Py_ssize_t i = 0; i < n; ++i) {
@@ -1146,37 +1127,63 @@ py::list fp4_decompress_modules(py::list modules, int64_t group, int device_inde
             scale = e.tensor(N.weight_scale);
             gs = e.tensor(g_weight_global_scale);
             ok = packed && scale && (gs != nullptr) == (group == 16) && (gs != nullptr || !e.has(g_weight_global_scale)) && !e.has(N.weight) &&
-                 packed->scalar_type() == at::kByte && packed->dim() == 2 && on_dev(*packed, device_index) && packed->is_contiguous() &&
-                 (reinterpret_cast<uintptr_t>(packed->data_ptr()) & 3u) == 0 && on_dev(*scale, device_index) && scale->is_contiguous() &&
-                 scale->scalar_type() == (group == 16 ? at::kFloat8_e4m3fn : at::kByte) && (!gs || plain_gs(*gs, device_index));
+                 packed->scalar_type() == at::kByte && packed->dim() == 2 && (packed->is_cuda() || g_allow_cpu) && packed->is_contiguous() &&
+                 (reinterpret_cast<uintptr_t>(packed->data_ptr()) & 3u) == 0 && scale->device() == packed->device() && scale->is_contiguous() &&
+                 scale->scalar_type() == (group == 16 ? at::kFloat8_e4m3fn : at::kByte) && (!gs || plain_gs(*gs, packed->device()));
         }
         int64_t rows = 0, cols = 0;
         if (ok) {
             rows = packed->size(0);
             cols = packed->size(1) * 2;
-            ok = rows > 0 && cols > 0 && cols % group == 0 && scale->dim() == 2 && scale->size(0) == rows && scale->size(1) == cols / group &&
+            ok = rows > 0 && cols > 0 && cols % group == 0 && (rows * cols) % 32 == 0 && scale->dim() == 2 && scale->size(0) == rows && scale->size(1) == cols / group &&
                  staying_entries_are_final(e, {N.weight_packed, N.weight_scale});
         }
-        if (ok) {
-            at::Tensor out = at::empty({rows, cols}, packed->options().dtype(at::kBFloat16));  // unpack_fp4_from_uint8's default dtype (nvfp4/base.py:118-131)
-            at::Tensor sout = at::empty({rows, cols / group}, packed->options().dtype(at::kBFloat16));
-            const int rc = g_allow_cpu && packed->is_cpu()
-                               ? 0
-                               : g_fp4_decompress(static_cast<const uint8_t*>(packed->data_ptr()), rows, cols, scale->data_ptr(), group == 16 ? 1 : 2, -1,
-                                                  gs ? static_cast<const float*>(gs->data_ptr()) : nullptr, group, out.data_ptr(), dtype_code(at::kBFloat16),
-                                                  sout.data_ptr(), reinterpret_cast<void*>(stream));
-            if (rc == 0) {
-                drop(e.params, N.weight_packed);
-                drop(e.params, N.weight_scale);
-                PyDict_SetItem(e.params, N.weight_scale, make_parameter(sout).ptr());
-                PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
-                set_status(m, status.ptr());
-                continue;
-            }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
         }
-        rest.append(py::reinterpret_borrow<py::object>(m));
+        at::Tensor out = at::empty({rows, cols}, packed->options().dtype(at::kBFloat16));  // unpack_fp4_from_uint8's default dtype (nvfp4/base.py:118-131)
+        at::Tensor sout = at::empty({rows, cols / group}, packed->options().dtype(at::kBFloat16));
+        Batch& b = batches[{packed->is_cuda() ? (int)packed->device().index() : -1, 0}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), gs ? (int64_t)(uintptr_t)gs->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)out.data_ptr(), rows, cols, group, 0, 0, 0, (int64_t)(uintptr_t)sout.data_ptr(), 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
+                                     py::reinterpret_steal<py::object>(THPVariable_Wrap(sout)), 0, py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_packed)),
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_scale))));
     }
-    return rest;
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+// after the launch; the entries arrive in the order swap_direct_entries leaves them: (weight_packed, weight_scale) resp. (weight_scale, weight)
+void fp4_finish(py::list jobs, py::object status, bool compress) {
+    touch_tls();
+    const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
+        PyObject* m = PyTuple_GET_ITEM(job, 0);
+        const at::Tensor& a = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));  // packed bytes / dense weight
+        const at::Tensor& sc = THPVariable_Unpack(PyTuple_GET_ITEM(job, 2));
+        const long dropmask = PyLong_AsLong(PyTuple_GET_ITEM(job, 3));
+        Entries e;
+        if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        if (compress) {
+            drop(e.params, N.weight);
+            drop(e.params, N.weight_scale);
+            if (dropmask & 1) drop(e.params, N.weight_zero_point);
+            if (dropmask & 2) drop(e.params, g_input_zero_point);
+            if (dropmask & 4) drop(e.params, g_output_zero_point);
+            PyDict_SetItem(e.params, N.weight_packed, make_parameter(a).ptr());
+            PyDict_SetItem(e.params, N.weight_scale, make_parameter(sc).ptr());
+        } else {
+            drop(e.params, N.weight_packed);
+            drop(e.params, N.weight_scale);
+            PyDict_SetItem(e.params, N.weight_scale, make_parameter(sc).ptr());
+            PyDict_SetItem(e.params, N.weight, make_parameter(a).ptr());
+        }
+        set_status(m, status.ptr());
+    }
 }
 
 // Marlin24Compressor.compress for an int4 scheme outside a deferred-check context, from the popped state-dict entries on: the layout tests
@@ -1221,9 +1228,9 @@ PYBIND11_MODULE(_hostpath, mod) {
     g_input_zero_point = PyUnicode_InternFromString("input_zero_point");
     g_output_zero_point = PyUnicode_InternFromString("output_zero_point");
     g_weight_global_scale = PyUnicode_InternFromString("weight_global_scale");
-    mod.def("bind_fp4", &bind_fp4);
-    mod.def("fp4_compress_modules", &fp4_compress_modules);
-    mod.def("fp4_decompress_modules", &fp4_decompress_modules);
+    mod.def("fp4_plan_compress", &fp4_plan_compress);
+    mod.def("fp4_plan_decompress", &fp4_plan_decompress);
+    mod.def("fp4_finish", &fp4_finish);
     mod.def("q8_plan_compress", &q8_plan_compress);
     mod.def("q8_plan_decompress", &q8_plan_decompress);
     mod.def("q8_finish", &q8_finish);

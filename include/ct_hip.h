@@ -305,6 +305,19 @@ int ct_fp4_quant_pack_stored(const void* x, int xdt, const void* scale, int sdt,
 int ct_fp4_unpack_dequant_scale(const uint8_t* packed, int64_t rows, int64_t cols, const void* scale, int scale_kind,
                                 int sdt, const float* global_scale, int64_t group, void* out, int odt,
                                 void* scale_bf16_out, ct_stream_t stream);
+/* Tables of FP4 tensors: ONE launch per direction for the modules of an NVFP4 / MXFP4 checkpoint (the per-module loop of ModelCompressor.compress_model /
+ * decompress_model, model_compressor.py:167-169,196-198, over NVFP4PackedCompressor / MXFP4PackedCompressor, nvfp4/base.py:68-139, mxfp4/base.py:27-65) —
+ * ct_fp4_quant_pack_stored / ct_fp4_unpack_dequant_scale for every item.  The table is `struct ct_w4_item` read this way: src / dst = weights and packed
+ * bytes in the direction's order, scale = the float scale (compress) resp. the stored float8 / E8M0 bytes (decompress), zp = the item's global scale (one
+ * float32 on the device; group 16) or NULL (group 32), group = 16 or 32 (one value per table), zp_packed = the stored-scale output (compress: float8 bytes
+ * resp. E8M0 codes, (rows, cols / group)) resp. the bfloat16 scale output (decompress).  ct_fp4_batch_plan fills the derived fields on the HOST copy and
+ * returns the workgroup count, or -1 (error set) for an item outside the layout: rows * cols % 32 == 0, cols % group == 0, 16-byte aligned weights / packed
+ * bytes (decompress: 4-byte aligned packed bytes), 8-byte aligned float scale.  xdt / sdt: the weights' and the float scales' dtype (one per table; MXFP4:
+ * 16-bit scales and `mx_code_table` as in ct_fp4_quant_pack_stored).  odt: bfloat16 (what the reference returns) or float16. */
+int64_t ct_fp4_batch_plan(ct_w4_item* items_host, int n, int direction);
+int ct_fp4_quant_pack_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int xdt, int sdt, int group,
+                            const uint8_t* mx_code_table, ct_stream_t stream);
+int ct_fp4_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int group, int odt, ct_stream_t stream);
 /* compress_mx_scale / decompress_mx_scale (compressors/mx_utils.py:18-44) on their own — the MXFP8 codec's scale conversions and upstream's helpers:
  * codes_out[i] = code_table[bits of scale[i]] (16-bit scales; the table as above) resp. scale_bf16_out[i] = 2 ** (codes[i] - 127) as bfloat16
  * (code 0: the bfloat16 subnormal 2^-127, code 255: inf). */

@@ -2121,6 +2121,109 @@ def test_fp4_codec_vs_oracle(cta, dev, fmt, group, xdt, shape):
     assert eq(back["weight_scale"].cpu(), rback["weight_scale"])
 
 
+@pytest.mark.parametrize("fmt,group", [("nvfp4-pack-quantized", 16), ("mxfp4-pack-quantized", 32)])
+@pytest.mark.parametrize("xdt,sdt", [(BF16, BF16), (F16, F16), (BF16, F32)])
+def test_fp4_table_launches_vs_oracle(cta, dev, fmt, group, xdt, sdt):
+    """ct_fp4_batch_plan + ct_fp4_quant_pack_batch / ct_fp4_unpack_dequant_batch (one launch for a table of tensors, each with its own global scale) against
+    the oracle per tensor: packed nibbles, stored scales (float8 bytes / E8M0 codes), dense bfloat16 weights and bfloat16 scales; shapes from one lane to
+    several workgroups, incl. sizes that end inside a workgroup's first / second chunk, special values; then the same modules through
+    compress_modules / decompress_modules (the C++ host loop + the table launch), state dicts equal to the per-module class calls"""
+    from compressed_tensors_amd import codec
+
+    if group == 32 and sdt is F32:
+        pytest.skip("MXFP4 scales are 16-bit")
+    shapes = [(1, 32), (2, 16), (3, 96), (64, 4096), (33, 1056), (7, 160), (256, 2048), (1024, 1024), (129, 992), (16, 4128)]
+    shapes = [sh for sh in shapes if sh[1] % group == 0 and (sh[0] * sh[1]) % 32 == 0]
+    g = torch.Generator().manual_seed(11)
+    xs, ss, gss, refs = [], [], [], []
+    for k, shape in enumerate(shapes):
+        x = (torch.randn(shape, generator=g) * (0.5 + k)).to(xdt)
+        sv = special_values(xdt)
+        x.view(-1)[: min(sv.numel(), x.numel())] = sv[: x.numel()]
+        x = torch.where(torch.isnan(x), torch.zeros_like(x), x)
+        amax = x.float().reshape(shape[0], -1, group).abs().amax(-1).clamp(min=1e-3, max=1e4)
+        if group == 16:
+            gs = torch.tensor([448.0 * 6.0 / float(amax.max())], dtype=torch.float32)
+            s = (gs * amax / 6.0).to(F8).to(torch.float32)
+            s = torch.where(s == 0, torch.full_like(s, 2.0 ** -9), s).to(sdt)
+        else:
+            gs = None
+            s = torch.exp2(torch.floor(torch.log2(amax)) - 2).to(sdt)
+        xs.append(x); ss.append(s); gss.append(gs)
+        refs.append(O.fp4_compress(x, s, gs, fmt=fmt))
+    import array
+
+    IW = codec._ITEM_WORDS
+    dx, ds, dg = [t.to(dev) for t in xs], [t.to(dev) for t in ss], [None if t is None else t.to(dev) for t in gss]
+    packed = [torch.empty((sh[0], sh[1] // 2), dtype=torch.uint8, device=dev) for sh in shapes]
+    stored = [torch.empty((sh[0], sh[1] // group), dtype=F8 if group == 16 else torch.uint8, device=dev) for sh in shapes]
+    flat = []
+    for x, s_, g_, p_, st, sh in zip(dx, ds, dg, packed, stored, shapes):
+        flat += [x.data_ptr(), s_.data_ptr(), 0 if g_ is None else g_.data_ptr(), p_.data_ptr(), sh[0], sh[1], group, 0, 0, 0, st.data_ptr()] + [0] * (IW - 11)
+    words = torch.tensor(flat, dtype=torch.int64)
+    codec.launch_fp4_words(words, len(shapes), "compress", dev, group, xdt, sdt)
+    for k, ref in enumerate(refs):
+        assert torch.equal(packed[k].cpu(), ref["weight_packed"]), (shapes[k], "packed")
+        assert torch.equal(stored[k].cpu().view(torch.uint8), ref["weight_scale"].view(torch.uint8)), (shapes[k], "stored scale")
+    outs = [torch.empty(sh, dtype=BF16, device=dev) for sh in shapes]
+    souts = [torch.empty((sh[0], sh[1] // group), dtype=BF16, device=dev) for sh in shapes]
+    flat = []
+    for p_, st, g_, o_, so, sh in zip(packed, stored, dg, outs, souts, shapes):
+        flat += [p_.data_ptr(), st.data_ptr(), 0 if g_ is None else g_.data_ptr(), o_.data_ptr(), sh[0], sh[1], group, 0, 0, 0, so.data_ptr()] + [0] * (IW - 11)
+    codec.launch_fp4_words(torch.tensor(flat, dtype=torch.int64), len(shapes), "decompress", dev, group)
+    for k, ref in enumerate(refs):
+        state = dict(ref)
+        if gss[k] is not None:
+            state["weight_global_scale"] = gss[k]
+        rb = O.fp4_decompress(state, fmt=fmt)
+        assert eq(outs[k].cpu(), rb["weight"]), (shapes[k], "weight")
+        assert eq(souts[k].cpu(), rb["weight_scale"]), (shapes[k], "bf16 scale")
+    # a table that holds an item outside the layout is refused with nothing launched
+    bad = words.clone()
+    bad[5] = 24  # cols not a multiple of the group
+    with pytest.raises(ValueError):
+        codec.launch_fp4_words(bad, len(shapes), "compress", dev, group, xdt, sdt)
+    # the module loops: C++ host loop + table launches against the per-module class calls
+    comp = cta.BaseCompressor.get_value_from_registry(fmt)
+    scheme = _fp4_scheme(cta, fmt)
+
+    def modules():
+        ms = []
+        for x, s_, g_ in zip(dx, ds, dg):
+            lin = torch.nn.Linear(x.shape[1], x.shape[0], bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(x.clone(), requires_grad=False)
+            lin.weight_scale = torch.nn.Parameter(s_.clone(), requires_grad=False)
+            if g_ is not None:
+                lin.weight_global_scale = torch.nn.Parameter(g_.clone(), requires_grad=False)
+            lin.quantization_scheme = scheme
+            ms.append(lin)
+        return ms
+
+    a, b = modules(), modules()
+    comp.compress_modules(a)
+    for m in b:
+        comp.compress_module(m)
+    for k, (x_, y_) in enumerate(zip(a, b)):
+        assert list(x_._parameters) == list(y_._parameters), shapes[k]
+        for name in x_._parameters:
+            tx, ty = x_._parameters[name], y_._parameters[name]
+            if tx is None or ty is None:
+                assert tx is ty
+                continue
+            assert tx.dtype == ty.dtype and torch.equal(tx.view(torch.uint8) if tx.element_size() == 1 else tx, ty.view(torch.uint8) if ty.element_size() == 1 else ty), (shapes[k], name)
+        assert torch.equal(x_.weight_packed.cpu(), refs[k]["weight_packed"])
+    comp.decompress_modules(a)
+    for m in b:
+        comp.decompress_module(m)
+    for k, (x_, y_) in enumerate(zip(a, b)):
+        assert list(x_._parameters) == list(y_._parameters), shapes[k]
+        for name in x_._parameters:
+            if x_._parameters[name] is None or y_._parameters[name] is None:
+                assert x_._parameters[name] is y_._parameters[name]
+                continue
+            assert eq(x_._parameters[name].data.cpu(), y_._parameters[name].data.cpu()), (shapes[k], name)
+
+
 def test_fp4_full_size_roundtrip(cta, dev):
     """8192 x 8192: decompress(compress(x)) re-compresses to the same bytes (idempotence), and E2M1-valued inputs
     under unit scales survive exactly"""

@@ -1012,7 +1012,7 @@ def test_cpp_host_loop_of_the_8bit_codecs_matches_the_python_loop(cta, monkeypat
 @pytest.mark.parametrize("fmt", ["nvfp4", "mxfp4"])
 @pytest.mark.parametrize("variant", ["plain", "zero_point", "static_input", "trainable_scale", "buffer_zp", "odd_class", "f32_scale", "odd_global_scale", "other_scale_dtype"])
 def test_cpp_host_loop_of_the_fp4_codecs_matches_the_python_loop(cta, monkeypatch, fmt, variant):
-    """csrc/host/ct_hostpath.cpp fp4_compress_modules / fp4_decompress_modules against the Python loops of NVFP4PackedCompressor / MXFP4PackedCompressor on CPU
+    """csrc/host/ct_hostpath.cpp fp4_plan_compress / fp4_plan_decompress / fp4_finish against the Python loops of NVFP4PackedCompressor / MXFP4PackedCompressor on CPU
     tensors (the launch itself skipped / stubbed): the same modules taken, every module left in the same state — names, ORDER, kinds, trainability, shapes,
     dtypes, status — incl. the zero points a symmetric scheme drops"""
     from compressed_tensors_amd import _lib as ctlib
@@ -1021,7 +1021,7 @@ def test_cpp_host_loop_of_the_fp4_codecs_matches_the_python_loop(cta, monkeypatc
     from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
 
     hp = ctlib.hostpath()
-    assert hp is not None and hasattr(hp, "fp4_compress_modules"), "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    assert hp is not None and hasattr(hp, "fp4_plan_compress"), "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
     F8 = torch.float8_e4m3fn
     group = 16 if fmt == "nvfp4" else 32
     if fmt == "mxfp4" and variant in ("f32_scale", "odd_global_scale"):
@@ -1084,9 +1084,14 @@ def test_cpp_host_loop_of_the_fp4_codecs_matches_the_python_loop(cta, monkeypatc
     monkeypatch.setattr(codec, "compress_mx_scale", lambda scale, dtype: torch.zeros(scale.shape, dtype=dtype))
     monkeypatch.setattr(codec, "_mx_code_table", lambda dt, dev: torch.zeros(65536, dtype=torch.uint8))
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
-    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
-    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
-    monkeypatch.setattr(ctlib, "stream_on", lambda device, handle=None: 0)
+    launched = []
+
+    def fake_words(words, n, direction, device, group_, x_dtype=None, scale_dtype=None):
+        rows = words.reshape(n, codec._ITEM_WORDS)
+        assert group_ == group and all(int(r[6]) == group and bool(r[2]) == (group == 16) and r[10] for r in rows.tolist())
+        launched.append((direction, n, x_dtype, scale_dtype, sorted((int(r[4]), int(r[5])) for r in rows.tolist())))
+
+    monkeypatch.setattr(codec, "launch_fp4_words", fake_words)
     hp.set_allow_cpu(True)
     try:
         a, b = tree(), tree()
@@ -1107,6 +1112,10 @@ def test_cpp_host_loop_of_the_fp4_codecs_matches_the_python_loop(cta, monkeypatc
             if variant == "other_scale_dtype" and direction == "decompress":
                 left = 4  # a stored scale of another dtype is not this format's byte layout
             assert python_calls_with_cpp == left, (fmt, variant, direction, python_calls_with_cpp)
+            mine = [t for t in launched if t[0] == direction]
+            assert sum(t[1] for t in mine) == 4 - left, (fmt, variant, direction, mine)
+            if mine and direction == "compress":
+                assert mine[0][2] is torch.bfloat16 and mine[0][3] is (torch.float32 if variant == "f32_scale" else torch.bfloat16)
     finally:
         hp.set_allow_cpu(False)
 
