@@ -908,7 +908,7 @@ def zp4_batch(pairs, direction: str) -> None:
     table.record_stream(torch.cuda.current_stream(dev))
 
 
-def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, group_size=None, g_idx=None, f8_zero_point=False):
+def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, group_size=None, g_idx=None, f8_zero_point=False, block_structure=None):
     """Elements per scale (the table's `group`) if this tensor can join a one-launch 8-bit batch, else None.  2-D, 16-bit
     float dtype equal to the scale's, tensor / channel / group scales (strategy given, or inferred from the scale's shape like
     `dequantize` does, forward.py:99-130), cols % 16 == 0, group % 16 == 0, int8 or absent zero point of the scale's shape,
@@ -929,9 +929,24 @@ def q8_batch_group(shape, w_dtype, scale, zero_point, *, device, strategy=None, 
         group = cols // scale.shape[1]
         if st == "group" and group_size and int(group_size) != group:
             return None
+    elif scale.dim() == 2 and st in (None, "block") and scale.shape[0] >= 1 and scale.shape[1] >= 1:
+        # block strategy (forward.py:198-216; inferred like `dequantize` does, forward.py:118-130, when no strategy is given): the table's group is
+        # -((rows per block << 24) | columns per block), include/ct_hip.h
+        if st == "block":
+            if block_structure is None or len(block_structure) != 2:
+                return None
+            bh, bw = int(block_structure[0]), int(block_structure[1])
+        else:
+            if rows % scale.shape[0] or cols % scale.shape[1]:
+                return None
+            bh, bw = rows // scale.shape[0], cols // scale.shape[1]
+        if (bh < 1 or bw < 16 or bh & (bh - 1) or bw & (bw - 1) or bh >= 1 << 24 or bw >= 1 << 24 or cols % bw or rows * cols >= 1 << 34
+                or tuple(scale.shape) != (-(-rows // bh), cols // bw)):
+            return None
+        group = -((bh << 24) | bw)
     else:
         return None
-    if group % 16:
+    if group > 0 and group % 16:
         return None
     # (f8_zero_point, round 6: the float8 zero points a calibrated FLOAT scheme carries — all zeros for the symmetric schemes upstream allows, but
     # read as the float8 values they are: kind "fp8z" of W4Batch)

@@ -18,7 +18,7 @@ from ..base import COMPRESSIBLE_MODULE_TYPES, BaseCompressor
 __all__ = ["NaiveQuantizationCompressor", "IntQuantizationCompressor", "FloatQuantizationCompressor"]
 
 _DTYPE_OF_CODE = {1: torch.float16, 2: torch.bfloat16}
-_STRATEGY_CODE = {"tensor": 0, "channel": 1, "group": 2}
+_STRATEGY_CODE = {"tensor": 0, "channel": 1, "group": 2, "block": 3}
 
 
 def _q8_compress_info(scheme) -> int:
@@ -36,12 +36,18 @@ def _q8_compress_info(scheme) -> int:
     if enum_value(getattr(wa, "actorder", None)) == "group":
         return -1
     gs = int(getattr(wa, "group_size", None) or 0) if st == "group" else 0
-    if not 0 <= gs < (1 << 20):
+    bh = 0
+    if st == "block":  # block width in the group-size field, block height behind the drop mask
+        bs = getattr(wa, "block_structure", None)
+        if bs is None or len(bs) != 2:
+            return -1
+        bh, gs = int(bs[0]), int(bs[1])
+    if not 0 <= gs < (1 << 20) or not 0 <= bh < (1 << 20):
         return -1
     drop = 0
     for key in symmetric_zp_keys(scheme):
         drop |= {"weight_zero_point": 1, "input_zero_point": 2, "output_zero_point": 4}[key]
-    return gs | (bits << 20) | ((qtype == "float") << 24) | (_STRATEGY_CODE[st] << 25) | (drop << 27)
+    return gs | (bits << 20) | ((qtype == "float") << 24) | (_STRATEGY_CODE[st] << 25) | (drop << 27) | (bh << 30)
 
 
 def _q8_decompress_info(scheme) -> int:
@@ -141,7 +147,7 @@ class NaiveQuantizationCompressor(BaseCompressor):
             w, scale, zp = sd.get("weight"), sd.get("weight_scale"), sd.get("weight_zero_point")
             wa = scheme.weights
             qtype, st = enum_value(getattr(wa, "type", "int")), enum_value(wa.strategy)
-            if w is None or not w.is_cuda or not w.is_contiguous() or w.data_ptr() % 16 or st not in ("tensor", "channel", "group"):
+            if w is None or not w.is_cuda or not w.is_contiguous() or w.data_ptr() % 16 or st not in ("tensor", "channel", "group", "block"):
                 continue
             if qtype == "float" and int(wa.num_bits) != 8:
                 continue
@@ -151,7 +157,7 @@ class NaiveQuantizationCompressor(BaseCompressor):
             if qtype == "float" and zp is not None and not f8z:
                 continue
             group = codec.q8_batch_group(w.shape, w.dtype, scale, zp, device=w.device, strategy=st, group_size=getattr(wa, "group_size", None),
-                                         g_idx=sd.get("weight_g_idx"), f8_zero_point=f8z)
+                                         g_idx=sd.get("weight_g_idx"), f8_zero_point=f8z, block_structure=getattr(wa, "block_structure", None))
             if group is None:
                 continue
             out = torch.empty(w.shape, dtype=wa.pytorch_dtype(), device=w.device)
@@ -226,8 +232,9 @@ class NaiveQuantizationCompressor(BaseCompressor):
             if q is None:
                 cls.compress_module(m)
                 continue
-            # what replace_direct_state_dict(module, compress(state_dict)) leaves: the codes in `weight`, no zero point for a symmetric scheme
-            swap_direct_entries(m, symmetric_zp_keys(m.quantization_scheme), {"weight": q}, QuantizationStatus.COMPRESSED)
+            # what replace_direct_state_dict(module, compress(state_dict)) leaves: the codes in `weight` — which `compress` pops and re-adds, so it ends
+            # up BEHIND the entries that stay (naive_quantized/base.py:62-100) —, no zero point for a symmetric scheme
+            swap_direct_entries(m, [*symmetric_zp_keys(m.quantization_scheme), "weight"], {"weight": q}, QuantizationStatus.COMPRESSED)
 
     @classmethod
     def decompress_many(cls, state_dicts, scheme) -> list:
@@ -260,7 +267,7 @@ class NaiveQuantizationCompressor(BaseCompressor):
             if w is None:
                 cls.decompress_module(m)
                 continue
-            swap_direct_entries(m, (), {"weight": w}, QuantizationStatus.DECOMPRESSED)
+            swap_direct_entries(m, ("weight",), {"weight": w}, QuantizationStatus.DECOMPRESSED)  # (popped and re-added by `decompress`: last, as upstream leaves it)
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

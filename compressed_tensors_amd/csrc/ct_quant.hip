@@ -1270,10 +1270,26 @@ __global__ __launch_bounds__(kBlock) void f8_dequant_kernel(W4Params p) {
 // naive_quantized/base.py:48-126).  Same table type; `group` = number of consecutive elements of the row-major stream that
 // share one scale: cols (channel), a divisor of cols (group) or rows * cols (tensor).  Zero points: int8 or none.
 // ------------------------------------------------------------------------------------------
+// the 8-bit tables' reading of an item: as batch_params, plus the block strategy (group < 0 in the caller's table: scale[r / bh][c / bw], the FP8-block
+// checkpoints' layout, forward.py:198-216).  ct_q8_batch_plan leaves log2(bh) + 1 in `main_blocks` (0: not a block item; the 8-bit tables have no
+// zero-point tail) and the multiply-high for n / (units per row) in g_magic / g_shift; bh and bw are powers of two, so the other two quotients are shifts.
+__device__ __forceinline__ W4Params q8_batch_params(const ct_w4_item& it) {
+    W4Params p = batch_params(it);
+    if (it.main_blocks > 0) {
+        const int L = (int)it.main_blocks - 1;
+        p.flat_scale = 0;
+        p.nf_fast = 1;
+        p.upr_magic = it.g_magic; p.upr_shift = it.g_shift;
+        p.rdiv = (int64_t)1 << L; p.rdiv_magic = 0x80000000u; p.rdiv_shift = 31 + L;  // n >> L as a multiply-high
+        p.scale_cols = p.upr >> p.upg_shift;
+    }
+    return p;
+}
+
 template <int DT, bool FP8>
 __global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int qmin, int qmax, int zdt) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
-    W4Params p = batch_params(it);
+    W4Params p = q8_batch_params(it);
     p.zdt = zdt;  // int8, or the float8 zero points a calibrated FLOAT scheme carries (round 6)
     const int64_t g = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
     if (g >= p.units / 2) return;
@@ -1289,7 +1305,7 @@ __global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item
 template <int DT, bool FP8>
 __global__ __launch_bounds__(kBlock) void q8_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride, int zdt) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
-    W4Params p = batch_params(it);
+    W4Params p = q8_batch_params(it);
     p.zdt = zdt;
     const int64_t first = ((int64_t)blockIdx.x - it.first_block) * kBlock * kBatchUnroll * kBatchIter;
     const int64_t limit = (first + stride * kBatchIter < p.units) ? first + stride * kBatchIter : p.units;
@@ -2309,6 +2325,30 @@ int64_t ct_q8_batch_plan(ct_w4_item* items, int n, int direction) {
     for (int i = 0; i < n; ++i) {
         ct_w4_item& it = items[i];
         const int64_t numel = it.rows * it.cols;
+        it.main_blocks = 0;
+        if (it.group < 0) {  // block strategy: -group = (rows per block << 24) | columns per block
+            const int64_t bh = (-it.group) >> 24, bw = (-it.group) & 0xffffff;
+            const bool okb = it.rows > 0 && it.cols > 0 && bh >= 1 && bw >= 16 && (bh & (bh - 1)) == 0 && (bw & (bw - 1)) == 0 && it.cols % bw == 0 && it.src && it.scale && it.dst &&
+                             aligned16(it.src) && aligned16(it.dst) && numel / 8 < ((int64_t)1 << 31);
+            if (!okb) {
+                set_error("ct_q8_batch_plan: item %d (rows %lld, cols %lld, block %lld x %lld) is not eligible for the batched 8-bit path (block sides must be powers of "
+                          "two, the width >= 16 and a divisor of cols, fewer than 2^34 elements, 16-byte aligned buffers)", i, (long long)it.rows, (long long)it.cols,
+                          (long long)bh, (long long)bw);
+                return -1;
+            }
+            it.units = numel / 8;
+            it.upg = (int32_t)(bw / 8);
+            it.upg_shift = log2_exact(it.upg);
+            it.main_blocks = log2_exact(bh) + 1;
+            const int64_t upr = it.cols / 8;  // n / upr as (n * magic) >> shift, exact for n < 2^31 (Granlund-Montgomery, N = 31)
+            int L = 0;
+            while (((int64_t)1 << L) < upr) ++L;
+            it.g_shift = 31 + L;
+            it.g_magic = (uint32_t)((((uint64_t)1 << it.g_shift) + (uint64_t)(upr - 1)) / (uint64_t)upr);
+            it.first_block = blocks;
+            blocks += direction == 0 ? cdiv64(it.units / 2, kBlock) : cdiv64(it.units, (int64_t)kBlock * kBatchUnroll * kBatchIter);
+            continue;
+        }
         const bool whole = it.rows > 0 && it.cols > 0 && it.group >= numel;  // per tensor
         const int64_t g = whole ? numel : ((it.group <= 0 || it.group > it.cols) ? it.cols : it.group);
         const bool ok = it.rows > 0 && it.cols > 0 && it.cols % 16 == 0 && g % 16 == 0 && (whole || it.cols % g == 0) && it.src && it.scale && it.dst &&

@@ -419,8 +419,9 @@ void w4_finish_decompress(py::list jobs, py::object status) {
 // `ct_q8_quant_batch` / `ct_q8_dequant_batch` from the modules' own entries, launch, rewrite the dictionaries under the kernel.  Mirrors
 // NaiveQuantizationCompressor._batch_compress / _batch_decompress and codec.q8_batch_group (the Python loop: 7-9 us per module and direction, which a
 // 1B-parameter FP8 checkpoint's modules do not hide).
-// compress infos[i]: group_size (bits 0-19; 0 = none) | num_bits << 20 | FLOAT << 24 | strategy << 25 (0 tensor, 1 channel, 2 group) |
-//                    drop mask << 27 (bit 0 weight_zero_point, 1 input_zero_point, 2 output_zero_point: the zero points a symmetric scheme does not store), or < 0
+// compress infos[i]: group_size (bits 0-19; 0 = none; the block width of a block scheme) | num_bits << 20 | FLOAT << 24 | strategy << 25 (0 tensor, 1 channel,
+//                    2 group, 3 block) | drop mask << 27 (bit 0 weight_zero_point, 1 input_zero_point, 2 output_zero_point: the zero points a symmetric scheme does
+//                    not store) | block height << 30, or < 0
 // batch key: (device index, dtype code | kind << 4 | num_bits << 8), kind 0 int8, 1 fp8, 2 fp8 with float8 zero points
 // ------------------------------------------------------------------------------------------
 PyObject* g_input_zero_point = nullptr;
@@ -428,7 +429,7 @@ PyObject* g_output_zero_point = nullptr;
 
 // codec.q8_batch_group: elements per scale, or 0.  strategy < 0: inferred from the scale's shape (forward.py:99-130)
 int64_t q8_group(int64_t rows, int64_t cols, const at::Tensor& scale, const at::Tensor* zp, at::ScalarType wdt, const at::Device& dev, int strategy, int64_t group_size,
-                 bool f8z) {
+                 bool f8z, int64_t block_rows = 0) {
     if (!half_type(wdt) || scale.scalar_type() != wdt || scale.device() != dev || !scale.is_contiguous() || !aligned16(scale)) return 0;
     if (rows <= 0 || cols % 16) return 0;
     int64_t group = 0;
@@ -437,8 +438,20 @@ int64_t q8_group(int64_t rows, int64_t cols, const at::Tensor& scale, const at::
     else if (scale.dim() == 2 && scale.size(0) == rows && scale.size(1) > 1 && cols % scale.size(1) == 0 && (strategy < 0 || strategy == 2)) {
         group = cols / scale.size(1);
         if (strategy == 2 && group_size && group_size != group) return 0;
+    } else if (scale.dim() == 2 && (strategy < 0 || strategy == 3) && scale.size(0) >= 1 && scale.size(1) >= 1) {
+        // block strategy: the table's group is -((rows per block << 24) | columns per block) (include/ct_hip.h)
+        int64_t bh = block_rows, bw = group_size;
+        if (strategy < 0) {
+            if (rows % scale.size(0) || cols % scale.size(1)) return 0;
+            bh = rows / scale.size(0);
+            bw = cols / scale.size(1);
+        }
+        if (bh < 1 || bw < 16 || (bh & (bh - 1)) || (bw & (bw - 1)) || bh >= (int64_t(1) << 24) || bw >= (int64_t(1) << 24) || cols % bw ||
+            rows * cols >= (int64_t(1) << 34) || scale.size(0) != (rows + bh - 1) / bh || scale.size(1) != cols / bw)
+            return 0;
+        group = -((bh << 24) | bw);
     } else return 0;
-    if (group % 16) return 0;
+    if (group > 0 && group % 16) return 0;
     if (zp && (zp->scalar_type() != (f8z ? at::kFloat8_e4m3fn : at::kChar) || zp->sizes() != scale.sizes() || zp->device() != dev || !zp->is_contiguous())) return 0;
     return group;
 }
@@ -454,6 +467,7 @@ py::tuple q8_plan_compress(py::list modules, py::object infos_arg) {
         const int64_t info = infos.of(m, i);
         const int64_t group_size = info & 0xfffff;
         const int bits = (int)((info >> 20) & 15), strategy = (int)((info >> 25) & 3), dropmask = (int)((info >> 27) & 7);
+        const int64_t block_rows = (info >> 30) & 0xfffff;
         const bool is_float = ((info >> 24) & 1) != 0;
         Entries e;
         bool ok = info >= 0 && plain_type(m) && e.open(m);
@@ -470,8 +484,8 @@ py::tuple q8_plan_compress(py::list modules, py::object infos_arg) {
         if (ok) {
             f8z = is_float && zp && zp->scalar_type() == at::kFloat8_e4m3fn;
             ok = !(is_float && zp && !f8z);
-            if (ok) group = q8_group(w->size(0), w->size(1), *scale, zp, w->scalar_type(), w->device(), strategy, group_size, f8z);
-            ok = ok && group > 0 &&
+            if (ok) group = q8_group(w->size(0), w->size(1), *scale, zp, w->scalar_type(), w->device(), strategy, group_size, f8z, block_rows);
+            ok = ok && group != 0 &&
                  staying_entries_are_final(e, {N.weight, (dropmask & 1) ? N.weight_zero_point : N.weight, (dropmask & 2) ? g_input_zero_point : N.weight,
                                                (dropmask & 4) ? g_output_zero_point : N.weight});
         }
@@ -495,7 +509,7 @@ py::tuple q8_plan_compress(py::list modules, py::object infos_arg) {
     return py::make_tuple(batches_to_python(batches), rest);
 }
 
-// after the launch: the codes take the place of `weight` (same dictionary position, as swap_direct_entries), a symmetric scheme's zero points leave
+// after the launch: the codes replace `weight` (re-added last, as swap_direct_entries with `weight` among the removed names), a symmetric scheme's zero points leave
 void q8_finish(py::list jobs, py::object status) {
     touch_tls();
     const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
@@ -509,6 +523,7 @@ void q8_finish(py::list jobs, py::object status) {
         if (dropmask & 1) drop(e.params, N.weight_zero_point);
         if (dropmask & 2) drop(e.params, g_input_zero_point);
         if (dropmask & 4) drop(e.params, g_output_zero_point);
+        drop(e.params, N.weight);  // `compress` / `decompress` pop `weight` and add the result last (naive_quantized/base.py:62-126): it ends up behind the entries that stay
         PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
         set_status(m, status.ptr());
     }
@@ -542,7 +557,7 @@ py::tuple q8_plan_decompress(py::list modules, py::object infos_arg) {
             ok = kind >= 0 && !(kind == 1 && zp && !f8z);
             if (f8z) kind = 2;
             if (ok) group = q8_group(q->size(0), q->size(1), *scale, zp, scale->scalar_type(), q->device(), -1, 0, f8z);
-            ok = ok && group > 0 && staying_entries_are_final(e, {N.weight});
+            ok = ok && group != 0 && staying_entries_are_final(e, {N.weight});
         }
         if (!ok) {
             rest.append(py::reinterpret_borrow<py::object>(m));

@@ -243,8 +243,10 @@ int ct_zp4_pack_dim0_batch(const ct_w4_item* items_dev, int n, int64_t total_blo
 /* Batched 8-bit codecs (Naive / Int / FloatQuantizationCompressor.compress / decompress, compressors/naive_quantized/
  * base.py:48-126, looped per module by model_compressor.py:167-169,196-198): quantize to int8 (num_bits <= 8, clamped to the
  * num_bits range) or float8_e4m3fn, and the inverse, for a whole table of 16-bit tensors in one launch.  Same table type and
- * protocol as the W4 batch; `group` counts the consecutive elements that share one scale: <= 0 or cols (one per row), a
- * divisor of cols, or >= rows * cols (one per tensor).  Needs cols % 16 == 0 and group % 16 == 0; zero points int8 or NULL —
+ * protocol as the W4 batch; `group` counts the consecutive elements that share one scale: 0 or cols (one per row), a
+ * divisor of cols, or >= rows * cols (one per tensor); a NEGATIVE group is the block strategy (forward.py:198-216, the FP8-block
+ * checkpoints): -group = (rows per block << 24) | columns per block, both powers of two, the width >= 16 and a divisor of cols,
+ * scale / zero point of shape (ceil(rows / block rows), cols / block columns).  Needs cols % 16 == 0 and group % 16 == 0; zero points int8 or NULL —
  * `fp8` = 2 (round 6): float8 codes whose zero points are float8_e4m3fn bytes (what a calibrated FLOAT scheme carries; 1: int8 or none).
  * direction: 0 = quantize (src = weights, dst = codes), 1 = dequantize (src = codes, dst = weights). */
 int64_t ct_q8_batch_plan(ct_w4_item* items_host, int n, int direction);

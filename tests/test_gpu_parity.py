@@ -1983,6 +1983,87 @@ def test_q8_batch_vs_oracle(cta, dev):
         cta.codec.W4Batch([(x, x, None, x, 8, 24, 24)], "compress", BF16, kind="int8")
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("kind", ["fp8", "fp8z", "int8"])
+def test_q8_batch_block_strategy_vs_oracle(cta, dev, dtype, kind):
+    """block-strategy items (FP8-block checkpoints: scale[r // bh][c // bw], forward.py:198-216) in the 8-bit tables — group = -((bh << 24) | bw) — mixed with
+    channel / group items in ONE launch, against the oracle: blocks 128 x 128, 64 x 128, 16 x 32, 1 x 16, row counts that are not a multiple of the block height,
+    with zero points (float8 for FLOAT, int8 for INT) and without; then the class paths: compress_modules / decompress_modules of block-scheme modules through the C++ host
+    loop against the per-module calls, and the layout the table refuses"""
+    g = torch.Generator().manual_seed(5)
+    qtype = "int" if kind == "int8" else "float"
+    qdt = torch.int8 if kind == "int8" else F8
+    entries, dent, refs = [], [], []
+    cases = ((256, 512, (128, 128)), (200, 256, (64, 128)), (48, 96, (16, 32)), (5, 64, (1, 16)), (40, 256, None), (1024, 1024, (128, 128)), (130, 384, (128, 128)), (64, 512, 64))
+    for rows, cols, blk in cases:
+        w = (torch.randn(rows, cols, generator=g) * 2).to(dtype)
+        if isinstance(blk, tuple):
+            bh, bw = blk
+            sshape = (-(-rows // bh), cols // bw)
+            strategy, gs, block = "block", None, [bh, bw]
+            group = -((bh << 24) | bw)
+        elif blk is None:
+            sshape, strategy, gs, block, group = (rows, 1), "channel", None, None, cols
+        else:
+            sshape, strategy, gs, block, group = (rows, cols // blk), "group", blk, None, blk
+        scale = (torch.rand(sshape, generator=g) * 0.05 + 0.003).to(dtype)
+        zp = None if kind == "fp8" else ((torch.randn(sshape, generator=g) * 3).to(F8) if kind == "fp8z" else torch.randint(-20, 20, sshape, generator=g, dtype=torch.int8))
+        kw = dict(num_bits=8, strategy=strategy, group_size=gs, block_structure=block, qtype=qtype)
+        q_ref = O.quantize(w, scale, zp, dtype=qdt, **kw)
+        d_ref = O.dequantize(q_ref, scale, zp, strategy=strategy, group_size=gs, block_structure=block)
+        wd, sd_, zd = w.to(dev), scale.to(dev), d(zp, dev)
+        assert cta.codec.q8_batch_group(w.shape, dtype, sd_, zd, device=dev, strategy=strategy, group_size=gs, block_structure=block, f8_zero_point=kind == "fp8z") == group
+        if strategy == "block" and rows % block[0] == 0 and block[0] > 1:  # the layout is also inferred from the scale's shape, as `dequantize` does (1-row blocks read as groups)
+            assert cta.codec.q8_batch_group(w.shape, dtype, sd_, zd, device=dev, f8_zero_point=kind == "fp8z") == group
+        q = torch.empty((rows, cols), dtype=qdt, device=dev)
+        out = torch.empty((rows, cols), dtype=dtype, device=dev)
+        entries.append((wd, sd_, zd, q, rows, cols, group))
+        dent.append((q, sd_, zd, out, rows, cols, group))
+        refs.append((q_ref, d_ref))
+    cta.codec.W4Batch(entries, "compress", dtype, kind=kind, bits=8).launch()
+    cta.codec.W4Batch(dent, "decompress", dtype, kind=kind).launch()
+    for (wd, sd_, zd, q, rows, cols, group), (q2, sd2, zd2, out, *_), (q_ref, d_ref) in zip(entries, dent, refs):
+        assert eq_f8(q.cpu(), q_ref) if qdt is F8 else torch.equal(q.cpu(), q_ref), (rows, cols, group)
+        assert eq(out.cpu(), d_ref), (rows, cols, group)
+    x = torch.zeros(96, 96, dtype=dtype, device=dev)
+    with pytest.raises(ValueError, match="not eligible"):  # a block width that is not a power of two
+        cta.codec.W4Batch([(x, x, None, x, 96, 96, -((32 << 24) | 48))], "compress", dtype, kind="int8")
+    assert cta.codec.q8_batch_group((96, 96), dtype, torch.ones(3, 2, dtype=dtype, device=dev), None, device=dev, strategy="block", block_structure=[32, 48]) is None
+    # the class paths
+    wa = cta.QuantizationArgs(num_bits=8, type=qtype, strategy="block", block_structure=[128, 128], symmetric=kind != "int8")
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=cta.QuantizationArgs(num_bits=8, type=qtype, strategy="tensor", symmetric=True, dynamic=True))
+    klass = cta.BaseCompressor.get_value_from_registry("float-quantized" if qtype == "float" else "int-quantized")
+
+    def modules():
+        ms = []
+        for k, (rows, cols) in enumerate(((256, 512), (1024, 1024), (130, 384), (128, 128))):
+            gk = torch.Generator().manual_seed(100 + k)
+            lin = torch.nn.Linear(cols, rows, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter((torch.randn(rows, cols, generator=gk) * 2).to(dtype).to(dev), requires_grad=False)
+            sshape = (-(-rows // 128), cols // 128)
+            lin.weight_scale = torch.nn.Parameter((torch.rand(sshape, generator=gk) * 0.05 + 0.003).to(dtype).to(dev), requires_grad=False)
+            if kind != "fp8":
+                zp = torch.zeros(sshape, dtype=F8) if kind == "fp8z" else torch.randint(-20, 20, sshape, generator=gk, dtype=torch.int8)
+                lin.weight_zero_point = torch.nn.Parameter(zp.to(dev), requires_grad=False)
+            lin.quantization_scheme = scheme
+            ms.append(lin)
+        return ms
+
+    a, b = modules(), modules()
+    for direction in ("compress", "decompress"):
+        getattr(klass, direction + "_modules")(a)
+        for m in b:
+            getattr(klass, direction + "_module")(m)
+        for x_, y_ in zip(a, b):
+            assert list(x_._parameters) == list(y_._parameters)
+            for name, tx in x_._parameters.items():
+                ty = y_._parameters[name]
+                if tx is None or ty is None:
+                    assert tx is ty
+                    continue
+                assert tx.dtype == ty.dtype and (eq_f8(tx.data.cpu(), ty.data.cpu()) if tx.dtype is F8 else eq(tx.data.cpu(), ty.data.cpu())), (direction, name)
+
+
 def test_w4_batch_vs_oracle(cta, dev):
     """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
     for dtype in (BF16, F16):

@@ -1002,7 +1002,7 @@ def test_cpp_host_loop_of_the_8bit_codecs_matches_the_python_loop(cta, monkeypat
             assert singles["cpp"] == singles["py"]
             # the C++ loop took the plain modules itself; a module with a trainable entry that stays, a buffer, a class with its own __setattr__, activation
             # ordering, a block layout or float32 weights went back to the Python loop
-            expect_native = {"trainable_scale": 4 if direction == "compress" else 5, "buffer_zp": 4 if direction == "compress" else 5, "odd_class": 4, "g_idx": 4, "block": 0, "float32": 0,
+            expect_native = {"trainable_scale": 4 if direction == "compress" else 5, "buffer_zp": 4 if direction == "compress" else 5, "odd_class": 4, "g_idx": 4, "block": 5, "float32": 0,
                              "int8_asymmetric_group": 4 if direction == "compress" else 5}.get(variant, 5)  # (96 x 128 in groups of 128: a (96, 1) scale)
             assert native[direction] == expect_native, (variant, direction, native)
     finally:

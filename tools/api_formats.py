@@ -14,6 +14,10 @@ def build(layer_shapes, nlayers, fmt):
     g = torch.Generator(device=dev).manual_seed(1)
     if fmt == "fp8":
         args = cta.QuantizationArgs(num_bits=8, type="float", strategy="channel", symmetric=True)
+    elif fmt == "fp8blk":  # block 128 x 128 (the FP8-block checkpoints' layout)
+        args = cta.QuantizationArgs(num_bits=8, type="float", strategy="block", block_structure=[128, 128], symmetric=True)
+    elif fmt == "w4asym":
+        args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, strategy="group")
     elif fmt == "nvfp4":
         args = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8)
     elif fmt == "mxfp4":
@@ -33,6 +37,12 @@ def build(layer_shapes, nlayers, fmt):
             if fmt == "fp8":
                 s = codec.minmax_qparams_float(w, kind="fp8"); z = torch.zeros(s.shape, dtype=F8, device=dev)
                 alg += 2 * (3 * r * c)
+            elif fmt == "fp8blk":
+                s = (w.float().reshape(r // 128, 128, c // 128, 128).abs().amax(dim=(1, 3)) / 448.0).to(torch.bfloat16); z = torch.zeros(s.shape, dtype=F8, device=dev)
+                alg += 2 * (3 * r * c)
+            elif fmt == "w4asym":
+                s, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=False)
+                alg += 2 * int(2.5 * r * c)
             elif fmt == "nvfp4":
                 gs = codec.generate_gparam(w); s = codec.minmax_qparams_float(w, kind="nvfp4", group_size=16, global_scale=gs); z = None
                 lin.weight_global_scale = torch.nn.Parameter(gs, requires_grad=False)
@@ -50,7 +60,7 @@ def build(layer_shapes, nlayers, fmt):
     return root, alg
 
 for name, shapes, nl in (("tinyllama 154 modules", TINY, 22), ("llama-8B-shaped 112 modules", L8B, 16)):
-    for fmt in ("w4", "fp8", "nvfp4", "mxfp4"):
+    for fmt in os.environ.get("FORMATS", "w4,w4asym,fp8,fp8blk,nvfp4,mxfp4").split(","):
         model, alg = build(shapes, nl, fmt)
         mc = cta.ModelCompressor()
         def cycle():
