@@ -57,6 +57,40 @@ def _plain_w4_scheme(scheme):
     return False, -1, False
 
 
+def _w8_info(scheme) -> int:
+    """csrc/host/ct_hostpath.cpp w8_plan_compress / w8_plan_decompress: a symmetric weights-only int8 scheme (the W8A16 preset) -> group size | strategy << 25,
+    else -1 (asymmetric 8-bit schemes store packed zero points and stay with the Python loop)"""
+    wa = scheme.weights
+    if (wa is None or getattr(scheme, "input_activations", None) is not None or getattr(scheme, "output_activations", None) is not None
+            or int(wa.num_bits) != 8 or enum_value(getattr(wa, "type", "int")) != "int" or not wa.symmetric or enum_value(getattr(wa, "actorder", None)) == "group"):
+        return -1
+    st = enum_value(wa.strategy)
+    if st not in ("tensor", "channel", "group"):
+        return -1
+    gs = int(getattr(wa, "group_size", None) or 0) if st == "group" else 0
+    if not 0 <= gs < (1 << 20):
+        return -1
+    return gs | ({"tensor": 0, "channel": 1, "group": 2}[st] << 25)
+
+
+def _native_w8(hp, modules, direction: str, status):
+    """the 8-bit pack-quantized modules of `modules` through the C++ loop and the 8-bit tables' packed kind (one launch per window); returns the rest"""
+    if not hasattr(hp, "w8_plan_compress") or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 0) or 0) == 8 for m in modules):
+        return modules
+    plan, finish = (hp.w8_plan_compress, hp.w4_finish_compress) if direction == "compress" else (hp.w8_plan_decompress, hp.w4_finish_decompress)
+    rest, pending = [], []
+    for lo, hi in _launch_chunks(len(modules)):
+        planned, back = plan(modules[lo:hi], _w8_info)
+        rest += back
+        for (dev_index, code), (words, n, jobs, _zw, _zn) in planned.items():
+            device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
+            codec.launch_q8_words(words, n, direction, _DTYPE_OF_CODE[code & 15], device, (code >> 4) & 15, code >> 8)
+            pending.append(jobs)
+    for jobs in pending:
+        finish(jobs, status)
+    return rest
+
+
 _ASYMMETRIC = 1 << 40  # csrc/host/ct_hostpath.cpp: kAsymmetric
 
 
@@ -213,7 +247,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
             # the plain case — int4 group / channel, parameters only, nn.Module's own attribute hooks — in C++: table rows, output allocations
             # and, after the launch, the parameter dictionaries; whatever it does not take comes back in `modules`
-            modules = list(modules)
+            modules = _native_w8(hp, list(modules), "compress", QuantizationStatus.COMPRESSED)
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):  # the first launch leaves after a fifth of the planning, not after all of it
                 planned, back = hp.w4_plan_compress(modules[lo:hi], _compress_info)  # (asked once per distinct scheme object and chunk)
@@ -365,6 +399,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         modules = list(modules)
         hp = _hostpath()
         if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
+            modules = _native_w8(hp, modules, "decompress", QuantizationStatus.DECOMPRESSED)
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):
                 planned, back = hp.w4_plan_decompress(modules[lo:hi], _decompress_info)

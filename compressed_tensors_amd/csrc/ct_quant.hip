@@ -1286,7 +1286,7 @@ __device__ __forceinline__ W4Params q8_batch_params(const ct_w4_item& it) {
     return p;
 }
 
-template <int DT, bool FP8>
+template <int DT, bool FP8, int OFF = 0 /* 128: the codes are stored + 128, four to an int32 word (pack-quantized 8-bit, pack_to_int32) */>
 __global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int qmin, int qmax, int zdt) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
     W4Params p = q8_batch_params(it);
@@ -1297,12 +1297,12 @@ __global__ __launch_bounds__(kBlock) void q8_quant_batch_kernel(const ct_w4_item
         if (p.zp) f8_quant_lane<DT, true, true>(p, g);
         else f8_quant_lane<DT, false, true>(p, g);
     } else {
-        if (p.zp) q8_quant_lane<DT, true, true, 0>(p, g, qmin, qmax);
-        else q8_quant_lane<DT, false, true, 0>(p, g, qmin, qmax);
+        if (p.zp) q8_quant_lane<DT, true, true, OFF>(p, g, qmin, qmax);
+        else q8_quant_lane<DT, false, true, OFF>(p, g, qmin, qmax);
     }
 }
 
-template <int DT, bool FP8>
+template <int DT, bool FP8, int OFF = 0>
 __global__ __launch_bounds__(kBlock) void q8_dequant_batch_kernel(const ct_w4_item* __restrict__ items, int n, int64_t stride, int zdt) {
     const ct_w4_item& it = batch_find(items, n, blockIdx.x);
     W4Params p = q8_batch_params(it);
@@ -1313,12 +1313,12 @@ __global__ __launch_bounds__(kBlock) void q8_dequant_batch_kernel(const ct_w4_it
     if (p.zp) {
         for (int64_t b = first + threadIdx.x; b < limit; b += stride) {
             if constexpr (FP8) f8_dequant_units<DT, kBatchUnroll, true>(p, b);
-            else q8_dequant_units<DT, kBatchUnroll, true, 0>(p, b);
+            else q8_dequant_units<DT, kBatchUnroll, true, OFF>(p, b);
         }
     } else {
         for (int64_t b = first + threadIdx.x; b < limit; b += stride) {
             if constexpr (FP8) f8_dequant_units<DT, kBatchUnroll, false>(p, b);
-            else q8_dequant_units<DT, kBatchUnroll, false, 0>(p, b);
+            else q8_dequant_units<DT, kBatchUnroll, false, OFF>(p, b);
         }
     }
 }
@@ -2381,12 +2381,19 @@ int64_t ct_q8_batch_plan(ct_w4_item* items, int n, int direction) {
 int ct_q8_quant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, int fp8, int bits, ct_stream_t stream) {
     CT_REQUIRE(dt == CT_BF16 || dt == CT_F16, "batched 8-bit path: 16-bit weights only, got dtype %d", dt);
     CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
-    CT_REQUIRE(fp8 || (bits >= 1 && bits <= 8), "num_bits must be in [1, 8], got %d", bits);
+    CT_REQUIRE((fp8 == 1 || fp8 == 2) || (bits >= 1 && bits <= 8), "num_bits must be in [1, 8], got %d", bits);
     if (n == 0 || total_blocks == 0) return CT_OK;
-    const int qmin = fp8 ? 0 : -(1 << (bits - 1)), qmax = fp8 ? 0 : (1 << (bits - 1)) - 1;
-    CT_REQUIRE(fp8 >= 0 && fp8 <= 2, "fp8 must be 0 (int8 codes), 1 (float8 codes, int8 zero points) or 2 (float8 codes, float8 zero points), got %d", fp8);
+    const bool f8codes = fp8 == 1 || fp8 == 2;
+    const int qmin = f8codes ? 0 : -(1 << (bits - 1)), qmax = f8codes ? 0 : (1 << (bits - 1)) - 1;
+    CT_REQUIRE(fp8 >= 0 && fp8 <= 3, "fp8 must be 0 (int8 codes), 1 (float8 codes, int8 zero points), 2 (float8 codes, float8 zero points) or 3 (int8 codes + 128 in int32 words), got %d", fp8);
     const int zdt = fp8 == 2 ? CT_F8E4M3 : CT_I8;
     const dim3 grid((unsigned)total_blocks);
+    if (fp8 == 3) {  // pack-quantized 8-bit (pack_to_int32 of 8-bit codes, helpers.py:39-75): dst = int32 (rows, cols / 4)
+        CT_REQUIRE(bits == 8, "packed 8-bit words need num_bits == 8, got %d", bits);
+        if (dt == CT_BF16) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, false, 128>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
+        else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_F16, false, 128>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
+        CT_LAUNCH_CHECK("ct_q8_quant_batch[packed]");
+    }
     if (dt == CT_BF16) {
         if (fp8) hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
         else hipLaunchKernelGGL((q8_quant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, qmin, qmax, zdt);
@@ -2402,9 +2409,14 @@ int ct_q8_dequant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks
     CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
     if (n == 0 || total_blocks == 0) return CT_OK;
     const int64_t stride = (int64_t)kBlock * kBatchUnroll;
-    CT_REQUIRE(fp8 >= 0 && fp8 <= 2, "fp8 must be 0, 1 or 2 (float8 codes with float8 zero points), got %d", fp8);
+    CT_REQUIRE(fp8 >= 0 && fp8 <= 3, "fp8 must be 0, 1, 2 (float8 codes with float8 zero points) or 3 (int8 codes + 128 in int32 words), got %d", fp8);
     const int zdt = fp8 == 2 ? CT_F8E4M3 : CT_I8;
     const dim3 grid((unsigned)total_blocks);
+    if (fp8 == 3) {
+        if (dt == CT_BF16) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, false, 128>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
+        else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_F16, false, 128>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
+        CT_LAUNCH_CHECK("ct_q8_dequant_batch[packed]");
+    }
     if (dt == CT_BF16) {
         if (fp8) hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, true>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);
         else hipLaunchKernelGGL((q8_dequant_batch_kernel<CT_BF16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n, stride, zdt);

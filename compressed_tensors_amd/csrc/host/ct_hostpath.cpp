@@ -1058,6 +1058,102 @@ int dtype_code(at::ScalarType t) {
     }
 }
 
+// pack-quantized with num_bits = 8 and a symmetric weights-only scheme (the W8A16 preset; reference compressors/pack_quantized/base.py:62-163): the codes are
+// the 8-bit tables' kind 3 (int8 + 128, four to an int32 word = pack_to_int32), the entries are the W4 ones (weight -> weight_packed + weight_shape), so the
+// jobs go to w4_finish_compress / w4_finish_decompress.  infos[i]: group_size | strategy << 25 (0 tensor, 1 channel, 2 group), or < 0.
+// batch key: (device index, dtype code | 3 << 4 | 8 << 8), as the 8-bit tables.
+py::tuple w8_plan_compress(py::list modules, py::object infos_arg) {
+    touch_tls();
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        Entries e;
+        bool ok = info >= 0 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
+        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
+        int64_t group = 0;
+        if (ok) {
+            w = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            zp = e.tensor(N.weight_zero_point);
+            // (a `weight_shape` left by an earlier decompress is overwritten in place, as in the W4 loop)
+            ok = w && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && !e.has(N.weight_packed) && w->dim() == 2 &&
+                 (w->is_cuda() || g_allow_cpu) && w->is_contiguous() && aligned16(*w) && w->size(1) % 32 == 0;
+        }
+        if (ok) {
+            group = q8_group(w->size(0), w->size(1), *scale, zp, w->scalar_type(), w->device(), (int)((info >> 25) & 3), info & 0xfffff, false);
+            ok = group > 0 && staying_entries_are_final(e, {N.weight, N.weight_zero_point});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        const int64_t rows = w->size(0), cols = w->size(1);
+        at::Tensor packed = at::empty({rows, cols / 4}, w->options().dtype(at::kInt));
+        Batch& b = batches[{w->is_cuda() ? (int)w->device().index() : -1, (w->scalar_type() == at::kHalf ? 1 : 2) | (3 << 4) | (8 << 8)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)packed.data_ptr(), rows, cols, group, 0, 0, 0, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
+        PyObject* zp_obj = zp ? PyDict_GetItem(e.params, N.weight_zero_point) : Py_None;
+        // w4_finish_compress's job: (module, packed, rows, cols, keep-alive weight, zp_packed = None: the symmetric scheme's zero point is dropped, keep-alive zp)
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(packed)), rows, cols,
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)), py::none(), py::reinterpret_borrow<py::object>(zp_obj)));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+py::tuple w8_plan_decompress(py::list modules, py::object infos_arg) {
+    touch_tls();
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        Entries e;
+        bool ok = info >= 0 && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
+        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr;
+        int64_t rows = 0, cols = 0, group = 0;
+        if (ok) {
+            packed = e.tensor(N.weight_packed);
+            scale = e.tensor(N.weight_scale);
+            shape_t = e.tensor(N.weight_shape);
+            ok = packed && scale && shape_t && !e.has(N.weight_g_idx) && !e.has(N.weight_zero_point) && !e.has(N.weight) && (packed->is_cuda() || g_allow_cpu) &&
+                 packed->is_contiguous() && packed->scalar_type() == at::kInt && aligned16(*packed) && packed->dim() == 2 && shape_t->device().is_cpu() &&
+                 shape_t->scalar_type() == at::kLong && shape_t->numel() == 2 && shape_t->is_contiguous();
+        }
+        if (ok) {
+            rows = shape_t->data_ptr<int64_t>()[0];
+            cols = shape_t->data_ptr<int64_t>()[1];
+            ok = rows > 0 && cols > 0 && cols % 32 == 0 && packed->size(0) == rows && packed->size(1) == cols / 4;
+        }
+        if (ok) {
+            // the layout is read off the scale's shape, as upstream's argument-free dequantize call does (pack_quantized/base.py:156-161, forward.py:99-130)
+            group = q8_group(rows, cols, *scale, nullptr, scale->scalar_type(), packed->device(), -1, 0, false);
+            ok = group != 0 && staying_entries_are_final(e, {N.weight_packed});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        at::Tensor out = at::empty({rows, cols}, scale->options());
+        Batch& b = batches[{packed->is_cuda() ? (int)packed->device().index() : -1, (scale->scalar_type() == at::kHalf ? 1 : 2) | (3 << 4) | (8 << 8)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)packed->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), 0, (int64_t)(uintptr_t)out.data_ptr(), rows, cols, group,
+                                          0, 0, 0, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.n += 1;
+        // w4_finish_decompress's job: (module, out, keep-alive packed, zp = None, -)
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_packed)), py::none(), py::none()));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
 // ------------------------------------------------------------------------------------------
 // FP4 codecs (nvfp4-pack-quantized, group 16 under a global scale; mxfp4-pack-quantized, group 32; reference compressors/nvfp4/base.py:68-139,
 // mxfp4/base.py:27-65): NVFP4PackedCompressor.compress_modules / decompress_modules in C++, as the W4 and 8-bit loops above — the table of
@@ -1246,6 +1342,8 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("fp4_plan_compress", &fp4_plan_compress);
     mod.def("fp4_plan_decompress", &fp4_plan_decompress);
     mod.def("fp4_finish", &fp4_finish);
+    mod.def("w8_plan_compress", &w8_plan_compress);
+    mod.def("w8_plan_decompress", &w8_plan_decompress);
     mod.def("q8_plan_compress", &q8_plan_compress);
     mod.def("q8_plan_decompress", &q8_plan_decompress);
     mod.def("q8_finish", &q8_finish);

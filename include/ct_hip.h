@@ -247,7 +247,9 @@ int ct_zp4_pack_dim0_batch(const ct_w4_item* items_dev, int n, int64_t total_blo
  * divisor of cols, or >= rows * cols (one per tensor); a NEGATIVE group is the block strategy (forward.py:198-216, the FP8-block
  * checkpoints): -group = (rows per block << 24) | columns per block, both powers of two, the width >= 16 and a divisor of cols,
  * scale / zero point of shape (ceil(rows / block rows), cols / block columns).  Needs cols % 16 == 0 and group % 16 == 0; zero points int8 or NULL —
- * `fp8` = 2 (round 6): float8 codes whose zero points are float8_e4m3fn bytes (what a calibrated FLOAT scheme carries; 1: int8 or none).
+ * `fp8` = 2 (round 6): float8 codes whose zero points are float8_e4m3fn bytes (what a calibrated FLOAT scheme carries; 1: int8 or none);
+ * `fp8` = 3 (round 6): int8 codes stored + 128, four to an int32 word — the 8-bit words of pack_to_int32 (pack_quantized/helpers.py:39-75;
+ * PackedQuantizationCompressor with num_bits = 8, e.g. the W8A16 preset): dst / src = int32 (rows, cols / 4), cols % 32 == 0.
  * direction: 0 = quantize (src = weights, dst = codes), 1 = dequantize (src = codes, dst = weights). */
 int64_t ct_q8_batch_plan(ct_w4_item* items_host, int n, int direction);
 int ct_q8_quant_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int dt, int fp8, int bits,

@@ -2064,6 +2064,56 @@ def test_q8_batch_block_strategy_vs_oracle(cta, dev, dtype, kind):
                 assert tx.dtype == ty.dtype and (eq_f8(tx.data.cpu(), ty.data.cpu()) if tx.dtype is F8 else eq(tx.data.cpu(), ty.data.cpu())), (direction, name)
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("strategy", ["channel", "group", "tensor"])
+def test_w8_pack_quantized_modules_through_the_tables(cta, dev, dtype, strategy):
+    """pack-quantized with num_bits = 8 (the W8A16 preset): compress_modules / decompress_modules — the C++ host loop and the 8-bit tables' packed kind
+    (int8 + 128, four codes to an int32 word) — against the per-module class calls (names, order, values) and against the oracle's pack_to_int32(quantize(...))
+    and dequantize"""
+    g = torch.Generator().manual_seed(21)
+    wa = cta.QuantizationArgs(num_bits=8, type="int", strategy=strategy, group_size=128 if strategy == "group" else None, symmetric=True)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa)
+    klass = cta.BaseCompressor.get_value_from_registry("pack-quantized")
+    shapes = [(256, 512), (1024, 1024), (130, 384), (7, 256), (64, 4096)]
+    ws = [(torch.randn(sh, generator=g) * 0.1).to(dtype) for sh in shapes]
+    for w in ws:
+        w.view(-1)[: special_values(dtype).numel()] = special_values(dtype)[: w.numel()]
+    ws = [torch.where(torch.isfinite(w), w, torch.zeros_like(w)) for w in ws]
+    qp = [O.calculate_qparams_minmax(w.reshape(1, -1) if strategy == "tensor" else w, num_bits=8, group_size=128 if strategy == "group" else None, symmetric=True) for w in ws]
+    qp = [(s_.reshape(1), z_.reshape(1)) if strategy == "tensor" else (s_, z_) for s_, z_ in qp]
+
+    def modules():
+        ms = []
+        for w, (s_, z_) in zip(ws, qp):
+            lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(w.clone().to(dev), requires_grad=False)
+            lin.weight_scale = torch.nn.Parameter(s_.clone().to(dev), requires_grad=False)
+            lin.weight_zero_point = torch.nn.Parameter(z_.clone().to(dev), requires_grad=False)
+            lin.quantization_scheme = scheme
+            ms.append(lin)
+        return ms
+
+    a, b = modules(), modules()
+    for direction in ("compress", "decompress"):
+        getattr(klass, direction + "_modules")(a)
+        for m in b:
+            getattr(klass, direction + "_module")(m)
+        for k, (x_, y_) in enumerate(zip(a, b)):
+            assert list(x_._parameters) == list(y_._parameters), (direction, shapes[k])
+            for name, tx in x_._parameters.items():
+                ty = y_._parameters[name]
+                if tx is None or ty is None:
+                    assert tx is ty
+                    continue
+                assert tx.dtype == ty.dtype and eq(tx.data.cpu(), ty.data.cpu()), (direction, shapes[k], name)
+            kw = dict(num_bits=8, strategy=strategy, group_size=128 if strategy == "group" else None)
+            q_ref = O.quantize(ws[k], qp[k][0], qp[k][1], dtype=torch.int8, **kw)
+            if direction == "compress":
+                assert torch.equal(x_.weight_packed.cpu(), O.pack_to_int32(q_ref, 8).contiguous()) and x_.weight_shape.tolist() == list(shapes[k])
+            else:
+                assert eq(x_.weight.data.cpu(), O.dequantize(q_ref, qp[k][0], None, **{k_: v for k_, v in kw.items() if k_ != "num_bits"}))
+
+
 def test_w4_batch_vs_oracle(cta, dev):
     """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
     for dtype in (BF16, F16):

@@ -1120,6 +1120,128 @@ def test_cpp_host_loop_of_the_fp4_codecs_matches_the_python_loop(cta, monkeypatc
         hp.set_allow_cpu(False)
 
 
+@pytest.mark.parametrize("variant", ["channel", "group", "tensor", "asymmetric", "trainable_scale", "odd_cols", "activations"])
+def test_cpp_host_loop_of_8bit_pack_quantized_matches_the_python_loop(cta, monkeypatch, variant):
+    """csrc/host/ct_hostpath.cpp w8_plan_compress / w8_plan_decompress (pack-quantized with num_bits = 8, symmetric, weights only — the W8A16 preset — on the
+    8-bit tables' packed kind, finished by the W4 finish functions) against the Python loop on CPU tensors with the launches stubbed out: same modules taken,
+    same table rows, every module left in the same state (names, order, kinds, shapes, dtypes, status)"""
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.compressors.pack_quantized import base as pq
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+
+    hp = ctlib.hostpath()
+    assert hp is not None and hasattr(hp, "w8_plan_compress"), "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    st = variant if variant in ("channel", "group", "tensor") else "channel"
+    wa = cta.QuantizationArgs(num_bits=8, type="int", strategy=st, group_size=128 if st == "group" else None, symmetric=variant != "asymmetric")
+    ia = cta.QuantizationArgs(num_bits=8, type="int", strategy="tensor", symmetric=True, dynamic=True) if variant == "activations" else None
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=ia)
+
+    def tree():
+        mods = []
+        for k, (r, c) in enumerate([(64, 256), (32, 512), (96, 128), (8, 264 if variant == "odd_cols" else 384)]):
+            lin = torch.nn.Linear(c, r, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=torch.bfloat16), requires_grad=True)
+            sshape = {"tensor": (1,), "channel": (r, 1), "group": (r, max(c // 128, 1))}[st]
+            lin.weight_scale = torch.nn.Parameter(torch.ones(sshape, dtype=torch.bfloat16), requires_grad=variant == "trainable_scale" and k == 2)
+            lin.weight_zero_point = torch.nn.Parameter(torch.zeros(sshape, dtype=torch.int8), requires_grad=False)
+            lin.quantization_scheme = scheme
+            mods.append(lin)
+        return mods
+
+    native = {"compress": [], "decompress": []}
+
+    def fake_words(words, n, direction, dtype, device, kind, bits=8):
+        assert kind == 3 and bits == 8 and dtype is torch.bfloat16
+        native[direction] += [tuple(r[4:7]) for r in words.reshape(n, codec._ITEM_WORDS).tolist()]
+
+    monkeypatch.setattr(codec, "launch_q8_words", fake_words)
+    monkeypatch.setattr(codec, "launch_w4_words", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "launch_zp4_words", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "quantize_and_pack_with_zp", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "unpack_and_dequantize_with_zp", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "pack_to_int32", lambda zp, bits, packed_dim=1: torch.zeros((zp.shape[0] * bits + 31) // 32, zp.shape[1], dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_from_int32", lambda p_, bits, shape, packed_dim=1: torch.zeros(tuple(shape), dtype=torch.int8))
+    monkeypatch.setattr(codec, "quantize_and_pack", lambda w, *a_, **k: torch.zeros(w.shape[0], -(-w.shape[1] * 8 // 32), dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_and_dequantize", lambda p_, shape, scale, *a_, **k: torch.zeros(tuple(shape), dtype=scale.dtype))
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    hp.set_allow_cpu(True)
+    try:
+        a, b = tree(), tree()
+        for direction, status in (("compress", QuantizationStatus.COMPRESSED), ("decompress", QuantizationStatus.DECOMPRESSED)):
+            getattr(pq.PackedQuantizationCompressor, direction + "_modules")(a)
+            monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
+            getattr(pq.PackedQuantizationCompressor, direction + "_modules")(b)
+            monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
+            for x, y in zip(a, b):
+                assert _module_state_no_ptr(x) == _module_state_no_ptr(y), (variant, direction)
+                assert x.quantization_status == status == y.quantization_status
+            expect = {"asymmetric": 0, "activations": 0, "trainable_scale": 3 if direction == "compress" else 4, "odd_cols": 3,
+                      "group": 3 if direction == "compress" else 4}.get(variant, 4)  # (96 x 128 in groups of 128: a (96, 1) scale — channel-wise by inference on the way back)
+            assert len(native[direction]) == expect, (variant, direction, native[direction])
+    finally:
+        hp.set_allow_cpu(False)
+
+
+@pytest.mark.parametrize("fmt", ["w8a16", "fp8", "fp8_block", "nvfp4", "mxfp4"])
+def test_cpp_host_loops_take_a_second_compress_after_a_decompress(cta, monkeypatch, fmt):
+    """compress -> decompress -> compress -> decompress of one tree (what a benchmark loop, or a model that is decompressed for fine-tuning and compressed again, does):
+    every module goes through the C++ loop in BOTH rounds — entries an earlier direction leaves behind (`weight_shape`, a bfloat16 scale) do not push the
+    module back to the interpreter — and the second round leaves the same entries as the first"""
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd import codec
+
+    hp = ctlib.hostpath()
+    assert hp is not None, "the host extension was not built"
+    F8 = torch.float8_e4m3fn
+    if fmt == "w8a16":
+        wa, sshape, zdt = cta.QuantizationArgs(num_bits=8, type="int", strategy="channel", symmetric=True), lambda r, c: (r, 1), torch.int8
+    elif fmt == "fp8":
+        wa, sshape, zdt = cta.QuantizationArgs(num_bits=8, type="float", strategy="channel", symmetric=True), lambda r, c: (r, 1), F8
+    elif fmt == "fp8_block":
+        wa, sshape, zdt = cta.QuantizationArgs(num_bits=8, type="float", strategy="block", block_structure=[16, 128], symmetric=True), lambda r, c: (r // 16, c // 128), F8
+    elif fmt == "nvfp4":
+        wa, sshape, zdt = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8), lambda r, c: (r, c // 16), None
+    else:
+        wa, sshape, zdt = cta.QuantizationArgs(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8), lambda r, c: (r, c // 32), None
+    ia = cta.QuantizationArgs(num_bits=8, type="float", strategy="tensor", symmetric=True, dynamic=True) if fmt.startswith("fp8") else None
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=ia)
+    if fmt in ("nvfp4", "mxfp4"):
+        scheme.format = fmt + "-pack-quantized"
+    root = torch.nn.Module()
+    root.blocks = torch.nn.ModuleList()
+    for r, c in [(64, 256), (32, 512), (96, 128)]:
+        lin = torch.nn.Linear(c, r, bias=False, device="meta")
+        lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=torch.bfloat16), requires_grad=True)
+        lin.weight_scale = torch.nn.Parameter(torch.ones(sshape(r, c), dtype=torch.bfloat16), requires_grad=False)
+        if zdt is not None:
+            lin.weight_zero_point = torch.nn.Parameter(torch.zeros(sshape(r, c), dtype=zdt), requires_grad=False)
+        if fmt == "nvfp4":
+            lin.weight_global_scale = torch.nn.Parameter(torch.ones(1), requires_grad=False)
+        lin.quantization_scheme = scheme
+        root.blocks.append(lin)
+    taken = []
+    monkeypatch.setattr(codec, "launch_q8_words", lambda words, n, direction, *a_, **k: taken.append((direction, n)))
+    monkeypatch.setattr(codec, "launch_fp4_words", lambda words, n, direction, *a_, **k: taken.append((direction, n)))
+    monkeypatch.setattr(codec, "_mx_code_table", lambda dt, dev: torch.zeros(65536, dtype=torch.uint8))
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    hp.set_allow_cpu(True)
+    try:
+        mc = cta.ModelCompressor()
+        states = []
+        for _ in range(2):
+            mc.compress_model(root)
+            states.append([_module_state_no_ptr(m) for m in root.blocks])
+            mc.decompress_model(root)
+            states.append([_module_state_no_ptr(m) for m in root.blocks])
+        assert [t for t in taken] == [("compress", 3), ("decompress", 3)] * 2, taken
+        # (same entries; `weight_shape`, which a decompress keeps, stays where it is in the second round — as upstream's compress, which assigns to the existing key)
+        norm = lambda st: [(sorted(p_, key=lambda kv: kv[0]), b_) for p_, b_ in st]
+        assert norm(states[0]) == norm(states[2]) and norm(states[1]) == norm(states[3])
+    finally:
+        hp.set_allow_cpu(False)
+
+
 def _module_state_no_ptr(m):
     return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
             [(k, None if v is None else (type(v).__name__, tuple(v.shape))) for k, v in m._buffers.items()])

@@ -18,6 +18,10 @@ def build(layer_shapes, nlayers, fmt):
         args = cta.QuantizationArgs(num_bits=8, type="float", strategy="block", block_structure=[128, 128], symmetric=True)
     elif fmt == "w4asym":
         args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, strategy="group")
+    elif fmt == "w8a16":  # the W8A16 preset: weight-only int8, channel-wise, stored pack-quantized
+        args = cta.QuantizationArgs(num_bits=8, symmetric=True, strategy="channel")
+    elif fmt == "w3":
+        args = cta.QuantizationArgs(num_bits=3, group_size=128, symmetric=True, strategy="group")
     elif fmt == "nvfp4":
         args = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8)
     elif fmt == "mxfp4":
@@ -43,6 +47,12 @@ def build(layer_shapes, nlayers, fmt):
             elif fmt == "w4asym":
                 s, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=False)
                 alg += 2 * int(2.5 * r * c)
+            elif fmt == "w8a16":
+                s, z = codec.minmax_qparams(w, num_bits=8, group_size=None, symmetric=True)
+                alg += 2 * (3 * r * c)
+            elif fmt == "w3":
+                s, z = codec.minmax_qparams(w, num_bits=3, group_size=128, symmetric=True)
+                alg += 2 * int((2 + 3 / 8) * r * c)
             elif fmt == "nvfp4":
                 gs = codec.generate_gparam(w); s = codec.minmax_qparams_float(w, kind="nvfp4", group_size=16, global_scale=gs); z = None
                 lin.weight_global_scale = torch.nn.Parameter(gs, requires_grad=False)
@@ -60,7 +70,7 @@ def build(layer_shapes, nlayers, fmt):
     return root, alg
 
 for name, shapes, nl in (("tinyllama 154 modules", TINY, 22), ("llama-8B-shaped 112 modules", L8B, 16)):
-    for fmt in os.environ.get("FORMATS", "w4,w4asym,fp8,fp8blk,nvfp4,mxfp4").split(","):
+    for fmt in os.environ.get("FORMATS", "w4,w4asym,w8a16,fp8,fp8blk,nvfp4,mxfp4").split(","):
         model, alg = build(shapes, nl, fmt)
         mc = cta.ModelCompressor()
         def cycle():
