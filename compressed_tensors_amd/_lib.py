@@ -83,6 +83,8 @@ _PROTOTYPES = {
     "ct_fp4_quant_pack_batch": ([_P, _I, _L, _I, _I, _I, _P, _S], _I),
     "ct_fp4_unpack_dequant_batch": ([_P, _I, _L, _I, _I, _S], _I),
     "ct_mx_scale_compress": ([_P, _I, _L, _P, _P, _S], _I),
+    "ct_mx_scale_batch_plan": ([_P, _I], _L),
+    "ct_mx_scale_batch": ([_P, _I, _L, _I, _I, _P, _S], _I),
     "ct_mx_scale_decompress": ([_P, _L, _P, _S], _I),
     "ct_rtn_mxfp4_quant_pack": ([_P, _I, _L, _L, _P, _P, _P, _S], _I),
     "ct_rtn_nvfp4_quant_pack": ([_P, _I, _L, _L, _P, _P, _P, _P, _S], _I),

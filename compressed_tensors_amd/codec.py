@@ -751,6 +751,20 @@ def launch_fp4_words(words: torch.Tensor, n: int, direction: str, device: torch.
         call("ct_fp4_unpack_dequant_batch", table.data_ptr(), n, blocks, int(group), DT[torch.bfloat16], _lib.stream_on(device))
 
 
+def launch_mx_scale_words(words: torch.Tensor, n: int, direction: str, device: torch.device, scale_dtype=None) -> None:
+    """a table of MX scale tensors in ONE launch (`ct_mx_scale_batch`): "compress" 16-bit scales -> E8M0 codes, "decompress" codes -> bfloat16"""
+    if not n:
+        return
+    blocks = int(_lib.load().ct_mx_scale_batch_plan(words.data_ptr(), n))
+    if blocks < 0:
+        raise ValueError(_lib.last_error())
+    table = _upload_table(words, device)
+    if direction == "compress":
+        call("ct_mx_scale_batch", table.data_ptr(), n, blocks, 0, DT[scale_dtype], ptr(_mx_code_table(scale_dtype, device)), _lib.stream_on(device))
+    else:
+        call("ct_mx_scale_batch", table.data_ptr(), n, blocks, 1, -1, None, _lib.stream_on(device))
+
+
 def launch_zp4_words(words: torch.Tensor, n: int, direction: str, device: torch.device) -> None:
     """`zp4_batch` for a table that already exists as a flat CPU int64 tensor (src, 0, 0, dst, unpacked rows, cols, 0 ... per item;
     built by the C++ host loop): plan, upload, ONE `ct_zp4_pack_dim0_batch` launch on `device`'s current stream"""

@@ -39,6 +39,61 @@ class MXFP8QuantizationCompressor(NaiveQuantizationCompressor):
         widened = dict(state_dict, weight_scale=cls._decompress_scale(state_dict["weight_scale"]))
         return _naive_decompress(cls, widened, scheme)
 
+    # ------------------------------------------------------------------ module loops (round 6)
+    # ModelCompressor's per-module loop in the C++ extension (csrc/host/ct_hostpath.cpp mx8_plan_compress / mx8_plan_decompress / mx8_finish): the weights of a
+    # window of modules ride ONE launch of the 8-bit tables (float8 codes, groups of 32), their scale tensors ONE launch of ct_mx_scale_batch; whatever the C++
+    # loop does not take goes through compress_module / decompress_module as before
+    @classmethod
+    def _native(cls, modules, direction: str):
+        from ... import _lib
+        from ...quantization.quant_args import QuantizationStatus
+        from ..base import symmetric_zp_keys
+        from ..pack_quantized.base import _launch_chunks
+
+        modules = list(modules)
+        hp = _lib.hostpath()
+        base = MXFP8QuantizationCompressor
+        if (hp is None or not hasattr(hp, "mx8_plan_compress") or torch.nn.modules.module._global_parameter_registration_hooks
+                or cls.compress.__func__ is not base.compress.__func__ or cls.decompress.__func__ is not base.decompress.__func__):
+            return modules
+
+        def info(scheme) -> int:
+            if not cls.can_compress(torch.nn.Linear, scheme):
+                return 0
+            drop = 0
+            for key in symmetric_zp_keys(scheme):
+                drop |= {"weight_zero_point": 1, "input_zero_point": 2, "output_zero_point": 4}[key]
+            return 1 | (drop << 1)
+
+        compress = direction == "compress"
+        codes = {1: torch.float16, 2: torch.bfloat16}
+        rest, pending = [], []
+        for lo, hi in _launch_chunks(len(modules)):
+            planned, back = hp.mx8_plan_compress(modules[lo:hi], info) if compress else hp.mx8_plan_decompress(modules[lo:hi])
+            rest += back
+            for (dev_index, code), (words, n, jobs, scale_words, scale_n) in planned.items():
+                device = torch.device("cuda", dev_index) if dev_index >= 0 else torch.device("cpu")
+                dtype = codes[code & 15]
+                if compress:
+                    codec.launch_q8_words(words, n, "compress", dtype, device, (code >> 4) & 15, 8)
+                    codec.launch_mx_scale_words(scale_words, scale_n, "compress", device, dtype)
+                else:  # the scales first: the weights' table reads their bfloat16 form
+                    codec.launch_mx_scale_words(scale_words, scale_n, "decompress", device)
+                    codec.launch_q8_words(words, n, "decompress", dtype, device, (code >> 4) & 15, 8)
+                pending.append(jobs)
+        status = QuantizationStatus.COMPRESSED if compress else QuantizationStatus.DECOMPRESSED
+        for jobs in pending:
+            hp.mx8_finish(jobs, status)
+        return rest
+
+    @classmethod
+    def compress_modules(cls, modules) -> None:
+        super().compress_modules(cls._native(modules, "compress"))
+
+    @classmethod
+    def decompress_modules(cls, modules) -> None:
+        super().decompress_modules(cls._native(modules, "decompress"))
+
     # the two hooks keep upstream's names: install() lets upstream's subclass call them
     @classmethod
     def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:

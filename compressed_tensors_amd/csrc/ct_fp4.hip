@@ -566,6 +566,21 @@ __global__ __launch_bounds__(kBlock) void mx_scale_decompress_kernel(const uint8
     }
 }
 
+// a table of MX scale tensors (MXFP8 modules: ModelCompressor's loop over MXFP8QuantizationCompressor.compress / .decompress, mxfp8/base.py:47-101): items' src /
+// dst and `rows` = the element count; COMPRESS: 16-bit scales -> E8M0 codes through the code table, else codes -> bfloat16 powers of two
+template <bool COMPRESS>
+__global__ __launch_bounds__(kBlock) void mx_scale_batch_kernel(const ct_w4_item* __restrict__ items, int n, const uint8_t* __restrict__ table) {
+    const ct_w4_item& it = fp4_batch_find(items, n, blockIdx.x);
+    const int64_t i = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
+    if (i >= it.rows) return;
+    if constexpr (COMPRESS) {
+        static_cast<uint8_t*>(it.dst)[i] = table[static_cast<const uint16_t*>(it.src)[i]];
+    } else {
+        const uint32_t e = static_cast<const uint8_t*>(it.src)[i];
+        static_cast<uint16_t*>(it.dst)[i] = (uint16_t)f_to_bf16_bits(e == 0 ? 0x1p-127f : bits_f(e << 23));
+    }
+}
+
 }  // namespace ct
 
 using namespace ct;
@@ -744,6 +759,38 @@ int ct_fp4_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t tota
         else hipLaunchKernelGGL((fp4_unpack_dequant_batch_kernel<CT_F16, false>), grid, dim3(kBlock), 0, as_stream(stream), items_dev, n);
     }
     CT_LAUNCH_CHECK("ct_fp4_unpack_dequant_batch");
+}
+
+int64_t ct_mx_scale_batch_plan(ct_w4_item* items, int n) {
+    if (!items || n < 0) {
+        set_error("ct_mx_scale_batch_plan: bad arguments");
+        return -1;
+    }
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        ct_w4_item& it = items[i];
+        if (!(it.rows > 0 && it.src && it.dst && (reinterpret_cast<uintptr_t>(it.src) & 1u) == 0 && (reinterpret_cast<uintptr_t>(it.dst) & 1u) == 0)) {
+            set_error("ct_mx_scale_batch_plan: item %d needs src, dst (2-byte aligned) and rows = its element count > 0", i);
+            return -1;
+        }
+        it.first_block = blocks;
+        blocks += cdiv64(it.rows, kBlock);
+    }
+    if (blocks >= ((int64_t)1 << 31)) {
+        set_error("ct_mx_scale_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);
+        return -1;
+    }
+    return blocks;
+}
+
+int ct_mx_scale_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int direction, int sdt, const uint8_t* code_table, ct_stream_t stream) {
+    CT_REQUIRE(direction == 0 || direction == 1, "direction must be 0 (compress) or 1 (decompress)");
+    CT_REQUIRE(direction == 1 || ((sdt == CT_BF16 || sdt == CT_F16) && code_table != nullptr), "compress takes 16-bit scales and their code table");
+    CT_REQUIRE(n >= 0 && total_blocks >= 0 && total_blocks < ((int64_t)1 << 31), "bad batch size");
+    if (n == 0 || total_blocks == 0) return CT_OK;
+    if (direction == 0) hipLaunchKernelGGL((mx_scale_batch_kernel<true>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n, code_table);
+    else hipLaunchKernelGGL((mx_scale_batch_kernel<false>), dim3((unsigned)total_blocks), dim3(kBlock), 0, as_stream(stream), items_dev, n, code_table);
+    CT_LAUNCH_CHECK("ct_mx_scale_batch");
 }
 
 int ct_mx_scale_compress(const void* scale, int sdt, int64_t n, const uint8_t* code_table, uint8_t* codes_out, ct_stream_t stream) {

@@ -1058,6 +1058,128 @@ int dtype_code(at::ScalarType t) {
     }
 }
 
+// mxfp8-quantized (reference compressors/mxfp8/base.py:29-118): float8 weights in groups of 32 — rows of the 8-bit tables, kind fp8 / fp8z — under 16-bit
+// power-of-two scales that are STORED as E8M0 codes: a second table (`zp_words` of the batch; ct_mx_scale_batch) converts the scales, float -> code on the way
+// in, code -> bfloat16 on the way back (launched BEFORE the weights' table, which reads the bfloat16 scales).  infos[i] (compress): 1 | drop mask << 1, or 0.
+py::tuple mx8_plan_compress(py::list modules, py::object infos_arg) {
+    touch_tls();
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        const int dropmask = (int)((info >> 1) & 7);
+        Entries e;
+        bool ok = info > 0 && (info & 1) && plain_type(m) && e.open(m);
+        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
+        int64_t group = 0;
+        bool f8z = false;
+        if (ok) {
+            w = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            zp = e.tensor(N.weight_zero_point);
+            ok = w && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && w->dim() == 2 && (w->is_cuda() || g_allow_cpu) &&
+                 w->is_contiguous() && aligned16(*w);
+        }
+        if (ok) {
+            f8z = zp && zp->scalar_type() == at::kFloat8_e4m3fn;
+            ok = !(zp && !f8z);
+            if (ok) group = q8_group(w->size(0), w->size(1), *scale, zp, w->scalar_type(), w->device(), 2, 32, f8z);
+            ok = ok && group == 32 &&
+                 staying_entries_are_final(e, {N.weight, N.weight_scale, (dropmask & 1) ? N.weight_zero_point : N.weight, (dropmask & 2) ? g_input_zero_point : N.weight,
+                                               (dropmask & 4) ? g_output_zero_point : N.weight});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        const int64_t rows = w->size(0), cols = w->size(1);
+        at::Tensor out = at::empty({rows, cols}, w->options().dtype(at::kFloat8_e4m3fn));
+        at::Tensor codes = at::empty(scale->sizes(), scale->options().dtype(at::kByte));
+        Batch& b = batches[{w->is_cuda() ? (int)w->device().index() : -1, (w->scalar_type() == at::kHalf ? 1 : 2) | ((f8z ? 2 : 1) << 4) | (8 << 8)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)w->data_ptr(), (int64_t)(uintptr_t)scale->data_ptr(), zp ? (int64_t)(uintptr_t)zp->data_ptr() : 0,
+                                          (int64_t)(uintptr_t)out.data_ptr(), rows, cols, group, 0, 0, 0, 0, 0, 0};
+        const int64_t sitem[kItemWords] = {(int64_t)(uintptr_t)scale->data_ptr(), 0, 0, (int64_t)(uintptr_t)codes.data_ptr(), scale->numel(), 1, 0, 0, 0, 0, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.zp_words.insert(b.zp_words.end(), sitem, sitem + kItemWords);
+        b.n += 1;
+        b.zp_n += 1;
+        PyObject* zp_obj = zp ? PyDict_GetItem(e.params, N.weight_zero_point) : Py_None;
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
+                                     py::reinterpret_steal<py::object>(THPVariable_Wrap(codes)), dropmask, py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)),
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_scale)), py::reinterpret_borrow<py::object>(zp_obj)));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+py::tuple mx8_plan_decompress(py::list modules) {
+    touch_tls();
+    std::map<std::pair<int, int>, Batch> batches;
+    py::list rest;
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        Entries e;
+        bool ok = plain_type(m) && e.open(m);
+        const at::Tensor *q = nullptr, *codes = nullptr;
+        int64_t rows = 0, cols = 0;
+        if (ok) {
+            q = e.tensor(N.weight);
+            codes = e.tensor(N.weight_scale);
+            ok = q && codes && !e.has(N.weight_g_idx) && !e.has(N.weight_zero_point) && q->dim() == 2 && q->scalar_type() == at::kFloat8_e4m3fn &&
+                 (q->is_cuda() || g_allow_cpu) && q->is_contiguous() && aligned16(*q) && codes->scalar_type() == at::kByte && codes->device() == q->device() &&
+                 codes->is_contiguous() && codes->dim() == 2;
+        }
+        if (ok) {
+            rows = q->size(0);
+            cols = q->size(1);
+            ok = rows > 0 && cols % 32 == 0 && codes->size(0) == rows && codes->size(1) == cols / 32 && cols / 32 > 1 && staying_entries_are_final(e, {N.weight, N.weight_scale});
+        }
+        if (!ok) {
+            rest.append(py::reinterpret_borrow<py::object>(m));
+            continue;
+        }
+        at::Tensor scale = at::empty(codes->sizes(), codes->options().dtype(at::kBFloat16));  // decompress_mx_scale: bfloat16, and so is the weight (mxfp8/base.py:74-101)
+        at::Tensor out = at::empty({rows, cols}, scale.options());
+        Batch& b = batches[{q->is_cuda() ? (int)q->device().index() : -1, 2 | (1 << 4) | (8 << 8)}];
+        const int64_t item[kItemWords] = {(int64_t)(uintptr_t)q->data_ptr(), (int64_t)(uintptr_t)scale.data_ptr(), 0, (int64_t)(uintptr_t)out.data_ptr(), rows, cols, 32,
+                                          0, 0, 0, 0, 0, 0};
+        const int64_t sitem[kItemWords] = {(int64_t)(uintptr_t)codes->data_ptr(), 0, 0, (int64_t)(uintptr_t)scale.data_ptr(), codes->numel(), 1, 0, 0, 0, 0, 0, 0, 0};
+        b.words.insert(b.words.end(), item, item + kItemWords);
+        b.zp_words.insert(b.zp_words.end(), sitem, sitem + kItemWords);
+        b.n += 1;
+        b.zp_n += 1;
+        b.jobs.append(py::make_tuple(py::reinterpret_borrow<py::object>(m), py::reinterpret_steal<py::object>(THPVariable_Wrap(out)),
+                                     py::reinterpret_steal<py::object>(THPVariable_Wrap(scale)), 0, py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight)),
+                                     py::reinterpret_borrow<py::object>(PyDict_GetItem(e.params, N.weight_scale)), py::none()));
+    }
+    return py::make_tuple(batches_to_python(batches), rest);
+}
+
+// the scale is replaced where it is, `weight` is re-added last (mxfp8/base.py: the naive codec pops and re-adds it, the scale is assigned to its existing key)
+void mx8_finish(py::list jobs, py::object status) {
+    touch_tls();
+    const Py_ssize_t n = PyList_GET_SIZE(jobs.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* job = PyList_GET_ITEM(jobs.ptr(), i);
+        PyObject* m = PyTuple_GET_ITEM(job, 0);
+        const at::Tensor& out = THPVariable_Unpack(PyTuple_GET_ITEM(job, 1));
+        const at::Tensor& sc = THPVariable_Unpack(PyTuple_GET_ITEM(job, 2));
+        const long dropmask = PyLong_AsLong(PyTuple_GET_ITEM(job, 3));
+        Entries e;
+        if (!e.open(m)) throw std::runtime_error("module lost its _parameters");
+        if (dropmask & 1) drop(e.params, N.weight_zero_point);
+        if (dropmask & 2) drop(e.params, g_input_zero_point);
+        if (dropmask & 4) drop(e.params, g_output_zero_point);
+        PyDict_SetItem(e.params, N.weight_scale, make_parameter(sc).ptr());
+        drop(e.params, N.weight);
+        PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
+        set_status(m, status.ptr());
+    }
+}
+
 // pack-quantized with num_bits = 8 and a symmetric weights-only scheme (the W8A16 preset; reference compressors/pack_quantized/base.py:62-163): the codes are
 // the 8-bit tables' kind 3 (int8 + 128, four to an int32 word = pack_to_int32), the entries are the W4 ones (weight -> weight_packed + weight_shape), so the
 // jobs go to w4_finish_compress / w4_finish_decompress.  infos[i]: group_size | strategy << 25 (0 tensor, 1 channel, 2 group), or < 0.
@@ -1342,6 +1464,9 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("fp4_plan_compress", &fp4_plan_compress);
     mod.def("fp4_plan_decompress", &fp4_plan_decompress);
     mod.def("fp4_finish", &fp4_finish);
+    mod.def("mx8_plan_compress", &mx8_plan_compress);
+    mod.def("mx8_plan_decompress", &mx8_plan_decompress);
+    mod.def("mx8_finish", &mx8_finish);
     mod.def("w8_plan_compress", &w8_plan_compress);
     mod.def("w8_plan_decompress", &w8_plan_decompress);
     mod.def("q8_plan_compress", &q8_plan_compress);

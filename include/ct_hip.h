@@ -326,6 +326,12 @@ int ct_fp4_unpack_dequant_batch(const ct_w4_item* items_dev, int n, int64_t tota
  * codes_out[i] = code_table[bits of scale[i]] (16-bit scales; the table as above) resp. scale_bf16_out[i] = 2 ** (codes[i] - 127) as bfloat16
  * (code 0: the bfloat16 subnormal 2^-127, code 255: inf). */
 int ct_mx_scale_compress(const void* scale, int sdt, int64_t n, const uint8_t* code_table, uint8_t* codes_out, ct_stream_t stream);
+/* ... for a table of scale tensors in one launch (the MXFP8 modules of a checkpoint: ModelCompressor's loop over MXFP8QuantizationCompressor.compress /
+ * .decompress, compressors/mxfp8/base.py:47-101; the weights ride ct_q8_quant_batch / ct_q8_dequant_batch with groups of 32).  Items: src, dst and `rows` = the
+ * element count (the other fields are ignored); direction 0: 16-bit scales (dtype `sdt`, one per table) -> uint8 codes through `code_table`; 1: codes ->
+ * bfloat16.  Plan on the host copy first. */
+int64_t ct_mx_scale_batch_plan(ct_w4_item* items_host, int n);
+int ct_mx_scale_batch(const ct_w4_item* items_dev, int n, int64_t total_blocks, int direction, int sdt, const uint8_t* code_table, ct_stream_t stream);
 int ct_mx_scale_decompress(const uint8_t* codes, int64_t n, void* scale_bf16_out, ct_stream_t stream);
 
 /* Round-to-nearest MXFP4 in one pass: per 32-element group the min-max observer, calculate_qparams' MX branch

@@ -2114,6 +2114,55 @@ def test_w8_pack_quantized_modules_through_the_tables(cta, dev, dtype, strategy)
                 assert eq(x_.weight.data.cpu(), O.dequantize(q_ref, qp[k][0], None, **{k_: v for k_, v in kw.items() if k_ != "num_bits"}))
 
 
+@pytest.mark.parametrize("dtype", [BF16, F16])
+@pytest.mark.parametrize("with_zp", [False, True])
+def test_mxfp8_modules_through_the_tables(cta, dev, dtype, with_zp):
+    """mxfp8-quantized: compress_modules / decompress_modules — the C++ host loop, the 8-bit tables (float8 codes, groups of 32) and the scale table
+    (ct_mx_scale_batch: E8M0 codes in, bfloat16 powers of two out) — against the per-module class calls: names, order, dtypes, values"""
+    g = torch.Generator().manual_seed(31)
+    wa = cta.QuantizationArgs(num_bits=8, type="float", strategy="group", group_size=32, symmetric=True, scale_dtype=torch.uint8)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa)
+    scheme.format = "mxfp8-quantized"
+    klass = cta.BaseCompressor.get_value_from_registry("mxfp8-quantized")
+    shapes = [(256, 512), (1024, 1024), (130, 384), (7, 256), (64, 4096), (3, 64)]
+
+    def modules():
+        ms = []
+        for k, (r, c) in enumerate(shapes):
+            gk = torch.Generator().manual_seed(300 + k)
+            w = (torch.randn(r, c, generator=gk) * 3).to(dtype)
+            w.view(-1)[: min(special_values(dtype).numel(), w.numel())] = special_values(dtype)[: w.numel()]
+            w = torch.where(torch.isfinite(w), w, torch.zeros_like(w))
+            amax = w.float().reshape(r, -1, 32).abs().amax(-1).clamp(min=1e-4)
+            s_ = torch.exp2(torch.floor(torch.log2(amax)) - 8).to(dtype)
+            lin = torch.nn.Linear(c, r, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(w.to(dev), requires_grad=False)
+            lin.weight_scale = torch.nn.Parameter(s_.to(dev), requires_grad=False)
+            if with_zp:
+                lin.weight_zero_point = torch.nn.Parameter(torch.zeros(s_.shape, dtype=F8).to(dev), requires_grad=False)
+            lin.quantization_scheme = scheme
+            ms.append(lin)
+        return ms
+
+    a, b = modules(), modules()
+    for direction in ("compress", "decompress"):
+        getattr(klass, direction + "_modules")(a)
+        for m in b:
+            getattr(klass, direction + "_module")(m)
+        for k, (x_, y_) in enumerate(zip(a, b)):
+            assert list(x_._parameters) == list(y_._parameters), (direction, shapes[k])
+            for name, tx in x_._parameters.items():
+                ty = y_._parameters[name]
+                if tx is None or ty is None:
+                    assert tx is ty
+                    continue
+                assert tx.dtype == ty.dtype and (eq_f8(tx.data.cpu(), ty.data.cpu()) if tx.dtype is F8 else eq(tx.data.cpu(), ty.data.cpu())), (direction, shapes[k], name)
+            if direction == "compress":
+                assert x_.weight.dtype is F8 and x_.weight_scale.dtype is torch.uint8 and "weight_zero_point" not in x_._parameters
+            else:
+                assert x_.weight.dtype is BF16 and x_.weight_scale.dtype is BF16
+
+
 def test_w4_batch_vs_oracle(cta, dev):
     """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
     for dtype in (BF16, F16):

@@ -1183,7 +1183,7 @@ def test_cpp_host_loop_of_8bit_pack_quantized_matches_the_python_loop(cta, monke
         hp.set_allow_cpu(False)
 
 
-@pytest.mark.parametrize("fmt", ["w8a16", "fp8", "fp8_block", "nvfp4", "mxfp4"])
+@pytest.mark.parametrize("fmt", ["w8a16", "fp8", "fp8_block", "nvfp4", "mxfp4", "mxfp8"])
 def test_cpp_host_loops_take_a_second_compress_after_a_decompress(cta, monkeypatch, fmt):
     """compress -> decompress -> compress -> decompress of one tree (what a benchmark loop, or a model that is decompressed for fine-tuning and compressed again, does):
     every module goes through the C++ loop in BOTH rounds — entries an earlier direction leaves behind (`weight_shape`, a bfloat16 scale) do not push the
@@ -1202,12 +1202,16 @@ def test_cpp_host_loops_take_a_second_compress_after_a_decompress(cta, monkeypat
         wa, sshape, zdt = cta.QuantizationArgs(num_bits=8, type="float", strategy="block", block_structure=[16, 128], symmetric=True), lambda r, c: (r // 16, c // 128), F8
     elif fmt == "nvfp4":
         wa, sshape, zdt = cta.QuantizationArgs(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8), lambda r, c: (r, c // 16), None
+    elif fmt == "mxfp8":
+        wa, sshape, zdt = cta.QuantizationArgs(num_bits=8, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8), lambda r, c: (r, c // 32), F8
     else:
         wa, sshape, zdt = cta.QuantizationArgs(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8), lambda r, c: (r, c // 32), None
     ia = cta.QuantizationArgs(num_bits=8, type="float", strategy="tensor", symmetric=True, dynamic=True) if fmt.startswith("fp8") else None
     scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa, input_activations=ia)
     if fmt in ("nvfp4", "mxfp4"):
         scheme.format = fmt + "-pack-quantized"
+    if fmt == "mxfp8":
+        scheme.format = "mxfp8-quantized"
     root = torch.nn.Module()
     root.blocks = torch.nn.ModuleList()
     for r, c in [(64, 256), (32, 512), (96, 128)]:
@@ -1223,6 +1227,8 @@ def test_cpp_host_loops_take_a_second_compress_after_a_decompress(cta, monkeypat
     taken = []
     monkeypatch.setattr(codec, "launch_q8_words", lambda words, n, direction, *a_, **k: taken.append((direction, n)))
     monkeypatch.setattr(codec, "launch_fp4_words", lambda words, n, direction, *a_, **k: taken.append((direction, n)))
+    scale_tables = []
+    monkeypatch.setattr(codec, "launch_mx_scale_words", lambda words, n, direction, *a_, **k: scale_tables.append((direction, n, len(taken))))
     monkeypatch.setattr(codec, "_mx_code_table", lambda dt, dev: torch.zeros(65536, dtype=torch.uint8))
     monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
     hp.set_allow_cpu(True)
@@ -1235,6 +1241,10 @@ def test_cpp_host_loops_take_a_second_compress_after_a_decompress(cta, monkeypat
             mc.decompress_model(root)
             states.append([_module_state_no_ptr(m) for m in root.blocks])
         assert [t for t in taken] == [("compress", 3), ("decompress", 3)] * 2, taken
+        if fmt == "mxfp8":  # one scale table per weights' table; on the way back it goes out BEFORE the weights' (which read the bfloat16 scales it writes)
+            assert [(d_, n_) for d_, n_, _ in scale_tables] == [("compress", 3), ("decompress", 3)] * 2
+            assert [k for d_, _, k in scale_tables if d_ == "decompress"] == [1, 3]
+            assert all(m.weight_scale.dtype is torch.bfloat16 and m.weight.dtype is torch.bfloat16 for m in root.blocks)
         # (same entries; `weight_shape`, which a decompress keeps, stays where it is in the second round — as upstream's compress, which assigns to the existing key)
         norm = lambda st: [(sorted(p_, key=lambda kv: kv[0]), b_) for p_, b_ in st]
         assert norm(states[0]) == norm(states[2]) and norm(states[1]) == norm(states[3])

@@ -5,6 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import compressed_tensors_amd as cta
 from compressed_tensors_amd import codec
 dev = torch.device("cuda:0")
+if os.environ.get("NATIVE", "1") == "0":  # the interpreter's module loops alone (what every format ran before its C++ loop existed)
+    from compressed_tensors_amd import _lib
+    _lib.hostpath()
+    _lib._HOSTPATH[:] = [None]
 TINY = (("q_proj", 2048, 2048), ("k_proj", 256, 2048), ("v_proj", 256, 2048), ("o_proj", 2048, 2048), ("gate_proj", 5632, 2048), ("up_proj", 5632, 2048), ("down_proj", 2048, 5632))
 L8B = (("q_proj", 4096, 4096), ("k_proj", 1024, 4096), ("v_proj", 1024, 4096), ("o_proj", 4096, 4096), ("gate_proj", 14336, 4096), ("up_proj", 14336, 4096), ("down_proj", 4096, 14336))
 F8 = torch.float8_e4m3fn
@@ -18,6 +22,8 @@ def build(layer_shapes, nlayers, fmt):
         args = cta.QuantizationArgs(num_bits=8, type="float", strategy="block", block_structure=[128, 128], symmetric=True)
     elif fmt == "w4asym":
         args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, strategy="group")
+    elif fmt == "mxfp8":
+        args = cta.QuantizationArgs(num_bits=8, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)
     elif fmt == "w8a16":  # the W8A16 preset: weight-only int8, channel-wise, stored pack-quantized
         args = cta.QuantizationArgs(num_bits=8, symmetric=True, strategy="channel")
     elif fmt == "w3":
@@ -31,6 +37,8 @@ def build(layer_shapes, nlayers, fmt):
     scheme = cta.QuantizationScheme(targets=["Linear"], weights=args)
     if fmt in ("nvfp4", "mxfp4"):
         scheme.format = fmt + "-pack-quantized"
+    if fmt == "mxfp8":
+        scheme.format = "mxfp8-quantized"
     alg = 0
     for l in range(nlayers):
         blk = torch.nn.Module(); root.layers.append(blk)
@@ -47,6 +55,10 @@ def build(layer_shapes, nlayers, fmt):
             elif fmt == "w4asym":
                 s, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=False)
                 alg += 2 * int(2.5 * r * c)
+            elif fmt == "mxfp8":
+                amax = w.float().reshape(r, -1, 32).abs().amax(-1).clamp(min=1e-4)
+                s = torch.exp2(torch.floor(torch.log2(amax)) - 8).to(torch.bfloat16); z = torch.zeros(s.shape, dtype=F8, device=dev)
+                alg += 2 * int((3 + 3 / 32) * r * c)
             elif fmt == "w8a16":
                 s, z = codec.minmax_qparams(w, num_bits=8, group_size=None, symmetric=True)
                 alg += 2 * (3 * r * c)
@@ -70,7 +82,7 @@ def build(layer_shapes, nlayers, fmt):
     return root, alg
 
 for name, shapes, nl in (("tinyllama 154 modules", TINY, 22), ("llama-8B-shaped 112 modules", L8B, 16)):
-    for fmt in os.environ.get("FORMATS", "w4,w4asym,w8a16,fp8,fp8blk,nvfp4,mxfp4").split(","):
+    for fmt in os.environ.get("FORMATS", "w4,w4asym,w8a16,fp8,fp8blk,mxfp8,nvfp4,mxfp4").split(","):
         model, alg = build(shapes, nl, fmt)
         mc = cta.ModelCompressor()
         def cycle():
