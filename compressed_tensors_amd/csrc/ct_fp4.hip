@@ -570,14 +570,44 @@ __global__ __launch_bounds__(kBlock) void mx_scale_decompress_kernel(const uint8
 // dst and `rows` = the element count; COMPRESS: 16-bit scales -> E8M0 codes through the code table, else codes -> bfloat16 powers of two
 template <bool COMPRESS>
 __global__ __launch_bounds__(kBlock) void mx_scale_batch_kernel(const ct_w4_item* __restrict__ items, int n, const uint8_t* __restrict__ table) {
+    // eight scales per lane (16 B of 16-bit scales <-> 8 B of codes): one scale per lane spent a table search per 256 scales — 0.4 ms per direction on an
+    // 8B-shaped MXFP8 tree's 109 M scales
     const ct_w4_item& it = fp4_batch_find(items, n, blockIdx.x);
-    const int64_t i = ((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x;
-    if (i >= it.rows) return;
+    const int64_t e0 = (((int64_t)blockIdx.x - it.first_block) * kBlock + threadIdx.x) * 8;
+    if (e0 >= it.rows) return;
+    const bool vec = e0 + 8 <= it.rows && ((reinterpret_cast<uintptr_t>(it.src) | reinterpret_cast<uintptr_t>(it.dst)) & 15u) == 0;
     if constexpr (COMPRESS) {
-        static_cast<uint8_t*>(it.dst)[i] = table[static_cast<const uint16_t*>(it.src)[i]];
+        const uint16_t* src = static_cast<const uint16_t*>(it.src);
+        uint8_t* dst = static_cast<uint8_t*>(it.dst);
+        if (vec) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + e0);
+            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                lo |= ((uint32_t)table[ws[k] & 0xffffu] | ((uint32_t)table[ws[k] >> 16] << 8)) << (16 * k);
+                hi |= ((uint32_t)table[ws[2 + k] & 0xffffu] | ((uint32_t)table[ws[2 + k] >> 16] << 8)) << (16 * k);
+            }
+            *reinterpret_cast<u32x2*>(dst + e0) = u32x2{lo, hi};
+        } else {
+            for (int64_t i = e0; i < e0 + 8 && i < it.rows; ++i) dst[i] = table[src[i]];
+        }
     } else {
-        const uint32_t e = static_cast<const uint8_t*>(it.src)[i];
-        static_cast<uint16_t*>(it.dst)[i] = (uint16_t)f_to_bf16_bits(e == 0 ? 0x1p-127f : bits_f(e << 23));
+        const uint8_t* src = static_cast<const uint8_t*>(it.src);
+        uint16_t* dst = static_cast<uint16_t*>(it.dst);
+        auto decode = [](uint32_t e) { return (uint32_t)f_to_bf16_bits(e == 0 ? 0x1p-127f : bits_f(e << 23)) & 0xffffu; };  // 2 ** (e - 127) as bfloat16
+        if (vec) {
+            const u32x2 v = *reinterpret_cast<const u32x2*>(src + e0);
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                w[k] = decode((v.x >> (16 * k)) & 0xffu) | (decode((v.x >> (16 * k + 8)) & 0xffu) << 16);
+                w[2 + k] = decode((v.y >> (16 * k)) & 0xffu) | (decode((v.y >> (16 * k + 8)) & 0xffu) << 16);
+            }
+            *reinterpret_cast<u32x4*>(dst + e0) = u32x4{w[0], w[1], w[2], w[3]};
+        } else {
+            for (int64_t i = e0; i < e0 + 8 && i < it.rows; ++i) dst[i] = (uint16_t)decode(src[i]);
+        }
     }
 }
 
@@ -774,7 +804,7 @@ int64_t ct_mx_scale_batch_plan(ct_w4_item* items, int n) {
             return -1;
         }
         it.first_block = blocks;
-        blocks += cdiv64(it.rows, kBlock);
+        blocks += cdiv64(cdiv64(it.rows, 8), kBlock);  // eight scales per lane
     }
     if (blocks >= ((int64_t)1 << 31)) {
         set_error("ct_mx_scale_batch_plan: %lld workgroups exceed one launch; split the batch", (long long)blocks);

@@ -58,7 +58,8 @@ for (r, c) in shapes:
         cases = []
         if "fp8" in which:
             cases += [("fp8 channel", "float", "channel", None, None, True), ("fp8 block128x128", "float", "block", None, [128, 128], True),
-                      ("fp8 group128", "float", "group", 128, None, True), ("fp8 tensor", "float", "tensor", None, None, True)]
+                      ("fp8 group128", "float", "group", 128, None, True), ("fp8 tensor", "float", "tensor", None, None, True),
+                      ("fp8 group32 (MXFP8's layout)", "float", "group", 32, None, True)]
         if "int8" in which:
             cases += [("int8 tensor", "int", "tensor", None, None, True), ("int8 block128x128", "int", "block", None, [128, 128], True),
                       ("int8 group128 asym", "int", "group", 128, None, False), ("int8 channel asym", "int", "channel", None, None, False)]
