@@ -330,7 +330,7 @@ class PackedQuantizationCompressor(BaseCompressor):
                 remove += symmetric_zp_keys(scheme)
                 swap_direct_entries(m, remove, add, QuantizationStatus.COMPRESSED)
         for m in rest:
-            cls.compress_module(m)
+            cls._delta_module(m, "compress")
 
     @classmethod
     def _batch_decompress(cls, state_dicts, schemes):
@@ -417,12 +417,40 @@ class PackedQuantizationCompressor(BaseCompressor):
         pre = PackedQuantizationCompressor._batch_decompress(sds, [m.quantization_scheme for m in modules])  # (`cls` may be install()'s subclass of the UPSTREAM codec)
         for m, (w, z) in zip(modules, pre):
             if w is None:
-                cls.decompress_module(m)
+                cls._delta_module(m, "decompress")
                 continue
             add = {"weight": w}
             if z is not None:
                 add["weight_zero_point"] = z
             swap_direct_entries(m, ("weight_packed",), add, QuantizationStatus.DECOMPRESSED)
+
+    _DELTA_NAMES = ("weight", "weight_packed", "weight_scale", "weight_shape", "weight_zero_point", "weight_g_idx")
+
+    @classmethod
+    def _delta_module(cls, m, direction: str) -> None:
+        """`compress_module` / `decompress_module` for a module no table takes (2 / 3 / 6-bit words, activation ordering, asymmetric 8-bit, odd layouts): the
+        codec itself on the module's own weight entries, the result written back as a delta (`swap_direct_entries`: same names, order and kinds as
+        replace_direct_state_dict leaves, compressors/base.py:95-131) — 31-35 us of host work per module through the generic path, ~20 this way.  Anything
+        but parameters on a GPU goes the generic way."""
+        from ...quantization.quant_args import QuantizationStatus
+        from ...utils.module import swap_direct_entries
+        from ..base import symmetric_zp_keys
+
+        params = m._parameters
+        sd = {k: params[k].data for k in cls._DELTA_NAMES if params.get(k) is not None}  # (.data: what get_direct_state_dict hands the codec)
+        src = sd.get("weight" if direction == "compress" else "weight_packed")
+        if src is None or not src.is_cuda or any(k in m._buffers for k in cls._DELTA_NAMES):
+            return cls.compress_module(m) if direction == "compress" else cls.decompress_module(m)
+        scheme = m.quantization_scheme
+        new = cls.compress(sd, scheme) if direction == "compress" else cls.decompress(sd, scheme)
+        remove = [k for k in sd if k not in new]
+        add = {k: v for k, v in new.items() if v is not sd.get(k)}
+        if direction == "compress":
+            remove += [k for k in symmetric_zp_keys(scheme) if k not in remove]
+            status = QuantizationStatus.COMPRESSED
+        else:
+            status = QuantizationStatus.DECOMPRESSED
+        swap_direct_entries(m, remove, add, status)
 
     @classmethod
     def can_compress(cls, module_type: type, scheme) -> bool:

@@ -2163,6 +2163,57 @@ def test_mxfp8_modules_through_the_tables(cta, dev, dtype, with_zp):
                 assert x_.weight.dtype is BF16 and x_.weight_scale.dtype is BF16
 
 
+@pytest.mark.parametrize("variant", ["w3", "w3_asym", "w2", "w6_channel", "w4_actorder", "w8_asym", "w5_trainable_bias"])
+def test_pack_quantized_modules_no_table_takes_match_the_per_module_calls(cta, dev, variant):
+    """pack-quantized modules outside every table (2 / 3 / 5 / 6-bit words, activation ordering, asymmetric 8-bit): compress_modules / decompress_modules write the
+    codec's result back as a delta (PackedQuantizationCompressor._delta_module) — the same names in the same order, the same kinds, dtypes and values as
+    compress_module / decompress_module (replace_direct_state_dict) leave, and the oracle's words"""
+    g = torch.Generator().manual_seed(41)
+    bits = {"w3": 3, "w3_asym": 3, "w2": 2, "w6_channel": 6, "w4_actorder": 4, "w8_asym": 8, "w5_trainable_bias": 5}[variant]
+    sym = variant not in ("w3_asym", "w8_asym")
+    strategy = "channel" if variant == "w6_channel" else "group"
+    wa = cta.QuantizationArgs(num_bits=bits, type="int", strategy=strategy, group_size=None if strategy == "channel" else 128, symmetric=sym,
+                              actorder="group" if variant == "w4_actorder" else None)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa)
+    klass = cta.BaseCompressor.get_value_from_registry("pack-quantized")
+    shapes = [(256, 512), (130, 384), (64, 1024)]
+
+    def modules():
+        ms = []
+        for k, (r, c) in enumerate(shapes):
+            gk = torch.Generator().manual_seed(500 + k)
+            w = (torch.randn(r, c, generator=gk) * 0.1).to(BF16)
+            s_, z_ = O.calculate_qparams_minmax(w, num_bits=bits, group_size=None if strategy == "channel" else 128, symmetric=sym)
+            lin = torch.nn.Linear(c, r, bias=variant == "w5_trainable_bias", device="meta")
+            if variant == "w5_trainable_bias":
+                lin.bias = torch.nn.Parameter(torch.zeros(r, dtype=BF16, device=dev), requires_grad=True)
+            lin.weight = torch.nn.Parameter(w.to(dev), requires_grad=True)
+            lin.weight_scale = torch.nn.Parameter(s_.to(dev), requires_grad=False)
+            lin.weight_zero_point = torch.nn.Parameter(z_.to(dev), requires_grad=False)
+            if variant == "w4_actorder":
+                perm = torch.randperm(c, generator=gk)
+                lin.weight_g_idx = torch.nn.Parameter((perm // 128).to(torch.int32).to(dev), requires_grad=False)
+            lin.quantization_scheme = scheme
+            ms.append(lin)
+        return ms
+
+    a, b = modules(), modules()
+    for direction in ("compress", "decompress"):
+        getattr(klass, direction + "_modules")(a)
+        for m in b:
+            getattr(klass, direction + "_module")(m)
+        for k, (x_, y_) in enumerate(zip(a, b)):
+            assert list(x_._parameters) == list(y_._parameters) and list(x_._buffers) == list(y_._buffers), (direction, shapes[k], list(x_._parameters), list(y_._parameters))
+            assert x_.quantization_status == y_.quantization_status
+            for name, tx in x_._parameters.items():
+                ty = y_._parameters[name]
+                if tx is None or ty is None:
+                    assert tx is ty
+                    continue
+                assert type(tx) is type(ty) and tx.requires_grad == ty.requires_grad and tx.dtype == ty.dtype and tx.device == ty.device, (direction, name)
+                assert eq(tx.data.cpu(), ty.data.cpu()) if tx.dtype.is_floating_point else torch.equal(tx.data.cpu(), ty.data.cpu()), (direction, shapes[k], name)
+
+
 def test_w4_batch_vs_oracle(cta, dev):
     """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
     for dtype in (BF16, F16):
