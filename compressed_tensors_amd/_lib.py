@@ -349,6 +349,8 @@ def hostpath():
             except (OSError, AttributeError):
                 pass  # the marlin-24 default mode then waits through ct_stream_wait
             hp.bind_abi(abi)
+            if hasattr(hp, "bind_pack"):  # the loop over pack-quantized modules of the word widths without a table launches these two by address
+                hp.bind_pack(ctypes.cast(lib["ct_quant_pack"], ctypes.c_void_p).value, ctypes.cast(lib["ct_unpack_dequant"], ctypes.c_void_p).value)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
 

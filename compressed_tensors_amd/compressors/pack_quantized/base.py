@@ -91,6 +91,32 @@ def _native_w8(hp, modules, direction: str, status):
     return rest
 
 
+def _wb_info(scheme) -> int:
+    """csrc/host/ct_hostpath.cpp wb_compress_modules / wb_decompress_modules: a symmetric weights-only int scheme of a word width without a table (not 4, not 8),
+    group / channel, no activation ordering -> group size | strategy << 25 | num_bits << 28, else -1"""
+    wa = scheme.weights
+    if (wa is None or getattr(scheme, "input_activations", None) is not None or getattr(scheme, "output_activations", None) is not None
+            or enum_value(getattr(wa, "type", "int")) != "int" or not wa.symmetric or enum_value(getattr(wa, "actorder", None)) == "group"):
+        return -1
+    bits, st = int(wa.num_bits), enum_value(wa.strategy)
+    if bits in (4, 8) or not 1 <= bits <= 8 or st not in ("channel", "group"):
+        return -1
+    gs = int(getattr(wa, "group_size", None) or 0) if st == "group" else 0
+    if not 0 <= gs < (1 << 20) or (st == "group" and gs <= 0):
+        return -1
+    return gs | ({"channel": 1, "group": 2}[st] << 25) | (bits << 28)
+
+
+def _native_wb(hp, modules, direction: str, status):
+    """the modules of the other word widths on the current GPU through the C++ loop (one launch per module, by address); returns the rest"""
+    if (not hasattr(hp, "wb_compress_modules") or not torch.cuda.is_available()
+            or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 4) or 4) not in (4, 8) for m in modules)):
+        return modules
+    dev = torch.device("cuda", torch.cuda.current_device())
+    fn = hp.wb_compress_modules if direction == "compress" else hp.wb_decompress_modules
+    return fn(modules, _wb_info, dev.index, int(_lib.stream_on(dev)), status)
+
+
 _ASYMMETRIC = 1 << 40  # csrc/host/ct_hostpath.cpp: kAsymmetric
 
 
@@ -248,6 +274,7 @@ class PackedQuantizationCompressor(BaseCompressor):
             # the plain case — int4 group / channel, parameters only, nn.Module's own attribute hooks — in C++: table rows, output allocations
             # and, after the launch, the parameter dictionaries; whatever it does not take comes back in `modules`
             modules = _native_w8(hp, list(modules), "compress", QuantizationStatus.COMPRESSED)
+            modules = _native_wb(hp, modules, "compress", QuantizationStatus.COMPRESSED)
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):  # the first launch leaves after a fifth of the planning, not after all of it
                 planned, back = hp.w4_plan_compress(modules[lo:hi], _compress_info)  # (asked once per distinct scheme object and chunk)
@@ -400,6 +427,7 @@ class PackedQuantizationCompressor(BaseCompressor):
         hp = _hostpath()
         if hp is not None and not torch.nn.modules.module._global_parameter_registration_hooks:
             modules = _native_w8(hp, modules, "decompress", QuantizationStatus.DECOMPRESSED)
+            modules = _native_wb(hp, modules, "decompress", QuantizationStatus.DECOMPRESSED)
             rest, pending = [], []
             for lo, hi in _launch_chunks(len(modules)):
                 planned, back = hp.w4_plan_decompress(modules[lo:hi], _decompress_info)

@@ -1058,6 +1058,125 @@ int dtype_code(at::ScalarType t) {
     }
 }
 
+// pack-quantized with the other word widths (2 / 3 / 5 / 6 / 7 bits; symmetric weights-only group / channel schemes, no activation ordering): no table form
+// exists for them, so this loop launches `ct_quant_pack` / `ct_unpack_dequant` per module BY ADDRESS on `stream` of device `device_index` (which the caller has
+// made current) and rewrites the dictionary right behind each launch — the interpreter's 22-33 us per module become ~7.  Entries as the W4 loop leaves them.
+// infos[i]: group_size | strategy << 25 (1 channel, 2 group) | num_bits << 28, or < 0.
+using quant_pack_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int64_t, int64_t, const int32_t*, int, int, int32_t*, void*);
+using unpack_dequant_fn = int (*)(const int32_t*, int64_t, int64_t, int64_t, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, const int32_t*, void*, int, void*);
+quant_pack_fn g_quant_pack = nullptr;
+unpack_dequant_fn g_unpack_dequant = nullptr;
+
+void bind_pack(uintptr_t quant_pack, uintptr_t unpack_dequant) {
+    g_quant_pack = reinterpret_cast<quant_pack_fn>(quant_pack);
+    g_unpack_dequant = reinterpret_cast<unpack_dequant_fn>(unpack_dequant);
+}
+
+inline int half_code(at::ScalarType t) { return t == at::kHalf ? 1 : 2; }  // _lib.F16 / _lib.BF16
+
+py::list wb_compress_modules(py::list modules, py::object infos_arg, int device_index, uintptr_t stream, py::object status) {
+    touch_tls();
+    if (!g_quant_pack) throw std::runtime_error("wb_compress_modules: bind_pack has not been called");
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        const int bits = (int)((info >> 28) & 15), strategy = (int)((info >> 25) & 3);
+        Entries e;
+        bool ok = info >= 0 && bits >= 1 && bits <= 8 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
+        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
+        int64_t rows = 0, cols = 0, group = 0;
+        if (ok) {
+            w = e.tensor(N.weight);
+            scale = e.tensor(N.weight_scale);
+            zp = e.tensor(N.weight_zero_point);
+            ok = w && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && !e.has(N.weight_packed) && w->dim() == 2 &&
+                 half_type(w->scalar_type()) && ((w->is_cuda() && w->device().index() == device_index) || g_allow_cpu) && w->is_contiguous() && aligned16(*w) &&
+                 scale->scalar_type() == w->scalar_type() && scale->device() == w->device() && scale->is_contiguous() && scale->dim() == 2;
+        }
+        if (ok) {
+            rows = w->size(0);
+            cols = w->size(1);
+            group = strategy == 1 ? cols : (info & 0xfffff);
+            ok = rows > 0 && cols > 0 && group > 0 && cols % group == 0 && scale->size(0) == rows && scale->size(1) == cols / group;
+            if (ok && zp) ok = zp->scalar_type() == at::kChar && zp->sizes() == scale->sizes() && zp->is_contiguous() && zp->device() == w->device();
+            ok = ok && staying_entries_are_final(e, {N.weight, N.weight_zero_point});
+        }
+        if (ok) {
+            const int64_t words = (cols * bits + 31) / 32;
+            at::Tensor packed = at::empty({rows, words}, w->options().dtype(at::kInt));
+            const int dt = half_code(w->scalar_type());
+            const int rc = w->is_cpu() ? 0
+                                       : g_quant_pack(w->data_ptr(), dt, scale->data_ptr(), dt, zp ? zp->data_ptr() : nullptr, zp ? 3 /* _lib.I8 */ : -1, rows, cols, 1, group,
+                                                      cols / group, nullptr, bits, dt, static_cast<int32_t*>(packed.data_ptr()), reinterpret_cast<void*>(stream));
+            if (rc == 0) {
+                drop(e.params, N.weight);
+                drop(e.params, N.weight_zero_point);  // a symmetric scheme stores none (compressors/base.py: symmetric_zp_keys)
+                at::Tensor shape = at::empty({2}, at::TensorOptions().dtype(at::kLong));
+                shape.data_ptr<int64_t>()[0] = rows;
+                shape.data_ptr<int64_t>()[1] = cols;
+                PyDict_SetItem(e.params, N.weight_packed, make_parameter(packed).ptr());
+                PyDict_SetItem(e.params, N.weight_shape, make_parameter(shape).ptr());
+                set_status(m, status.ptr());
+                continue;
+            }
+        }
+        rest.append(py::reinterpret_borrow<py::object>(m));  // (a refused launch too: the Python path repeats it and reports the library's message)
+    }
+    return rest;
+}
+
+py::list wb_decompress_modules(py::list modules, py::object infos_arg, int device_index, uintptr_t stream, py::object status) {
+    touch_tls();
+    if (!g_unpack_dequant) throw std::runtime_error("wb_decompress_modules: bind_pack has not been called");
+    py::list rest;
+    Infos infos(infos_arg.ptr());
+    const Py_ssize_t n = PyList_GET_SIZE(modules.ptr());
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
+        const int64_t info = infos.of(m, i);
+        const int bits = (int)((info >> 28) & 15);
+        Entries e;
+        bool ok = info >= 0 && bits >= 1 && bits <= 8 && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
+        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr;
+        int64_t rows = 0, cols = 0, group = 0;
+        if (ok) {
+            packed = e.tensor(N.weight_packed);
+            scale = e.tensor(N.weight_scale);
+            shape_t = e.tensor(N.weight_shape);
+            ok = packed && scale && shape_t && !e.has(N.weight_g_idx) && !e.has(N.weight_zero_point) && !e.has(N.weight) &&
+                 ((packed->is_cuda() && packed->device().index() == device_index) || g_allow_cpu) && packed->is_contiguous() && packed->scalar_type() == at::kInt &&
+                 aligned16(*packed) && packed->dim() == 2 && scale->dim() == 2 && half_type(scale->scalar_type()) && scale->is_contiguous() &&
+                 scale->device() == packed->device() && shape_t->device().is_cpu() && shape_t->scalar_type() == at::kLong && shape_t->numel() == 2 && shape_t->is_contiguous();
+        }
+        if (ok) {
+            rows = shape_t->data_ptr<int64_t>()[0];
+            cols = shape_t->data_ptr<int64_t>()[1];
+            // (R, 1): channel; (R, G): groups of cols / G — the layout upstream's argument-free dequantize infers (forward.py:99-130)
+            ok = rows > 0 && cols > 0 && scale->size(0) == rows && scale->size(1) > 0 && cols % scale->size(1) == 0 && packed->size(0) == rows &&
+                 packed->size(1) == (cols * bits + 31) / 32 && staying_entries_are_final(e, {N.weight_packed});
+            group = ok ? cols / scale->size(1) : 0;
+        }
+        if (ok) {
+            at::Tensor out = at::empty({rows, cols}, scale->options());
+            const int dt = half_code(scale->scalar_type());
+            const int rc = packed->is_cpu() ? 0
+                                            : g_unpack_dequant(static_cast<const int32_t*>(packed->data_ptr()), rows, packed->size(1), cols, bits, scale->data_ptr(), dt, nullptr, -1, 1,
+                                                               group, cols / group, nullptr, out.data_ptr(), dt, reinterpret_cast<void*>(stream));
+            if (rc == 0) {
+                drop(e.params, N.weight_packed);
+                PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
+                set_status(m, status.ptr());
+                continue;
+            }
+        }
+        rest.append(py::reinterpret_borrow<py::object>(m));
+    }
+    return rest;
+}
+
 // mxfp8-quantized (reference compressors/mxfp8/base.py:29-118): float8 weights in groups of 32 — rows of the 8-bit tables, kind fp8 / fp8z — under 16-bit
 // power-of-two scales that are STORED as E8M0 codes: a second table (`zp_words` of the batch; ct_mx_scale_batch) converts the scales, float -> code on the way
 // in, code -> bfloat16 on the way back (launched BEFORE the weights' table, which reads the bfloat16 scales).  infos[i] (compress): 1 | drop mask << 1, or 0.
@@ -1464,6 +1583,9 @@ PYBIND11_MODULE(_hostpath, mod) {
     mod.def("fp4_plan_compress", &fp4_plan_compress);
     mod.def("fp4_plan_decompress", &fp4_plan_decompress);
     mod.def("fp4_finish", &fp4_finish);
+    mod.def("bind_pack", &bind_pack);
+    mod.def("wb_compress_modules", &wb_compress_modules);
+    mod.def("wb_decompress_modules", &wb_decompress_modules);
     mod.def("mx8_plan_compress", &mx8_plan_compress);
     mod.def("mx8_plan_decompress", &mx8_plan_decompress);
     mod.def("mx8_finish", &mx8_finish);

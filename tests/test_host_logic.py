@@ -1252,6 +1252,81 @@ def test_cpp_host_loops_take_a_second_compress_after_a_decompress(cta, monkeypat
         hp.set_allow_cpu(False)
 
 
+@pytest.mark.parametrize("variant", ["w3_group", "w6_channel", "w2_asymmetric", "w3_odd_class", "w5_trainable_scale"])
+def test_cpp_host_loop_of_the_other_word_widths_matches_the_python_loop(cta, monkeypatch, variant):
+    """csrc/host/ct_hostpath.cpp wb_compress_modules / wb_decompress_modules (pack-quantized with 2 / 3 / 5 / 6 / 7 bits: one launch per module by address, the
+    dictionary rewritten behind it) against the Python loop on CPU tensors (launches skipped / stubbed): same modules taken, every module left in the same
+    state over two rounds of compress -> decompress"""
+    from compressed_tensors_amd import _lib as ctlib
+    from compressed_tensors_amd import codec
+    from compressed_tensors_amd.compressors.pack_quantized import base as pq
+    from compressed_tensors_amd.quantization.quant_args import QuantizationStatus
+
+    hp = ctlib.hostpath()
+    assert hp is not None and hasattr(hp, "wb_compress_modules"), "the host extension was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    bits = int(variant[1])
+    st = "channel" if "channel" in variant else "group"
+    wa = cta.QuantizationArgs(num_bits=bits, type="int", strategy=st, group_size=128 if st == "group" else None, symmetric="asymmetric" not in variant)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa)
+
+    class Odd(torch.nn.Linear):
+        def __setattr__(self, name, value):
+            super().__setattr__(name, value)
+
+    def tree():
+        mods = []
+        for k, (r, c) in enumerate([(64, 256), (32, 512), (96, 128), (8, 384)]):
+            lin = (Odd if variant == "w3_odd_class" and k == 1 else torch.nn.Linear)(c, r, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(torch.zeros(r, c, dtype=torch.bfloat16), requires_grad=True)
+            sshape = (r, 1) if st == "channel" else (r, c // 128)
+            lin.weight_scale = torch.nn.Parameter(torch.ones(sshape, dtype=torch.bfloat16), requires_grad=variant == "w5_trainable_scale" and k == 2)
+            lin.weight_zero_point = torch.nn.Parameter(torch.zeros(sshape, dtype=torch.int8), requires_grad=False)
+            lin.quantization_scheme = scheme
+            mods.append(lin)
+        return mods
+
+    calls = {"n": 0}
+
+    def fake_pack(w, *a_, **k):
+        calls["n"] += 1
+        return torch.zeros(w.shape[0], -(-w.shape[1] * bits // 32), dtype=torch.int32)
+
+    def fake_unpack(p_, shape, scale, *a_, **k):
+        calls["n"] += 1
+        return torch.zeros(tuple(shape), dtype=scale.dtype)
+
+    monkeypatch.setattr(codec, "quantize_and_pack", fake_pack)
+    monkeypatch.setattr(codec, "unpack_and_dequantize", fake_unpack)
+    monkeypatch.setattr(codec, "quantize_and_pack_with_zp", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "unpack_and_dequantize_with_zp", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "pack_to_int32", lambda zp, b_, packed_dim=1: torch.zeros((zp.shape[0] * b_ + 31) // 32, zp.shape[1], dtype=torch.int32))
+    monkeypatch.setattr(codec, "unpack_from_int32", lambda p_, b_, shape, packed_dim=1: torch.zeros(tuple(shape), dtype=torch.int8))
+    monkeypatch.setattr(codec, "launch_w4_words", lambda *a_, **k: None)
+    monkeypatch.setattr(codec, "launch_zp4_words", lambda *a_, **k: None)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(ctlib, "stream_on", lambda device, handle=None: 0)
+    hp.set_allow_cpu(True)
+    try:
+        a, b = tree(), tree()
+        for rnd in range(2):
+            for direction, status in (("compress", QuantizationStatus.COMPRESSED), ("decompress", QuantizationStatus.DECOMPRESSED)):
+                before = calls["n"]
+                getattr(pq.PackedQuantizationCompressor, direction + "_modules")(a)
+                left = calls["n"] - before  # modules the C++ loop handed back (each makes one codec call in the Python loop)
+                monkeypatch.setattr(ctlib, "_HOSTPATH", [None])
+                getattr(pq.PackedQuantizationCompressor, direction + "_modules")(b)
+                monkeypatch.setattr(ctlib, "_HOSTPATH", [hp])
+                for x, y in zip(a, b):
+                    assert _module_state_no_ptr(x) == _module_state_no_ptr(y), (variant, rnd, direction)
+                    assert x.quantization_status == status == y.quantization_status
+                expect = {"w2_asymmetric": 4, "w3_odd_class": 1, "w5_trainable_scale": 1 if (rnd == 0 and direction == "compress") else 0}.get(variant, 0)
+                assert left == expect, (variant, rnd, direction, left)
+    finally:
+        hp.set_allow_cpu(False)
+
+
 def _module_state_no_ptr(m):
     return ([(k, None if v is None else (type(v).__name__, v.requires_grad, tuple(v.shape), v.dtype)) for k, v in m._parameters.items()],
             [(k, None if v is None else (type(v).__name__, tuple(v.shape))) for k, v in m._buffers.items()])
