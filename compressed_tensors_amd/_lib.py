@@ -67,6 +67,7 @@ _PROTOTYPES = {
     "ct_unpack_dequant": ([_P, _L, _L, _L, _I, _P, _I, _P, _I, _L, _L, _L, _P, _P, _I, _S], _I),
     "ct_quant_pack_w4_zp": ([_P, _I, _P, _P, _L, _L, _L, _P, _P, _S], _I),
     "ct_unpack_dequant_w4_zp": ([_P, _P, _I, _P, _L, _L, _L, _P, _P, _S], _I),
+    "ct_gidx_col_group": ([_P, _L, _L, _P, _P, _S], _I),
     "ct_w4_batch_plan": ([_P, _I, _I], _L),
     "ct_quant_pack_batch": ([_P, _I, _L, _I, _S], _I),
     "ct_unpack_dequant_batch": ([_P, _I, _L, _I, _S], _I),
@@ -350,7 +351,8 @@ def hostpath():
                 pass  # the marlin-24 default mode then waits through ct_stream_wait
             hp.bind_abi(abi)
             if hasattr(hp, "bind_pack"):  # the loop over pack-quantized modules of the word widths without a table launches these two by address
-                hp.bind_pack(ctypes.cast(lib["ct_quant_pack"], ctypes.c_void_p).value, ctypes.cast(lib["ct_unpack_dequant"], ctypes.c_void_p).value)
+                hp.bind_pack(ctypes.cast(lib["ct_quant_pack"], ctypes.c_void_p).value, ctypes.cast(lib["ct_unpack_dequant"], ctypes.c_void_p).value,
+                             ctypes.cast(lib["ct_gidx_col_group"], ctypes.c_void_p).value)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
 

@@ -162,6 +162,12 @@ def _col_group_of(g_idx: torch.Tensor, group_size: int) -> torch.Tensor:
     g_idx in place without moving its pointer or bumping its version counter, so no key derived from the tensor is safe
     (ADVICE r03), and the two argsorts of a (cols,) vector are noise next to the weight pass."""
     flat = g_idx.detach().reshape(-1)
+    if flat.is_cuda and flat.dtype is torch.int32 and flat.is_contiguous() and flat.numel() and int(group_size) > 0:
+        # two small launches instead of two argsorts and five more tensor ops per call (ct_gidx_col_group: a balanced g_idx needs no sort at all) — a
+        # module with activation ordering spent 86 us of host time per direction, most of it here
+        out = torch.empty(flat.numel() + 1, dtype=torch.int32, device=flat.device)  # the last word: the kernel pair's mode scratch
+        call("ct_gidx_col_group", ptr(flat), flat.numel(), int(group_size), ptr(out), out.data_ptr() + 4 * flat.numel(), stream_of(flat))
+        return out[:-1]
     inv = torch.argsort(torch.argsort(flat))
     plain = torch.arange(flat.numel(), device=flat.device)
     return (torch.where((flat == -1).any(), plain, inv) // int(group_size)).to(torch.int32)

@@ -92,14 +92,15 @@ def _native_w8(hp, modules, direction: str, status):
 
 
 def _wb_info(scheme) -> int:
-    """csrc/host/ct_hostpath.cpp wb_compress_modules / wb_decompress_modules: a symmetric weights-only int scheme of a word width without a table (not 4, not 8),
-    group / channel, no activation ordering -> group size | strategy << 25 | num_bits << 28, else -1"""
+    """csrc/host/ct_hostpath.cpp wb_compress_modules / wb_decompress_modules: a symmetric weights-only int scheme, group / channel -> group size |
+    strategy << 25 | num_bits << 28, else -1.  (The loop takes the modules no table does: the widths other than 4 and 8, and every width's modules with
+    activation ordering — a `weight_g_idx` entry; it hands the others back.)"""
     wa = scheme.weights
     if (wa is None or getattr(scheme, "input_activations", None) is not None or getattr(scheme, "output_activations", None) is not None
-            or enum_value(getattr(wa, "type", "int")) != "int" or not wa.symmetric or enum_value(getattr(wa, "actorder", None)) == "group"):
+            or enum_value(getattr(wa, "type", "int")) != "int" or not wa.symmetric):
         return -1
     bits, st = int(wa.num_bits), enum_value(wa.strategy)
-    if bits in (4, 8) or not 1 <= bits <= 8 or st not in ("channel", "group"):
+    if not 1 <= bits <= 8 or st not in ("channel", "group"):
         return -1
     gs = int(getattr(wa, "group_size", None) or 0) if st == "group" else 0
     if not 0 <= gs < (1 << 20) or (st == "group" and gs <= 0):
@@ -110,7 +111,8 @@ def _wb_info(scheme) -> int:
 def _native_wb(hp, modules, direction: str, status):
     """the modules of the other word widths on the current GPU through the C++ loop (one launch per module, by address); returns the rest"""
     if (not hasattr(hp, "wb_compress_modules") or not torch.cuda.is_available()
-            or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 4) or 4) not in (4, 8) for m in modules)):
+            or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 4) or 4) not in (4, 8) or m._parameters.get("weight_g_idx") is not None
+                       for m in modules)):
         return modules
     dev = torch.device("cuda", torch.cuda.current_device())
     fn = hp.wb_compress_modules if direction == "compress" else hp.wb_decompress_modules

@@ -274,6 +274,73 @@ static dim3 grid_rows(int64_t rows, int64_t items_per_row) {
         case 8: { constexpr int B = 8; __VA_ARGS__; } break; \
     }
 
+// ------------------------------------------------------------------------------------------
+// Activation ordering: the group of every column (forward_helpers.py:147-175 — the weight's columns are permuted by argsort(g_idx), groups of
+// `group_size` consecutive SORTED columns share a scale, the result is permuted back): col_group[c] = rank(c) / group_size with rank = the position of c
+// in the stable sort of g_idx, or c / group_size while g_idx still holds a -1.  The host composed this from two argsorts and five more tensor ops PER
+// CALL (~60 us of launches, nothing cached: a g_idx can be rewritten in place) — more than the weight pass of most modules.  Two small launches:
+//   gidx_mode_kernel (one workgroup): any -1 -> mode 0; every value g in [0, cols / group_size) exactly group_size times -> mode 1 (the usual case: the
+//     sorted positions of the columns of value g are [g gs, (g + 1) gs), whatever the order of ties: col_group = g_idx); else mode 2;
+//   gidx_col_group_kernel: mode 2 counts, per column, the columns with a smaller value and the EARLIER columns with an equal one (tiles of g_idx in LDS,
+//     broadcast reads: O(cols) per column, rare).
+// ------------------------------------------------------------------------------------------
+constexpr int kGidxBins = 4096;
+
+constexpr int kGidxModeBlock = 1024;  // ONE workgroup reads the whole g_idx: wide, and four columns per lane and trip (a 256-lane workgroup with one column
+                                      // per lane took 56 dependent trips for 14336 columns: 10-20 us in front of every weight launch)
+__global__ __launch_bounds__(kGidxModeBlock) void gidx_mode_kernel(const int32_t* __restrict__ g_idx, int64_t cols, int64_t group_size, int32_t* __restrict__ mode) {
+    __shared__ int hist[kGidxBins];
+    __shared__ int flags[2];  // any -1, any value outside [0, G)
+    const int64_t G = group_size > 0 ? cols / group_size : 0;
+    const bool binned = group_size > 0 && cols % group_size == 0 && G <= kGidxBins;
+    for (int i = threadIdx.x; i < kGidxBins; i += kGidxModeBlock) hist[i] = 0;
+    if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+    __syncthreads();
+    auto take = [&](int32_t v) {
+        if (v == -1) flags[0] = 1;
+        if (binned && v >= 0 && v < G) atomicAdd(&hist[v], 1);
+        else flags[1] = 1;
+    };
+    const bool vec = (reinterpret_cast<uintptr_t>(g_idx) & 15u) == 0;
+    const int64_t quads = vec ? cols / 4 : 0;
+    for (int64_t q = threadIdx.x; q < quads; q += kGidxModeBlock) {
+        const u32x4 v = reinterpret_cast<const u32x4*>(g_idx)[q];
+        take((int32_t)v.x); take((int32_t)v.y); take((int32_t)v.z); take((int32_t)v.w);
+    }
+    for (int64_t c = quads * 4 + threadIdx.x; c < cols; c += kGidxModeBlock) take(g_idx[c]);
+    __syncthreads();
+    if (binned && !flags[1]) {
+        for (int64_t g = threadIdx.x; g < G; g += kGidxModeBlock)
+            if (hist[g] != group_size) flags[1] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) mode[0] = flags[0] ? 0 : (flags[1] ? 2 : 1);
+}
+
+__global__ __launch_bounds__(kBlock) void gidx_col_group_kernel(const int32_t* __restrict__ g_idx, int64_t cols, int64_t group_size, const int32_t* __restrict__ mode,
+                                                                int32_t* __restrict__ out) {
+    __shared__ int32_t tile[1024];
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int m = mode[0];
+    if (m != 2) {
+        if (c < cols) out[c] = m == 0 ? (int32_t)(c / group_size) : g_idx[c];
+        return;
+    }
+    const int32_t v = c < cols ? g_idx[c] : 0;
+    int64_t rank = 0;
+    for (int64_t t0 = 0; t0 < cols; t0 += 1024) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1024; i += kBlock) tile[i] = t0 + i < cols ? g_idx[t0 + i] : 0x7fffffff;
+        __syncthreads();
+        const int lim = (int)(cols - t0 < 1024 ? cols - t0 : 1024);
+        for (int i = 0; i < lim; ++i) {
+            const int32_t u = tile[i];
+            rank += (u < v) || (u == v && t0 + i < c);
+        }
+    }
+    if (c < cols) out[c] = (int32_t)(rank / group_size);
+}
+
 }  // namespace ct
 
 using namespace ct;
@@ -390,6 +457,16 @@ int ct_unpack_int32_dim0(const int32_t* p, int64_t words, int64_t cols, int64_t 
     CT_BITS_SWITCH(bits, hipLaunchKernelGGL((unpack_dim0_kernel<B>), grid, dim3(kBlock), 0, as_stream(stream), p, words, cols, rows,
                                             out));
     CT_LAUNCH_CHECK("ct_unpack_int32_dim0");
+}
+
+int ct_gidx_col_group(const int32_t* g_idx, int64_t cols, int64_t group_size, int32_t* col_group, int32_t* mode_word, ct_stream_t stream) {
+    CT_REQUIRE(cols >= 0 && group_size > 0, "ct_gidx_col_group: cols >= 0 and group_size > 0, got %lld / %lld", (long long)cols, (long long)group_size);
+    CT_REQUIRE(g_idx != nullptr && col_group != nullptr && mode_word != nullptr, "ct_gidx_col_group: null buffer");
+    CT_REQUIRE(cdiv64(cols, kBlock) < ((int64_t)1 << 31), "too many columns for one launch");
+    if (cols == 0) return CT_OK;
+    hipLaunchKernelGGL(gidx_mode_kernel, dim3(1), dim3(kGidxModeBlock), 0, as_stream(stream), g_idx, cols, group_size, mode_word);
+    hipLaunchKernelGGL(gidx_col_group_kernel, dim3((unsigned)cdiv64(cols, kBlock)), dim3(kBlock), 0, as_stream(stream), g_idx, cols, group_size, mode_word, col_group);
+    CT_LAUNCH_CHECK("ct_gidx_col_group");
 }
 
 }  // extern "C"

@@ -1058,18 +1058,33 @@ int dtype_code(at::ScalarType t) {
     }
 }
 
-// pack-quantized with the other word widths (2 / 3 / 5 / 6 / 7 bits; symmetric weights-only group / channel schemes, no activation ordering): no table form
-// exists for them, so this loop launches `ct_quant_pack` / `ct_unpack_dequant` per module BY ADDRESS on `stream` of device `device_index` (which the caller has
+// pack-quantized with the other word widths (2 / 3 / 5 / 6 / 7 bits) and, for EVERY width, modules with activation ordering (a `weight_g_idx` entry; symmetric
+// weights-only group / channel schemes): no table form exists for them, so this loop launches `ct_quant_pack` / `ct_unpack_dequant` per module BY ADDRESS on `stream` of device `device_index` (which the caller has
 // made current) and rewrites the dictionary right behind each launch — the interpreter's 22-33 us per module become ~7.  Entries as the W4 loop leaves them.
 // infos[i]: group_size | strategy << 25 (1 channel, 2 group) | num_bits << 28, or < 0.
 using quant_pack_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int64_t, int64_t, const int32_t*, int, int, int32_t*, void*);
 using unpack_dequant_fn = int (*)(const int32_t*, int64_t, int64_t, int64_t, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, const int32_t*, void*, int, void*);
+using gidx_fn = int (*)(const int32_t*, int64_t, int64_t, int32_t*, int32_t*, void*);
 quant_pack_fn g_quant_pack = nullptr;
 unpack_dequant_fn g_unpack_dequant = nullptr;
+gidx_fn g_gidx_col_group = nullptr;  // optional: without it modules with activation ordering go back to the Python loop
 
-void bind_pack(uintptr_t quant_pack, uintptr_t unpack_dequant) {
+void bind_pack(uintptr_t quant_pack, uintptr_t unpack_dequant, uintptr_t gidx_col_group) {
     g_quant_pack = reinterpret_cast<quant_pack_fn>(quant_pack);
     g_unpack_dequant = reinterpret_cast<unpack_dequant_fn>(unpack_dequant);
+    g_gidx_col_group = reinterpret_cast<gidx_fn>(gidx_col_group);
+}
+
+// the `col_group` table of a module with activation ordering (codec._col_group_of's device form: ct_gidx_col_group); cols + 1 words, the last one the
+// kernels' scratch.  An undefined tensor: g_idx is not the plain case (int32, one entry per column, contiguous, on the weights' device).
+at::Tensor col_group_of(const at::Tensor& g_idx, const at::Tensor& like, int64_t cols, int64_t group, uintptr_t stream) {
+    if (!g_gidx_col_group || g_idx.scalar_type() != at::kInt || g_idx.numel() != cols || !g_idx.is_contiguous() || g_idx.device() != like.device()) return at::Tensor();
+    at::Tensor cg = at::empty({cols + 1}, g_idx.options());
+    if (g_idx.is_cuda() &&
+        g_gidx_col_group(static_cast<const int32_t*>(g_idx.data_ptr()), cols, group, static_cast<int32_t*>(cg.data_ptr()), static_cast<int32_t*>(cg.data_ptr()) + cols,
+                         reinterpret_cast<void*>(stream)) != 0)
+        return at::Tensor();
+    return cg;
 }
 
 inline int half_code(at::ScalarType t) { return t == at::kHalf ? 1 : 2; }  // _lib.F16 / _lib.BF16
@@ -1086,15 +1101,18 @@ py::list wb_compress_modules(py::list modules, py::object infos_arg, int device_
         const int bits = (int)((info >> 28) & 15), strategy = (int)((info >> 25) & 3);
         Entries e;
         bool ok = info >= 0 && bits >= 1 && bits <= 8 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
-        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr;
+        const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr, *gidx = nullptr;
         int64_t rows = 0, cols = 0, group = 0;
         if (ok) {
             w = e.tensor(N.weight);
             scale = e.tensor(N.weight_scale);
             zp = e.tensor(N.weight_zero_point);
-            ok = w && scale && !e.has(N.weight_g_idx) && (zp != nullptr || !e.has(N.weight_zero_point)) && !e.has(N.weight_packed) && w->dim() == 2 &&
-                 half_type(w->scalar_type()) && ((w->is_cuda() && w->device().index() == device_index) || g_allow_cpu) && w->is_contiguous() && aligned16(*w) &&
-                 scale->scalar_type() == w->scalar_type() && scale->device() == w->device() && scale->is_contiguous() && scale->dim() == 2;
+            gidx = e.tensor(N.weight_g_idx);
+            // (the widths 4 and 8 without activation ordering ride their tables: handed back)
+            ok = w && scale && (gidx != nullptr || (!e.has(N.weight_g_idx) && bits != 4 && bits != 8)) && (zp != nullptr || !e.has(N.weight_zero_point)) &&
+                 !e.has(N.weight_packed) && w->dim() == 2 && half_type(w->scalar_type()) && ((w->is_cuda() && w->device().index() == device_index) || g_allow_cpu) &&
+                 w->is_contiguous() && aligned16(*w) && scale->scalar_type() == w->scalar_type() && scale->device() == w->device() && scale->is_contiguous() &&
+                 scale->dim() == 2 && (gidx == nullptr || strategy == 2);
         }
         if (ok) {
             rows = w->size(0);
@@ -1104,13 +1122,19 @@ py::list wb_compress_modules(py::list modules, py::object infos_arg, int device_
             if (ok && zp) ok = zp->scalar_type() == at::kChar && zp->sizes() == scale->sizes() && zp->is_contiguous() && zp->device() == w->device();
             ok = ok && staying_entries_are_final(e, {N.weight, N.weight_zero_point});
         }
+        at::Tensor cg;
+        if (ok && gidx) {
+            cg = col_group_of(*gidx, *w, cols, group, stream);
+            ok = cg.defined();
+        }
         if (ok) {
             const int64_t words = (cols * bits + 31) / 32;
             at::Tensor packed = at::empty({rows, words}, w->options().dtype(at::kInt));
             const int dt = half_code(w->scalar_type());
             const int rc = w->is_cpu() ? 0
                                        : g_quant_pack(w->data_ptr(), dt, scale->data_ptr(), dt, zp ? zp->data_ptr() : nullptr, zp ? 3 /* _lib.I8 */ : -1, rows, cols, 1, group,
-                                                      cols / group, nullptr, bits, dt, static_cast<int32_t*>(packed.data_ptr()), reinterpret_cast<void*>(stream));
+                                                      cols / group, cg.defined() ? static_cast<const int32_t*>(cg.data_ptr()) : nullptr, bits, dt,
+                                                      static_cast<int32_t*>(packed.data_ptr()), reinterpret_cast<void*>(stream));
             if (rc == 0) {
                 drop(e.params, N.weight);
                 drop(e.params, N.weight_zero_point);  // a symmetric scheme stores none (compressors/base.py: symmetric_zp_keys)
@@ -1140,13 +1164,14 @@ py::list wb_decompress_modules(py::list modules, py::object infos_arg, int devic
         const int bits = (int)((info >> 28) & 15);
         Entries e;
         bool ok = info >= 0 && bits >= 1 && bits <= 8 && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
-        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr;
+        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr, *gidx = nullptr;
         int64_t rows = 0, cols = 0, group = 0;
         if (ok) {
             packed = e.tensor(N.weight_packed);
             scale = e.tensor(N.weight_scale);
             shape_t = e.tensor(N.weight_shape);
-            ok = packed && scale && shape_t && !e.has(N.weight_g_idx) && !e.has(N.weight_zero_point) && !e.has(N.weight) &&
+            gidx = e.tensor(N.weight_g_idx);
+            ok = packed && scale && shape_t && (gidx != nullptr || (!e.has(N.weight_g_idx) && bits != 4 && bits != 8)) && !e.has(N.weight_zero_point) && !e.has(N.weight) &&
                  ((packed->is_cuda() && packed->device().index() == device_index) || g_allow_cpu) && packed->is_contiguous() && packed->scalar_type() == at::kInt &&
                  aligned16(*packed) && packed->dim() == 2 && scale->dim() == 2 && half_type(scale->scalar_type()) && scale->is_contiguous() &&
                  scale->device() == packed->device() && shape_t->device().is_cpu() && shape_t->scalar_type() == at::kLong && shape_t->numel() == 2 && shape_t->is_contiguous();
@@ -1159,12 +1184,18 @@ py::list wb_decompress_modules(py::list modules, py::object infos_arg, int devic
                  packed->size(1) == (cols * bits + 31) / 32 && staying_entries_are_final(e, {N.weight_packed});
             group = ok ? cols / scale->size(1) : 0;
         }
+        at::Tensor cg;
+        if (ok && gidx) {
+            cg = col_group_of(*gidx, *packed, cols, group, stream);
+            ok = cg.defined();
+        }
         if (ok) {
             at::Tensor out = at::empty({rows, cols}, scale->options());
             const int dt = half_code(scale->scalar_type());
             const int rc = packed->is_cpu() ? 0
                                             : g_unpack_dequant(static_cast<const int32_t*>(packed->data_ptr()), rows, packed->size(1), cols, bits, scale->data_ptr(), dt, nullptr, -1, 1,
-                                                               group, cols / group, nullptr, out.data_ptr(), dt, reinterpret_cast<void*>(stream));
+                                                               group, cols / group, cg.defined() ? static_cast<const int32_t*>(cg.data_ptr()) : nullptr, out.data_ptr(), dt,
+                                                               reinterpret_cast<void*>(stream));
             if (rc == 0) {
                 drop(e.params, N.weight_packed);
                 PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());

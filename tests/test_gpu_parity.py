@@ -2214,6 +2214,36 @@ def test_pack_quantized_modules_no_table_takes_match_the_per_module_calls(cta, d
                 assert eq(tx.data.cpu(), ty.data.cpu()) if tx.dtype.is_floating_point else torch.equal(tx.data.cpu(), ty.data.cpu()), (direction, shapes[k], name)
 
 
+def test_gidx_col_group_on_the_device(cta, dev):
+    """ct_gidx_col_group (the activation-ordering group table: rank in the stable sort of g_idx // group_size, or plain column order while a -1 is left) against
+    the reference's expression (forward_helpers.py:147-175) evaluated on the CPU: balanced permutations (no sort needed), unbalanced and out-of-range values,
+    more groups than the histogram has bins, a -1 anywhere, one column"""
+    from compressed_tensors_amd.codec import _col_group_of
+
+    def ref(flat, gs):
+        inv = torch.argsort(torch.argsort(flat, stable=True), stable=True)
+        plain = torch.arange(flat.numel())
+        return (torch.where((flat == -1).any(), plain, inv) // gs).to(torch.int32)
+
+    g = torch.Generator().manual_seed(61)
+    cases = []
+    for cols, gs in ((256, 128), (4096, 128), (28672, 128), (14336, 32), (384, 128), (1024, 1024), (96, 32)):
+        cases.append((torch.randperm(cols, generator=g) // gs, gs, "balanced"))
+    for cols, gs in ((4096, 128), (1000, 128), (5000, 64), (257, 16)):
+        cases.append((torch.randint(0, max(cols // gs, 1) + 3, (cols,), generator=g), gs, "unbalanced"))
+    cases.append((torch.randint(-5, 100000, (3000,), generator=g), 128, "any values"))
+    cases.append((torch.randperm(8192, generator=g), 1, "more groups than bins"))
+    minus = torch.randperm(4096, generator=g) // 128
+    minus[777] = -1
+    cases.append((minus, 128, "a -1 left"))
+    cases.append((torch.full((512,), -1), 128, "not initialised"))
+    cases.append((torch.zeros(1, dtype=torch.int64), 128, "one column"))
+    for flat, gs, what in cases:
+        flat = flat.to(torch.int32)
+        got = _col_group_of(flat.to(dev), gs)
+        assert got.dtype is torch.int32 and got.data_ptr() % 16 == 0 and torch.equal(got.cpu(), ref(flat.long(), gs)), (what, flat.numel(), gs)
+
+
 def test_w4_batch_vs_oracle(cta, dev):
     """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
     for dtype in (BF16, F16):

@@ -24,6 +24,8 @@ def build(layer_shapes, nlayers, fmt):
         args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=False, strategy="group")
     elif fmt == "mxfp8":
         args = cta.QuantizationArgs(num_bits=8, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)
+    elif fmt == "w4act":  # activation ordering (GPTQ actorder="group"): the modules carry weight_g_idx
+        args = cta.QuantizationArgs(num_bits=4, group_size=128, symmetric=True, strategy="group", actorder="group")
     elif fmt == "w8a16":  # the W8A16 preset: weight-only int8, channel-wise, stored pack-quantized
         args = cta.QuantizationArgs(num_bits=8, symmetric=True, strategy="channel")
     elif fmt == "w3":
@@ -59,6 +61,10 @@ def build(layer_shapes, nlayers, fmt):
                 amax = w.float().reshape(r, -1, 32).abs().amax(-1).clamp(min=1e-4)
                 s = torch.exp2(torch.floor(torch.log2(amax)) - 8).to(torch.bfloat16); z = torch.zeros(s.shape, dtype=F8, device=dev)
                 alg += 2 * int((3 + 3 / 32) * r * c)
+            elif fmt == "w4act":
+                s, z = codec.minmax_qparams(w, num_bits=4, group_size=128, symmetric=True)
+                lin.weight_g_idx = torch.nn.Parameter((torch.randperm(c, device=dev, generator=g) // 128).to(torch.int32), requires_grad=False)
+                alg += 2 * int(2.5 * r * c)
             elif fmt == "w8a16":
                 s, z = codec.minmax_qparams(w, num_bits=8, group_size=None, symmetric=True)
                 alg += 2 * (3 * r * c)
