@@ -352,7 +352,8 @@ def hostpath():
             hp.bind_abi(abi)
             if hasattr(hp, "bind_pack"):  # the loop over pack-quantized modules of the word widths without a table launches these two by address
                 hp.bind_pack(ctypes.cast(lib["ct_quant_pack"], ctypes.c_void_p).value, ctypes.cast(lib["ct_unpack_dequant"], ctypes.c_void_p).value,
-                             ctypes.cast(lib["ct_gidx_col_group"], ctypes.c_void_p).value)
+                             ctypes.cast(lib["ct_gidx_col_group"], ctypes.c_void_p).value, ctypes.cast(lib["ct_pack_int32_dim0"], ctypes.c_void_p).value,
+                             ctypes.cast(lib["ct_unpack_int32_dim0"], ctypes.c_void_p).value)
         _HOSTPATH.append(hp)
     return _HOSTPATH[0]
 

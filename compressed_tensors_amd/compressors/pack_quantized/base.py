@@ -97,21 +97,21 @@ def _wb_info(scheme) -> int:
     activation ordering — a `weight_g_idx` entry; it hands the others back.)"""
     wa = scheme.weights
     if (wa is None or getattr(scheme, "input_activations", None) is not None or getattr(scheme, "output_activations", None) is not None
-            or enum_value(getattr(wa, "type", "int")) != "int" or not wa.symmetric):
+            or enum_value(getattr(wa, "type", "int")) != "int"):
         return -1
     bits, st = int(wa.num_bits), enum_value(wa.strategy)
-    if not 1 <= bits <= 8 or st not in ("channel", "group"):
+    if not 1 <= bits <= 8 or st not in ("channel", "group"):  # (= PACK_ZP_STRATS: an asymmetric scheme of these stores its zero points packed)
         return -1
     gs = int(getattr(wa, "group_size", None) or 0) if st == "group" else 0
     if not 0 <= gs < (1 << 20) or (st == "group" and gs <= 0):
         return -1
-    return gs | ({"channel": 1, "group": 2}[st] << 25) | (bits << 28)
+    return gs | ((0 if wa.symmetric else 1) << 24) | ({"channel": 1, "group": 2}[st] << 25) | (bits << 28)
 
 
 def _native_wb(hp, modules, direction: str, status):
     """the modules of the other word widths on the current GPU through the C++ loop (one launch per module, by address); returns the rest"""
     if (not hasattr(hp, "wb_compress_modules") or not torch.cuda.is_available()
-            or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 4) or 4) not in (4, 8) or m._parameters.get("weight_g_idx") is not None
+            or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 4) or 4) != 4 or m._parameters.get("weight_g_idx") is not None
                        for m in modules)):
         return modules
     dev = torch.device("cuda", torch.cuda.current_device())

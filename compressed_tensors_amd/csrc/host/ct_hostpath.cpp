@@ -1061,7 +1061,8 @@ int dtype_code(at::ScalarType t) {
 // pack-quantized with the other word widths (2 / 3 / 5 / 6 / 7 bits) and, for EVERY width, modules with activation ordering (a `weight_g_idx` entry; symmetric
 // weights-only group / channel schemes): no table form exists for them, so this loop launches `ct_quant_pack` / `ct_unpack_dequant` per module BY ADDRESS on `stream` of device `device_index` (which the caller has
 // made current) and rewrites the dictionary right behind each launch — the interpreter's 22-33 us per module become ~7.  Entries as the W4 loop leaves them.
-// infos[i]: group_size | strategy << 25 (1 channel, 2 group) | num_bits << 28, or < 0.
+// infos[i]: group_size | ASYMMETRIC << 24 (the scheme stores its zero points packed along rows, pack_quantized/base.py:107-110: one more launch,
+// ct_pack_int32_dim0 / ct_unpack_int32_dim0) | strategy << 25 (1 channel, 2 group) | num_bits << 28, or < 0.
 using quant_pack_fn = int (*)(const void*, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, int64_t, int64_t, const int32_t*, int, int, int32_t*, void*);
 using unpack_dequant_fn = int (*)(const int32_t*, int64_t, int64_t, int64_t, int, const void*, int, const void*, int, int64_t, int64_t, int64_t, const int32_t*, void*, int, void*);
 using gidx_fn = int (*)(const int32_t*, int64_t, int64_t, int32_t*, int32_t*, void*);
@@ -1069,10 +1070,17 @@ quant_pack_fn g_quant_pack = nullptr;
 unpack_dequant_fn g_unpack_dequant = nullptr;
 gidx_fn g_gidx_col_group = nullptr;  // optional: without it modules with activation ordering go back to the Python loop
 
-void bind_pack(uintptr_t quant_pack, uintptr_t unpack_dequant, uintptr_t gidx_col_group) {
+using pack_dim0_fn = int (*)(const int8_t*, int64_t, int64_t, int, int32_t*, void*);
+using unpack_dim0_fn = int (*)(const int32_t*, int64_t, int64_t, int64_t, int, int8_t*, void*);
+pack_dim0_fn g_pack_dim0 = nullptr;      // optional: without them asymmetric schemes go back to the Python loop
+unpack_dim0_fn g_unpack_dim0 = nullptr;
+
+void bind_pack(uintptr_t quant_pack, uintptr_t unpack_dequant, uintptr_t gidx_col_group, uintptr_t pack_dim0, uintptr_t unpack_dim0) {
     g_quant_pack = reinterpret_cast<quant_pack_fn>(quant_pack);
     g_unpack_dequant = reinterpret_cast<unpack_dequant_fn>(unpack_dequant);
     g_gidx_col_group = reinterpret_cast<gidx_fn>(gidx_col_group);
+    g_pack_dim0 = reinterpret_cast<pack_dim0_fn>(pack_dim0);
+    g_unpack_dim0 = reinterpret_cast<unpack_dim0_fn>(unpack_dim0);
 }
 
 // the `col_group` table of a module with activation ordering (codec._col_group_of's device form: ct_gidx_col_group); cols + 1 words, the last one the
@@ -1099,6 +1107,7 @@ py::list wb_compress_modules(py::list modules, py::object infos_arg, int device_
         PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
         const int64_t info = infos.of(m, i);
         const int bits = (int)((info >> 28) & 15), strategy = (int)((info >> 25) & 3);
+        const bool asym = ((info >> 24) & 1) != 0;
         Entries e;
         bool ok = info >= 0 && bits >= 1 && bits <= 8 && plain_type(m) && e.open(m) && !dict_has(m, N.weight_packed) && !dict_has(m, N.weight_shape);
         const at::Tensor *w = nullptr, *scale = nullptr, *zp = nullptr, *gidx = nullptr;
@@ -1108,8 +1117,9 @@ py::list wb_compress_modules(py::list modules, py::object infos_arg, int device_
             scale = e.tensor(N.weight_scale);
             zp = e.tensor(N.weight_zero_point);
             gidx = e.tensor(N.weight_g_idx);
-            // (the widths 4 and 8 without activation ordering ride their tables: handed back)
-            ok = w && scale && (gidx != nullptr || (!e.has(N.weight_g_idx) && bits != 4 && bits != 8)) && (zp != nullptr || !e.has(N.weight_zero_point)) &&
+            // (the widths 4 and — symmetric — 8 without activation ordering ride their tables: handed back)
+            ok = w && scale && (gidx != nullptr || (!e.has(N.weight_g_idx) && bits != 4 && (bits != 8 || asym))) && (zp != nullptr || !e.has(N.weight_zero_point)) &&
+                 (!asym || (zp != nullptr && g_pack_dim0 != nullptr)) &&
                  !e.has(N.weight_packed) && w->dim() == 2 && half_type(w->scalar_type()) && ((w->is_cuda() && w->device().index() == device_index) || g_allow_cpu) &&
                  w->is_contiguous() && aligned16(*w) && scale->scalar_type() == w->scalar_type() && scale->device() == w->device() && scale->is_contiguous() &&
                  scale->dim() == 2 && (gidx == nullptr || strategy == 2);
@@ -1135,9 +1145,17 @@ py::list wb_compress_modules(py::list modules, py::object infos_arg, int device_
                                        : g_quant_pack(w->data_ptr(), dt, scale->data_ptr(), dt, zp ? zp->data_ptr() : nullptr, zp ? 3 /* _lib.I8 */ : -1, rows, cols, 1, group,
                                                       cols / group, cg.defined() ? static_cast<const int32_t*>(cg.data_ptr()) : nullptr, bits, dt,
                                                       static_cast<int32_t*>(packed.data_ptr()), reinterpret_cast<void*>(stream));
-            if (rc == 0) {
+            at::Tensor zpp;
+            int rc2 = 0;
+            if (rc == 0 && asym) {  // pack_to_int32(zp, num_bits, packed_dim=0)
+                zpp = at::empty({(rows * bits + 31) / 32, zp->size(1)}, w->options().dtype(at::kInt));
+                rc2 = w->is_cpu() ? 0
+                                  : g_pack_dim0(static_cast<const int8_t*>(zp->data_ptr()), rows, zp->size(1), bits, static_cast<int32_t*>(zpp.data_ptr()), reinterpret_cast<void*>(stream));
+            }
+            if (rc == 0 && rc2 == 0) {
                 drop(e.params, N.weight);
-                drop(e.params, N.weight_zero_point);  // a symmetric scheme stores none (compressors/base.py: symmetric_zp_keys)
+                if (asym) PyDict_SetItem(e.params, N.weight_zero_point, make_parameter(zpp).ptr());  // in place: same position
+                else drop(e.params, N.weight_zero_point);  // a symmetric scheme stores none (compressors/base.py: symmetric_zp_keys)
                 at::Tensor shape = at::empty({2}, at::TensorOptions().dtype(at::kLong));
                 shape.data_ptr<int64_t>()[0] = rows;
                 shape.data_ptr<int64_t>()[1] = cols;
@@ -1162,16 +1180,19 @@ py::list wb_decompress_modules(py::list modules, py::object infos_arg, int devic
         PyObject* m = PyList_GET_ITEM(modules.ptr(), i);
         const int64_t info = infos.of(m, i);
         const int bits = (int)((info >> 28) & 15);
+        const bool asym = ((info >> 24) & 1) != 0;
         Entries e;
         bool ok = info >= 0 && bits >= 1 && bits <= 8 && plain_type(m) && e.open(m) && !dict_has(m, N.weight);
-        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr, *gidx = nullptr;
+        const at::Tensor *packed = nullptr, *scale = nullptr, *shape_t = nullptr, *gidx = nullptr, *zpp = nullptr;
         int64_t rows = 0, cols = 0, group = 0;
         if (ok) {
             packed = e.tensor(N.weight_packed);
             scale = e.tensor(N.weight_scale);
             shape_t = e.tensor(N.weight_shape);
             gidx = e.tensor(N.weight_g_idx);
-            ok = packed && scale && shape_t && (gidx != nullptr || (!e.has(N.weight_g_idx) && bits != 4 && bits != 8)) && !e.has(N.weight_zero_point) && !e.has(N.weight) &&
+            zpp = e.tensor(N.weight_zero_point);
+            ok = packed && scale && shape_t && (gidx != nullptr || (!e.has(N.weight_g_idx) && bits != 4 && (bits != 8 || asym))) &&
+                 (asym ? (zpp != nullptr && g_unpack_dim0 != nullptr) : !e.has(N.weight_zero_point)) && !e.has(N.weight) &&
                  ((packed->is_cuda() && packed->device().index() == device_index) || g_allow_cpu) && packed->is_contiguous() && packed->scalar_type() == at::kInt &&
                  aligned16(*packed) && packed->dim() == 2 && scale->dim() == 2 && half_type(scale->scalar_type()) && scale->is_contiguous() &&
                  scale->device() == packed->device() && shape_t->device().is_cpu() && shape_t->scalar_type() == at::kLong && shape_t->numel() == 2 && shape_t->is_contiguous();
@@ -1181,8 +1202,11 @@ py::list wb_decompress_modules(py::list modules, py::object infos_arg, int devic
             cols = shape_t->data_ptr<int64_t>()[1];
             // (R, 1): channel; (R, G): groups of cols / G — the layout upstream's argument-free dequantize infers (forward.py:99-130)
             ok = rows > 0 && cols > 0 && scale->size(0) == rows && scale->size(1) > 0 && cols % scale->size(1) == 0 && packed->size(0) == rows &&
-                 packed->size(1) == (cols * bits + 31) / 32 && staying_entries_are_final(e, {N.weight_packed});
+                 packed->size(1) == (cols * bits + 31) / 32 && staying_entries_are_final(e, {N.weight_packed, N.weight_zero_point});
             group = ok ? cols / scale->size(1) : 0;
+            if (ok && asym)
+                ok = zpp->scalar_type() == at::kInt && zpp->dim() == 2 && zpp->size(0) == (rows * bits + 31) / 32 && zpp->size(1) == scale->size(1) && zpp->is_contiguous() &&
+                     zpp->device() == packed->device();
         }
         at::Tensor cg;
         if (ok && gidx) {
@@ -1192,12 +1216,22 @@ py::list wb_decompress_modules(py::list modules, py::object infos_arg, int devic
         if (ok) {
             at::Tensor out = at::empty({rows, cols}, scale->options());
             const int dt = half_code(scale->scalar_type());
-            const int rc = packed->is_cpu() ? 0
-                                            : g_unpack_dequant(static_cast<const int32_t*>(packed->data_ptr()), rows, packed->size(1), cols, bits, scale->data_ptr(), dt, nullptr, -1, 1,
+            at::Tensor zp8;
+            int rc0 = 0;
+            if (asym) {  // unpack_from_int32(zp, num_bits, (rows, G), packed_dim=0): in front of the weights' launch, which reads it
+                zp8 = at::empty({rows, scale->size(1)}, packed->options().dtype(at::kChar));
+                rc0 = packed->is_cpu() ? 0
+                                       : g_unpack_dim0(static_cast<const int32_t*>(zpp->data_ptr()), zpp->size(0), zpp->size(1), rows, bits, static_cast<int8_t*>(zp8.data_ptr()),
+                                                       reinterpret_cast<void*>(stream));
+            }
+            const int rc = rc0 != 0 || packed->is_cpu() ? rc0
+                                            : g_unpack_dequant(static_cast<const int32_t*>(packed->data_ptr()), rows, packed->size(1), cols, bits, scale->data_ptr(), dt,
+                                                               asym ? zp8.data_ptr() : nullptr, asym ? 3 : -1, 1,
                                                                group, cols / group, cg.defined() ? static_cast<const int32_t*>(cg.data_ptr()) : nullptr, out.data_ptr(), dt,
                                                                reinterpret_cast<void*>(stream));
             if (rc == 0) {
                 drop(e.params, N.weight_packed);
+                if (asym) PyDict_SetItem(e.params, N.weight_zero_point, make_parameter(zp8).ptr());  // unpacked, int8, in place
                 PyDict_SetItem(e.params, N.weight, make_parameter(out).ptr());
                 set_status(m, status.ptr());
                 continue;

@@ -2163,17 +2163,17 @@ def test_mxfp8_modules_through_the_tables(cta, dev, dtype, with_zp):
                 assert x_.weight.dtype is BF16 and x_.weight_scale.dtype is BF16
 
 
-@pytest.mark.parametrize("variant", ["w3", "w3_asym", "w2", "w6_channel", "w4_actorder", "w8_asym", "w5_trainable_bias"])
+@pytest.mark.parametrize("variant", ["w3", "w3_asym", "w2", "w6_channel", "w4_actorder", "w4_actorder_asym", "w8_asym", "w5_trainable_bias"])
 def test_pack_quantized_modules_no_table_takes_match_the_per_module_calls(cta, dev, variant):
     """pack-quantized modules outside every table (2 / 3 / 5 / 6-bit words, activation ordering, asymmetric 8-bit): compress_modules / decompress_modules write the
     codec's result back as a delta (PackedQuantizationCompressor._delta_module) — the same names in the same order, the same kinds, dtypes and values as
     compress_module / decompress_module (replace_direct_state_dict) leave, and the oracle's words"""
     g = torch.Generator().manual_seed(41)
-    bits = {"w3": 3, "w3_asym": 3, "w2": 2, "w6_channel": 6, "w4_actorder": 4, "w8_asym": 8, "w5_trainable_bias": 5}[variant]
-    sym = variant not in ("w3_asym", "w8_asym")
+    bits = {"w3": 3, "w3_asym": 3, "w2": 2, "w6_channel": 6, "w4_actorder": 4, "w4_actorder_asym": 4, "w8_asym": 8, "w5_trainable_bias": 5}[variant]
+    sym = variant not in ("w3_asym", "w8_asym", "w4_actorder_asym")
     strategy = "channel" if variant == "w6_channel" else "group"
     wa = cta.QuantizationArgs(num_bits=bits, type="int", strategy=strategy, group_size=None if strategy == "channel" else 128, symmetric=sym,
-                              actorder="group" if variant == "w4_actorder" else None)
+                              actorder="group" if variant.startswith("w4_actorder") else None)
     scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa)
     klass = cta.BaseCompressor.get_value_from_registry("pack-quantized")
     shapes = [(256, 512), (130, 384), (64, 1024)]
@@ -2190,7 +2190,7 @@ def test_pack_quantized_modules_no_table_takes_match_the_per_module_calls(cta, d
             lin.weight = torch.nn.Parameter(w.to(dev), requires_grad=True)
             lin.weight_scale = torch.nn.Parameter(s_.to(dev), requires_grad=False)
             lin.weight_zero_point = torch.nn.Parameter(z_.to(dev), requires_grad=False)
-            if variant == "w4_actorder":
+            if variant.startswith("w4_actorder"):
                 perm = torch.randperm(c, generator=gk)
                 lin.weight_g_idx = torch.nn.Parameter((perm // 128).to(torch.int32).to(dev), requires_grad=False)
             lin.quantization_scheme = scheme

@@ -1321,7 +1321,7 @@ def test_cpp_host_loop_of_the_other_word_widths_matches_the_python_loop(cta, mon
                 for x, y in zip(a, b):
                     assert _module_state_no_ptr(x) == _module_state_no_ptr(y), (variant, rnd, direction)
                     assert x.quantization_status == status == y.quantization_status
-                expect = {"w2_asymmetric": 4, "w3_odd_class": 1, "w5_trainable_scale": 1 if (rnd == 0 and direction == "compress") else 0}.get(variant, 0)
+                expect = {"w3_odd_class": 1, "w5_trainable_scale": 1 if (rnd == 0 and direction == "compress") else 0}.get(variant, 0)  # (asymmetric too: C++)
                 assert left == expect, (variant, rnd, direction, left)
     finally:
         hp.set_allow_cpu(False)
