@@ -1619,8 +1619,9 @@ def fp4_api_leg(dev):
     """The float-4 formats through the plug-in API at a real checkpoint's module sizes (round 6): 16 layers of a Llama-3-8B-shaped tree (112 Linear modules,
     3.49 G weights, 6.98 GB bf16, synthetic), NVFP4 (groups of 16, float8 scales under a global scale) and MXFP4 (groups of 32, E8M0 scales),
     `ModelCompressor().compress_model(model)` + `.decompress_model(model)` — wall clock, median of 5 cycles after 2 warm-up cycles, HBM-cold by size —
-    beside the same modules' launches through the C ABI into preallocated outputs (`ct_fp4_quant_pack_stored` + `ct_fp4_unpack_dequant_scale`, one per
-    module and direction; these formats have no table launch).  alg bytes per element and direction: 2 + 0.5 + the stored scale (1/16 resp. 1/32 B)
+    beside the same modules' launches through the C ABI into preallocated outputs (`ct_fp4_quant_pack_stored` + `ct_fp4_unpack_dequant_scale`, ONE PER MODULE
+    and direction — the class path itself goes through the C++ host loop and the FP4 table launches, `ct_fp4_quant_pack_batch` / `ct_fp4_unpack_dequant_batch`,
+    and so ends up below the per-module launches' time).  alg bytes per element and direction: 2 + 0.5 + the stored scale (1/16 resp. 1/32 B)
     + the float scale read (4/16 resp. 2/32 B) resp. the bfloat16 scale written (2/16, 2/32 B)."""
     import compressed_tensors_amd as cta
     from compressed_tensors_amd import _lib, codec
@@ -1709,6 +1710,105 @@ def fp4_api_leg(dev):
                     "ms_model_compressor": round(median(both) * 1e3, 3), "model_compressor_frac_hbm": round(alg / median(both) / 1e9 / HBM_PEAK_GBPS, 4),
                     "api_over_launches": round(median(both) / kernels_s, 3), "us_host_per_module_and_direction": round(median(host) * 1e6 / 224, 2),
                     "class_result_equals_c_abi_result": ok}
+        del root, first
+        torch.cuda.empty_cache()
+    return out
+
+
+def formats_api_leg(dev):
+    """The other formats' module loops through the plug-in API (round 6, third session): 8 layers of a Llama-3-8B-shaped tree (56 Linear modules, 1.74 G weights,
+    synthetic) per format — pack-quantized with 8 bits (the W8A16 preset), float8 channel-wise, float8 in blocks of 128 x 128, MXFP8, pack-quantized with 3 bits,
+    activation-ordered W4 — `ModelCompressor().compress_model(model)` + `.decompress_model(model)`, wall clock, median of 5 cycles after 2 warm-up cycles, HBM-cold by
+    size.  alg bytes per element and direction: the 16-bit weight + the stored codes (+ the stored scales where they are a thirty-second of the weight or more)."""
+    import compressed_tensors_amd as cta
+    from compressed_tensors_amd import codec
+
+    F8 = torch.float8_e4m3fn
+    QA, QS = cta.QuantizationArgs, cta.QuantizationScheme
+    fmts = {
+        "w8a16_pack_quantized": (QA(num_bits=8, symmetric=True, strategy="channel"), None, 3.0),
+        "fp8_channel": (QA(num_bits=8, type="float", strategy="channel", symmetric=True), None, 3.0),
+        "fp8_block128": (QA(num_bits=8, type="float", strategy="block", block_structure=[128, 128], symmetric=True), None, 3.0),
+        "mxfp8": (QA(num_bits=8, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8), "mxfp8-quantized", 3.0 + 3.0 / 32),
+        "w3_pack_quantized": (QA(num_bits=3, group_size=128, symmetric=True, strategy="group"), None, 2.0 + 3.0 / 8),
+        "w4_activation_ordered": (QA(num_bits=4, group_size=128, symmetric=True, strategy="group", actorder="group"), None, 2.5),
+    }
+    out = {"workload": "8 layers of a Llama-3-8B-shaped tree (56 Linear modules, 1.74 G weights, synthetic) per format, ModelCompressor.compress_model + decompress_model",
+           "timing": "wall clock, synchronize on both sides, median of 5 cycles after 2 warm-up cycles"}
+    for name, (args, fmt, bytes_per_el) in fmts.items():
+        g = torch.Generator(device=dev).manual_seed(77)
+        scheme = QS(targets=["Linear"], weights=args)
+        if fmt:
+            scheme.format = fmt
+        root = torch.nn.Module()
+        root.layers = torch.nn.ModuleList()
+        alg = 0
+        for layer in range(8):
+            blk = torch.nn.Module()
+            root.layers.append(blk)
+            for (proj, r, c) in LLAMA8B_LAYER:
+                w = torch.randn(r, c, dtype=torch.bfloat16, device=dev, generator=g)
+                lin = torch.nn.Linear(c, r, bias=False, device="meta")
+                lin.weight = torch.nn.Parameter(w, requires_grad=False)
+                z = None
+                if name == "fp8_channel":
+                    sc = codec.minmax_qparams_float(w, kind="fp8")
+                elif name == "fp8_block128":
+                    sc = (w.float().reshape(r // 128, 128, c // 128, 128).abs().amax(dim=(1, 3)) / 448.0).to(torch.bfloat16)
+                elif name == "mxfp8":
+                    sc = torch.exp2(torch.floor(torch.log2(w.float().reshape(r, -1, 32).abs().amax(-1).clamp(min=1e-4))) - 8).to(torch.bfloat16)
+                else:
+                    sc, z = codec.minmax_qparams(w, num_bits=int(args.num_bits), group_size=getattr(args, "group_size", None), symmetric=True)
+                lin.weight_scale = torch.nn.Parameter(sc, requires_grad=False)
+                if z is not None:
+                    lin.weight_zero_point = torch.nn.Parameter(z, requires_grad=False)
+                if name == "w4_activation_ordered":
+                    lin.weight_g_idx = torch.nn.Parameter((torch.randperm(c, device=dev, generator=g) // 128).to(torch.int32), requires_grad=False)
+                lin.quantization_scheme = scheme
+                setattr(blk, proj, lin)
+                alg += 2 * int(bytes_per_el * r * c)
+        mc = cta.ModelCompressor()
+
+        def cycle():
+            mc.compress_model(root)
+            mc.decompress_model(root)
+
+        # the tree's first module against the per-module class call on a copy of it (names, order, bytes), in both directions
+        import copy
+
+        from compressed_tensors_amd.compressors.base import compress_module, decompress_module
+        first = root.layers[0].q_proj
+        twin = copy.deepcopy(first)
+        twin.quantization_scheme = scheme
+
+        def same_entries(a, b):
+            if list(a._parameters) != list(b._parameters):
+                return False
+            for k, t in a._parameters.items():
+                u = b._parameters[k]
+                if (t is None) != (u is None) or (t is not None and (t.dtype != u.dtype or t.shape != u.shape or not torch.equal(t.data.view(torch.uint8).cpu(), u.data.view(torch.uint8).cpu()))):
+                    return False
+            return True
+
+        mc.compress_model(root)
+        compress_module(twin)
+        same = same_entries(first, twin)
+        mc.decompress_model(root)
+        decompress_module(twin)
+        same = same and same_entries(first, twin)
+        del twin
+        cycle()
+        both, host = [], []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cycle()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            both.append(time.perf_counter() - t0)
+            host.append(t1 - t0)
+        out[name] = {"alg_bytes": alg, "modules": 56, "ms_model_compressor": round(median(both) * 1e3, 3), "frac_hbm": round(alg / median(both) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "us_host_per_module_and_direction": round(median(host) * 1e6 / 112, 2), "first_module_equals_per_module_class_call": bool(same)}
         del root, first
         torch.cuda.empty_cache()
     return out
@@ -2370,7 +2470,7 @@ def main():
             torch.cuda.empty_cache()
             for key, leg in (("kernels_other", w4_variants_leg), ("other_widths", other_widths_leg), ("bitmask", bitmask_leg), ("int8_per_tensor", int8_leg), ("quantize_dequantize_fake_quantize", quantize_leg), ("marlin24", marlin24_leg), ("minmax_qparams", qparams_leg),
                              ("float_formats", float_formats_leg), ("pack_unpack", pack_unpack_leg), ("tinyllama_w8a8", tinyllama_w8_leg),
-                             ("sparse_checkpoint", sparse_checkpoint_leg), ("llama8b_checkpoint", llama8b_api_leg), ("fp4_checkpoint_api", fp4_api_leg)):
+                             ("sparse_checkpoint", sparse_checkpoint_leg), ("llama8b_checkpoint", llama8b_api_leg), ("fp4_checkpoint_api", fp4_api_leg), ("formats_api", formats_api_leg)):
                 try:
                     result[key] = leg(dev)
                 except Exception as e:  # an extra leg must never take the headline line down
