@@ -278,22 +278,25 @@ static dim3 grid_rows(int64_t rows, int64_t items_per_row) {
 // Activation ordering: the group of every column (forward_helpers.py:147-175 — the weight's columns are permuted by argsort(g_idx), groups of
 // `group_size` consecutive SORTED columns share a scale, the result is permuted back): col_group[c] = rank(c) / group_size with rank = the position of c
 // in the stable sort of g_idx, or c / group_size while g_idx still holds a -1.  The host composed this from two argsorts and five more tensor ops PER
-// CALL (~60 us of launches, nothing cached: a g_idx can be rewritten in place) — more than the weight pass of most modules.  Two small launches:
-//   gidx_mode_kernel (one workgroup): any -1 -> mode 0; every value g in [0, cols / group_size) exactly group_size times -> mode 1 (the usual case: the
-//     sorted positions of the columns of value g are [g gs, (g + 1) gs), whatever the order of ties: col_group = g_idx); else mode 2;
-//   gidx_col_group_kernel: mode 2 counts, per column, the columns with a smaller value and the EARLIER columns with an equal one (tiles of g_idx in LDS,
-//     broadcast reads: O(cols) per column, rare).
+// CALL (~60 us of launches, nothing cached: a g_idx can be rewritten in place) — more than the weight pass of most modules.  One small launch:
+//   any -1 -> mode 0; every value g in [0, cols / group_size) exactly group_size times -> mode 1 (the usual case: the sorted positions of the columns of
+//   value g are [g gs, (g + 1) gs), whatever the order of ties: col_group = g_idx); else mode 2: per column, the columns with a smaller value and the
+//   EARLIER columns with an equal one are counted.
 // ------------------------------------------------------------------------------------------
 constexpr int kGidxBins = 4096;
 
-constexpr int kGidxModeBlock = 1024;  // ONE workgroup reads the whole g_idx: wide, and four columns per lane and trip (a 256-lane workgroup with one column
-                                      // per lane took 56 dependent trips for 14336 columns: 10-20 us in front of every weight launch)
-__global__ __launch_bounds__(kGidxModeBlock) void gidx_mode_kernel(const int32_t* __restrict__ g_idx, int64_t cols, int64_t group_size, int32_t* __restrict__ mode) {
+// ONE launch: every workgroup classifies the whole g_idx by itself (at most 112 KB, from L2 after the first reader; four columns per lane and trip) and then
+// writes the table entries of its own 1024 columns — the first version ran a one-workgroup classifier in front of the table kernel: two dependent launches,
+// 6-7 us in front of every weight launch (an 8B-shaped activation-ordered tree: 4.98 ms, of which ~1.5 ms were these)
+constexpr int kGidxBlock = 1024;
+__global__ __launch_bounds__(kGidxBlock) void gidx_col_group_kernel(const int32_t* __restrict__ g_idx, int64_t cols, int64_t group_size, int32_t* __restrict__ mode_out,
+                                                                    int32_t* __restrict__ out) {
     __shared__ int hist[kGidxBins];
-    __shared__ int flags[2];  // any -1, any value outside [0, G)
+    __shared__ int flags[2];  // any -1, any value outside [0, G) or a group that is not exactly group_size columns
+    __shared__ int32_t tile[1024];
     const int64_t G = group_size > 0 ? cols / group_size : 0;
     const bool binned = group_size > 0 && cols % group_size == 0 && G <= kGidxBins;
-    for (int i = threadIdx.x; i < kGidxBins; i += kGidxModeBlock) hist[i] = 0;
+    for (int i = threadIdx.x; i < kGidxBins; i += kGidxBlock) hist[i] = 0;
     if (threadIdx.x < 2) flags[threadIdx.x] = 0;
     __syncthreads();
     auto take = [&](int32_t v) {
@@ -303,34 +306,30 @@ __global__ __launch_bounds__(kGidxModeBlock) void gidx_mode_kernel(const int32_t
     };
     const bool vec = (reinterpret_cast<uintptr_t>(g_idx) & 15u) == 0;
     const int64_t quads = vec ? cols / 4 : 0;
-    for (int64_t q = threadIdx.x; q < quads; q += kGidxModeBlock) {
+    for (int64_t q = threadIdx.x; q < quads; q += kGidxBlock) {
         const u32x4 v = reinterpret_cast<const u32x4*>(g_idx)[q];
         take((int32_t)v.x); take((int32_t)v.y); take((int32_t)v.z); take((int32_t)v.w);
     }
-    for (int64_t c = quads * 4 + threadIdx.x; c < cols; c += kGidxModeBlock) take(g_idx[c]);
+    for (int64_t c = quads * 4 + threadIdx.x; c < cols; c += kGidxBlock) take(g_idx[c]);
     __syncthreads();
     if (binned && !flags[1]) {
-        for (int64_t g = threadIdx.x; g < G; g += kGidxModeBlock)
+        for (int64_t g = threadIdx.x; g < G; g += kGidxBlock)
             if (hist[g] != group_size) flags[1] = 1;
     }
     __syncthreads();
-    if (threadIdx.x == 0) mode[0] = flags[0] ? 0 : (flags[1] ? 2 : 1);
-}
-
-__global__ __launch_bounds__(kBlock) void gidx_col_group_kernel(const int32_t* __restrict__ g_idx, int64_t cols, int64_t group_size, const int32_t* __restrict__ mode,
-                                                                int32_t* __restrict__ out) {
-    __shared__ int32_t tile[1024];
-    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int m = mode[0];
+    const int m = flags[0] ? 0 : (flags[1] ? 2 : 1);  // the same in every workgroup
+    if (blockIdx.x == 0 && threadIdx.x == 0) mode_out[0] = m;
+    const int64_t c = (int64_t)blockIdx.x * kGidxBlock + threadIdx.x;
     if (m != 2) {
         if (c < cols) out[c] = m == 0 ? (int32_t)(c / group_size) : g_idx[c];
         return;
     }
+    // the general case: the rank of column c in the stable sort of g_idx, by counting (tiles of g_idx in LDS, broadcast reads: O(cols) per column, rare)
     const int32_t v = c < cols ? g_idx[c] : 0;
     int64_t rank = 0;
     for (int64_t t0 = 0; t0 < cols; t0 += 1024) {
         __syncthreads();
-        for (int i = threadIdx.x; i < 1024; i += kBlock) tile[i] = t0 + i < cols ? g_idx[t0 + i] : 0x7fffffff;
+        tile[threadIdx.x] = t0 + threadIdx.x < cols ? g_idx[t0 + threadIdx.x] : 0x7fffffff;
         __syncthreads();
         const int lim = (int)(cols - t0 < 1024 ? cols - t0 : 1024);
         for (int i = 0; i < lim; ++i) {
@@ -462,10 +461,9 @@ int ct_unpack_int32_dim0(const int32_t* p, int64_t words, int64_t cols, int64_t 
 int ct_gidx_col_group(const int32_t* g_idx, int64_t cols, int64_t group_size, int32_t* col_group, int32_t* mode_word, ct_stream_t stream) {
     CT_REQUIRE(cols >= 0 && group_size > 0, "ct_gidx_col_group: cols >= 0 and group_size > 0, got %lld / %lld", (long long)cols, (long long)group_size);
     CT_REQUIRE(g_idx != nullptr && col_group != nullptr && mode_word != nullptr, "ct_gidx_col_group: null buffer");
-    CT_REQUIRE(cdiv64(cols, kBlock) < ((int64_t)1 << 31), "too many columns for one launch");
+    CT_REQUIRE(cdiv64(cols, kGidxBlock) < ((int64_t)1 << 31), "too many columns for one launch");
     if (cols == 0) return CT_OK;
-    hipLaunchKernelGGL(gidx_mode_kernel, dim3(1), dim3(kGidxModeBlock), 0, as_stream(stream), g_idx, cols, group_size, mode_word);
-    hipLaunchKernelGGL(gidx_col_group_kernel, dim3((unsigned)cdiv64(cols, kBlock)), dim3(kBlock), 0, as_stream(stream), g_idx, cols, group_size, mode_word, col_group);
+    hipLaunchKernelGGL(gidx_col_group_kernel, dim3((unsigned)cdiv64(cols, kGidxBlock)), dim3(kGidxBlock), 0, as_stream(stream), g_idx, cols, group_size, mode_word, col_group);
     CT_LAUNCH_CHECK("ct_gidx_col_group");
 }
 

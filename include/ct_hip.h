@@ -183,8 +183,8 @@ int ct_unpack_dequant(const int32_t* packed, int64_t rows, int64_t words, int64_
 
 /* Activation ordering (quantization/lifecycle/forward_helpers.py:147-175): the `col_group` table the entries above take, from a module's `weight_g_idx` —
  * col_group[c] = (position of column c in the stable sort of g_idx) / group_size, or c / group_size while g_idx still holds a -1 (not initialised; the
- * reference tests `-1 in g_idx` on the host, here the choice is made on the device: no synchronisation).  `mode_word`: one int32 of device scratch.
- * Two small launches; the usual, balanced g_idx (every group exactly group_size columns) needs no sort at all. */
+ * reference tests `-1 in g_idx` on the host, here the choice is made on the device: no synchronisation).  `mode_word`: one int32 that receives what was
+ * found (0: a -1 left, 1: balanced — every group exactly group_size columns, the usual case: no sort at all —, 2: the general stable rank).  One small launch. */
 int ct_gidx_col_group(const int32_t* g_idx, int64_t cols, int64_t group_size, int32_t* col_group, int32_t* mode_word, ct_stream_t stream);
 
 /* Batched W4A16 (int4, 16-bit weights and scales of one dtype, group or channel scales, int8 zero
