@@ -114,9 +114,26 @@ def _native_wb(hp, modules, direction: str, status):
             or not any(int(getattr(getattr(m.quantization_scheme, "weights", None), "num_bits", 4) or 4) != 4 or m._parameters.get("weight_g_idx") is not None
                        for m in modules)):
         return modules
-    dev = torch.device("cuda", torch.cuda.current_device())
     fn = hp.wb_compress_modules if direction == "compress" else hp.wb_decompress_modules
-    return fn(modules, _wb_info, dev.index, int(_lib.stream_on(dev)), status)
+    # per GPU (an HF `device_map` model spreads its modules over several in one process): the loop launches on the device it is given, which is made
+    # current for the call; a module whose tensors are elsewhere comes back in the rest
+    name = "weight" if direction == "compress" else "weight_packed"
+    by_device, rest = {}, []
+    for m in modules:
+        t = m._parameters.get(name)
+        if t is not None and t.is_cuda:
+            by_device.setdefault(t.device.index if t.device.type == "cuda" else None, []).append(m)  # (None: the CPU stand-ins of tests/test_host_logic.py)
+        else:
+            rest.append(m)
+    for index, ms in by_device.items():
+        if index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            rest += fn(ms, _wb_info, dev.index, int(_lib.stream_on(dev)), status)
+            continue
+        dev = torch.device("cuda", index)
+        with torch.cuda.device(dev):
+            rest += fn(ms, _wb_info, index, int(_lib.stream_on(dev)), status)
+    return rest
 
 
 _ASYMMETRIC = 1 << 40  # csrc/host/ct_hostpath.cpp: kAsymmetric
