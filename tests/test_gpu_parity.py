@@ -2244,6 +2244,84 @@ def test_gidx_col_group_on_the_device(cta, dev):
         assert got.dtype is torch.int32 and got.data_ptr() % 16 == 0 and torch.equal(got.cpu(), ref(flat.long(), gs)), (what, flat.numel(), gs)
 
 
+def test_model_compressor_on_a_tree_of_mixed_formats(cta, dev):
+    """one model whose modules carry different schemes — W4 g128, W4 asymmetric, activation-ordered W4, W3, W8A16, FP8 channel, FP8 block, MXFP8, NVFP4, MXFP4 —
+    through ModelCompressor.compress_model / decompress_model (every format's own C++ loop and table in one call) against compress_module / decompress_module
+    on a twin of each module: names, order, dtypes, bytes"""
+    import copy
+
+    from compressed_tensors_amd.compressors.base import compress_module, decompress_module
+
+    QA, QS = cta.QuantizationArgs, cta.QuantizationScheme
+    g = torch.Generator().manual_seed(71)
+    schemes = {
+        "w4": QS(targets=["Linear"], weights=QA(num_bits=4, group_size=128, symmetric=True, strategy="group")),
+        "w4asym": QS(targets=["Linear"], weights=QA(num_bits=4, group_size=128, symmetric=False, strategy="group")),
+        "w4act": QS(targets=["Linear"], weights=QA(num_bits=4, group_size=128, symmetric=True, strategy="group", actorder="group")),
+        "w3": QS(targets=["Linear"], weights=QA(num_bits=3, group_size=128, symmetric=True, strategy="group")),
+        "w8a16": QS(targets=["Linear"], weights=QA(num_bits=8, symmetric=True, strategy="channel")),
+        "fp8": QS(targets=["Linear"], weights=QA(num_bits=8, type="float", strategy="channel", symmetric=True),
+                  input_activations=QA(num_bits=8, type="float", strategy="tensor", symmetric=True, dynamic=True)),
+        "fp8blk": QS(targets=["Linear"], weights=QA(num_bits=8, type="float", strategy="block", block_structure=[128, 128], symmetric=True),
+                     input_activations=QA(num_bits=8, type="float", strategy="tensor", symmetric=True, dynamic=True)),
+        "mxfp8": QS(targets=["Linear"], weights=QA(num_bits=8, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)),
+        "nvfp4": QS(targets=["Linear"], weights=QA(num_bits=4, type="float", strategy="tensor_group", symmetric=True, group_size=16, scale_dtype=F8)),
+        "mxfp4": QS(targets=["Linear"], weights=QA(num_bits=4, type="float", strategy="group", symmetric=True, group_size=32, scale_dtype=torch.uint8)),
+    }
+    schemes["mxfp8"].format = "mxfp8-quantized"
+    schemes["nvfp4"].format = "nvfp4-pack-quantized"
+    schemes["mxfp4"].format = "mxfp4-pack-quantized"
+    root = torch.nn.Module()
+    root.layers = torch.nn.ModuleList()
+    twins = []
+    for rep in range(2):
+        for name, scheme in schemes.items():
+            r, c = (256, 512) if rep == 0 else (384, 1024)
+            w = (torch.randn(r, c, generator=g) * 0.3).to(BF16)
+            lin = torch.nn.Linear(c, r, bias=False, device="meta")
+            lin.weight = torch.nn.Parameter(w.to(dev), requires_grad=False)
+            wa = scheme.weights
+            entries = {}
+            if name in ("fp8",):
+                entries["weight_scale"] = O.calculate_qparams_float(w, kind="fp8")
+                entries["weight_zero_point"] = torch.zeros(r, 1, dtype=F8)
+            elif name == "fp8blk":
+                entries["weight_scale"] = (w.float().reshape(r // 128, 128, c // 128, 128).abs().amax(dim=(1, 3)) / 448.0).to(BF16)
+            elif name == "mxfp8":
+                entries["weight_scale"] = torch.exp2(torch.floor(torch.log2(w.float().reshape(r, -1, 32).abs().amax(-1).clamp(min=1e-4))) - 8).to(BF16)
+            elif name == "nvfp4":
+                gs_ = O.generate_gparam(w)
+                entries["weight_global_scale"] = gs_
+                entries["weight_scale"] = O.calculate_qparams_float(w, kind="nvfp4", group_size=16, global_scale=gs_)
+            elif name == "mxfp4":
+                entries["weight_scale"] = O.calculate_qparams_float(w, kind="mxfp4", group_size=32)
+            else:
+                s_, z_ = O.calculate_qparams_minmax(w, num_bits=int(wa.num_bits), group_size=getattr(wa, "group_size", None), symmetric=bool(wa.symmetric))
+                entries["weight_scale"], entries["weight_zero_point"] = s_, z_
+                if name == "w4act":
+                    entries["weight_g_idx"] = (torch.randperm(c, generator=g) // 128).to(torch.int32)
+            for k, v in entries.items():
+                setattr(lin, k, torch.nn.Parameter(v.to(dev), requires_grad=False))
+            lin.quantization_scheme = scheme
+            root.layers.append(lin)
+            twin = copy.deepcopy(lin)
+            twin.quantization_scheme = scheme
+            twins.append((name, twin))
+    mc = cta.ModelCompressor()
+    for direction, per_module in (("compress", compress_module), ("decompress", decompress_module)):
+        getattr(mc, direction + "_model")(root)
+        for lin, (name, twin) in zip(root.layers, twins):
+            per_module(twin)
+            assert list(lin._parameters) == list(twin._parameters), (direction, name, list(lin._parameters), list(twin._parameters))
+            for k, t in lin._parameters.items():
+                u = twin._parameters[k]
+                if t is None or u is None:
+                    assert t is u
+                    continue
+                assert t.dtype == u.dtype and t.shape == u.shape and t.device == u.device and torch.equal(t.data.contiguous().view(torch.uint8).cpu(), u.data.contiguous().view(torch.uint8).cpu()), (direction, name, k)
+            assert lin.quantization_status == twin.quantization_status
+
+
 def test_w4_batch_vs_oracle(cta, dev):
     """the batched C-ABI entry points against the CPU oracle, bf16 and fp16, group and channel"""
     for dtype in (BF16, F16):
