@@ -149,6 +149,44 @@ class NVFP4PackedCompressor(BaseCompressor):
             swap_direct_entries(m, ["weight_packed", "weight_scale"], {"weight_scale": scale, "weight": weight}, status=QuantizationStatus.DECOMPRESSED)
 
     @classmethod
+    def decompress_many(cls, state_dicts, scheme) -> list:
+        """`decompress` for several local-name state dicts of one scheme (the model-free converter: one safetensors shard, converters/ct_dequantizer.py:63-99):
+        the tensors of the usual layout leave in ONE table launch (`ct_fp4_unpack_dequant_batch`: weights and bfloat16 scales), the rest one by one"""
+        if cls._native_group() is None:
+            return super().decompress_many(state_dicts, scheme)
+        want = torch.float8_e4m3fn if cls.GROUP == 16 else torch.uint8
+        out, words, keep, where = [None] * len(state_dicts), [], [], []
+        device = None
+        tail = (0,) * (codec._ITEM_WORDS - 11)
+        for i, sd in enumerate(state_dicts):
+            packed, sc, gs = sd.get("weight_packed"), sd.get("weight_scale"), sd.get("weight_global_scale")
+            ok = (packed is not None and sc is not None and packed.is_cuda and packed.dtype is torch.uint8 and packed.dim() == 2 and packed.is_contiguous()
+                  and packed.data_ptr() % 4 == 0 and sc.dtype is want and sc.device == packed.device and sc.is_contiguous() and (gs is not None) == (cls.GROUP == 16)
+                  and (device is None or packed.device == device))
+            if ok:
+                rows, cols = int(packed.shape[0]), int(packed.shape[1]) * 2
+                ok = rows > 0 and cols % cls.GROUP == 0 and (rows * cols) % 32 == 0 and tuple(sc.shape) == (rows, cols // cls.GROUP)
+            if ok and gs is not None:
+                ok = gs.dtype is torch.float32 and gs.numel() == 1 and gs.device == packed.device and gs.data_ptr() % 4 == 0
+            if not ok:
+                out[i] = cls.decompress(sd, scheme)
+                continue
+            device = packed.device
+            weight = torch.empty((rows, cols), dtype=torch.bfloat16, device=device)  # unpack_fp4_from_uint8's default dtype (nvfp4/base.py:118-131)
+            scale = torch.empty((rows, cols // cls.GROUP), dtype=torch.bfloat16, device=device)
+            words += (packed.data_ptr(), sc.data_ptr(), 0 if gs is None else gs.data_ptr(), weight.data_ptr(), rows, cols, cls.GROUP, 0, 0, 0, scale.data_ptr(), *tail)
+            keep.append((packed, sc, gs))
+            new = dict(sd)
+            del new["weight_packed"]
+            new["weight_scale"] = scale
+            new["weight"] = weight  # the entries in the order `decompress` leaves them
+            out[i] = new
+            where.append(i)
+        if where:
+            codec.launch_fp4_words(torch.tensor(words, dtype=torch.int64), len(where), "decompress", device, cls.GROUP)
+        return out
+
+    @classmethod
     def compress_rtn(cls, weight: torch.Tensor, scheme, global_scale=None) -> dict:
         """Round-to-nearest compression straight from the dense weight: generate_gparam (unless given), then observer +
         calculate_qparams + compress in ONE pass over the weight (codec.rtn_nvfp4_quantize_and_pack) — the state dict

@@ -2244,6 +2244,37 @@ def test_gidx_col_group_on_the_device(cta, dev):
         assert got.dtype is torch.int32 and got.data_ptr() % 16 == 0 and torch.equal(got.cpu(), ref(flat.long(), gs)), (what, flat.numel(), gs)
 
 
+@pytest.mark.parametrize("fmt,group", [("nvfp4-pack-quantized", 16), ("mxfp4-pack-quantized", 32)])
+def test_fp4_decompress_many_equals_decompress(cta, dev, fmt, group):
+    """NVFP4 / MXFP4 `decompress_many` (the model-free converter's call: a shard's state dicts through ONE table launch) against `decompress` per state dict:
+    same keys in the same order, same dtypes and bytes; a state dict outside the table's layout (CPU tensors) takes the single path inside the same call"""
+    klass = cta.BaseCompressor.get_value_from_registry(fmt)
+    scheme = _fp4_scheme(cta, fmt)
+    g = torch.Generator().manual_seed(81)
+    sds = []
+    for k, (r, c) in enumerate(((256, 512), (7, 64), (1024, 1024), (33, 1056), (64, 128))):
+        x = (torch.randn(r, c, generator=g) * (1 + k)).to(BF16)
+        if group == 16:
+            gs = O.generate_gparam(x)
+            s_ = O.calculate_qparams_float(x, kind="nvfp4", group_size=16, global_scale=gs)
+        else:
+            gs, s_ = None, O.calculate_qparams_float(x, kind="mxfp4", group_size=32)
+        sd = {"weight": x.to(dev), "weight_scale": s_.to(dev)}
+        if gs is not None:
+            sd["weight_global_scale"] = gs.to(dev)
+        c_ = klass.compress(sd, scheme)
+        if k == 4:
+            c_ = {kk: v.cpu() for kk, v in c_.items()}  # not the table's layout: decompressed by the single path (staged through the GPU)
+        sds.append(c_)
+    many = klass.decompress_many(sds, scheme)
+    for sd, got in zip(sds, many):
+        ref = klass.decompress(sd, scheme)
+        assert list(got) == list(ref)
+        for kk in ref:
+            assert got[kk].dtype == ref[kk].dtype and got[kk].shape == ref[kk].shape and got[kk].device == ref[kk].device, kk
+            assert torch.equal(got[kk].contiguous().view(torch.uint8).cpu(), ref[kk].contiguous().view(torch.uint8).cpu()), kk
+
+
 def test_model_compressor_on_a_tree_of_mixed_formats(cta, dev):
     """one model whose modules carry different schemes — W4 g128, W4 asymmetric, activation-ordered W4, W3, W8A16, FP8 channel, FP8 block, MXFP8, NVFP4, MXFP4 —
     through ModelCompressor.compress_model / decompress_model (every format's own C++ loop and table in one call) against compress_module / decompress_module
