@@ -94,6 +94,42 @@ class MXFP8QuantizationCompressor(NaiveQuantizationCompressor):
     def decompress_modules(cls, modules) -> None:
         super().decompress_modules(cls._native(modules, "decompress"))
 
+    @classmethod
+    def decompress_many(cls, state_dicts, scheme) -> list:
+        """`decompress` for several local-name state dicts (the model-free converter: one safetensors shard): the scale tensors of the usual layout through ONE
+        launch of `ct_mx_scale_batch`, the weights through ONE of the 8-bit tables; the rest one by one"""
+        base = MXFP8QuantizationCompressor
+        if cls.compress.__func__ is not base.compress.__func__ or cls.decompress.__func__ is not base.decompress.__func__:
+            return [cls.decompress(sd, scheme) for sd in state_dicts]
+        out, words, swords, where = [None] * len(state_dicts), [], [], []
+        device = None
+        tail = (0,) * (codec._ITEM_WORDS - 7)
+        for i, sd in enumerate(state_dicts):
+            q, sc = sd.get("weight"), sd.get("weight_scale")
+            ok = (q is not None and sc is not None and sd.get("weight_zero_point") is None and sd.get("weight_g_idx") is None and q.is_cuda and q.dim() == 2
+                  and q.dtype is torch.float8_e4m3fn and q.is_contiguous() and q.data_ptr() % 16 == 0 and sc.dtype is torch.uint8 and sc.device == q.device
+                  and sc.is_contiguous() and sc.dim() == 2 and (device is None or q.device == device))
+            if ok:
+                rows, cols = int(q.shape[0]), int(q.shape[1])
+                ok = rows > 0 and cols % 32 == 0 and tuple(sc.shape) == (rows, cols // 32)
+            if not ok:
+                out[i] = cls.decompress(sd, scheme)
+                continue
+            device = q.device
+            scale = torch.empty(sc.shape, dtype=torch.bfloat16, device=device)  # decompress_mx_scale: bfloat16, and so is the weight (mxfp8/base.py:74-101)
+            weight = torch.empty((rows, cols), dtype=torch.bfloat16, device=device)
+            words += (q.data_ptr(), scale.data_ptr(), 0, weight.data_ptr(), rows, cols, 32, *tail)
+            swords += (sc.data_ptr(), 0, 0, scale.data_ptr(), sc.numel(), 1, 0, *tail)
+            new = dict(sd, weight_scale=scale)
+            del new["weight"]
+            new["weight"] = weight  # the entries in the order `decompress` leaves them
+            out[i] = new
+            where.append(i)
+        if where:
+            codec.launch_mx_scale_words(torch.tensor(swords, dtype=torch.int64), len(where), "decompress", device)  # first: the weights' table reads the bfloat16 scales
+            codec.launch_q8_words(torch.tensor(words, dtype=torch.int64), len(where), "decompress", torch.bfloat16, device, 1, 8)
+        return out
+
     # the two hooks keep upstream's names: install() lets upstream's subclass call them
     @classmethod
     def _compress_scale(cls, scale: torch.Tensor, weights) -> torch.Tensor:

@@ -2275,6 +2275,31 @@ def test_fp4_decompress_many_equals_decompress(cta, dev, fmt, group):
             assert torch.equal(got[kk].contiguous().view(torch.uint8).cpu(), ref[kk].contiguous().view(torch.uint8).cpu()), kk
 
 
+def test_mxfp8_decompress_many_equals_decompress(cta, dev):
+    """mxfp8-quantized `decompress_many` (a shard's state dicts: one scale-table launch + one launch of the 8-bit tables) against `decompress` per state dict: same
+    keys in the same order, dtypes and bytes; a CPU state dict takes the single path inside the same call"""
+    klass = cta.BaseCompressor.get_value_from_registry("mxfp8-quantized")
+    wa = cta.QuantizationArgs(num_bits=8, type="float", strategy="group", group_size=32, symmetric=True, scale_dtype=torch.uint8)
+    scheme = cta.QuantizationScheme(targets=["Linear"], weights=wa)
+    scheme.format = "mxfp8-quantized"
+    g = torch.Generator().manual_seed(91)
+    sds = []
+    for k, (r, c) in enumerate(((256, 512), (7, 64), (1024, 1024), (33, 1056), (64, 128))):
+        x = (torch.randn(r, c, generator=g) * (1 + k)).to(BF16)
+        s_ = torch.exp2(torch.floor(torch.log2(x.float().reshape(r, -1, 32).abs().amax(-1).clamp(min=1e-4))) - 8).to(BF16)
+        c_ = klass.compress({"weight": x.to(dev), "weight_scale": s_.to(dev)}, scheme)
+        if k == 4:
+            c_ = {kk: v.cpu() for kk, v in c_.items()}
+        sds.append(c_)
+    many = klass.decompress_many(sds, scheme)
+    for sd, got in zip(sds, many):
+        ref = klass.decompress(sd, scheme)
+        assert list(got) == list(ref)
+        for kk in ref:
+            assert got[kk].dtype == ref[kk].dtype and got[kk].shape == ref[kk].shape and got[kk].device == ref[kk].device, kk
+            assert torch.equal(got[kk].contiguous().view(torch.uint8).cpu(), ref[kk].contiguous().view(torch.uint8).cpu()), kk
+
+
 def test_model_compressor_on_a_tree_of_mixed_formats(cta, dev):
     """one model whose modules carry different schemes — W4 g128, W4 asymmetric, activation-ordered W4, W3, W8A16, FP8 channel, FP8 block, MXFP8, NVFP4, MXFP4 —
     through ModelCompressor.compress_model / decompress_model (every format's own C++ loop and table in one call) against compress_module / decompress_module
